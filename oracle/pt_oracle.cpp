@@ -1,0 +1,932 @@
+/*
+ * pt_oracle.cpp -- CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE).  See pt_oracle.h.
+ *
+ * Plain single-thread C++.  Build: g++ -O2 -ffp-contract=off (no FMA contraction, no
+ * fast-math) so that every fp32 operation below is one IEEE-754 round-to-nearest op,
+ * in the order the reference (glm 0.9.6.3 + src/intersections.h + src/interactions.h)
+ * performs it.  Citations are relative to /root/reference.
+ */
+#include "pt_oracle.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+namespace {
+
+/* src/utilities.h:12-15 */
+const float kPI = 3.1415926535897932384626422832795028841971f;
+const float kTWO_PI = 6.2831853071795864769252867665590057683943f;
+const float kSQRT_OF_ONE_THIRD = 0.5773502691896257645091487805019574556476f;
+
+struct V3 {
+    float x, y, z;
+};
+struct V4 {
+    float x, y, z, w;
+};
+
+inline V3 v3(float x, float y, float z) { V3 r = {x, y, z}; return r; }
+inline V4 v4(float x, float y, float z, float w) { V4 r = {x, y, z, w}; return r; }
+inline V3 add(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+inline V3 sub(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline V3 mul(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+inline V3 muls(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+inline V3 neg(V3 a) { return v3(-a.x, -a.y, -a.z); }
+inline V4 add4(V4 a, V4 b) { return v4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+inline V4 sub4(V4 a, V4 b) { return v4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+inline V4 mul4(V4 a, V4 b) { return v4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+inline V4 muls4(V4 a, float s) { return v4(a.x * s, a.y * s, a.z * s, a.w * s); }
+
+/* glm/detail/func_geometric.inl:64-83 : tmp = x*y ; tmp.x + tmp.y + tmp.z */
+inline float dot3(V3 a, V3 b) {
+    V3 t = mul(a, b);
+    return t.x + t.y + t.z;
+}
+/* glm/detail/func_geometric.inl:134-143 */
+inline V3 cross3(V3 x, V3 y) {
+    return v3(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y);
+}
+/* glm/detail/func_exponential.inl:150-153 : 1 / sqrt(x) */
+inline float inversesqrt1(float x) { return 1.0f / std::sqrt(x); }
+/* glm/detail/func_geometric.inl:154-159 : x * inversesqrt(dot(x,x)) */
+inline V3 normalize3(V3 a) { return muls(a, inversesqrt1(dot3(a, a))); }
+/* glm/detail/func_geometric.inl:95-100 */
+inline float length3(V3 a) { return std::sqrt(dot3(a, a)); }
+/* glm/detail/func_geometric.inl:176-179 : I - N * dot(N, I) * 2 */
+inline V3 reflect3(V3 I, V3 N) { return sub(I, muls(muls(N, dot3(N, I)), 2.0f)); }
+/* glm/detail/func_geometric.inl:193-200 (vector overload) */
+inline V3 refract3(V3 I, V3 N, float eta) {
+    float d = dot3(N, I);
+    float k = 1.0f - eta * eta * (1.0f - d * d);
+    V3 r = sub(muls(I, eta), muls(N, eta * d + std::sqrt(k)));
+    return muls(r, (float)(k >= 0.0f));
+}
+
+/* column-major mat4: m[col*4 + row] (glm tmat4x4: m[col][row]) */
+struct M4 {
+    V4 c[4];
+};
+inline M4 m4_from(const float *p) {
+    M4 m;
+    for (int i = 0; i < 4; ++i) m.c[i] = v4(p[4 * i], p[4 * i + 1], p[4 * i + 2], p[4 * i + 3]);
+    return m;
+}
+inline void m4_to(const M4 &m, float *p) {
+    for (int i = 0; i < 4; ++i) {
+        p[4 * i] = m.c[i].x; p[4 * i + 1] = m.c[i].y; p[4 * i + 2] = m.c[i].z; p[4 * i + 3] = m.c[i].w;
+    }
+}
+inline M4 m4_identity() {
+    M4 m;
+    m.c[0] = v4(1, 0, 0, 0); m.c[1] = v4(0, 1, 0, 0); m.c[2] = v4(0, 0, 1, 0); m.c[3] = v4(0, 0, 0, 1);
+    return m;
+}
+/* glm/detail/type_mat4x4.inl:617-628 : (m0*v0 + m1*v1) + (m2*v2 + m3*v3) */
+inline V4 m4_mulv(const M4 &m, V4 v) {
+    V4 mul0 = muls4(m.c[0], v.x);
+    V4 mul1 = muls4(m.c[1], v.y);
+    V4 add0 = add4(mul0, mul1);
+    V4 mul2 = muls4(m.c[2], v.z);
+    V4 mul3 = muls4(m.c[3], v.w);
+    V4 add1 = add4(mul2, mul3);
+    return add4(add0, add1);
+}
+/* src/intersections.h:33-35 */
+inline V3 multiplyMV(const M4 &m, V4 v) {
+    V4 r = m4_mulv(m, v);
+    return v3(r.x, r.y, r.z);
+}
+/* glm/detail/type_mat4x4.inl:686-704 : ((A0*b0 + A1*b1) + A2*b2) + A3*b3 */
+inline M4 m4_mul(const M4 &a, const M4 &b) {
+    M4 r;
+    for (int j = 0; j < 4; ++j) {
+        V4 bj = b.c[j];
+        r.c[j] = add4(add4(add4(muls4(a.c[0], bj.x), muls4(a.c[1], bj.y)), muls4(a.c[2], bj.z)),
+                      muls4(a.c[3], bj.w));
+    }
+    return r;
+}
+/* glm/gtc/matrix_transform.inl:40-50 */
+inline M4 m4_translate(const M4 &m, V3 v) {
+    M4 r = m;
+    r.c[3] = add4(add4(add4(muls4(m.c[0], v.x), muls4(m.c[1], v.y)), muls4(m.c[2], v.z)), m.c[3]);
+    return r;
+}
+/* glm/gtc/matrix_transform.inl:52-86 */
+inline M4 m4_rotate(const M4 &m, float angle, V3 v) {
+    const float a = angle;
+    const float c = std::cos(a);
+    const float s = std::sin(a);
+    V3 axis = normalize3(v);
+    V3 temp = v3((1.0f - c) * axis.x, (1.0f - c) * axis.y, (1.0f - c) * axis.z);
+    float R00 = c + temp.x * axis.x;
+    float R01 = 0 + temp.x * axis.y + s * axis.z;
+    float R02 = 0 + temp.x * axis.z - s * axis.y;
+    float R10 = 0 + temp.y * axis.x - s * axis.z;
+    float R11 = c + temp.y * axis.y;
+    float R12 = 0 + temp.y * axis.z + s * axis.x;
+    float R20 = 0 + temp.z * axis.x + s * axis.y;
+    float R21 = 0 + temp.z * axis.y - s * axis.x;
+    float R22 = c + temp.z * axis.z;
+    M4 r;
+    r.c[0] = add4(add4(muls4(m.c[0], R00), muls4(m.c[1], R01)), muls4(m.c[2], R02));
+    r.c[1] = add4(add4(muls4(m.c[0], R10), muls4(m.c[1], R11)), muls4(m.c[2], R12));
+    r.c[2] = add4(add4(muls4(m.c[0], R20), muls4(m.c[1], R21)), muls4(m.c[2], R22));
+    r.c[3] = m.c[3];
+    return r;
+}
+/* glm/gtc/matrix_transform.inl:122-134 */
+inline M4 m4_scale(const M4 &m, V3 v) {
+    M4 r;
+    r.c[0] = muls4(m.c[0], v.x);
+    r.c[1] = muls4(m.c[1], v.y);
+    r.c[2] = muls4(m.c[2], v.z);
+    r.c[3] = m.c[3];
+    return r;
+}
+inline float E(const M4 &m, int col, int row) {
+    const V4 &c = m.c[col];
+    return row == 0 ? c.x : row == 1 ? c.y : row == 2 ? c.z : c.w;
+}
+/* glm/detail/type_mat4x4.inl:37-91 */
+M4 m4_inverse(const M4 &m) {
+#define M(c, r) E(m, c, r)
+    float Coef00 = M(2, 2) * M(3, 3) - M(3, 2) * M(2, 3);
+    float Coef02 = M(1, 2) * M(3, 3) - M(3, 2) * M(1, 3);
+    float Coef03 = M(1, 2) * M(2, 3) - M(2, 2) * M(1, 3);
+    float Coef04 = M(2, 1) * M(3, 3) - M(3, 1) * M(2, 3);
+    float Coef06 = M(1, 1) * M(3, 3) - M(3, 1) * M(1, 3);
+    float Coef07 = M(1, 1) * M(2, 3) - M(2, 1) * M(1, 3);
+    float Coef08 = M(2, 1) * M(3, 2) - M(3, 1) * M(2, 2);
+    float Coef10 = M(1, 1) * M(3, 2) - M(3, 1) * M(1, 2);
+    float Coef11 = M(1, 1) * M(2, 2) - M(2, 1) * M(1, 2);
+    float Coef12 = M(2, 0) * M(3, 3) - M(3, 0) * M(2, 3);
+    float Coef14 = M(1, 0) * M(3, 3) - M(3, 0) * M(1, 3);
+    float Coef15 = M(1, 0) * M(2, 3) - M(2, 0) * M(1, 3);
+    float Coef16 = M(2, 0) * M(3, 2) - M(3, 0) * M(2, 2);
+    float Coef18 = M(1, 0) * M(3, 2) - M(3, 0) * M(1, 2);
+    float Coef19 = M(1, 0) * M(2, 2) - M(2, 0) * M(1, 2);
+    float Coef20 = M(2, 0) * M(3, 1) - M(3, 0) * M(2, 1);
+    float Coef22 = M(1, 0) * M(3, 1) - M(3, 0) * M(1, 1);
+    float Coef23 = M(1, 0) * M(2, 1) - M(2, 0) * M(1, 1);
+    V4 Fac0 = v4(Coef00, Coef00, Coef02, Coef03);
+    V4 Fac1 = v4(Coef04, Coef04, Coef06, Coef07);
+    V4 Fac2 = v4(Coef08, Coef08, Coef10, Coef11);
+    V4 Fac3 = v4(Coef12, Coef12, Coef14, Coef15);
+    V4 Fac4 = v4(Coef16, Coef16, Coef18, Coef19);
+    V4 Fac5 = v4(Coef20, Coef20, Coef22, Coef23);
+    V4 Vec0 = v4(M(1, 0), M(0, 0), M(0, 0), M(0, 0));
+    V4 Vec1 = v4(M(1, 1), M(0, 1), M(0, 1), M(0, 1));
+    V4 Vec2 = v4(M(1, 2), M(0, 2), M(0, 2), M(0, 2));
+    V4 Vec3 = v4(M(1, 3), M(0, 3), M(0, 3), M(0, 3));
+    V4 Inv0 = add4(sub4(mul4(Vec1, Fac0), mul4(Vec2, Fac1)), mul4(Vec3, Fac2));
+    V4 Inv1 = add4(sub4(mul4(Vec0, Fac0), mul4(Vec2, Fac3)), mul4(Vec3, Fac4));
+    V4 Inv2 = add4(sub4(mul4(Vec0, Fac1), mul4(Vec1, Fac3)), mul4(Vec3, Fac5));
+    V4 Inv3 = add4(sub4(mul4(Vec0, Fac2), mul4(Vec1, Fac4)), mul4(Vec2, Fac5));
+    V4 SignA = v4(+1, -1, +1, -1);
+    V4 SignB = v4(-1, +1, -1, +1);
+    M4 Inverse;
+    Inverse.c[0] = mul4(Inv0, SignA);
+    Inverse.c[1] = mul4(Inv1, SignB);
+    Inverse.c[2] = mul4(Inv2, SignA);
+    Inverse.c[3] = mul4(Inv3, SignB);
+    V4 Row0 = v4(Inverse.c[0].x, Inverse.c[1].x, Inverse.c[2].x, Inverse.c[3].x);
+    V4 Dot0 = mul4(m.c[0], Row0);
+    float Dot1 = (Dot0.x + Dot0.y) + (Dot0.z + Dot0.w);
+    float OneOverDeterminant = 1.0f / Dot1;
+    M4 r;
+    for (int i = 0; i < 4; ++i) r.c[i] = muls4(Inverse.c[i], OneOverDeterminant);
+    return r;
+#undef M
+}
+/* glm/gtc/matrix_inverse.inl:95-158 */
+M4 m4_inverse_transpose(const M4 &m) {
+#define M(c, r) E(m, c, r)
+    float S00 = M(2, 2) * M(3, 3) - M(3, 2) * M(2, 3);
+    float S01 = M(2, 1) * M(3, 3) - M(3, 1) * M(2, 3);
+    float S02 = M(2, 1) * M(3, 2) - M(3, 1) * M(2, 2);
+    float S03 = M(2, 0) * M(3, 3) - M(3, 0) * M(2, 3);
+    float S04 = M(2, 0) * M(3, 2) - M(3, 0) * M(2, 2);
+    float S05 = M(2, 0) * M(3, 1) - M(3, 0) * M(2, 1);
+    float S06 = M(1, 2) * M(3, 3) - M(3, 2) * M(1, 3);
+    float S07 = M(1, 1) * M(3, 3) - M(3, 1) * M(1, 3);
+    float S08 = M(1, 1) * M(3, 2) - M(3, 1) * M(1, 2);
+    float S09 = M(1, 0) * M(3, 3) - M(3, 0) * M(1, 3);
+    float S10 = M(1, 0) * M(3, 2) - M(3, 0) * M(1, 2);
+    float S11 = M(1, 1) * M(3, 3) - M(3, 1) * M(1, 3);
+    float S12 = M(1, 0) * M(3, 1) - M(3, 0) * M(1, 1);
+    float S13 = M(1, 2) * M(2, 3) - M(2, 2) * M(1, 3);
+    float S14 = M(1, 1) * M(2, 3) - M(2, 1) * M(1, 3);
+    float S15 = M(1, 1) * M(2, 2) - M(2, 1) * M(1, 2);
+    float S16 = M(1, 0) * M(2, 3) - M(2, 0) * M(1, 3);
+    float S17 = M(1, 0) * M(2, 2) - M(2, 0) * M(1, 2);
+    float S18 = M(1, 0) * M(2, 1) - M(2, 0) * M(1, 1);
+    float I[4][4];
+    I[0][0] = +(M(1, 1) * S00 - M(1, 2) * S01 + M(1, 3) * S02);
+    I[0][1] = -(M(1, 0) * S00 - M(1, 2) * S03 + M(1, 3) * S04);
+    I[0][2] = +(M(1, 0) * S01 - M(1, 1) * S03 + M(1, 3) * S05);
+    I[0][3] = -(M(1, 0) * S02 - M(1, 1) * S04 + M(1, 2) * S05);
+    I[1][0] = -(M(0, 1) * S00 - M(0, 2) * S01 + M(0, 3) * S02);
+    I[1][1] = +(M(0, 0) * S00 - M(0, 2) * S03 + M(0, 3) * S04);
+    I[1][2] = -(M(0, 0) * S01 - M(0, 1) * S03 + M(0, 3) * S05);
+    I[1][3] = +(M(0, 0) * S02 - M(0, 1) * S04 + M(0, 2) * S05);
+    I[2][0] = +(M(0, 1) * S06 - M(0, 2) * S07 + M(0, 3) * S08);
+    I[2][1] = -(M(0, 0) * S06 - M(0, 2) * S09 + M(0, 3) * S10);
+    I[2][2] = +(M(0, 0) * S11 - M(0, 1) * S09 + M(0, 3) * S12);
+    I[2][3] = -(M(0, 0) * S08 - M(0, 1) * S10 + M(0, 2) * S12);
+    I[3][0] = -(M(0, 1) * S13 - M(0, 2) * S14 + M(0, 3) * S15);
+    I[3][1] = +(M(0, 0) * S13 - M(0, 2) * S16 + M(0, 3) * S17);
+    I[3][2] = -(M(0, 0) * S14 - M(0, 1) * S16 + M(0, 3) * S18);
+    I[3][3] = +(M(0, 0) * S15 - M(0, 1) * S17 + M(0, 2) * S18);
+    float Determinant = +M(0, 0) * I[0][0] + M(0, 1) * I[0][1] + M(0, 2) * I[0][2] + M(0, 3) * I[0][3];
+    M4 r;
+    for (int c = 0; c < 4; ++c)
+        r.c[c] = v4(I[c][0] / Determinant, I[c][1] / Determinant, I[c][2] / Determinant,
+                    I[c][3] / Determinant);
+    return r;
+#undef M
+}
+
+/* src/utilities.cpp:65-72 */
+M4 build_transformation_matrix(V3 translation, V3 rotation, V3 scale) {
+    M4 translationMat = m4_translate(m4_identity(), translation);
+    M4 rotationMat = m4_rotate(m4_identity(), rotation.x * kPI / 180, v3(1, 0, 0));
+    rotationMat = m4_mul(rotationMat, m4_rotate(m4_identity(), rotation.y * kPI / 180, v3(0, 1, 0)));
+    rotationMat = m4_mul(rotationMat, m4_rotate(m4_identity(), rotation.z * kPI / 180, v3(0, 0, 1)));
+    M4 scaleMat = m4_scale(m4_identity(), scale);
+    return m4_mul(m4_mul(translationMat, rotationMat), scaleMat);
+}
+
+/* ---- RNG: thrust::default_random_engine == minstd_rand (a=48271, c=0, m=2^31-1);
+ *      thrust/random/detail/linear_congruential_engine.inl (seed, operator()),
+ *      thrust/random/detail/uniform_real_distribution.inl:71-79 (u01).          */
+const uint32_t kM = 2147483647u;
+inline uint32_t rng_seed(uint32_t s) {
+    uint32_t x = s % kM;
+    return x == 0 ? 1u : x;
+}
+inline uint32_t rng_next(uint32_t &x) {
+    x = (uint32_t)(((uint64_t)x * 48271ull) % (uint64_t)kM);
+    return x;
+}
+inline float rng_u01(uint32_t &x) {
+    float result = (float)(rng_next(x) - 1u);               /* urng() - min, min = 1 */
+    result /= (1.0f + (float)(2147483646u - 1u));           /* 1 + float(max - min) == 2^31 */
+    return (result * (1.0f - 0.0f)) + 0.0f;
+}
+
+inline uint32_t utilhash(uint32_t a) {
+    a = (a + 0x7ed55d16) + (a << 12);
+    a = (a ^ 0xc761c23c) ^ (a >> 19);
+    a = (a + 0x165667b1) + (a << 5);
+    a = (a + 0xd3a2646c) ^ (a << 9);
+    a = (a + 0xfd7046c5) + (a << 3);
+    a = (a ^ 0xb55a4f09) ^ (a >> 16);
+    return a;
+}
+/* src/pathtrace.cu:41-45 */
+inline uint32_t make_seed(int iter, int index, int depth) {
+    return utilhash((uint32_t)((1 << 31) | (depth << 22) | iter)) ^ utilhash((uint32_t)index);
+}
+
+/* ---- build-defined sin/cos (the reference calls the platform libm; CUDA's sinf/cosf and
+ * glibc's differ by ulps, so the build fixes ONE polynomial, used bit-identically by the
+ * HIP kernels).  Cody-Waite reduction by pi/2 (3 constants), cephes-style minimax
+ * polynomials on [-pi/4, pi/4]; max error measured in tests/test_oracle_math.py. */
+inline void sincos_poly(float x, float *s, float *c) {
+    float kf = std::rint(x * 0.636619747f);  /* 2/pi, round-to-nearest-even */
+    int k = (int)kf;
+    float r = x - kf * 1.5703125f;
+    r = r - kf * 4.837512969970703125e-4f;
+    r = r - kf * 7.54978995489188216e-8f;
+    float z = r * r;
+    float ps = -1.9515295891e-4f;
+    ps = ps * z + 8.3321608736e-3f;
+    ps = ps * z - 1.6666654611e-1f;
+    ps = ps * z;
+    ps = ps * r;
+    float sr = ps + r;
+    float pc = 2.443315711809948e-5f;
+    pc = pc * z - 1.388731625493765e-3f;
+    pc = pc * z + 4.166664568298827e-2f;
+    pc = pc * z;
+    pc = pc * z;
+    float cr = (pc - 0.5f * z) + 1.0f;
+    switch (k & 3) {
+        case 0: *s = sr; *c = cr; break;
+        case 1: *s = cr; *c = -sr; break;
+        case 2: *s = -sr; *c = -cr; break;
+        default: *s = -cr; *c = sr; break;
+    }
+}
+
+struct Ray {
+    V3 origin, direction;
+};
+
+/* src/intersections.h:26-28 */
+inline V3 get_point_on_ray(const Ray &r, float t) {
+    return add(r.origin, muls(normalize3(r.direction), t - .0001f));
+}
+
+inline float comp(V3 v, int i) { return i == 0 ? v.x : i == 1 ? v.y : v.z; }
+inline void setcomp(V3 &v, int i, float f) {
+    if (i == 0) v.x = f; else if (i == 1) v.y = f; else v.z = f;
+}
+
+/* src/intersections.h:47-89 */
+float box_intersection_test(const OGeom &box, const Ray &r, V3 &intersectionPoint, V3 &normal,
+                            bool &outside) {
+    M4 inv = m4_from(box.inverseTransform);
+    M4 xf = m4_from(box.transform);
+    Ray q;
+    q.origin = multiplyMV(inv, v4(r.origin.x, r.origin.y, r.origin.z, 1.0f));
+    q.direction = normalize3(multiplyMV(inv, v4(r.direction.x, r.direction.y, r.direction.z, 0.0f)));
+
+    float tmin = -1e38f;
+    float tmax = 1e38f;
+    V3 tmin_n = v3(0, 0, 0);
+    V3 tmax_n = v3(0, 0, 0);
+    for (int xyz = 0; xyz < 3; ++xyz) {
+        float qdxyz = comp(q.direction, xyz);
+        {
+            float t1 = (-0.5f - comp(q.origin, xyz)) / qdxyz;
+            float t2 = (+0.5f - comp(q.origin, xyz)) / qdxyz;
+            float ta = t1 < t2 ? t1 : t2; /* glm::min, func_common.inl:409-414 */
+            float tb = t1 > t2 ? t1 : t2; /* glm::max, func_common.inl:430-435 */
+            V3 n = v3(0, 0, 0);
+            setcomp(n, xyz, t2 < t1 ? +1.0f : -1.0f);
+            if (ta > 0 && ta > tmin) {
+                tmin = ta;
+                tmin_n = n;
+            }
+            if (tb < tmax) {
+                tmax = tb;
+                tmax_n = n;
+            }
+        }
+    }
+    if (tmax >= tmin && tmax > 0) {
+        outside = true;
+        if (tmin <= 0) {
+            tmin = tmax;
+            tmin_n = tmax_n;
+            outside = false;
+        }
+        V3 op = get_point_on_ray(q, tmin);
+        intersectionPoint = multiplyMV(xf, v4(op.x, op.y, op.z, 1.0f));
+        normal = normalize3(multiplyMV(xf, v4(tmin_n.x, tmin_n.y, tmin_n.z, 0.0f)));
+        return length3(sub(r.origin, intersectionPoint));
+    }
+    return -1;
+}
+
+/* src/intersections.h:101-143.  pow(radius, 2) is exactly 0.25f in the float overload nvcc
+ * selects; all arithmetic fp32. */
+float sphere_intersection_test(const OGeom &sphere, const Ray &r, V3 &intersectionPoint, V3 &normal,
+                               bool &outside) {
+    M4 inv = m4_from(sphere.inverseTransform);
+    M4 xf = m4_from(sphere.transform);
+    M4 invT = m4_from(sphere.invTranspose);
+    V3 ro = multiplyMV(inv, v4(r.origin.x, r.origin.y, r.origin.z, 1.0f));
+    V3 rd = normalize3(multiplyMV(inv, v4(r.direction.x, r.direction.y, r.direction.z, 0.0f)));
+    Ray rt;
+    rt.origin = ro;
+    rt.direction = rd;
+
+    float vDotDirection = dot3(rt.origin, rt.direction);
+    float radicand = vDotDirection * vDotDirection - (dot3(rt.origin, rt.origin) - 0.25f);
+    if (radicand < 0) return -1;
+
+    float squareRoot = std::sqrt(radicand);
+    float firstTerm = -vDotDirection;
+    float t1 = firstTerm + squareRoot;
+    float t2 = firstTerm - squareRoot;
+
+    float t = 0;
+    if (t1 < 0 && t2 < 0) {
+        return -1;
+    } else if (t1 > 0 && t2 > 0) {
+        t = t2 < t1 ? t2 : t1; /* min(t1, t2) */
+        outside = true;
+    } else {
+        t = t1 < t2 ? t2 : t1; /* max(t1, t2) */
+        outside = false;
+    }
+    V3 obj = get_point_on_ray(rt, t);
+    intersectionPoint = multiplyMV(xf, v4(obj.x, obj.y, obj.z, 1.f));
+    normal = normalize3(multiplyMV(invT, v4(obj.x, obj.y, obj.z, 0.f)));
+    if (!outside) normal = neg(normal);
+    return length3(sub(r.origin, intersectionPoint));
+}
+
+/* src/interactions.h:10-42 */
+V3 random_direction_in_hemisphere(V3 normal, uint32_t &rng) {
+    float up = std::sqrt(rng_u01(rng));     /* cos(theta) */
+    float over = std::sqrt(1 - up * up);    /* sin(theta) */
+    float around = rng_u01(rng) * kTWO_PI;
+
+    V3 directionNotNormal;
+    if (std::fabs(normal.x) < kSQRT_OF_ONE_THIRD) {
+        directionNotNormal = v3(1, 0, 0);
+    } else if (std::fabs(normal.y) < kSQRT_OF_ONE_THIRD) {
+        directionNotNormal = v3(0, 1, 0);
+    } else {
+        directionNotNormal = v3(0, 0, 1);
+    }
+    V3 p1 = normalize3(cross3(normal, directionNotNormal));
+    V3 p2 = normalize3(cross3(normal, p1));
+    float s, c;
+    sincos_poly(around, &s, &c);
+    return add(add(muls(normal, up), muls(p1, c * over)), muls(p2, s * over));
+}
+
+}  // namespace
+
+/* ===================================================================== */
+/* scene + renderer objects                                               */
+/* ===================================================================== */
+struct OScene {
+    std::vector<OGeom> geoms;
+    std::vector<OMaterial> materials;
+    OCamera camera;
+    int iterations;
+    int traceDepth;
+    std::string imageName;
+};
+
+struct ORender {
+    OCamera cam;
+    std::vector<OGeom> geoms;
+    std::vector<OMaterial> mats;
+    int traceDepth;
+    /* derived camera constants (spec S2) */
+    V3 view, up, right, position;
+    float pixLenX, pixLenY, halfW, halfH;
+};
+
+namespace {
+
+inline V3 from(const OVec3 &v) { return v3(v.x, v.y, v.z); }
+
+/* src/utilities.cpp:82-112 */
+std::istream &safe_getline(std::istream &is, std::string &t) {
+    t.clear();
+    std::istream::sentry se(is, true);
+    std::streambuf *sb = is.rdbuf();
+    for (;;) {
+        int c = sb->sbumpc();
+        switch (c) {
+            case '\n': return is;
+            case '\r':
+                if (sb->sgetc() == '\n') sb->sbumpc();
+                return is;
+            case EOF:
+                if (t.empty()) is.setstate(std::ios::eofbit);
+                return is;
+            default: t += (char)c;
+        }
+    }
+}
+/* src/utilities.cpp:74-80 */
+std::vector<std::string> tokenize(const std::string &s) {
+    std::stringstream ss(s);
+    std::vector<std::string> out;
+    std::string tok;
+    while (ss >> tok) out.push_back(tok);
+    return out;
+}
+inline float atoff(const std::string &s) { return (float)atof(s.c_str()); }
+inline bool is(const std::vector<std::string> &t, const char *key) {
+    return !t.empty() && strcmp(t[0].c_str(), key) == 0;
+}
+inline OVec3 tok3(const std::vector<std::string> &t) {
+    OVec3 v = {0, 0, 0};
+    if (t.size() >= 4) { v.x = atoff(t[1]); v.y = atoff(t[2]); v.z = atoff(t[3]); }
+    return v;
+}
+
+/* src/scene.cpp:132-136 */
+void compute_fov(OCamera &cam, float fovy) {
+    float yscaled = std::tan(fovy * (kPI / 180));
+    float xscaled = (yscaled * cam.resX) / cam.resY;
+    float fovx = (std::atan(xscaled) * 180) / kPI;
+    cam.fovX = fovx;
+    cam.fovY = fovy;
+}
+
+/* src/scene.cpp:147-182 */
+void load_material(OScene &sc, std::ifstream &fp, const std::string &idtok) {
+    int id = atoi(idtok.c_str());
+    if (id != (int)sc.materials.size()) return; /* :149-151 prints ERROR and skips */
+    OMaterial m;
+    memset(&m, 0, sizeof m);
+    for (int i = 0; i < 7; ++i) {
+        std::string line;
+        safe_getline(fp, line);
+        std::vector<std::string> t = tokenize(line);
+        if (is(t, "RGB")) m.color = tok3(t);
+        else if (is(t, "SPECEX")) m.specExponent = atoff(t[1]);
+        else if (is(t, "SPECRGB")) m.specColor = tok3(t);
+        else if (is(t, "REFL")) m.hasReflective = atoff(t[1]);
+        else if (is(t, "REFR")) m.hasRefractive = atoff(t[1]);
+        else if (is(t, "REFRIOR")) m.indexOfRefraction = atoff(t[1]);
+        else if (is(t, "EMITTANCE")) m.emittance = atoff(t[1]);
+    }
+    sc.materials.push_back(m);
+}
+
+/* src/scene.cpp:92-145 */
+void load_camera(OScene &sc, std::ifstream &fp) {
+    OCamera &cam = sc.camera;
+    float fovy = 0;
+    for (int i = 0; i < 5; ++i) {
+        std::string line;
+        safe_getline(fp, line);
+        std::vector<std::string> t = tokenize(line);
+        if (is(t, "RES")) { cam.resX = atoi(t[1].c_str()); cam.resY = atoi(t[2].c_str()); }
+        else if (is(t, "FOVY")) fovy = atoff(t[1]);
+        else if (is(t, "ITERATIONS")) sc.iterations = atoi(t[1].c_str());
+        else if (is(t, "DEPTH")) sc.traceDepth = atoi(t[1].c_str());
+        else if (is(t, "FILE")) sc.imageName = t[1];
+    }
+    std::string line;
+    safe_getline(fp, line);
+    while (!line.empty() && fp.good()) {
+        std::vector<std::string> t = tokenize(line);
+        if (is(t, "EYE")) cam.position = tok3(t);
+        else if (is(t, "VIEW")) cam.view = tok3(t);
+        else if (is(t, "UP")) cam.up = tok3(t);
+        safe_getline(fp, line);
+    }
+    compute_fov(cam, fovy);
+}
+
+/* src/scene.cpp:35-90 */
+void load_geom(OScene &sc, std::ifstream &fp, const std::string &idtok) {
+    int id = atoi(idtok.c_str());
+    if (id != (int)sc.geoms.size()) return; /* :37-39 */
+    OGeom g;
+    memset(&g, 0, sizeof g);
+    std::string line;
+    safe_getline(fp, line);
+    if (!line.empty() && fp.good()) {
+        if (strcmp(line.c_str(), "sphere") == 0) g.type = 0;
+        else if (strcmp(line.c_str(), "cube") == 0) g.type = 1;
+    }
+    safe_getline(fp, line);
+    if (!line.empty() && fp.good()) {
+        std::vector<std::string> t = tokenize(line);
+        if (t.size() >= 2) g.materialid = atoi(t[1].c_str());
+    }
+    safe_getline(fp, line);
+    while (!line.empty() && fp.good()) {
+        std::vector<std::string> t = tokenize(line);
+        if (is(t, "TRANS")) g.translation = tok3(t);
+        else if (is(t, "ROTAT")) g.rotation = tok3(t);
+        else if (is(t, "SCALE")) g.scale = tok3(t);
+        safe_getline(fp, line);
+    }
+    M4 xf = build_transformation_matrix(from(g.translation), from(g.rotation), from(g.scale));
+    m4_to(xf, g.transform);
+    m4_to(m4_inverse(xf), g.inverseTransform);
+    m4_to(m4_inverse_transpose(xf), g.invTranspose);
+    sc.geoms.push_back(g);
+}
+
+/* Nearest hit over all geoms in file order (spec S3).  Returns geom index or -1. */
+int nearest_hit(const ORender &R, const Ray &ray, V3 &p, V3 &n, bool &outside) {
+    float t_min = 0;
+    int hit = -1;
+    for (int i = 0; i < (int)R.geoms.size(); ++i) {
+        V3 tp = v3(0, 0, 0), tn = v3(0, 0, 0);
+        bool to = false;
+        float t = R.geoms[i].type == 0 ? sphere_intersection_test(R.geoms[i], ray, tp, tn, to)
+                                       : box_intersection_test(R.geoms[i], ray, tp, tn, to);
+        if (t > 0.0f && (hit < 0 || t < t_min)) {
+            t_min = t;
+            hit = i;
+            p = tp;
+            n = tn;
+            outside = to;
+        }
+    }
+    return hit;
+}
+
+/* spec S2 */
+Ray camera_ray(const ORender &R, int iter, int index) {
+    int W = R.cam.resX;
+    int x = index % W, y = index / W;
+    uint32_t rng = rng_seed(make_seed(iter, index, 0));
+    float jx = rng_u01(rng);
+    float jy = rng_u01(rng);
+    float sx = ((float)x + jx) - R.halfW;
+    float sy = ((float)y + jy) - R.halfH;
+    float a = R.pixLenX * sx;
+    float b = R.pixLenY * sy;
+    Ray r;
+    r.origin = R.position;
+    r.direction = normalize3(sub(sub(R.view, muls(R.right, a)), muls(R.up, b)));
+    return r;
+}
+
+enum Fate { ALIVE = 0, MISS = 1, LIGHT = 2 };
+
+/* One bounce of one path (spec S3-S6).  On LIGHT, `contrib` holds the radiance to add. */
+Fate bounce(const ORender &R, int iter, int index, int depth, Ray &ray, V3 &color, V3 &contrib) {
+    V3 p = v3(0, 0, 0), n = v3(0, 0, 0);
+    bool outside = false;
+    int g = nearest_hit(R, ray, p, n, outside);
+    if (g < 0) return MISS;
+    const OMaterial &m = R.mats[R.geoms[g].materialid];
+    V3 mcol = from(m.color);
+    if (m.emittance > 0.0f) {
+        contrib = muls(mul(color, mcol), m.emittance);
+        return LIGHT;
+    }
+    uint32_t rng = rng_seed(make_seed(iter, index, depth));
+    V3 scol = from(m.specColor);
+    V3 ndir;
+    V3 norg;
+    if (m.hasRefractive > 0.0f) {
+        /* dielectric, Schlick Fresnel (README.md:96-99); normal always faces the incoming ray */
+        float ior = m.indexOfRefraction;
+        float eta = outside ? 1.0f / ior : ior;
+        float c = dot3(n, ray.direction);
+        float k = 1.0f - eta * eta * (1.0f - c * c);
+        float u = rng_u01(rng);
+        bool doReflect = true;
+        if (k >= 0.0f) {
+            float r0 = (1.0f - ior) / (1.0f + ior);
+            r0 = r0 * r0;
+            float cosx = outside ? -c : std::sqrt(k);
+            float w = 1.0f - cosx;
+            float w2 = w * w;
+            float w5 = w2 * w2 * w;
+            float fres = r0 + (1.0f - r0) * w5;
+            doReflect = u < fres;
+        }
+        if (doReflect) {
+            ndir = reflect3(ray.direction, n);
+            norg = add(p, muls(n, 0.001f));
+            color = mul(color, scol);
+        } else {
+            ndir = refract3(ray.direction, n, eta);
+            norg = sub(p, muls(n, 0.001f));
+            color = mul(color, mcol);
+        }
+    } else if (m.hasReflective > 0.0f) {
+        /* energy-conserving 50/50 mirror/diffuse mixture (spec S6) */
+        float u = rng_u01(rng);
+        if (u < 0.5f) {
+            ndir = reflect3(ray.direction, n);
+            color = mul(color, scol);
+        } else {
+            ndir = random_direction_in_hemisphere(n, rng);
+            color = mul(color, mcol);
+        }
+        norg = add(p, muls(n, 0.001f));
+    } else {
+        ndir = random_direction_in_hemisphere(n, rng);
+        color = mul(color, mcol);
+        norg = add(p, muls(n, 0.001f));
+    }
+    ray.origin = norg;
+    ray.direction = ndir;
+    return ALIVE;
+}
+
+inline int shard_rows(int H, int rank, int count) { return (H - rank + count - 1) / count; }
+
+}  // namespace
+
+extern "C" {
+
+uint32_t orc_utilhash(uint32_t a) { return utilhash(a); }
+uint32_t orc_seed(int iter, int index, int depth) { return make_seed(iter, index, depth); }
+
+void orc_rng_stream_from_seed(uint32_t seed, int n, float *u01_out, uint32_t *state_out) {
+    uint32_t x = rng_seed(seed);
+    for (int i = 0; i < n; ++i) {
+        float u = rng_u01(x);
+        if (u01_out) u01_out[i] = u;
+        if (state_out) state_out[i] = x;
+    }
+}
+void orc_rng_stream(int iter, int index, int depth, int n, float *u01_out, uint32_t *state_out) {
+    orc_rng_stream_from_seed(make_seed(iter, index, depth), n, u01_out, state_out);
+}
+void orc_sincos(float x, float *s, float *c) { sincos_poly(x, s, c); }
+void orc_normalize(const float v[3], float out[3]) {
+    V3 r = normalize3(v3(v[0], v[1], v[2]));
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+void orc_reflect(const float I[3], const float N[3], float out[3]) {
+    V3 r = reflect3(v3(I[0], I[1], I[2]), v3(N[0], N[1], N[2]));
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+void orc_refract(const float I[3], const float N[3], float eta, float out[3]) {
+    V3 r = refract3(v3(I[0], I[1], I[2]), v3(N[0], N[1], N[2]), eta);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+void orc_mulmv(const float m[16], const float v[4], float out[3]) {
+    V3 r = multiplyMV(m4_from(m), v4(v[0], v[1], v[2], v[3]));
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+void orc_point_on_ray(const float ray[6], float t, float out[3]) {
+    Ray r;
+    r.origin = v3(ray[0], ray[1], ray[2]);
+    r.direction = v3(ray[3], ray[4], ray[5]);
+    V3 p = get_point_on_ray(r, t);
+    out[0] = p.x; out[1] = p.y; out[2] = p.z;
+}
+void orc_build_transform(const float t[3], const float r[3], const float s[3], float transform[16],
+                         float inverse[16], float invTranspose[16]) {
+    M4 xf = build_transformation_matrix(v3(t[0], t[1], t[2]), v3(r[0], r[1], r[2]), v3(s[0], s[1], s[2]));
+    m4_to(xf, transform);
+    m4_to(m4_inverse(xf), inverse);
+    m4_to(m4_inverse_transpose(xf), invTranspose);
+}
+static float isect(const OGeom *g, const float ray[6], float p[3], float n[3], int *outside, bool sphere) {
+    Ray r;
+    r.origin = v3(ray[0], ray[1], ray[2]);
+    r.direction = v3(ray[3], ray[4], ray[5]);
+    V3 P = v3(p[0], p[1], p[2]), N = v3(n[0], n[1], n[2]);
+    bool o = *outside != 0;
+    float t = sphere ? sphere_intersection_test(*g, r, P, N, o) : box_intersection_test(*g, r, P, N, o);
+    p[0] = P.x; p[1] = P.y; p[2] = P.z;
+    n[0] = N.x; n[1] = N.y; n[2] = N.z;
+    *outside = o ? 1 : 0;
+    return t;
+}
+float orc_box_intersect(const OGeom *g, const float ray[6], float p[3], float n[3], int *outside) {
+    return isect(g, ray, p, n, outside, false);
+}
+float orc_sphere_intersect(const OGeom *g, const float ray[6], float p[3], float n[3], int *outside) {
+    return isect(g, ray, p, n, outside, true);
+}
+void orc_hemisphere(const float n[3], uint32_t *rng_state, float out[3]) {
+    V3 r = random_direction_in_hemisphere(v3(n[0], n[1], n[2]), *rng_state);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+void orc_hemisphere_seeded(const float n[3], int iter, int index, int depth, float out[3]) {
+    uint32_t x = rng_seed(make_seed(iter, index, depth));
+    orc_hemisphere(n, &x, out);
+}
+
+/* ---- scene -------------------------------------------------------------- */
+OScene *orc_scene_load(const char *path) {
+    std::ifstream fp(path);
+    if (!fp.is_open()) return NULL; /* scene.cpp:12-15 aborts */
+    OScene *sc = new OScene();
+    memset(&sc->camera, 0, sizeof(OCamera));
+    sc->iterations = 0;
+    sc->traceDepth = 0;
+    while (fp.good()) { /* scene.cpp:16-32 */
+        std::string line;
+        safe_getline(fp, line);
+        if (!line.empty()) {
+            std::vector<std::string> t = tokenize(line);
+            if (t.size() >= 2 && is(t, "MATERIAL")) load_material(*sc, fp, t[1]);
+            else if (t.size() >= 2 && is(t, "OBJECT")) load_geom(*sc, fp, t[1]);
+            else if (is(t, "CAMERA")) load_camera(*sc, fp);
+        }
+    }
+    return sc;
+}
+void orc_scene_free(OScene *s) { delete s; }
+int orc_scene_num_geoms(const OScene *s) { return (int)s->geoms.size(); }
+int orc_scene_num_materials(const OScene *s) { return (int)s->materials.size(); }
+const OGeom *orc_scene_geoms(const OScene *s) { return s->geoms.data(); }
+const OMaterial *orc_scene_materials(const OScene *s) { return s->materials.data(); }
+const OCamera *orc_scene_camera(const OScene *s) { return &s->camera; }
+int orc_scene_iterations(const OScene *s) { return s->iterations; }
+int orc_scene_depth(const OScene *s) { return s->traceDepth; }
+const char *orc_scene_image_name(const OScene *s) { return s->imageName.c_str(); }
+void orc_camera_set_resolution(OCamera *cam, int w, int h) {
+    cam->resX = w;
+    cam->resY = h;
+    compute_fov(*cam, cam->fovY);
+}
+
+/* ---- renderer ------------------------------------------------------------ */
+ORender *orc_render_create(const OCamera *cam, const OGeom *geoms, int ngeoms, const OMaterial *mats,
+                           int nmats, int traceDepth) {
+    ORender *R = new ORender();
+    R->cam = *cam;
+    R->geoms.assign(geoms, geoms + ngeoms);
+    R->mats.assign(mats, mats + nmats);
+    R->traceDepth = traceDepth;
+    R->view = from(cam->view);
+    R->up = from(cam->up);
+    R->position = from(cam->position);
+    R->right = normalize3(cross3(R->view, R->up));
+    float ys = std::tan(cam->fovY * (kPI / 180));
+    float xs = (ys * cam->resX) / cam->resY;
+    R->pixLenX = (2.0f * xs) / (float)cam->resX;
+    R->pixLenY = (2.0f * ys) / (float)cam->resY;
+    R->halfW = (float)cam->resX * 0.5f;
+    R->halfH = (float)cam->resY * 0.5f;
+    return R;
+}
+void orc_render_free(ORender *R) { delete R; }
+
+void orc_camera_ray(ORender *R, int iter, int index, float ray[6]) {
+    Ray r = camera_ray(*R, iter, index);
+    ray[0] = r.origin.x; ray[1] = r.origin.y; ray[2] = r.origin.z;
+    ray[3] = r.direction.x; ray[4] = r.direction.y; ray[5] = r.direction.z;
+}
+
+void orc_render_iterate(ORender *R, int iter, float *image, int shardRank, int shardCount,
+                        OCounters *counters) {
+    const int W = R->cam.resX, H = R->cam.resY;
+    OCounters local;
+    memset(&local, 0, sizeof local);
+    for (int y = shardRank; y < H; y += shardCount) {
+        for (int x = 0; x < W; ++x) {
+            int index = x + y * W;
+            Ray ray = camera_ray(*R, iter, index);
+            V3 color = v3(1, 1, 1);
+            bool alive = true;
+            for (int d = 1; d <= R->traceDepth && alive; ++d) {
+                if (d < 64) local.live[d]++;
+                V3 contrib = v3(0, 0, 0);
+                Fate f = bounce(*R, iter, index, d, ray, color, contrib);
+                if (f == MISS) {
+                    local.misses++;
+                    alive = false;
+                } else if (f == LIGHT) {
+                    image[3 * index + 0] += contrib.x;
+                    image[3 * index + 1] += contrib.y;
+                    image[3 * index + 2] += contrib.z;
+                    local.lightHits++;
+                    alive = false;
+                }
+            }
+            if (alive) local.depthKilled++;
+        }
+    }
+    if (counters) *counters = local;
+}
+
+int orc_render_dump_paths(ORender *R, int iter, int bounces, int shardRank, int shardCount,
+                          float *origin3, float *dir3, float *color3, int *pixelIndex) {
+    const int W = R->cam.resX, H = R->cam.resY;
+    int n = 0;
+    for (int y = shardRank; y < H; y += shardCount) {
+        for (int x = 0; x < W; ++x) {
+            int index = x + y * W;
+            Ray ray = camera_ray(*R, iter, index);
+            V3 color = v3(1, 1, 1);
+            bool alive = true;
+            for (int d = 1; d <= bounces && alive; ++d) {
+                V3 contrib;
+                alive = bounce(*R, iter, index, d, ray, color, contrib) == ALIVE;
+            }
+            if (!alive) continue;
+            origin3[3 * n] = ray.origin.x; origin3[3 * n + 1] = ray.origin.y; origin3[3 * n + 2] = ray.origin.z;
+            dir3[3 * n] = ray.direction.x; dir3[3 * n + 1] = ray.direction.y; dir3[3 * n + 2] = ray.direction.z;
+            color3[3 * n] = color.x; color3[3 * n + 1] = color.y; color3[3 * n + 2] = color.z;
+            pixelIndex[n] = index;
+            ++n;
+        }
+    }
+    (void)shard_rows;
+    return n;
+}
+
+/* src/pathtrace.cu:48-68 : clamp((int)(pix / iter * 255.0), 0, 255), fp64 multiply */
+void orc_to_rgba8(const float *image, int npixels, int iter, uint8_t *rgba) {
+    for (int i = 0; i < npixels; ++i) {
+        for (int c = 0; c < 3; ++c) {
+            int v = (int)(image[3 * i + c] / iter * 255.0);
+            v = v < 0 ? 0 : (v > 255 ? 255 : v);
+            rgba[4 * i + c] = (uint8_t)v;
+        }
+        rgba[4 * i + 3] = 0;
+    }
+}
+
+void orc_scan_exclusive_i32(const int32_t *in, int32_t *out, int64_t n) {
+    int32_t acc = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        int32_t v = in[i];
+        out[i] = acc;
+        acc += v;
+    }
+}
+int64_t orc_compact_nonzero_i32(const int32_t *in, int32_t *out, int64_t n) {
+    int64_t k = 0;
+    for (int64_t i = 0; i < n; ++i)
+        if (in[i] != 0) out[k++] = in[i];
+    return k;
+}
+
+}  // extern "C"
