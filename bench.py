@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the path-tracing hot path on MI355X.
+
+Metric (BASELINE.json): Mpaths/s, paths = pixels x bounces x spp (NOMINAL segments), Cornell box at
+1280x720, 8 bounces.  One "step" = one iteration (1 spp) of the whole frame: camera rays, 8 fused
+intersect+shade+compact launches, accumulation (+ the per-iteration RCCL reduce of the accumulator
+when N > 1).  Scene, accumulator and path state are resident in HBM before the timed region.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU)
+
+N > 1: image rows are sharded round-robin over the ranks (row y -> rank y % N), every rank renders
+its rows into a zeroed full-frame accumulator, and a single RCCL reduce(sum) to rank 0 per iteration
+assembles the frame (disjoint rows: x + 0 is exact, so the result is bit-identical to 1 GPU).
+Fixed total work -> "scaling": "strong".
+
+Prints ONE JSON line on rank 0, with `roofline` (dominant kernel = the fused bounce kernel, HIP-event
+timed, against the 8 TB/s HBM peak) and `cpu_baseline` (the single-thread CPU oracle on a bounded
+sample of the same workload; N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PATH_BYTES = 44                # SoA PathSegment: origin 12 + dir 12 + throughput 12 + pixelIndex 4 + remainingBounces 4
+ACCUM_BYTES = 24               # accumulator read + write of one emitter hit (vec3 fp32)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)          # BASELINE config C2: 64 spp
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--scene", default=os.path.join(ROOT, "scenes", "cornell.txt"))
+    ap.add_argument("--res", type=int, nargs=2, default=[1280, 720])
+    ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--cpu-spp", type=int, default=12, help="spp of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--pmc-traffic-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"),
+                    help="HBM bytes per bounce-kernel launch from a rocprofv3 --pmc run (profiles/README.md)")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, scene):
+    """Single-thread CPU oracle (oracle/, kind 'port') on a bounded sample of the same workload."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as orc
+    W, H = args.res
+    ref = orc.Renderer(scene.camera.view(orc.CAMERA_DTYPE), scene.geoms.view(orc.GEOM_DTYPE),
+                       scene.materials.view(orc.MATERIAL_DTYPE), args.depth)
+    img = np.zeros(W * H * 3, np.float32)
+    ref.iterate(1, img)                                    # warm the caches / page in
+    t0 = time.perf_counter()
+    for it in range(2, 2 + args.cpu_spp):
+        ref.iterate(it, img)
+    dt = time.perf_counter() - t0
+    return {"value": round(W * H * args.depth * args.cpu_spp / dt / 1e6, 3), "unit": "Mpaths/s", "cores": 1,
+            "kind": "port",
+            "sample": "%d spp of %s %dx%d depth %d (%.1f s, single thread, g++ -O2 -ffp-contract=off, host has %d cores)"
+                      % (args.cpu_spp, os.path.basename(args.scene), W, H, args.depth, dt, os.cpu_count())}
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__ as ge
+    pt = ge.load_package()
+
+    W, H = args.res
+    scene = pt.Scene(args.scene)
+    scene.set_resolution(W, H)
+    P = W * H
+    # accumulator as a torch tensor so RCCL can reduce it; zeroed full frame on every rank
+    accum = torch.zeros(P * 3, dtype=torch.float32, device="cuda")
+    frame = torch.zeros_like(accum) if world > 1 else None           # rank 0 receives the assembled frame here
+    stream = torch.cuda.current_stream()
+
+    def init(flags):
+        pt.pathtraceFree()
+        pt.pathtraceInit(scene, shard_rank=rank, shard_count=world, stream=stream.cuda_stream,
+                         accum_dev=accum.data_ptr(), device=local_rank, flags=flags, traceDepth=args.depth)
+
+    def step(it):
+        pt.pathtrace(None, 0, it, readback=False)
+        if world > 1:
+            # the single collective of the data path: per-iteration reduce of the accumulator over xGMI
+            frame.copy_(accum)
+            dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(first_iter, steps):
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            step(first_iter + k)
+        barrier()
+        return time.perf_counter() - t0
+
+    # ---- pass A: the headline number ----------------------------------------------------------
+    init(0)
+    for k in range(args.warmup):
+        step(1 + k)
+    barrier()
+    pt.counters_reset()
+    dt = timed(1 + args.warmup, args.steps)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    cntA = pt.counters()
+
+    # ---- pass B: same steps with HIP events around every launch (roofline of the bounce kernel) -
+    init(pt.PT_FLAG_KERNEL_TIMING)
+    for k in range(min(args.warmup, 2)):
+        step(1 + k)
+    barrier()
+    pt.counters_reset()
+    dtB = timed(1 + args.warmup, args.steps)
+    cnt = pt.counters()
+    pt.pathtraceFree()
+
+    D = args.depth
+    live = [int(cnt.live[d]) for d in range(D + 2)]
+    hits = int(cnt.light_hits)
+    # algorithmic HBM bytes of the bounce launches: read every live path, write every survivor
+    # (nothing is written after the last bounce), read+write the accumulator for every emitter hit
+    bounce_bytes = sum(PATH_BYTES * live[d] for d in range(1, D + 1)) \
+        + sum(PATH_BYTES * live[d + 1] for d in range(1, D)) + ACCUM_BYTES * hits
+    raygen_bytes = PATH_BYTES * live[1]
+    launches = max(int(cnt.bounce_launches), 1)
+    avg_ms = cnt.bounce_kernel_ms / launches
+    achieved = bounce_bytes / launches / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    traffic = None
+    try:
+        traffic = json.load(open(args.pmc_traffic_json)).get("hbm_bytes_per_bounce_launch")
+    except Exception:
+        pass
+
+    if rank == 0:
+        nominal = P * D * args.steps
+        out = {
+            "metric": "Mpaths/sec (paths = pixels x bounces x spp) at 1280x720, 8 bounces",
+            "value": round(nominal / dt / 1e6, 2), "unit": "Mpaths/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s %dx%d, %d spp, %d bounces%s" % (
+                           os.path.relpath(args.scene, ROOT), W, H, args.steps, D,
+                           "" if world == 1 else ", rows sharded y%%%d + RCCL reduce per iteration" % world),
+                       "paths_per_step_nominal": P * D,
+                       "live_segments_per_step": round(sum(live[1:D + 1]) / max(args.steps, 1), 1),
+                       "live_Msegments_per_s": round(sum(int(cntA.live[d]) for d in range(1, D + 1)) / dt / 1e6, 2)},
+            "roofline": {"bound": "hbm", "kernel": "k_bounce (fused intersect+shade+compact, one launch per bounce)",
+                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "traffic": traffic,
+                         "algorithmic_bytes_per_launch": round(bounce_bytes / launches, 1),
+                         "avg_launch_ms": round(avg_ms, 5), "launches": launches,
+                         "bounce_kernel_share_of_step": round(cnt.bounce_kernel_ms / (dtB * 1e3), 4),
+                         "raygen_avg_ms": round(cnt.raygen_kernel_ms / max(int(cnt.raygen_launches), 1), 5),
+                         "raygen_GBps": round(raygen_bytes / max(cnt.raygen_kernel_ms, 1e-9) / 1e6, 2),
+                         "ms_per_step_with_events": round(dtB / args.steps * 1e3, 4)},
+        }
+        if world == 1 and args.cpu_spp > 0:
+            out["cpu_baseline"] = cpu_baseline(args, scene)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

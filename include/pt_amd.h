@@ -1,0 +1,157 @@
+/*
+ * pt_amd.h -- C ABI of the MI355X-native path-tracing hot path (libpt_amd.so).
+ *
+ * Drop-in boundary for CIS565-Fall-2015/Project3-CUDA-Path-Tracer's renderer API
+ *     void pathtraceInit(Scene *scene);                       reference src/pathtrace.h:6,  src/pathtrace.cu:75-85
+ *     void pathtraceFree();                                   reference src/pathtrace.h:7,  src/pathtrace.cu:87-92
+ *     void pathtrace(uchar4 *pbo, int frame, int iteration);  reference src/pathtrace.h:8,  src/pathtrace.cu:123-174
+ * Those three symbols are C++-mangled and take a libstdc++/glm-dependent `Scene*`, so the FFI-able
+ * core below takes plain pointers and sizes; the ~40-line C++ shim that provides the three reference
+ * symbols on top of it is project3-cuda-path-tracer_amd/host/pathtrace_shim.cpp.
+ *
+ * PtGeom / PtMaterial / PtCamera are byte-identical to Geom / Material / Camera of reference
+ * src/sceneStructs.h:18-47, so `scene->geoms.data()`, `scene->materials.data()` and
+ * `&scene->state.camera` pass straight through.
+ *
+ * All functions return PT_OK (0) or a negative PtStatus; pt_last_error() describes the last failure.
+ * The library keeps ONE renderer instance per process, like the reference's file-static state
+ * (src/pathtrace.cu:70-71).  Not thread-safe (the reference is single-threaded).
+ */
+#ifndef PT_AMD_H
+#define PT_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct PtVec3 { float x, y, z; } PtVec3;
+
+/* reference src/sceneStructs.h:8-11 */
+enum { PT_SPHERE = 0, PT_CUBE = 1 };
+
+/* reference src/sceneStructs.h:18-27 -- 236 bytes, mat4 column-major (m[col*4+row]) */
+typedef struct PtGeom {
+    int32_t type;
+    int32_t materialid;
+    PtVec3  translation, rotation, scale;
+    float   transform[16];
+    float   inverseTransform[16];
+    float   invTranspose[16];
+} PtGeom;
+
+/* reference src/sceneStructs.h:29-39 -- 44 bytes (flags are floats) */
+typedef struct PtMaterial {
+    PtVec3 color;
+    float  specularExponent;
+    PtVec3 specularColor;
+    float  hasReflective, hasRefractive, indexOfRefraction, emittance;
+} PtMaterial;
+
+/* reference src/sceneStructs.h:41-47 -- 52 bytes; fov in degrees, fov.y = vertical HALF angle */
+typedef struct PtCamera {
+    int32_t resolution[2];
+    PtVec3  position, view, up;
+    float   fov[2];
+} PtCamera;
+
+typedef enum PtStatus {
+    PT_OK = 0,
+    PT_ERR_INVALID = -1,      /* bad argument */
+    PT_ERR_NOT_INIT = -2,     /* pt_iterate & co. before pt_init */
+    PT_ERR_HIP = -3,          /* a HIP runtime call failed (replaces checkCUDAError, pathtrace.cu:21-39) */
+    PT_ERR_DEVICE = -4,       /* a kernel reported an internal fault (scan look-back timeout) */
+    PT_ERR_NO_GPU = -5        /* no HIP device: there is NO CPU fallback */
+} PtStatus;
+
+enum {
+    PT_FLAG_KERNEL_TIMING = 1 /* bracket every bounce-kernel launch with HIP events (roofline measurement) */
+};
+
+typedef struct PtOptions {
+    int32_t shard_rank;       /* this process renders image rows y with y % shard_count == shard_rank */
+    int32_t shard_count;      /* 1 = whole frame (reference behaviour) */
+    int32_t device;           /* HIP device ordinal; -1 = current device */
+    int32_t flags;            /* PT_FLAG_* */
+    void   *stream;           /* hipStream_t to enqueue on; NULL = the default stream */
+    float  *accum_dev;        /* optional caller-owned device accumulator, W*H*3 floats, zeroed by the
+                                 caller (e.g. a torch tensor used for the RCCL reduce); NULL = owned
+                                 by the library like dev_image (pathtrace.cu:71,80-81) */
+} PtOptions;
+
+#define PT_MAX_DEPTH 62
+
+typedef struct PtCounters {
+    int64_t live[PT_MAX_DEPTH + 2]; /* live[d] = paths entering bounce d (d = 1..depth), summed over   */
+    int64_t light_hits;             /*           every iteration since pt_init / pt_counters_reset      */
+    int64_t misses;
+    int64_t iterations;
+    int64_t bounce_launches;        /* bounce-kernel launches covered by bounce_kernel_ms               */
+    double  bounce_kernel_ms;       /* sum of HIP-event durations (PT_FLAG_KERNEL_TIMING only)          */
+    double  raygen_kernel_ms;
+    int64_t raygen_launches;
+} PtCounters;
+
+/* pathtraceInit: upload scene, allocate the accumulator and the SoA path-state buffers.
+ * Replaces reference src/pathtrace.cu:75-85.  Calling it twice without pt_free re-initialises. */
+int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMaterial *mats, int nmats,
+            int traceDepth, const PtOptions *opts /* may be NULL */);
+
+/* pathtrace(pbo, frame, iter): one iteration (1 spp), iter is 1-based like src/main.cpp:97-103.
+ * Enqueues camera-ray generation, traceDepth fused intersect+shade+compact launches and, when
+ * rgba8_dev != NULL, the sendImageToPBO conversion (src/pathtrace.cu:48-68) into that DEVICE
+ * buffer of W*H uchar4.  Asynchronous on the configured stream.  Replaces src/pathtrace.cu:123-167. */
+int pt_iterate(int frame, int iter, void *rgba8_dev /* may be NULL (headless) */);
+
+/* Wait for the stream; reports device-side faults.  (checkCUDAError's sync, pathtrace.cu:23.) */
+int pt_sync(void);
+
+/* Copy the un-normalised running sum (W*H*3 floats, index = x + y*W) to host: the D2H copy of
+ * src/pathtrace.cu:170-171 into scene->state.image.  Synchronises. */
+int pt_readback(float *rgb_sum_host);
+
+/* sendImageToPBO into a HOST buffer (W*H*4 bytes). Synchronises. */
+int pt_readback_rgba8(int iter, uint8_t *rgba_host);
+
+int pt_counters(PtCounters *out);     /* synchronises */
+int pt_counters_reset(void);
+
+/* pathtraceFree: tolerant of the never-initialised state (src/main.cpp:91-94 calls it first). */
+void pt_free(void);
+
+const char *pt_last_error(void);
+
+/* Number of HIP devices visible (0 = none; the library then refuses to run). */
+int pt_device_count(void);
+
+/* ---- diagnostics for parity tests -------------------------------------------------------------
+ * State of the paths still alive after `bounces` bounces of iteration `iter`, in compacted (stable,
+ * pixel) order: arrays of capacity W*H (x3).  Does not touch the accumulator. */
+int pt_debug_trace_paths(int iter, int bounces, float *origin3, float *dir3, float *color3,
+                         int32_t *pixelIndex, int32_t *count);
+
+/* ---- stream compaction library (the reference's empty stream_compaction/ stub, README.md:83-86):
+ * work-efficient exclusive scan / compaction over DEVICE buffers, multi-block, any n >= 0. ---------- */
+int pt_scan_exclusive_i32(const int32_t *in_dev, int32_t *out_dev, int64_t n, void *stream);
+/* keeps the non-zero elements in order; *count_dev (device) receives how many were kept */
+int pt_compact_nonzero_i32(const int32_t *in_dev, int32_t *out_dev, int64_t n, int64_t *count_dev,
+                           void *stream);
+
+/* ---- device primitives evaluated on the GPU over HOST arrays (parity tests of rows a6-a12, a19):
+ * the same __device__ functions the render kernels call. ------------------------------------------ */
+int pt_test_utilhash(const uint32_t *in, uint32_t *out, int n);
+int pt_test_rng(const uint32_t *seeds, int nseeds, int ndraws, float *u01_out /* nseeds*ndraws */);
+/* rays: n x 6; each ray against ONE geom (geoms[geom_index[i]]); outputs keep their input values
+ * on a miss like the reference's out-parameters (intersections.h:86-88,114-126). */
+int pt_test_intersect(const PtGeom *geoms, int ngeoms, const int32_t *geom_index, const float *rays,
+                      int n, float *t, float *p3, float *n3, int32_t *outside);
+int pt_test_hemisphere(const float *normals3, const int32_t *iter_index_depth3, int n, float *out3);
+int pt_test_sincos(const float *x, int n, float *s, float *c);
+int pt_test_reflect_refract(const float *I3, const float *N3, const float *eta, int n, float *refl3,
+                            float *refr3);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PT_AMD_H */

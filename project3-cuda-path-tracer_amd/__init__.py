@@ -1,0 +1,320 @@
+"""project3-cuda-path-tracer_amd -- MI355X-native hot path of CIS565 Project3-CUDA-Path-Tracer.
+
+Python host-side mirror of the reference's renderer interface (src/pathtrace.h:6-8):
+
+    pathtraceInit(scene)                 reference src/pathtrace.cu:75-85
+    pathtrace(pbo, frame, iteration)     reference src/pathtrace.cu:123-174
+    pathtraceFree()                      reference src/pathtrace.cu:87-92
+
+over the C ABI declared in include/pt_amd.h (csrc/libpt_amd.so, hand-written HIP for gfx950) and
+the C++ scene loader in host/ (libpt_host.so).  There is NO CPU fallback: importing works
+anywhere (so the library's symbols can be checked), but every compute entry point fails loudly
+when the extension or a GPU is missing.  This package never touches oracle/.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libpt_amd.so")
+HOST_LIB_PATH = os.path.join(HERE, "host", "libpt_host.so")
+
+# byte-identical to reference src/sceneStructs.h:18-47 (include/pt_amd.h PtGeom/PtMaterial/PtCamera)
+GEOM_DTYPE = np.dtype([
+    ("type", "<i4"), ("materialid", "<i4"),
+    ("translation", "<f4", 3), ("rotation", "<f4", 3), ("scale", "<f4", 3),
+    ("transform", "<f4", 16), ("inverseTransform", "<f4", 16), ("invTranspose", "<f4", 16),
+])
+MATERIAL_DTYPE = np.dtype([
+    ("color", "<f4", 3), ("specularExponent", "<f4"), ("specularColor", "<f4", 3),
+    ("hasReflective", "<f4"), ("hasRefractive", "<f4"), ("indexOfRefraction", "<f4"),
+    ("emittance", "<f4"),
+])
+CAMERA_DTYPE = np.dtype([
+    ("resolution", "<i4", 2), ("position", "<f4", 3), ("view", "<f4", 3), ("up", "<f4", 3),
+    ("fov", "<f4", 2),
+])
+assert GEOM_DTYPE.itemsize == 236 and MATERIAL_DTYPE.itemsize == 44 and CAMERA_DTYPE.itemsize == 52
+
+PT_MAX_DEPTH = 62
+PT_FLAG_KERNEL_TIMING = 1
+
+# every symbol include/pt_amd.h declares
+ABI_SYMBOLS = [
+    "pt_init", "pt_iterate", "pt_sync", "pt_readback", "pt_readback_rgba8", "pt_counters",
+    "pt_counters_reset", "pt_free", "pt_last_error", "pt_device_count", "pt_debug_trace_paths",
+    "pt_scan_exclusive_i32", "pt_compact_nonzero_i32", "pt_test_utilhash", "pt_test_rng",
+    "pt_test_intersect", "pt_test_hemisphere", "pt_test_sincos", "pt_test_reflect_refract",
+]
+
+
+class PtOptions(C.Structure):
+    _fields_ = [("shard_rank", C.c_int32), ("shard_count", C.c_int32), ("device", C.c_int32),
+                ("flags", C.c_int32), ("stream", C.c_void_p), ("accum_dev", C.c_void_p)]
+
+
+class PtCounters(C.Structure):
+    _fields_ = [("live", C.c_int64 * (PT_MAX_DEPTH + 2)), ("light_hits", C.c_int64), ("misses", C.c_int64),
+                ("iterations", C.c_int64), ("bounce_launches", C.c_int64), ("bounce_kernel_ms", C.c_double),
+                ("raygen_kernel_ms", C.c_double), ("raygen_launches", C.c_int64)]
+
+
+class PtError(RuntimeError):
+    pass
+
+
+_lib = None
+_host = None
+
+
+def lib():
+    """The HIP extension.  Raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PtError("HIP extension missing: %s (run __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+        # torch (device memory / streams / RCCL plumbing) bundles its own libamdhip64.so; it has to be
+        # loaded FIRST so that this library binds to the same HIP runtime instance (same soname) and
+        # torch stream handles / device pointers are valid here.  Two runtimes in one process break both.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        L = C.CDLL(LIB_PATH)
+        vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
+        L.pt_init.argtypes = [vp, vp, i32, vp, i32, i32, C.POINTER(PtOptions)]
+        L.pt_iterate.argtypes = [i32, i32, vp]
+        L.pt_sync.argtypes = []
+        L.pt_readback.argtypes = [vp]
+        L.pt_readback_rgba8.argtypes = [i32, vp]
+        L.pt_counters.argtypes = [C.POINTER(PtCounters)]
+        L.pt_counters_reset.argtypes = []
+        L.pt_free.argtypes = []
+        L.pt_free.restype = None
+        L.pt_last_error.restype = C.c_char_p
+        L.pt_device_count.argtypes = []
+        L.pt_debug_trace_paths.argtypes = [i32, i32, vp, vp, vp, vp, C.POINTER(C.c_int32)]
+        L.pt_scan_exclusive_i32.argtypes = [vp, vp, i64, vp]
+        L.pt_compact_nonzero_i32.argtypes = [vp, vp, i64, vp, vp]
+        L.pt_test_utilhash.argtypes = [vp, vp, i32]
+        L.pt_test_rng.argtypes = [vp, i32, i32, vp]
+        L.pt_test_intersect.argtypes = [vp, i32, vp, vp, i32, vp, vp, vp, vp]
+        L.pt_test_hemisphere.argtypes = [vp, vp, i32, vp]
+        L.pt_test_sincos.argtypes = [vp, i32, vp, vp]
+        L.pt_test_reflect_refract.argtypes = [vp, vp, vp, i32, vp, vp]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise PtError("pt_amd error %d: %s" % (rc, lib().pt_last_error().decode()))
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def device_count():
+    return lib().pt_device_count()
+
+
+# --------------------------------------------------------------------------- scene (host/ loader)
+def host_lib():
+    global _host
+    if _host is None:
+        if not os.path.exists(HOST_LIB_PATH):
+            raise PtError("host library missing: %s (run __graft_entry__.build())" % HOST_LIB_PATH)
+        H = C.CDLL(HOST_LIB_PATH)
+        vp = C.c_void_p
+        H.pth_scene_load.restype = vp
+        H.pth_scene_load.argtypes = [C.c_char_p]
+        H.pth_scene_free.argtypes = [vp]
+        H.pth_scene_free.restype = None
+        for n in ("pth_scene_num_geoms", "pth_scene_num_materials", "pth_scene_iterations", "pth_scene_depth"):
+            getattr(H, n).argtypes = [vp]
+            getattr(H, n).restype = C.c_int
+        for n in ("pth_scene_geoms", "pth_scene_materials", "pth_scene_camera"):
+            getattr(H, n).argtypes = [vp]
+            getattr(H, n).restype = vp
+        H.pth_scene_image_name.argtypes = [vp]
+        H.pth_scene_image_name.restype = C.c_char_p
+        H.pth_scene_set_resolution.argtypes = [vp, C.c_int, C.c_int]
+        H.pth_scene_set_resolution.restype = None
+        H.pth_save_png.argtypes = [C.c_char_p, vp, C.c_int, C.c_int, C.c_float]
+        H.pth_save_png.restype = C.c_int
+        _host = H
+    return _host
+
+
+class Scene:
+    """Mirror of the reference's `Scene` (src/scene.h:13-26): geoms, materials, state."""
+
+    def __init__(self, filename):
+        H = host_lib()
+        h = H.pth_scene_load(os.fsencode(filename))
+        if not h:
+            raise IOError("Error reading from file - aborting!")  # reference src/scene.cpp:12-15
+        self._h = h
+        self._refresh()
+
+    def _refresh(self):
+        H, h = host_lib(), self._h
+        ng, nm = H.pth_scene_num_geoms(h), H.pth_scene_num_materials(h)
+        self.geoms = np.frombuffer(C.string_at(H.pth_scene_geoms(h), 236 * ng), GEOM_DTYPE).copy() if ng \
+            else np.zeros(0, GEOM_DTYPE)
+        self.materials = np.frombuffer(C.string_at(H.pth_scene_materials(h), 44 * nm), MATERIAL_DTYPE).copy() if nm \
+            else np.zeros(0, MATERIAL_DTYPE)
+        self.camera = np.frombuffer(C.string_at(H.pth_scene_camera(h), 52), CAMERA_DTYPE).copy()
+        self.iterations = H.pth_scene_iterations(h)
+        self.traceDepth = H.pth_scene_depth(h)
+        self.imageName = H.pth_scene_image_name(h).decode()
+        w, hh = (int(v) for v in self.camera["resolution"][0])
+        self.image = np.zeros((hh, w, 3), np.float32)   # RenderState::image (src/sceneStructs.h:53)
+
+    def set_resolution(self, w, h):
+        """RES override; fov.x is recomputed as src/scene.cpp:133-136 does."""
+        host_lib().pth_scene_set_resolution(self._h, w, h)
+        self._refresh()
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            host_lib().pth_scene_free(self._h)
+            self._h = None
+
+
+# --------------------------------------------------------------------------- renderer API
+_scene = None
+
+
+def pathtraceInit(scene, shard_rank=0, shard_count=1, stream=0, accum_dev=0, device=-1, flags=0, traceDepth=None):
+    """reference src/pathtrace.cu:75-85.  `scene` is borrowed until pathtraceFree()."""
+    global _scene
+    opt = PtOptions(shard_rank, shard_count, device, flags, stream or None, accum_dev or None)
+    geoms = np.ascontiguousarray(scene.geoms)
+    mats = np.ascontiguousarray(scene.materials)
+    cam = np.ascontiguousarray(scene.camera)
+    depth = scene.traceDepth if traceDepth is None else traceDepth
+    _check(lib().pt_init(_p(cam), _p(geoms), len(geoms), _p(mats), len(mats), depth, C.byref(opt)))
+    _scene = scene
+
+
+def pathtrace(pbo, frame, iteration, readback=True):
+    """reference src/pathtrace.cu:123-174: one iteration; `pbo` is a DEVICE pointer (int) or None.
+    With readback=True the running sum lands in scene.image like the reference's D2H copy (:170-171)."""
+    _check(lib().pt_iterate(frame, iteration, pbo or None))
+    if readback and _scene is not None:
+        _check(lib().pt_readback(_p(_scene.image)))
+
+
+def pathtraceFree():
+    """reference src/pathtrace.cu:87-92; legal before the first pathtraceInit (src/main.cpp:91-94)."""
+    global _scene
+    lib().pt_free()
+    _scene = None
+
+
+def sync():
+    _check(lib().pt_sync())
+
+
+def readback(npixels):
+    out = np.empty(npixels * 3, np.float32)
+    _check(lib().pt_readback(_p(out)))
+    return out
+
+
+def readback_rgba8(iteration, npixels):
+    out = np.empty((npixels, 4), np.uint8)
+    _check(lib().pt_readback_rgba8(iteration, _p(out)))
+    return out
+
+
+def counters():
+    c = PtCounters()
+    _check(lib().pt_counters(C.byref(c)))
+    return c
+
+
+def counters_reset():
+    _check(lib().pt_counters_reset())
+
+
+def debug_trace_paths(iteration, bounces, npixels):
+    o, d, c = (np.empty((npixels, 3), np.float32) for _ in range(3))
+    pix = np.empty(npixels, np.int32)
+    n = C.c_int32(0)
+    _check(lib().pt_debug_trace_paths(iteration, bounces, _p(o), _p(d), _p(c), _p(pix), C.byref(n)))
+    k = n.value
+    return o[:k], d[:k], c[:k], pix[:k]
+
+
+def save_png(basename, image_sum, samples):
+    """saveImage + image::savePNG (reference src/main.cpp:49-70, src/image.cpp:22-39): divide by the
+    sample count, mirror X, clamp, x255, truncate; writes <basename>.png."""
+    img = np.ascontiguousarray(image_sum, np.float32)
+    h, w = img.shape[0], img.shape[1]
+    rc = host_lib().pth_save_png(os.fsencode(basename), _p(img), w, h, C.c_float(samples))
+    if rc != 0:
+        raise IOError("could not write %s.png" % basename)
+
+
+# --------------------------------------------------------------------------- primitive / scan entry points (host arrays)
+def test_utilhash(x):
+    x = np.ascontiguousarray(x, np.uint32)
+    out = np.empty_like(x)
+    _check(lib().pt_test_utilhash(_p(x), _p(out), x.size))
+    return out
+
+
+def test_rng(seeds, ndraws):
+    seeds = np.ascontiguousarray(seeds, np.uint32)
+    out = np.empty((seeds.size, ndraws), np.float32)
+    _check(lib().pt_test_rng(_p(seeds), seeds.size, ndraws, _p(out)))
+    return out
+
+
+def test_intersect(geoms, geom_index, rays, sentinel=-7.0):
+    geoms = np.ascontiguousarray(geoms)
+    gi = np.ascontiguousarray(geom_index, np.int32)
+    rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+    n = len(rays)
+    t = np.empty(n, np.float32)
+    p = np.full((n, 3), sentinel, np.float32)
+    nn = np.full((n, 3), sentinel, np.float32)
+    o = np.ones(n, np.int32)
+    _check(lib().pt_test_intersect(_p(geoms), len(geoms), _p(gi), _p(rays), n, _p(t), _p(p), _p(nn), _p(o)))
+    return t, p, nn, o
+
+
+def test_hemisphere(normals, iter_index_depth):
+    normals = np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
+    iid = np.ascontiguousarray(iter_index_depth, np.int32).reshape(-1, 3)
+    out = np.empty_like(normals)
+    _check(lib().pt_test_hemisphere(_p(normals), _p(iid), len(normals), _p(out)))
+    return out
+
+
+def test_sincos(x):
+    x = np.ascontiguousarray(x, np.float32)
+    s, c = np.empty_like(x), np.empty_like(x)
+    _check(lib().pt_test_sincos(_p(x), x.size, _p(s), _p(c)))
+    return s, c
+
+
+def test_reflect_refract(I, N, eta):
+    I = np.ascontiguousarray(I, np.float32).reshape(-1, 3)
+    N = np.ascontiguousarray(N, np.float32).reshape(-1, 3)
+    eta = np.ascontiguousarray(eta, np.float32)
+    r1, r2 = np.empty_like(I), np.empty_like(I)
+    _check(lib().pt_test_reflect_refract(_p(I), _p(N), _p(eta), len(I), _p(r1), _p(r2)))
+    return r1, r2
+
+
+def scan_exclusive_dev(in_ptr, out_ptr, n, stream=0):
+    _check(lib().pt_scan_exclusive_i32(in_ptr, out_ptr, n, stream or None))
+
+
+def compact_nonzero_dev(in_ptr, out_ptr, n, count_ptr, stream=0):
+    _check(lib().pt_compact_nonzero_i32(in_ptr, out_ptr, n, count_ptr, stream or None))

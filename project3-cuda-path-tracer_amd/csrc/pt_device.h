@@ -1,0 +1,257 @@
+// pt_device.h -- device-side math of the MI355X path tracer (gfx950 only).
+//
+// Every function is a restatement, in the reference's operation order, of what its kernels
+// would inline from src/intersections.h, src/interactions.h and the vendored glm 0.9.6.3
+// (citations relative to the reference root).  The translation unit is compiled with
+// -ffp-contract=off and correctly-rounded fp32 divide/sqrt, so each source-level operation is
+// exactly one IEEE-754 fp32 operation and results are bit-identical to the reference's host
+// evaluation of the same functions.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ptd {
+
+struct F3 {
+    float x, y, z;
+};
+
+__device__ __forceinline__ F3 f3(float x, float y, float z) { return F3{x, y, z}; }
+__device__ __forceinline__ F3 operator+(F3 a, F3 b) { return f3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ F3 operator-(F3 a, F3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ F3 operator*(F3 a, F3 b) { return f3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ F3 operator*(F3 a, float s) { return f3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ F3 operator-(F3 a) { return f3(-a.x, -a.y, -a.z); }
+
+// glm/detail/func_geometric.inl:64-83 (compute_dot<tvec3>): tmp = x*y; tmp.x + tmp.y + tmp.z
+__device__ __forceinline__ float dot(F3 a, F3 b) {
+    F3 t = a * b;
+    return t.x + t.y + t.z;
+}
+// glm/detail/func_geometric.inl:134-143
+__device__ __forceinline__ F3 cross(F3 x, F3 y) {
+    return f3(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y);
+}
+// glm/detail/func_geometric.inl:154-159 with inversesqrt = 1/sqrt (func_exponential.inl:150-153)
+__device__ __forceinline__ F3 normalize(F3 a) { return a * (1.0f / __builtin_sqrtf(dot(a, a))); }
+// glm/detail/func_geometric.inl:95-100
+__device__ __forceinline__ float length(F3 a) { return __builtin_sqrtf(dot(a, a)); }
+// glm/detail/func_geometric.inl:176-179 : I - N * dot(N, I) * 2
+__device__ __forceinline__ F3 reflect(F3 I, F3 N) { return I - (N * dot(N, I)) * 2.0f; }
+// glm/detail/func_geometric.inl:193-200.  NaN when k < 0 (sqrt of a negative times 0): callers test k.
+__device__ __forceinline__ F3 refract(F3 I, F3 N, float eta) {
+    float d = dot(N, I);
+    float k = 1.0f - eta * eta * (1.0f - d * d);
+    F3 r = I * eta - N * (eta * d + __builtin_sqrtf(k));
+    return r * (k >= 0.0f ? 1.0f : 0.0f);
+}
+
+// src/utilities.h:12-15
+constexpr float kTwoPi = 6.2831853071795864769252867665590057683943f;
+constexpr float kSqrtOneThird = 0.5773502691896257645091487805019574556476f;
+
+// ---- scene data as staged in LDS -------------------------------------------------------------
+// Rows 0..2 of the three column-major mat4 of a Geom (the w row is never used: multiplyMV clips
+// to vec3, src/intersections.h:33-35).  m[col*3 + row].
+struct GeomDev {
+    float inv[12];   // inverseTransform
+    float xf[12];    // transform
+    float invT[12];  // invTranspose
+    int   type;      // 0 sphere, 1 cube (src/sceneStructs.h:8-11)
+    int   material;
+    int   pad0, pad1;
+};
+static_assert(sizeof(GeomDev) == 160, "GeomDev is 10 x 16 B so LDS reads are ds_read_b128");
+
+struct MaterialDev {
+    float color[3];
+    float specColor[3];
+    float hasReflective, hasRefractive, ior, emittance;
+    float pad0, pad1;
+};
+static_assert(sizeof(MaterialDev) == 48, "MaterialDev is 3 x 16 B");
+
+// multiplyMV (src/intersections.h:33-35) = vec3(m * v), glm/detail/type_mat4x4.inl:617-628:
+// (m0*v0 + m1*v1) + (m2*v2 + m3*v3).  The products with w = 0 / w = 1 are kept as IEEE ops
+// (x*1 folds exactly; x*0 keeps its signed zero), so signed zeros match the reference too.
+__device__ __forceinline__ F3 mulMV(const float *m, F3 v, float w) {
+    F3 r;
+    r.x = (m[0] * v.x + m[3] * v.y) + (m[6] * v.z + m[9] * w);
+    r.y = (m[1] * v.x + m[4] * v.y) + (m[7] * v.z + m[10] * w);
+    r.z = (m[2] * v.x + m[5] * v.y) + (m[8] * v.z + m[11] * w);
+    return r;
+}
+
+// src/intersections.h:11-19
+__device__ __forceinline__ uint32_t utilhash(uint32_t a) {
+    a = (a + 0x7ed55d16u) + (a << 12);
+    a = (a ^ 0xc761c23cu) ^ (a >> 19);
+    a = (a + 0x165667b1u) + (a << 5);
+    a = (a + 0xd3a2646cu) ^ (a << 9);
+    a = (a + 0xfd7046c5u) + (a << 3);
+    a = (a ^ 0xb55a4f09u) ^ (a >> 16);
+    return a;
+}
+
+// thrust::default_random_engine = minstd_rand: x' = 48271 x mod (2^31 - 1); seed s -> s mod m, 0 -> 1
+// (thrust/random/detail/linear_congruential_engine.inl).  The Mersenne-prime fold replaces
+// thrust's Schrage form (thrust/random/detail/mod.h); both equal (48271 * x) mod m.
+struct Rng {
+    uint32_t x;
+};
+__device__ __forceinline__ uint32_t mod_m31(uint64_t p) {
+    const uint32_t m = 2147483647u;
+    uint64_t r = (p & m) + (p >> 31);       // p < 2^63  ->  r < 2^32 + 2^31
+    r = (r & m) + (r >> 31);                // r <= m + 2
+    uint32_t q = (uint32_t)r;
+    return q >= m ? q - m : q;
+}
+// src/pathtrace.cu:41-45
+__device__ __forceinline__ Rng makeSeededRandomEngine(int iter, int index, int depth) {
+    uint32_t h = utilhash((1u << 31) | ((uint32_t)depth << 22) | (uint32_t)iter) ^ utilhash((uint32_t)index);
+    uint32_t x = mod_m31(h);
+    Rng r;
+    r.x = x == 0u ? 1u : x;
+    return r;
+}
+__device__ __forceinline__ Rng seedEngine(uint32_t h) {
+    uint32_t x = mod_m31(h);
+    Rng r;
+    r.x = x == 0u ? 1u : x;
+    return r;
+}
+// thrust::uniform_real_distribution<float>(0,1) (uniform_real_distribution.inl:71-79):
+// float(x - min) / (1.0f + float(max - min)) = float(x - 1) / 2^31 (both roundings give 2^31).
+__device__ __forceinline__ float u01(Rng &r) {
+    r.x = mod_m31((uint64_t)r.x * 48271ull);
+    return (float)(r.x - 1u) * 4.656612873077392578125e-10f;  // exact power-of-two scaling
+}
+
+// Build-defined sin/cos, identical to the CPU oracle's polynomial (the reference calls the
+// platform libm, src/interactions.h:40-41): Cody-Waite reduction by pi/2 + minimax polynomials.
+__device__ __forceinline__ void sincosPoly(float x, float &s, float &c) {
+    float kf = __builtin_rintf(x * 0.636619747f);
+    int k = (int)kf;
+    float r = x - kf * 1.5703125f;
+    r = r - kf * 4.837512969970703125e-4f;
+    r = r - kf * 7.54978995489188216e-8f;
+    float z = r * r;
+    float ps = -1.9515295891e-4f;
+    ps = ps * z + 8.3321608736e-3f;
+    ps = ps * z - 1.6666654611e-1f;
+    ps = ps * z;
+    ps = ps * r;
+    float sr = ps + r;
+    float pc = 2.443315711809948e-5f;
+    pc = pc * z - 1.388731625493765e-3f;
+    pc = pc * z + 4.166664568298827e-2f;
+    pc = pc * z;
+    pc = pc * z;
+    float cr = (pc - 0.5f * z) + 1.0f;
+    float s0 = (k & 1) ? cr : sr;
+    float c0 = (k & 1) ? sr : cr;
+    s = (k & 2) ? -s0 : s0;
+    c = ((k + 1) & 2) ? -c0 : c0;
+}
+
+// src/intersections.h:26-28 : origin + (t - .0001f) * normalize(direction)
+__device__ __forceinline__ F3 getPointOnRay(F3 origin, F3 direction, float t) {
+    return origin + normalize(direction) * (t - .0001f);
+}
+
+struct Hit {
+    float t;        // world-space distance, -1 on a miss
+    F3    p, n;     // written only on a hit (reference leaves its out-parameters untouched on a miss)
+    bool  outside;
+};
+
+// src/intersections.h:47-89
+__device__ __forceinline__ float boxIntersectionTest(const GeomDev &g, F3 ro, F3 rd, F3 &P, F3 &N, bool &outside) {
+    F3 qo = mulMV(g.inv, ro, 1.0f);
+    F3 qd = normalize(mulMV(g.inv, rd, 0.0f));
+    float tmin = -1e38f, tmax = 1e38f;
+    F3 tmin_n = f3(0, 0, 0), tmax_n = f3(0, 0, 0);
+    const float qoa[3] = {qo.x, qo.y, qo.z};
+    const float qda[3] = {qd.x, qd.y, qd.z};
+#pragma unroll
+    for (int xyz = 0; xyz < 3; ++xyz) {
+        float qdxyz = qda[xyz];
+        float t1 = (-0.5f - qoa[xyz]) / qdxyz;
+        float t2 = (+0.5f - qoa[xyz]) / qdxyz;
+        float ta = t1 < t2 ? t1 : t2;  // glm::min, func_common.inl:409-414
+        float tb = t1 > t2 ? t1 : t2;  // glm::max, func_common.inl:430-435
+        float nv = t2 < t1 ? +1.0f : -1.0f;
+        F3 n = f3(xyz == 0 ? nv : 0.0f, xyz == 1 ? nv : 0.0f, xyz == 2 ? nv : 0.0f);
+        if (ta > 0 && ta > tmin) {
+            tmin = ta;
+            tmin_n = n;
+        }
+        if (tb < tmax) {
+            tmax = tb;
+            tmax_n = n;
+        }
+    }
+    if (tmax >= tmin && tmax > 0) {
+        outside = true;
+        if (tmin <= 0) {
+            tmin = tmax;
+            tmin_n = tmax_n;
+            outside = false;
+        }
+        P = mulMV(g.xf, getPointOnRay(qo, qd, tmin), 1.0f);
+        N = normalize(mulMV(g.xf, tmin_n, 0.0f));
+        return length(ro - P);
+    }
+    return -1.0f;
+}
+
+// src/intersections.h:101-143 (pow(radius, 2) == 0.25f in the float overload nvcc selects)
+__device__ __forceinline__ float sphereIntersectionTest(const GeomDev &g, F3 ro_w, F3 rd_w, F3 &P, F3 &N,
+                                                        bool &outside) {
+    F3 ro = mulMV(g.inv, ro_w, 1.0f);
+    F3 rd = normalize(mulMV(g.inv, rd_w, 0.0f));
+    float vDotDirection = dot(ro, rd);
+    float radicand = vDotDirection * vDotDirection - (dot(ro, ro) - 0.25f);
+    if (radicand < 0) return -1.0f;
+    float squareRoot = __builtin_sqrtf(radicand);
+    float firstTerm = -vDotDirection;
+    float t1 = firstTerm + squareRoot;
+    float t2 = firstTerm - squareRoot;
+    float t;
+    if (t1 < 0 && t2 < 0) {
+        return -1.0f;
+    } else if (t1 > 0 && t2 > 0) {
+        t = t2 < t1 ? t2 : t1;  // min(t1, t2)
+        outside = true;
+    } else {
+        t = t1 < t2 ? t2 : t1;  // max(t1, t2)
+        outside = false;
+    }
+    F3 obj = getPointOnRay(ro, rd, t);
+    P = mulMV(g.xf, obj, 1.0f);
+    N = normalize(mulMV(g.invT, obj, 0.0f));
+    if (!outside) N = -N;
+    return length(ro_w - P);
+}
+
+// src/interactions.h:10-42
+__device__ __forceinline__ F3 calculateRandomDirectionInHemisphere(F3 normal, Rng &rng) {
+    float up = __builtin_sqrtf(u01(rng));
+    float over = __builtin_sqrtf(1 - up * up);
+    float around = u01(rng) * kTwoPi;
+    F3 notNormal;
+    if (__builtin_fabsf(normal.x) < kSqrtOneThird) {
+        notNormal = f3(1, 0, 0);
+    } else if (__builtin_fabsf(normal.y) < kSqrtOneThird) {
+        notNormal = f3(0, 1, 0);
+    } else {
+        notNormal = f3(0, 0, 1);
+    }
+    F3 p1 = normalize(cross(normal, notNormal));
+    F3 p2 = normalize(cross(normal, p1));
+    float s, c;
+    sincosPoly(around, s, c);
+    return (normal * up + p1 * (c * over)) + p2 * (s * over);
+}
+
+}  // namespace ptd

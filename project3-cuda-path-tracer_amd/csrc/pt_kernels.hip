@@ -1,0 +1,1072 @@
+// pt_kernels.hip -- MI355X (gfx950 / CDNA4) path-tracing hot path + its C ABI (include/pt_amd.h).
+//
+// One iteration = camera-ray generation, then `traceDepth` launches of ONE fused persistent kernel
+// per bounce: nearest-hit over LDS-staged geometry -> shade/scatter -> accumulate emitter hits ->
+// stable stream compaction of the survivors straight into the next bounce's SoA buffers
+// (wave64 ballot/mbcnt ranks, LDS wave totals, cross-workgroup prefix by decoupled look-back over
+// ticket-ordered tiles).  No host round trip inside an iteration: live counts stay on the device.
+//
+// Replaces the unsolved pipeline of reference src/pathtrace.cu:133-167 (spec: SURVEY.md 3.4 S0-S9).
+// HBM layout, kernels, rooflines: DESIGN.md.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/pt_amd.h"
+#include "pt_device.h"
+
+using namespace ptd;
+
+static_assert(sizeof(PtGeom) == 236 && sizeof(PtMaterial) == 44 && sizeof(PtCamera) == 52,
+              "layout must equal reference src/sceneStructs.h:18-47");
+
+namespace {
+
+constexpr int kBlock = 256;          // threads per workgroup = paths per tile (4 wave64)
+constexpr int kWaves = kBlock / 64;
+constexpr int kNumArrays = 11;       // SoA PathSegment: origin3, dir3, throughput3, pixelIndex, remainingBounces
+constexpr int kMaxDepthSlots = PT_MAX_DEPTH + 2;
+
+// ---- device control block ------------------------------------------------------------------------
+struct Ctrl {
+    // zeroed/re-armed by the ray-generation kernel every iteration
+    uint32_t n_live[kMaxDepthSlots];   // n_live[d] = paths entering bounce d
+    uint32_t ticket[kMaxDepthSlots];   // tile tickets of bounce d's launch
+    // never zeroed by an iteration
+    uint32_t error;                    // sticky device fault (look-back spin timeout)
+    uint32_t pad;
+    unsigned long long sum_live[kMaxDepthSlots];
+    unsigned long long light_hits, misses;
+};
+
+// Camera constants derived once on the host (spec S2)
+struct KParams {
+    float view[3], up[3], right[3], pos[3];
+    float pixLenX, pixLenY, halfW, halfH;
+    int   W, H;
+    int   shardRank, shardCount;
+    int   nLocal;       // pixels rendered by this shard
+    int   ngeoms, nmats;
+    int   traceDepth;
+};
+
+struct PathSoA {
+    float *a[9];        // ox oy oz dx dy dz cr cg cb
+    int   *pix;
+    int   *rem;
+};
+
+// tile descriptor granule: [63:32] status, [31:0] value
+constexpr uint32_t kStInvalid = 0, kStAggregate = 1, kStInclusive = 2;
+constexpr int kSpinLimit = 1 << 24;
+
+__device__ __forceinline__ void desc_store(unsigned long long *p, uint32_t status, uint32_t value) {
+    __hip_atomic_store(p, ((unsigned long long)status << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long desc_load(unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Cross-workgroup exclusive prefix of `block_total` for ticket-ordered tile `tile` (decoupled
+// look-back, one wave, 64 predecessors per probe).  Called by all 64 lanes of wave 0.  Tiles are
+// handed out by an atomic ticket, so every predecessor is owned by a workgroup that is already
+// running: no residency assumption.  The value IS the flag (one 8-byte agent-scope granule), so no
+// fence is needed.  Spins are bounded; a timeout sets ctrl->error.
+__device__ __forceinline__ uint32_t lookback_exclusive(unsigned long long *desc, int tile, uint32_t block_total,
+                                                       uint32_t *error_word) {
+    const int lane = threadIdx.x & 63;
+    if (tile == 0) {
+        if (lane == 0) desc_store(&desc[0], kStInclusive, block_total);
+        return 0u;
+    }
+    if (lane == 0) desc_store(&desc[tile], kStAggregate, block_total);
+    uint32_t excl = 0;
+    int base = tile - 1;
+    for (;;) {
+        const int j = base - lane;
+        unsigned long long d = ((unsigned long long)kStInclusive << 32);  // virtual tile < 0: inclusive 0
+        int spins = 0;
+        for (;;) {
+            if (j >= 0) d = desc_load(&desc[j]);
+            if (__all((uint32_t)(d >> 32) != kStInvalid)) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > kSpinLimit) {
+                if (lane == 0) atomicExch(error_word, 1u);
+                return excl;
+            }
+        }
+        const unsigned long long incl = __ballot((uint32_t)(d >> 32) == kStInclusive);
+        const int first = incl ? (__ffsll((long long)incl) - 1) : 63;
+        excl += wave_sum(lane <= first ? (uint32_t)d : 0u);
+        if (incl) break;
+        base -= 64;
+    }
+    if (lane == 0) desc_store(&desc[tile], kStInclusive, excl + block_total);
+    return excl;
+}
+
+// Workgroup-level stable compaction rank of a 0/1 flag: ballot + mbcnt inside each wave, wave
+// totals through LDS, cross-tile base from the look-back.  Returns the destination slot of this
+// thread (valid when flag) and the tile's inclusive end in *tile_end (valid in every thread).
+__device__ __forceinline__ uint32_t compact_slot(bool flag, int tile, unsigned long long *desc, uint32_t *s_wave,
+                                                 uint32_t *s_excl, uint32_t *error_word, uint32_t *tile_end) {
+    const int wave = threadIdx.x >> 6;
+    const unsigned long long ballot = __ballot(flag);
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32),
+                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, 0u));
+    if ((threadIdx.x & 63) == 0) s_wave[wave] = (uint32_t)__popcll(ballot);
+    __syncthreads();
+    uint32_t wave_off = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) {
+        uint32_t c = s_wave[w];
+        wave_off += w < wave ? c : 0u;
+        total += c;
+    }
+    if (wave == 0) {
+        uint32_t e = lookback_exclusive(desc, tile, total, error_word);
+        if (threadIdx.x == 0) *s_excl = e;
+    }
+    __syncthreads();
+    const uint32_t excl = *s_excl;
+    *tile_end = excl + total;
+    return excl + wave_off + rank;
+}
+
+// ---- camera rays (spec S2) + per-iteration re-arm of the control block ----------------------------
+__global__ __launch_bounds__(kBlock) void k_generate_rays(KParams prm, int iter, PathSoA out, Ctrl *ctrl,
+                                                          unsigned long long *desc, int ndesc) {
+    const int gtid = blockIdx.x * kBlock + threadIdx.x;
+    const int gsize = gridDim.x * kBlock;
+    for (int i = gtid; i < ndesc; i += gsize) desc[i] = 0ull;
+    if (gtid < kMaxDepthSlots) {
+        ctrl->n_live[gtid] = gtid == 1 ? (uint32_t)prm.nLocal : 0u;
+        ctrl->ticket[gtid] = 0u;
+    }
+    const F3 view = f3(prm.view[0], prm.view[1], prm.view[2]);
+    const F3 up = f3(prm.up[0], prm.up[1], prm.up[2]);
+    const F3 right = f3(prm.right[0], prm.right[1], prm.right[2]);
+    for (int j = gtid; j < prm.nLocal; j += gsize) {
+        const int lr = j / prm.W;
+        const int x = j - lr * prm.W;
+        const int y = lr * prm.shardCount + prm.shardRank;
+        const int index = x + y * prm.W;
+        Rng rng = makeSeededRandomEngine(iter, index, 0);
+        const float jx = u01(rng);
+        const float jy = u01(rng);
+        const float sx = ((float)x + jx) - prm.halfW;
+        const float sy = ((float)y + jy) - prm.halfH;
+        const float a = prm.pixLenX * sx;
+        const float b = prm.pixLenY * sy;
+        const F3 dir = normalize((view - right * a) - up * b);
+        out.a[0][j] = prm.pos[0]; out.a[1][j] = prm.pos[1]; out.a[2][j] = prm.pos[2];
+        out.a[3][j] = dir.x; out.a[4][j] = dir.y; out.a[5][j] = dir.z;
+        out.a[6][j] = 1.0f; out.a[7][j] = 1.0f; out.a[8][j] = 1.0f;
+        out.pix[j] = index;
+        out.rem[j] = prm.traceDepth;
+    }
+}
+
+// ---- one bounce: intersect + shade + accumulate + compact (spec S3-S8) -----------------------------
+// Persistent workgroups pull 256-path tiles by ticket until the bounce's queue is drained.
+__global__ __launch_bounds__(kBlock) void k_bounce(KParams prm, int iter, int depth, int lastBounce,
+                                                   PathSoA in, PathSoA out, Ctrl *ctrl, unsigned long long *desc,
+                                                   const GeomDev *__restrict__ ggeoms,
+                                                   const MaterialDev *__restrict__ gmats, float *image) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    GeomDev *sgeoms = reinterpret_cast<GeomDev *>(smem);
+    MaterialDev *smats = reinterpret_cast<MaterialDev *>(smem + sizeof(GeomDev) * prm.ngeoms);
+    uint32_t *s_misc = reinterpret_cast<uint32_t *>(smem + sizeof(GeomDev) * prm.ngeoms + sizeof(MaterialDev) * prm.nmats);
+    uint32_t *s_wave = s_misc;          // [kWaves]
+    uint32_t *s_excl = s_misc + kWaves; // [1]
+    uint32_t *s_tile = s_misc + kWaves + 1;
+
+    // stage the scene in LDS once per (persistent) workgroup, 16 B per lane per step
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(ggeoms);
+        float4 *dst = reinterpret_cast<float4 *>(sgeoms);
+        const int n16 = prm.ngeoms * (int)(sizeof(GeomDev) / 16);
+        for (int i = threadIdx.x; i < n16; i += kBlock) dst[i] = src[i];
+        const float4 *msrc = reinterpret_cast<const float4 *>(gmats);
+        float4 *mdst = reinterpret_cast<float4 *>(smats);
+        const int m16 = prm.nmats * (int)(sizeof(MaterialDev) / 16);
+        for (int i = threadIdx.x; i < m16; i += kBlock) mdst[i] = msrc[i];
+    }
+    const uint32_t nLive = ctrl->n_live[depth];
+    const int numTiles = (int)((nLive + kBlock - 1) / kBlock);
+
+    for (;;) {
+        if (threadIdx.x == 0) *s_tile = atomicAdd(&ctrl->ticket[depth], 1u);
+        __syncthreads();
+        const int tile = (int)*s_tile;
+        if (tile >= numTiles) break;
+        if (tile == 0 && threadIdx.x == 0) atomicAdd(&ctrl->sum_live[depth], (unsigned long long)nLive);
+
+        const uint32_t idx = (uint32_t)tile * kBlock + threadIdx.x;
+        const bool valid = idx < nLive;
+        bool alive = false;
+        bool lightHit = false, missed = false;
+        F3 org = f3(0, 0, 0), dir = f3(0, 0, 1), col = f3(0, 0, 0);
+        int pix = 0, rem = 0;
+        if (valid) {
+            org = f3(in.a[0][idx], in.a[1][idx], in.a[2][idx]);
+            dir = f3(in.a[3][idx], in.a[4][idx], in.a[5][idx]);
+            col = f3(in.a[6][idx], in.a[7][idx], in.a[8][idx]);
+            pix = in.pix[idx];
+            rem = in.rem[idx];
+
+            // nearest hit, geoms in file order, strict '<' so the first geom wins ties (S3)
+            float tbest = 0.0f;
+            int hit = -1;
+            F3 P = f3(0, 0, 0), N = f3(0, 0, 0);
+            bool outside = false;
+            for (int g = 0; g < prm.ngeoms; ++g) {
+                const GeomDev &G = sgeoms[g];
+                const int type = __builtin_amdgcn_readfirstlane(G.type);
+                F3 p, n;
+                bool o = false;
+                float t;
+                if (type == 0) t = sphereIntersectionTest(G, org, dir, p, n, o);
+                else           t = boxIntersectionTest(G, org, dir, p, n, o);
+                if (t > 0.0f && (hit < 0 || t < tbest)) {
+                    tbest = t; hit = g; P = p; N = n; outside = o;
+                }
+            }
+            if (hit < 0) {
+                missed = true;                                   // S4: background is black
+            } else {
+                const MaterialDev &M = smats[sgeoms[hit].material];
+                const F3 mcol = f3(M.color[0], M.color[1], M.color[2]);
+                if (M.emittance > 0.0f) {                        // S5: emitter ends the path
+                    lightHit = true;
+                    if (image) {
+                        const F3 c = (col * mcol) * M.emittance;
+                        float *px = image + 3 * (size_t)pix;     // one path per pixel: race-free
+                        px[0] += c.x; px[1] += c.y; px[2] += c.z;
+                    }
+                } else if (!lastBounce) {                        // S6 scatter (S7: skipped on the last bounce)
+                    Rng rng = makeSeededRandomEngine(iter, pix, depth);
+                    const F3 scol = f3(M.specColor[0], M.specColor[1], M.specColor[2]);
+                    F3 ndir, norg;
+                    if (M.hasRefractive > 0.0f) {
+                        const float ior = M.ior;
+                        const float eta = outside ? 1.0f / ior : ior;
+                        const float c = dot(N, dir);
+                        const float k = 1.0f - eta * eta * (1.0f - c * c);
+                        const float u = u01(rng);
+                        bool doReflect = true;
+                        if (k >= 0.0f) {
+                            float r0 = (1.0f - ior) / (1.0f + ior);
+                            r0 = r0 * r0;
+                            const float cosx = outside ? -c : __builtin_sqrtf(k);
+                            const float w = 1.0f - cosx;
+                            const float w2 = w * w;
+                            const float w5 = w2 * w2 * w;
+                            const float fres = r0 + (1.0f - r0) * w5;
+                            doReflect = u < fres;
+                        }
+                        if (doReflect) {
+                            ndir = reflect(dir, N);
+                            norg = P + N * 0.001f;
+                            col = col * scol;
+                        } else {
+                            ndir = refract(dir, N, eta);
+                            norg = P - N * 0.001f;
+                            col = col * mcol;
+                        }
+                    } else if (M.hasReflective > 0.0f) {
+                        const float u = u01(rng);
+                        if (u < 0.5f) {
+                            ndir = reflect(dir, N);
+                            col = col * scol;
+                        } else {
+                            ndir = calculateRandomDirectionInHemisphere(N, rng);
+                            col = col * mcol;
+                        }
+                        norg = P + N * 0.001f;
+                    } else {
+                        ndir = calculateRandomDirectionInHemisphere(N, rng);
+                        col = col * mcol;
+                        norg = P + N * 0.001f;
+                    }
+                    org = norg;
+                    dir = ndir;
+                    alive = true;
+                }
+            }
+        }
+
+        // statistics: one atomic per wave
+        {
+            const unsigned long long bl = __ballot(lightHit), bm = __ballot(missed);
+            if ((threadIdx.x & 63) == 0) {
+                if (bl) atomicAdd(&ctrl->light_hits, (unsigned long long)__popcll(bl));
+                if (bm) atomicAdd(&ctrl->misses, (unsigned long long)__popcll(bm));
+            }
+        }
+
+        if (!lastBounce) {                                       // S8: stable compaction into `out`
+            uint32_t tileEnd;
+            const uint32_t slot = compact_slot(alive, tile, desc, s_wave, s_excl, &ctrl->error, &tileEnd);
+            if (alive) {
+                out.a[0][slot] = org.x; out.a[1][slot] = org.y; out.a[2][slot] = org.z;
+                out.a[3][slot] = dir.x; out.a[4][slot] = dir.y; out.a[5][slot] = dir.z;
+                out.a[6][slot] = col.x; out.a[7][slot] = col.y; out.a[8][slot] = col.z;
+                out.pix[slot] = pix;
+                out.rem[slot] = rem - 1;
+            }
+            if (tile == numTiles - 1 && threadIdx.x == 0) ctrl->n_live[depth + 1] = tileEnd;
+        } else {
+            __syncthreads();  // keep s_tile stable until every thread has read it
+        }
+    }
+}
+
+// ---- sendImageToPBO (reference src/pathtrace.cu:48-68) ---------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_to_rgba8(const float *image, int npix, int iter, uchar4 *pbo) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= npix) return;
+    const float *p = image + 3 * (size_t)i;
+    int r = (int)(p[0] / iter * 255.0);
+    int g = (int)(p[1] / iter * 255.0);
+    int b = (int)(p[2] / iter * 255.0);
+    r = r < 0 ? 0 : (r > 255 ? 255 : r);   // glm::clamp = min(max(x, lo), hi), func_common.inl:451-456
+    g = g < 0 ? 0 : (g > 255 ? 255 : g);
+    b = b < 0 ? 0 : (b > 255 ? 255 : b);
+    uchar4 o;
+    o.w = 0; o.x = (unsigned char)r; o.y = (unsigned char)g; o.z = (unsigned char)b;
+    pbo[i] = o;
+}
+
+// ---- stream-compaction library kernels ---------------------------------------------------------------
+struct ScanCtrl {
+    uint32_t ticket;
+    uint32_t error;
+};
+constexpr int kScanItems = 4;                 // int4 per thread
+constexpr int kScanTile = kBlock * kScanItems;
+
+__global__ __launch_bounds__(kBlock) void k_scan_exclusive(const int32_t *__restrict__ in, int32_t *__restrict__ out,
+                                                           long long n, ScanCtrl *sc, unsigned long long *desc) {
+    __shared__ uint32_t s_wave[kWaves];
+    __shared__ uint32_t s_excl, s_tile;
+    const long long numTiles = (n + kScanTile - 1) / kScanTile;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (;;) {
+        if (threadIdx.x == 0) s_tile = atomicAdd(&sc->ticket, 1u);
+        __syncthreads();
+        const long long tile = s_tile;
+        if (tile >= numTiles) break;
+        const long long base = tile * kScanTile + (long long)threadIdx.x * kScanItems;
+        int32_t v[kScanItems];
+        if (base + kScanItems <= n && ((reinterpret_cast<uintptr_t>(in + base) & 15) == 0)) {
+            const int4 q = *reinterpret_cast<const int4 *>(in + base);
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < kScanItems; ++k) v[k] = base + k < n ? in[base + k] : 0;
+        }
+        const uint32_t tsum = (uint32_t)v[0] + (uint32_t)v[1] + (uint32_t)v[2] + (uint32_t)v[3];
+        // wave-level inclusive scan of the per-thread sums
+        uint32_t inc = tsum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t up = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += up;
+        }
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        uint32_t wave_off = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) {
+            uint32_t c = s_wave[w];
+            wave_off += w < wave ? c : 0u;
+            total += c;
+        }
+        if (wave == 0) {
+            uint32_t e = lookback_exclusive(desc, (int)tile, total, &sc->error);
+            if (threadIdx.x == 0) s_excl = e;
+        }
+        __syncthreads();
+        uint32_t run = s_excl + wave_off + (inc - tsum);
+        int32_t o4[kScanItems];
+#pragma unroll
+        for (int k = 0; k < kScanItems; ++k) {
+            o4[k] = (int32_t)run;
+            run += (uint32_t)v[k];
+        }
+        if (base + kScanItems <= n && ((reinterpret_cast<uintptr_t>(out + base) & 15) == 0)) {
+            *reinterpret_cast<int4 *>(out + base) = make_int4(o4[0], o4[1], o4[2], o4[3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < kScanItems; ++k)
+                if (base + k < n) out[base + k] = o4[k];
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_compact_nonzero(const int32_t *__restrict__ in, int32_t *__restrict__ out,
+                                                            long long n, ScanCtrl *sc, unsigned long long *desc,
+                                                            long long *count_out) {
+    __shared__ uint32_t s_wave[kWaves];
+    __shared__ uint32_t s_excl, s_tile;
+    const long long numTiles = (n + kBlock - 1) / kBlock;
+    if (n == 0 && blockIdx.x == 0 && threadIdx.x == 0) *count_out = 0;
+    for (;;) {
+        if (threadIdx.x == 0) s_tile = atomicAdd(&sc->ticket, 1u);
+        __syncthreads();
+        const long long tile = s_tile;
+        if (tile >= numTiles) break;
+        const long long i = tile * kBlock + threadIdx.x;
+        const int32_t v = i < n ? in[i] : 0;
+        uint32_t tileEnd;
+        const uint32_t slot = compact_slot(v != 0, (int)tile, desc, s_wave, &s_excl, &sc->error, &tileEnd);
+        if (v != 0) out[slot] = v;
+        if (tile == numTiles - 1 && threadIdx.x == 0) *count_out = (long long)tileEnd;
+    }
+}
+
+// ---- primitive test kernels (device functions exactly as the render kernels use them) -------------------
+__global__ void k_test_utilhash(const uint32_t *in, uint32_t *out, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = utilhash(in[i]);
+}
+__global__ void k_test_rng(const uint32_t *seeds, int nseeds, int ndraws, float *out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nseeds) return;
+    Rng r = seedEngine(seeds[i]);
+    for (int k = 0; k < ndraws; ++k) out[(size_t)i * ndraws + k] = u01(r);
+}
+__global__ void k_test_intersect(const GeomDev *geoms, const int *gidx, const float *rays, int n, float *t, float *p3,
+                                 float *n3, int *outside) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const GeomDev G = geoms[gidx[i]];
+    F3 ro = f3(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]);
+    F3 rd = f3(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
+    F3 P = f3(p3[3 * i], p3[3 * i + 1], p3[3 * i + 2]);
+    F3 N = f3(n3[3 * i], n3[3 * i + 1], n3[3 * i + 2]);
+    bool o = outside[i] != 0;
+    t[i] = G.type == 0 ? sphereIntersectionTest(G, ro, rd, P, N, o) : boxIntersectionTest(G, ro, rd, P, N, o);
+    p3[3 * i] = P.x; p3[3 * i + 1] = P.y; p3[3 * i + 2] = P.z;
+    n3[3 * i] = N.x; n3[3 * i + 1] = N.y; n3[3 * i + 2] = N.z;
+    outside[i] = o ? 1 : 0;
+}
+__global__ void k_test_hemisphere(const float *nrm, const int *iid, int n, float *out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Rng r = makeSeededRandomEngine(iid[3 * i], iid[3 * i + 1], iid[3 * i + 2]);
+    F3 d = calculateRandomDirectionInHemisphere(f3(nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2]), r);
+    out[3 * i] = d.x; out[3 * i + 1] = d.y; out[3 * i + 2] = d.z;
+}
+__global__ void k_test_sincos(const float *x, int n, float *s, float *c) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) sincosPoly(x[i], s[i], c[i]);
+}
+__global__ void k_test_reflect_refract(const float *I, const float *N, const float *eta, int n, float *rl, float *rr) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    F3 a = f3(I[3 * i], I[3 * i + 1], I[3 * i + 2]), b = f3(N[3 * i], N[3 * i + 1], N[3 * i + 2]);
+    F3 r1 = reflect(a, b), r2 = refract(a, b, eta[i]);
+    rl[3 * i] = r1.x; rl[3 * i + 1] = r1.y; rl[3 * i + 2] = r1.z;
+    rr[3 * i] = r2.x; rr[3 * i + 1] = r2.y; rr[3 * i + 2] = r2.z;
+}
+
+// =====================================================================================================
+// host side
+// =====================================================================================================
+std::string g_err = "";
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHECK(expr)                                                                              \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            return fail(PT_ERR_HIP, "HIP error (%s:%d): %s: %s", "pt_kernels.hip", __LINE__, #expr, \
+                        hipGetErrorString(e_));                                                     \
+    } while (0)
+
+struct State {
+    bool init = false;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    PtCamera cam;
+    KParams prm;
+    int P = 0;              // W*H
+    int nLocal = 0;
+    int flags = 0;
+    float *image = nullptr;
+    bool ownImage = false;
+    float *pathbuf[2] = {nullptr, nullptr};
+    GeomDev *dgeoms = nullptr;
+    MaterialDev *dmats = nullptr;
+    Ctrl *ctrl = nullptr;
+    unsigned long long *desc = nullptr;
+    int numTilesMax = 0;
+    int grid = 0;
+    size_t ldsBytes = 0;
+    long long iterations = 0;
+    // kernel timing
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> evBounce, evRaygen;
+    double msBounce = 0, msRaygen = 0;
+    long long nBounce = 0, nRaygen = 0;
+} S;
+
+int count_devices() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+PathSoA soa(float *base, int cap) {
+    PathSoA s;
+    for (int i = 0; i < 9; ++i) s.a[i] = base + (size_t)i * cap;
+    s.pix = reinterpret_cast<int *>(base + (size_t)9 * cap);
+    s.rem = reinterpret_cast<int *>(base + (size_t)10 * cap);
+    return s;
+}
+
+void pack_geom(const PtGeom &g, GeomDev &d) {
+    memset(&d, 0, sizeof d);
+    for (int c = 0; c < 4; ++c)
+        for (int r = 0; r < 3; ++r) {
+            d.inv[c * 3 + r] = g.inverseTransform[c * 4 + r];
+            d.xf[c * 3 + r] = g.transform[c * 4 + r];
+            d.invT[c * 3 + r] = g.invTranspose[c * 4 + r];
+        }
+    d.type = g.type;
+    d.material = g.materialid;
+}
+void pack_material(const PtMaterial &m, MaterialDev &d) {
+    memset(&d, 0, sizeof d);
+    d.color[0] = m.color.x; d.color[1] = m.color.y; d.color[2] = m.color.z;
+    d.specColor[0] = m.specularColor.x; d.specColor[1] = m.specularColor.y; d.specColor[2] = m.specularColor.z;
+    d.hasReflective = m.hasReflective;
+    d.hasRefractive = m.hasRefractive;
+    d.ior = m.indexOfRefraction;
+    d.emittance = m.emittance;
+}
+
+// host mirrors of the glm ops used for the camera basis (same op order as ptd::)
+struct H3 { float x, y, z; };
+H3 hcross(H3 x, H3 y) { return H3{x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y}; }
+H3 hnormalize(H3 a) {
+    float d = a.x * a.x + a.y * a.y + a.z * a.z;
+    float s = 1.0f / std::sqrt(d);
+    return H3{a.x * s, a.y * s, a.z * s};
+}
+
+int resolve_events(std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, double &ms, long long &n) {
+    for (auto &pr : v) {
+        float t = 0;
+        HIPCHECK(hipEventSynchronize(pr.second));
+        HIPCHECK(hipEventElapsedTime(&t, pr.first, pr.second));
+        ms += t;
+        n += 1;
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
+    v.clear();
+    return PT_OK;
+}
+
+int launch_raygen(int iter) {
+    const PathSoA out = soa(S.pathbuf[0], S.nLocal);
+    const int ndesc = S.numTilesMax * (S.prm.traceDepth + 1);
+    int blocks = (S.nLocal + kBlock - 1) / kBlock;
+    if (blocks < 1) blocks = 1;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (S.flags & PT_FLAG_KERNEL_TIMING) {
+        HIPCHECK(hipEventCreate(&e0));
+        HIPCHECK(hipEventCreate(&e1));
+        HIPCHECK(hipEventRecord(e0, S.stream));
+    }
+    hipLaunchKernelGGL(k_generate_rays, dim3(blocks), dim3(kBlock), 0, S.stream, S.prm, iter, out, S.ctrl, S.desc, ndesc);
+    if (e0) {
+        HIPCHECK(hipEventRecord(e1, S.stream));
+        S.evRaygen.emplace_back(e0, e1);
+    }
+    HIPCHECK(hipGetLastError());
+    return PT_OK;
+}
+
+int launch_bounce(int iter, int depth, bool lastBounce, float *image) {
+    const PathSoA in = soa(S.pathbuf[(depth - 1) & 1], S.nLocal);
+    const PathSoA out = soa(S.pathbuf[depth & 1], S.nLocal);
+    unsigned long long *desc = S.desc + (size_t)depth * S.numTilesMax;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (S.flags & PT_FLAG_KERNEL_TIMING) {
+        HIPCHECK(hipEventCreate(&e0));
+        HIPCHECK(hipEventCreate(&e1));
+        HIPCHECK(hipEventRecord(e0, S.stream));
+    }
+    hipLaunchKernelGGL(k_bounce, dim3(S.grid), dim3(kBlock), S.ldsBytes, S.stream, S.prm, iter, depth,
+                       lastBounce ? 1 : 0, in, out, S.ctrl, desc, S.dgeoms, S.dmats, image);
+    if (e0) {
+        HIPCHECK(hipEventRecord(e1, S.stream));
+        S.evBounce.emplace_back(e0, e1);
+        if (S.evBounce.size() > 8192) {
+            int rc = resolve_events(S.evBounce, S.msBounce, S.nBounce);
+            if (rc) return rc;
+            rc = resolve_events(S.evRaygen, S.msRaygen, S.nRaygen);
+            if (rc) return rc;
+        }
+    }
+    HIPCHECK(hipGetLastError());
+    return PT_OK;
+}
+
+int check_device_fault() {
+    uint32_t err = 0;
+    HIPCHECK(hipMemcpyAsync(&err, &S.ctrl->error, sizeof err, hipMemcpyDeviceToHost, S.stream));
+    HIPCHECK(hipStreamSynchronize(S.stream));
+    if (err) return fail(PT_ERR_DEVICE, "device fault: compaction look-back timed out");
+    return PT_OK;
+}
+
+// scan library workspace
+struct ScanWs {
+    ScanCtrl *ctrl = nullptr;
+    unsigned long long *desc = nullptr;
+    long long tiles = 0;
+} W;
+
+int scan_ws(long long tiles) {
+    if (!W.ctrl) HIPCHECK(hipMalloc(&W.ctrl, sizeof(ScanCtrl)));
+    if (tiles > W.tiles) {
+        if (W.desc) HIPCHECK(hipFree(W.desc));
+        W.desc = nullptr;
+        long long cap = tiles < 1024 ? 1024 : tiles;
+        HIPCHECK(hipMalloc(&W.desc, (size_t)cap * 8));
+        W.tiles = cap;
+    }
+    return PT_OK;
+}
+
+int persistent_grid(const void *kernel, size_t lds, int *grid) {
+    int dev = 0;
+    HIPCHECK(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    HIPCHECK(hipGetDeviceProperties(&prop, dev));
+    int perCU = 0;
+    HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kernel, kBlock, lds));
+    if (perCU < 1) perCU = 1;
+    if (perCU > 8) perCU = 8;
+    *grid = prop.multiProcessorCount * perCU;
+    return PT_OK;
+}
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t n) {
+        HIPCHECK(hipMalloc(&p, (n ? n : 1) * sizeof(T)));
+        return PT_OK;
+    }
+};
+
+}  // namespace
+
+// =====================================================================================================
+// C ABI
+// =====================================================================================================
+extern "C" {
+
+const char *pt_last_error(void) { return g_err.c_str(); }
+int pt_device_count(void) { return count_devices(); }
+
+void pt_free(void) {
+    // pathtraceFree before the first Init (src/main.cpp:91-94) must be a no-op
+    if (!S.init && !S.pathbuf[0] && !S.image && !S.dgeoms && !S.ctrl) return;
+    (void)hipStreamSynchronize(S.stream);
+    for (auto *v : {&S.evBounce, &S.evRaygen}) {
+        for (auto &pr : *v) {
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+        v->clear();
+    }
+    if (S.ownImage && S.image) (void)hipFree(S.image);
+    for (int i = 0; i < 2; ++i)
+        if (S.pathbuf[i]) (void)hipFree(S.pathbuf[i]);
+    if (S.dgeoms) (void)hipFree(S.dgeoms);
+    if (S.dmats) (void)hipFree(S.dmats);
+    if (S.ctrl) (void)hipFree(S.ctrl);
+    if (S.desc) (void)hipFree(S.desc);
+    S = State();
+}
+
+int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMaterial *mats, int nmats, int traceDepth,
+            const PtOptions *opts) {
+    if (!cam || ngeoms < 0 || nmats < 0 || (ngeoms && !geoms) || (nmats && !mats))
+        return fail(PT_ERR_INVALID, "pt_init: null argument");
+    if (cam->resolution[0] <= 0 || cam->resolution[1] <= 0) return fail(PT_ERR_INVALID, "pt_init: bad resolution");
+    if (traceDepth < 1 || traceDepth > PT_MAX_DEPTH) return fail(PT_ERR_INVALID, "pt_init: traceDepth must be 1..%d", PT_MAX_DEPTH);
+    if ((long long)cam->resolution[0] * cam->resolution[1] > (1ll << 30)) return fail(PT_ERR_INVALID, "pt_init: frame too large");
+    for (int i = 0; i < ngeoms; ++i) {
+        if (geoms[i].type != PT_SPHERE && geoms[i].type != PT_CUBE) return fail(PT_ERR_INVALID, "pt_init: geom %d has unknown type", i);
+        if (geoms[i].materialid < 0 || geoms[i].materialid >= nmats) return fail(PT_ERR_INVALID, "pt_init: geom %d references material %d", i, geoms[i].materialid);
+    }
+    if (count_devices() < 1) return fail(PT_ERR_NO_GPU, "pt_init: no HIP device (this library has no CPU fallback)");
+    pt_free();
+
+    PtOptions o;
+    memset(&o, 0, sizeof o);
+    o.shard_count = 1;
+    o.device = -1;
+    if (opts) o = *opts;
+    if (o.shard_count < 1 || o.shard_rank < 0 || o.shard_rank >= o.shard_count) return fail(PT_ERR_INVALID, "pt_init: bad shard %d/%d", o.shard_rank, o.shard_count);
+    if (o.device >= 0) HIPCHECK(hipSetDevice(o.device));
+    HIPCHECK(hipGetDevice(&S.device));
+    S.stream = (hipStream_t)o.stream;
+    S.flags = o.flags;
+    S.cam = *cam;
+
+    const int Wd = cam->resolution[0], H = cam->resolution[1];
+    S.P = Wd * H;
+    const int rows = H > o.shard_rank ? (H - o.shard_rank + o.shard_count - 1) / o.shard_count : 0;
+    S.nLocal = rows * Wd;
+
+    KParams &k = S.prm;
+    memset(&k, 0, sizeof k);
+    const H3 view{cam->view.x, cam->view.y, cam->view.z}, up{cam->up.x, cam->up.y, cam->up.z};
+    const H3 right = hnormalize(hcross(view, up));
+    k.view[0] = view.x; k.view[1] = view.y; k.view[2] = view.z;
+    k.up[0] = up.x; k.up[1] = up.y; k.up[2] = up.z;
+    k.right[0] = right.x; k.right[1] = right.y; k.right[2] = right.z;
+    k.pos[0] = cam->position.x; k.pos[1] = cam->position.y; k.pos[2] = cam->position.z;
+    const float kPI = 3.1415926535897932384626422832795028841971f;   // src/utilities.h:12
+    const float ys = std::tan(cam->fov[1] * (kPI / 180));            // src/scene.cpp:133 convention
+    const float xs = (ys * Wd) / H;
+    k.pixLenX = (2.0f * xs) / (float)Wd;
+    k.pixLenY = (2.0f * ys) / (float)H;
+    k.halfW = (float)Wd * 0.5f;
+    k.halfH = (float)H * 0.5f;
+    k.W = Wd; k.H = H;
+    k.shardRank = o.shard_rank; k.shardCount = o.shard_count;
+    k.nLocal = S.nLocal;
+    k.ngeoms = ngeoms; k.nmats = nmats;
+    k.traceDepth = traceDepth;
+
+    if (o.accum_dev) {
+        S.image = o.accum_dev;
+        S.ownImage = false;
+    } else {
+        HIPCHECK(hipMalloc(&S.image, (size_t)S.P * 3 * sizeof(float)));
+        S.ownImage = true;
+        HIPCHECK(hipMemsetAsync(S.image, 0, (size_t)S.P * 3 * sizeof(float), S.stream));
+    }
+    const size_t cap = S.nLocal > 0 ? S.nLocal : 1;
+    for (int i = 0; i < 2; ++i) HIPCHECK(hipMalloc(&S.pathbuf[i], cap * kNumArrays * sizeof(float)));
+
+    std::vector<GeomDev> hg(ngeoms ? ngeoms : 1);
+    std::vector<MaterialDev> hm(nmats ? nmats : 1);
+    for (int i = 0; i < ngeoms; ++i) pack_geom(geoms[i], hg[i]);
+    for (int i = 0; i < nmats; ++i) pack_material(mats[i], hm[i]);
+    HIPCHECK(hipMalloc(&S.dgeoms, hg.size() * sizeof(GeomDev)));
+    HIPCHECK(hipMalloc(&S.dmats, hm.size() * sizeof(MaterialDev)));
+    HIPCHECK(hipMemcpy(S.dgeoms, hg.data(), hg.size() * sizeof(GeomDev), hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(S.dmats, hm.data(), hm.size() * sizeof(MaterialDev), hipMemcpyHostToDevice));
+
+    S.numTilesMax = (int)((cap + kBlock - 1) / kBlock);
+    HIPCHECK(hipMalloc(&S.ctrl, sizeof(Ctrl)));
+    HIPCHECK(hipMemset(S.ctrl, 0, sizeof(Ctrl)));
+    HIPCHECK(hipMalloc(&S.desc, (size_t)S.numTilesMax * (traceDepth + 2) * 8));
+    HIPCHECK(hipMemset(S.desc, 0, (size_t)S.numTilesMax * (traceDepth + 2) * 8));
+
+    S.ldsBytes = sizeof(GeomDev) * ngeoms + sizeof(MaterialDev) * nmats + 16 * sizeof(uint32_t);
+    if (S.ldsBytes > 160 * 1024) return fail(PT_ERR_INVALID, "pt_init: scene does not fit the 160 KiB LDS (%zu B)", S.ldsBytes);
+    if (S.ldsBytes > 64 * 1024)
+        HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bounce), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.ldsBytes));
+    int rc = persistent_grid(reinterpret_cast<const void *>(k_bounce), S.ldsBytes, &S.grid);
+    if (rc) return rc;
+    if (S.grid > S.numTilesMax) S.grid = S.numTilesMax;
+    if (S.grid < 1) S.grid = 1;
+    HIPCHECK(hipStreamSynchronize(S.stream));
+    S.init = true;
+    g_err.clear();
+    return PT_OK;
+}
+
+int pt_iterate(int frame, int iter, void *rgba8_dev) {
+    (void)frame;  // always 0 in the reference (src/main.cpp:102)
+    if (!S.init) return fail(PT_ERR_NOT_INIT, "pt_iterate before pt_init");
+    if (iter < 1 || iter >= (1 << 22)) return fail(PT_ERR_INVALID, "pt_iterate: iter must be 1..4194303 (seed bits, pathtrace.cu:43)");
+    int rc = launch_raygen(iter);
+    if (rc) return rc;
+    const int D = S.prm.traceDepth;
+    for (int d = 1; d <= D; ++d) {
+        rc = launch_bounce(iter, d, d == D, S.image);
+        if (rc) return rc;
+    }
+    if (rgba8_dev) {
+        hipLaunchKernelGGL(k_to_rgba8, dim3((S.P + kBlock - 1) / kBlock), dim3(kBlock), 0, S.stream, S.image, S.P, iter,
+                           reinterpret_cast<uchar4 *>(rgba8_dev));
+        HIPCHECK(hipGetLastError());
+    }
+    S.iterations += 1;
+    return PT_OK;
+}
+
+int pt_sync(void) {
+    if (!S.init) return fail(PT_ERR_NOT_INIT, "pt_sync before pt_init");
+    HIPCHECK(hipStreamSynchronize(S.stream));
+    return check_device_fault();
+}
+
+int pt_readback(float *rgb_sum_host) {
+    if (!S.init) return fail(PT_ERR_NOT_INIT, "pt_readback before pt_init");
+    if (!rgb_sum_host) return fail(PT_ERR_INVALID, "pt_readback: null");
+    HIPCHECK(hipMemcpyAsync(rgb_sum_host, S.image, (size_t)S.P * 3 * sizeof(float), hipMemcpyDeviceToHost, S.stream));
+    HIPCHECK(hipStreamSynchronize(S.stream));
+    return check_device_fault();
+}
+
+int pt_readback_rgba8(int iter, uint8_t *rgba_host) {
+    if (!S.init) return fail(PT_ERR_NOT_INIT, "pt_readback_rgba8 before pt_init");
+    if (!rgba_host || iter < 1) return fail(PT_ERR_INVALID, "pt_readback_rgba8: bad argument");
+    DevBuf<uchar4> tmp;
+    int rc = tmp.alloc(S.P);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_to_rgba8, dim3((S.P + kBlock - 1) / kBlock), dim3(kBlock), 0, S.stream, S.image, S.P, iter, tmp.p);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipMemcpyAsync(rgba_host, tmp.p, (size_t)S.P * 4, hipMemcpyDeviceToHost, S.stream));
+    HIPCHECK(hipStreamSynchronize(S.stream));
+    return PT_OK;
+}
+
+int pt_counters(PtCounters *out) {
+    if (!S.init) return fail(PT_ERR_NOT_INIT, "pt_counters before pt_init");
+    if (!out) return fail(PT_ERR_INVALID, "pt_counters: null");
+    Ctrl h;
+    HIPCHECK(hipMemcpyAsync(&h, S.ctrl, sizeof h, hipMemcpyDeviceToHost, S.stream));
+    HIPCHECK(hipStreamSynchronize(S.stream));
+    int rc = resolve_events(S.evBounce, S.msBounce, S.nBounce);
+    if (rc) return rc;
+    rc = resolve_events(S.evRaygen, S.msRaygen, S.nRaygen);
+    if (rc) return rc;
+    memset(out, 0, sizeof *out);
+    for (int d = 0; d < kMaxDepthSlots; ++d) out->live[d] = (int64_t)h.sum_live[d];
+    out->light_hits = (int64_t)h.light_hits;
+    out->misses = (int64_t)h.misses;
+    out->iterations = S.iterations;
+    out->bounce_launches = S.nBounce;
+    out->bounce_kernel_ms = S.msBounce;
+    out->raygen_kernel_ms = S.msRaygen;
+    out->raygen_launches = S.nRaygen;
+    if (h.error) return fail(PT_ERR_DEVICE, "device fault: compaction look-back timed out");
+    return PT_OK;
+}
+
+int pt_counters_reset(void) {
+    if (!S.init) return fail(PT_ERR_NOT_INIT, "pt_counters_reset before pt_init");
+    HIPCHECK(hipStreamSynchronize(S.stream));
+    int rc = resolve_events(S.evBounce, S.msBounce, S.nBounce);
+    if (rc) return rc;
+    rc = resolve_events(S.evRaygen, S.msRaygen, S.nRaygen);
+    if (rc) return rc;
+    S.msBounce = S.msRaygen = 0;
+    S.nBounce = S.nRaygen = 0;
+    S.iterations = 0;
+    HIPCHECK(hipMemset(S.ctrl, 0, sizeof(Ctrl)));
+    return PT_OK;
+}
+
+int pt_debug_trace_paths(int iter, int bounces, float *origin3, float *dir3, float *color3, int32_t *pixelIndex,
+                         int32_t *count) {
+    if (!S.init) return fail(PT_ERR_NOT_INIT, "pt_debug_trace_paths before pt_init");
+    if (bounces < 0 || bounces > PT_MAX_DEPTH || !count) return fail(PT_ERR_INVALID, "pt_debug_trace_paths: bad argument");
+    if (bounces > S.prm.traceDepth) return fail(PT_ERR_INVALID, "pt_debug_trace_paths: bounces > traceDepth");
+    int rc = launch_raygen(iter);
+    if (rc) return rc;
+    for (int d = 1; d <= bounces; ++d) {
+        rc = launch_bounce(iter, d, false, nullptr);  // no accumulation, survivors always written
+        if (rc) return rc;
+    }
+    uint32_t n = 0;
+    HIPCHECK(hipMemcpyAsync(&n, &S.ctrl->n_live[bounces + 1], 4, hipMemcpyDeviceToHost, S.stream));
+    HIPCHECK(hipStreamSynchronize(S.stream));
+    rc = check_device_fault();
+    if (rc) return rc;
+    *count = (int32_t)n;
+    if (n == 0) return PT_OK;
+    std::vector<float> h((size_t)n);
+    const PathSoA s = soa(S.pathbuf[bounces & 1], S.nLocal);
+    float *dst[3] = {origin3, dir3, color3};
+    for (int grp = 0; grp < 3; ++grp) {
+        if (!dst[grp]) continue;
+        for (int c = 0; c < 3; ++c) {
+            HIPCHECK(hipMemcpy(h.data(), s.a[grp * 3 + c], (size_t)n * 4, hipMemcpyDeviceToHost));
+            for (uint32_t i = 0; i < n; ++i) dst[grp][3 * (size_t)i + c] = h[i];
+        }
+    }
+    if (pixelIndex) HIPCHECK(hipMemcpy(pixelIndex, s.pix, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+// ---- stream compaction library -------------------------------------------------------------------------
+int pt_scan_exclusive_i32(const int32_t *in_dev, int32_t *out_dev, int64_t n, void *stream) {
+    if (n < 0 || (n > 0 && (!in_dev || !out_dev))) return fail(PT_ERR_INVALID, "pt_scan_exclusive_i32: bad argument");
+    if (n == 0) return PT_OK;
+    if (count_devices() < 1) return fail(PT_ERR_NO_GPU, "no HIP device");
+    const long long tiles = (n + kScanTile - 1) / kScanTile;
+    if (tiles > 0x7fffffffll) return fail(PT_ERR_INVALID, "pt_scan_exclusive_i32: n too large");
+    int rc = scan_ws(tiles);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHECK(hipMemsetAsync(W.ctrl, 0, sizeof(ScanCtrl), st));
+    HIPCHECK(hipMemsetAsync(W.desc, 0, (size_t)tiles * 8, st));
+    int grid = 0;
+    rc = persistent_grid(reinterpret_cast<const void *>(k_scan_exclusive), 0, &grid);
+    if (rc) return rc;
+    if (grid > tiles) grid = (int)tiles;
+    hipLaunchKernelGGL(k_scan_exclusive, dim3(grid), dim3(kBlock), 0, st, in_dev, out_dev, (long long)n, W.ctrl, W.desc);
+    HIPCHECK(hipGetLastError());
+    return PT_OK;
+}
+
+int pt_compact_nonzero_i32(const int32_t *in_dev, int32_t *out_dev, int64_t n, int64_t *count_dev, void *stream) {
+    if (n < 0 || !count_dev || (n > 0 && (!in_dev || !out_dev))) return fail(PT_ERR_INVALID, "pt_compact_nonzero_i32: bad argument");
+    if (count_devices() < 1) return fail(PT_ERR_NO_GPU, "no HIP device");
+    const long long tiles = (n + kBlock - 1) / kBlock;
+    if (tiles > 0x7fffffffll) return fail(PT_ERR_INVALID, "pt_compact_nonzero_i32: n too large");
+    int rc = scan_ws(tiles ? tiles : 1);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHECK(hipMemsetAsync(W.ctrl, 0, sizeof(ScanCtrl), st));
+    HIPCHECK(hipMemsetAsync(W.desc, 0, (size_t)(tiles ? tiles : 1) * 8, st));
+    int grid = 0;
+    rc = persistent_grid(reinterpret_cast<const void *>(k_compact_nonzero), 0, &grid);
+    if (rc) return rc;
+    if (grid > tiles) grid = (int)tiles;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(k_compact_nonzero, dim3(grid), dim3(kBlock), 0, st, in_dev, out_dev, (long long)n, W.ctrl, W.desc,
+                       reinterpret_cast<long long *>(count_dev));
+    HIPCHECK(hipGetLastError());
+    return PT_OK;
+}
+
+// ---- primitive tests over host arrays ------------------------------------------------------------------
+#define NEED_GPU() do { if (count_devices() < 1) return fail(PT_ERR_NO_GPU, "no HIP device"); } while (0)
+#define UP(buf, host, count) do { int rc_ = buf.alloc(count); if (rc_) return rc_; \
+    HIPCHECK(hipMemcpy(buf.p, host, (size_t)(count) * sizeof(*buf.p), hipMemcpyHostToDevice)); } while (0)
+#define DOWN(host, buf, count) HIPCHECK(hipMemcpy(host, buf.p, (size_t)(count) * sizeof(*buf.p), hipMemcpyDeviceToHost))
+#define GRID(n) dim3(((n) + 255) / 256), dim3(256), 0, 0
+
+int pt_test_utilhash(const uint32_t *in, uint32_t *out, int n) {
+    NEED_GPU();
+    if (n <= 0) return PT_OK;
+    DevBuf<uint32_t> a, b;
+    UP(a, in, n);
+    int rc = b.alloc(n); if (rc) return rc;
+    hipLaunchKernelGGL(k_test_utilhash, GRID(n), a.p, b.p, n);
+    HIPCHECK(hipDeviceSynchronize());
+    DOWN(out, b, n);
+    return PT_OK;
+}
+
+int pt_test_rng(const uint32_t *seeds, int nseeds, int ndraws, float *u01_out) {
+    NEED_GPU();
+    if (nseeds <= 0 || ndraws <= 0) return PT_OK;
+    DevBuf<uint32_t> a;
+    DevBuf<float> b;
+    UP(a, seeds, nseeds);
+    int rc = b.alloc((size_t)nseeds * ndraws); if (rc) return rc;
+    hipLaunchKernelGGL(k_test_rng, GRID(nseeds), a.p, nseeds, ndraws, b.p);
+    HIPCHECK(hipDeviceSynchronize());
+    DOWN(u01_out, b, (size_t)nseeds * ndraws);
+    return PT_OK;
+}
+
+int pt_test_intersect(const PtGeom *geoms, int ngeoms, const int32_t *geom_index, const float *rays, int n, float *t,
+                      float *p3, float *n3, int32_t *outside) {
+    NEED_GPU();
+    if (n <= 0) return PT_OK;
+    for (int i = 0; i < n; ++i)
+        if (geom_index[i] < 0 || geom_index[i] >= ngeoms) return fail(PT_ERR_INVALID, "pt_test_intersect: geom index out of range");
+    std::vector<GeomDev> hg(ngeoms);
+    for (int i = 0; i < ngeoms; ++i) pack_geom(geoms[i], hg[i]);
+    DevBuf<GeomDev> dg;
+    DevBuf<int> di, dout;
+    DevBuf<float> dr, dt, dp, dn;
+    UP(dg, hg.data(), ngeoms);
+    UP(di, geom_index, n);
+    UP(dr, rays, (size_t)n * 6);
+    UP(dp, p3, (size_t)n * 3);
+    UP(dn, n3, (size_t)n * 3);
+    UP(dout, outside, n);
+    int rc = dt.alloc(n); if (rc) return rc;
+    hipLaunchKernelGGL(k_test_intersect, GRID(n), dg.p, di.p, dr.p, n, dt.p, dp.p, dn.p, dout.p);
+    HIPCHECK(hipDeviceSynchronize());
+    DOWN(t, dt, n);
+    DOWN(p3, dp, (size_t)n * 3);
+    DOWN(n3, dn, (size_t)n * 3);
+    DOWN(outside, dout, n);
+    return PT_OK;
+}
+
+int pt_test_hemisphere(const float *normals3, const int32_t *iid3, int n, float *out3) {
+    NEED_GPU();
+    if (n <= 0) return PT_OK;
+    DevBuf<float> a, o;
+    DevBuf<int> b;
+    UP(a, normals3, (size_t)n * 3);
+    UP(b, iid3, (size_t)n * 3);
+    int rc = o.alloc((size_t)n * 3); if (rc) return rc;
+    hipLaunchKernelGGL(k_test_hemisphere, GRID(n), a.p, b.p, n, o.p);
+    HIPCHECK(hipDeviceSynchronize());
+    DOWN(out3, o, (size_t)n * 3);
+    return PT_OK;
+}
+
+int pt_test_sincos(const float *x, int n, float *s, float *c) {
+    NEED_GPU();
+    if (n <= 0) return PT_OK;
+    DevBuf<float> a, ds, dc;
+    UP(a, x, n);
+    int rc = ds.alloc(n); if (rc) return rc;
+    rc = dc.alloc(n); if (rc) return rc;
+    hipLaunchKernelGGL(k_test_sincos, GRID(n), a.p, n, ds.p, dc.p);
+    HIPCHECK(hipDeviceSynchronize());
+    DOWN(s, ds, n);
+    DOWN(c, dc, n);
+    return PT_OK;
+}
+
+int pt_test_reflect_refract(const float *I3, const float *N3, const float *eta, int n, float *refl3, float *refr3) {
+    NEED_GPU();
+    if (n <= 0) return PT_OK;
+    DevBuf<float> a, b, e, r1, r2;
+    UP(a, I3, (size_t)n * 3);
+    UP(b, N3, (size_t)n * 3);
+    UP(e, eta, n);
+    int rc = r1.alloc((size_t)n * 3); if (rc) return rc;
+    rc = r2.alloc((size_t)n * 3); if (rc) return rc;
+    hipLaunchKernelGGL(k_test_reflect_refract, GRID(n), a.p, b.p, e.p, n, r1.p, r2.p);
+    HIPCHECK(hipDeviceSynchronize());
+    DOWN(refl3, r1, (size_t)n * 3);
+    DOWN(refr3, r2, (size_t)n * 3);
+    return PT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,37 @@
+// pathtrace_shim.cpp -- the three reference symbols (src/pathtrace.cu:75-92,123-174) over the C ABI.
+// Error behaviour follows checkCUDAError (src/pathtrace.cu:21-39): message on stderr, exit(EXIT_FAILURE).
+#include "pathtrace.h"
+
+#include <cstdio>
+#include <cstdlib>
+
+#include "../../include/pt_amd.h"
+
+static Scene *hst_scene = NULL;
+
+static void checkPtError(int status, const char *msg) {
+    if (status == PT_OK) return;
+    fprintf(stderr, "HIP error (pathtrace_shim.cpp): %s: %s\n", msg, pt_last_error());
+    exit(EXIT_FAILURE);
+}
+
+void pathtraceInit(Scene *scene) {
+    hst_scene = scene;
+    static_assert(sizeof(Geom) == sizeof(PtGeom) && sizeof(Material) == sizeof(PtMaterial) &&
+                  sizeof(Camera) == sizeof(PtCamera), "layout contract of include/pt_amd.h");
+    checkPtError(pt_init(reinterpret_cast<const PtCamera *>(&scene->state.camera),
+                         reinterpret_cast<const PtGeom *>(scene->geoms.data()), (int)scene->geoms.size(),
+                         reinterpret_cast<const PtMaterial *>(scene->materials.data()), (int)scene->materials.size(),
+                         scene->state.traceDepth, NULL),
+                 "pathtraceInit");
+}
+
+void pathtraceFree() {
+    pt_free();  // no-op when nothing was initialised (src/main.cpp:91-94 calls Free before the first Init)
+}
+
+void pathtrace(uchar4 *pbo, int frame, int iter) {
+    checkPtError(pt_iterate(frame, iter, pbo), "pathtrace");
+    // Retrieve image from GPU: the un-normalised running sum (src/pathtrace.cu:170-171)
+    checkPtError(pt_readback(reinterpret_cast<float *>(hst_scene->state.image.data())), "pathtrace");
+}

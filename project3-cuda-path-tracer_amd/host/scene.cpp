@@ -1,0 +1,144 @@
+// scene.cpp -- parser for the reference's scene-file format (reference src/scene.cpp:7-182), quirks kept:
+//   * MATERIAL / OBJECT ids must be sequential, otherwise the block is skipped with an ERROR line (:37,:149)
+//   * a MATERIAL block is exactly 7 lines, a CAMERA block 5 lines + EYE/VIEW/UP lines up to a blank line
+//   * the object type line must be exactly "sphere" or "cube" (:48-53); TRANS/ROTAT/SCALE up to a blank line
+//   * the specular exponent keyword is SPECEX (:164) although the README says SPECX
+//   * CRLF / CR / LF line ends; '//' comment lines are simply unknown keywords
+// Unlike the reference, fields whose keyword is missing are zero instead of uninitialised.
+#include "scene.h"
+
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <stdexcept>
+
+using utilityCore::safeGetline;
+using utilityCore::tokenizeString;
+
+namespace {
+typedef std::vector<std::string> Tokens;
+bool key(const Tokens &t, const char *k) { return !t.empty() && t[0] == k; }
+float num(const Tokens &t, size_t i) { return i < t.size() ? (float)atof(t[i].c_str()) : 0.0f; }
+lin::vec3 triple(const Tokens &t) { return lin::vec3(num(t, 1), num(t, 2), num(t, 3)); }
+
+void deriveFov(Camera &camera, float fovy) {
+    // reference src/scene.cpp:133-136
+    float yscaled = std::tan(fovy * (PI / 180));
+    float xscaled = (yscaled * camera.resolution.x) / camera.resolution.y;
+    float fovx = (std::atan(xscaled) * 180) / PI;
+    camera.fov.x = fovx;
+    camera.fov.y = fovy;
+}
+}  // namespace
+
+Scene::Scene(std::string filename, bool verbose_) : verbose(verbose_) {
+    if (verbose) std::cout << "Reading scene from " << filename << " ..." << std::endl;
+    state.iterations = 0;
+    state.traceDepth = 0;
+    state.camera.resolution.x = state.camera.resolution.y = 0;
+    state.camera.fov.x = state.camera.fov.y = 0.0f;
+    fp_in.open(filename.c_str());
+    if (!fp_in.is_open()) {
+        std::cout << "Error reading from file - aborting!" << std::endl;
+        throw std::runtime_error("Error reading from file - aborting!");
+    }
+    std::string line;
+    while (fp_in.good()) {
+        safeGetline(fp_in, line);
+        if (line.empty()) continue;
+        const Tokens tokens = tokenizeString(line);
+        if (tokens.size() >= 2 && key(tokens, "MATERIAL")) loadMaterial(tokens[1]);
+        else if (tokens.size() >= 2 && key(tokens, "OBJECT")) loadGeom(tokens[1]);
+        else if (key(tokens, "CAMERA")) loadCamera();
+    }
+}
+
+Scene::~Scene() {}
+
+int Scene::loadMaterial(std::string materialid) {
+    if (atoi(materialid.c_str()) != (int)materials.size()) {
+        std::cout << "ERROR: MATERIAL ID does not match expected number of materials" << std::endl;
+        return -1;
+    }
+    Material m;
+    m.specular.exponent = m.hasReflective = m.hasRefractive = m.indexOfRefraction = m.emittance = 0.0f;
+    std::string line;
+    for (int i = 0; i < 7; ++i) {
+        safeGetline(fp_in, line);
+        const Tokens t = tokenizeString(line);
+        if (key(t, "RGB")) m.color = triple(t);
+        else if (key(t, "SPECEX")) m.specular.exponent = num(t, 1);
+        else if (key(t, "SPECRGB")) m.specular.color = triple(t);
+        else if (key(t, "REFL")) m.hasReflective = num(t, 1);
+        else if (key(t, "REFR")) m.hasRefractive = num(t, 1);
+        else if (key(t, "REFRIOR")) m.indexOfRefraction = num(t, 1);
+        else if (key(t, "EMITTANCE")) m.emittance = num(t, 1);
+    }
+    materials.push_back(m);
+    return 1;
+}
+
+int Scene::loadCamera() {
+    Camera &camera = state.camera;
+    float fovy = 0;
+    std::string line;
+    for (int i = 0; i < 5; ++i) {
+        safeGetline(fp_in, line);
+        const Tokens t = tokenizeString(line);
+        if (key(t, "RES") && t.size() >= 3) {
+            camera.resolution.x = atoi(t[1].c_str());
+            camera.resolution.y = atoi(t[2].c_str());
+        } else if (key(t, "FOVY")) fovy = num(t, 1);
+        else if (key(t, "ITERATIONS") && t.size() >= 2) state.iterations = atoi(t[1].c_str());
+        else if (key(t, "DEPTH") && t.size() >= 2) state.traceDepth = atoi(t[1].c_str());
+        else if (key(t, "FILE") && t.size() >= 2) state.imageName = t[1];
+    }
+    for (safeGetline(fp_in, line); !line.empty() && fp_in.good(); safeGetline(fp_in, line)) {
+        const Tokens t = tokenizeString(line);
+        if (key(t, "EYE")) camera.position = triple(t);
+        else if (key(t, "VIEW")) camera.view = triple(t);
+        else if (key(t, "UP")) camera.up = triple(t);
+    }
+    deriveFov(camera, fovy);
+    state.image.assign((size_t)camera.resolution.x * camera.resolution.y, lin::vec3());
+    return 1;
+}
+
+int Scene::loadGeom(std::string objectid) {
+    if (atoi(objectid.c_str()) != (int)geoms.size()) {
+        std::cout << "ERROR: OBJECT ID does not match expected number of geoms" << std::endl;
+        return -1;
+    }
+    Geom g;
+    g.type = SPHERE;
+    g.materialid = 0;
+    std::string line;
+    safeGetline(fp_in, line);
+    if (!line.empty() && fp_in.good()) {
+        if (line == "sphere") g.type = SPHERE;
+        else if (line == "cube") g.type = CUBE;
+    }
+    safeGetline(fp_in, line);
+    if (!line.empty() && fp_in.good()) {
+        const Tokens t = tokenizeString(line);
+        if (t.size() >= 2) g.materialid = atoi(t[1].c_str());
+    }
+    for (safeGetline(fp_in, line); !line.empty() && fp_in.good(); safeGetline(fp_in, line)) {
+        const Tokens t = tokenizeString(line);
+        if (key(t, "TRANS")) g.translation = triple(t);
+        else if (key(t, "ROTAT")) g.rotation = triple(t);
+        else if (key(t, "SCALE")) g.scale = triple(t);
+    }
+    g.transform = utilityCore::buildTransformationMatrix(g.translation, g.rotation, g.scale);
+    g.inverseTransform = lin::inverse(g.transform);
+    g.invTranspose = lin::inverseTranspose(g.transform);
+    geoms.push_back(g);
+    return 1;
+}
+
+void Scene::setResolution(int w, int h) {
+    state.camera.resolution.x = w;
+    state.camera.resolution.y = h;
+    deriveFov(state.camera, state.camera.fov.y);
+    state.image.assign((size_t)w * h, lin::vec3());
+}

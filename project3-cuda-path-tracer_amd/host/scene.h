@@ -1,0 +1,30 @@
+// scene.h -- the reference's `Scene` (src/scene.h:13-26): text scene file -> geoms, materials, state.
+#pragma once
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "sceneStructs.h"
+#include "utilities.h"
+
+class Scene {
+private:
+    std::ifstream fp_in;
+    int loadMaterial(std::string materialid);
+    int loadGeom(std::string objectid);
+    int loadCamera();
+    bool verbose;
+
+public:
+    // Throws std::runtime_error when the file cannot be opened (the reference prints
+    // "Error reading from file - aborting!" and terminates, src/scene.cpp:12-15).
+    explicit Scene(std::string filename, bool verbose = false);
+    ~Scene();
+
+    // RES override used by the headless driver; recomputes fov.x like src/scene.cpp:133-136
+    void setResolution(int w, int h);
+
+    std::vector<Geom> geoms;
+    std::vector<Material> materials;
+    RenderState state;
+};
