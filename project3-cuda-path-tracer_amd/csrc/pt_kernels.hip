@@ -55,20 +55,31 @@ struct KParams {
     int   traceDepth;
 };
 
+// SoA PathSegment buffer: 11 arrays of `cap` 4-byte elements, array k at base + k*cap:
+// 0-2 origin, 3-5 direction, 6-8 throughput, 9 pixelIndex, 10 remainingBounces
 struct PathSoA {
-    float *a[9];        // ox oy oz dx dy dz cr cg cb
-    int   *pix;
-    int   *rem;
+    float *base;
+    int    cap;
+    __host__ __device__ __forceinline__ float *a(int k) const { return base + (size_t)k * cap; }
+    __host__ __device__ __forceinline__ int *pix() const { return reinterpret_cast<int *>(base + (size_t)9 * cap); }
+    __host__ __device__ __forceinline__ int *rem() const { return reinterpret_cast<int *>(base + (size_t)10 * cap); }
 };
 
-// tile descriptor granule: [63:32] status, [31:0] value
-constexpr uint32_t kStInvalid = 0, kStAggregate = 1, kStInclusive = 2;
-constexpr int kSpinLimit = 1 << 24;
+// ---- cross-workgroup ordered prefix: two-level look-back ----------------------------------------------
+// Tiles are handed out by an atomic ticket, so every predecessor of a tile is owned by a workgroup that
+// is already running: no residency or dispatch-order assumption.  Each tile publishes
+//   * its aggregate as ONE 8-byte agent-scope granule  desc[tile] = {status = 1 (hi), value (lo)}
+//   * and adds it to its 64-tile group's word          grp[tile/64] += {value (hi), 1 (lo)}   (count in the
+//     low half so that the wrapping sum can never carry into it).
+// The exclusive prefix of tile t = sum of the full groups before it (one probe per 64 groups = 4096 tiles)
+// + sum of the aggregates of its own group's earlier tiles (one probe).  Both probes are issued together,
+// so the dependent latency is ~one memory round trip instead of the (tiles in flight)/64 serial probes of a
+// flat decoupled look-back.  The value IS the flag in both words, so no fence is needed (the payload
+// travels inside the granule).  Spins are bounded; a timeout sets the sticky error word.
+constexpr int kSpinLimit = 1 << 22;
+constexpr int kGroup = 64;
 
-__device__ __forceinline__ void desc_store(unsigned long long *p, uint32_t status, uint32_t value) {
-    __hip_atomic_store(p, ((unsigned long long)status << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ unsigned long long desc_load(unsigned long long *p) {
+__device__ __forceinline__ unsigned long long word_load(unsigned long long *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
@@ -77,49 +88,59 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
-// Cross-workgroup exclusive prefix of `block_total` for ticket-ordered tile `tile` (decoupled
-// look-back, one wave, 64 predecessors per probe).  Called by all 64 lanes of wave 0.  Tiles are
-// handed out by an atomic ticket, so every predecessor is owned by a workgroup that is already
-// running: no residency assumption.  The value IS the flag (one 8-byte agent-scope granule), so no
-// fence is needed.  Spins are bounded; a timeout sets ctrl->error.
-__device__ __forceinline__ uint32_t lookback_exclusive(unsigned long long *desc, int tile, uint32_t block_total,
-                                                       uint32_t *error_word) {
+// Called by all 64 lanes of wave 0 of the workgroup that owns `tile`.
+__device__ __forceinline__ uint32_t lookback_exclusive(unsigned long long *desc, unsigned long long *grp, int tile,
+                                                       uint32_t block_total, uint32_t *error_word) {
     const int lane = threadIdx.x & 63;
-    if (tile == 0) {
-        if (lane == 0) desc_store(&desc[0], kStInclusive, block_total);
-        return 0u;
+    const int g = tile / kGroup, r = tile - g * kGroup;
+    if (lane == 0) {
+        __hip_atomic_store(&desc[tile], (1ull << 32) | block_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&grp[g], ((unsigned long long)block_total << 32) | 1ull, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (lane == 0) desc_store(&desc[tile], kStAggregate, block_total);
     uint32_t excl = 0;
-    int base = tile - 1;
-    for (;;) {
-        const int j = base - lane;
-        unsigned long long d = ((unsigned long long)kStInclusive << 32);  // virtual tile < 0: inclusive 0
+    // own group: aggregates of tiles 64g .. tile-1; first window of previous groups probed in the same trip
+    {
+        const int jg = g - 1 - lane;
+        unsigned long long dt = 1ull << 32, dg = (unsigned long long)kGroup;   // "ready, value 0"
         int spins = 0;
         for (;;) {
-            if (j >= 0) d = desc_load(&desc[j]);
-            if (__all((uint32_t)(d >> 32) != kStInvalid)) break;
+            if (lane < r) dt = word_load(&desc[g * kGroup + lane]);
+            if (jg >= 0) dg = word_load(&grp[jg]);
+            if (__all((uint32_t)(dt >> 32) != 0u && (uint32_t)dg == (uint32_t)kGroup)) break;
             __builtin_amdgcn_s_sleep(1);
             if (++spins > kSpinLimit) {
                 if (lane == 0) atomicExch(error_word, 1u);
-                return excl;
+                return 0u;
             }
         }
-        const unsigned long long incl = __ballot((uint32_t)(d >> 32) == kStInclusive);
-        const int first = incl ? (__ffsll((long long)incl) - 1) : 63;
-        excl += wave_sum(lane <= first ? (uint32_t)d : 0u);
-        if (incl) break;
-        base -= 64;
+        excl = wave_sum((lane < r ? (uint32_t)dt : 0u) + (jg >= 0 ? (uint32_t)(dg >> 32) : 0u));
     }
-    if (lane == 0) desc_store(&desc[tile], kStInclusive, excl + block_total);
+    // more than 64 previous groups (> 4096 tiles ahead of this one)
+    for (int base = g - 1 - 64; base >= 0; base -= 64) {
+        const int jg = base - lane;
+        unsigned long long dg = (unsigned long long)kGroup;
+        int spins = 0;
+        for (;;) {
+            if (jg >= 0) dg = word_load(&grp[jg]);
+            if (__all((uint32_t)dg == (uint32_t)kGroup)) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > kSpinLimit) {
+                if (lane == 0) atomicExch(error_word, 1u);
+                return 0u;
+            }
+        }
+        excl += wave_sum(jg >= 0 ? (uint32_t)(dg >> 32) : 0u);
+    }
     return excl;
 }
 
 // Workgroup-level stable compaction rank of a 0/1 flag: ballot + mbcnt inside each wave, wave
 // totals through LDS, cross-tile base from the look-back.  Returns the destination slot of this
 // thread (valid when flag) and the tile's inclusive end in *tile_end (valid in every thread).
-__device__ __forceinline__ uint32_t compact_slot(bool flag, int tile, unsigned long long *desc, uint32_t *s_wave,
-                                                 uint32_t *s_excl, uint32_t *error_word, uint32_t *tile_end) {
+__device__ __forceinline__ uint32_t compact_slot(bool flag, int tile, unsigned long long *desc, unsigned long long *grp,
+                                                 uint32_t *s_wave, uint32_t *s_excl, uint32_t *error_word,
+                                                 uint32_t *tile_end) {
     const int wave = threadIdx.x >> 6;
     const unsigned long long ballot = __ballot(flag);
     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32),
@@ -134,7 +155,7 @@ __device__ __forceinline__ uint32_t compact_slot(bool flag, int tile, unsigned l
         total += c;
     }
     if (wave == 0) {
-        uint32_t e = lookback_exclusive(desc, tile, total, error_word);
+        uint32_t e = lookback_exclusive(desc, grp, tile, total, error_word);
         if (threadIdx.x == 0) *s_excl = e;
     }
     __syncthreads();
@@ -169,11 +190,11 @@ __global__ __launch_bounds__(kBlock) void k_generate_rays(KParams prm, int iter,
         const float a = prm.pixLenX * sx;
         const float b = prm.pixLenY * sy;
         const F3 dir = normalize((view - right * a) - up * b);
-        out.a[0][j] = prm.pos[0]; out.a[1][j] = prm.pos[1]; out.a[2][j] = prm.pos[2];
-        out.a[3][j] = dir.x; out.a[4][j] = dir.y; out.a[5][j] = dir.z;
-        out.a[6][j] = 1.0f; out.a[7][j] = 1.0f; out.a[8][j] = 1.0f;
-        out.pix[j] = index;
-        out.rem[j] = prm.traceDepth;
+        out.a(0)[j] = prm.pos[0]; out.a(1)[j] = prm.pos[1]; out.a(2)[j] = prm.pos[2];
+        out.a(3)[j] = dir.x; out.a(4)[j] = dir.y; out.a(5)[j] = dir.z;
+        out.a(6)[j] = 1.0f; out.a(7)[j] = 1.0f; out.a(8)[j] = 1.0f;
+        out.pix()[j] = index;
+        out.rem()[j] = prm.traceDepth;
     }
 }
 
@@ -181,6 +202,7 @@ __global__ __launch_bounds__(kBlock) void k_generate_rays(KParams prm, int iter,
 // Persistent workgroups pull 256-path tiles by ticket until the bounce's queue is drained.
 __global__ __launch_bounds__(kBlock) void k_bounce(KParams prm, int iter, int depth, int lastBounce,
                                                    PathSoA in, PathSoA out, Ctrl *ctrl, unsigned long long *desc,
+                                                   unsigned long long *grp,
                                                    const GeomDev *__restrict__ ggeoms,
                                                    const MaterialDev *__restrict__ gmats, float *image) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -189,7 +211,7 @@ __global__ __launch_bounds__(kBlock) void k_bounce(KParams prm, int iter, int de
     uint32_t *s_misc = reinterpret_cast<uint32_t *>(smem + sizeof(GeomDev) * prm.ngeoms + sizeof(MaterialDev) * prm.nmats);
     uint32_t *s_wave = s_misc;          // [kWaves]
     uint32_t *s_excl = s_misc + kWaves; // [1]
-    uint32_t *s_tile = s_misc + kWaves + 1;
+    uint32_t *s_tile = s_misc + kWaves + 1;   // [2], double-buffered ticket hand-off
 
     // stage the scene in LDS once per (persistent) workgroup, 16 B per lane per step
     {
@@ -205,10 +227,10 @@ __global__ __launch_bounds__(kBlock) void k_bounce(KParams prm, int iter, int de
     const uint32_t nLive = ctrl->n_live[depth];
     const int numTiles = (int)((nLive + kBlock - 1) / kBlock);
 
-    for (;;) {
-        if (threadIdx.x == 0) *s_tile = atomicAdd(&ctrl->ticket[depth], 1u);
-        __syncthreads();
-        const int tile = (int)*s_tile;
+    if (threadIdx.x == 0) s_tile[0] = atomicAdd(&ctrl->ticket[depth], 1u);
+    __syncthreads();
+    for (int round = 0;; ++round) {
+        const int tile = (int)s_tile[round & 1];
         if (tile >= numTiles) break;
         if (tile == 0 && threadIdx.x == 0) atomicAdd(&ctrl->sum_live[depth], (unsigned long long)nLive);
 
@@ -219,11 +241,16 @@ __global__ __launch_bounds__(kBlock) void k_bounce(KParams prm, int iter, int de
         F3 org = f3(0, 0, 0), dir = f3(0, 0, 1), col = f3(0, 0, 0);
         int pix = 0, rem = 0;
         if (valid) {
-            org = f3(in.a[0][idx], in.a[1][idx], in.a[2][idx]);
-            dir = f3(in.a[3][idx], in.a[4][idx], in.a[5][idx]);
-            col = f3(in.a[6][idx], in.a[7][idx], in.a[8][idx]);
-            pix = in.pix[idx];
-            rem = in.rem[idx];
+            org = f3(in.a(0)[idx], in.a(1)[idx], in.a(2)[idx]);
+            dir = f3(in.a(3)[idx], in.a(4)[idx], in.a(5)[idx]);
+            col = f3(in.a(6)[idx], in.a(7)[idx], in.a(8)[idx]);
+            pix = in.pix()[idx];
+            rem = in.rem()[idx];
+        }
+        // next tile's ticket: issued behind this tile's loads, its latency hides under the compute
+        uint32_t nextTile = 0;
+        if (threadIdx.x == 0) nextTile = atomicAdd(&ctrl->ticket[depth], 1u);
+        if (valid) {
 
             // nearest hit, geoms in file order, strict '<' so the first geom wins ties (S3)
             float tbest = 0.0f;
@@ -317,17 +344,19 @@ __global__ __launch_bounds__(kBlock) void k_bounce(KParams prm, int iter, int de
 
         if (!lastBounce) {                                       // S8: stable compaction into `out`
             uint32_t tileEnd;
-            const uint32_t slot = compact_slot(alive, tile, desc, s_wave, s_excl, &ctrl->error, &tileEnd);
+            if (threadIdx.x == 0) s_tile[(round + 1) & 1] = nextTile;   // published by compact_slot's barriers
+            const uint32_t slot = compact_slot(alive, tile, desc, grp, s_wave, s_excl, &ctrl->error, &tileEnd);
             if (alive) {
-                out.a[0][slot] = org.x; out.a[1][slot] = org.y; out.a[2][slot] = org.z;
-                out.a[3][slot] = dir.x; out.a[4][slot] = dir.y; out.a[5][slot] = dir.z;
-                out.a[6][slot] = col.x; out.a[7][slot] = col.y; out.a[8][slot] = col.z;
-                out.pix[slot] = pix;
-                out.rem[slot] = rem - 1;
+                out.a(0)[slot] = org.x; out.a(1)[slot] = org.y; out.a(2)[slot] = org.z;
+                out.a(3)[slot] = dir.x; out.a(4)[slot] = dir.y; out.a(5)[slot] = dir.z;
+                out.a(6)[slot] = col.x; out.a(7)[slot] = col.y; out.a(8)[slot] = col.z;
+                out.pix()[slot] = pix;
+                out.rem()[slot] = rem - 1;
             }
             if (tile == numTiles - 1 && threadIdx.x == 0) ctrl->n_live[depth + 1] = tileEnd;
         } else {
-            __syncthreads();  // keep s_tile stable until every thread has read it
+            if (threadIdx.x == 0) s_tile[(round + 1) & 1] = nextTile;
+            __syncthreads();
         }
     }
 }
@@ -357,7 +386,8 @@ constexpr int kScanItems = 4;                 // int4 per thread
 constexpr int kScanTile = kBlock * kScanItems;
 
 __global__ __launch_bounds__(kBlock) void k_scan_exclusive(const int32_t *__restrict__ in, int32_t *__restrict__ out,
-                                                           long long n, ScanCtrl *sc, unsigned long long *desc) {
+                                                           long long n, ScanCtrl *sc, unsigned long long *desc,
+                                                           unsigned long long *grp) {
     __shared__ uint32_t s_wave[kWaves];
     __shared__ uint32_t s_excl, s_tile;
     const long long numTiles = (n + kScanTile - 1) / kScanTile;
@@ -394,7 +424,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_exclusive(const int32_t *__rest
             total += c;
         }
         if (wave == 0) {
-            uint32_t e = lookback_exclusive(desc, (int)tile, total, &sc->error);
+            uint32_t e = lookback_exclusive(desc, grp, (int)tile, total, &sc->error);
             if (threadIdx.x == 0) s_excl = e;
         }
         __syncthreads();
@@ -417,7 +447,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_exclusive(const int32_t *__rest
 
 __global__ __launch_bounds__(kBlock) void k_compact_nonzero(const int32_t *__restrict__ in, int32_t *__restrict__ out,
                                                             long long n, ScanCtrl *sc, unsigned long long *desc,
-                                                            long long *count_out) {
+                                                            unsigned long long *grp, long long *count_out) {
     __shared__ uint32_t s_wave[kWaves];
     __shared__ uint32_t s_excl, s_tile;
     const long long numTiles = (n + kBlock - 1) / kBlock;
@@ -430,7 +460,7 @@ __global__ __launch_bounds__(kBlock) void k_compact_nonzero(const int32_t *__res
         const long long i = tile * kBlock + threadIdx.x;
         const int32_t v = i < n ? in[i] : 0;
         uint32_t tileEnd;
-        const uint32_t slot = compact_slot(v != 0, (int)tile, desc, s_wave, &s_excl, &sc->error, &tileEnd);
+        const uint32_t slot = compact_slot(v != 0, (int)tile, desc, grp, s_wave, &s_excl, &sc->error, &tileEnd);
         if (v != 0) out[slot] = v;
         if (tile == numTiles - 1 && threadIdx.x == 0) *count_out = (long long)tileEnd;
     }
@@ -522,6 +552,7 @@ struct State {
     Ctrl *ctrl = nullptr;
     unsigned long long *desc = nullptr;
     int numTilesMax = 0;
+    int descStride = 0;     // 8-byte words per bounce: numTilesMax tile words + ceil(numTilesMax/64) group words
     int grid = 0;
     size_t ldsBytes = 0;
     long long iterations = 0;
@@ -539,9 +570,8 @@ int count_devices() {
 
 PathSoA soa(float *base, int cap) {
     PathSoA s;
-    for (int i = 0; i < 9; ++i) s.a[i] = base + (size_t)i * cap;
-    s.pix = reinterpret_cast<int *>(base + (size_t)9 * cap);
-    s.rem = reinterpret_cast<int *>(base + (size_t)10 * cap);
+    s.base = base;
+    s.cap = cap > 0 ? cap : 1;
     return s;
 }
 
@@ -591,7 +621,7 @@ int resolve_events(std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, double &ms
 
 int launch_raygen(int iter) {
     const PathSoA out = soa(S.pathbuf[0], S.nLocal);
-    const int ndesc = S.numTilesMax * (S.prm.traceDepth + 1);
+    const int ndesc = S.descStride * (S.prm.traceDepth + 1);
     int blocks = (S.nLocal + kBlock - 1) / kBlock;
     if (blocks < 1) blocks = 1;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -612,7 +642,8 @@ int launch_raygen(int iter) {
 int launch_bounce(int iter, int depth, bool lastBounce, float *image) {
     const PathSoA in = soa(S.pathbuf[(depth - 1) & 1], S.nLocal);
     const PathSoA out = soa(S.pathbuf[depth & 1], S.nLocal);
-    unsigned long long *desc = S.desc + (size_t)depth * S.numTilesMax;
+    unsigned long long *desc = S.desc + (size_t)depth * S.descStride;
+    unsigned long long *grp = desc + S.numTilesMax;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (S.flags & PT_FLAG_KERNEL_TIMING) {
         HIPCHECK(hipEventCreate(&e0));
@@ -620,7 +651,7 @@ int launch_bounce(int iter, int depth, bool lastBounce, float *image) {
         HIPCHECK(hipEventRecord(e0, S.stream));
     }
     hipLaunchKernelGGL(k_bounce, dim3(S.grid), dim3(kBlock), S.ldsBytes, S.stream, S.prm, iter, depth,
-                       lastBounce ? 1 : 0, in, out, S.ctrl, desc, S.dgeoms, S.dmats, image);
+                       lastBounce ? 1 : 0, in, out, S.ctrl, desc, grp, S.dgeoms, S.dmats, image);
     if (e0) {
         HIPCHECK(hipEventRecord(e1, S.stream));
         S.evBounce.emplace_back(e0, e1);
@@ -656,7 +687,7 @@ int scan_ws(long long tiles) {
         if (W.desc) HIPCHECK(hipFree(W.desc));
         W.desc = nullptr;
         long long cap = tiles < 1024 ? 1024 : tiles;
-        HIPCHECK(hipMalloc(&W.desc, (size_t)cap * 8));
+        HIPCHECK(hipMalloc(&W.desc, (size_t)(cap + (cap + kGroup - 1) / kGroup) * 8));
         W.tiles = cap;
     }
     return PT_OK;
@@ -791,8 +822,9 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     S.numTilesMax = (int)((cap + kBlock - 1) / kBlock);
     HIPCHECK(hipMalloc(&S.ctrl, sizeof(Ctrl)));
     HIPCHECK(hipMemset(S.ctrl, 0, sizeof(Ctrl)));
-    HIPCHECK(hipMalloc(&S.desc, (size_t)S.numTilesMax * (traceDepth + 2) * 8));
-    HIPCHECK(hipMemset(S.desc, 0, (size_t)S.numTilesMax * (traceDepth + 2) * 8));
+    S.descStride = S.numTilesMax + (S.numTilesMax + kGroup - 1) / kGroup;
+    HIPCHECK(hipMalloc(&S.desc, (size_t)S.descStride * (traceDepth + 2) * 8));
+    HIPCHECK(hipMemset(S.desc, 0, (size_t)S.descStride * (traceDepth + 2) * 8));
 
     S.ldsBytes = sizeof(GeomDev) * ngeoms + sizeof(MaterialDev) * nmats + 16 * sizeof(uint32_t);
     if (S.ldsBytes > 160 * 1024) return fail(PT_ERR_INVALID, "pt_init: scene does not fit the 160 KiB LDS (%zu B)", S.ldsBytes);
@@ -916,11 +948,11 @@ int pt_debug_trace_paths(int iter, int bounces, float *origin3, float *dir3, flo
     for (int grp = 0; grp < 3; ++grp) {
         if (!dst[grp]) continue;
         for (int c = 0; c < 3; ++c) {
-            HIPCHECK(hipMemcpy(h.data(), s.a[grp * 3 + c], (size_t)n * 4, hipMemcpyDeviceToHost));
+            HIPCHECK(hipMemcpy(h.data(), s.a(grp * 3 + c), (size_t)n * 4, hipMemcpyDeviceToHost));
             for (uint32_t i = 0; i < n; ++i) dst[grp][3 * (size_t)i + c] = h[i];
         }
     }
-    if (pixelIndex) HIPCHECK(hipMemcpy(pixelIndex, s.pix, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (pixelIndex) HIPCHECK(hipMemcpy(pixelIndex, s.pix(), (size_t)n * 4, hipMemcpyDeviceToHost));
     return PT_OK;
 }
 
@@ -935,12 +967,14 @@ int pt_scan_exclusive_i32(const int32_t *in_dev, int32_t *out_dev, int64_t n, vo
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     HIPCHECK(hipMemsetAsync(W.ctrl, 0, sizeof(ScanCtrl), st));
-    HIPCHECK(hipMemsetAsync(W.desc, 0, (size_t)tiles * 8, st));
+    const long long words = tiles + (tiles + kGroup - 1) / kGroup;
+    HIPCHECK(hipMemsetAsync(W.desc, 0, (size_t)words * 8, st));
     int grid = 0;
     rc = persistent_grid(reinterpret_cast<const void *>(k_scan_exclusive), 0, &grid);
     if (rc) return rc;
     if (grid > tiles) grid = (int)tiles;
-    hipLaunchKernelGGL(k_scan_exclusive, dim3(grid), dim3(kBlock), 0, st, in_dev, out_dev, (long long)n, W.ctrl, W.desc);
+    hipLaunchKernelGGL(k_scan_exclusive, dim3(grid), dim3(kBlock), 0, st, in_dev, out_dev, (long long)n, W.ctrl, W.desc,
+                       W.desc + tiles);
     HIPCHECK(hipGetLastError());
     return PT_OK;
 }
@@ -954,14 +988,15 @@ int pt_compact_nonzero_i32(const int32_t *in_dev, int32_t *out_dev, int64_t n, i
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     HIPCHECK(hipMemsetAsync(W.ctrl, 0, sizeof(ScanCtrl), st));
-    HIPCHECK(hipMemsetAsync(W.desc, 0, (size_t)(tiles ? tiles : 1) * 8, st));
+    const long long words = tiles + (tiles + kGroup - 1) / kGroup;
+    HIPCHECK(hipMemsetAsync(W.desc, 0, (size_t)(words ? words : 1) * 8, st));
     int grid = 0;
     rc = persistent_grid(reinterpret_cast<const void *>(k_compact_nonzero), 0, &grid);
     if (rc) return rc;
     if (grid > tiles) grid = (int)tiles;
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(k_compact_nonzero, dim3(grid), dim3(kBlock), 0, st, in_dev, out_dev, (long long)n, W.ctrl, W.desc,
-                       reinterpret_cast<long long *>(count_dev));
+                       W.desc + tiles, reinterpret_cast<long long *>(count_dev));
     HIPCHECK(hipGetLastError());
     return PT_OK;
 }
