@@ -126,8 +126,9 @@ const char *pt_last_error(void);
 int pt_device_count(void);
 
 /* ---- diagnostics for parity tests -------------------------------------------------------------
- * State of the paths still alive after `bounces` bounces of iteration `iter`, in compacted (stable,
- * pixel) order: arrays of capacity W*H (x3).  Does not touch the accumulator. */
+ * State of the paths still alive after `bounces` bounces of iteration `iter`, sorted by pixel index
+ * (the device queue order is arrival order): arrays of capacity W*H (x3).  Does not touch the
+ * accumulator. */
 int pt_debug_trace_paths(int iter, int bounces, float *origin3, float *dir3, float *color3,
                          int32_t *pixelIndex, int32_t *count);
 

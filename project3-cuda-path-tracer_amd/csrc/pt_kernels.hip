@@ -2,14 +2,18 @@
 //
 // One iteration = camera-ray generation, then `traceDepth` launches of ONE fused persistent kernel
 // per bounce: nearest-hit over LDS-staged geometry -> shade/scatter -> accumulate emitter hits ->
-// stable stream compaction of the survivors straight into the next bounce's SoA buffers
-// (wave64 ballot/mbcnt ranks, LDS wave totals, cross-workgroup prefix by decoupled look-back over
-// ticket-ordered tiles).  No host round trip inside an iteration: live counts stay on the device.
+// stream compaction of the survivors straight into the next bounce's SoA buffers (wave64
+// ballot/mbcnt ranks, LDS wave totals = workgroup-level exclusive scan; the workgroup's output range
+// is reserved with ONE atomic on one of 8 sharded segment counters).  No host round trip inside an
+// iteration: live counts stay on the device.  The multi-workgroup ORDERED scan (two-level decoupled
+// look-back) is the stream-compaction library at the end of this file (pt_scan_exclusive_i32 /
+// pt_compact_nonzero_i32).
 //
 // Replaces the unsolved pipeline of reference src/pathtrace.cu:133-167 (spec: SURVEY.md 3.4 S0-S9).
 // HBM layout, kernels, rooflines: DESIGN.md.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -33,15 +37,18 @@ constexpr int kNumArrays = 11;       // SoA PathSegment: origin3, dir3, throughp
 constexpr int kMaxDepthSlots = PT_MAX_DEPTH + 2;
 
 // ---- device control block ------------------------------------------------------------------------
+constexpr int kSeg = 8;              // path buffers are split into kSeg segments with one append counter each
+constexpr int kCtrPad = 32;          // one counter per 128-byte line: same-line atomics serialise at the memory side
+
 struct Ctrl {
-    // zeroed/re-armed by the ray-generation kernel every iteration
-    uint32_t n_live[kMaxDepthSlots];   // n_live[d] = paths entering bounce d
-    uint32_t ticket[kMaxDepthSlots];   // tile tickets of bounce d's launch
+    // re-armed by the ray-generation kernel every iteration:
+    // seg_count[d][s][0] = paths in segment s entering bounce d
+    uint32_t seg_count[kMaxDepthSlots][kSeg][kCtrPad];
     // never zeroed by an iteration
-    uint32_t error;                    // sticky device fault (look-back spin timeout)
-    uint32_t pad;
+    uint32_t error;                    // sticky device fault (scan-library look-back timeout)
+    uint32_t pad[kCtrPad - 1];
     unsigned long long sum_live[kMaxDepthSlots];
-    unsigned long long light_hits, misses;
+    unsigned long long light_hits[kSeg][kCtrPad / 2], misses[kSeg][kCtrPad / 2];
 };
 
 // Camera constants derived once on the host (spec S2)
@@ -53,10 +60,12 @@ struct KParams {
     int   nLocal;       // pixels rendered by this shard
     int   ngeoms, nmats;
     int   traceDepth;
+    int   segCap;       // capacity (paths) of one segment of a path buffer, multiple of kBlock
 };
 
-// SoA PathSegment buffer: 11 arrays of `cap` 4-byte elements, array k at base + k*cap:
-// 0-2 origin, 3-5 direction, 6-8 throughput, 9 pixelIndex, 10 remainingBounces
+// SoA PathSegment buffer: 11 arrays of `cap` = kSeg * segCap 4-byte elements, array k at base + k*cap
+// (0-2 origin, 3-5 direction, 6-8 throughput, 9 pixelIndex, 10 remainingBounces); inside every array
+// segment s owns [s*segCap, (s+1)*segCap) and is filled from its start.
 struct PathSoA {
     float *base;
     int    cap;
@@ -165,14 +174,27 @@ __device__ __forceinline__ uint32_t compact_slot(bool flag, int tile, unsigned l
 }
 
 // ---- camera rays (spec S2) + per-iteration re-arm of the control block ----------------------------
-__global__ __launch_bounds__(kBlock) void k_generate_rays(KParams prm, int iter, PathSoA out, Ctrl *ctrl,
-                                                          unsigned long long *desc, int ndesc) {
+// Path j goes to tile T = j/256, which lives in segment T % kSeg at local tile T / kSeg.
+__global__ __launch_bounds__(kBlock) void k_generate_rays(KParams prm, int iter, PathSoA out, Ctrl *ctrl) {
     const int gtid = blockIdx.x * kBlock + threadIdx.x;
     const int gsize = gridDim.x * kBlock;
-    for (int i = gtid; i < ndesc; i += gsize) desc[i] = 0ull;
-    if (gtid < kMaxDepthSlots) {
-        ctrl->n_live[gtid] = gtid == 1 ? (uint32_t)prm.nLocal : 0u;
-        ctrl->ticket[gtid] = 0u;
+    {
+        uint32_t *cnt = &ctrl->seg_count[0][0][0];
+        const int nwords = (prm.traceDepth + 2) * kSeg * kCtrPad;
+        const int tilesTotal = (prm.nLocal + kBlock - 1) / kBlock;
+        for (int i = gtid; i < nwords; i += gsize) {
+            uint32_t v = 0;
+            const int d = i / (kSeg * kCtrPad), r = i - d * (kSeg * kCtrPad);
+            const int sgm = r / kCtrPad;
+            if (d == 1 && r - sgm * kCtrPad == 0) {
+                // paths of the tiles T = sgm, sgm + kSeg, ... (only the globally last tile can be partial)
+                const int nt = tilesTotal > sgm ? (tilesTotal - sgm + kSeg - 1) / kSeg : 0;
+                int n = nt * kBlock;
+                if (nt > 0 && (tilesTotal - 1) % kSeg == sgm) n -= tilesTotal * kBlock - prm.nLocal;
+                v = (uint32_t)n;
+            }
+            cnt[i] = v;
+        }
     }
     const F3 view = f3(prm.view[0], prm.view[1], prm.view[2]);
     const F3 up = f3(prm.up[0], prm.up[1], prm.up[2]);
@@ -190,28 +212,48 @@ __global__ __launch_bounds__(kBlock) void k_generate_rays(KParams prm, int iter,
         const float a = prm.pixLenX * sx;
         const float b = prm.pixLenY * sy;
         const F3 dir = normalize((view - right * a) - up * b);
-        out.a(0)[j] = prm.pos[0]; out.a(1)[j] = prm.pos[1]; out.a(2)[j] = prm.pos[2];
-        out.a(3)[j] = dir.x; out.a(4)[j] = dir.y; out.a(5)[j] = dir.z;
-        out.a(6)[j] = 1.0f; out.a(7)[j] = 1.0f; out.a(8)[j] = 1.0f;
-        out.pix()[j] = index;
-        out.rem()[j] = prm.traceDepth;
+        const int T = j / kBlock;
+        const int slot = (T % kSeg) * prm.segCap + (T / kSeg) * kBlock + (j - T * kBlock);
+        out.a(0)[slot] = prm.pos[0]; out.a(1)[slot] = prm.pos[1]; out.a(2)[slot] = prm.pos[2];
+        out.a(3)[slot] = dir.x; out.a(4)[slot] = dir.y; out.a(5)[slot] = dir.z;
+        out.a(6)[slot] = 1.0f; out.a(7)[slot] = 1.0f; out.a(8)[slot] = 1.0f;
+        out.pix()[slot] = index;
+        out.rem()[slot] = prm.traceDepth;
     }
 }
 
 // ---- one bounce: intersect + shade + accumulate + compact (spec S3-S8) -----------------------------
-// Persistent workgroups pull 256-path tiles by ticket until the bounce's queue is drained.
+// Persistent workgroups walk the 256-path tiles of the bounce's queue (the kSeg input segments laid
+// end to end), blockIdx-strided.  Survivors of tile T are appended to output segment T % kSeg:
+//   ranks inside the workgroup  = exclusive scan of the alive flags (ballot + mbcnt per wave,
+//                                 wave totals through LDS),
+//   base of the workgroup       = ONE atomicAdd on that segment's counter.
+// No workgroup ever waits for another one, so there is no residency / dispatch-order assumption.
+// Output segment T % kSeg receives at most ceil(tiles/kSeg) * 256 paths <= segCap (see pt_init).
 __global__ __launch_bounds__(kBlock) void k_bounce(KParams prm, int iter, int depth, int lastBounce,
-                                                   PathSoA in, PathSoA out, Ctrl *ctrl, unsigned long long *desc,
-                                                   unsigned long long *grp,
+                                                   PathSoA in, PathSoA out, Ctrl *ctrl,
                                                    const GeomDev *__restrict__ ggeoms,
                                                    const MaterialDev *__restrict__ gmats, float *image) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     GeomDev *sgeoms = reinterpret_cast<GeomDev *>(smem);
     MaterialDev *smats = reinterpret_cast<MaterialDev *>(smem + sizeof(GeomDev) * prm.ngeoms);
     uint32_t *s_misc = reinterpret_cast<uint32_t *>(smem + sizeof(GeomDev) * prm.ngeoms + sizeof(MaterialDev) * prm.nmats);
-    uint32_t *s_wave = s_misc;          // [kWaves]
-    uint32_t *s_excl = s_misc + kWaves; // [1]
-    uint32_t *s_tile = s_misc + kWaves + 1;   // [2], double-buffered ticket hand-off
+    uint32_t *s_wave = s_misc;           // [kWaves] alive count per wave
+    uint32_t *s_base = s_misc + kWaves;  // [1]      first output slot of this tile
+
+    // input queue: segment s holds cnt[s] paths = tiles [pre[s], pre[s+1]) of the global tile index
+    uint32_t cnt[kSeg], pre[kSeg + 1];
+    pre[0] = 0;
+    uint32_t nLive = 0;
+#pragma unroll
+    for (int sg = 0; sg < kSeg; ++sg) {
+        cnt[sg] = ctrl->seg_count[depth][sg][0];
+        pre[sg + 1] = pre[sg] + (cnt[sg] + kBlock - 1) / kBlock;
+        nLive += cnt[sg];
+    }
+    const uint32_t numTiles = pre[kSeg];
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctrl->sum_live[depth], (unsigned long long)nLive);
+    if (blockIdx.x >= numTiles) return;
 
     // stage the scene in LDS once per (persistent) workgroup, 16 B per lane per step
     {
@@ -224,18 +266,23 @@ __global__ __launch_bounds__(kBlock) void k_bounce(KParams prm, int iter, int de
         const int m16 = prm.nmats * (int)(sizeof(MaterialDev) / 16);
         for (int i = threadIdx.x; i < m16; i += kBlock) mdst[i] = msrc[i];
     }
-    const uint32_t nLive = ctrl->n_live[depth];
-    const int numTiles = (int)((nLive + kBlock - 1) / kBlock);
-
-    if (threadIdx.x == 0) s_tile[0] = atomicAdd(&ctrl->ticket[depth], 1u);
     __syncthreads();
-    for (int round = 0;; ++round) {
-        const int tile = (int)s_tile[round & 1];
-        if (tile >= numTiles) break;
-        if (tile == 0 && threadIdx.x == 0) atomicAdd(&ctrl->sum_live[depth], (unsigned long long)nLive);
 
-        const uint32_t idx = (uint32_t)tile * kBlock + threadIdx.x;
-        const bool valid = idx < nLive;
+    uint32_t waveLight = 0, waveMiss = 0;   // wave-uniform tallies, flushed once at the end
+    for (uint32_t T = blockIdx.x; T < numTiles; T += gridDim.x) {
+        // global tile -> (segment, local tile)
+        uint32_t sg = 0;
+#pragma unroll
+        for (int k = 1; k < kSeg; ++k) sg += T >= pre[k] ? 1u : 0u;
+        uint32_t segBase = 0, segCnt = cnt[0], segPre = 0;
+#pragma unroll
+        for (int k = 1; k < kSeg; ++k)
+            if (sg == (uint32_t)k) { segCnt = cnt[k]; segPre = pre[k]; }
+        segBase = sg * (uint32_t)prm.segCap;
+        const uint32_t local = (T - segPre) * kBlock + threadIdx.x;
+        const bool valid = local < segCnt;
+        const uint32_t idx = segBase + local;
+
         bool alive = false;
         bool lightHit = false, missed = false;
         F3 org = f3(0, 0, 0), dir = f3(0, 0, 1), col = f3(0, 0, 0);
@@ -246,11 +293,6 @@ __global__ __launch_bounds__(kBlock) void k_bounce(KParams prm, int iter, int de
             col = f3(in.a(6)[idx], in.a(7)[idx], in.a(8)[idx]);
             pix = in.pix()[idx];
             rem = in.rem()[idx];
-        }
-        // next tile's ticket: issued behind this tile's loads, its latency hides under the compute
-        uint32_t nextTile = 0;
-        if (threadIdx.x == 0) nextTile = atomicAdd(&ctrl->ticket[depth], 1u);
-        if (valid) {
 
             // nearest hit, geoms in file order, strict '<' so the first geom wins ties (S3)
             float tbest = 0.0f;
@@ -332,32 +374,40 @@ __global__ __launch_bounds__(kBlock) void k_bounce(KParams prm, int iter, int de
                 }
             }
         }
+        waveLight += (uint32_t)__popcll(__ballot(lightHit));
+        waveMiss += (uint32_t)__popcll(__ballot(missed));
 
-        // statistics: one atomic per wave
-        {
-            const unsigned long long bl = __ballot(lightHit), bm = __ballot(missed);
-            if ((threadIdx.x & 63) == 0) {
-                if (bl) atomicAdd(&ctrl->light_hits, (unsigned long long)__popcll(bl));
-                if (bm) atomicAdd(&ctrl->misses, (unsigned long long)__popcll(bm));
+        if (!lastBounce) {                                       // S8: compaction into `out`
+            const int wave = threadIdx.x >> 6;
+            const unsigned long long ballot = __ballot(alive);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32),
+                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, 0u));
+            if ((threadIdx.x & 63) == 0) s_wave[wave] = (uint32_t)__popcll(ballot);
+            __syncthreads();
+            uint32_t waveOff = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) {
+                const uint32_t c = s_wave[w];
+                waveOff += w < wave ? c : 0u;
+                total += c;
             }
-        }
-
-        if (!lastBounce) {                                       // S8: stable compaction into `out`
-            uint32_t tileEnd;
-            if (threadIdx.x == 0) s_tile[(round + 1) & 1] = nextTile;   // published by compact_slot's barriers
-            const uint32_t slot = compact_slot(alive, tile, desc, grp, s_wave, s_excl, &ctrl->error, &tileEnd);
+            const uint32_t oseg = T % kSeg;
+            if (threadIdx.x == 0) *s_base = total ? atomicAdd(&ctrl->seg_count[depth + 1][oseg][0], total) : 0u;
+            __syncthreads();
             if (alive) {
+                const uint32_t slot = oseg * (uint32_t)prm.segCap + *s_base + waveOff + rank;
                 out.a(0)[slot] = org.x; out.a(1)[slot] = org.y; out.a(2)[slot] = org.z;
                 out.a(3)[slot] = dir.x; out.a(4)[slot] = dir.y; out.a(5)[slot] = dir.z;
                 out.a(6)[slot] = col.x; out.a(7)[slot] = col.y; out.a(8)[slot] = col.z;
                 out.pix()[slot] = pix;
                 out.rem()[slot] = rem - 1;
             }
-            if (tile == numTiles - 1 && threadIdx.x == 0) ctrl->n_live[depth + 1] = tileEnd;
-        } else {
-            if (threadIdx.x == 0) s_tile[(round + 1) & 1] = nextTile;
-            __syncthreads();
         }
+    }
+    if ((threadIdx.x & 63) == 0) {
+        const int shard = blockIdx.x % kSeg;
+        if (waveLight) atomicAdd(&ctrl->light_hits[shard][0], (unsigned long long)waveLight);
+        if (waveMiss) atomicAdd(&ctrl->misses[shard][0], (unsigned long long)waveMiss);
     }
 }
 
@@ -550,9 +600,8 @@ struct State {
     GeomDev *dgeoms = nullptr;
     MaterialDev *dmats = nullptr;
     Ctrl *ctrl = nullptr;
-    unsigned long long *desc = nullptr;
-    int numTilesMax = 0;
-    int descStride = 0;     // 8-byte words per bounce: numTilesMax tile words + ceil(numTilesMax/64) group words
+    int numTilesMax = 0;    // upper bound of tiles in one bounce queue (incl. one partial tile per segment)
+    int segCap = 0;         // paths per segment; a path buffer holds kSeg * segCap paths per array
     int grid = 0;
     size_t ldsBytes = 0;
     long long iterations = 0;
@@ -620,8 +669,7 @@ int resolve_events(std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, double &ms
 }
 
 int launch_raygen(int iter) {
-    const PathSoA out = soa(S.pathbuf[0], S.nLocal);
-    const int ndesc = S.descStride * (S.prm.traceDepth + 1);
+    const PathSoA out = soa(S.pathbuf[0], kSeg * S.segCap);
     int blocks = (S.nLocal + kBlock - 1) / kBlock;
     if (blocks < 1) blocks = 1;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -630,7 +678,7 @@ int launch_raygen(int iter) {
         HIPCHECK(hipEventCreate(&e1));
         HIPCHECK(hipEventRecord(e0, S.stream));
     }
-    hipLaunchKernelGGL(k_generate_rays, dim3(blocks), dim3(kBlock), 0, S.stream, S.prm, iter, out, S.ctrl, S.desc, ndesc);
+    hipLaunchKernelGGL(k_generate_rays, dim3(blocks), dim3(kBlock), 0, S.stream, S.prm, iter, out, S.ctrl);
     if (e0) {
         HIPCHECK(hipEventRecord(e1, S.stream));
         S.evRaygen.emplace_back(e0, e1);
@@ -640,10 +688,8 @@ int launch_raygen(int iter) {
 }
 
 int launch_bounce(int iter, int depth, bool lastBounce, float *image) {
-    const PathSoA in = soa(S.pathbuf[(depth - 1) & 1], S.nLocal);
-    const PathSoA out = soa(S.pathbuf[depth & 1], S.nLocal);
-    unsigned long long *desc = S.desc + (size_t)depth * S.descStride;
-    unsigned long long *grp = desc + S.numTilesMax;
+    const PathSoA in = soa(S.pathbuf[(depth - 1) & 1], kSeg * S.segCap);
+    const PathSoA out = soa(S.pathbuf[depth & 1], kSeg * S.segCap);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (S.flags & PT_FLAG_KERNEL_TIMING) {
         HIPCHECK(hipEventCreate(&e0));
@@ -651,7 +697,7 @@ int launch_bounce(int iter, int depth, bool lastBounce, float *image) {
         HIPCHECK(hipEventRecord(e0, S.stream));
     }
     hipLaunchKernelGGL(k_bounce, dim3(S.grid), dim3(kBlock), S.ldsBytes, S.stream, S.prm, iter, depth,
-                       lastBounce ? 1 : 0, in, out, S.ctrl, desc, grp, S.dgeoms, S.dmats, image);
+                       lastBounce ? 1 : 0, in, out, S.ctrl, S.dgeoms, S.dmats, image);
     if (e0) {
         HIPCHECK(hipEventRecord(e1, S.stream));
         S.evBounce.emplace_back(e0, e1);
@@ -670,7 +716,7 @@ int check_device_fault() {
     uint32_t err = 0;
     HIPCHECK(hipMemcpyAsync(&err, &S.ctrl->error, sizeof err, hipMemcpyDeviceToHost, S.stream));
     HIPCHECK(hipStreamSynchronize(S.stream));
-    if (err) return fail(PT_ERR_DEVICE, "device fault: compaction look-back timed out");
+    if (err) return fail(PT_ERR_DEVICE, "device fault flag set");
     return PT_OK;
 }
 
@@ -743,7 +789,6 @@ void pt_free(void) {
     if (S.dgeoms) (void)hipFree(S.dgeoms);
     if (S.dmats) (void)hipFree(S.dmats);
     if (S.ctrl) (void)hipFree(S.ctrl);
-    if (S.desc) (void)hipFree(S.desc);
     S = State();
 }
 
@@ -807,7 +852,12 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
         S.ownImage = true;
         HIPCHECK(hipMemsetAsync(S.image, 0, (size_t)S.P * 3 * sizeof(float), S.stream));
     }
-    const size_t cap = S.nLocal > 0 ? S.nLocal : 1;
+    // Path buffers: kSeg segments.  Output segment T % kSeg of a bounce receives the survivors of at most
+    // ceil(tiles / kSeg) tiles, and tiles <= ceil(nLocal/256) + kSeg (one partial tile per input segment).
+    S.numTilesMax = (S.nLocal + kBlock - 1) / kBlock + kSeg;
+    S.segCap = ((S.numTilesMax + kSeg - 1) / kSeg) * kBlock;
+    k.segCap = S.segCap;
+    const size_t cap = (size_t)kSeg * S.segCap;
     for (int i = 0; i < 2; ++i) HIPCHECK(hipMalloc(&S.pathbuf[i], cap * kNumArrays * sizeof(float)));
 
     std::vector<GeomDev> hg(ngeoms ? ngeoms : 1);
@@ -819,12 +869,8 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     HIPCHECK(hipMemcpy(S.dgeoms, hg.data(), hg.size() * sizeof(GeomDev), hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(S.dmats, hm.data(), hm.size() * sizeof(MaterialDev), hipMemcpyHostToDevice));
 
-    S.numTilesMax = (int)((cap + kBlock - 1) / kBlock);
     HIPCHECK(hipMalloc(&S.ctrl, sizeof(Ctrl)));
     HIPCHECK(hipMemset(S.ctrl, 0, sizeof(Ctrl)));
-    S.descStride = S.numTilesMax + (S.numTilesMax + kGroup - 1) / kGroup;
-    HIPCHECK(hipMalloc(&S.desc, (size_t)S.descStride * (traceDepth + 2) * 8));
-    HIPCHECK(hipMemset(S.desc, 0, (size_t)S.descStride * (traceDepth + 2) * 8));
 
     S.ldsBytes = sizeof(GeomDev) * ngeoms + sizeof(MaterialDev) * nmats + 16 * sizeof(uint32_t);
     if (S.ldsBytes > 160 * 1024) return fail(PT_ERR_INVALID, "pt_init: scene does not fit the 160 KiB LDS (%zu B)", S.ldsBytes);
@@ -833,7 +879,8 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     int rc = persistent_grid(reinterpret_cast<const void *>(k_bounce), S.ldsBytes, &S.grid);
     if (rc) return rc;
     if (S.grid > S.numTilesMax) S.grid = S.numTilesMax;
-    if (S.grid < 1) S.grid = 1;
+    S.grid = (S.grid / kSeg) * kSeg;      // consecutive tiles of one workgroup cycle through all output segments
+    if (S.grid < kSeg) S.grid = kSeg;
     HIPCHECK(hipStreamSynchronize(S.stream));
     S.init = true;
     g_err.clear();
@@ -890,7 +937,7 @@ int pt_readback_rgba8(int iter, uint8_t *rgba_host) {
 int pt_counters(PtCounters *out) {
     if (!S.init) return fail(PT_ERR_NOT_INIT, "pt_counters before pt_init");
     if (!out) return fail(PT_ERR_INVALID, "pt_counters: null");
-    Ctrl h;
+    static Ctrl h;   // 100+ KB: keep it off the stack
     HIPCHECK(hipMemcpyAsync(&h, S.ctrl, sizeof h, hipMemcpyDeviceToHost, S.stream));
     HIPCHECK(hipStreamSynchronize(S.stream));
     int rc = resolve_events(S.evBounce, S.msBounce, S.nBounce);
@@ -899,14 +946,16 @@ int pt_counters(PtCounters *out) {
     if (rc) return rc;
     memset(out, 0, sizeof *out);
     for (int d = 0; d < kMaxDepthSlots; ++d) out->live[d] = (int64_t)h.sum_live[d];
-    out->light_hits = (int64_t)h.light_hits;
-    out->misses = (int64_t)h.misses;
+    for (int sg = 0; sg < kSeg; ++sg) {
+        out->light_hits += (int64_t)h.light_hits[sg][0];
+        out->misses += (int64_t)h.misses[sg][0];
+    }
     out->iterations = S.iterations;
     out->bounce_launches = S.nBounce;
     out->bounce_kernel_ms = S.msBounce;
     out->raygen_kernel_ms = S.msRaygen;
     out->raygen_launches = S.nRaygen;
-    if (h.error) return fail(PT_ERR_DEVICE, "device fault: compaction look-back timed out");
+    if (h.error) return fail(PT_ERR_DEVICE, "device fault flag set");
     return PT_OK;
 }
 
@@ -935,24 +984,40 @@ int pt_debug_trace_paths(int iter, int bounces, float *origin3, float *dir3, flo
         rc = launch_bounce(iter, d, false, nullptr);  // no accumulation, survivors always written
         if (rc) return rc;
     }
-    uint32_t n = 0;
-    HIPCHECK(hipMemcpyAsync(&n, &S.ctrl->n_live[bounces + 1], 4, hipMemcpyDeviceToHost, S.stream));
+    // gather the kSeg segments of the queue entering bounce `bounces + 1`, then sort by pixel index
+    uint32_t segn[kSeg];
+    for (int sg = 0; sg < kSeg; ++sg)
+        HIPCHECK(hipMemcpyAsync(&segn[sg], &S.ctrl->seg_count[bounces + 1][sg][0], 4, hipMemcpyDeviceToHost, S.stream));
     HIPCHECK(hipStreamSynchronize(S.stream));
     rc = check_device_fault();
     if (rc) return rc;
+    size_t n = 0;
+    for (int sg = 0; sg < kSeg; ++sg) n += segn[sg];
     *count = (int32_t)n;
     if (n == 0) return PT_OK;
-    std::vector<float> h((size_t)n);
-    const PathSoA s = soa(S.pathbuf[bounces & 1], S.nLocal);
-    float *dst[3] = {origin3, dir3, color3};
-    for (int grp = 0; grp < 3; ++grp) {
-        if (!dst[grp]) continue;
-        for (int c = 0; c < 3; ++c) {
-            HIPCHECK(hipMemcpy(h.data(), s.a(grp * 3 + c), (size_t)n * 4, hipMemcpyDeviceToHost));
-            for (uint32_t i = 0; i < n; ++i) dst[grp][3 * (size_t)i + c] = h[i];
+    const PathSoA sb = soa(S.pathbuf[bounces & 1], kSeg * S.segCap);
+    std::vector<float> cols[kNumArrays];
+    for (int k = 0; k < kNumArrays; ++k) {
+        cols[k].resize(n);
+        size_t off = 0;
+        for (int sg = 0; sg < kSeg; ++sg) {
+            if (segn[sg])
+                HIPCHECK(hipMemcpy(cols[k].data() + off, sb.a(k) + (size_t)sg * S.segCap, (size_t)segn[sg] * 4, hipMemcpyDeviceToHost));
+            off += segn[sg];
         }
     }
-    if (pixelIndex) HIPCHECK(hipMemcpy(pixelIndex, s.pix(), (size_t)n * 4, hipMemcpyDeviceToHost));
+    const int *pixcol = reinterpret_cast<const int *>(cols[9].data());
+    std::vector<size_t> order(n);
+    for (size_t i = 0; i < n; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return pixcol[x] < pixcol[y]; });
+    float *dst[3] = {origin3, dir3, color3};
+    for (size_t i = 0; i < n; ++i) {
+        const size_t src = order[i];
+        for (int grp = 0; grp < 3; ++grp)
+            if (dst[grp])
+                for (int c = 0; c < 3; ++c) dst[grp][3 * i + c] = cols[grp * 3 + c][src];
+        if (pixelIndex) pixelIndex[i] = pixcol[src];
+    }
     return PT_OK;
 }
 
