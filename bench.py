@@ -82,12 +82,11 @@ def main():
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the hot path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-
     import __graft_entry__ as ge
     pt = ge.load_package()
+    ptdist = ge.load_submodule("distributed")
+    if world > 1:
+        ptdist.init_process_group("nccl")
 
     W, H = args.res
     scene = pt.Scene(args.scene)
@@ -107,8 +106,7 @@ def main():
         pt.pathtrace(None, 0, it, readback=False)
         if world > 1:
             # the single collective of the data path: per-iteration reduce of the accumulator over xGMI
-            frame.copy_(accum)
-            dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM)
+            ptdist.reduce_frame(accum, frame, dst=0)
 
     def barrier():
         if world > 1:

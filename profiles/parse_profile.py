@@ -1,0 +1,128 @@
+#!/usr/bin/env python3
+"""Distil gpurun_out/prof_<tag>/ (rocprofv3 output of profiles/run_profile.sh) into profiles/:
+
+    profiles/<tag>_kernel_stats.csv      verbatim rocprofv3 --kernel-trace --stats summary
+    profiles/<tag>_one_iteration.txt     per-dispatch durations of one iteration (per-bounce)
+    profiles/<tag>_pmc_summary.json      PMC counters per kernel, per dispatch
+    profiles/pmc_traffic.json            {"hbm_bytes_per_bounce_launch": ...} read by bench.py
+
+HBM traffic per launch = FETCH_SIZE * 1024 * read_factor + WRITE_SIZE * 1024 (both counters are in KiB).
+read_factor is CALIBRATED on this access pattern (4 B per lane SoA reads): the first bounce launch of
+every iteration reads exactly 44 B x P of path state, so factor = known bytes / counted bytes
+(MI355X_MICROARCH.md, section HBM: FETCH_SIZE under-counts coalesced streams by 2x on gfx950; calibrate).
+WRITE_SIZE is checked the same way on the ray-generation kernel (44 B x P written).
+
+    python profiles/parse_profile.py <tag> [--pixels 921600]
+"""
+import argparse
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def kind(name):
+    if "k_bounce" in name:
+        return "k_bounce"
+    if "k_generate_rays" in name:
+        return "k_generate_rays"
+    if "k_to_rgba8" in name:
+        return "k_to_rgba8"
+    return "other"
+
+
+def load_pmc(d):
+    files = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))
+    return list(csv.DictReader(open(files[0]))) if files else []
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("tag")
+    ap.add_argument("--pixels", type=int, default=1280 * 720)
+    ap.add_argument("--depth", type=int, default=8)
+    args = ap.parse_args()
+    src = os.path.join(ROOT, "gpurun_out", "prof_" + args.tag)
+    out = {}
+
+    stats = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))
+    if stats:
+        shutil.copy(stats[0], os.path.join(HERE, args.tag + "_kernel_stats.csv"))
+        txt = subprocess.run([sys.executable, os.path.join(HERE, "trace_summary.py"), os.path.join(src, "trace")],
+                             capture_output=True, text=True).stdout
+        open(os.path.join(HERE, args.tag + "_one_iteration.txt"), "w").write(txt)
+        for r in csv.DictReader(open(stats[0])):
+            k = kind(r["Name"])
+            if k != "other":
+                out.setdefault(k, {})["trace_avg_ns"] = float(r["AverageNs"])
+                out[k]["trace_calls"] = int(r["Calls"])
+
+    per_dispatch = collections.defaultdict(dict)   # (pass, dispatch id) -> counters
+    for p in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds"):
+        rows = load_pmc(os.path.join(src, p))
+        agg = collections.defaultdict(lambda: collections.defaultdict(float))
+        n = collections.Counter()
+        for r in rows:
+            k = kind(r["Kernel_Name"])
+            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            n[(k, r["Counter_Name"])] += 1
+            per_dispatch[(p, int(r["Dispatch_Id"]))][r["Counter_Name"]] = float(r["Counter_Value"])
+            per_dispatch[(p, int(r["Dispatch_Id"]))]["_kind"] = k
+        for k in agg:
+            if k == "other":
+                continue
+            for c, v in agg[k].items():
+                out.setdefault(k, {}).setdefault("pmc_per_dispatch", {})[c] = v / n[(k, c)]
+                out[k].setdefault("pmc_dispatches", {})[c] = n[(k, c)]
+
+    # ---- calibration of FETCH_SIZE / WRITE_SIZE on known byte counts -------------------------------------
+    known = 44.0 * args.pixels
+    fetch = sorted((d, v) for (p, d), v in per_dispatch.items() if p == "pmc_fetch")
+    first_bounce, prev = [], None
+    for d, v in fetch:
+        if v["_kind"] == "k_bounce" and prev == "k_generate_rays":
+            first_bounce.append(v["FETCH_SIZE"] * 1024.0)
+        prev = v["_kind"]
+    cal = {}
+    if first_bounce:
+        counted = sum(first_bounce) / len(first_bounce)
+        cal["first_bounce_fetch_counted_bytes"] = counted
+        cal["first_bounce_known_read_bytes"] = known
+        cal["read_factor"] = known / counted
+    wr = [v["WRITE_SIZE"] * 1024.0 for (p, d), v in per_dispatch.items() if p == "pmc_write" and v["_kind"] == "k_generate_rays"]
+    if wr:
+        cal["raygen_write_counted_bytes"] = sum(wr) / len(wr)
+        cal["raygen_known_write_bytes"] = known
+        cal["write_factor"] = known / (sum(wr) / len(wr))
+    out["calibration"] = cal
+
+    kb = out.get("k_bounce", {}).get("pmc_per_dispatch", {})
+    if "FETCH_SIZE" in kb and "WRITE_SIZE" in kb:
+        rf = cal.get("read_factor", 1.0)
+        # snap to the two documented regimes (exact, or the 2x under-count of coalesced streams)
+        rf_used = 2.0 if rf > 1.5 else 1.0
+        traffic = kb["FETCH_SIZE"] * 1024.0 * rf_used + kb["WRITE_SIZE"] * 1024.0
+        out["k_bounce"]["hbm_bytes_per_launch"] = traffic
+        out["k_bounce"]["read_factor_used"] = rf_used
+        json.dump({"hbm_bytes_per_bounce_launch": round(traffic, 1), "read_factor_used": rf_used,
+                   "read_factor_calibrated": rf, "write_factor_calibrated": cal.get("write_factor"),
+                   "source": "profiles/%s_pmc_summary.json" % args.tag},
+                  open(os.path.join(HERE, "pmc_traffic.json"), "w"), indent=1)
+    if "SQ_LDS_BANK_CONFLICT" in kb:
+        out["k_bounce"]["lds_bank_conflict_cycles_per_launch"] = kb["SQ_LDS_BANK_CONFLICT"]
+        out["k_bounce"]["lds_bank_conflict_fraction"] = kb["SQ_LDS_BANK_CONFLICT"] / max(kb.get("SQ_LDS_IDX_ACTIVE", 1.0), 1.0)
+    if "SQ_WAVE_CYCLES" in kb:
+        out["k_bounce"]["wave_wait_fraction"] = kb["SQ_WAIT_ANY"] / kb["SQ_WAVE_CYCLES"]
+    json.dump(out, open(os.path.join(HERE, args.tag + "_pmc_summary.json"), "w"), indent=1, sort_keys=True)
+    print(json.dumps(out, indent=1, sort_keys=True))
+
+
+if __name__ == "__main__":
+    main()

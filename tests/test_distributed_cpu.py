@@ -1,0 +1,73 @@
+"""World-size-2 test of the N>1 path on CPU (gloo): row sharding + the single reduce of the frame.
+
+No GPU here, so each rank renders ITS rows with the CPU oracle (checker standing in for the kernels)
+into a zeroed full frame and then runs the SAME `reduce_frame` bench.py uses; rank 0 must end up with
+a frame that is bit-identical to the unsharded render after every iteration."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, SCENES
+
+
+def _worker(rank, world, port, res, iters, out_path):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch
+    import __graft_entry__ as ge
+    import oracle as orc
+    ptdist = ge.load_submodule("distributed")
+    r, w = ptdist.init_process_group("gloo")
+    assert (r, w) == (rank, world)
+    W, H = res
+    sc = orc.Scene(os.path.join(SCENES, "cornell.txt"))
+    sc.set_resolution(W, H)
+    ren = orc.Renderer(sc.camera, sc.geoms, sc.materials, 8)
+    accum = torch.zeros(W * H * 3, dtype=torch.float32)
+    frame = torch.zeros_like(accum)
+    full = np.zeros(W * H * 3, np.float32)
+    ok = True
+    npix = 0
+    for it in iters:
+        c = ren.iterate(it, accum.numpy(), rank, world)          # this rank's rows only
+        npix = c.live[1]
+        ptdist.reduce_frame(accum, frame, dst=0)
+        if rank == 0:
+            ren.iterate(it, full)
+            ok = ok and np.array_equal(frame.numpy().view(np.uint32), full.view(np.uint32))
+    assert npix == ptdist.local_pixel_count(W, H, rank, world)
+    rows = accum.numpy().reshape(H, W, 3)
+    mine = np.zeros(H, bool)
+    mine[list(ptdist.shard_rows(H, rank, world))] = True
+    assert not np.any(rows[~mine])                               # other ranks' rows stay exactly zero
+    if rank == 0:
+        np.save(out_path, np.array([1 if ok else 0]))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_ranks_gloo_assemble_the_frame_bit_exactly(tmp_path):
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "ok.npy")
+    mp.spawn(_worker, args=(2, port, (48, 37), [1, 2, 3], out), nprocs=2, join=True)
+    assert np.load(out)[0] == 1
+
+
+def test_shard_rows_partition():
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge
+    d = ge.load_submodule("distributed")
+    for H in (1, 7, 8, 720, 1080, 4096):
+        for world in (1, 2, 3, 4, 8):
+            rows = sorted(y for r in range(world) for y in d.shard_rows(H, r, world))
+            assert rows == list(range(H))
+            counts = [len(d.shard_rows(H, r, world)) for r in range(world)]
+            assert max(counts) - min(counts) <= 1
