@@ -147,11 +147,11 @@ def main():
     D = args.depth
     live = [int(cnt.live[d]) for d in range(D + 2)]
     hits = int(cnt.light_hits)
-    # algorithmic HBM bytes of the bounce launches: read every live path, write every survivor
-    # (nothing is written after the last bounce), read+write the accumulator for every emitter hit
-    bounce_bytes = sum(PATH_BYTES * live[d] for d in range(1, D + 1)) \
+    # algorithmic HBM bytes of the bounce launches: read every live path (bounce 1 builds its camera
+    # rays in registers and reads nothing), write every survivor (nothing is written after the last
+    # bounce), read+write the accumulator for every emitter hit
+    bounce_bytes = sum(PATH_BYTES * live[d] for d in range(2, D + 1)) \
         + sum(PATH_BYTES * live[d + 1] for d in range(1, D)) + ACCUM_BYTES * hits
-    raygen_bytes = PATH_BYTES * live[1]
     launches = max(int(cnt.bounce_launches), 1)
     avg_ms = cnt.bounce_kernel_ms / launches
     achieved = bounce_bytes / launches / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
@@ -176,15 +176,13 @@ def main():
                        "paths_per_step_nominal": P * D,
                        "live_segments_per_step": round(sum(live[1:D + 1]) / max(args.steps, 1), 1),
                        "live_Msegments_per_s": round(sum(int(cntA.live[d]) for d in range(1, D + 1)) / dt / 1e6, 2)},
-            "roofline": {"bound": "hbm", "kernel": "k_bounce (fused intersect+shade+compact, one launch per bounce)",
+            "roofline": {"bound": "hbm", "kernel": "k_bounce (fused [camera rays+]intersect+shade+compact, one launch per bounce)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": traffic,
                          "algorithmic_bytes_per_launch": round(bounce_bytes / launches, 1),
                          "avg_launch_ms": round(avg_ms, 5), "launches": launches,
                          "bounce_kernel_share_of_step": round(cnt.bounce_kernel_ms / (dtB * 1e3), 4),
-                         "raygen_avg_ms": round(cnt.raygen_kernel_ms / max(int(cnt.raygen_launches), 1), 5),
-                         "raygen_GBps": round(raygen_bytes / max(cnt.raygen_kernel_ms, 1e-9) / 1e6, 2),
                          "ms_per_step_with_events": round(dtB / args.steps * 1e3, 4)},
         }
         if world == 1 and args.cpu_spp > 0:

@@ -31,7 +31,7 @@ ROOT = os.path.dirname(HERE)
 def kind(name):
     if "k_bounce" in name:
         return "k_bounce"
-    if "k_generate_rays" in name:
+    if "k_generate_rays" in name or "k_bounce<true>" in name and False:
         return "k_generate_rays"
     if "k_to_rgba8" in name:
         return "k_to_rgba8"

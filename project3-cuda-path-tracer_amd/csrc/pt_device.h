@@ -166,38 +166,62 @@ struct Hit {
 };
 
 // src/intersections.h:47-89
+//
+// Early miss (exact, not a heuristic): if on some axis the object-space origin lies beyond a face
+// (o > .5 or o < -.5) and the ray moves further away (d has the sign of o), then in the reference's
+// slab loop both quotients t1, t2 of that axis are <= -0 (a non-zero numerator over a divisor of the
+// opposite sign; +-0 and inf divisors included, NaN impossible), so tb <= -0 updates tmax to a value
+// <= 0 and the final `tmax > 0` fails whatever the other axes do: the test returns -1.  The sign of
+// every component of normalize(v) equals the sign of v's component (the scale 1/sqrt(dot) is >= 0 or
+// NaN, and NaN fails the comparisons below), so the decision is taken BEFORE the normalisation and
+// the six correctly rounded divisions.  It only pays when whole waves take it, i.e. for coherent
+// rays (EARLY_MISS is set for the camera-ray bounce); results are identical either way.
+template <bool EARLY_MISS>
 __device__ __forceinline__ float boxIntersectionTest(const GeomDev &g, F3 ro, F3 rd, F3 &P, F3 &N, bool &outside) {
-    F3 qo = mulMV(g.inv, ro, 1.0f);
-    F3 qd = normalize(mulMV(g.inv, rd, 0.0f));
+    const F3 qo = mulMV(g.inv, ro, 1.0f);
+    const F3 qdu = mulMV(g.inv, rd, 0.0f);
+    if (EARLY_MISS) {
+        const bool away = (qo.x > 0.5f && qdu.x > 0.0f) || (qo.x < -0.5f && qdu.x < 0.0f) ||
+                          (qo.y > 0.5f && qdu.y > 0.0f) || (qo.y < -0.5f && qdu.y < 0.0f) ||
+                          (qo.z > 0.5f && qdu.z > 0.0f) || (qo.z < -0.5f && qdu.z < 0.0f);
+        if (away) return -1.0f;
+    }
+    const F3 qd = normalize(qdu);
     float tmin = -1e38f, tmax = 1e38f;
-    F3 tmin_n = f3(0, 0, 0), tmax_n = f3(0, 0, 0);
+    // the slab normal n (zero except n[xyz] = +-1) is tracked as axis + value instead of a vector
+    int tmin_axis = -1, tmax_axis = -1;
+    float tmin_nv = 0.0f, tmax_nv = 0.0f;
     const float qoa[3] = {qo.x, qo.y, qo.z};
     const float qda[3] = {qd.x, qd.y, qd.z};
 #pragma unroll
     for (int xyz = 0; xyz < 3; ++xyz) {
-        float qdxyz = qda[xyz];
-        float t1 = (-0.5f - qoa[xyz]) / qdxyz;
-        float t2 = (+0.5f - qoa[xyz]) / qdxyz;
-        float ta = t1 < t2 ? t1 : t2;  // glm::min, func_common.inl:409-414
-        float tb = t1 > t2 ? t1 : t2;  // glm::max, func_common.inl:430-435
-        float nv = t2 < t1 ? +1.0f : -1.0f;
-        F3 n = f3(xyz == 0 ? nv : 0.0f, xyz == 1 ? nv : 0.0f, xyz == 2 ? nv : 0.0f);
+        const float qdxyz = qda[xyz];
+        const float t1 = (-0.5f - qoa[xyz]) / qdxyz;
+        const float t2 = (+0.5f - qoa[xyz]) / qdxyz;
+        const float ta = t1 < t2 ? t1 : t2;  // glm::min, func_common.inl:409-414
+        const float tb = t1 > t2 ? t1 : t2;  // glm::max, func_common.inl:430-435
+        const float nv = t2 < t1 ? +1.0f : -1.0f;
         if (ta > 0 && ta > tmin) {
             tmin = ta;
-            tmin_n = n;
+            tmin_axis = xyz;
+            tmin_nv = nv;
         }
         if (tb < tmax) {
             tmax = tb;
-            tmax_n = n;
+            tmax_axis = xyz;
+            tmax_nv = nv;
         }
     }
     if (tmax >= tmin && tmax > 0) {
         outside = true;
         if (tmin <= 0) {
             tmin = tmax;
-            tmin_n = tmax_n;
+            tmin_axis = tmax_axis;
+            tmin_nv = tmax_nv;
             outside = false;
         }
+        const F3 tmin_n = f3(tmin_axis == 0 ? tmin_nv : 0.0f, tmin_axis == 1 ? tmin_nv : 0.0f,
+                             tmin_axis == 2 ? tmin_nv : 0.0f);
         P = mulMV(g.xf, getPointOnRay(qo, qd, tmin), 1.0f);
         N = normalize(mulMV(g.xf, tmin_n, 0.0f));
         return length(ro - P);

@@ -41,9 +41,10 @@ constexpr int kSeg = 8;              // path buffers are split into kSeg segment
 constexpr int kCtrPad = 32;          // one counter per 128-byte line: same-line atomics serialise at the memory side
 
 struct Ctrl {
-    // re-armed by the ray-generation kernel every iteration:
-    // seg_count[d][s][0] = paths in segment s entering bounce d
-    uint32_t seg_count[kMaxDepthSlots][kSeg][kCtrPad];
+    // seg_count[p][d][s][0] = paths in segment s entering bounce d of an iteration with parity p.
+    // The last bounce launch of an iteration zeroes the OTHER parity, i.e. re-arms the next iteration,
+    // so an iteration needs neither a memset nor a separate re-arm launch.
+    uint32_t seg_count[2][kMaxDepthSlots][kSeg][kCtrPad];
     // never zeroed by an iteration
     uint32_t error;                    // sticky device fault (scan-library look-back timeout)
     uint32_t pad[kCtrPad - 1];
@@ -173,53 +174,36 @@ __device__ __forceinline__ uint32_t compact_slot(bool flag, int tile, unsigned l
     return excl + wave_off + rank;
 }
 
-// ---- camera rays (spec S2) + per-iteration re-arm of the control block ----------------------------
-// Path j goes to tile T = j/256, which lives in segment T % kSeg at local tile T / kSeg.
-__global__ __launch_bounds__(kBlock) void k_generate_rays(KParams prm, int iter, PathSoA out, Ctrl *ctrl) {
-    const int gtid = blockIdx.x * kBlock + threadIdx.x;
-    const int gsize = gridDim.x * kBlock;
-    {
-        uint32_t *cnt = &ctrl->seg_count[0][0][0];
-        const int nwords = (prm.traceDepth + 2) * kSeg * kCtrPad;
-        const int tilesTotal = (prm.nLocal + kBlock - 1) / kBlock;
-        for (int i = gtid; i < nwords; i += gsize) {
-            uint32_t v = 0;
-            const int d = i / (kSeg * kCtrPad), r = i - d * (kSeg * kCtrPad);
-            const int sgm = r / kCtrPad;
-            if (d == 1 && r - sgm * kCtrPad == 0) {
-                // paths of the tiles T = sgm, sgm + kSeg, ... (only the globally last tile can be partial)
-                const int nt = tilesTotal > sgm ? (tilesTotal - sgm + kSeg - 1) / kSeg : 0;
-                int n = nt * kBlock;
-                if (nt > 0 && (tilesTotal - 1) % kSeg == sgm) n -= tilesTotal * kBlock - prm.nLocal;
-                v = (uint32_t)n;
-            }
-            cnt[i] = v;
-        }
-    }
+// ---- camera ray of the j-th pixel of this shard (spec S2) ------------------------------------------
+__device__ __forceinline__ void cameraRay(const KParams &prm, int iter, int j, int &pix, F3 &org, F3 &dir) {
+    const int lr = j / prm.W;
+    const int x = j - lr * prm.W;
+    const int y = lr * prm.shardCount + prm.shardRank;
+    pix = x + y * prm.W;
+    Rng rng = makeSeededRandomEngine(iter, pix, 0);
+    const float jx = u01(rng);
+    const float jy = u01(rng);
+    const float sx = ((float)x + jx) - prm.halfW;
+    const float sy = ((float)y + jy) - prm.halfH;
+    const float a = prm.pixLenX * sx;
+    const float b = prm.pixLenY * sy;
     const F3 view = f3(prm.view[0], prm.view[1], prm.view[2]);
     const F3 up = f3(prm.up[0], prm.up[1], prm.up[2]);
     const F3 right = f3(prm.right[0], prm.right[1], prm.right[2]);
-    for (int j = gtid; j < prm.nLocal; j += gsize) {
-        const int lr = j / prm.W;
-        const int x = j - lr * prm.W;
-        const int y = lr * prm.shardCount + prm.shardRank;
-        const int index = x + y * prm.W;
-        Rng rng = makeSeededRandomEngine(iter, index, 0);
-        const float jx = u01(rng);
-        const float jy = u01(rng);
-        const float sx = ((float)x + jx) - prm.halfW;
-        const float sy = ((float)y + jy) - prm.halfH;
-        const float a = prm.pixLenX * sx;
-        const float b = prm.pixLenY * sy;
-        const F3 dir = normalize((view - right * a) - up * b);
-        const int T = j / kBlock;
-        const int slot = (T % kSeg) * prm.segCap + (T / kSeg) * kBlock + (j - T * kBlock);
-        out.a(0)[slot] = prm.pos[0]; out.a(1)[slot] = prm.pos[1]; out.a(2)[slot] = prm.pos[2];
-        out.a(3)[slot] = dir.x; out.a(4)[slot] = dir.y; out.a(5)[slot] = dir.z;
-        out.a(6)[slot] = 1.0f; out.a(7)[slot] = 1.0f; out.a(8)[slot] = 1.0f;
-        out.pix()[slot] = index;
-        out.rem()[slot] = prm.traceDepth;
-    }
+    org = f3(prm.pos[0], prm.pos[1], prm.pos[2]);
+    dir = normalize((view - right * a) - up * b);
+}
+
+// camera rays alone, for pt_debug_trace_paths(bounces = 0)
+__global__ __launch_bounds__(kBlock) void k_debug_camera_rays(KParams prm, int iter, float *o3, float *d3, int *pixOut) {
+    const int j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= prm.nLocal) return;
+    int pix;
+    F3 org, dir;
+    cameraRay(prm, iter, j, pix, org, dir);
+    o3[3 * j] = org.x; o3[3 * j + 1] = org.y; o3[3 * j + 2] = org.z;
+    d3[3 * j] = dir.x; d3[3 * j + 1] = dir.y; d3[3 * j + 2] = dir.z;
+    pixOut[j] = pix;
 }
 
 // ---- one bounce: intersect + shade + accumulate + compact (spec S3-S8) -----------------------------
@@ -230,7 +214,12 @@ __global__ __launch_bounds__(kBlock) void k_generate_rays(KParams prm, int iter,
 //   base of the workgroup       = ONE atomicAdd on that segment's counter.
 // No workgroup ever waits for another one, so there is no residency / dispatch-order assumption.
 // Output segment T % kSeg receives at most ceil(tiles/kSeg) * 256 paths <= segCap (see pt_init).
-__global__ __launch_bounds__(kBlock) void k_bounce(KParams prm, int iter, int depth, int lastBounce,
+//
+// FIRST = true is bounce 1 fused with camera-ray generation (spec S2): tile T holds the paths
+// j = 256 T + lane of this shard's pixel list and the ray is built in registers, so the first bounce
+// reads no path state at all.
+template <bool FIRST>
+__global__ __launch_bounds__(kBlock) void k_bounce(KParams prm, int iter, int depth, int lastBounce, int parity,
                                                    PathSoA in, PathSoA out, Ctrl *ctrl,
                                                    const GeomDev *__restrict__ ggeoms,
                                                    const MaterialDev *__restrict__ gmats, float *image) {
@@ -241,15 +230,27 @@ __global__ __launch_bounds__(kBlock) void k_bounce(KParams prm, int iter, int de
     uint32_t *s_wave = s_misc;           // [kWaves] alive count per wave
     uint32_t *s_base = s_misc + kWaves;  // [1]      first output slot of this tile
 
+    if (lastBounce) {   // re-arm the next iteration: nobody touches the other parity's counters now
+        uint32_t *other = &ctrl->seg_count[parity ^ 1][0][0][0];
+        const int nwords = (prm.traceDepth + 2) * kSeg * kCtrPad;
+        for (int i = blockIdx.x * kBlock + threadIdx.x; i < nwords; i += gridDim.x * kBlock) other[i] = 0u;
+    }
     // input queue: segment s holds cnt[s] paths = tiles [pre[s], pre[s+1]) of the global tile index
     uint32_t cnt[kSeg], pre[kSeg + 1];
     pre[0] = 0;
     uint32_t nLive = 0;
+    if (FIRST) {
+        nLive = (uint32_t)prm.nLocal;
 #pragma unroll
-    for (int sg = 0; sg < kSeg; ++sg) {
-        cnt[sg] = ctrl->seg_count[depth][sg][0];
-        pre[sg + 1] = pre[sg] + (cnt[sg] + kBlock - 1) / kBlock;
-        nLive += cnt[sg];
+        for (int sg = 0; sg < kSeg; ++sg) { cnt[sg] = 0; pre[sg + 1] = 0; }
+        pre[kSeg] = (nLive + kBlock - 1) / kBlock;
+    } else {
+#pragma unroll
+        for (int sg = 0; sg < kSeg; ++sg) {
+            cnt[sg] = ctrl->seg_count[parity][depth][sg][0];
+            pre[sg + 1] = pre[sg] + (cnt[sg] + kBlock - 1) / kBlock;
+            nLive += cnt[sg];
+        }
     }
     const uint32_t numTiles = pre[kSeg];
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctrl->sum_live[depth], (unsigned long long)nLive);
@@ -270,29 +271,41 @@ __global__ __launch_bounds__(kBlock) void k_bounce(KParams prm, int iter, int de
 
     uint32_t waveLight = 0, waveMiss = 0;   // wave-uniform tallies, flushed once at the end
     for (uint32_t T = blockIdx.x; T < numTiles; T += gridDim.x) {
-        // global tile -> (segment, local tile)
-        uint32_t sg = 0;
+        bool valid;
+        uint32_t idx = 0;
+        if (FIRST) {
+            idx = T * kBlock + threadIdx.x;                     // position in this shard's pixel list
+            valid = idx < nLive;
+        } else {
+            // global tile -> (segment, local tile)
+            uint32_t sg = 0;
 #pragma unroll
-        for (int k = 1; k < kSeg; ++k) sg += T >= pre[k] ? 1u : 0u;
-        uint32_t segBase = 0, segCnt = cnt[0], segPre = 0;
+            for (int k = 1; k < kSeg; ++k) sg += T >= pre[k] ? 1u : 0u;
+            uint32_t segCnt = cnt[0], segPre = 0;
 #pragma unroll
-        for (int k = 1; k < kSeg; ++k)
-            if (sg == (uint32_t)k) { segCnt = cnt[k]; segPre = pre[k]; }
-        segBase = sg * (uint32_t)prm.segCap;
-        const uint32_t local = (T - segPre) * kBlock + threadIdx.x;
-        const bool valid = local < segCnt;
-        const uint32_t idx = segBase + local;
+            for (int k = 1; k < kSeg; ++k)
+                if (sg == (uint32_t)k) { segCnt = cnt[k]; segPre = pre[k]; }
+            const uint32_t local = (T - segPre) * kBlock + threadIdx.x;
+            valid = local < segCnt;
+            idx = sg * (uint32_t)prm.segCap + local;
+        }
 
         bool alive = false;
         bool lightHit = false, missed = false;
         F3 org = f3(0, 0, 0), dir = f3(0, 0, 1), col = f3(0, 0, 0);
         int pix = 0, rem = 0;
         if (valid) {
-            org = f3(in.a(0)[idx], in.a(1)[idx], in.a(2)[idx]);
-            dir = f3(in.a(3)[idx], in.a(4)[idx], in.a(5)[idx]);
-            col = f3(in.a(6)[idx], in.a(7)[idx], in.a(8)[idx]);
-            pix = in.pix()[idx];
-            rem = in.rem()[idx];
+            if (FIRST) {
+                cameraRay(prm, iter, (int)idx, pix, org, dir);
+                col = f3(1.0f, 1.0f, 1.0f);
+                rem = prm.traceDepth;
+            } else {
+                org = f3(in.a(0)[idx], in.a(1)[idx], in.a(2)[idx]);
+                dir = f3(in.a(3)[idx], in.a(4)[idx], in.a(5)[idx]);
+                col = f3(in.a(6)[idx], in.a(7)[idx], in.a(8)[idx]);
+                pix = in.pix()[idx];
+                rem = in.rem()[idx];
+            }
 
             // nearest hit, geoms in file order, strict '<' so the first geom wins ties (S3)
             float tbest = 0.0f;
@@ -306,7 +319,7 @@ __global__ __launch_bounds__(kBlock) void k_bounce(KParams prm, int iter, int de
                 bool o = false;
                 float t;
                 if (type == 0) t = sphereIntersectionTest(G, org, dir, p, n, o);
-                else           t = boxIntersectionTest(G, org, dir, p, n, o);
+                else           t = boxIntersectionTest<FIRST>(G, org, dir, p, n, o);
                 if (t > 0.0f && (hit < 0 || t < tbest)) {
                     tbest = t; hit = g; P = p; N = n; outside = o;
                 }
@@ -392,7 +405,7 @@ __global__ __launch_bounds__(kBlock) void k_bounce(KParams prm, int iter, int de
                 total += c;
             }
             const uint32_t oseg = T % kSeg;
-            if (threadIdx.x == 0) *s_base = total ? atomicAdd(&ctrl->seg_count[depth + 1][oseg][0], total) : 0u;
+            if (threadIdx.x == 0) *s_base = total ? atomicAdd(&ctrl->seg_count[parity][depth + 1][oseg][0], total) : 0u;
             __syncthreads();
             if (alive) {
                 const uint32_t slot = oseg * (uint32_t)prm.segCap + *s_base + waveOff + rank;
@@ -537,7 +550,9 @@ __global__ void k_test_intersect(const GeomDev *geoms, const int *gidx, const fl
     F3 P = f3(p3[3 * i], p3[3 * i + 1], p3[3 * i + 2]);
     F3 N = f3(n3[3 * i], n3[3 * i + 1], n3[3 * i + 2]);
     bool o = outside[i] != 0;
-    t[i] = G.type == 0 ? sphereIntersectionTest(G, ro, rd, P, N, o) : boxIntersectionTest(G, ro, rd, P, N, o);
+    // odd lanes take the early-miss variant so both instantiations are checked against the golden vectors
+    t[i] = G.type == 0 ? sphereIntersectionTest(G, ro, rd, P, N, o)
+         : ((i & 1) ? boxIntersectionTest<true>(G, ro, rd, P, N, o) : boxIntersectionTest<false>(G, ro, rd, P, N, o));
     p3[3 * i] = P.x; p3[3 * i + 1] = P.y; p3[3 * i + 2] = P.z;
     n3[3 * i] = N.x; n3[3 * i + 1] = N.y; n3[3 * i + 2] = N.z;
     outside[i] = o ? 1 : 0;
@@ -605,10 +620,11 @@ struct State {
     int grid = 0;
     size_t ldsBytes = 0;
     long long iterations = 0;
+    int parity = 0;         // which half of Ctrl::seg_count the next iteration uses
     // kernel timing
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> evBounce, evRaygen;
-    double msBounce = 0, msRaygen = 0;
-    long long nBounce = 0, nRaygen = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> evBounce;
+    double msBounce = 0;
+    long long nBounce = 0;
 } S;
 
 int count_devices() {
@@ -668,25 +684,6 @@ int resolve_events(std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, double &ms
     return PT_OK;
 }
 
-int launch_raygen(int iter) {
-    const PathSoA out = soa(S.pathbuf[0], kSeg * S.segCap);
-    int blocks = (S.nLocal + kBlock - 1) / kBlock;
-    if (blocks < 1) blocks = 1;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (S.flags & PT_FLAG_KERNEL_TIMING) {
-        HIPCHECK(hipEventCreate(&e0));
-        HIPCHECK(hipEventCreate(&e1));
-        HIPCHECK(hipEventRecord(e0, S.stream));
-    }
-    hipLaunchKernelGGL(k_generate_rays, dim3(blocks), dim3(kBlock), 0, S.stream, S.prm, iter, out, S.ctrl);
-    if (e0) {
-        HIPCHECK(hipEventRecord(e1, S.stream));
-        S.evRaygen.emplace_back(e0, e1);
-    }
-    HIPCHECK(hipGetLastError());
-    return PT_OK;
-}
-
 int launch_bounce(int iter, int depth, bool lastBounce, float *image) {
     const PathSoA in = soa(S.pathbuf[(depth - 1) & 1], kSeg * S.segCap);
     const PathSoA out = soa(S.pathbuf[depth & 1], kSeg * S.segCap);
@@ -696,15 +693,17 @@ int launch_bounce(int iter, int depth, bool lastBounce, float *image) {
         HIPCHECK(hipEventCreate(&e1));
         HIPCHECK(hipEventRecord(e0, S.stream));
     }
-    hipLaunchKernelGGL(k_bounce, dim3(S.grid), dim3(kBlock), S.ldsBytes, S.stream, S.prm, iter, depth,
-                       lastBounce ? 1 : 0, in, out, S.ctrl, S.dgeoms, S.dmats, image);
+    if (depth == 1)
+        hipLaunchKernelGGL(k_bounce<true>, dim3(S.grid), dim3(kBlock), S.ldsBytes, S.stream, S.prm, iter, depth,
+                           lastBounce ? 1 : 0, S.parity, in, out, S.ctrl, S.dgeoms, S.dmats, image);
+    else
+        hipLaunchKernelGGL(k_bounce<false>, dim3(S.grid), dim3(kBlock), S.ldsBytes, S.stream, S.prm, iter, depth,
+                           lastBounce ? 1 : 0, S.parity, in, out, S.ctrl, S.dgeoms, S.dmats, image);
     if (e0) {
         HIPCHECK(hipEventRecord(e1, S.stream));
         S.evBounce.emplace_back(e0, e1);
         if (S.evBounce.size() > 8192) {
             int rc = resolve_events(S.evBounce, S.msBounce, S.nBounce);
-            if (rc) return rc;
-            rc = resolve_events(S.evRaygen, S.msRaygen, S.nRaygen);
             if (rc) return rc;
         }
     }
@@ -776,7 +775,7 @@ void pt_free(void) {
     // pathtraceFree before the first Init (src/main.cpp:91-94) must be a no-op
     if (!S.init && !S.pathbuf[0] && !S.image && !S.dgeoms && !S.ctrl) return;
     (void)hipStreamSynchronize(S.stream);
-    for (auto *v : {&S.evBounce, &S.evRaygen}) {
+    for (auto *v : {&S.evBounce}) {
         for (auto &pr : *v) {
             (void)hipEventDestroy(pr.first);
             (void)hipEventDestroy(pr.second);
@@ -874,9 +873,11 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
 
     S.ldsBytes = sizeof(GeomDev) * ngeoms + sizeof(MaterialDev) * nmats + 16 * sizeof(uint32_t);
     if (S.ldsBytes > 160 * 1024) return fail(PT_ERR_INVALID, "pt_init: scene does not fit the 160 KiB LDS (%zu B)", S.ldsBytes);
-    if (S.ldsBytes > 64 * 1024)
-        HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bounce), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.ldsBytes));
-    int rc = persistent_grid(reinterpret_cast<const void *>(k_bounce), S.ldsBytes, &S.grid);
+    if (S.ldsBytes > 64 * 1024) {
+        HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bounce<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.ldsBytes));
+        HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bounce<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.ldsBytes));
+    }
+    int rc = persistent_grid(reinterpret_cast<const void *>(k_bounce<false>), S.ldsBytes, &S.grid);
     if (rc) return rc;
     if (S.grid > S.numTilesMax) S.grid = S.numTilesMax;
     S.grid = (S.grid / kSeg) * kSeg;      // consecutive tiles of one workgroup cycle through all output segments
@@ -891,13 +892,12 @@ int pt_iterate(int frame, int iter, void *rgba8_dev) {
     (void)frame;  // always 0 in the reference (src/main.cpp:102)
     if (!S.init) return fail(PT_ERR_NOT_INIT, "pt_iterate before pt_init");
     if (iter < 1 || iter >= (1 << 22)) return fail(PT_ERR_INVALID, "pt_iterate: iter must be 1..4194303 (seed bits, pathtrace.cu:43)");
-    int rc = launch_raygen(iter);
-    if (rc) return rc;
     const int D = S.prm.traceDepth;
     for (int d = 1; d <= D; ++d) {
-        rc = launch_bounce(iter, d, d == D, S.image);
+        int rc = launch_bounce(iter, d, d == D, S.image);
         if (rc) return rc;
     }
+    S.parity ^= 1;   // the last launch re-armed the other half of the counters
     if (rgba8_dev) {
         hipLaunchKernelGGL(k_to_rgba8, dim3((S.P + kBlock - 1) / kBlock), dim3(kBlock), 0, S.stream, S.image, S.P, iter,
                            reinterpret_cast<uchar4 *>(rgba8_dev));
@@ -942,8 +942,6 @@ int pt_counters(PtCounters *out) {
     HIPCHECK(hipStreamSynchronize(S.stream));
     int rc = resolve_events(S.evBounce, S.msBounce, S.nBounce);
     if (rc) return rc;
-    rc = resolve_events(S.evRaygen, S.msRaygen, S.nRaygen);
-    if (rc) return rc;
     memset(out, 0, sizeof *out);
     for (int d = 0; d < kMaxDepthSlots; ++d) out->live[d] = (int64_t)h.sum_live[d];
     for (int sg = 0; sg < kSeg; ++sg) {
@@ -953,8 +951,8 @@ int pt_counters(PtCounters *out) {
     out->iterations = S.iterations;
     out->bounce_launches = S.nBounce;
     out->bounce_kernel_ms = S.msBounce;
-    out->raygen_kernel_ms = S.msRaygen;
-    out->raygen_launches = S.nRaygen;
+    out->raygen_kernel_ms = 0.0;   // camera rays are generated inside the first bounce launch
+    out->raygen_launches = 0;
     if (h.error) return fail(PT_ERR_DEVICE, "device fault flag set");
     return PT_OK;
 }
@@ -964,10 +962,8 @@ int pt_counters_reset(void) {
     HIPCHECK(hipStreamSynchronize(S.stream));
     int rc = resolve_events(S.evBounce, S.msBounce, S.nBounce);
     if (rc) return rc;
-    rc = resolve_events(S.evRaygen, S.msRaygen, S.nRaygen);
-    if (rc) return rc;
-    S.msBounce = S.msRaygen = 0;
-    S.nBounce = S.nRaygen = 0;
+    S.msBounce = 0;
+    S.nBounce = 0;
     S.iterations = 0;
     HIPCHECK(hipMemset(S.ctrl, 0, sizeof(Ctrl)));
     return PT_OK;
@@ -978,8 +974,26 @@ int pt_debug_trace_paths(int iter, int bounces, float *origin3, float *dir3, flo
     if (!S.init) return fail(PT_ERR_NOT_INIT, "pt_debug_trace_paths before pt_init");
     if (bounces < 0 || bounces > PT_MAX_DEPTH || !count) return fail(PT_ERR_INVALID, "pt_debug_trace_paths: bad argument");
     if (bounces > S.prm.traceDepth) return fail(PT_ERR_INVALID, "pt_debug_trace_paths: bounces > traceDepth");
-    int rc = launch_raygen(iter);
-    if (rc) return rc;
+    int rc = PT_OK;
+    if (bounces == 0) {   // camera rays only (they never exist in HBM: generation is fused into bounce 1)
+        const int nl = S.nLocal;
+        *count = nl;
+        if (nl == 0) return PT_OK;
+        DevBuf<float> o, d;
+        DevBuf<int> px;
+        if ((rc = o.alloc((size_t)nl * 3)) || (rc = d.alloc((size_t)nl * 3)) || (rc = px.alloc(nl))) return rc;
+        hipLaunchKernelGGL(k_debug_camera_rays, dim3((nl + kBlock - 1) / kBlock), dim3(kBlock), 0, S.stream, S.prm, iter,
+                           o.p, d.p, px.p);
+        HIPCHECK(hipGetLastError());
+        HIPCHECK(hipStreamSynchronize(S.stream));
+        if (origin3) HIPCHECK(hipMemcpy(origin3, o.p, (size_t)nl * 12, hipMemcpyDeviceToHost));
+        if (dir3) HIPCHECK(hipMemcpy(dir3, d.p, (size_t)nl * 12, hipMemcpyDeviceToHost));
+        if (pixelIndex) HIPCHECK(hipMemcpy(pixelIndex, px.p, (size_t)nl * 4, hipMemcpyDeviceToHost));
+        if (color3)
+            for (size_t i = 0; i < (size_t)nl * 3; ++i) color3[i] = 1.0f;
+        return PT_OK;
+    }
+    HIPCHECK(hipMemsetAsync(&S.ctrl->seg_count[0][0][0][0], 0, sizeof(S.ctrl->seg_count), S.stream));
     for (int d = 1; d <= bounces; ++d) {
         rc = launch_bounce(iter, d, false, nullptr);  // no accumulation, survivors always written
         if (rc) return rc;
@@ -987,7 +1001,8 @@ int pt_debug_trace_paths(int iter, int bounces, float *origin3, float *dir3, flo
     // gather the kSeg segments of the queue entering bounce `bounces + 1`, then sort by pixel index
     uint32_t segn[kSeg];
     for (int sg = 0; sg < kSeg; ++sg)
-        HIPCHECK(hipMemcpyAsync(&segn[sg], &S.ctrl->seg_count[bounces + 1][sg][0], 4, hipMemcpyDeviceToHost, S.stream));
+        HIPCHECK(hipMemcpyAsync(&segn[sg], &S.ctrl->seg_count[S.parity][bounces + 1][sg][0], 4, hipMemcpyDeviceToHost, S.stream));
+    HIPCHECK(hipMemsetAsync(&S.ctrl->seg_count[0][0][0][0], 0, sizeof(S.ctrl->seg_count), S.stream));
     HIPCHECK(hipStreamSynchronize(S.stream));
     rc = check_device_fault();
     if (rc) return rc;
