@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--res", type=int, nargs=2, default=[1280, 720])
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--cpu-spp", type=int, default=12, help="spp of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--pipeline", type=int, default=0, help="iterations in flight (PtOptions.pipeline_depth; 0 = library default)")
     ap.add_argument("--pmc-traffic-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"),
                     help="HBM bytes per bounce-kernel launch from a rocprofv3 --pmc run (profiles/README.md)")
     return ap.parse_args()
@@ -97,10 +98,11 @@ def main():
     frame = torch.zeros_like(accum) if world > 1 else None           # rank 0 receives the assembled frame here
     stream = torch.cuda.current_stream()
 
-    def init(flags):
+    def init(flags, pipeline):
         pt.pathtraceFree()
         pt.pathtraceInit(scene, shard_rank=rank, shard_count=world, stream=stream.cuda_stream,
-                         accum_dev=accum.data_ptr(), device=local_rank, flags=flags, traceDepth=args.depth)
+                         accum_dev=accum.data_ptr(), device=local_rank, flags=flags, traceDepth=args.depth,
+                         pipeline_depth=pipeline)
 
     def step(it):
         pt.pathtrace(None, 0, it, readback=False)
@@ -122,7 +124,7 @@ def main():
         return time.perf_counter() - t0
 
     # ---- pass A: the headline number ----------------------------------------------------------
-    init(0)
+    init(0, args.pipeline)
     for k in range(args.warmup):
         step(1 + k)
     barrier()
@@ -134,8 +136,11 @@ def main():
         dt = float(t.item())
     cntA = pt.counters()
 
-    # ---- pass B: same steps with HIP events around every launch (roofline of the bounce kernel) -
-    init(pt.PT_FLAG_KERNEL_TIMING)
+    # ---- pass B: same steps with HIP events around every launch (roofline of the bounce kernel); one
+    #      iteration in flight, so that a launch's duration is the kernel's own and not its share of a GPU it
+    #      co-occupies with the neighbouring iterations' launches
+    accum.zero_()
+    init(pt.PT_FLAG_KERNEL_TIMING, 1)
     for k in range(min(args.warmup, 2)):
         step(1 + k)
     barrier()

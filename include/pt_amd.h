@@ -74,6 +74,9 @@ typedef struct PtOptions {
     int32_t shard_count;      /* 1 = whole frame (reference behaviour) */
     int32_t device;           /* HIP device ordinal; -1 = current device */
     int32_t flags;            /* PT_FLAG_* */
+    int32_t pipeline_depth;   /* iterations kept in flight on internal streams: 0 = default (3), 1 = none, max 4.
+                                 Results do not depend on it: radiance is committed in iteration order. */
+    int32_t reserved;
     void   *stream;           /* hipStream_t to enqueue on; NULL = the default stream */
     float  *accum_dev;        /* optional caller-owned device accumulator, W*H*3 floats, zeroed by the
                                  caller (e.g. a torch tensor used for the RCCL reduce); NULL = owned

@@ -51,7 +51,8 @@ ABI_SYMBOLS = [
 
 class PtOptions(C.Structure):
     _fields_ = [("shard_rank", C.c_int32), ("shard_count", C.c_int32), ("device", C.c_int32),
-                ("flags", C.c_int32), ("stream", C.c_void_p), ("accum_dev", C.c_void_p)]
+                ("flags", C.c_int32), ("pipeline_depth", C.c_int32), ("reserved", C.c_int32),
+                ("stream", C.c_void_p), ("accum_dev", C.c_void_p)]
 
 
 class PtCounters(C.Structure):
@@ -188,10 +189,11 @@ class Scene:
 _scene = None
 
 
-def pathtraceInit(scene, shard_rank=0, shard_count=1, stream=0, accum_dev=0, device=-1, flags=0, traceDepth=None):
+def pathtraceInit(scene, shard_rank=0, shard_count=1, stream=0, accum_dev=0, device=-1, flags=0, traceDepth=None,
+                  pipeline_depth=0):
     """reference src/pathtrace.cu:75-85.  `scene` is borrowed until pathtraceFree()."""
     global _scene
-    opt = PtOptions(shard_rank, shard_count, device, flags, stream or None, accum_dev or None)
+    opt = PtOptions(shard_rank, shard_count, device, flags, pipeline_depth, 0, stream or None, accum_dev or None)
     geoms = np.ascontiguousarray(scene.geoms)
     mats = np.ascontiguousarray(scene.materials)
     cam = np.ascontiguousarray(scene.camera)

@@ -222,7 +222,7 @@ template <bool FIRST>
 __global__ __launch_bounds__(kBlock) void k_bounce(KParams prm, int iter, int depth, int lastBounce, int parity,
                                                    PathSoA in, PathSoA out, Ctrl *ctrl,
                                                    const GeomDev *__restrict__ ggeoms,
-                                                   const MaterialDev *__restrict__ gmats, float *image) {
+                                                   const MaterialDev *__restrict__ gmats, float *contrib) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     GeomDev *sgeoms = reinterpret_cast<GeomDev *>(smem);
     MaterialDev *smats = reinterpret_cast<MaterialDev *>(smem + sizeof(GeomDev) * prm.ngeoms);
@@ -331,10 +331,13 @@ __global__ __launch_bounds__(kBlock) void k_bounce(KParams prm, int iter, int de
                 const F3 mcol = f3(M.color[0], M.color[1], M.color[2]);
                 if (M.emittance > 0.0f) {                        // S5: emitter ends the path
                     lightHit = true;
-                    if (image) {
+                    if (contrib) {
+                        // Deferred accumulation: iterations overlap on several streams, so the radiance
+                        // is parked in this iteration's own buffer (one path per pixel: race-free, no
+                        // read) and k_commit adds it to the accumulator in iteration order.
                         const F3 c = (col * mcol) * M.emittance;
-                        float *px = image + 3 * (size_t)pix;     // one path per pixel: race-free
-                        px[0] += c.x; px[1] += c.y; px[2] += c.z;
+                        float *px = contrib + 3 * (size_t)pix;
+                        px[0] = c.x; px[1] = c.y; px[2] = c.z;
                     }
                 } else if (!lastBounce) {                        // S6 scatter (S7: skipped on the last bounce)
                     Rng rng = makeSeededRandomEngine(iter, pix, depth);
@@ -421,6 +424,25 @@ __global__ __launch_bounds__(kBlock) void k_bounce(KParams prm, int iter, int de
         const int shard = blockIdx.x % kSeg;
         if (waveLight) atomicAdd(&ctrl->light_hits[shard][0], (unsigned long long)waveLight);
         if (waveMiss) atomicAdd(&ctrl->misses[shard][0], (unsigned long long)waveMiss);
+    }
+}
+
+// ---- commit one iteration's radiance: image[pix] += contrib[pix]; contrib[pix] = 0 -------------------
+// Runs on the caller's stream, one launch per iteration in iteration order, so every pixel receives its
+// samples in exactly the order a sequential renderer adds them (fp32 addition is not associative).
+// Skipping an all-zero contribution equals adding +0 (the accumulator is never -0).
+__global__ __launch_bounds__(kBlock) void k_commit(KParams prm, float *image, float *contrib) {
+    const int j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= prm.nLocal) return;
+    const int lr = j / prm.W;
+    const int x = j - lr * prm.W;
+    const size_t pix = (size_t)x + (size_t)(lr * prm.shardCount + prm.shardRank) * prm.W;
+    float *c = contrib + 3 * pix;
+    const float cx = c[0], cy = c[1], cz = c[2];
+    if (cx != 0.0f || cy != 0.0f || cz != 0.0f) {
+        float *px = image + 3 * pix;
+        px[0] += cx; px[1] += cy; px[2] += cz;
+        c[0] = 0.0f; c[1] = 0.0f; c[2] = 0.0f;
     }
 }
 
@@ -600,10 +622,23 @@ int fail(int code, const char *fmt, ...) {
                         hipGetErrorString(e_));                                                     \
     } while (0)
 
+constexpr int kMaxSlots = 4;
+
+// One in-flight iteration: its own stream, path buffers, counters and deferred-radiance buffer.
+struct Slot {
+    hipStream_t stream = nullptr;
+    float *pathbuf[2] = {nullptr, nullptr};
+    Ctrl *ctrl = nullptr;
+    float *contrib = nullptr;      // W*H*3, zero between iterations
+    hipEvent_t evDone = nullptr;       // all bounce launches of the slot's current iteration finished
+    hipEvent_t evCommitted = nullptr;  // k_commit consumed (and re-zeroed) `contrib`
+    int parity = 0;                // which half of Ctrl::seg_count the slot's next iteration uses
+};
+
 struct State {
     bool init = false;
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;   // the caller's stream: commits, PBO conversion, readback
     PtCamera cam;
     KParams prm;
     int P = 0;              // W*H
@@ -611,16 +646,16 @@ struct State {
     int flags = 0;
     float *image = nullptr;
     bool ownImage = false;
-    float *pathbuf[2] = {nullptr, nullptr};
+    int nslots = 0;
+    Slot slot[kMaxSlots];
     GeomDev *dgeoms = nullptr;
     MaterialDev *dmats = nullptr;
-    Ctrl *ctrl = nullptr;
     int numTilesMax = 0;    // upper bound of tiles in one bounce queue (incl. one partial tile per segment)
     int segCap = 0;         // paths per segment; a path buffer holds kSeg * segCap paths per array
     int grid = 0;
     size_t ldsBytes = 0;
     long long iterations = 0;
-    int parity = 0;         // which half of Ctrl::seg_count the next iteration uses
+    long long seq = 0;      // iterations enqueued since pt_init: slot = seq % nslots
     // kernel timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> evBounce;
     double msBounce = 0;
@@ -684,23 +719,23 @@ int resolve_events(std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, double &ms
     return PT_OK;
 }
 
-int launch_bounce(int iter, int depth, bool lastBounce, float *image) {
-    const PathSoA in = soa(S.pathbuf[(depth - 1) & 1], kSeg * S.segCap);
-    const PathSoA out = soa(S.pathbuf[depth & 1], kSeg * S.segCap);
+int launch_bounce(Slot &sl, int iter, int depth, bool lastBounce, float *contrib) {
+    const PathSoA in = soa(sl.pathbuf[(depth - 1) & 1], kSeg * S.segCap);
+    const PathSoA out = soa(sl.pathbuf[depth & 1], kSeg * S.segCap);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (S.flags & PT_FLAG_KERNEL_TIMING) {
         HIPCHECK(hipEventCreate(&e0));
         HIPCHECK(hipEventCreate(&e1));
-        HIPCHECK(hipEventRecord(e0, S.stream));
+        HIPCHECK(hipEventRecord(e0, sl.stream));
     }
     if (depth == 1)
-        hipLaunchKernelGGL(k_bounce<true>, dim3(S.grid), dim3(kBlock), S.ldsBytes, S.stream, S.prm, iter, depth,
-                           lastBounce ? 1 : 0, S.parity, in, out, S.ctrl, S.dgeoms, S.dmats, image);
+        hipLaunchKernelGGL(k_bounce<true>, dim3(S.grid), dim3(kBlock), S.ldsBytes, sl.stream, S.prm, iter, depth,
+                           lastBounce ? 1 : 0, sl.parity, in, out, sl.ctrl, S.dgeoms, S.dmats, contrib);
     else
-        hipLaunchKernelGGL(k_bounce<false>, dim3(S.grid), dim3(kBlock), S.ldsBytes, S.stream, S.prm, iter, depth,
-                           lastBounce ? 1 : 0, S.parity, in, out, S.ctrl, S.dgeoms, S.dmats, image);
+        hipLaunchKernelGGL(k_bounce<false>, dim3(S.grid), dim3(kBlock), S.ldsBytes, sl.stream, S.prm, iter, depth,
+                           lastBounce ? 1 : 0, sl.parity, in, out, sl.ctrl, S.dgeoms, S.dmats, contrib);
     if (e0) {
-        HIPCHECK(hipEventRecord(e1, S.stream));
+        HIPCHECK(hipEventRecord(e1, sl.stream));
         S.evBounce.emplace_back(e0, e1);
         if (S.evBounce.size() > 8192) {
             int rc = resolve_events(S.evBounce, S.msBounce, S.nBounce);
@@ -711,11 +746,21 @@ int launch_bounce(int iter, int depth, bool lastBounce, float *image) {
     return PT_OK;
 }
 
-int check_device_fault() {
-    uint32_t err = 0;
-    HIPCHECK(hipMemcpyAsync(&err, &S.ctrl->error, sizeof err, hipMemcpyDeviceToHost, S.stream));
+// wait for every stream the renderer uses
+int sync_all() {
+    for (int i = 0; i < S.nslots; ++i) HIPCHECK(hipStreamSynchronize(S.slot[i].stream));
     HIPCHECK(hipStreamSynchronize(S.stream));
-    if (err) return fail(PT_ERR_DEVICE, "device fault flag set");
+    return PT_OK;
+}
+
+int check_device_fault() {
+    int rc = sync_all();
+    if (rc) return rc;
+    for (int i = 0; i < S.nslots; ++i) {
+        uint32_t err = 0;
+        HIPCHECK(hipMemcpy(&err, &S.slot[i].ctrl->error, sizeof err, hipMemcpyDeviceToHost));
+        if (err) return fail(PT_ERR_DEVICE, "device fault flag set");
+    }
     return PT_OK;
 }
 
@@ -773,21 +818,28 @@ int pt_device_count(void) { return count_devices(); }
 
 void pt_free(void) {
     // pathtraceFree before the first Init (src/main.cpp:91-94) must be a no-op
-    if (!S.init && !S.pathbuf[0] && !S.image && !S.dgeoms && !S.ctrl) return;
+    if (!S.init && !S.image && !S.dgeoms && S.nslots == 0) return;
+    for (int i = 0; i < kMaxSlots; ++i)
+        if (S.slot[i].stream) (void)hipStreamSynchronize(S.slot[i].stream);
     (void)hipStreamSynchronize(S.stream);
-    for (auto *v : {&S.evBounce}) {
-        for (auto &pr : *v) {
-            (void)hipEventDestroy(pr.first);
-            (void)hipEventDestroy(pr.second);
-        }
-        v->clear();
+    for (auto &pr : S.evBounce) {
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
+    S.evBounce.clear();
+    for (int i = 0; i < kMaxSlots; ++i) {
+        Slot &sl = S.slot[i];
+        for (int k = 0; k < 2; ++k)
+            if (sl.pathbuf[k]) (void)hipFree(sl.pathbuf[k]);
+        if (sl.ctrl) (void)hipFree(sl.ctrl);
+        if (sl.contrib) (void)hipFree(sl.contrib);
+        if (sl.evDone) (void)hipEventDestroy(sl.evDone);
+        if (sl.evCommitted) (void)hipEventDestroy(sl.evCommitted);
+        if (sl.stream) (void)hipStreamDestroy(sl.stream);
     }
     if (S.ownImage && S.image) (void)hipFree(S.image);
-    for (int i = 0; i < 2; ++i)
-        if (S.pathbuf[i]) (void)hipFree(S.pathbuf[i]);
     if (S.dgeoms) (void)hipFree(S.dgeoms);
     if (S.dmats) (void)hipFree(S.dmats);
-    if (S.ctrl) (void)hipFree(S.ctrl);
     S = State();
 }
 
@@ -811,6 +863,7 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     o.device = -1;
     if (opts) o = *opts;
     if (o.shard_count < 1 || o.shard_rank < 0 || o.shard_rank >= o.shard_count) return fail(PT_ERR_INVALID, "pt_init: bad shard %d/%d", o.shard_rank, o.shard_count);
+    if (o.pipeline_depth < 0 || o.pipeline_depth > kMaxSlots) return fail(PT_ERR_INVALID, "pt_init: pipeline_depth must be 0..%d", kMaxSlots);
     if (o.device >= 0) HIPCHECK(hipSetDevice(o.device));
     HIPCHECK(hipGetDevice(&S.device));
     S.stream = (hipStream_t)o.stream;
@@ -857,7 +910,20 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     S.segCap = ((S.numTilesMax + kSeg - 1) / kSeg) * kBlock;
     k.segCap = S.segCap;
     const size_t cap = (size_t)kSeg * S.segCap;
-    for (int i = 0; i < 2; ++i) HIPCHECK(hipMalloc(&S.pathbuf[i], cap * kNumArrays * sizeof(float)));
+    // Iterations are independent (RNG keyed on pixel/iteration/depth), so up to `nslots` of them are in flight
+    // on their own streams; the small late-bounce launches of one overlap the big early launches of the next.
+    S.nslots = o.pipeline_depth > 0 ? o.pipeline_depth : 3;
+    for (int i = 0; i < S.nslots; ++i) {
+        Slot &sl = S.slot[i];
+        HIPCHECK(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+        for (int b = 0; b < 2; ++b) HIPCHECK(hipMalloc(&sl.pathbuf[b], cap * kNumArrays * sizeof(float)));
+        HIPCHECK(hipMalloc(&sl.ctrl, sizeof(Ctrl)));
+        HIPCHECK(hipMemset(sl.ctrl, 0, sizeof(Ctrl)));
+        HIPCHECK(hipMalloc(&sl.contrib, (size_t)S.P * 3 * sizeof(float)));
+        HIPCHECK(hipMemset(sl.contrib, 0, (size_t)S.P * 3 * sizeof(float)));
+        HIPCHECK(hipEventCreateWithFlags(&sl.evDone, hipEventDisableTiming));
+        HIPCHECK(hipEventCreateWithFlags(&sl.evCommitted, hipEventDisableTiming));
+    }
 
     std::vector<GeomDev> hg(ngeoms ? ngeoms : 1);
     std::vector<MaterialDev> hm(nmats ? nmats : 1);
@@ -867,9 +933,6 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     HIPCHECK(hipMalloc(&S.dmats, hm.size() * sizeof(MaterialDev)));
     HIPCHECK(hipMemcpy(S.dgeoms, hg.data(), hg.size() * sizeof(GeomDev), hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(S.dmats, hm.data(), hm.size() * sizeof(MaterialDev), hipMemcpyHostToDevice));
-
-    HIPCHECK(hipMalloc(&S.ctrl, sizeof(Ctrl)));
-    HIPCHECK(hipMemset(S.ctrl, 0, sizeof(Ctrl)));
 
     S.ldsBytes = sizeof(GeomDev) * ngeoms + sizeof(MaterialDev) * nmats + 16 * sizeof(uint32_t);
     if (S.ldsBytes > 160 * 1024) return fail(PT_ERR_INVALID, "pt_init: scene does not fit the 160 KiB LDS (%zu B)", S.ldsBytes);
@@ -882,7 +945,7 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     if (S.grid > S.numTilesMax) S.grid = S.numTilesMax;
     S.grid = (S.grid / kSeg) * kSeg;      // consecutive tiles of one workgroup cycle through all output segments
     if (S.grid < kSeg) S.grid = kSeg;
-    HIPCHECK(hipStreamSynchronize(S.stream));
+    HIPCHECK(hipDeviceSynchronize());
     S.init = true;
     g_err.clear();
     return PT_OK;
@@ -892,33 +955,45 @@ int pt_iterate(int frame, int iter, void *rgba8_dev) {
     (void)frame;  // always 0 in the reference (src/main.cpp:102)
     if (!S.init) return fail(PT_ERR_NOT_INIT, "pt_iterate before pt_init");
     if (iter < 1 || iter >= (1 << 22)) return fail(PT_ERR_INVALID, "pt_iterate: iter must be 1..4194303 (seed bits, pathtrace.cu:43)");
+    Slot &sl = S.slot[S.seq % S.nslots];
+    // the slot's radiance buffer must have been consumed by the commit of its previous iteration
+    HIPCHECK(hipStreamWaitEvent(sl.stream, sl.evCommitted, 0));
     const int D = S.prm.traceDepth;
     for (int d = 1; d <= D; ++d) {
-        int rc = launch_bounce(iter, d, d == D, S.image);
+        int rc = launch_bounce(sl, iter, d, d == D, sl.contrib);
         if (rc) return rc;
     }
-    S.parity ^= 1;   // the last launch re-armed the other half of the counters
+    sl.parity ^= 1;   // the last launch re-armed the other half of the slot's counters
+    HIPCHECK(hipEventRecord(sl.evDone, sl.stream));
+    // commit on the caller's stream: commits are therefore ordered like the pt_iterate calls
+    HIPCHECK(hipStreamWaitEvent(S.stream, sl.evDone, 0));
+    if (S.nLocal > 0) {
+        hipLaunchKernelGGL(k_commit, dim3((S.nLocal + kBlock - 1) / kBlock), dim3(kBlock), 0, S.stream, S.prm, S.image, sl.contrib);
+        HIPCHECK(hipGetLastError());
+    }
+    HIPCHECK(hipEventRecord(sl.evCommitted, S.stream));
     if (rgba8_dev) {
         hipLaunchKernelGGL(k_to_rgba8, dim3((S.P + kBlock - 1) / kBlock), dim3(kBlock), 0, S.stream, S.image, S.P, iter,
                            reinterpret_cast<uchar4 *>(rgba8_dev));
         HIPCHECK(hipGetLastError());
     }
+    S.seq += 1;
     S.iterations += 1;
     return PT_OK;
 }
 
 int pt_sync(void) {
     if (!S.init) return fail(PT_ERR_NOT_INIT, "pt_sync before pt_init");
-    HIPCHECK(hipStreamSynchronize(S.stream));
     return check_device_fault();
 }
 
 int pt_readback(float *rgb_sum_host) {
     if (!S.init) return fail(PT_ERR_NOT_INIT, "pt_readback before pt_init");
     if (!rgb_sum_host) return fail(PT_ERR_INVALID, "pt_readback: null");
+    // every commit so far is already ordered before this copy on the caller's stream
     HIPCHECK(hipMemcpyAsync(rgb_sum_host, S.image, (size_t)S.P * 3 * sizeof(float), hipMemcpyDeviceToHost, S.stream));
     HIPCHECK(hipStreamSynchronize(S.stream));
-    return check_device_fault();
+    return PT_OK;
 }
 
 int pt_readback_rgba8(int iter, uint8_t *rgba_host) {
@@ -937,35 +1012,41 @@ int pt_readback_rgba8(int iter, uint8_t *rgba_host) {
 int pt_counters(PtCounters *out) {
     if (!S.init) return fail(PT_ERR_NOT_INIT, "pt_counters before pt_init");
     if (!out) return fail(PT_ERR_INVALID, "pt_counters: null");
-    static Ctrl h;   // 100+ KB: keep it off the stack
-    HIPCHECK(hipMemcpyAsync(&h, S.ctrl, sizeof h, hipMemcpyDeviceToHost, S.stream));
-    HIPCHECK(hipStreamSynchronize(S.stream));
-    int rc = resolve_events(S.evBounce, S.msBounce, S.nBounce);
+    int rc = sync_all();
+    if (rc) return rc;
+    rc = resolve_events(S.evBounce, S.msBounce, S.nBounce);
     if (rc) return rc;
     memset(out, 0, sizeof *out);
-    for (int d = 0; d < kMaxDepthSlots; ++d) out->live[d] = (int64_t)h.sum_live[d];
-    for (int sg = 0; sg < kSeg; ++sg) {
-        out->light_hits += (int64_t)h.light_hits[sg][0];
-        out->misses += (int64_t)h.misses[sg][0];
+    static Ctrl h;   // 130 KB: keep it off the stack
+    bool fault = false;
+    for (int i = 0; i < S.nslots; ++i) {
+        HIPCHECK(hipMemcpy(&h, S.slot[i].ctrl, sizeof h, hipMemcpyDeviceToHost));
+        for (int d = 0; d < kMaxDepthSlots; ++d) out->live[d] += (int64_t)h.sum_live[d];
+        for (int sg = 0; sg < kSeg; ++sg) {
+            out->light_hits += (int64_t)h.light_hits[sg][0];
+            out->misses += (int64_t)h.misses[sg][0];
+        }
+        fault = fault || h.error != 0;
     }
     out->iterations = S.iterations;
     out->bounce_launches = S.nBounce;
     out->bounce_kernel_ms = S.msBounce;
     out->raygen_kernel_ms = 0.0;   // camera rays are generated inside the first bounce launch
     out->raygen_launches = 0;
-    if (h.error) return fail(PT_ERR_DEVICE, "device fault flag set");
+    if (fault) return fail(PT_ERR_DEVICE, "device fault flag set");
     return PT_OK;
 }
 
 int pt_counters_reset(void) {
     if (!S.init) return fail(PT_ERR_NOT_INIT, "pt_counters_reset before pt_init");
-    HIPCHECK(hipStreamSynchronize(S.stream));
-    int rc = resolve_events(S.evBounce, S.msBounce, S.nBounce);
+    int rc = sync_all();
+    if (rc) return rc;
+    rc = resolve_events(S.evBounce, S.msBounce, S.nBounce);
     if (rc) return rc;
     S.msBounce = 0;
     S.nBounce = 0;
     S.iterations = 0;
-    HIPCHECK(hipMemset(S.ctrl, 0, sizeof(Ctrl)));
+    for (int i = 0; i < S.nslots; ++i) HIPCHECK(hipMemset(S.slot[i].ctrl, 0, sizeof(Ctrl)));
     return PT_OK;
 }
 
@@ -974,7 +1055,9 @@ int pt_debug_trace_paths(int iter, int bounces, float *origin3, float *dir3, flo
     if (!S.init) return fail(PT_ERR_NOT_INIT, "pt_debug_trace_paths before pt_init");
     if (bounces < 0 || bounces > PT_MAX_DEPTH || !count) return fail(PT_ERR_INVALID, "pt_debug_trace_paths: bad argument");
     if (bounces > S.prm.traceDepth) return fail(PT_ERR_INVALID, "pt_debug_trace_paths: bounces > traceDepth");
-    int rc = PT_OK;
+    int rc = sync_all();
+    if (rc) return rc;
+    Slot &sl = S.slot[0];
     if (bounces == 0) {   // camera rays only (they never exist in HBM: generation is fused into bounce 1)
         const int nl = S.nLocal;
         *count = nl;
@@ -982,10 +1065,10 @@ int pt_debug_trace_paths(int iter, int bounces, float *origin3, float *dir3, flo
         DevBuf<float> o, d;
         DevBuf<int> px;
         if ((rc = o.alloc((size_t)nl * 3)) || (rc = d.alloc((size_t)nl * 3)) || (rc = px.alloc(nl))) return rc;
-        hipLaunchKernelGGL(k_debug_camera_rays, dim3((nl + kBlock - 1) / kBlock), dim3(kBlock), 0, S.stream, S.prm, iter,
+        hipLaunchKernelGGL(k_debug_camera_rays, dim3((nl + kBlock - 1) / kBlock), dim3(kBlock), 0, sl.stream, S.prm, iter,
                            o.p, d.p, px.p);
         HIPCHECK(hipGetLastError());
-        HIPCHECK(hipStreamSynchronize(S.stream));
+        HIPCHECK(hipStreamSynchronize(sl.stream));
         if (origin3) HIPCHECK(hipMemcpy(origin3, o.p, (size_t)nl * 12, hipMemcpyDeviceToHost));
         if (dir3) HIPCHECK(hipMemcpy(dir3, d.p, (size_t)nl * 12, hipMemcpyDeviceToHost));
         if (pixelIndex) HIPCHECK(hipMemcpy(pixelIndex, px.p, (size_t)nl * 4, hipMemcpyDeviceToHost));
@@ -993,24 +1076,22 @@ int pt_debug_trace_paths(int iter, int bounces, float *origin3, float *dir3, flo
             for (size_t i = 0; i < (size_t)nl * 3; ++i) color3[i] = 1.0f;
         return PT_OK;
     }
-    HIPCHECK(hipMemsetAsync(&S.ctrl->seg_count[0][0][0][0], 0, sizeof(S.ctrl->seg_count), S.stream));
+    HIPCHECK(hipMemsetAsync(&sl.ctrl->seg_count[0][0][0][0], 0, sizeof(sl.ctrl->seg_count), sl.stream));
     for (int d = 1; d <= bounces; ++d) {
-        rc = launch_bounce(iter, d, false, nullptr);  // no accumulation, survivors always written
+        rc = launch_bounce(sl, iter, d, false, nullptr);  // no radiance, survivors always written
         if (rc) return rc;
     }
     // gather the kSeg segments of the queue entering bounce `bounces + 1`, then sort by pixel index
     uint32_t segn[kSeg];
     for (int sg = 0; sg < kSeg; ++sg)
-        HIPCHECK(hipMemcpyAsync(&segn[sg], &S.ctrl->seg_count[S.parity][bounces + 1][sg][0], 4, hipMemcpyDeviceToHost, S.stream));
-    HIPCHECK(hipMemsetAsync(&S.ctrl->seg_count[0][0][0][0], 0, sizeof(S.ctrl->seg_count), S.stream));
-    HIPCHECK(hipStreamSynchronize(S.stream));
-    rc = check_device_fault();
-    if (rc) return rc;
+        HIPCHECK(hipMemcpyAsync(&segn[sg], &sl.ctrl->seg_count[sl.parity][bounces + 1][sg][0], 4, hipMemcpyDeviceToHost, sl.stream));
+    HIPCHECK(hipMemsetAsync(&sl.ctrl->seg_count[0][0][0][0], 0, sizeof(sl.ctrl->seg_count), sl.stream));
+    HIPCHECK(hipStreamSynchronize(sl.stream));
     size_t n = 0;
     for (int sg = 0; sg < kSeg; ++sg) n += segn[sg];
     *count = (int32_t)n;
     if (n == 0) return PT_OK;
-    const PathSoA sb = soa(S.pathbuf[bounces & 1], kSeg * S.segCap);
+    const PathSoA sb = soa(sl.pathbuf[bounces & 1], kSeg * S.segCap);
     std::vector<float> cols[kNumArrays];
     for (int k = 0; k < kNumArrays; ++k) {
         cols[k].resize(n);
