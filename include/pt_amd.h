@@ -150,6 +150,11 @@ int pt_test_rng(const uint32_t *seeds, int nseeds, int ndraws, float *u01_out /*
  * on a miss like the reference's out-parameters (intersections.h:86-88,114-126). */
 int pt_test_intersect(const PtGeom *geoms, int ngeoms, const int32_t *geom_index, const float *rays,
                       int n, float *t, float *p3, float *n3, int32_t *outside);
+/* slabQuotients (shared-reciprocal packed division of the box test) next to the compiler's correctly
+ * rounded `/`: per-element outputs, and a device-side pseudo-random sweep that returns the number of
+ * bit mismatches over `pairs` (o, d) pairs (must be 0). */
+int pt_test_slab_quotients(const float *o, const float *d, int n, float *t1, float *t2, float *ref1, float *ref2);
+int pt_test_slab_quotients_sweep(uint64_t seed, int64_t pairs, uint64_t *mismatches);
 int pt_test_hemisphere(const float *normals3, const int32_t *iter_index_depth3, int n, float *out3);
 int pt_test_sincos(const float *x, int n, float *s, float *c);
 int pt_test_reflect_refract(const float *I3, const float *N3, const float *eta, int n, float *refl3,

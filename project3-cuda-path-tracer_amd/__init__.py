@@ -46,6 +46,7 @@ ABI_SYMBOLS = [
     "pt_counters_reset", "pt_free", "pt_last_error", "pt_device_count", "pt_debug_trace_paths",
     "pt_scan_exclusive_i32", "pt_compact_nonzero_i32", "pt_test_utilhash", "pt_test_rng",
     "pt_test_intersect", "pt_test_hemisphere", "pt_test_sincos", "pt_test_reflect_refract",
+    "pt_test_slab_quotients", "pt_test_slab_quotients_sweep",
 ]
 
 
@@ -104,6 +105,8 @@ def lib():
         L.pt_test_hemisphere.argtypes = [vp, vp, i32, vp]
         L.pt_test_sincos.argtypes = [vp, i32, vp, vp]
         L.pt_test_reflect_refract.argtypes = [vp, vp, vp, i32, vp, vp]
+        L.pt_test_slab_quotients.argtypes = [vp, vp, i32, vp, vp, vp, vp]
+        L.pt_test_slab_quotients_sweep.argtypes = [C.c_uint64, i64, C.POINTER(C.c_uint64)]
         _lib = L
     return _lib
 
@@ -312,6 +315,20 @@ def test_reflect_refract(I, N, eta):
     r1, r2 = np.empty_like(I), np.empty_like(I)
     _check(lib().pt_test_reflect_refract(_p(I), _p(N), _p(eta), len(I), _p(r1), _p(r2)))
     return r1, r2
+
+
+def test_slab_quotients(o, d):
+    o = np.ascontiguousarray(o, np.float32)
+    d = np.ascontiguousarray(d, np.float32)
+    out = [np.empty_like(o) for _ in range(4)]
+    _check(lib().pt_test_slab_quotients(_p(o), _p(d), o.size, *[_p(a) for a in out]))
+    return out
+
+
+def test_slab_quotients_sweep(seed, pairs):
+    m = C.c_uint64(0)
+    _check(lib().pt_test_slab_quotients_sweep(seed, pairs, C.byref(m)))
+    return int(m.value)
 
 
 def scan_exclusive_dev(in_ptr, out_ptr, n, stream=0):

@@ -165,6 +165,38 @@ struct Hit {
     bool  outside;
 };
 
+// ---- the two slab quotients of one axis: t1 = (-.5 - o) / d, t2 = (+.5 - o) / d ---------------------
+// Correctly rounded fp32 division is ~11 VALU instructions on gfx950 (v_div_scale x2, v_rcp, 4 fma, mul,
+// v_div_fmas, v_div_fixup) and hipcc does not share anything between two quotients of one divisor.
+// Inside the range where v_div_scale_f32 leaves both operands unscaled and v_div_fixup_f32 returns its
+// first operand (both operands normal and far from the exponent limits), that sequence is exactly
+//     r = rcp(d); r += fma(-d, r, 1) * r;  q = a * r;  q += fma(-d, q, a) * r;  q += fma(-d, q, a) * r
+// The same instructions are issued here ONCE for the shared reciprocal and as packed (v_pk_*) pairs for
+// the two numerators; outside the guarded range the plain `/` is used.  Bit-identical to `/` by
+// construction; tests/test_gpu_parity.py::test_slab_quotients_equal_ieee_division checks it on 10^9 pairs.
+// Numerators: o is a float, so a = +-.5 - o is either +0 (o = +-.5) or at least 2^-25 in magnitude, never
+// -0 and never tiny; the guard therefore only bounds |o| and |d|.
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void slabQuotients(float o, float d, float &t1, float &t2) {
+    const float a1 = -0.5f - o, a2 = +0.5f - o;
+    const float ad = __builtin_fabsf(d);
+    const bool fast = __builtin_fabsf(o) <= 0x1p+39f && ad >= 0x1p-40f && ad <= 0x1p+40f;   // NaN fails all three
+    if (fast) {
+        float r = __builtin_amdgcn_rcpf(d);
+        r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+        const float2v nd = {-d, -d}, rr = {r, r}, a = {a1, a2};
+        float2v q = a * rr;
+        q = __builtin_elementwise_fma(__builtin_elementwise_fma(nd, q, a), rr, q);
+        q = __builtin_elementwise_fma(__builtin_elementwise_fma(nd, q, a), rr, q);
+        t1 = q.x;
+        t2 = q.y;
+    } else {
+        t1 = a1 / d;
+        t2 = a2 / d;
+    }
+}
+
 // src/intersections.h:47-89
 //
 // Early miss (exact, not a heuristic): if on some axis the object-space origin lies beyond a face
@@ -195,9 +227,8 @@ __device__ __forceinline__ float boxIntersectionTest(const GeomDev &g, F3 ro, F3
     const float qda[3] = {qd.x, qd.y, qd.z};
 #pragma unroll
     for (int xyz = 0; xyz < 3; ++xyz) {
-        const float qdxyz = qda[xyz];
-        const float t1 = (-0.5f - qoa[xyz]) / qdxyz;
-        const float t2 = (+0.5f - qoa[xyz]) / qdxyz;
+        float t1, t2;
+        slabQuotients(qoa[xyz], qda[xyz], t1, t2);
         const float ta = t1 < t2 ? t1 : t2;  // glm::min, func_common.inl:409-414
         const float tb = t1 > t2 ? t1 : t2;  // glm::max, func_common.inl:430-435
         const float nv = t2 < t1 ? +1.0f : -1.0f;

@@ -579,6 +579,38 @@ __global__ void k_test_intersect(const GeomDev *geoms, const int *gidx, const fl
     n3[3 * i] = N.x; n3[3 * i + 1] = N.y; n3[3 * i + 2] = N.z;
     outside[i] = o ? 1 : 0;
 }
+// slabQuotients vs the compiler's correctly rounded division; counts mismatching lanes
+__global__ void k_test_slab_quotients(const float *o, const float *d, int n, float *t1, float *t2, float *r1, float *r2) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    slabQuotients(o[i], d[i], t1[i], t2[i]);
+    r1[i] = (-0.5f - o[i]) / d[i];
+    r2[i] = (+0.5f - o[i]) / d[i];
+}
+// pseudo-random sweep entirely on the device: returns the number of bit mismatches (NaN == NaN)
+__global__ void k_sweep_slab_quotients(unsigned long long seed, int per_thread, unsigned long long *mismatches) {
+    unsigned long long x = seed + (blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ull;
+    unsigned int bad = 0;
+    for (int k = 0; k < per_thread; ++k) {
+        x ^= x << 13; x ^= x >> 7; x ^= x << 17;                     // xorshift64
+        const uint32_t ob = (uint32_t)x, db = (uint32_t)(x >> 32);
+        float o, d;
+        if ((k & 3) == 0) {            // raw bit patterns: every exponent, denormals, inf, NaN
+            o = __uint_as_float(ob); d = __uint_as_float(db);
+        } else {                       // the range the tracer lives in: |o| < ~4000, |d| <= 1
+            o = ((int)(ob >> 8) - (1 << 23)) * (1.0f / 2048.0f) * ((k & 4) ? 1.0f : 1e-3f);
+            d = __uint_as_float((db & 0x807fffffu) | ((uint32_t)(127 - (db >> 23 & 31)) << 23));
+            if ((k & 15) == 5) o = (ob & 1) ? 0.5f : -0.5f;           // numerator exactly +0
+        }
+        float t1, t2;
+        slabQuotients(o, d, t1, t2);
+        const float r1 = (-0.5f - o) / d, r2 = (+0.5f - o) / d;
+        const bool e1 = __float_as_uint(t1) == __float_as_uint(r1) || (t1 != t1 && r1 != r1);
+        const bool e2 = __float_as_uint(t2) == __float_as_uint(r2) || (t2 != t2 && r2 != r2);
+        bad += (e1 ? 0u : 1u) + (e2 ? 0u : 1u);
+    }
+    if (bad) atomicAdd(mismatches, (unsigned long long)bad);
+}
 __global__ void k_test_hemisphere(const float *nrm, const int *iid, int n, float *out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1218,6 +1250,42 @@ int pt_test_intersect(const PtGeom *geoms, int ngeoms, const int32_t *geom_index
     DOWN(p3, dp, (size_t)n * 3);
     DOWN(n3, dn, (size_t)n * 3);
     DOWN(outside, dout, n);
+    return PT_OK;
+}
+
+int pt_test_slab_quotients(const float *o, const float *d, int n, float *t1, float *t2, float *ref1, float *ref2) {
+    NEED_GPU();
+    if (n <= 0) return PT_OK;
+    DevBuf<float> a, b, q1, q2, r1, r2;
+    UP(a, o, n);
+    UP(b, d, n);
+    int rc;
+    if ((rc = q1.alloc(n)) || (rc = q2.alloc(n)) || (rc = r1.alloc(n)) || (rc = r2.alloc(n))) return rc;
+    hipLaunchKernelGGL(k_test_slab_quotients, GRID(n), a.p, b.p, n, q1.p, q2.p, r1.p, r2.p);
+    HIPCHECK(hipDeviceSynchronize());
+    DOWN(t1, q1, n);
+    DOWN(t2, q2, n);
+    DOWN(ref1, r1, n);
+    DOWN(ref2, r2, n);
+    return PT_OK;
+}
+
+int pt_test_slab_quotients_sweep(uint64_t seed, int64_t pairs, uint64_t *mismatches) {
+    NEED_GPU();
+    if (!mismatches || pairs < 0) return fail(PT_ERR_INVALID, "pt_test_slab_quotients_sweep: bad argument");
+    DevBuf<unsigned long long> m;
+    int rc = m.alloc(1);
+    if (rc) return rc;
+    HIPCHECK(hipMemset(m.p, 0, 8));
+    const int per_thread = 1024, threads = 256;
+    long long blocks = (pairs + (long long)per_thread * threads - 1) / ((long long)per_thread * threads);
+    if (blocks < 1) blocks = 1;
+    if (blocks > (1 << 20)) blocks = 1 << 20;
+    hipLaunchKernelGGL(k_sweep_slab_quotients, dim3((unsigned)blocks), dim3(threads), 0, 0, (unsigned long long)seed, per_thread, m.p);
+    HIPCHECK(hipDeviceSynchronize());
+    unsigned long long h = 0;
+    HIPCHECK(hipMemcpy(&h, m.p, 8, hipMemcpyDeviceToHost));
+    *mismatches = h;
     return PT_OK;
 }
 

@@ -79,6 +79,29 @@ def test_intersections_bit_exact_vs_reference_vectors(gpu, oracle):
     assert np.array_equal(o, z["outside"].reshape(-1))
 
 
+def test_slab_quotients_equal_ieee_division(gpu):
+    # The box test's two quotients per axis share one reciprocal and run as packed Newton steps inside a
+    # guarded exponent range; they must equal the correctly rounded `/` bit for bit, everywhere.
+    rng = np.random.default_rng(11)
+    n = 1 << 20
+    o = np.concatenate([rng.uniform(-2000, 2000, n // 2), rng.uniform(-1, 1, n // 4),
+                        rng.integers(0, 2**32, n // 4, dtype=np.uint64).astype(np.uint32).view(np.float32)]).astype(np.float32)
+    d = np.concatenate([rng.uniform(-1, 1, n // 2), rng.normal(size=n // 4) * 1e-6,
+                        rng.integers(0, 2**32, n // 4, dtype=np.uint64).astype(np.uint32).view(np.float32)]).astype(np.float32)
+    special = np.array([0.0, -0.0, 0.5, -0.5, 1.0, np.inf, -np.inf, np.nan, 1e-45, 1e-38, 2.0**-40, 2.0**-41, 2.0**40,
+                        2.0**41, 2.0**39, 3.4e38, 1e-30], np.float32)
+    so, sd = np.meshgrid(special, special)
+    o = np.concatenate([o, so.ravel()])
+    d = np.concatenate([d, sd.ravel()])
+    t1, t2, r1, r2 = gpu.test_slab_quotients(o, d)
+    assert np.array_equal(bits(t1), bits(r1)) and np.array_equal(bits(t2), bits(r2))
+    # and against numpy's IEEE division on the host
+    with np.errstate(all="ignore"):
+        assert np.array_equal(bits(r1), bits((np.float32(-0.5) - o) / d))
+        assert np.array_equal(bits(r2), bits((np.float32(0.5) - o) / d))
+    assert gpu.test_slab_quotients_sweep(12345, 1 << 30) == 0        # 2^30 more pairs on the device
+
+
 def test_reflect_refract_bit_exact(gpu):
     z = np.load(os.path.join(GOLD, "glm_ops.npz"))
     r1, r2 = gpu.test_reflect_refract(z["An"], z["Bn"], z["eta"])
