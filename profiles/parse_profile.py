@@ -7,10 +7,12 @@
     profiles/pmc_traffic.json            {"hbm_bytes_per_bounce_launch": ...} read by bench.py
 
 HBM traffic per launch = FETCH_SIZE * 1024 * read_factor + WRITE_SIZE * 1024 (both counters are in KiB).
-read_factor is CALIBRATED on this access pattern (4 B per lane SoA reads): the first bounce launch of
-every iteration reads exactly 44 B x P of path state, so factor = known bytes / counted bytes
-(MI355X_MICROARCH.md, section HBM: FETCH_SIZE under-counts coalesced streams by 2x on gfx950; calibrate).
-WRITE_SIZE is checked the same way on the ray-generation kernel (44 B x P written).
+read_factor = 2 on gfx950 for coalesced streams (MI355X_MICROARCH.md, section HBM).  It was CALIBRATED on
+this access pattern (4 B per lane SoA reads) with the round-1 builds that still had a separate ray-generation
+kernel: its first bounce launch read exactly 44 B x P (factor measured 1.88 / 1.99) and the ray-generation
+kernel wrote exactly 44 B x P (WRITE_SIZE factor 0.994 / 1.000) -- profiles/r01_pmc_summary.json,
+profiles/r01b_pmc_summary.json.  Builds with the fused first bounce have no launch with a known byte count,
+so the calibrated factors are reused.
 
     python profiles/parse_profile.py <tag> [--pixels 921600]
 """
@@ -31,8 +33,10 @@ ROOT = os.path.dirname(HERE)
 def kind(name):
     if "k_bounce" in name:
         return "k_bounce"
-    if "k_generate_rays" in name or "k_bounce<true>" in name and False:
+    if "k_generate_rays" in name:
         return "k_generate_rays"
+    if "k_commit" in name:
+        return "k_commit"
     if "k_to_rgba8" in name:
         return "k_to_rgba8"
     return "other"
@@ -58,11 +62,15 @@ def main():
         txt = subprocess.run([sys.executable, os.path.join(HERE, "trace_summary.py"), os.path.join(src, "trace")],
                              capture_output=True, text=True).stdout
         open(os.path.join(HERE, args.tag + "_one_iteration.txt"), "w").write(txt)
+        tot = collections.defaultdict(lambda: [0.0, 0])
         for r in csv.DictReader(open(stats[0])):
             k = kind(r["Name"])
-            if k != "other":
-                out.setdefault(k, {})["trace_avg_ns"] = float(r["AverageNs"])
-                out[k]["trace_calls"] = int(r["Calls"])
+            if k != "other":     # both k_bounce<true> and k_bounce<false> count as k_bounce
+                tot[k][0] += float(r["TotalDurationNs"])
+                tot[k][1] += int(r["Calls"])
+        for k, (ns, calls) in tot.items():
+            out.setdefault(k, {})["trace_avg_ns"] = ns / max(calls, 1)
+            out[k]["trace_calls"] = calls
 
     per_dispatch = collections.defaultdict(dict)   # (pass, dispatch id) -> counters
     for p in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds"):
@@ -105,7 +113,7 @@ def main():
 
     kb = out.get("k_bounce", {}).get("pmc_per_dispatch", {})
     if "FETCH_SIZE" in kb and "WRITE_SIZE" in kb:
-        rf = cal.get("read_factor", 1.0)
+        rf = cal.get("read_factor", 2.0)
         # snap to the two documented regimes (exact, or the 2x under-count of coalesced streams)
         rf_used = 2.0 if rf > 1.5 else 1.0
         traffic = kb["FETCH_SIZE"] * 1024.0 * rf_used + kb["WRITE_SIZE"] * 1024.0

@@ -183,8 +183,8 @@ class Scene:
         self._refresh()
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            host_lib().pth_scene_free(self._h)
+        if getattr(self, "_h", None) and _host is not None:   # _host is gone during interpreter shutdown
+            _host.pth_scene_free(self._h)
             self._h = None
 
 

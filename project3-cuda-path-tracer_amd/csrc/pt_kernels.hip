@@ -37,7 +37,9 @@ constexpr int kNumArrays = 11;       // SoA PathSegment: origin3, dir3, throughp
 constexpr int kMaxDepthSlots = PT_MAX_DEPTH + 2;
 
 // ---- device control block ------------------------------------------------------------------------
-constexpr int kSeg = 8;              // path buffers are split into kSeg segments with one append counter each
+constexpr int kOct = 8;              // direction octants: paths are binned by the signs of their new direction
+constexpr int kSub = 4;              // append-counter shards per octant (workgroup blockIdx % kSub)
+constexpr int kSeg = kOct * kSub;    // path buffers are split into kSeg segments with one append counter each
 constexpr int kCtrPad = 32;          // one counter per 128-byte line: same-line atomics serialise at the memory side
 
 struct Ctrl {
@@ -49,7 +51,7 @@ struct Ctrl {
     uint32_t error;                    // sticky device fault (scan-library look-back timeout)
     uint32_t pad[kCtrPad - 1];
     unsigned long long sum_live[kMaxDepthSlots];
-    unsigned long long light_hits[kSeg][kCtrPad / 2], misses[kSeg][kCtrPad / 2];
+    unsigned long long light_hits[kOct][kCtrPad / 2], misses[kOct][kCtrPad / 2];
 };
 
 // Camera constants derived once on the host (spec S2)
@@ -208,12 +210,18 @@ __global__ __launch_bounds__(kBlock) void k_debug_camera_rays(KParams prm, int i
 
 // ---- one bounce: intersect + shade + accumulate + compact (spec S3-S8) -----------------------------
 // Persistent workgroups walk the 256-path tiles of the bounce's queue (the kSeg input segments laid
-// end to end), blockIdx-strided.  Survivors of tile T are appended to output segment T % kSeg:
-//   ranks inside the workgroup  = exclusive scan of the alive flags (ballot + mbcnt per wave,
-//                                 wave totals through LDS),
-//   base of the workgroup       = ONE atomicAdd on that segment's counter.
+// end to end), blockIdx-strided.  Survivors are BINNED BY DIRECTION OCTANT while they are compacted:
+//   segment   = octant(new direction) * kSub + blockIdx % kSub,
+//   rank      = exclusive scan of the lane's octant flag inside the wave (ballot + mbcnt) plus the earlier
+//               waves' totals through LDS = workgroup-level exclusive scan per octant,
+//   base      = ONE atomicAdd per non-empty octant of the tile on that segment's counter (8 lanes, one
+//               instruction).
+// A tile of the next bounce therefore holds rays of a single direction octant, which turns the exact
+// early-miss of the box test (pt_device.h) into a wave-uniform branch for axis-aligned boxes.  Queue order
+// never influences results: RNG and accumulator are keyed on the pixel index.
 // No workgroup ever waits for another one, so there is no residency / dispatch-order assumption.
-// Output segment T % kSeg receives at most ceil(tiles/kSeg) * 256 paths <= segCap (see pt_init).
+// A segment receives survivors of the tiles of the workgroups with one value of blockIdx % kSub only,
+// i.e. at most ceil(tiles / kSub) * 256 <= segCap paths (see pt_init).
 //
 // FIRST = true is bounce 1 fused with camera-ray generation (spec S2): tile T holds the paths
 // j = 256 T + lane of this shard's pixel list and the ray is built in registers, so the first bounce
@@ -227,32 +235,39 @@ __global__ __launch_bounds__(kBlock) void k_bounce(KParams prm, int iter, int de
     GeomDev *sgeoms = reinterpret_cast<GeomDev *>(smem);
     MaterialDev *smats = reinterpret_cast<MaterialDev *>(smem + sizeof(GeomDev) * prm.ngeoms);
     uint32_t *s_misc = reinterpret_cast<uint32_t *>(smem + sizeof(GeomDev) * prm.ngeoms + sizeof(MaterialDev) * prm.nmats);
-    uint32_t *s_wave = s_misc;           // [kWaves] alive count per wave
-    uint32_t *s_base = s_misc + kWaves;  // [1]      first output slot of this tile
+    uint32_t *s_wave = s_misc;                       // [kWaves][kOct] alive count per wave and octant
+    uint32_t *s_base = s_wave + kWaves * kOct;       // [kOct]   first output slot of this tile per octant
+    uint32_t *s_segcnt = s_base + kOct;              // [kSeg]   paths per input segment
+    uint32_t *s_segpre = s_segcnt + kSeg;            // [kSeg+2] tile prefix per input segment, [kSeg+1] = live paths
 
     if (lastBounce) {   // re-arm the next iteration: nobody touches the other parity's counters now
         uint32_t *other = &ctrl->seg_count[parity ^ 1][0][0][0];
         const int nwords = (prm.traceDepth + 2) * kSeg * kCtrPad;
         for (int i = blockIdx.x * kBlock + threadIdx.x; i < nwords; i += gridDim.x * kBlock) other[i] = 0u;
     }
-    // input queue: segment s holds cnt[s] paths = tiles [pre[s], pre[s+1]) of the global tile index
-    uint32_t cnt[kSeg], pre[kSeg + 1];
-    pre[0] = 0;
-    uint32_t nLive = 0;
+    // input queue: segment s holds s_cnt[s] paths = tiles [s_pre[s], s_pre[s+1]) of the global tile index
+    uint32_t nLive, numTiles;
     if (FIRST) {
         nLive = (uint32_t)prm.nLocal;
-#pragma unroll
-        for (int sg = 0; sg < kSeg; ++sg) { cnt[sg] = 0; pre[sg + 1] = 0; }
-        pre[kSeg] = (nLive + kBlock - 1) / kBlock;
+        numTiles = (nLive + kBlock - 1) / kBlock;
     } else {
+        if (threadIdx.x < 64) {          // wave 0: exclusive scan of the kSeg tile counts
+            const uint32_t c = threadIdx.x < kSeg ? ctrl->seg_count[parity][depth][threadIdx.x][0] : 0u;
+            const uint32_t t = (c + kBlock - 1) / kBlock;
+            uint32_t inc = t, sum = c;
 #pragma unroll
-        for (int sg = 0; sg < kSeg; ++sg) {
-            cnt[sg] = ctrl->seg_count[parity][depth][sg][0];
-            pre[sg + 1] = pre[sg] + (cnt[sg] + kBlock - 1) / kBlock;
-            nLive += cnt[sg];
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t up = __shfl_up(inc, o, 64), us = __shfl_up(sum, o, 64);
+                if ((int)threadIdx.x >= o) { inc += up; sum += us; }
+            }
+            if (threadIdx.x < kSeg) { s_segcnt[threadIdx.x] = c; s_segpre[threadIdx.x + 1] = inc; }
+            if (threadIdx.x == 0) s_segpre[0] = 0;
+            if (threadIdx.x == 63) s_segpre[kSeg + 1] = sum;   // total live paths
         }
+        __syncthreads();
+        numTiles = s_segpre[kSeg];
+        nLive = s_segpre[kSeg + 1];
     }
-    const uint32_t numTiles = pre[kSeg];
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctrl->sum_live[depth], (unsigned long long)nLive);
     if (blockIdx.x >= numTiles) return;
 
@@ -270,6 +285,7 @@ __global__ __launch_bounds__(kBlock) void k_bounce(KParams prm, int iter, int de
     __syncthreads();
 
     uint32_t waveLight = 0, waveMiss = 0;   // wave-uniform tallies, flushed once at the end
+    uint32_t sgIn = 0;                      // input segment of the current tile (tiles are visited in increasing order)
     for (uint32_t T = blockIdx.x; T < numTiles; T += gridDim.x) {
         bool valid;
         uint32_t idx = 0;
@@ -278,16 +294,10 @@ __global__ __launch_bounds__(kBlock) void k_bounce(KParams prm, int iter, int de
             valid = idx < nLive;
         } else {
             // global tile -> (segment, local tile)
-            uint32_t sg = 0;
-#pragma unroll
-            for (int k = 1; k < kSeg; ++k) sg += T >= pre[k] ? 1u : 0u;
-            uint32_t segCnt = cnt[0], segPre = 0;
-#pragma unroll
-            for (int k = 1; k < kSeg; ++k)
-                if (sg == (uint32_t)k) { segCnt = cnt[k]; segPre = pre[k]; }
-            const uint32_t local = (T - segPre) * kBlock + threadIdx.x;
-            valid = local < segCnt;
-            idx = sg * (uint32_t)prm.segCap + local;
+            while (T >= s_segpre[sgIn + 1]) ++sgIn;
+            const uint32_t local = (T - s_segpre[sgIn]) * kBlock + threadIdx.x;
+            valid = local < s_segcnt[sgIn];
+            idx = sgIn * (uint32_t)prm.segCap + local;
         }
 
         bool alive = false;
@@ -319,7 +329,7 @@ __global__ __launch_bounds__(kBlock) void k_bounce(KParams prm, int iter, int de
                 bool o = false;
                 float t;
                 if (type == 0) t = sphereIntersectionTest(G, org, dir, p, n, o);
-                else           t = boxIntersectionTest<FIRST>(G, org, dir, p, n, o);
+                else           t = boxIntersectionTest<true>(G, org, dir, p, n, o);
                 if (t > 0.0f && (hit < 0 || t < tbest)) {
                     tbest = t; hit = g; P = p; N = n; outside = o;
                 }
@@ -393,35 +403,43 @@ __global__ __launch_bounds__(kBlock) void k_bounce(KParams prm, int iter, int de
         waveLight += (uint32_t)__popcll(__ballot(lightHit));
         waveMiss += (uint32_t)__popcll(__ballot(missed));
 
-        if (!lastBounce) {                                       // S8: compaction into `out`
-            const int wave = threadIdx.x >> 6;
-            const unsigned long long ballot = __ballot(alive);
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32),
-                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, 0u));
-            if ((threadIdx.x & 63) == 0) s_wave[wave] = (uint32_t)__popcll(ballot);
-            __syncthreads();
-            uint32_t waveOff = 0, total = 0;
+        if (!lastBounce) {                                       // S8: compaction into `out`, binned by octant
+            const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+            const int oct = (dir.x < 0.0f ? 1 : 0) | (dir.y < 0.0f ? 2 : 0) | (dir.z < 0.0f ? 4 : 0);
+            uint32_t rank = 0, myCount = 0;
 #pragma unroll
-            for (int w = 0; w < kWaves; ++w) {
-                const uint32_t c = s_wave[w];
-                waveOff += w < wave ? c : 0u;
-                total += c;
+            for (int k = 0; k < kOct; ++k) {
+                const unsigned long long m = __ballot(alive && oct == k);
+                const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (oct == k) rank = r;
+                if (lane == k) myCount = (uint32_t)__popcll(m);
             }
-            const uint32_t oseg = T % kSeg;
-            if (threadIdx.x == 0) *s_base = total ? atomicAdd(&ctrl->seg_count[parity][depth + 1][oseg][0], total) : 0u;
+            if (lane < kOct) s_wave[wave * kOct + lane] = myCount;
+            __syncthreads();
+            if (threadIdx.x < kOct) {
+                uint32_t total = 0;
+#pragma unroll
+                for (int w = 0; w < kWaves; ++w) total += s_wave[w * kOct + threadIdx.x];
+                const uint32_t oseg = threadIdx.x * kSub + (blockIdx.x % kSub);
+                s_base[threadIdx.x] = total ? atomicAdd(&ctrl->seg_count[parity][depth + 1][oseg][0], total) : 0u;
+            }
             __syncthreads();
             if (alive) {
-                const uint32_t slot = oseg * (uint32_t)prm.segCap + *s_base + waveOff + rank;
+                uint32_t waveOff = 0;
+                for (int w = 0; w < wave; ++w) waveOff += s_wave[w * kOct + oct];
+                const uint32_t oseg = (uint32_t)oct * kSub + (blockIdx.x % kSub);
+                const uint32_t slot = oseg * (uint32_t)prm.segCap + s_base[oct] + waveOff + rank;
                 out.a(0)[slot] = org.x; out.a(1)[slot] = org.y; out.a(2)[slot] = org.z;
                 out.a(3)[slot] = dir.x; out.a(4)[slot] = dir.y; out.a(5)[slot] = dir.z;
                 out.a(6)[slot] = col.x; out.a(7)[slot] = col.y; out.a(8)[slot] = col.z;
                 out.pix()[slot] = pix;
                 out.rem()[slot] = rem - 1;
             }
+            __syncthreads();   // s_wave / s_base are rewritten by the next tile
         }
     }
     if ((threadIdx.x & 63) == 0) {
-        const int shard = blockIdx.x % kSeg;
+        const int shard = blockIdx.x % kOct;
         if (waveLight) atomicAdd(&ctrl->light_hits[shard][0], (unsigned long long)waveLight);
         if (waveMiss) atomicAdd(&ctrl->misses[shard][0], (unsigned long long)waveMiss);
     }
@@ -936,10 +954,12 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
         S.ownImage = true;
         HIPCHECK(hipMemsetAsync(S.image, 0, (size_t)S.P * 3 * sizeof(float), S.stream));
     }
-    // Path buffers: kSeg segments.  Output segment T % kSeg of a bounce receives the survivors of at most
-    // ceil(tiles / kSeg) tiles, and tiles <= ceil(nLocal/256) + kSeg (one partial tile per input segment).
+    // Path buffers: kSeg = kOct x kSub segments.  A segment receives survivors only from the workgroups with one
+    // value of blockIdx % kSub; tiles are blockIdx-strided and the grid is a multiple of kSub, so those workgroups
+    // process at most ceil(tiles / kSub) tiles, and tiles <= ceil(nLocal/256) + kSeg (one partial tile per input
+    // segment).  Worst case (every ray in one octant) is provisioned: 8x the live paths, 325 MB per buffer at 720p.
     S.numTilesMax = (S.nLocal + kBlock - 1) / kBlock + kSeg;
-    S.segCap = ((S.numTilesMax + kSeg - 1) / kSeg) * kBlock;
+    S.segCap = ((S.numTilesMax + kSub - 1) / kSub) * kBlock;
     k.segCap = S.segCap;
     const size_t cap = (size_t)kSeg * S.segCap;
     // Iterations are independent (RNG keyed on pixel/iteration/depth), so up to `nslots` of them are in flight
@@ -966,7 +986,8 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     HIPCHECK(hipMemcpy(S.dgeoms, hg.data(), hg.size() * sizeof(GeomDev), hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(S.dmats, hm.data(), hm.size() * sizeof(MaterialDev), hipMemcpyHostToDevice));
 
-    S.ldsBytes = sizeof(GeomDev) * ngeoms + sizeof(MaterialDev) * nmats + 16 * sizeof(uint32_t);
+    S.ldsBytes = sizeof(GeomDev) * ngeoms + sizeof(MaterialDev) * nmats +
+                 (kWaves * kOct + kOct + kSeg + kSeg + 2 + 2) * sizeof(uint32_t);
     if (S.ldsBytes > 160 * 1024) return fail(PT_ERR_INVALID, "pt_init: scene does not fit the 160 KiB LDS (%zu B)", S.ldsBytes);
     if (S.ldsBytes > 64 * 1024) {
         HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bounce<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.ldsBytes));
@@ -975,8 +996,8 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     int rc = persistent_grid(reinterpret_cast<const void *>(k_bounce<false>), S.ldsBytes, &S.grid);
     if (rc) return rc;
     if (S.grid > S.numTilesMax) S.grid = S.numTilesMax;
-    S.grid = (S.grid / kSeg) * kSeg;      // consecutive tiles of one workgroup cycle through all output segments
-    if (S.grid < kSeg) S.grid = kSeg;
+    S.grid = (S.grid / kSub) * kSub;      // T % kSub == blockIdx % kSub for every tile T of a workgroup
+    if (S.grid < kSub) S.grid = kSub;
     HIPCHECK(hipDeviceSynchronize());
     S.init = true;
     g_err.clear();
@@ -1049,12 +1070,12 @@ int pt_counters(PtCounters *out) {
     rc = resolve_events(S.evBounce, S.msBounce, S.nBounce);
     if (rc) return rc;
     memset(out, 0, sizeof *out);
-    static Ctrl h;   // 130 KB: keep it off the stack
+    static Ctrl h;   // 0.5 MB: keep it off the stack
     bool fault = false;
     for (int i = 0; i < S.nslots; ++i) {
         HIPCHECK(hipMemcpy(&h, S.slot[i].ctrl, sizeof h, hipMemcpyDeviceToHost));
         for (int d = 0; d < kMaxDepthSlots; ++d) out->live[d] += (int64_t)h.sum_live[d];
-        for (int sg = 0; sg < kSeg; ++sg) {
+        for (int sg = 0; sg < kOct; ++sg) {
             out->light_hits += (int64_t)h.light_hits[sg][0];
             out->misses += (int64_t)h.misses[sg][0];
         }
