@@ -9,10 +9,10 @@ when N > 1).  Scene, accumulator and path state are resident in HBM before the t
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU)
 
-N > 1: image rows are sharded round-robin over the ranks (row y -> rank y % N), every rank renders
-its rows into a zeroed full-frame accumulator, and a single RCCL reduce(sum) to rank 0 per iteration
-assembles the frame (disjoint rows: x + 0 is exact, so the result is bit-identical to 1 GPU).
-Fixed total work -> "scaling": "strong".
+N > 1: image rows are sharded round-robin over the ranks (row y -> rank y % N), every rank accumulates
+only its own rows (packed), and ONE RCCL collective per iteration -- a gather of the row blocks to rank 0
+over xGMI -- assembles the frame (disjoint rows: bit-identical to 1 GPU; it moves 1/N of the bytes the
+reduce of zero-padded full frames would).  Fixed total work -> "scaling": "strong".
 
 Prints ONE JSON line on rank 0, with `roofline` (dominant kernel = the fused bounce kernel, HIP-event
 timed, against the 8 TB/s HBM peak) and `cpu_baseline` (the single-thread CPU oracle on a bounded
@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--scene", default=os.path.join(ROOT, "scenes", "cornell.txt"))
     ap.add_argument("--res", type=int, nargs=2, default=[1280, 720])
     ap.add_argument("--depth", type=int, default=8)
-    ap.add_argument("--cpu-spp", type=int, default=12, help="spp of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-spp", type=int, default=40, help="spp of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--pipeline", type=int, default=0, help="iterations in flight (PtOptions.pipeline_depth; 0 = library default)")
     ap.add_argument("--pmc-traffic-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"),
                     help="HBM bytes per bounce-kernel launch from a rocprofv3 --pmc run (profiles/README.md)")
@@ -82,33 +82,44 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the hot path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    # BENCH_BACKEND=gloo lets the N > 1 path be rehearsed with several ranks on ONE GPU (RCCL needs one
+    # GPU per rank); the real runs use nccl = RCCL over xGMI.
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    device_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
     import __graft_entry__ as ge
     pt = ge.load_package()
     ptdist = ge.load_submodule("distributed")
     if world > 1:
-        ptdist.init_process_group("nccl")
+        ptdist.init_process_group(backend)
 
     W, H = args.res
     scene = pt.Scene(args.scene)
     scene.set_resolution(W, H)
     P = W * H
-    # accumulator as a torch tensor so RCCL can reduce it; zeroed full frame on every rank
-    accum = torch.zeros(P * 3, dtype=torch.float32, device="cuda")
-    frame = torch.zeros_like(accum) if world > 1 else None           # rank 0 receives the assembled frame here
+    # accumulator as a torch tensor so RCCL can move it.  N = 1: the full frame.  N > 1: this rank's rows
+    # only (packed, padded to the largest shard); rank 0 assembles `frame` from the gathered blocks.
+    if world > 1:
+        accum = torch.zeros(ptdist.padded_block_floats(W, H, world), dtype=torch.float32, device="cuda")
+        frame = torch.zeros(P * 3, dtype=torch.float32, device="cuda") if rank == 0 else None
+        bufs = ptdist.make_gather_buffers(accum, world, rank)
+        shard_flag = pt.PT_FLAG_ACCUM_SHARD_ROWS
+    else:
+        accum = torch.zeros(P * 3, dtype=torch.float32, device="cuda")
+        frame, bufs, shard_flag = None, None, 0
     stream = torch.cuda.current_stream()
 
     def init(flags, pipeline):
         pt.pathtraceFree()
         pt.pathtraceInit(scene, shard_rank=rank, shard_count=world, stream=stream.cuda_stream,
-                         accum_dev=accum.data_ptr(), device=local_rank, flags=flags, traceDepth=args.depth,
-                         pipeline_depth=pipeline)
+                         accum_dev=accum.data_ptr(), device=device_index, flags=flags | shard_flag,
+                         traceDepth=args.depth, pipeline_depth=pipeline)
 
     def step(it):
         pt.pathtrace(None, 0, it, readback=False)
         if world > 1:
-            # the single collective of the data path: per-iteration reduce of the accumulator over xGMI
-            ptdist.reduce_frame(accum, frame, dst=0)
+            # the single collective of the data path: per-iteration gather of the row blocks over xGMI
+            ptdist.gather_frame(accum, bufs, frame, W, H, dst=0)
 
     def barrier():
         if world > 1:
@@ -131,7 +142,7 @@ def main():
     pt.counters_reset()
     dt = timed(1 + args.warmup, args.steps)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     cntA = pt.counters()
@@ -177,7 +188,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s %dx%d, %d spp, %d bounces%s" % (
                            os.path.relpath(args.scene, ROOT), W, H, args.steps, D,
-                           "" if world == 1 else ", rows sharded y%%%d + RCCL reduce per iteration" % world),
+                           "" if world == 1 else ", rows sharded y%%%d + RCCL gather of the row blocks per iteration" % world),
                        "paths_per_step_nominal": P * D,
                        "live_segments_per_step": round(sum(live[1:D + 1]) / max(args.steps, 1), 1),
                        "live_Msegments_per_s": round(sum(int(cntA.live[d]) for d in range(1, D + 1)) / dt / 1e6, 2)},

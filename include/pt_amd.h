@@ -66,7 +66,11 @@ typedef enum PtStatus {
 } PtStatus;
 
 enum {
-    PT_FLAG_KERNEL_TIMING = 1 /* bracket every bounce-kernel launch with HIP events (roofline measurement) */
+    PT_FLAG_KERNEL_TIMING = 1,   /* bracket every bounce-kernel launch with HIP events (roofline measurement) */
+    PT_FLAG_ACCUM_SHARD_ROWS = 2 /* the accumulator holds ONLY this shard's rows, packed (local row lr = global row
+                                    lr * shard_count + shard_rank; nLocal * 3 floats): what a multi-GPU run gathers
+                                    at rank 0 instead of reducing zero-padded full frames.  pt_readback still returns
+                                    a full frame (other rows zero). */
 };
 
 typedef struct PtOptions {
@@ -78,9 +82,9 @@ typedef struct PtOptions {
                                  Results do not depend on it: radiance is committed in iteration order. */
     int32_t reserved;
     void   *stream;           /* hipStream_t to enqueue on; NULL = the default stream */
-    float  *accum_dev;        /* optional caller-owned device accumulator, W*H*3 floats, zeroed by the
-                                 caller (e.g. a torch tensor used for the RCCL reduce); NULL = owned
-                                 by the library like dev_image (pathtrace.cu:71,80-81) */
+    float  *accum_dev;        /* optional caller-owned device accumulator, W*H*3 floats (or the shard's rows only
+                                 with PT_FLAG_ACCUM_SHARD_ROWS), zeroed by the caller (e.g. a torch tensor that
+                                 RCCL exchanges); NULL = owned by the library like dev_image (pathtrace.cu:71,80-81) */
 } PtOptions;
 
 #define PT_MAX_DEPTH 62

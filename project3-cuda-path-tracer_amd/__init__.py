@@ -39,6 +39,7 @@ assert GEOM_DTYPE.itemsize == 236 and MATERIAL_DTYPE.itemsize == 44 and CAMERA_D
 
 PT_MAX_DEPTH = 62
 PT_FLAG_KERNEL_TIMING = 1
+PT_FLAG_ACCUM_SHARD_ROWS = 2
 
 # every symbol include/pt_amd.h declares
 ABI_SYMBOLS = [

@@ -449,7 +449,9 @@ __global__ __launch_bounds__(kBlock) void k_bounce(KParams prm, int iter, int de
 // Runs on the caller's stream, one launch per iteration in iteration order, so every pixel receives its
 // samples in exactly the order a sequential renderer adds them (fp32 addition is not associative).
 // Skipping an all-zero contribution equals adding +0 (the accumulator is never -0).
-__global__ __launch_bounds__(kBlock) void k_commit(KParams prm, float *image, float *contrib) {
+// `compactRows`: the accumulator holds only this shard's rows (PT_FLAG_ACCUM_SHARD_ROWS), pixel j of the shard
+// at image[3j]; otherwise it is the full frame indexed by the global pixel index.
+__global__ __launch_bounds__(kBlock) void k_commit(KParams prm, float *image, float *contrib, int compactRows) {
     const int j = blockIdx.x * kBlock + threadIdx.x;
     if (j >= prm.nLocal) return;
     const int lr = j / prm.W;
@@ -458,7 +460,7 @@ __global__ __launch_bounds__(kBlock) void k_commit(KParams prm, float *image, fl
     float *c = contrib + 3 * pix;
     const float cx = c[0], cy = c[1], cz = c[2];
     if (cx != 0.0f || cy != 0.0f || cz != 0.0f) {
-        float *px = image + 3 * pix;
+        float *px = image + 3 * (compactRows ? (size_t)j : pix);
         px[0] += cx; px[1] += cy; px[2] += cz;
         c[0] = 0.0f; c[1] = 0.0f; c[2] = 0.0f;
     }
@@ -950,9 +952,10 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
         S.image = o.accum_dev;
         S.ownImage = false;
     } else {
-        HIPCHECK(hipMalloc(&S.image, (size_t)S.P * 3 * sizeof(float)));
+        const size_t n = (S.flags & PT_FLAG_ACCUM_SHARD_ROWS) ? (size_t)(S.nLocal > 0 ? S.nLocal : 1) : (size_t)S.P;
+        HIPCHECK(hipMalloc(&S.image, n * 3 * sizeof(float)));
         S.ownImage = true;
-        HIPCHECK(hipMemsetAsync(S.image, 0, (size_t)S.P * 3 * sizeof(float), S.stream));
+        HIPCHECK(hipMemsetAsync(S.image, 0, n * 3 * sizeof(float), S.stream));
     }
     // Path buffers: kSeg = kOct x kSub segments.  A segment receives survivors only from the workgroups with one
     // value of blockIdx % kSub; tiles are blockIdx-strided and the grid is a multiple of kSub, so those workgroups
@@ -1021,11 +1024,13 @@ int pt_iterate(int frame, int iter, void *rgba8_dev) {
     // commit on the caller's stream: commits are therefore ordered like the pt_iterate calls
     HIPCHECK(hipStreamWaitEvent(S.stream, sl.evDone, 0));
     if (S.nLocal > 0) {
-        hipLaunchKernelGGL(k_commit, dim3((S.nLocal + kBlock - 1) / kBlock), dim3(kBlock), 0, S.stream, S.prm, S.image, sl.contrib);
+        hipLaunchKernelGGL(k_commit, dim3((S.nLocal + kBlock - 1) / kBlock), dim3(kBlock), 0, S.stream, S.prm, S.image, sl.contrib,
+                           (S.flags & PT_FLAG_ACCUM_SHARD_ROWS) ? 1 : 0);
         HIPCHECK(hipGetLastError());
     }
     HIPCHECK(hipEventRecord(sl.evCommitted, S.stream));
     if (rgba8_dev) {
+        if (S.flags & PT_FLAG_ACCUM_SHARD_ROWS) return fail(PT_ERR_INVALID, "pt_iterate: no PBO conversion from a row-sharded accumulator");
         hipLaunchKernelGGL(k_to_rgba8, dim3((S.P + kBlock - 1) / kBlock), dim3(kBlock), 0, S.stream, S.image, S.P, iter,
                            reinterpret_cast<uchar4 *>(rgba8_dev));
         HIPCHECK(hipGetLastError());
@@ -1044,6 +1049,17 @@ int pt_readback(float *rgb_sum_host) {
     if (!S.init) return fail(PT_ERR_NOT_INIT, "pt_readback before pt_init");
     if (!rgb_sum_host) return fail(PT_ERR_INVALID, "pt_readback: null");
     // every commit so far is already ordered before this copy on the caller's stream
+    if (S.flags & PT_FLAG_ACCUM_SHARD_ROWS) {   // scatter this shard's rows into a zeroed full frame
+        std::vector<float> rows((size_t)S.nLocal * 3);
+        if (S.nLocal) HIPCHECK(hipMemcpyAsync(rows.data(), S.image, rows.size() * sizeof(float), hipMemcpyDeviceToHost, S.stream));
+        HIPCHECK(hipStreamSynchronize(S.stream));
+        memset(rgb_sum_host, 0, (size_t)S.P * 3 * sizeof(float));
+        const size_t rowFloats = (size_t)S.prm.W * 3;
+        for (int lr = 0; lr * S.prm.W < S.nLocal; ++lr)
+            memcpy(rgb_sum_host + (size_t)(lr * S.prm.shardCount + S.prm.shardRank) * rowFloats, rows.data() + lr * rowFloats,
+                   rowFloats * sizeof(float));
+        return PT_OK;
+    }
     HIPCHECK(hipMemcpyAsync(rgb_sum_host, S.image, (size_t)S.P * 3 * sizeof(float), hipMemcpyDeviceToHost, S.stream));
     HIPCHECK(hipStreamSynchronize(S.stream));
     return PT_OK;
@@ -1052,6 +1068,7 @@ int pt_readback(float *rgb_sum_host) {
 int pt_readback_rgba8(int iter, uint8_t *rgba_host) {
     if (!S.init) return fail(PT_ERR_NOT_INIT, "pt_readback_rgba8 before pt_init");
     if (!rgba_host || iter < 1) return fail(PT_ERR_INVALID, "pt_readback_rgba8: bad argument");
+    if (S.flags & PT_FLAG_ACCUM_SHARD_ROWS) return fail(PT_ERR_INVALID, "pt_readback_rgba8: accumulator is row-sharded");
     DevBuf<uchar4> tmp;
     int rc = tmp.alloc(S.P);
     if (rc) return rc;

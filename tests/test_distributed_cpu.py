@@ -1,8 +1,9 @@
-"""World-size-2 test of the N>1 path on CPU (gloo): row sharding + the single reduce of the frame.
+"""World-size-2 test of the N>1 path on CPU (gloo): row sharding + the single collective (gather of the
+packed row blocks).
 
-No GPU here, so each rank renders ITS rows with the CPU oracle (checker standing in for the kernels)
-into a zeroed full frame and then runs the SAME `reduce_frame` bench.py uses; rank 0 must end up with
-a frame that is bit-identical to the unsharded render after every iteration."""
+No GPU here, so each rank renders ITS rows with the CPU oracle (checker standing in for the kernels),
+packs them the way PT_FLAG_ACCUM_SHARD_ROWS does, and then runs the SAME `gather_frame` bench.py uses;
+rank 0 must end up with a frame that is bit-identical to the unsharded render after every iteration."""
 import os
 import socket
 import sys
@@ -28,23 +29,28 @@ def _worker(rank, world, port, res, iters, out_path):
     sc = orc.Scene(os.path.join(SCENES, "cornell.txt"))
     sc.set_resolution(W, H)
     ren = orc.Renderer(sc.camera, sc.geoms, sc.materials, 8)
-    accum = torch.zeros(W * H * 3, dtype=torch.float32)
-    frame = torch.zeros_like(accum)
+    sparse = np.zeros(W * H * 3, np.float32)                     # oracle output: full frame, own rows only
+    block = torch.zeros(ptdist.padded_block_floats(W, H, world), dtype=torch.float32)
+    bufs = ptdist.make_gather_buffers(block, world, rank)
+    frame = torch.zeros(W * H * 3, dtype=torch.float32)
     full = np.zeros(W * H * 3, np.float32)
+    mine = list(ptdist.shard_rows(H, rank, world))
     ok = True
     npix = 0
     for it in iters:
-        c = ren.iterate(it, accum.numpy(), rank, world)          # this rank's rows only
+        c = ren.iterate(it, sparse, rank, world)                 # this rank's rows only
         npix = c.live[1]
-        ptdist.reduce_frame(accum, frame, dst=0)
+        packed = sparse.reshape(H, W * 3)[mine].reshape(-1)      # what PT_FLAG_ACCUM_SHARD_ROWS holds
+        block[:packed.size] = torch.from_numpy(packed)
+        ptdist.gather_frame(block, bufs, frame, W, H, dst=0)
         if rank == 0:
             ren.iterate(it, full)
             ok = ok and np.array_equal(frame.numpy().view(np.uint32), full.view(np.uint32))
     assert npix == ptdist.local_pixel_count(W, H, rank, world)
-    rows = accum.numpy().reshape(H, W, 3)
-    mine = np.zeros(H, bool)
-    mine[list(ptdist.shard_rows(H, rank, world))] = True
-    assert not np.any(rows[~mine])                               # other ranks' rows stay exactly zero
+    rows = sparse.reshape(H, W, 3)
+    other = np.ones(H, bool)
+    other[mine] = False
+    assert not np.any(rows[other])                               # other ranks' rows stay exactly zero
     if rank == 0:
         np.save(out_path, np.array([1 if ok else 0]))
     torch.distributed.destroy_process_group()
@@ -57,7 +63,7 @@ def test_two_ranks_gloo_assemble_the_frame_bit_exactly(tmp_path):
     port = s.getsockname()[1]
     s.close()
     out = str(tmp_path / "ok.npy")
-    mp.spawn(_worker, args=(2, port, (48, 37), [1, 2, 3], out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, (48, 37), [1, 2, 3], out), nprocs=2, join=True)   # 37 rows: ragged shards (19 / 18)
     assert np.load(out)[0] == 1
 
 
