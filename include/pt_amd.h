@@ -154,6 +154,10 @@ int pt_test_rng(const uint32_t *seeds, int nseeds, int ndraws, float *u01_out /*
  * on a miss like the reference's out-parameters (intersections.h:86-88,114-126). */
 int pt_test_intersect(const PtGeom *geoms, int ngeoms, const int32_t *geom_index, const float *rays,
                       int n, float *t, float *p3, float *n3, int32_t *outside);
+/* sphereCertainMiss (world-space culling of spheres) soundness: `rays` pseudo-random rays against the spheres
+ * of `geoms`; *violations = rays culled although the full test hits (must be 0), *culled = rays culled. */
+int pt_test_sphere_cull_sweep(const PtGeom *geoms, int ngeoms, uint64_t seed, int64_t rays, uint64_t *culled,
+                              uint64_t *violations);
 /* slabQuotients (shared-reciprocal packed division of the box test) next to the compiler's correctly
  * rounded `/`: per-element outputs, and a device-side pseudo-random sweep that returns the number of
  * bit mismatches over `pairs` (o, d) pairs (must be 0). */

@@ -47,7 +47,7 @@ ABI_SYMBOLS = [
     "pt_counters_reset", "pt_free", "pt_last_error", "pt_device_count", "pt_debug_trace_paths",
     "pt_scan_exclusive_i32", "pt_compact_nonzero_i32", "pt_test_utilhash", "pt_test_rng",
     "pt_test_intersect", "pt_test_hemisphere", "pt_test_sincos", "pt_test_reflect_refract",
-    "pt_test_slab_quotients", "pt_test_slab_quotients_sweep",
+    "pt_test_slab_quotients", "pt_test_slab_quotients_sweep", "pt_test_sphere_cull_sweep",
 ]
 
 
@@ -108,6 +108,7 @@ def lib():
         L.pt_test_reflect_refract.argtypes = [vp, vp, vp, i32, vp, vp]
         L.pt_test_slab_quotients.argtypes = [vp, vp, i32, vp, vp, vp, vp]
         L.pt_test_slab_quotients_sweep.argtypes = [C.c_uint64, i64, C.POINTER(C.c_uint64)]
+        L.pt_test_sphere_cull_sweep.argtypes = [vp, i32, C.c_uint64, i64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         _lib = L
     return _lib
 
@@ -330,6 +331,13 @@ def test_slab_quotients_sweep(seed, pairs):
     m = C.c_uint64(0)
     _check(lib().pt_test_slab_quotients_sweep(seed, pairs, C.byref(m)))
     return int(m.value)
+
+
+def test_sphere_cull_sweep(geoms, seed, rays):
+    geoms = np.ascontiguousarray(geoms)
+    culled, bad = C.c_uint64(0), C.c_uint64(0)
+    _check(lib().pt_test_sphere_cull_sweep(_p(geoms), len(geoms), seed, rays, C.byref(culled), C.byref(bad)))
+    return int(culled.value), int(bad.value)
 
 
 def scan_exclusive_dev(in_ptr, out_ptr, n, stream=0):

@@ -322,14 +322,18 @@ __global__ __launch_bounds__(kBlock) void k_bounce(KParams prm, int iter, int de
             int hit = -1;
             F3 P = f3(0, 0, 0), N = f3(0, 0, 0);
             bool outside = false;
+            const float dd = dot(dir, dir);
             for (int g = 0; g < prm.ngeoms; ++g) {
                 const GeomDev &G = sgeoms[g];
                 const int type = __builtin_amdgcn_readfirstlane(G.type);
                 F3 p, n;
                 bool o = false;
-                float t;
-                if (type == 0) t = sphereIntersectionTest(G, org, dir, p, n, o);
-                else           t = boxIntersectionTest<true>(G, org, dir, p, n, o);
+                float t = -1.0f;
+                if (type == 0) {
+                    if (!sphereCertainMiss(G, org, dir, dd)) t = sphereIntersectionTest(G, org, dir, p, n, o);
+                } else {
+                    t = boxIntersectionTest<true>(G, org, dir, p, n, o);
+                }
                 if (t > 0.0f && (hit < 0 || t < tbest)) {
                     tbest = t; hit = g; P = p; N = n; outside = o;
                 }
@@ -593,12 +597,50 @@ __global__ void k_test_intersect(const GeomDev *geoms, const int *gidx, const fl
     F3 N = f3(n3[3 * i], n3[3 * i + 1], n3[3 * i + 2]);
     bool o = outside[i] != 0;
     // odd lanes take the early-miss variant so both instantiations are checked against the golden vectors
-    t[i] = G.type == 0 ? sphereIntersectionTest(G, ro, rd, P, N, o)
+    // the certain-miss shortcut must agree with the full test on every golden vector
+    const bool cull = G.type == 0 && sphereCertainMiss(G, ro, rd, dot(rd, rd));
+    if (cull && sphereIntersectionTest(G, ro, rd, P, N, o) != -1.0f) { t[i] = __builtin_nanf(""); return; }
+    t[i] = G.type == 0 ? (cull ? -1.0f : sphereIntersectionTest(G, ro, rd, P, N, o))
          : ((i & 1) ? boxIntersectionTest<true>(G, ro, rd, P, N, o) : boxIntersectionTest<false>(G, ro, rd, P, N, o));
     p3[3 * i] = P.x; p3[3 * i + 1] = P.y; p3[3 * i + 2] = P.z;
     n3[3 * i] = N.x; n3[3 * i + 1] = N.y; n3[3 * i + 2] = N.z;
     outside[i] = o ? 1 : 0;
 }
+// sphereCertainMiss soundness sweep: pseudo-random rays (origins up to ~60 units away, aimed near the sphere
+// so that grazing cases are dense) against every sphere of `geoms`; counts culled rays and VIOLATIONS
+// (culled although the full test returns a hit).
+__global__ void k_sweep_sphere_cull(const GeomDev *geoms, int ngeoms, unsigned long long seed, int per_thread,
+                                    unsigned long long *culled, unsigned long long *violations) {
+    unsigned long long x = seed + (blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ull;
+    unsigned int nc = 0, nv = 0;
+    for (int k = 0; k < per_thread; ++k) {
+        float u[8];
+        for (int j = 0; j < 8; ++j) {
+            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+            u[j] = (float)(x >> 40) * (1.0f / 16777216.0f);
+        }
+        const GeomDev G = geoms[(blockIdx.x + k) % ngeoms];
+        if (G.type != 0) continue;
+        const F3 c = f3(G.centre[0], G.centre[1], G.centre[2]);
+        const float dist = __builtin_exp2f(u[0] * 12.0f - 6.0f);                 // 1/64 .. 64 units
+        const F3 od = normalize(f3(u[1] - 0.5f, u[2] - 0.5f, u[3] - 0.5f));
+        const F3 org = c + od * dist;
+        // aim at a point within ~1.3 bounding radii of the centre: hits, grazes and near misses
+        const float R = __builtin_sqrtf(G.cullR2 * 4.0f) * 0.5f;
+        const F3 tgt = c + f3(u[4] - 0.5f, u[5] - 0.5f, u[6] - 0.5f) * (2.6f * R);
+        F3 dir = normalize(tgt - org);
+        if (u[7] < 0.1f) dir = -dir;
+        if (sphereCertainMiss(G, org, dir, dot(dir, dir))) {
+            ++nc;
+            F3 P, N;
+            bool o;
+            if (sphereIntersectionTest(G, org, dir, P, N, o) != -1.0f) ++nv;
+        }
+    }
+    if (nc) atomicAdd(culled, (unsigned long long)nc);
+    if (nv) atomicAdd(violations, (unsigned long long)nv);
+}
+
 // slabQuotients vs the compiler's correctly rounded division; counts mismatching lanes
 __global__ void k_test_slab_quotients(const float *o, const float *d, int n, float *t1, float *t2, float *r1, float *r2) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -737,6 +779,34 @@ void pack_geom(const PtGeom &g, GeomDev &d) {
         }
     d.type = g.type;
     d.material = g.materialid;
+    // sphere culling data (sphereCertainMiss): bounds smax >= sigma_max, smin <= sigma_min of the 3x3 part
+    double A[3][3], Ai[3][3];
+    for (int c = 0; c < 3; ++c)
+        for (int r = 0; r < 3; ++r) { A[c][r] = g.transform[c * 4 + r]; Ai[c][r] = g.inverseTransform[c * 4 + r]; }
+    double len[3], fro = 0, froi = 0;
+    bool orth = true;
+    for (int c = 0; c < 3; ++c) {
+        len[c] = std::sqrt(A[c][0] * A[c][0] + A[c][1] * A[c][1] + A[c][2] * A[c][2]);
+        for (int r = 0; r < 3; ++r) { fro += A[c][r] * A[c][r]; froi += Ai[c][r] * Ai[c][r]; }
+    }
+    for (int a = 0; a < 3; ++a)
+        for (int b = a + 1; b < 3; ++b) {
+            const double dp = A[a][0] * A[b][0] + A[a][1] * A[b][1] + A[a][2] * A[b][2];
+            if (!(std::fabs(dp) <= 1e-5 * len[a] * len[b])) orth = false;
+        }
+    double smax, smin;
+    if (orth) {            // rotation x scale: the singular values are the column lengths
+        smax = std::max(len[0], std::max(len[1], len[2])) * (1 + 1e-5);
+        smin = std::min(len[0], std::min(len[1], len[2])) * (1 - 1e-5);
+    } else {               // any matrix: Frobenius bounds
+        smax = std::sqrt(fro);
+        smin = froi > 0 ? 1.0 / std::sqrt(froi) : 0.0;
+    }
+    d.centre[0] = g.transform[12]; d.centre[1] = g.transform[13]; d.centre[2] = g.transform[14];
+    const double r2 = 0.25 * smax * smax * (1 + 1e-3), kk = smin > 0 ? 1e-4 * (smax / smin) * (smax / smin) : INFINITY;
+    const bool ok = std::isfinite(r2) && std::isfinite(kk) && kk < 0.5 && smin > 0;
+    d.cullR2 = ok ? (float)r2 : INFINITY;      // infinite radius: never culled
+    d.cullK = ok ? (float)kk : 0.0f;
 }
 void pack_material(const PtMaterial &m, MaterialDev &d) {
     memset(&d, 0, sizeof d);
@@ -1288,6 +1358,32 @@ int pt_test_intersect(const PtGeom *geoms, int ngeoms, const int32_t *geom_index
     DOWN(p3, dp, (size_t)n * 3);
     DOWN(n3, dn, (size_t)n * 3);
     DOWN(outside, dout, n);
+    return PT_OK;
+}
+
+int pt_test_sphere_cull_sweep(const PtGeom *geoms, int ngeoms, uint64_t seed, int64_t rays, uint64_t *culled,
+                              uint64_t *violations) {
+    NEED_GPU();
+    if (!geoms || ngeoms < 1 || !culled || !violations || rays < 0) return fail(PT_ERR_INVALID, "pt_test_sphere_cull_sweep: bad argument");
+    std::vector<GeomDev> hg(ngeoms);
+    for (int i = 0; i < ngeoms; ++i) pack_geom(geoms[i], hg[i]);
+    DevBuf<GeomDev> dg;
+    DevBuf<unsigned long long> cnt;
+    UP(dg, hg.data(), ngeoms);
+    int rc = cnt.alloc(2);
+    if (rc) return rc;
+    HIPCHECK(hipMemset(cnt.p, 0, 16));
+    const int per_thread = 256, threads = 256;
+    long long blocks = (rays + (long long)per_thread * threads - 1) / ((long long)per_thread * threads);
+    if (blocks < 1) blocks = 1;
+    if (blocks > (1 << 20)) blocks = 1 << 20;
+    hipLaunchKernelGGL(k_sweep_sphere_cull, dim3((unsigned)blocks), dim3(threads), 0, 0, dg.p, ngeoms, (unsigned long long)seed,
+                       per_thread, cnt.p, cnt.p + 1);
+    HIPCHECK(hipDeviceSynchronize());
+    unsigned long long h[2] = {0, 0};
+    HIPCHECK(hipMemcpy(h, cnt.p, 16, hipMemcpyDeviceToHost));
+    *culled = h[0];
+    *violations = h[1];
     return PT_OK;
 }
 

@@ -102,6 +102,22 @@ def test_slab_quotients_equal_ieee_division(gpu):
     assert gpu.test_slab_quotients_sweep(12345, 1 << 30) == 0        # 2^30 more pairs on the device
 
 
+def test_sphere_culling_never_rejects_a_hit(gpu, oracle):
+    # sphereCertainMiss is a sufficient condition for the reference's `radicand < 0` exit; 2^28 rays (dense in
+    # grazing cases, origins 1/64 .. 64 units away) against uniform spheres, ellipsoids, tiny and huge ones
+    geoms = np.concatenate([
+        oracle.make_geom(0, 0, (-1, 4, -1), (0, 0, 0), (3, 3, 3)),            # Cornell sphere
+        oracle.make_geom(0, 0, (1, 2, 3), (30, 45, 60), (1, 2, 3)),           # ellipsoid
+        oracle.make_geom(0, 0, (0, 0, 0), (0, 0, 0), (0.6, 0.6, 0.6)),        # C5-sized
+        oracle.make_geom(0, 0, (2.5, 6, -2), (10, 20, 30), (0.05, 0.05, 0.05)),
+        oracle.make_geom(0, 0, (-3, 1, 2), (75, -20, 130), (8, 0.5, 3)),      # 16:1 anisotropy
+        oracle.make_geom(0, 0, (100, -50, 25), (0, 0, 0), (40, 40, 40)),
+    ]).view(gpu.GEOM_DTYPE)
+    culled, bad = gpu.test_sphere_cull_sweep(geoms, 2024, 1 << 28)
+    assert bad == 0
+    assert culled > (1 << 28) // 10           # the shortcut actually fires (most sweep rays are aimed at the sphere)
+
+
 def test_reflect_refract_bit_exact(gpu):
     z = np.load(os.path.join(GOLD, "glm_ops.npz"))
     r1, r2 = gpu.test_reflect_refract(z["An"], z["Bn"], z["eta"])
