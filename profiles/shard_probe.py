@@ -1,0 +1,31 @@
+"""Per-rank cost of an N-way row shard, measured on ONE GPU without any collective: an upper bound for
+the strong-scaling curve (the driver runs the real 8-GPU bench).  python profiles/shard_probe.py"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import __graft_entry__ as ge
+pt = ge.load_package()
+scene = pt.Scene(os.path.join(ROOT, "scenes", "cornell.txt"))
+scene.set_resolution(1280, 720)
+P = 1280 * 720
+for world in (1, 2, 4, 8):
+    for depth_pipe in (1, 3, 4):
+        acc = torch.zeros(P * 3, device="cuda")
+        pt.pathtraceFree()
+        pt.pathtraceInit(scene, shard_rank=0, shard_count=world, stream=torch.cuda.current_stream().cuda_stream,
+                         accum_dev=acc.data_ptr(), pipeline_depth=depth_pipe)
+        for it in range(1, 9):
+            pt.pathtrace(None, 0, it, readback=False)
+        torch.cuda.synchronize()
+        N = 128
+        t0 = time.perf_counter()
+        for it in range(9, 9 + N):
+            pt.pathtrace(None, 0, it, readback=False)
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        us = (t2 - t0) / N * 1e6
+        print("shard 1/%d pipeline %d: enqueue %.1f us/iter, total %.1f us/iter -> whole-job bound %.1f Gpaths/s"
+              % (world, depth_pipe, (t1 - t0) / N * 1e6, us, P * 8 / us / 1e3))
+pt.pathtraceFree()

@@ -64,8 +64,12 @@ struct GeomDev {
     float cullR2, cullK;
     float centre[3];
     float pad;
+    // object-space camera position multiplyMV(inverseTransform, (eye, 1)), evaluated once on the host with the
+    // same operation order: every camera ray of the first bounce shares it
+    float camObj[3];
+    float pad2;
 };
-static_assert(sizeof(GeomDev) == 176, "GeomDev is 11 x 16 B so LDS reads are ds_read_b128");
+static_assert(sizeof(GeomDev) == 192, "GeomDev is 12 x 16 B");
 
 struct MaterialDev {
     float color[3];
@@ -212,9 +216,10 @@ __device__ __forceinline__ void slabQuotients(float o, float d, float &t1, float
 // NaN, and NaN fails the comparisons below), so the decision is taken BEFORE the normalisation and
 // the six correctly rounded divisions.  It only pays when whole waves take it, i.e. for coherent
 // rays (EARLY_MISS is set for the camera-ray bounce); results are identical either way.
-template <bool EARLY_MISS>
+// CAM_ORIGIN: the ray starts at the camera, whose object-space position is precomputed (GeomDev::camObj).
+template <bool EARLY_MISS, bool CAM_ORIGIN = false>
 __device__ __forceinline__ float boxIntersectionTest(const GeomDev &g, F3 ro, F3 rd, F3 &P, F3 &N, bool &outside) {
-    const F3 qo = mulMV(g.inv, ro, 1.0f);
+    const F3 qo = CAM_ORIGIN ? f3(g.camObj[0], g.camObj[1], g.camObj[2]) : mulMV(g.inv, ro, 1.0f);
     const F3 qdu = mulMV(g.inv, rd, 0.0f);
     if (EARLY_MISS) {
         const bool away = (qo.x > 0.5f && qdu.x > 0.0f) || (qo.x < -0.5f && qdu.x < 0.0f) ||
@@ -282,9 +287,10 @@ __device__ __forceinline__ bool sphereCertainMiss(const GeomDev &g, F3 org, F3 d
 }
 
 // src/intersections.h:101-143 (pow(radius, 2) == 0.25f in the float overload nvcc selects)
+template <bool CAM_ORIGIN = false>
 __device__ __forceinline__ float sphereIntersectionTest(const GeomDev &g, F3 ro_w, F3 rd_w, F3 &P, F3 &N,
                                                         bool &outside) {
-    F3 ro = mulMV(g.inv, ro_w, 1.0f);
+    F3 ro = CAM_ORIGIN ? f3(g.camObj[0], g.camObj[1], g.camObj[2]) : mulMV(g.inv, ro_w, 1.0f);
     F3 rd = normalize(mulMV(g.inv, rd_w, 0.0f));
     float vDotDirection = dot(ro, rd);
     float radicand = vDotDirection * vDotDirection - (dot(ro, ro) - 0.25f);

@@ -333,9 +333,9 @@ __global__ __launch_bounds__(kBlock) void k_bounce(KParams prm, int iter, int de
                 bool o = false;
                 float t = -1.0f;
                 if (type == 0) {
-                    if (!sphereCertainMiss(G, org, dir, dd)) t = sphereIntersectionTest(G, org, dir, p, n, o);
+                    if (!sphereCertainMiss(G, org, dir, dd)) t = sphereIntersectionTest<FIRST>(G, org, dir, p, n, o);
                 } else {
-                    t = boxIntersectionTest<true>(G, org, dir, p, n, o);
+                    t = boxIntersectionTest<true, FIRST>(G, org, dir, p, n, o);
                 }
                 if (t > 0.0f && (hit < 0 || t < tbest)) {
                     tbest = t; hit = g; P = p; N = n; outside = o;
@@ -772,7 +772,7 @@ PathSoA soa(float *base, int cap) {
     return s;
 }
 
-void pack_geom(const PtGeom &g, GeomDev &d) {
+void pack_geom(const PtGeom &g, GeomDev &d, const float *eye = nullptr) {
     memset(&d, 0, sizeof d);
     for (int c = 0; c < 4; ++c)
         for (int r = 0; r < 3; ++r) {
@@ -810,6 +810,14 @@ void pack_geom(const PtGeom &g, GeomDev &d) {
     const bool ok = std::isfinite(r2) && std::isfinite(kk) && kk < 0.5 && smin > 0;
     d.cullR2 = ok ? (float)r2 : INFINITY;      // infinite radius: never culled
     d.cullK = ok ? (float)kk : 0.0f;
+    if (eye) {   // ptd::mulMV(inv, eye, 1) in the same operation order (this file is built with -ffp-contract=off)
+        const float *m = d.inv;
+        for (int r = 0; r < 3; ++r) {
+            const float a0 = m[0 + r] * eye[0], a1 = m[3 + r] * eye[1], a2 = m[6 + r] * eye[2], a3 = m[9 + r] * 1.0f;
+            const float s01 = a0 + a1, s23 = a2 + a3;
+            d.camObj[r] = s01 + s23;
+        }
+    }
 }
 void pack_material(const PtMaterial &m, MaterialDev &d) {
     memset(&d, 0, sizeof d);
@@ -1055,7 +1063,7 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
 
     std::vector<GeomDev> hg(ngeoms ? ngeoms : 1);
     std::vector<MaterialDev> hm(nmats ? nmats : 1);
-    for (int i = 0; i < ngeoms; ++i) pack_geom(geoms[i], hg[i]);
+    for (int i = 0; i < ngeoms; ++i) pack_geom(geoms[i], hg[i], k.pos);
     for (int i = 0; i < nmats; ++i) pack_material(mats[i], hm[i]);
     HIPCHECK(hipMalloc(&S.dgeoms, hg.size() * sizeof(GeomDev)));
     HIPCHECK(hipMalloc(&S.dmats, hm.size() * sizeof(MaterialDev)));
