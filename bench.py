@@ -3,15 +3,17 @@
 
 Metric (BASELINE.json): Mpaths/s, paths = pixels x bounces x spp (NOMINAL segments), Cornell box at
 1280x720, 8 bounces.  One "step" = one iteration (1 spp) of the whole frame: camera rays, 8 fused
-intersect+shade+compact launches, accumulation (+ the per-iteration RCCL reduce of the accumulator
-when N > 1).  Scene, accumulator and path state are resident in HBM before the timed region.
+intersect+shade+compact bounces, ordered accumulation.  Steps are issued as wavefront batches of
+--batch iterations (pt_iterate_batch: their paths share the 8 launches; results are identical to
+one call per iteration) with up to 3 batches in flight on internal streams.  Scene, accumulator
+and path state are resident in HBM before the timed region.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU)
 
 N > 1: image rows are sharded round-robin over the ranks (row y -> rank y % N), every rank accumulates
-only its own rows (packed), and ONE RCCL collective per iteration -- a gather of the row blocks to rank 0
-over xGMI -- assembles the frame (disjoint rows: bit-identical to 1 GPU; it moves 1/N of the bytes the
+only its own rows (packed), and ONE RCCL collective per committed batch -- a gather of the row blocks to
+rank 0 over xGMI -- assembles the frame (disjoint rows: bit-identical to 1 GPU; it moves 1/N of the bytes the
 reduce of zero-padded full frames would).  Fixed total work -> "scaling": "strong".
 
 Prints ONE JSON line on rank 0, with `roofline` (dominant kernel = the fused bounce kernel, HIP-event
@@ -41,7 +43,8 @@ def parse():
     ap.add_argument("--res", type=int, nargs=2, default=[1280, 720])
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--cpu-spp", type=int, default=40, help="spp of the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--pipeline", type=int, default=0, help="iterations in flight (PtOptions.pipeline_depth; 0 = library default)")
+    ap.add_argument("--pipeline", type=int, default=0, help="batches in flight (PtOptions.pipeline_depth; 0 = library default 3)")
+    ap.add_argument("--batch", type=int, default=8, help="iterations traced as one wavefront per pt_iterate_batch call")
     ap.add_argument("--pmc-traffic-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"),
                     help="HBM bytes per bounce-kernel launch from a rocprofv3 --pmc run (profiles/README.md)")
     return ap.parse_args()
@@ -109,17 +112,25 @@ def main():
         frame, bufs, shard_flag = None, None, 0
     stream = torch.cuda.current_stream()
 
+    B = max(1, min(args.batch, 16))
+
     def init(flags, pipeline):
         pt.pathtraceFree()
         pt.pathtraceInit(scene, shard_rank=rank, shard_count=world, stream=stream.cuda_stream,
                          accum_dev=accum.data_ptr(), device=device_index, flags=flags | shard_flag,
-                         traceDepth=args.depth, pipeline_depth=pipeline)
+                         traceDepth=args.depth, pipeline_depth=pipeline, max_batch=B)
 
-    def step(it):
-        pt.pathtrace(None, 0, it, readback=False)
-        if world > 1:
-            # the single collective of the data path: per-iteration gather of the row blocks over xGMI
-            ptdist.gather_frame(accum, bufs, frame, W, H, dst=0)
+    def run_steps(first_iter, steps):
+        """`steps` iterations (1 spp each), issued as wavefront batches of up to B iterations; the frame is
+        assembled at rank 0 after every batch."""
+        it, end = first_iter, first_iter + steps
+        while it < end:
+            n = min(B, end - it)
+            pt.pathtrace_batch(None, 0, it, n)
+            if world > 1:
+                # the single collective of the data path: gather of the row blocks over xGMI
+                ptdist.gather_frame(accum, bufs, frame, W, H, dst=0)
+            it += n
 
     def barrier():
         if world > 1:
@@ -129,15 +140,13 @@ def main():
     def timed(first_iter, steps):
         barrier()
         t0 = time.perf_counter()
-        for k in range(steps):
-            step(first_iter + k)
+        run_steps(first_iter, steps)
         barrier()
         return time.perf_counter() - t0
 
     # ---- pass A: the headline number ----------------------------------------------------------
     init(0, args.pipeline)
-    for k in range(args.warmup):
-        step(1 + k)
+    run_steps(1, args.warmup)
     barrier()
     pt.counters_reset()
     dt = timed(1 + args.warmup, args.steps)
@@ -152,8 +161,7 @@ def main():
     #      co-occupies with the neighbouring iterations' launches
     accum.zero_()
     init(pt.PT_FLAG_KERNEL_TIMING, 1)
-    for k in range(min(args.warmup, 2)):
-        step(1 + k)
+    run_steps(1, min(args.warmup, B))
     barrier()
     pt.counters_reset()
     dtB = timed(1 + args.warmup, args.steps)
@@ -188,8 +196,10 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s %dx%d, %d spp, %d bounces%s" % (
                            os.path.relpath(args.scene, ROOT), W, H, args.steps, D,
-                           "" if world == 1 else ", rows sharded y%%%d + RCCL gather of the row blocks per iteration" % world),
+                           "" if world == 1 else ", rows sharded y%%%d + RCCL gather of the row blocks per batch" % world),
                        "paths_per_step_nominal": P * D,
+                       "iterations_per_wavefront_batch": B,
+                       "batches_in_flight": args.pipeline if args.pipeline > 0 else 3,
                        "live_segments_per_step": round(sum(live[1:D + 1]) / max(args.steps, 1), 1),
                        "live_Msegments_per_s": round(sum(int(cntA.live[d]) for d in range(1, D + 1)) / dt / 1e6, 2)},
             "roofline": {"bound": "hbm", "kernel": "k_bounce (fused [camera rays+]intersect+shade+compact, one launch per bounce)",

@@ -80,7 +80,8 @@ typedef struct PtOptions {
     int32_t flags;            /* PT_FLAG_* */
     int32_t pipeline_depth;   /* iterations kept in flight on internal streams: 0 = default (3), 1 = none, max 4.
                                  Results do not depend on it: radiance is committed in iteration order. */
-    int32_t reserved;
+    int32_t max_batch;        /* largest `count` pt_iterate_batch will be given (sizes the path buffers: they grow
+                                 linearly with it); 0 = 1, max PT_MAX_BATCH */
     void   *stream;           /* hipStream_t to enqueue on; NULL = the default stream */
     float  *accum_dev;        /* optional caller-owned device accumulator, W*H*3 floats (or the shard's rows only
                                  with PT_FLAG_ACCUM_SHARD_ROWS), zeroed by the caller (e.g. a torch tensor that
@@ -88,6 +89,7 @@ typedef struct PtOptions {
 } PtOptions;
 
 #define PT_MAX_DEPTH 62
+#define PT_MAX_BATCH 16
 
 typedef struct PtCounters {
     int64_t live[PT_MAX_DEPTH + 2]; /* live[d] = paths entering bounce d (d = 1..depth), summed over   */
@@ -110,6 +112,13 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
  * rgba8_dev != NULL, the sendImageToPBO conversion (src/pathtrace.cu:48-68) into that DEVICE
  * buffer of W*H uchar4.  Asynchronous on the configured stream.  Replaces src/pathtrace.cu:123-167. */
 int pt_iterate(int frame, int iter, void *rgba8_dev /* may be NULL (headless) */);
+
+/* `count` consecutive iterations first_iter .. first_iter+count-1 traced as ONE wavefront (their paths share the
+ * bounce launches, which makes each launch `count` times larger: fewer, fatter launches for small frames or
+ * small multi-GPU shards).  The result is identical to `count` pt_iterate calls: every pixel still receives its
+ * samples in iteration order.  rgba8_dev, if given, is converted with iter = first_iter+count-1.
+ * pt_iterate(frame, iter, pbo) == pt_iterate_batch(frame, iter, 1, pbo). */
+int pt_iterate_batch(int frame, int first_iter, int count, void *rgba8_dev);
 
 /* Wait for the stream; reports device-side faults.  (checkCUDAError's sync, pathtrace.cu:23.) */
 int pt_sync(void);

@@ -10,22 +10,22 @@ scene = pt.Scene(os.path.join(ROOT, "scenes", "cornell.txt"))
 scene.set_resolution(1280, 720)
 P = 1280 * 720
 for world in (1, 2, 4, 8):
-    for depth_pipe in (1, 3, 4):
+    for depth_pipe, batch in ((1, 1), (3, 1), (2, 2), (3, 2), (2, 4), (3, 4), (2, 8), (3, 8)):
         acc = torch.zeros(P * 3, device="cuda")
         pt.pathtraceFree()
         pt.pathtraceInit(scene, shard_rank=0, shard_count=world, stream=torch.cuda.current_stream().cuda_stream,
-                         accum_dev=acc.data_ptr(), pipeline_depth=depth_pipe)
-        for it in range(1, 9):
-            pt.pathtrace(None, 0, it, readback=False)
+                         accum_dev=acc.data_ptr(), pipeline_depth=depth_pipe, max_batch=batch)
+        for it in range(1, 1 + 4 * batch, batch):
+            pt.pathtrace_batch(None, 0, it, batch)
         torch.cuda.synchronize()
         N = 128
         t0 = time.perf_counter()
-        for it in range(9, 9 + N):
-            pt.pathtrace(None, 0, it, readback=False)
+        for it in range(100, 100 + N, batch):
+            pt.pathtrace_batch(None, 0, it, batch)
         t1 = time.perf_counter()
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         us = (t2 - t0) / N * 1e6
-        print("shard 1/%d pipeline %d: enqueue %.1f us/iter, total %.1f us/iter -> whole-job bound %.1f Gpaths/s"
-              % (world, depth_pipe, (t1 - t0) / N * 1e6, us, P * 8 / us / 1e3))
+        print("shard 1/%d pipeline %d batch %d: enqueue %.1f us/iter, total %.1f us/iter -> whole-job bound %.1f Gpaths/s"
+              % (world, depth_pipe, batch, (t1 - t0) / N * 1e6, us, P * 8 / us / 1e3))
 pt.pathtraceFree()

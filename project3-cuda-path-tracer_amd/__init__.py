@@ -43,7 +43,7 @@ PT_FLAG_ACCUM_SHARD_ROWS = 2
 
 # every symbol include/pt_amd.h declares
 ABI_SYMBOLS = [
-    "pt_init", "pt_iterate", "pt_sync", "pt_readback", "pt_readback_rgba8", "pt_counters",
+    "pt_init", "pt_iterate", "pt_iterate_batch", "pt_sync", "pt_readback", "pt_readback_rgba8", "pt_counters",
     "pt_counters_reset", "pt_free", "pt_last_error", "pt_device_count", "pt_debug_trace_paths",
     "pt_scan_exclusive_i32", "pt_compact_nonzero_i32", "pt_test_utilhash", "pt_test_rng",
     "pt_test_intersect", "pt_test_hemisphere", "pt_test_sincos", "pt_test_reflect_refract",
@@ -53,7 +53,7 @@ ABI_SYMBOLS = [
 
 class PtOptions(C.Structure):
     _fields_ = [("shard_rank", C.c_int32), ("shard_count", C.c_int32), ("device", C.c_int32),
-                ("flags", C.c_int32), ("pipeline_depth", C.c_int32), ("reserved", C.c_int32),
+                ("flags", C.c_int32), ("pipeline_depth", C.c_int32), ("max_batch", C.c_int32),
                 ("stream", C.c_void_p), ("accum_dev", C.c_void_p)]
 
 
@@ -88,6 +88,7 @@ def lib():
         vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
         L.pt_init.argtypes = [vp, vp, i32, vp, i32, i32, C.POINTER(PtOptions)]
         L.pt_iterate.argtypes = [i32, i32, vp]
+        L.pt_iterate_batch.argtypes = [i32, i32, i32, vp]
         L.pt_sync.argtypes = []
         L.pt_readback.argtypes = [vp]
         L.pt_readback_rgba8.argtypes = [i32, vp]
@@ -195,10 +196,10 @@ _scene = None
 
 
 def pathtraceInit(scene, shard_rank=0, shard_count=1, stream=0, accum_dev=0, device=-1, flags=0, traceDepth=None,
-                  pipeline_depth=0):
+                  pipeline_depth=0, max_batch=0):
     """reference src/pathtrace.cu:75-85.  `scene` is borrowed until pathtraceFree()."""
     global _scene
-    opt = PtOptions(shard_rank, shard_count, device, flags, pipeline_depth, 0, stream or None, accum_dev or None)
+    opt = PtOptions(shard_rank, shard_count, device, flags, pipeline_depth, max_batch, stream or None, accum_dev or None)
     geoms = np.ascontiguousarray(scene.geoms)
     mats = np.ascontiguousarray(scene.materials)
     cam = np.ascontiguousarray(scene.camera)
@@ -211,6 +212,13 @@ def pathtrace(pbo, frame, iteration, readback=True):
     """reference src/pathtrace.cu:123-174: one iteration; `pbo` is a DEVICE pointer (int) or None.
     With readback=True the running sum lands in scene.image like the reference's D2H copy (:170-171)."""
     _check(lib().pt_iterate(frame, iteration, pbo or None))
+    if readback and _scene is not None:
+        _check(lib().pt_readback(_p(_scene.image)))
+
+
+def pathtrace_batch(pbo, frame, first_iteration, count, readback=False):
+    """`count` iterations in one wavefront (pt_iterate_batch); same result as `count` pathtrace() calls."""
+    _check(lib().pt_iterate_batch(frame, first_iteration, count, pbo or None))
     if readback and _scene is not None:
         _check(lib().pt_readback(_p(_scene.image)))
 

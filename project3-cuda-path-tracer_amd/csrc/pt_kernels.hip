@@ -228,7 +228,7 @@ __global__ __launch_bounds__(kBlock) void k_debug_camera_rays(KParams prm, int i
 // j = 256 T + lane of this shard's pixel list and the ray is built in registers, so the first bounce
 // reads no path state at all.
 template <bool FIRST>
-__global__ __launch_bounds__(kBlock) void k_bounce(KParams prm, int iter, int depth, int lastBounce, int parity,
+__global__ __launch_bounds__(kBlock, 5) void k_bounce(KParams prm, int iter, int batch, int depth, int lastBounce, int parity,
                                                    PathSoA in, PathSoA out, Ctrl *ctrl,
                                                    const GeomDev *__restrict__ ggeoms,
                                                    const MaterialDev *__restrict__ gmats, float *contrib) {
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(kBlock) void k_bounce(KParams prm, int iter, int de
     // input queue: segment s holds s_cnt[s] paths = tiles [s_pre[s], s_pre[s+1]) of the global tile index
     uint32_t nLive, numTiles;
     if (FIRST) {
-        nLive = (uint32_t)prm.nLocal;
+        nLive = (uint32_t)prm.nLocal * (uint32_t)batch;     // `batch` consecutive iterations share one wavefront
         numTiles = (nLive + kBlock - 1) / kBlock;
     } else {
         if (threadIdx.x < 64) {          // wave 0: exclusive scan of the kSeg tile counts
@@ -307,9 +307,11 @@ __global__ __launch_bounds__(kBlock) void k_bounce(KParams prm, int iter, int de
         bool lightHit = false, missed = false;
         F3 org = f3(0, 0, 0), dir = f3(0, 0, 1), col = f3(0, 0, 0);
         int pix = 0, rem = 0;
+        int itb = 0;                                            // which iteration of the batch this path belongs to
         if (valid) {
             if (FIRST) {
-                cameraRay(prm, iter, (int)idx, pix, org, dir);
+                itb = (int)(idx / (uint32_t)prm.nLocal);
+                cameraRay(prm, iter + itb, (int)(idx - (uint32_t)itb * (uint32_t)prm.nLocal), pix, org, dir);
                 col = f3(1.0f, 1.0f, 1.0f);
                 rem = prm.traceDepth;
             } else {
@@ -317,7 +319,9 @@ __global__ __launch_bounds__(kBlock) void k_bounce(KParams prm, int iter, int de
                 dir = f3(in.a(3)[idx], in.a(4)[idx], in.a(5)[idx]);
                 col = f3(in.a(6)[idx], in.a(7)[idx], in.a(8)[idx]);
                 pix = in.pix()[idx];
-                rem = in.rem()[idx];
+                const int packed = in.rem()[idx];               // remainingBounces | batch index << 8
+                rem = packed & 0xff;
+                itb = packed >> 8;
             }
 
             // nearest hit, geoms in file order, strict '<' so the first geom wins ties (S3)
@@ -353,11 +357,11 @@ __global__ __launch_bounds__(kBlock) void k_bounce(KParams prm, int iter, int de
                         // is parked in this iteration's own buffer (one path per pixel: race-free, no
                         // read) and k_commit adds it to the accumulator in iteration order.
                         const F3 c = (col * mcol) * M.emittance;
-                        float *px = contrib + 3 * (size_t)pix;
+                        float *px = contrib + 3 * ((size_t)itb * ((size_t)prm.W * prm.H) + (size_t)pix);
                         px[0] = c.x; px[1] = c.y; px[2] = c.z;
                     }
                 } else if (!lastBounce) {                        // S6 scatter (S7: skipped on the last bounce)
-                    Rng rng = makeSeededRandomEngine(iter, pix, depth);
+                    Rng rng = makeSeededRandomEngine(iter + itb, pix, depth);
                     const F3 scol = f3(M.specColor[0], M.specColor[1], M.specColor[2]);
                     F3 ndir, norg;
                     if (M.hasRefractive > 0.0f) {
@@ -440,7 +444,7 @@ __global__ __launch_bounds__(kBlock) void k_bounce(KParams prm, int iter, int de
                 out.a(3)[slot] = dir.x; out.a(4)[slot] = dir.y; out.a(5)[slot] = dir.z;
                 out.a(6)[slot] = col.x; out.a(7)[slot] = col.y; out.a(8)[slot] = col.z;
                 out.pix()[slot] = pix;
-                out.rem()[slot] = rem - 1;
+                out.rem()[slot] = (rem - 1) | (itb << 8);
             }
             __syncthreads();   // s_wave / s_base are rewritten by the next tile
         }
@@ -458,19 +462,27 @@ __global__ __launch_bounds__(kBlock) void k_bounce(KParams prm, int iter, int de
 // Skipping an all-zero contribution equals adding +0 (the accumulator is never -0).
 // `compactRows`: the accumulator holds only this shard's rows (PT_FLAG_ACCUM_SHARD_ROWS), pixel j of the shard
 // at image[3j]; otherwise it is the full frame indexed by the global pixel index.
-__global__ __launch_bounds__(kBlock) void k_commit(KParams prm, float *image, float *contrib, int compactRows) {
+// `batch` iterations were traced together; their radiance buffers are consumed in iteration order.
+__global__ __launch_bounds__(kBlock) void k_commit(KParams prm, float *image, float *contrib, int batch, int compactRows) {
     const int j = blockIdx.x * kBlock + threadIdx.x;
     if (j >= prm.nLocal) return;
     const int lr = j / prm.W;
     const int x = j - lr * prm.W;
     const size_t pix = (size_t)x + (size_t)(lr * prm.shardCount + prm.shardRank) * prm.W;
-    float *c = contrib + 3 * pix;
-    const float cx = c[0], cy = c[1], cz = c[2];
-    if (cx != 0.0f || cy != 0.0f || cz != 0.0f) {
-        float *px = image + 3 * (compactRows ? (size_t)j : pix);
-        px[0] += cx; px[1] += cy; px[2] += cz;
-        c[0] = 0.0f; c[1] = 0.0f; c[2] = 0.0f;
+    const size_t frame = (size_t)prm.W * prm.H;
+    float *px = image + 3 * (compactRows ? (size_t)j : pix);
+    float ax = px[0], ay = px[1], az = px[2];
+    bool dirty = false;
+    for (int b = 0; b < batch; ++b) {
+        float *c = contrib + 3 * ((size_t)b * frame + pix);
+        const float cx = c[0], cy = c[1], cz = c[2];
+        if (cx != 0.0f || cy != 0.0f || cz != 0.0f) {
+            ax += cx; ay += cy; az += cz;
+            c[0] = 0.0f; c[1] = 0.0f; c[2] = 0.0f;
+            dirty = true;
+        }
     }
+    if (dirty) { px[0] = ax; px[1] = ay; px[2] = az; }
 }
 
 // ---- sendImageToPBO (reference src/pathtrace.cu:48-68) ---------------------------------------------
@@ -726,7 +738,7 @@ struct Slot {
     hipStream_t stream = nullptr;
     float *pathbuf[2] = {nullptr, nullptr};
     Ctrl *ctrl = nullptr;
-    float *contrib = nullptr;      // W*H*3, zero between iterations
+    float *contrib = nullptr;      // maxBatch x W*H*3, zero between batches
     hipEvent_t evDone = nullptr;       // all bounce launches of the slot's current iteration finished
     hipEvent_t evCommitted = nullptr;  // k_commit consumed (and re-zeroed) `contrib`
     int parity = 0;                // which half of Ctrl::seg_count the slot's next iteration uses
@@ -744,6 +756,7 @@ struct State {
     float *image = nullptr;
     bool ownImage = false;
     int nslots = 0;
+    int maxBatch = 1;       // iterations that may share one wavefront (pt_iterate_batch)
     Slot slot[kMaxSlots];
     GeomDev *dgeoms = nullptr;
     MaterialDev *dmats = nullptr;
@@ -852,7 +865,7 @@ int resolve_events(std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, double &ms
     return PT_OK;
 }
 
-int launch_bounce(Slot &sl, int iter, int depth, bool lastBounce, float *contrib) {
+int launch_bounce(Slot &sl, int iter, int batch, int depth, bool lastBounce, float *contrib) {
     const PathSoA in = soa(sl.pathbuf[(depth - 1) & 1], kSeg * S.segCap);
     const PathSoA out = soa(sl.pathbuf[depth & 1], kSeg * S.segCap);
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -862,10 +875,10 @@ int launch_bounce(Slot &sl, int iter, int depth, bool lastBounce, float *contrib
         HIPCHECK(hipEventRecord(e0, sl.stream));
     }
     if (depth == 1)
-        hipLaunchKernelGGL(k_bounce<true>, dim3(S.grid), dim3(kBlock), S.ldsBytes, sl.stream, S.prm, iter, depth,
+        hipLaunchKernelGGL(k_bounce<true>, dim3(S.grid), dim3(kBlock), S.ldsBytes, sl.stream, S.prm, iter, batch, depth,
                            lastBounce ? 1 : 0, sl.parity, in, out, sl.ctrl, S.dgeoms, S.dmats, contrib);
     else
-        hipLaunchKernelGGL(k_bounce<false>, dim3(S.grid), dim3(kBlock), S.ldsBytes, sl.stream, S.prm, iter, depth,
+        hipLaunchKernelGGL(k_bounce<false>, dim3(S.grid), dim3(kBlock), S.ldsBytes, sl.stream, S.prm, iter, batch, depth,
                            lastBounce ? 1 : 0, sl.parity, in, out, sl.ctrl, S.dgeoms, S.dmats, contrib);
     if (e0) {
         HIPCHECK(hipEventRecord(e1, sl.stream));
@@ -997,6 +1010,7 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     if (opts) o = *opts;
     if (o.shard_count < 1 || o.shard_rank < 0 || o.shard_rank >= o.shard_count) return fail(PT_ERR_INVALID, "pt_init: bad shard %d/%d", o.shard_rank, o.shard_count);
     if (o.pipeline_depth < 0 || o.pipeline_depth > kMaxSlots) return fail(PT_ERR_INVALID, "pt_init: pipeline_depth must be 0..%d", kMaxSlots);
+    if (o.max_batch < 0 || o.max_batch > PT_MAX_BATCH) return fail(PT_ERR_INVALID, "pt_init: max_batch must be 0..%d", PT_MAX_BATCH);
     if (o.device >= 0) HIPCHECK(hipSetDevice(o.device));
     HIPCHECK(hipGetDevice(&S.device));
     S.stream = (hipStream_t)o.stream;
@@ -1042,7 +1056,9 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     // value of blockIdx % kSub; tiles are blockIdx-strided and the grid is a multiple of kSub, so those workgroups
     // process at most ceil(tiles / kSub) tiles, and tiles <= ceil(nLocal/256) + kSeg (one partial tile per input
     // segment).  Worst case (every ray in one octant) is provisioned: 8x the live paths, 325 MB per buffer at 720p.
-    S.numTilesMax = (S.nLocal + kBlock - 1) / kBlock + kSeg;
+    S.maxBatch = o.max_batch > 0 ? o.max_batch : 1;
+    if ((long long)S.nLocal * S.maxBatch > (1ll << 30)) return fail(PT_ERR_INVALID, "pt_init: max_batch x pixels too large");
+    S.numTilesMax = (int)(((long long)S.nLocal * S.maxBatch + kBlock - 1) / kBlock) + kSeg;
     S.segCap = ((S.numTilesMax + kSub - 1) / kSub) * kBlock;
     k.segCap = S.segCap;
     const size_t cap = (size_t)kSeg * S.segCap;
@@ -1055,8 +1071,8 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
         for (int b = 0; b < 2; ++b) HIPCHECK(hipMalloc(&sl.pathbuf[b], cap * kNumArrays * sizeof(float)));
         HIPCHECK(hipMalloc(&sl.ctrl, sizeof(Ctrl)));
         HIPCHECK(hipMemset(sl.ctrl, 0, sizeof(Ctrl)));
-        HIPCHECK(hipMalloc(&sl.contrib, (size_t)S.P * 3 * sizeof(float)));
-        HIPCHECK(hipMemset(sl.contrib, 0, (size_t)S.P * 3 * sizeof(float)));
+        HIPCHECK(hipMalloc(&sl.contrib, (size_t)S.maxBatch * S.P * 3 * sizeof(float)));
+        HIPCHECK(hipMemset(sl.contrib, 0, (size_t)S.maxBatch * S.P * 3 * sizeof(float)));
         HIPCHECK(hipEventCreateWithFlags(&sl.evDone, hipEventDisableTiming));
         HIPCHECK(hipEventCreateWithFlags(&sl.evCommitted, hipEventDisableTiming));
     }
@@ -1088,16 +1104,18 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     return PT_OK;
 }
 
-int pt_iterate(int frame, int iter, void *rgba8_dev) {
+int pt_iterate_batch(int frame, int first_iter, int count, void *rgba8_dev) {
     (void)frame;  // always 0 in the reference (src/main.cpp:102)
     if (!S.init) return fail(PT_ERR_NOT_INIT, "pt_iterate before pt_init");
-    if (iter < 1 || iter >= (1 << 22)) return fail(PT_ERR_INVALID, "pt_iterate: iter must be 1..4194303 (seed bits, pathtrace.cu:43)");
+    if (count < 1 || count > S.maxBatch) return fail(PT_ERR_INVALID, "pt_iterate_batch: count must be 1..max_batch (%d)", S.maxBatch);
+    if (first_iter < 1 || first_iter + count - 1 >= (1 << 22))
+        return fail(PT_ERR_INVALID, "pt_iterate: iter must be 1..4194303 (seed bits, pathtrace.cu:43)");
     Slot &sl = S.slot[S.seq % S.nslots];
-    // the slot's radiance buffer must have been consumed by the commit of its previous iteration
+    // the slot's radiance buffers must have been consumed by the commit of its previous batch
     HIPCHECK(hipStreamWaitEvent(sl.stream, sl.evCommitted, 0));
     const int D = S.prm.traceDepth;
     for (int d = 1; d <= D; ++d) {
-        int rc = launch_bounce(sl, iter, d, d == D, sl.contrib);
+        int rc = launch_bounce(sl, first_iter, count, d, d == D, sl.contrib);
         if (rc) return rc;
     }
     sl.parity ^= 1;   // the last launch re-armed the other half of the slot's counters
@@ -1106,20 +1124,22 @@ int pt_iterate(int frame, int iter, void *rgba8_dev) {
     HIPCHECK(hipStreamWaitEvent(S.stream, sl.evDone, 0));
     if (S.nLocal > 0) {
         hipLaunchKernelGGL(k_commit, dim3((S.nLocal + kBlock - 1) / kBlock), dim3(kBlock), 0, S.stream, S.prm, S.image, sl.contrib,
-                           (S.flags & PT_FLAG_ACCUM_SHARD_ROWS) ? 1 : 0);
+                           count, (S.flags & PT_FLAG_ACCUM_SHARD_ROWS) ? 1 : 0);
         HIPCHECK(hipGetLastError());
     }
     HIPCHECK(hipEventRecord(sl.evCommitted, S.stream));
     if (rgba8_dev) {
         if (S.flags & PT_FLAG_ACCUM_SHARD_ROWS) return fail(PT_ERR_INVALID, "pt_iterate: no PBO conversion from a row-sharded accumulator");
-        hipLaunchKernelGGL(k_to_rgba8, dim3((S.P + kBlock - 1) / kBlock), dim3(kBlock), 0, S.stream, S.image, S.P, iter,
-                           reinterpret_cast<uchar4 *>(rgba8_dev));
+        hipLaunchKernelGGL(k_to_rgba8, dim3((S.P + kBlock - 1) / kBlock), dim3(kBlock), 0, S.stream, S.image, S.P,
+                           first_iter + count - 1, reinterpret_cast<uchar4 *>(rgba8_dev));
         HIPCHECK(hipGetLastError());
     }
     S.seq += 1;
-    S.iterations += 1;
+    S.iterations += count;
     return PT_OK;
 }
+
+int pt_iterate(int frame, int iter, void *rgba8_dev) { return pt_iterate_batch(frame, iter, 1, rgba8_dev); }
 
 int pt_sync(void) {
     if (!S.init) return fail(PT_ERR_NOT_INIT, "pt_sync before pt_init");
@@ -1229,7 +1249,7 @@ int pt_debug_trace_paths(int iter, int bounces, float *origin3, float *dir3, flo
     }
     HIPCHECK(hipMemsetAsync(&sl.ctrl->seg_count[0][0][0][0], 0, sizeof(sl.ctrl->seg_count), sl.stream));
     for (int d = 1; d <= bounces; ++d) {
-        rc = launch_bounce(sl, iter, d, false, nullptr);  // no radiance, survivors always written
+        rc = launch_bounce(sl, iter, 1, d, false, nullptr);  // no radiance, survivors always written
         if (rc) return rc;
     }
     // gather the kSeg segments of the queue entering bounce `bounces + 1`, then sort by pixel index

@@ -252,6 +252,34 @@ def test_pipeline_depth_does_not_change_the_image(gpu, oracle, pipeline):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
+@pytest.mark.parametrize("batches", [[3, 1, 4], [8], [2, 2, 2, 2]])
+def test_batched_iterations_equal_sequential_iterations(gpu, oracle, batches):
+    # pt_iterate_batch traces `count` iterations as one wavefront; every pixel must still receive its samples in
+    # iteration order, so the running sum stays bit-identical to the sequential oracle
+    res, depth = (160, 90), 8
+    sc = gpu.Scene(os.path.join(SCENES, "cornell_glass.txt"))
+    sc.set_resolution(*res)
+    ref = oracle.Renderer(sc.camera.view(oracle.CAMERA_DTYPE), sc.geoms.view(oracle.GEOM_DTYPE),
+                          sc.materials.view(oracle.MATERIAL_DTYPE), depth)
+    want = np.zeros(res[0] * res[1] * 3, np.float32)
+    gpu.pathtraceFree()
+    gpu.pathtraceInit(sc, traceDepth=depth, max_batch=8, pipeline_depth=2)
+    it, live = 1, 0
+    for count in batches:
+        gpu.pathtrace_batch(None, 0, it, count)
+        for k in range(count):
+            c = ref.iterate(it + k, want)
+            live += c.live[3]
+        it += count
+    got = gpu.readback(res[0] * res[1])
+    cnt = gpu.counters()
+    with pytest.raises(gpu.PtError, match="count must be"):
+        gpu.pathtrace_batch(None, 0, it, 9)
+    gpu.pathtraceFree()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert cnt.iterations == sum(batches) and cnt.live[3] == live
+
+
 def test_rgba8_conversion_matches_reference_formula(gpu, oracle):
     sc = gpu.Scene(os.path.join(SCENES, "cornell.txt"))
     sc.set_resolution(64, 48)
