@@ -179,9 +179,10 @@ def main():
     launches = max(int(cnt.bounce_launches), 1)
     avg_ms = cnt.bounce_kernel_ms / launches
     achieved = bounce_bytes / launches / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    traffic = None
+    traffic, pmc = None, {}
     try:
-        traffic = json.load(open(args.pmc_traffic_json)).get("hbm_bytes_per_bounce_launch")
+        pmc = json.load(open(args.pmc_traffic_json))
+        traffic = pmc.get("hbm_bytes_per_bounce_launch")
     except Exception:
         pass
 
@@ -209,7 +210,11 @@ def main():
                          "algorithmic_bytes_per_launch": round(bounce_bytes / launches, 1),
                          "avg_launch_ms": round(avg_ms, 5), "launches": launches,
                          "bounce_kernel_share_of_step": round(cnt.bounce_kernel_ms / (dtB * 1e3), 4),
-                         "ms_per_step_with_events": round(dtB / args.steps * 1e3, 4)},
+                         "ms_per_step_with_events": round(dtB / args.steps * 1e3, 4),
+                         # the kernel is VALU-issue-bound, not HBM-bound (profiles/): VALU
+                         # wave-instructions per launch from the PMC pass x 4 cycles / (1024 SIMDs x 2.4 GHz)
+                         "valu_issue_bound_ms_per_launch": pmc.get("valu_issue_bound_ms_per_launch"),
+                         "lds_bank_conflict_cycles_per_launch": pmc.get("lds_bank_conflict_cycles_per_launch")},
         }
         if world == 1 and args.cpu_spp > 0:
             out["cpu_baseline"] = cpu_baseline(args, scene)

@@ -119,10 +119,16 @@ def main():
         traffic = kb["FETCH_SIZE"] * 1024.0 * rf_used + kb["WRITE_SIZE"] * 1024.0
         out["k_bounce"]["hbm_bytes_per_launch"] = traffic
         out["k_bounce"]["read_factor_used"] = rf_used
-        json.dump({"hbm_bytes_per_bounce_launch": round(traffic, 1), "read_factor_used": rf_used,
-                   "read_factor_calibrated": rf, "write_factor_calibrated": cal.get("write_factor"),
-                   "source": "profiles/%s_pmc_summary.json" % args.tag},
-                  open(os.path.join(HERE, "pmc_traffic.json"), "w"), indent=1)
+        pj = {"hbm_bytes_per_bounce_launch": round(traffic, 1), "read_factor_used": rf_used,
+              "read_factor_calibrated": rf, "write_factor_calibrated": cal.get("write_factor"),
+              "source": "profiles/%s_pmc_summary.json" % args.tag}
+        if "SQ_INSTS_VALU" in kb:
+            # a wave64 VALU instruction occupies its SIMD for 4 cycles (SQ_ACTIVE_INST_VALU ~= SQ_INSTS_VALU quad-cycles);
+            # 1024 SIMDs at 2.4 GHz -> the time the launch needs if the VALUs never idle
+            pj["valu_wave_insts_per_bounce_launch"] = kb["SQ_INSTS_VALU"]
+            pj["valu_issue_bound_ms_per_launch"] = kb["SQ_INSTS_VALU"] * 4.0 / (1024 * 2.4e9) * 1e3
+            pj["lds_bank_conflict_cycles_per_launch"] = kb.get("SQ_LDS_BANK_CONFLICT")
+        json.dump(pj, open(os.path.join(HERE, "pmc_traffic.json"), "w"), indent=1)
     if "SQ_LDS_BANK_CONFLICT" in kb:
         out["k_bounce"]["lds_bank_conflict_cycles_per_launch"] = kb["SQ_LDS_BANK_CONFLICT"]
         out["k_bounce"]["lds_bank_conflict_fraction"] = kb["SQ_LDS_BANK_CONFLICT"] / max(kb.get("SQ_LDS_IDX_ACTIVE", 1.0), 1.0)
