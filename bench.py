@@ -38,7 +38,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)          # BASELINE config C2: 64 spp
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=128)         # ~14 ms: clocks and first-touch pages settle
     ap.add_argument("--scene", default=os.path.join(ROOT, "scenes", "cornell.txt"))
     ap.add_argument("--res", type=int, nargs=2, default=[1280, 720])
     ap.add_argument("--depth", type=int, default=8)

@@ -215,7 +215,7 @@ def main():
         np.savez_compressed(os.path.join(GOLD, f"scene_{name}.npz"), geoms=g.view(np.uint8), materials=m.view(np.uint8),
                             camera=c.view(np.uint8), meta=json.dumps(meta))
     # authored scenes (C4, C5) through the reference loader as well
-    for name in ("cornell_glass", "spheres64"):
+    for name in ("cornell_glass", "spheres64", "rotated"):
         g, m, c, meta = ref_scene(L, os.path.join(ROOT, "scenes", f"{name}.txt"))
         np.savez_compressed(os.path.join(GOLD, f"scene_{name}.npz"), geoms=g.view(np.uint8), materials=m.view(np.uint8),
                             camera=c.view(np.uint8), meta=json.dumps(meta))

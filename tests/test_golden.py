@@ -68,7 +68,7 @@ def test_transform_builder_bit_exact(oracle):
         assert_bits(it, z["invTranspose"][i], f"invTranspose[{i}]")
 
 
-@pytest.mark.parametrize("name", ["cornell", "sphere", "cornell_glass", "spheres64"])
+@pytest.mark.parametrize("name", ["cornell", "sphere", "cornell_glass", "spheres64", "rotated"])
 def test_scene_loader_matches_reference_loader(oracle, name):
     z = np.load(os.path.join(GOLD, f"scene_{name}.npz"))
     sc = oracle.Scene(os.path.join(SCENES, f"{name}.txt"))

@@ -1,0 +1,159 @@
+"""GPU edge cases against the oracle (bit-exact): degenerate frames and scenes, limits of the API,
+rotated geometry with an oblique camera, and the full BASELINE size."""
+import os
+import types
+
+import numpy as np
+import pytest
+
+from conftest import SCENES
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu(pt):
+    if pt.device_count() < 1:
+        pytest.fail("no HIP device: GPU tests must run on the MI355X box")
+    return pt
+
+
+def _scene(gpu, oracle, geoms, mats, res, depth, eye=(0, 5, 10.5), view=(0, 0, -1), up=(0, 1, 0), fovy=45.0):
+    cam = np.zeros(1, oracle.CAMERA_DTYPE)
+    cam["resolution"] = res
+    cam["position"], cam["view"], cam["up"] = eye, view, up
+    cam["fov"] = (0.0, fovy)
+    oracle.lib().orc_camera_set_resolution(cam.ctypes.data, res[0], res[1])
+    return types.SimpleNamespace(geoms=np.ascontiguousarray(geoms).view(gpu.GEOM_DTYPE) if len(geoms) else np.zeros(0, gpu.GEOM_DTYPE),
+                                 materials=np.ascontiguousarray(mats).view(gpu.MATERIAL_DTYPE),
+                                 camera=cam.view(gpu.CAMERA_DTYPE), traceDepth=depth,
+                                 image=np.zeros((res[1], res[0], 3), np.float32))
+
+
+def _compare(gpu, oracle, sc, iters, **init):
+    W, H = (int(v) for v in sc.camera["resolution"][0])
+    ref = oracle.Renderer(sc.camera.view(oracle.CAMERA_DTYPE), sc.geoms.view(oracle.GEOM_DTYPE),
+                          sc.materials.view(oracle.MATERIAL_DTYPE), sc.traceDepth)
+    want = np.zeros(W * H * 3, np.float32)
+    gpu.pathtraceFree()
+    gpu.pathtraceInit(sc, **init)
+    for it in iters:
+        gpu.pathtrace(None, 0, it, readback=False)
+        ref.iterate(it, want)
+    got = gpu.readback(W * H)
+    gpu.pathtraceFree()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    return got
+
+
+def _mat(oracle, color=(1, 1, 1), emit=0.0, refl=0.0, refr=0.0, ior=0.0, spec=(0, 0, 0)):
+    m = np.zeros(1, oracle.MATERIAL_DTYPE)
+    m["color"], m["specColor"], m["emittance"] = color, spec, emit
+    m["hasReflective"], m["hasRefractive"], m["indexOfRefraction"] = refl, refr, ior
+    return m
+
+
+def test_one_pixel_frame_and_depth_one(gpu, oracle):
+    light = oracle.make_geom(0, 0, (0, 5, 0), (0, 0, 0), (30, 30, 30))          # camera inside an emissive sphere
+    sc = _scene(gpu, oracle, light, _mat(oracle, emit=2.0), (1, 1), 1)
+    img = _compare(gpu, oracle, sc, [1, 2, 3])
+    assert img.tolist() == [6.0, 6.0, 6.0]
+
+
+def test_empty_scene_is_black(gpu, oracle):
+    sc = _scene(gpu, oracle, [], _mat(oracle), (33, 17), 4)
+    img = _compare(gpu, oracle, sc, [1])
+    assert not img.any()
+
+
+def test_more_shards_than_rows(gpu, oracle):
+    sc = gpu.Scene(os.path.join(SCENES, "cornell.txt"))
+    sc.set_resolution(40, 3)
+    ref = oracle.Renderer(sc.camera.view(oracle.CAMERA_DTYPE), sc.geoms.view(oracle.GEOM_DTYPE),
+                          sc.materials.view(oracle.MATERIAL_DTYPE), 8)
+    want = np.zeros(40 * 3 * 3, np.float32)
+    ref.iterate(1, want)
+    acc = np.zeros_like(want)
+    for r in range(5):                                    # ranks 3 and 4 own no row at all
+        gpu.pathtraceFree()
+        gpu.pathtraceInit(sc, shard_rank=r, shard_count=5)
+        gpu.pathtrace(None, 0, 1, readback=False)
+        acc += gpu.readback(40 * 3)
+        assert gpu.counters().live[1] == (40 if r < 3 else 0)
+    gpu.pathtraceFree()
+    assert np.array_equal(acc.view(np.uint32), want.view(np.uint32))
+
+
+def test_maximum_depth_and_iteration_index(gpu, oracle):
+    sc = gpu.Scene(os.path.join(SCENES, "cornell_glass.txt"))
+    sc.set_resolution(48, 40)
+    sc.traceDepth = gpu.PT_MAX_DEPTH
+    _compare(gpu, oracle, sc, [4194302, 4194303], traceDepth=gpu.PT_MAX_DEPTH)
+    with pytest.raises(gpu.PtError, match="traceDepth"):
+        gpu.pathtraceInit(sc, traceDepth=gpu.PT_MAX_DEPTH + 1)
+    gpu.pathtraceInit(sc)
+    with pytest.raises(gpu.PtError, match="iter"):
+        gpu.pathtrace(None, 0, 4194304)
+    gpu.pathtraceFree()
+
+
+def test_rotated_geometry_oblique_camera(gpu, oracle):
+    sc = gpu.Scene(os.path.join(SCENES, "rotated.txt"))
+    img = _compare(gpu, oracle, sc, [1, 2, 3, 4])
+    assert img.max() > 0
+    # per-bounce state too (arrival order on the device, pixel order here)
+    ref = oracle.Renderer(sc.camera.view(oracle.CAMERA_DTYPE), sc.geoms.view(oracle.GEOM_DTYPE),
+                          sc.materials.view(oracle.MATERIAL_DTYPE), sc.traceDepth)
+    gpu.pathtraceInit(sc)
+    for b in (0, 1, 3, 6):
+        o, d, c, pix = gpu.debug_trace_paths(7, b, 320 * 200)
+        wo, wd, wc, wpix = ref.dump_paths(7, b)
+        assert np.array_equal(pix, wpix)
+        assert np.array_equal(o.view(np.uint32), wo.view(np.uint32)) and np.array_equal(d.view(np.uint32), wd.view(np.uint32))
+        assert np.array_equal(c.view(np.uint32), wc.view(np.uint32))
+    gpu.pathtraceFree()
+
+
+def test_two_hundred_spheres_in_lds_and_scalar_path(gpu, oracle):
+    rng = np.random.default_rng(5)
+    geoms = [oracle.make_geom(1, 1, (0, -1, 0), (0, 0, 0), (40, 1, 40)), oracle.make_geom(0, 0, (0, 14, 0), (0, 0, 0), (8, 1, 8))]
+    for _ in range(200):
+        geoms.append(oracle.make_geom(0, int(rng.integers(1, 4)), rng.uniform(-7, 7, 3) + (0, 6, 0), rng.uniform(-90, 90, 3),
+                                      rng.uniform(0.3, 1.5, 3)))
+    mats = np.concatenate([_mat(oracle, emit=4.0), _mat(oracle, (.8, .8, .8)), _mat(oracle, (.9, .3, .3), refl=1.0, spec=(.9, .9, .9)),
+                           _mat(oracle, (.95, .95, .95), refr=1.0, ior=1.5, spec=(.95, .95, .95))])
+    sc = _scene(gpu, oracle, np.concatenate(geoms), mats, (96, 64), 8, eye=(0, 6, 16))
+    _compare(gpu, oracle, sc, [1, 2])
+
+
+def test_full_baseline_frame_is_bit_identical(gpu, oracle):
+    # BASELINE config C2 at its real size (1280x720, depth 8), 2 spp: every one of the 2.7 M floats
+    sc = gpu.Scene(os.path.join(SCENES, "cornell.txt"))
+    sc.set_resolution(1280, 720)
+    _compare(gpu, oracle, sc, [1, 2], max_batch=8)
+
+
+def test_large_frame_properties(gpu):
+    # 4096x4096 (config C5's frame): too slow for the CPU oracle, so size-independent properties:
+    # conservation of paths per bounce, and the row-sharded halves sum to the unsharded frame bit for bit
+    sc = gpu.Scene(os.path.join(SCENES, "spheres64.txt"))
+    sc.set_resolution(4096, 4096)
+    P = 4096 * 4096
+    gpu.pathtraceFree()
+    gpu.pathtraceInit(sc, pipeline_depth=1)
+    gpu.pathtrace(None, 0, 1, readback=False)
+    full = gpu.readback(P)
+    c = gpu.counters()
+    live = [int(c.live[d]) for d in range(10)]
+    assert live[1] == P and all(live[d + 1] <= live[d] for d in range(1, 8))
+    # every path ends exactly once: on an emitter, in the void, or at the depth limit (survivors of bounce 8)
+    assert c.light_hits + c.misses <= P and c.light_hits > 0 and c.misses > 0
+    acc = np.zeros_like(full)
+    for r in range(2):
+        gpu.pathtraceFree()
+        gpu.pathtraceInit(sc, shard_rank=r, shard_count=2, pipeline_depth=1)
+        gpu.pathtrace(None, 0, 1, readback=False)
+        acc += gpu.readback(P)
+    gpu.pathtraceFree()
+    assert np.array_equal(acc.view(np.uint32), full.view(np.uint32))
+    assert np.isfinite(full).all() and full.min() >= 0

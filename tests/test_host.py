@@ -46,7 +46,7 @@ def test_no_gpu_means_loud_failure_not_fallback(pt):
     pt.pathtraceFree()  # legal before any Init (src/main.cpp:91-94)
 
 
-@pytest.mark.parametrize("name", ["cornell", "sphere", "cornell_glass", "spheres64"])
+@pytest.mark.parametrize("name", ["cornell", "sphere", "cornell_glass", "spheres64", "rotated"])
 def test_scene_loader_matches_reference_loader(pt, name):
     z = np.load(os.path.join(GOLD, f"scene_{name}.npz"))
     sc = pt.Scene(os.path.join(SCENES, f"{name}.txt"))
