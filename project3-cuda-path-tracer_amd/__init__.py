@@ -149,8 +149,9 @@ def host_lib():
         H.pth_scene_image_name.restype = C.c_char_p
         H.pth_scene_set_resolution.argtypes = [vp, C.c_int, C.c_int]
         H.pth_scene_set_resolution.restype = None
-        H.pth_save_png.argtypes = [C.c_char_p, vp, C.c_int, C.c_int, C.c_float]
-        H.pth_save_png.restype = C.c_int
+        for n in ("pth_save_png", "pth_save_hdr"):
+            getattr(H, n).argtypes = [C.c_char_p, vp, C.c_int, C.c_int, C.c_float]
+            getattr(H, n).restype = C.c_int
         _host = H
     return _host
 
@@ -273,6 +274,14 @@ def save_png(basename, image_sum, samples):
     rc = host_lib().pth_save_png(os.fsencode(basename), _p(img), w, h, C.c_float(samples))
     if rc != 0:
         raise IOError("could not write %s.png" % basename)
+
+
+def save_hdr(basename, image_sum, samples):
+    """saveImage + image::saveHDR (reference src/main.cpp:49-70, src/image.cpp:41-45): writes <basename>.hdr."""
+    img = np.ascontiguousarray(image_sum, np.float32)
+    h, w = img.shape[0], img.shape[1]
+    if host_lib().pth_save_hdr(os.fsencode(basename), _p(img), w, h, C.c_float(samples)) != 0:
+        raise IOError("could not write %s.hdr" % basename)
 
 
 # --------------------------------------------------------------------------- primitive / scan entry points (host arrays)

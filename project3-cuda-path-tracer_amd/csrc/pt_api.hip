@@ -1,4 +1,4 @@
-// pt_kernels.hip -- MI355X (gfx950 / CDNA4) path-tracing hot path + its C ABI (include/pt_amd.h).
+// pt_api.hip -- MI355X (gfx950 / CDNA4) path-tracing hot path + its C ABI (include/pt_amd.h).
 //
 // One iteration = camera-ray generation, then `traceDepth` launches of ONE fused persistent kernel
 // per bounce: nearest-hit over the scene (geometry through the scalar path, materials in LDS) -> shade/scatter
@@ -7,8 +7,9 @@
 // ballot/mbcnt ranks, LDS wave totals = workgroup-level exclusive scan; the workgroup's output range
 // is reserved with ONE atomic on one of 8 sharded segment counters).  No host round trip inside an
 // iteration: live counts stay on the device.  The multi-workgroup ORDERED scan (two-level decoupled
-// look-back) is the stream-compaction library at the end of this file (pt_scan_exclusive_i32 /
-// pt_compact_nonzero_i32).
+// look-back) is the stream-compaction library in pt_compaction.h (pt_scan_exclusive_i32 /
+// pt_compact_nonzero_i32).  Files: pt_device.h (math), pt_trace.h (render kernels), pt_compaction.h,
+// pt_test_kernels.h (primitives for the parity tests), this file (host side + C ABI).
 //
 // Replaces the unsolved pipeline of reference src/pathtrace.cu:133-167 (spec: SURVEY.md 3.4 S0-S9).
 // HBM layout, kernels, rooflines: DESIGN.md.
@@ -23,690 +24,16 @@
 #include <vector>
 
 #include "../../include/pt_amd.h"
-#include "pt_device.h"
+#include "pt_compaction.h"
+#include "pt_test_kernels.h"
+#include "pt_trace.h"
 
 using namespace ptd;
+using namespace ptk;
 
 static_assert(sizeof(PtGeom) == 236 && sizeof(PtMaterial) == 44 && sizeof(PtCamera) == 52,
               "layout must equal reference src/sceneStructs.h:18-47");
-
 namespace {
-
-constexpr int kBlock = 256;          // threads per workgroup = paths per tile (4 wave64)
-constexpr int kWaves = kBlock / 64;
-constexpr int kNumArrays = 11;       // SoA PathSegment: origin3, dir3, throughput3, pixelIndex, remainingBounces
-constexpr int kMaxDepthSlots = PT_MAX_DEPTH + 2;
-
-// ---- device control block ------------------------------------------------------------------------
-constexpr int kOct = 8;              // direction octants: paths are binned by the signs of their new direction
-constexpr int kSub = 4;              // append-counter shards per octant (workgroup blockIdx % kSub)
-constexpr int kSeg = kOct * kSub;    // path buffers are split into kSeg segments with one append counter each
-constexpr int kCtrPad = 32;          // one counter per 128-byte line: same-line atomics serialise at the memory side
-
-struct Ctrl {
-    // seg_count[p][d][s][0] = paths in segment s entering bounce d of an iteration with parity p.
-    // The last bounce launch of an iteration zeroes the OTHER parity, i.e. re-arms the next iteration,
-    // so an iteration needs neither a memset nor a separate re-arm launch.
-    uint32_t seg_count[2][kMaxDepthSlots][kSeg][kCtrPad];
-    // never zeroed by an iteration
-    uint32_t error;                    // sticky device fault (scan-library look-back timeout)
-    uint32_t pad[kCtrPad - 1];
-    unsigned long long sum_live[kMaxDepthSlots];
-    unsigned long long light_hits[kOct][kCtrPad / 2], misses[kOct][kCtrPad / 2];
-};
-
-// Camera constants derived once on the host (spec S2)
-struct KParams {
-    float view[3], up[3], right[3], pos[3];
-    float pixLenX, pixLenY, halfW, halfH;
-    int   W, H;
-    int   shardRank, shardCount;
-    int   nLocal;       // pixels rendered by this shard
-    int   ngeoms, nmats;
-    int   traceDepth;
-    int   segCap;       // capacity (paths) of one segment of a path buffer, multiple of kBlock
-};
-
-// SoA PathSegment buffer: 11 arrays of `cap` = kSeg * segCap 4-byte elements, array k at base + k*cap
-// (0-2 origin, 3-5 direction, 6-8 throughput, 9 pixelIndex, 10 remainingBounces); inside every array
-// segment s owns [s*segCap, (s+1)*segCap) and is filled from its start.
-struct PathSoA {
-    float *base;
-    int    cap;
-    __host__ __device__ __forceinline__ float *a(int k) const { return base + (size_t)k * cap; }
-    __host__ __device__ __forceinline__ int *pix() const { return reinterpret_cast<int *>(base + (size_t)9 * cap); }
-    __host__ __device__ __forceinline__ int *rem() const { return reinterpret_cast<int *>(base + (size_t)10 * cap); }
-};
-
-// ---- cross-workgroup ordered prefix: two-level look-back ----------------------------------------------
-// Tiles are handed out by an atomic ticket, so every predecessor of a tile is owned by a workgroup that
-// is already running: no residency or dispatch-order assumption.  Each tile publishes
-//   * its aggregate as ONE 8-byte agent-scope granule  desc[tile] = {status = 1 (hi), value (lo)}
-//   * and adds it to its 64-tile group's word          grp[tile/64] += {value (hi), 1 (lo)}   (count in the
-//     low half so that the wrapping sum can never carry into it).
-// The exclusive prefix of tile t = sum of the full groups before it (one probe per 64 groups = 4096 tiles)
-// + sum of the aggregates of its own group's earlier tiles (one probe).  Both probes are issued together,
-// so the dependent latency is ~one memory round trip instead of the (tiles in flight)/64 serial probes of a
-// flat decoupled look-back.  The value IS the flag in both words, so no fence is needed (the payload
-// travels inside the granule).  Spins are bounded; a timeout sets the sticky error word.
-constexpr int kSpinLimit = 1 << 22;
-constexpr int kGroup = 64;
-
-__device__ __forceinline__ unsigned long long word_load(unsigned long long *p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
-// Called by all 64 lanes of wave 0 of the workgroup that owns `tile`.
-__device__ __forceinline__ uint32_t lookback_exclusive(unsigned long long *desc, unsigned long long *grp, int tile,
-                                                       uint32_t block_total, uint32_t *error_word) {
-    const int lane = threadIdx.x & 63;
-    const int g = tile / kGroup, r = tile - g * kGroup;
-    if (lane == 0) {
-        __hip_atomic_store(&desc[tile], (1ull << 32) | block_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(&grp[g], ((unsigned long long)block_total << 32) | 1ull, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-    }
-    uint32_t excl = 0;
-    // own group: aggregates of tiles 64g .. tile-1; first window of previous groups probed in the same trip
-    {
-        const int jg = g - 1 - lane;
-        unsigned long long dt = 1ull << 32, dg = (unsigned long long)kGroup;   // "ready, value 0"
-        int spins = 0;
-        for (;;) {
-            if (lane < r) dt = word_load(&desc[g * kGroup + lane]);
-            if (jg >= 0) dg = word_load(&grp[jg]);
-            if (__all((uint32_t)(dt >> 32) != 0u && (uint32_t)dg == (uint32_t)kGroup)) break;
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > kSpinLimit) {
-                if (lane == 0) atomicExch(error_word, 1u);
-                return 0u;
-            }
-        }
-        excl = wave_sum((lane < r ? (uint32_t)dt : 0u) + (jg >= 0 ? (uint32_t)(dg >> 32) : 0u));
-    }
-    // more than 64 previous groups (> 4096 tiles ahead of this one)
-    for (int base = g - 1 - 64; base >= 0; base -= 64) {
-        const int jg = base - lane;
-        unsigned long long dg = (unsigned long long)kGroup;
-        int spins = 0;
-        for (;;) {
-            if (jg >= 0) dg = word_load(&grp[jg]);
-            if (__all((uint32_t)dg == (uint32_t)kGroup)) break;
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > kSpinLimit) {
-                if (lane == 0) atomicExch(error_word, 1u);
-                return 0u;
-            }
-        }
-        excl += wave_sum(jg >= 0 ? (uint32_t)(dg >> 32) : 0u);
-    }
-    return excl;
-}
-
-// Workgroup-level stable compaction rank of a 0/1 flag: ballot + mbcnt inside each wave, wave
-// totals through LDS, cross-tile base from the look-back.  Returns the destination slot of this
-// thread (valid when flag) and the tile's inclusive end in *tile_end (valid in every thread).
-__device__ __forceinline__ uint32_t compact_slot(bool flag, int tile, unsigned long long *desc, unsigned long long *grp,
-                                                 uint32_t *s_wave, uint32_t *s_excl, uint32_t *error_word,
-                                                 uint32_t *tile_end) {
-    const int wave = threadIdx.x >> 6;
-    const unsigned long long ballot = __ballot(flag);
-    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32),
-                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, 0u));
-    if ((threadIdx.x & 63) == 0) s_wave[wave] = (uint32_t)__popcll(ballot);
-    __syncthreads();
-    uint32_t wave_off = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < kWaves; ++w) {
-        uint32_t c = s_wave[w];
-        wave_off += w < wave ? c : 0u;
-        total += c;
-    }
-    if (wave == 0) {
-        uint32_t e = lookback_exclusive(desc, grp, tile, total, error_word);
-        if (threadIdx.x == 0) *s_excl = e;
-    }
-    __syncthreads();
-    const uint32_t excl = *s_excl;
-    *tile_end = excl + total;
-    return excl + wave_off + rank;
-}
-
-// ---- camera ray of the j-th pixel of this shard (spec S2) ------------------------------------------
-__device__ __forceinline__ void cameraRay(const KParams &prm, int iter, int j, int &pix, F3 &org, F3 &dir) {
-    const int lr = j / prm.W;
-    const int x = j - lr * prm.W;
-    const int y = lr * prm.shardCount + prm.shardRank;
-    pix = x + y * prm.W;
-    Rng rng = makeSeededRandomEngine(iter, pix, 0);
-    const float jx = u01(rng);
-    const float jy = u01(rng);
-    const float sx = ((float)x + jx) - prm.halfW;
-    const float sy = ((float)y + jy) - prm.halfH;
-    const float a = prm.pixLenX * sx;
-    const float b = prm.pixLenY * sy;
-    const F3 view = f3(prm.view[0], prm.view[1], prm.view[2]);
-    const F3 up = f3(prm.up[0], prm.up[1], prm.up[2]);
-    const F3 right = f3(prm.right[0], prm.right[1], prm.right[2]);
-    org = f3(prm.pos[0], prm.pos[1], prm.pos[2]);
-    dir = normalize((view - right * a) - up * b);
-}
-
-// camera rays alone, for pt_debug_trace_paths(bounces = 0)
-__global__ __launch_bounds__(kBlock) void k_debug_camera_rays(KParams prm, int iter, float *o3, float *d3, int *pixOut) {
-    const int j = blockIdx.x * kBlock + threadIdx.x;
-    if (j >= prm.nLocal) return;
-    int pix;
-    F3 org, dir;
-    cameraRay(prm, iter, j, pix, org, dir);
-    o3[3 * j] = org.x; o3[3 * j + 1] = org.y; o3[3 * j + 2] = org.z;
-    d3[3 * j] = dir.x; d3[3 * j + 1] = dir.y; d3[3 * j + 2] = dir.z;
-    pixOut[j] = pix;
-}
-
-// ---- one bounce: intersect + shade + accumulate + compact (spec S3-S8) -----------------------------
-// Persistent workgroups walk the 256-path tiles of the bounce's queue (the kSeg input segments laid
-// end to end), blockIdx-strided.  Survivors are BINNED BY DIRECTION OCTANT while they are compacted:
-//   segment   = octant(new direction) * kSub + blockIdx % kSub,
-//   rank      = exclusive scan of the lane's octant flag inside the wave (ballot + mbcnt) plus the earlier
-//               waves' totals through LDS = workgroup-level exclusive scan per octant,
-//   base      = ONE atomicAdd per non-empty octant of the tile on that segment's counter (8 lanes, one
-//               instruction).
-// A tile of the next bounce therefore holds rays of a single direction octant, which turns the exact
-// early-miss of the box test (pt_device.h) into a wave-uniform branch for axis-aligned boxes.  Queue order
-// never influences results: RNG and accumulator are keyed on the pixel index.
-// No workgroup ever waits for another one, so there is no residency / dispatch-order assumption.
-// A segment receives survivors of the tiles of the workgroups with one value of blockIdx % kSub only,
-// i.e. at most ceil(tiles / kSub) * 256 <= segCap paths (see pt_init).
-//
-// FIRST = true is bounce 1 fused with camera-ray generation (spec S2): tile T holds the paths
-// j = 256 T + lane of this shard's pixel list and the ray is built in registers, so the first bounce
-// reads no path state at all.
-template <bool FIRST>
-__global__ __launch_bounds__(kBlock, 5) void k_bounce(KParams prm, int iter, int batch, int depth, int lastBounce, int parity,
-                                                   PathSoA in, PathSoA out, Ctrl *ctrl,
-                                                   const GeomDev *__restrict__ ggeoms,
-                                                   const MaterialDev *__restrict__ gmats, float *contrib) {
-    // LDS: the material table and the geom -> material map (indexed per lane by the nearest hit), and the
-    // compaction scratch.  Geometry itself is wave-uniform in the nearest-hit loop, so it is fetched through the
-    // scalar path (s_load into SGPRs, used directly as VALU operands): measured against an LDS-staged copy
-    // read back with ds_read_b128 broadcasts this is 5 % faster on Cornell (7 geoms) and 11 % on the 70-geom
-    // scene, and it frees ~40 VGPRs.
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    MaterialDev *smats = reinterpret_cast<MaterialDev *>(smem);
-    int *s_geomMat = reinterpret_cast<int *>(smem + sizeof(MaterialDev) * prm.nmats);
-    uint32_t *s_misc = reinterpret_cast<uint32_t *>(smem + sizeof(MaterialDev) * prm.nmats + sizeof(int) * ((prm.ngeoms + 3) & ~3));
-    uint32_t *s_wave = s_misc;                       // [kWaves][kOct] alive count per wave and octant
-    uint32_t *s_base = s_wave + kWaves * kOct;       // [kOct]   first output slot of this tile per octant
-    uint32_t *s_segcnt = s_base + kOct;              // [kSeg]   paths per input segment
-    uint32_t *s_segpre = s_segcnt + kSeg;            // [kSeg+2] tile prefix per input segment, [kSeg+1] = live paths
-
-    if (lastBounce) {   // re-arm the next iteration: nobody touches the other parity's counters now
-        uint32_t *other = &ctrl->seg_count[parity ^ 1][0][0][0];
-        const int nwords = (prm.traceDepth + 2) * kSeg * kCtrPad;
-        for (int i = blockIdx.x * kBlock + threadIdx.x; i < nwords; i += gridDim.x * kBlock) other[i] = 0u;
-    }
-    // input queue: segment s holds s_cnt[s] paths = tiles [s_pre[s], s_pre[s+1]) of the global tile index
-    uint32_t nLive, numTiles;
-    if (FIRST) {
-        nLive = (uint32_t)prm.nLocal * (uint32_t)batch;     // `batch` consecutive iterations share one wavefront
-        numTiles = (nLive + kBlock - 1) / kBlock;
-    } else {
-        if (threadIdx.x < 64) {          // wave 0: exclusive scan of the kSeg tile counts
-            const uint32_t c = threadIdx.x < kSeg ? ctrl->seg_count[parity][depth][threadIdx.x][0] : 0u;
-            const uint32_t t = (c + kBlock - 1) / kBlock;
-            uint32_t inc = t, sum = c;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t up = __shfl_up(inc, o, 64), us = __shfl_up(sum, o, 64);
-                if ((int)threadIdx.x >= o) { inc += up; sum += us; }
-            }
-            if (threadIdx.x < kSeg) { s_segcnt[threadIdx.x] = c; s_segpre[threadIdx.x + 1] = inc; }
-            if (threadIdx.x == 0) s_segpre[0] = 0;
-            if (threadIdx.x == 63) s_segpre[kSeg + 1] = sum;   // total live paths
-        }
-        __syncthreads();
-        numTiles = s_segpre[kSeg];
-        nLive = s_segpre[kSeg + 1];
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctrl->sum_live[depth], (unsigned long long)nLive);
-    if (blockIdx.x >= numTiles) return;
-
-    // stage the materials in LDS once per (persistent) workgroup, 16 B per lane per step
-    {
-        const float4 *msrc = reinterpret_cast<const float4 *>(gmats);
-        float4 *mdst = reinterpret_cast<float4 *>(smats);
-        const int m16 = prm.nmats * (int)(sizeof(MaterialDev) / 16);
-        for (int i = threadIdx.x; i < m16; i += kBlock) mdst[i] = msrc[i];
-        for (int i = threadIdx.x; i < prm.ngeoms; i += kBlock) s_geomMat[i] = ggeoms[i].material;
-    }
-    __syncthreads();
-
-    uint32_t waveLight = 0, waveMiss = 0;   // wave-uniform tallies, flushed once at the end
-    uint32_t sgIn = 0;                      // input segment of the current tile (tiles are visited in increasing order)
-    for (uint32_t T = blockIdx.x; T < numTiles; T += gridDim.x) {
-        bool valid;
-        uint32_t idx = 0;
-        if (FIRST) {
-            idx = T * kBlock + threadIdx.x;                     // position in this shard's pixel list
-            valid = idx < nLive;
-        } else {
-            // global tile -> (segment, local tile)
-            while (T >= s_segpre[sgIn + 1]) ++sgIn;
-            const uint32_t local = (T - s_segpre[sgIn]) * kBlock + threadIdx.x;
-            valid = local < s_segcnt[sgIn];
-            idx = sgIn * (uint32_t)prm.segCap + local;
-        }
-
-        bool alive = false;
-        bool lightHit = false, missed = false;
-        F3 org = f3(0, 0, 0), dir = f3(0, 0, 1), col = f3(0, 0, 0);
-        int pix = 0, rem = 0;
-        int itb = 0;                                            // which iteration of the batch this path belongs to
-        if (valid) {
-            if (FIRST) {
-                itb = (int)(idx / (uint32_t)prm.nLocal);
-                cameraRay(prm, iter + itb, (int)(idx - (uint32_t)itb * (uint32_t)prm.nLocal), pix, org, dir);
-                col = f3(1.0f, 1.0f, 1.0f);
-                rem = prm.traceDepth;
-            } else {
-                org = f3(in.a(0)[idx], in.a(1)[idx], in.a(2)[idx]);
-                dir = f3(in.a(3)[idx], in.a(4)[idx], in.a(5)[idx]);
-                col = f3(in.a(6)[idx], in.a(7)[idx], in.a(8)[idx]);
-                pix = in.pix()[idx];
-                const int packed = in.rem()[idx];               // remainingBounces | batch index << 8
-                rem = packed & 0xff;
-                itb = packed >> 8;
-            }
-
-            // nearest hit, geoms in file order, strict '<' so the first geom wins ties (S3)
-            float tbest = 0.0f;
-            int hit = -1;
-            F3 P = f3(0, 0, 0), N = f3(0, 0, 0);
-            bool outside = false;
-            const float dd = dot(dir, dir);
-            for (int g = 0; g < prm.ngeoms; ++g) {
-                const GeomDev &G = ggeoms[g];
-                const int type = G.type;
-                F3 p, n;
-                bool o = false;
-                float t = -1.0f;
-                if (type == 0) {
-                    if (!sphereCertainMiss(G, org, dir, dd)) t = sphereIntersectionTest<FIRST>(G, org, dir, p, n, o);
-                } else {
-                    t = boxIntersectionTest<true, FIRST>(G, org, dir, p, n, o);
-                }
-                if (t > 0.0f && (hit < 0 || t < tbest)) {
-                    tbest = t; hit = g; P = p; N = n; outside = o;
-                }
-            }
-            if (hit < 0) {
-                missed = true;                                   // S4: background is black
-            } else {
-                const MaterialDev &M = smats[s_geomMat[hit]];
-                const F3 mcol = f3(M.color[0], M.color[1], M.color[2]);
-                if (M.emittance > 0.0f) {                        // S5: emitter ends the path
-                    lightHit = true;
-                    if (contrib) {
-                        // Deferred accumulation: iterations overlap on several streams, so the radiance
-                        // is parked in this iteration's own buffer (one path per pixel: race-free, no
-                        // read) and k_commit adds it to the accumulator in iteration order.
-                        const F3 c = (col * mcol) * M.emittance;
-                        float *px = contrib + 3 * ((size_t)itb * ((size_t)prm.W * prm.H) + (size_t)pix);
-                        px[0] = c.x; px[1] = c.y; px[2] = c.z;
-                    }
-                } else if (!lastBounce) {                        // S6 scatter (S7: skipped on the last bounce)
-                    Rng rng = makeSeededRandomEngine(iter + itb, pix, depth);
-                    const F3 scol = f3(M.specColor[0], M.specColor[1], M.specColor[2]);
-                    F3 ndir, norg;
-                    if (M.hasRefractive > 0.0f) {
-                        const float ior = M.ior;
-                        const float eta = outside ? 1.0f / ior : ior;
-                        const float c = dot(N, dir);
-                        const float k = 1.0f - eta * eta * (1.0f - c * c);
-                        const float u = u01(rng);
-                        bool doReflect = true;
-                        if (k >= 0.0f) {
-                            float r0 = (1.0f - ior) / (1.0f + ior);
-                            r0 = r0 * r0;
-                            const float cosx = outside ? -c : __builtin_sqrtf(k);
-                            const float w = 1.0f - cosx;
-                            const float w2 = w * w;
-                            const float w5 = w2 * w2 * w;
-                            const float fres = r0 + (1.0f - r0) * w5;
-                            doReflect = u < fres;
-                        }
-                        if (doReflect) {
-                            ndir = reflect(dir, N);
-                            norg = P + N * 0.001f;
-                            col = col * scol;
-                        } else {
-                            ndir = refract(dir, N, eta);
-                            norg = P - N * 0.001f;
-                            col = col * mcol;
-                        }
-                    } else if (M.hasReflective > 0.0f) {
-                        const float u = u01(rng);
-                        if (u < 0.5f) {
-                            ndir = reflect(dir, N);
-                            col = col * scol;
-                        } else {
-                            ndir = calculateRandomDirectionInHemisphere(N, rng);
-                            col = col * mcol;
-                        }
-                        norg = P + N * 0.001f;
-                    } else {
-                        ndir = calculateRandomDirectionInHemisphere(N, rng);
-                        col = col * mcol;
-                        norg = P + N * 0.001f;
-                    }
-                    org = norg;
-                    dir = ndir;
-                    alive = true;
-                }
-            }
-        }
-        waveLight += (uint32_t)__popcll(__ballot(lightHit));
-        waveMiss += (uint32_t)__popcll(__ballot(missed));
-
-        if (!lastBounce) {                                       // S8: compaction into `out`, binned by octant
-            const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-            const int oct = (dir.x < 0.0f ? 1 : 0) | (dir.y < 0.0f ? 2 : 0) | (dir.z < 0.0f ? 4 : 0);
-            uint32_t rank = 0, myCount = 0;
-#pragma unroll
-            for (int k = 0; k < kOct; ++k) {
-                const unsigned long long m = __ballot(alive && oct == k);
-                const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                if (oct == k) rank = r;
-                if (lane == k) myCount = (uint32_t)__popcll(m);
-            }
-            if (lane < kOct) s_wave[wave * kOct + lane] = myCount;
-            __syncthreads();
-            if (threadIdx.x < kOct) {
-                uint32_t total = 0;
-#pragma unroll
-                for (int w = 0; w < kWaves; ++w) total += s_wave[w * kOct + threadIdx.x];
-                const uint32_t oseg = threadIdx.x * kSub + (blockIdx.x % kSub);
-                s_base[threadIdx.x] = total ? atomicAdd(&ctrl->seg_count[parity][depth + 1][oseg][0], total) : 0u;
-            }
-            __syncthreads();
-            if (alive) {
-                uint32_t waveOff = 0;
-                for (int w = 0; w < wave; ++w) waveOff += s_wave[w * kOct + oct];
-                const uint32_t oseg = (uint32_t)oct * kSub + (blockIdx.x % kSub);
-                const uint32_t slot = oseg * (uint32_t)prm.segCap + s_base[oct] + waveOff + rank;
-                out.a(0)[slot] = org.x; out.a(1)[slot] = org.y; out.a(2)[slot] = org.z;
-                out.a(3)[slot] = dir.x; out.a(4)[slot] = dir.y; out.a(5)[slot] = dir.z;
-                out.a(6)[slot] = col.x; out.a(7)[slot] = col.y; out.a(8)[slot] = col.z;
-                out.pix()[slot] = pix;
-                out.rem()[slot] = (rem - 1) | (itb << 8);
-            }
-            __syncthreads();   // s_wave / s_base are rewritten by the next tile
-        }
-    }
-    if ((threadIdx.x & 63) == 0) {
-        const int shard = blockIdx.x % kOct;
-        if (waveLight) atomicAdd(&ctrl->light_hits[shard][0], (unsigned long long)waveLight);
-        if (waveMiss) atomicAdd(&ctrl->misses[shard][0], (unsigned long long)waveMiss);
-    }
-}
-
-// ---- commit one iteration's radiance: image[pix] += contrib[pix]; contrib[pix] = 0 -------------------
-// Runs on the caller's stream, one launch per iteration in iteration order, so every pixel receives its
-// samples in exactly the order a sequential renderer adds them (fp32 addition is not associative).
-// Skipping an all-zero contribution equals adding +0 (the accumulator is never -0).
-// `compactRows`: the accumulator holds only this shard's rows (PT_FLAG_ACCUM_SHARD_ROWS), pixel j of the shard
-// at image[3j]; otherwise it is the full frame indexed by the global pixel index.
-// `batch` iterations were traced together; their radiance buffers are consumed in iteration order.
-__global__ __launch_bounds__(kBlock) void k_commit(KParams prm, float *image, float *contrib, int batch, int compactRows) {
-    const int j = blockIdx.x * kBlock + threadIdx.x;
-    if (j >= prm.nLocal) return;
-    const int lr = j / prm.W;
-    const int x = j - lr * prm.W;
-    const size_t pix = (size_t)x + (size_t)(lr * prm.shardCount + prm.shardRank) * prm.W;
-    const size_t frame = (size_t)prm.W * prm.H;
-    float *px = image + 3 * (compactRows ? (size_t)j : pix);
-    float ax = px[0], ay = px[1], az = px[2];
-    bool dirty = false;
-    for (int b = 0; b < batch; ++b) {
-        float *c = contrib + 3 * ((size_t)b * frame + pix);
-        const float cx = c[0], cy = c[1], cz = c[2];
-        if (cx != 0.0f || cy != 0.0f || cz != 0.0f) {
-            ax += cx; ay += cy; az += cz;
-            c[0] = 0.0f; c[1] = 0.0f; c[2] = 0.0f;
-            dirty = true;
-        }
-    }
-    if (dirty) { px[0] = ax; px[1] = ay; px[2] = az; }
-}
-
-// ---- sendImageToPBO (reference src/pathtrace.cu:48-68) ---------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_to_rgba8(const float *image, int npix, int iter, uchar4 *pbo) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= npix) return;
-    const float *p = image + 3 * (size_t)i;
-    int r = (int)(p[0] / iter * 255.0);
-    int g = (int)(p[1] / iter * 255.0);
-    int b = (int)(p[2] / iter * 255.0);
-    r = r < 0 ? 0 : (r > 255 ? 255 : r);   // glm::clamp = min(max(x, lo), hi), func_common.inl:451-456
-    g = g < 0 ? 0 : (g > 255 ? 255 : g);
-    b = b < 0 ? 0 : (b > 255 ? 255 : b);
-    uchar4 o;
-    o.w = 0; o.x = (unsigned char)r; o.y = (unsigned char)g; o.z = (unsigned char)b;
-    pbo[i] = o;
-}
-
-// ---- stream-compaction library kernels ---------------------------------------------------------------
-struct ScanCtrl {
-    uint32_t ticket;
-    uint32_t error;
-};
-constexpr int kScanItems = 4;                 // int4 per thread
-constexpr int kScanTile = kBlock * kScanItems;
-
-__global__ __launch_bounds__(kBlock) void k_scan_exclusive(const int32_t *__restrict__ in, int32_t *__restrict__ out,
-                                                           long long n, ScanCtrl *sc, unsigned long long *desc,
-                                                           unsigned long long *grp) {
-    __shared__ uint32_t s_wave[kWaves];
-    __shared__ uint32_t s_excl, s_tile;
-    const long long numTiles = (n + kScanTile - 1) / kScanTile;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (;;) {
-        if (threadIdx.x == 0) s_tile = atomicAdd(&sc->ticket, 1u);
-        __syncthreads();
-        const long long tile = s_tile;
-        if (tile >= numTiles) break;
-        const long long base = tile * kScanTile + (long long)threadIdx.x * kScanItems;
-        int32_t v[kScanItems];
-        if (base + kScanItems <= n && ((reinterpret_cast<uintptr_t>(in + base) & 15) == 0)) {
-            const int4 q = *reinterpret_cast<const int4 *>(in + base);
-            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-        } else {
-#pragma unroll
-            for (int k = 0; k < kScanItems; ++k) v[k] = base + k < n ? in[base + k] : 0;
-        }
-        const uint32_t tsum = (uint32_t)v[0] + (uint32_t)v[1] + (uint32_t)v[2] + (uint32_t)v[3];
-        // wave-level inclusive scan of the per-thread sums
-        uint32_t inc = tsum;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            uint32_t up = __shfl_up(inc, o, 64);
-            if (lane >= o) inc += up;
-        }
-        if (lane == 63) s_wave[wave] = inc;
-        __syncthreads();
-        uint32_t wave_off = 0, total = 0;
-#pragma unroll
-        for (int w = 0; w < kWaves; ++w) {
-            uint32_t c = s_wave[w];
-            wave_off += w < wave ? c : 0u;
-            total += c;
-        }
-        if (wave == 0) {
-            uint32_t e = lookback_exclusive(desc, grp, (int)tile, total, &sc->error);
-            if (threadIdx.x == 0) s_excl = e;
-        }
-        __syncthreads();
-        uint32_t run = s_excl + wave_off + (inc - tsum);
-        int32_t o4[kScanItems];
-#pragma unroll
-        for (int k = 0; k < kScanItems; ++k) {
-            o4[k] = (int32_t)run;
-            run += (uint32_t)v[k];
-        }
-        if (base + kScanItems <= n && ((reinterpret_cast<uintptr_t>(out + base) & 15) == 0)) {
-            *reinterpret_cast<int4 *>(out + base) = make_int4(o4[0], o4[1], o4[2], o4[3]);
-        } else {
-#pragma unroll
-            for (int k = 0; k < kScanItems; ++k)
-                if (base + k < n) out[base + k] = o4[k];
-        }
-    }
-}
-
-__global__ __launch_bounds__(kBlock) void k_compact_nonzero(const int32_t *__restrict__ in, int32_t *__restrict__ out,
-                                                            long long n, ScanCtrl *sc, unsigned long long *desc,
-                                                            unsigned long long *grp, long long *count_out) {
-    __shared__ uint32_t s_wave[kWaves];
-    __shared__ uint32_t s_excl, s_tile;
-    const long long numTiles = (n + kBlock - 1) / kBlock;
-    if (n == 0 && blockIdx.x == 0 && threadIdx.x == 0) *count_out = 0;
-    for (;;) {
-        if (threadIdx.x == 0) s_tile = atomicAdd(&sc->ticket, 1u);
-        __syncthreads();
-        const long long tile = s_tile;
-        if (tile >= numTiles) break;
-        const long long i = tile * kBlock + threadIdx.x;
-        const int32_t v = i < n ? in[i] : 0;
-        uint32_t tileEnd;
-        const uint32_t slot = compact_slot(v != 0, (int)tile, desc, grp, s_wave, &s_excl, &sc->error, &tileEnd);
-        if (v != 0) out[slot] = v;
-        if (tile == numTiles - 1 && threadIdx.x == 0) *count_out = (long long)tileEnd;
-    }
-}
-
-// ---- primitive test kernels (device functions exactly as the render kernels use them) -------------------
-__global__ void k_test_utilhash(const uint32_t *in, uint32_t *out, int n) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = utilhash(in[i]);
-}
-__global__ void k_test_rng(const uint32_t *seeds, int nseeds, int ndraws, float *out) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nseeds) return;
-    Rng r = seedEngine(seeds[i]);
-    for (int k = 0; k < ndraws; ++k) out[(size_t)i * ndraws + k] = u01(r);
-}
-__global__ void k_test_intersect(const GeomDev *geoms, const int *gidx, const float *rays, int n, float *t, float *p3,
-                                 float *n3, int *outside) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const GeomDev G = geoms[gidx[i]];
-    F3 ro = f3(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]);
-    F3 rd = f3(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
-    F3 P = f3(p3[3 * i], p3[3 * i + 1], p3[3 * i + 2]);
-    F3 N = f3(n3[3 * i], n3[3 * i + 1], n3[3 * i + 2]);
-    bool o = outside[i] != 0;
-    // odd lanes take the early-miss variant so both instantiations are checked against the golden vectors
-    // the certain-miss shortcut must agree with the full test on every golden vector
-    const bool cull = G.type == 0 && sphereCertainMiss(G, ro, rd, dot(rd, rd));
-    if (cull && sphereIntersectionTest(G, ro, rd, P, N, o) != -1.0f) { t[i] = __builtin_nanf(""); return; }
-    t[i] = G.type == 0 ? (cull ? -1.0f : sphereIntersectionTest(G, ro, rd, P, N, o))
-         : ((i & 1) ? boxIntersectionTest<true>(G, ro, rd, P, N, o) : boxIntersectionTest<false>(G, ro, rd, P, N, o));
-    p3[3 * i] = P.x; p3[3 * i + 1] = P.y; p3[3 * i + 2] = P.z;
-    n3[3 * i] = N.x; n3[3 * i + 1] = N.y; n3[3 * i + 2] = N.z;
-    outside[i] = o ? 1 : 0;
-}
-// sphereCertainMiss soundness sweep: pseudo-random rays (origins up to ~60 units away, aimed near the sphere
-// so that grazing cases are dense) against every sphere of `geoms`; counts culled rays and VIOLATIONS
-// (culled although the full test returns a hit).
-__global__ void k_sweep_sphere_cull(const GeomDev *geoms, int ngeoms, unsigned long long seed, int per_thread,
-                                    unsigned long long *culled, unsigned long long *violations) {
-    unsigned long long x = seed + (blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ull;
-    unsigned int nc = 0, nv = 0;
-    for (int k = 0; k < per_thread; ++k) {
-        float u[8];
-        for (int j = 0; j < 8; ++j) {
-            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
-            u[j] = (float)(x >> 40) * (1.0f / 16777216.0f);
-        }
-        const GeomDev G = geoms[(blockIdx.x + k) % ngeoms];
-        if (G.type != 0) continue;
-        const F3 c = f3(G.centre[0], G.centre[1], G.centre[2]);
-        const float dist = __builtin_exp2f(u[0] * 12.0f - 6.0f);                 // 1/64 .. 64 units
-        const F3 od = normalize(f3(u[1] - 0.5f, u[2] - 0.5f, u[3] - 0.5f));
-        const F3 org = c + od * dist;
-        // aim at a point within ~1.3 bounding radii of the centre: hits, grazes and near misses
-        const float R = __builtin_sqrtf(G.cullR2 * 4.0f) * 0.5f;
-        const F3 tgt = c + f3(u[4] - 0.5f, u[5] - 0.5f, u[6] - 0.5f) * (2.6f * R);
-        F3 dir = normalize(tgt - org);
-        if (u[7] < 0.1f) dir = -dir;
-        if (sphereCertainMiss(G, org, dir, dot(dir, dir))) {
-            ++nc;
-            F3 P, N;
-            bool o;
-            if (sphereIntersectionTest(G, org, dir, P, N, o) != -1.0f) ++nv;
-        }
-    }
-    if (nc) atomicAdd(culled, (unsigned long long)nc);
-    if (nv) atomicAdd(violations, (unsigned long long)nv);
-}
-
-// slabQuotients vs the compiler's correctly rounded division; counts mismatching lanes
-__global__ void k_test_slab_quotients(const float *o, const float *d, int n, float *t1, float *t2, float *r1, float *r2) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    slabQuotients(o[i], d[i], t1[i], t2[i]);
-    r1[i] = (-0.5f - o[i]) / d[i];
-    r2[i] = (+0.5f - o[i]) / d[i];
-}
-// pseudo-random sweep entirely on the device: returns the number of bit mismatches (NaN == NaN)
-__global__ void k_sweep_slab_quotients(unsigned long long seed, int per_thread, unsigned long long *mismatches) {
-    unsigned long long x = seed + (blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ull;
-    unsigned int bad = 0;
-    for (int k = 0; k < per_thread; ++k) {
-        x ^= x << 13; x ^= x >> 7; x ^= x << 17;                     // xorshift64
-        const uint32_t ob = (uint32_t)x, db = (uint32_t)(x >> 32);
-        float o, d;
-        if ((k & 3) == 0) {            // raw bit patterns: every exponent, denormals, inf, NaN
-            o = __uint_as_float(ob); d = __uint_as_float(db);
-        } else {                       // the range the tracer lives in: |o| < ~4000, |d| <= 1
-            o = ((int)(ob >> 8) - (1 << 23)) * (1.0f / 2048.0f) * ((k & 4) ? 1.0f : 1e-3f);
-            d = __uint_as_float((db & 0x807fffffu) | ((uint32_t)(127 - (db >> 23 & 31)) << 23));
-            if ((k & 15) == 5) o = (ob & 1) ? 0.5f : -0.5f;           // numerator exactly +0
-        }
-        float t1, t2;
-        slabQuotients(o, d, t1, t2);
-        const float r1 = (-0.5f - o) / d, r2 = (+0.5f - o) / d;
-        const bool e1 = __float_as_uint(t1) == __float_as_uint(r1) || (t1 != t1 && r1 != r1);
-        const bool e2 = __float_as_uint(t2) == __float_as_uint(r2) || (t2 != t2 && r2 != r2);
-        bad += (e1 ? 0u : 1u) + (e2 ? 0u : 1u);
-    }
-    if (bad) atomicAdd(mismatches, (unsigned long long)bad);
-}
-__global__ void k_test_hemisphere(const float *nrm, const int *iid, int n, float *out) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Rng r = makeSeededRandomEngine(iid[3 * i], iid[3 * i + 1], iid[3 * i + 2]);
-    F3 d = calculateRandomDirectionInHemisphere(f3(nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2]), r);
-    out[3 * i] = d.x; out[3 * i + 1] = d.y; out[3 * i + 2] = d.z;
-}
-__global__ void k_test_sincos(const float *x, int n, float *s, float *c) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) sincosPoly(x[i], s[i], c[i]);
-}
-__global__ void k_test_reflect_refract(const float *I, const float *N, const float *eta, int n, float *rl, float *rr) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    F3 a = f3(I[3 * i], I[3 * i + 1], I[3 * i + 2]), b = f3(N[3 * i], N[3 * i + 1], N[3 * i + 2]);
-    F3 r1 = reflect(a, b), r2 = refract(a, b, eta[i]);
-    rl[3 * i] = r1.x; rl[3 * i + 1] = r1.y; rl[3 * i + 2] = r1.z;
-    rr[3 * i] = r2.x; rr[3 * i + 1] = r2.y; rr[3 * i + 2] = r2.z;
-}
 
 // =====================================================================================================
 // host side
@@ -727,7 +54,7 @@ int fail(int code, const char *fmt, ...) {
     do {                                                                                            \
         hipError_t e_ = (expr);                                                                     \
         if (e_ != hipSuccess)                                                                       \
-            return fail(PT_ERR_HIP, "HIP error (%s:%d): %s: %s", "pt_kernels.hip", __LINE__, #expr, \
+            return fail(PT_ERR_HIP, "HIP error (%s:%d): %s: %s", "pt_api.hip", __LINE__, #expr, \
                         hipGetErrorString(e_));                                                     \
     } while (0)
 

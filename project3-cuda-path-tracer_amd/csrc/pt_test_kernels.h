@@ -1,0 +1,126 @@
+// pt_test_kernels.h -- device primitives exposed one by one for the parity tests (include/pt_amd.h, pt_test_*):
+// the same __device__ functions the render kernels call.  Included by pt_api.hip only.
+#pragma once
+#include "pt_trace.h"
+
+namespace ptk {
+
+// ---- primitive test kernels (device functions exactly as the render kernels use them) -------------------
+__global__ void k_test_utilhash(const uint32_t *in, uint32_t *out, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = utilhash(in[i]);
+}
+__global__ void k_test_rng(const uint32_t *seeds, int nseeds, int ndraws, float *out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nseeds) return;
+    Rng r = seedEngine(seeds[i]);
+    for (int k = 0; k < ndraws; ++k) out[(size_t)i * ndraws + k] = u01(r);
+}
+__global__ void k_test_intersect(const GeomDev *geoms, const int *gidx, const float *rays, int n, float *t, float *p3,
+                                 float *n3, int *outside) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const GeomDev G = geoms[gidx[i]];
+    F3 ro = f3(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]);
+    F3 rd = f3(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
+    F3 P = f3(p3[3 * i], p3[3 * i + 1], p3[3 * i + 2]);
+    F3 N = f3(n3[3 * i], n3[3 * i + 1], n3[3 * i + 2]);
+    bool o = outside[i] != 0;
+    // odd lanes take the early-miss variant so both instantiations are checked against the golden vectors
+    // the certain-miss shortcut must agree with the full test on every golden vector
+    const bool cull = G.type == 0 && sphereCertainMiss(G, ro, rd, dot(rd, rd));
+    if (cull && sphereIntersectionTest(G, ro, rd, P, N, o) != -1.0f) { t[i] = __builtin_nanf(""); return; }
+    t[i] = G.type == 0 ? (cull ? -1.0f : sphereIntersectionTest(G, ro, rd, P, N, o))
+         : ((i & 1) ? boxIntersectionTest<true>(G, ro, rd, P, N, o) : boxIntersectionTest<false>(G, ro, rd, P, N, o));
+    p3[3 * i] = P.x; p3[3 * i + 1] = P.y; p3[3 * i + 2] = P.z;
+    n3[3 * i] = N.x; n3[3 * i + 1] = N.y; n3[3 * i + 2] = N.z;
+    outside[i] = o ? 1 : 0;
+}
+// sphereCertainMiss soundness sweep: pseudo-random rays (origins up to ~60 units away, aimed near the sphere
+// so that grazing cases are dense) against every sphere of `geoms`; counts culled rays and VIOLATIONS
+// (culled although the full test returns a hit).
+__global__ void k_sweep_sphere_cull(const GeomDev *geoms, int ngeoms, unsigned long long seed, int per_thread,
+                                    unsigned long long *culled, unsigned long long *violations) {
+    unsigned long long x = seed + (blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ull;
+    unsigned int nc = 0, nv = 0;
+    for (int k = 0; k < per_thread; ++k) {
+        float u[8];
+        for (int j = 0; j < 8; ++j) {
+            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+            u[j] = (float)(x >> 40) * (1.0f / 16777216.0f);
+        }
+        const GeomDev G = geoms[(blockIdx.x + k) % ngeoms];
+        if (G.type != 0) continue;
+        const F3 c = f3(G.centre[0], G.centre[1], G.centre[2]);
+        const float dist = __builtin_exp2f(u[0] * 12.0f - 6.0f);                 // 1/64 .. 64 units
+        const F3 od = normalize(f3(u[1] - 0.5f, u[2] - 0.5f, u[3] - 0.5f));
+        const F3 org = c + od * dist;
+        // aim at a point within ~1.3 bounding radii of the centre: hits, grazes and near misses
+        const float R = __builtin_sqrtf(G.cullR2 * 4.0f) * 0.5f;
+        const F3 tgt = c + f3(u[4] - 0.5f, u[5] - 0.5f, u[6] - 0.5f) * (2.6f * R);
+        F3 dir = normalize(tgt - org);
+        if (u[7] < 0.1f) dir = -dir;
+        if (sphereCertainMiss(G, org, dir, dot(dir, dir))) {
+            ++nc;
+            F3 P, N;
+            bool o;
+            if (sphereIntersectionTest(G, org, dir, P, N, o) != -1.0f) ++nv;
+        }
+    }
+    if (nc) atomicAdd(culled, (unsigned long long)nc);
+    if (nv) atomicAdd(violations, (unsigned long long)nv);
+}
+
+// slabQuotients vs the compiler's correctly rounded division; counts mismatching lanes
+__global__ void k_test_slab_quotients(const float *o, const float *d, int n, float *t1, float *t2, float *r1, float *r2) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    slabQuotients(o[i], d[i], t1[i], t2[i]);
+    r1[i] = (-0.5f - o[i]) / d[i];
+    r2[i] = (+0.5f - o[i]) / d[i];
+}
+// pseudo-random sweep entirely on the device: returns the number of bit mismatches (NaN == NaN)
+__global__ void k_sweep_slab_quotients(unsigned long long seed, int per_thread, unsigned long long *mismatches) {
+    unsigned long long x = seed + (blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ull;
+    unsigned int bad = 0;
+    for (int k = 0; k < per_thread; ++k) {
+        x ^= x << 13; x ^= x >> 7; x ^= x << 17;                     // xorshift64
+        const uint32_t ob = (uint32_t)x, db = (uint32_t)(x >> 32);
+        float o, d;
+        if ((k & 3) == 0) {            // raw bit patterns: every exponent, denormals, inf, NaN
+            o = __uint_as_float(ob); d = __uint_as_float(db);
+        } else {                       // the range the tracer lives in: |o| < ~4000, |d| <= 1
+            o = ((int)(ob >> 8) - (1 << 23)) * (1.0f / 2048.0f) * ((k & 4) ? 1.0f : 1e-3f);
+            d = __uint_as_float((db & 0x807fffffu) | ((uint32_t)(127 - (db >> 23 & 31)) << 23));
+            if ((k & 15) == 5) o = (ob & 1) ? 0.5f : -0.5f;           // numerator exactly +0
+        }
+        float t1, t2;
+        slabQuotients(o, d, t1, t2);
+        const float r1 = (-0.5f - o) / d, r2 = (+0.5f - o) / d;
+        const bool e1 = __float_as_uint(t1) == __float_as_uint(r1) || (t1 != t1 && r1 != r1);
+        const bool e2 = __float_as_uint(t2) == __float_as_uint(r2) || (t2 != t2 && r2 != r2);
+        bad += (e1 ? 0u : 1u) + (e2 ? 0u : 1u);
+    }
+    if (bad) atomicAdd(mismatches, (unsigned long long)bad);
+}
+__global__ void k_test_hemisphere(const float *nrm, const int *iid, int n, float *out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Rng r = makeSeededRandomEngine(iid[3 * i], iid[3 * i + 1], iid[3 * i + 2]);
+    F3 d = calculateRandomDirectionInHemisphere(f3(nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2]), r);
+    out[3 * i] = d.x; out[3 * i + 1] = d.y; out[3 * i + 2] = d.z;
+}
+__global__ void k_test_sincos(const float *x, int n, float *s, float *c) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) sincosPoly(x[i], s[i], c[i]);
+}
+__global__ void k_test_reflect_refract(const float *I, const float *N, const float *eta, int n, float *rl, float *rr) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    F3 a = f3(I[3 * i], I[3 * i + 1], I[3 * i + 2]), b = f3(N[3 * i], N[3 * i + 1], N[3 * i + 2]);
+    F3 r1 = reflect(a, b), r2 = refract(a, b, eta[i]);
+    rl[3 * i] = r1.x; rl[3 * i + 1] = r1.y; rl[3 * i + 2] = r1.z;
+    rr[3 * i] = r2.x; rr[3 * i + 1] = r2.y; rr[3 * i + 2] = r2.z;
+}
+
+}  // namespace ptk

@@ -1,0 +1,380 @@
+// pt_trace.h -- render kernels of the MI355X path tracer (gfx950): fused per-bounce kernel, ordered radiance
+// commit, PBO conversion, and the device-side control block / path-state layout they share.
+// Header-only part of the single translation unit pt_api.hip (namespace ptk).
+#pragma once
+#include "../../include/pt_amd.h"
+#include "pt_common.h"
+#include "pt_device.h"
+
+namespace ptk {
+using namespace ptd;
+
+constexpr int kNumArrays = 11;       // SoA PathSegment: origin3, dir3, throughput3, pixelIndex, remainingBounces
+constexpr int kMaxDepthSlots = PT_MAX_DEPTH + 2;
+
+// ---- device control block ------------------------------------------------------------------------
+constexpr int kOct = 8;              // direction octants: paths are binned by the signs of their new direction
+constexpr int kSub = 4;              // append-counter shards per octant (workgroup blockIdx % kSub)
+constexpr int kSeg = kOct * kSub;    // path buffers are split into kSeg segments with one append counter each
+constexpr int kCtrPad = 32;          // one counter per 128-byte line: same-line atomics serialise at the memory side
+
+struct Ctrl {
+    // seg_count[p][d][s][0] = paths in segment s entering bounce d of an iteration with parity p.
+    // The last bounce launch of an iteration zeroes the OTHER parity, i.e. re-arms the next iteration,
+    // so an iteration needs neither a memset nor a separate re-arm launch.
+    uint32_t seg_count[2][kMaxDepthSlots][kSeg][kCtrPad];
+    // never zeroed by an iteration
+    uint32_t error;                    // sticky device fault (scan-library look-back timeout)
+    uint32_t pad[kCtrPad - 1];
+    unsigned long long sum_live[kMaxDepthSlots];
+    unsigned long long light_hits[kOct][kCtrPad / 2], misses[kOct][kCtrPad / 2];
+};
+
+// Camera constants derived once on the host (spec S2)
+struct KParams {
+    float view[3], up[3], right[3], pos[3];
+    float pixLenX, pixLenY, halfW, halfH;
+    int   W, H;
+    int   shardRank, shardCount;
+    int   nLocal;       // pixels rendered by this shard
+    int   ngeoms, nmats;
+    int   traceDepth;
+    int   segCap;       // capacity (paths) of one segment of a path buffer, multiple of kBlock
+};
+
+// SoA PathSegment buffer: 11 arrays of `cap` = kSeg * segCap 4-byte elements, array k at base + k*cap
+// (0-2 origin, 3-5 direction, 6-8 throughput, 9 pixelIndex, 10 remainingBounces); inside every array
+// segment s owns [s*segCap, (s+1)*segCap) and is filled from its start.
+struct PathSoA {
+    float *base;
+    int    cap;
+    __host__ __device__ __forceinline__ float *a(int k) const { return base + (size_t)k * cap; }
+    __host__ __device__ __forceinline__ int *pix() const { return reinterpret_cast<int *>(base + (size_t)9 * cap); }
+    __host__ __device__ __forceinline__ int *rem() const { return reinterpret_cast<int *>(base + (size_t)10 * cap); }
+};
+
+// ---- camera ray of the j-th pixel of this shard (spec S2) ------------------------------------------
+__device__ __forceinline__ void cameraRay(const KParams &prm, int iter, int j, int &pix, F3 &org, F3 &dir) {
+    const int lr = j / prm.W;
+    const int x = j - lr * prm.W;
+    const int y = lr * prm.shardCount + prm.shardRank;
+    pix = x + y * prm.W;
+    Rng rng = makeSeededRandomEngine(iter, pix, 0);
+    const float jx = u01(rng);
+    const float jy = u01(rng);
+    const float sx = ((float)x + jx) - prm.halfW;
+    const float sy = ((float)y + jy) - prm.halfH;
+    const float a = prm.pixLenX * sx;
+    const float b = prm.pixLenY * sy;
+    const F3 view = f3(prm.view[0], prm.view[1], prm.view[2]);
+    const F3 up = f3(prm.up[0], prm.up[1], prm.up[2]);
+    const F3 right = f3(prm.right[0], prm.right[1], prm.right[2]);
+    org = f3(prm.pos[0], prm.pos[1], prm.pos[2]);
+    dir = normalize((view - right * a) - up * b);
+}
+
+// camera rays alone, for pt_debug_trace_paths(bounces = 0)
+__global__ __launch_bounds__(kBlock) void k_debug_camera_rays(KParams prm, int iter, float *o3, float *d3, int *pixOut) {
+    const int j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= prm.nLocal) return;
+    int pix;
+    F3 org, dir;
+    cameraRay(prm, iter, j, pix, org, dir);
+    o3[3 * j] = org.x; o3[3 * j + 1] = org.y; o3[3 * j + 2] = org.z;
+    d3[3 * j] = dir.x; d3[3 * j + 1] = dir.y; d3[3 * j + 2] = dir.z;
+    pixOut[j] = pix;
+}
+
+// ---- one bounce: intersect + shade + accumulate + compact (spec S3-S8) -----------------------------
+// Persistent workgroups walk the 256-path tiles of the bounce's queue (the kSeg input segments laid
+// end to end), blockIdx-strided.  Survivors are BINNED BY DIRECTION OCTANT while they are compacted:
+//   segment   = octant(new direction) * kSub + blockIdx % kSub,
+//   rank      = exclusive scan of the lane's octant flag inside the wave (ballot + mbcnt) plus the earlier
+//               waves' totals through LDS = workgroup-level exclusive scan per octant,
+//   base      = ONE atomicAdd per non-empty octant of the tile on that segment's counter (8 lanes, one
+//               instruction).
+// A tile of the next bounce therefore holds rays of a single direction octant, which turns the exact
+// early-miss of the box test (pt_device.h) into a wave-uniform branch for axis-aligned boxes.  Queue order
+// never influences results: RNG and accumulator are keyed on the pixel index.
+// No workgroup ever waits for another one, so there is no residency / dispatch-order assumption.
+// A segment receives survivors of the tiles of the workgroups with one value of blockIdx % kSub only,
+// i.e. at most ceil(tiles / kSub) * 256 <= segCap paths (see pt_init).
+//
+// FIRST = true is bounce 1 fused with camera-ray generation (spec S2): tile T holds the paths
+// j = 256 T + lane of this shard's pixel list and the ray is built in registers, so the first bounce
+// reads no path state at all.
+template <bool FIRST>
+__global__ __launch_bounds__(kBlock, 5) void k_bounce(KParams prm, int iter, int batch, int depth, int lastBounce, int parity,
+                                                   PathSoA in, PathSoA out, Ctrl *ctrl,
+                                                   const GeomDev *__restrict__ ggeoms,
+                                                   const MaterialDev *__restrict__ gmats, float *contrib) {
+    // LDS: the material table and the geom -> material map (indexed per lane by the nearest hit), and the
+    // compaction scratch.  Geometry itself is wave-uniform in the nearest-hit loop, so it is fetched through the
+    // scalar path (s_load into SGPRs, used directly as VALU operands): measured against an LDS-staged copy
+    // read back with ds_read_b128 broadcasts this is 5 % faster on Cornell (7 geoms) and 11 % on the 70-geom
+    // scene, and it frees ~40 VGPRs.
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    MaterialDev *smats = reinterpret_cast<MaterialDev *>(smem);
+    int *s_geomMat = reinterpret_cast<int *>(smem + sizeof(MaterialDev) * prm.nmats);
+    uint32_t *s_misc = reinterpret_cast<uint32_t *>(smem + sizeof(MaterialDev) * prm.nmats + sizeof(int) * ((prm.ngeoms + 3) & ~3));
+    uint32_t *s_wave = s_misc;                       // [kWaves][kOct] alive count per wave and octant
+    uint32_t *s_base = s_wave + kWaves * kOct;       // [kOct]   first output slot of this tile per octant
+    uint32_t *s_segcnt = s_base + kOct;              // [kSeg]   paths per input segment
+    uint32_t *s_segpre = s_segcnt + kSeg;            // [kSeg+2] tile prefix per input segment, [kSeg+1] = live paths
+
+    if (lastBounce) {   // re-arm the next iteration: nobody touches the other parity's counters now
+        uint32_t *other = &ctrl->seg_count[parity ^ 1][0][0][0];
+        const int nwords = (prm.traceDepth + 2) * kSeg * kCtrPad;
+        for (int i = blockIdx.x * kBlock + threadIdx.x; i < nwords; i += gridDim.x * kBlock) other[i] = 0u;
+    }
+    // input queue: segment s holds s_cnt[s] paths = tiles [s_pre[s], s_pre[s+1]) of the global tile index
+    uint32_t nLive, numTiles;
+    if (FIRST) {
+        nLive = (uint32_t)prm.nLocal * (uint32_t)batch;     // `batch` consecutive iterations share one wavefront
+        numTiles = (nLive + kBlock - 1) / kBlock;
+    } else {
+        if (threadIdx.x < 64) {          // wave 0: exclusive scan of the kSeg tile counts
+            const uint32_t c = threadIdx.x < kSeg ? ctrl->seg_count[parity][depth][threadIdx.x][0] : 0u;
+            const uint32_t t = (c + kBlock - 1) / kBlock;
+            uint32_t inc = t, sum = c;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t up = __shfl_up(inc, o, 64), us = __shfl_up(sum, o, 64);
+                if ((int)threadIdx.x >= o) { inc += up; sum += us; }
+            }
+            if (threadIdx.x < kSeg) { s_segcnt[threadIdx.x] = c; s_segpre[threadIdx.x + 1] = inc; }
+            if (threadIdx.x == 0) s_segpre[0] = 0;
+            if (threadIdx.x == 63) s_segpre[kSeg + 1] = sum;   // total live paths
+        }
+        __syncthreads();
+        numTiles = s_segpre[kSeg];
+        nLive = s_segpre[kSeg + 1];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctrl->sum_live[depth], (unsigned long long)nLive);
+    if (blockIdx.x >= numTiles) return;
+
+    // stage the materials in LDS once per (persistent) workgroup, 16 B per lane per step
+    {
+        const float4 *msrc = reinterpret_cast<const float4 *>(gmats);
+        float4 *mdst = reinterpret_cast<float4 *>(smats);
+        const int m16 = prm.nmats * (int)(sizeof(MaterialDev) / 16);
+        for (int i = threadIdx.x; i < m16; i += kBlock) mdst[i] = msrc[i];
+        for (int i = threadIdx.x; i < prm.ngeoms; i += kBlock) s_geomMat[i] = ggeoms[i].material;
+    }
+    __syncthreads();
+
+    uint32_t waveLight = 0, waveMiss = 0;   // wave-uniform tallies, flushed once at the end
+    uint32_t sgIn = 0;                      // input segment of the current tile (tiles are visited in increasing order)
+    for (uint32_t T = blockIdx.x; T < numTiles; T += gridDim.x) {
+        bool valid;
+        uint32_t idx = 0;
+        if (FIRST) {
+            idx = T * kBlock + threadIdx.x;                     // position in this shard's pixel list
+            valid = idx < nLive;
+        } else {
+            // global tile -> (segment, local tile)
+            while (T >= s_segpre[sgIn + 1]) ++sgIn;
+            const uint32_t local = (T - s_segpre[sgIn]) * kBlock + threadIdx.x;
+            valid = local < s_segcnt[sgIn];
+            idx = sgIn * (uint32_t)prm.segCap + local;
+        }
+
+        bool alive = false;
+        bool lightHit = false, missed = false;
+        F3 org = f3(0, 0, 0), dir = f3(0, 0, 1), col = f3(0, 0, 0);
+        int pix = 0, rem = 0;
+        int itb = 0;                                            // which iteration of the batch this path belongs to
+        if (valid) {
+            if (FIRST) {
+                itb = (int)(idx / (uint32_t)prm.nLocal);
+                cameraRay(prm, iter + itb, (int)(idx - (uint32_t)itb * (uint32_t)prm.nLocal), pix, org, dir);
+                col = f3(1.0f, 1.0f, 1.0f);
+                rem = prm.traceDepth;
+            } else {
+                org = f3(in.a(0)[idx], in.a(1)[idx], in.a(2)[idx]);
+                dir = f3(in.a(3)[idx], in.a(4)[idx], in.a(5)[idx]);
+                col = f3(in.a(6)[idx], in.a(7)[idx], in.a(8)[idx]);
+                pix = in.pix()[idx];
+                const int packed = in.rem()[idx];               // remainingBounces | batch index << 8
+                rem = packed & 0xff;
+                itb = packed >> 8;
+            }
+
+            // nearest hit, geoms in file order, strict '<' so the first geom wins ties (S3)
+            float tbest = 0.0f;
+            int hit = -1;
+            F3 P = f3(0, 0, 0), N = f3(0, 0, 0);
+            bool outside = false;
+            const float dd = dot(dir, dir);
+            for (int g = 0; g < prm.ngeoms; ++g) {
+                const GeomDev &G = ggeoms[g];
+                const int type = G.type;
+                F3 p, n;
+                bool o = false;
+                float t = -1.0f;
+                if (type == 0) {
+                    if (!sphereCertainMiss(G, org, dir, dd)) t = sphereIntersectionTest<FIRST>(G, org, dir, p, n, o);
+                } else {
+                    t = boxIntersectionTest<true, FIRST>(G, org, dir, p, n, o);
+                }
+                if (t > 0.0f && (hit < 0 || t < tbest)) {
+                    tbest = t; hit = g; P = p; N = n; outside = o;
+                }
+            }
+            if (hit < 0) {
+                missed = true;                                   // S4: background is black
+            } else {
+                const MaterialDev &M = smats[s_geomMat[hit]];
+                const F3 mcol = f3(M.color[0], M.color[1], M.color[2]);
+                if (M.emittance > 0.0f) {                        // S5: emitter ends the path
+                    lightHit = true;
+                    if (contrib) {
+                        // Deferred accumulation: iterations overlap on several streams, so the radiance
+                        // is parked in this iteration's own buffer (one path per pixel: race-free, no
+                        // read) and k_commit adds it to the accumulator in iteration order.
+                        const F3 c = (col * mcol) * M.emittance;
+                        float *px = contrib + 3 * ((size_t)itb * ((size_t)prm.W * prm.H) + (size_t)pix);
+                        px[0] = c.x; px[1] = c.y; px[2] = c.z;
+                    }
+                } else if (!lastBounce) {                        // S6 scatter (S7: skipped on the last bounce)
+                    Rng rng = makeSeededRandomEngine(iter + itb, pix, depth);
+                    const F3 scol = f3(M.specColor[0], M.specColor[1], M.specColor[2]);
+                    F3 ndir, norg;
+                    if (M.hasRefractive > 0.0f) {
+                        const float ior = M.ior;
+                        const float eta = outside ? 1.0f / ior : ior;
+                        const float c = dot(N, dir);
+                        const float k = 1.0f - eta * eta * (1.0f - c * c);
+                        const float u = u01(rng);
+                        bool doReflect = true;
+                        if (k >= 0.0f) {
+                            float r0 = (1.0f - ior) / (1.0f + ior);
+                            r0 = r0 * r0;
+                            const float cosx = outside ? -c : __builtin_sqrtf(k);
+                            const float w = 1.0f - cosx;
+                            const float w2 = w * w;
+                            const float w5 = w2 * w2 * w;
+                            const float fres = r0 + (1.0f - r0) * w5;
+                            doReflect = u < fres;
+                        }
+                        if (doReflect) {
+                            ndir = reflect(dir, N);
+                            norg = P + N * 0.001f;
+                            col = col * scol;
+                        } else {
+                            ndir = refract(dir, N, eta);
+                            norg = P - N * 0.001f;
+                            col = col * mcol;
+                        }
+                    } else if (M.hasReflective > 0.0f) {
+                        const float u = u01(rng);
+                        if (u < 0.5f) {
+                            ndir = reflect(dir, N);
+                            col = col * scol;
+                        } else {
+                            ndir = calculateRandomDirectionInHemisphere(N, rng);
+                            col = col * mcol;
+                        }
+                        norg = P + N * 0.001f;
+                    } else {
+                        ndir = calculateRandomDirectionInHemisphere(N, rng);
+                        col = col * mcol;
+                        norg = P + N * 0.001f;
+                    }
+                    org = norg;
+                    dir = ndir;
+                    alive = true;
+                }
+            }
+        }
+        waveLight += (uint32_t)__popcll(__ballot(lightHit));
+        waveMiss += (uint32_t)__popcll(__ballot(missed));
+
+        if (!lastBounce) {                                       // S8: compaction into `out`, binned by octant
+            const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+            const int oct = (dir.x < 0.0f ? 1 : 0) | (dir.y < 0.0f ? 2 : 0) | (dir.z < 0.0f ? 4 : 0);
+            uint32_t rank = 0, myCount = 0;
+#pragma unroll
+            for (int k = 0; k < kOct; ++k) {
+                const unsigned long long m = __ballot(alive && oct == k);
+                const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (oct == k) rank = r;
+                if (lane == k) myCount = (uint32_t)__popcll(m);
+            }
+            if (lane < kOct) s_wave[wave * kOct + lane] = myCount;
+            __syncthreads();
+            if (threadIdx.x < kOct) {
+                uint32_t total = 0;
+#pragma unroll
+                for (int w = 0; w < kWaves; ++w) total += s_wave[w * kOct + threadIdx.x];
+                const uint32_t oseg = threadIdx.x * kSub + (blockIdx.x % kSub);
+                s_base[threadIdx.x] = total ? atomicAdd(&ctrl->seg_count[parity][depth + 1][oseg][0], total) : 0u;
+            }
+            __syncthreads();
+            if (alive) {
+                uint32_t waveOff = 0;
+                for (int w = 0; w < wave; ++w) waveOff += s_wave[w * kOct + oct];
+                const uint32_t oseg = (uint32_t)oct * kSub + (blockIdx.x % kSub);
+                const uint32_t slot = oseg * (uint32_t)prm.segCap + s_base[oct] + waveOff + rank;
+                out.a(0)[slot] = org.x; out.a(1)[slot] = org.y; out.a(2)[slot] = org.z;
+                out.a(3)[slot] = dir.x; out.a(4)[slot] = dir.y; out.a(5)[slot] = dir.z;
+                out.a(6)[slot] = col.x; out.a(7)[slot] = col.y; out.a(8)[slot] = col.z;
+                out.pix()[slot] = pix;
+                out.rem()[slot] = (rem - 1) | (itb << 8);
+            }
+            __syncthreads();   // s_wave / s_base are rewritten by the next tile
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+        const int shard = blockIdx.x % kOct;
+        if (waveLight) atomicAdd(&ctrl->light_hits[shard][0], (unsigned long long)waveLight);
+        if (waveMiss) atomicAdd(&ctrl->misses[shard][0], (unsigned long long)waveMiss);
+    }
+}
+
+// ---- commit one iteration's radiance: image[pix] += contrib[pix]; contrib[pix] = 0 -------------------
+// Runs on the caller's stream, one launch per iteration in iteration order, so every pixel receives its
+// samples in exactly the order a sequential renderer adds them (fp32 addition is not associative).
+// Skipping an all-zero contribution equals adding +0 (the accumulator is never -0).
+// `compactRows`: the accumulator holds only this shard's rows (PT_FLAG_ACCUM_SHARD_ROWS), pixel j of the shard
+// at image[3j]; otherwise it is the full frame indexed by the global pixel index.
+// `batch` iterations were traced together; their radiance buffers are consumed in iteration order.
+__global__ __launch_bounds__(kBlock) void k_commit(KParams prm, float *image, float *contrib, int batch, int compactRows) {
+    const int j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= prm.nLocal) return;
+    const int lr = j / prm.W;
+    const int x = j - lr * prm.W;
+    const size_t pix = (size_t)x + (size_t)(lr * prm.shardCount + prm.shardRank) * prm.W;
+    const size_t frame = (size_t)prm.W * prm.H;
+    float *px = image + 3 * (compactRows ? (size_t)j : pix);
+    float ax = px[0], ay = px[1], az = px[2];
+    bool dirty = false;
+    for (int b = 0; b < batch; ++b) {
+        float *c = contrib + 3 * ((size_t)b * frame + pix);
+        const float cx = c[0], cy = c[1], cz = c[2];
+        if (cx != 0.0f || cy != 0.0f || cz != 0.0f) {
+            ax += cx; ay += cy; az += cz;
+            c[0] = 0.0f; c[1] = 0.0f; c[2] = 0.0f;
+            dirty = true;
+        }
+    }
+    if (dirty) { px[0] = ax; px[1] = ay; px[2] = az; }
+}
+
+// ---- sendImageToPBO (reference src/pathtrace.cu:48-68) ---------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_to_rgba8(const float *image, int npix, int iter, uchar4 *pbo) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= npix) return;
+    const float *p = image + 3 * (size_t)i;
+    int r = (int)(p[0] / iter * 255.0);
+    int g = (int)(p[1] / iter * 255.0);
+    int b = (int)(p[2] / iter * 255.0);
+    r = r < 0 ? 0 : (r > 255 ? 255 : r);   // glm::clamp = min(max(x, lo), hi), func_common.inl:451-456
+    g = g < 0 ? 0 : (g > 255 ? 255 : g);
+    b = b < 0 ? 0 : (b > 255 ? 255 : b);
+    uchar4 o;
+    o.w = 0; o.x = (unsigned char)r; o.y = (unsigned char)g; o.z = (unsigned char)b;
+    pbo[i] = o;
+}
+
+}  // namespace ptk

@@ -37,4 +37,15 @@ int pth_save_png(const char *basename, const float *rgb_sum, int w, int h, float
     return img.savePNG(basename) ? 0 : -1;
 }
 
+// same image as pth_save_png, written as Radiance .hdr (reference image::saveHDR, src/image.cpp:41-45)
+int pth_save_hdr(const char *basename, const float *rgb_sum, int w, int h, float samples) {
+    image img(w, h);
+    for (int x = 0; x < w; x++)
+        for (int y = 0; y < h; y++) {
+            const float *p = rgb_sum + 3 * ((size_t)x + (size_t)y * w);
+            img.setPixel(w - 1 - x, y, lin::vec3(p[0], p[1], p[2]) / samples);
+        }
+    return img.saveHDR(basename) ? 0 : -1;
+}
+
 }  // extern "C"

@@ -5,6 +5,7 @@
 
 #include <cassert>
 #include <cstdint>
+#include <cmath>
 #include <cstdio>
 #include <iostream>
 
@@ -96,5 +97,35 @@ bool image::savePNG(const std::string &baseFilename) {
     const bool ok = fwrite(png.data(), 1, png.size(), f) == png.size();
     fclose(f);
     if (ok) std::cout << "Saved " << filename << "." << std::endl;
+    return ok;
+}
+
+bool image::saveHDR(const std::string &baseFilename) {
+    const std::string filename = baseFilename + ".hdr";
+    FILE *f = fopen(filename.c_str(), "wb");
+    if (!f) return false;
+    fprintf(f, "#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n", ySize, xSize);
+    std::vector<unsigned char> row((size_t)4 * xSize);
+    bool ok = true;
+    for (int y = 0; y < ySize && ok; ++y) {
+        for (int x = 0; x < xSize; ++x) {
+            const lin::vec3 &p = pixels[(size_t)y * xSize + x];
+            const float m = std::fmax(p.x, std::fmax(p.y, p.z));
+            unsigned char *o = &row[(size_t)4 * x];
+            if (!(m >= 1e-32f)) {
+                o[0] = o[1] = o[2] = o[3] = 0;
+            } else {                     // shared exponent: value = mantissa/256 * 2^(e-128)
+                int e;
+                const float scale = std::frexp(m, &e) * 256.0f / m;
+                o[0] = (unsigned char)(p.x * scale);
+                o[1] = (unsigned char)(p.y * scale);
+                o[2] = (unsigned char)(p.z * scale);
+                o[3] = (unsigned char)(e + 128);
+            }
+        }
+        ok = fwrite(row.data(), 1, row.size(), f) == row.size();
+    }
+    fclose(f);
+    if (ok) std::cout << "Saved " + filename + "." << std::endl;
     return ok;
 }

@@ -3,7 +3,7 @@
 // iteration passed to pathtrace(pbo, 0, iteration), save + Free when the sample count is reached,
 // output name <FILE>.<start time>.<N>samp.png, X mirrored, divided by the sample count.
 //
-//   pt_render SCENEFILE.txt [--res W H] [--iterations N] [--depth D] [--out BASENAME]
+//   pt_render SCENEFILE.txt [--res W H] [--iterations N] [--depth D] [--out BASENAME] [--hdr]
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -19,6 +19,7 @@ static RenderState *renderState;
 static int iteration;
 static int width, height;
 static std::string outBase;
+static bool writeHdr = false;
 
 static std::string currentTimeString() {
     time_t now;
@@ -42,6 +43,7 @@ static void saveImage() {
     if (outBase.empty()) ss << renderState->imageName << "." << startTimeString << "." << samples << "samp";
     else ss << outBase;
     img.savePNG(ss.str());
+    if (writeHdr) img.saveHDR(ss.str());   // the reference keeps this behind a comment, src/main.cpp:69
 }
 
 // one trip through the reference's per-frame function; returns false when rendering is complete
@@ -63,7 +65,7 @@ static bool runHip() {
 int main(int argc, char **argv) {
     startTimeString = currentTimeString();
     if (argc < 2) {
-        printf("Usage: %s SCENEFILE.txt [--res W H] [--iterations N] [--depth D] [--out BASENAME]\n", argv[0]);
+        printf("Usage: %s SCENEFILE.txt [--res W H] [--iterations N] [--depth D] [--out BASENAME] [--hdr]\n", argv[0]);
         return 1;
     }
     scene = new Scene(argv[1], true);
@@ -73,6 +75,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--iterations") && i + 1 < argc) renderState->iterations = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--depth") && i + 1 < argc) renderState->traceDepth = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--out") && i + 1 < argc) outBase = argv[++i];
+        else if (!strcmp(argv[i], "--hdr")) writeHdr = true;
         else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 1; }
     }
     iteration = 0;

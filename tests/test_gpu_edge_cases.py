@@ -157,3 +157,26 @@ def test_large_frame_properties(gpu):
     gpu.pathtraceFree()
     assert np.array_equal(acc.view(np.uint32), full.view(np.uint32))
     assert np.isfinite(full).all() and full.min() >= 0
+
+
+def test_headless_driver_renders_the_reference_protocol(gpu, oracle, tmp_path):
+    # pt_render = main()/runCuda()/saveImage() of the reference (src/main.cpp:21-113) over the C++ shim:
+    # Free -> Init at iteration 0, 1-based iterations with a D2H copy each, save at the end (X mirror, /samples)
+    import subprocess
+    from test_host import _decode_png
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "project3-cuda-path-tracer_amd", "host", "pt_render")
+    base = str(tmp_path / "render")
+    r = subprocess.run([exe, os.path.join(SCENES, "cornell.txt"), "--res", "96", "64", "--iterations", "5", "--depth", "8",
+                        "--out", base, "--hdr"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = _decode_png(base + ".png")
+    sc = oracle.Scene(os.path.join(SCENES, "cornell.txt"))
+    sc.set_resolution(96, 64)
+    ref = oracle.Renderer(sc.camera, sc.geoms, sc.materials, 8)
+    img = np.zeros(96 * 64 * 3, np.float32)
+    for it in range(1, 6):
+        ref.iterate(it, img)
+    want = (np.clip(img.reshape(64, 96, 3) / np.float32(5), 0, 1) * np.float32(255)).astype(np.uint8)[:, ::-1]
+    assert np.array_equal(got, want)
+    assert os.path.getsize(base + ".hdr") > 4 * 96 * 64

@@ -122,6 +122,26 @@ def test_save_png_semantics(pt, tmp_path):
     assert np.array_equal(got, want)
 
 
+def test_save_hdr_round_trip(pt, tmp_path):
+    # Radiance RGBE: shared exponent, 8-bit mantissas -> relative error below 1/128 of the brightest channel
+    w, h, samples = 7, 4, 2
+    rng = np.random.default_rng(2)
+    img = (rng.random((h, w, 3)) * np.array([0.01, 5.0, 300.0])).astype(np.float32)
+    img[0, 0] = 0
+    base = str(tmp_path / "out")
+    pt.save_hdr(base, img, samples)
+    data = open(base + ".hdr", "rb").read()
+    head, _, body = data.partition(b"\n\n")
+    assert head.startswith(b"#?RADIANCE") and b"FORMAT=32-bit_rle_rgbe" in head
+    dims, _, px = body.partition(b"\n")
+    assert dims == b"-Y %d +X %d" % (h, w) and len(px) == 4 * w * h
+    rgbe = np.frombuffer(px, np.uint8).reshape(h, w, 4).astype(np.float64)
+    dec = rgbe[:, :, :3] / 256.0 * np.exp2(rgbe[:, :, 3:4] - 128.0) * (rgbe[:, :, 3:4] > 0)
+    want = (img / np.float32(samples))[:, ::-1].astype(np.float64)      # X mirror like the PNG path
+    tol = want.max(axis=2, keepdims=True) / 128.0 + 1e-30
+    assert np.all(np.abs(dec - want) <= tol)
+
+
 def test_headless_driver_without_gpu_reports_and_exits_nonzero(pt, tmp_path):
     if pt.device_count() > 0:
         pytest.skip("GPU present")
