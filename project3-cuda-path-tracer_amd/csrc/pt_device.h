@@ -167,12 +167,6 @@ __device__ __forceinline__ F3 getPointOnRay(F3 origin, F3 direction, float t) {
     return origin + normalize(direction) * (t - .0001f);
 }
 
-struct Hit {
-    float t;        // world-space distance, -1 on a miss
-    F3    p, n;     // written only on a hit (reference leaves its out-parameters untouched on a miss)
-    bool  outside;
-};
-
 // ---- the two slab quotients of one axis: t1 = (-.5 - o) / d, t2 = (+.5 - o) / d ---------------------
 // Correctly rounded fp32 division is ~11 VALU instructions on gfx950 (v_div_scale x2, v_rcp, 4 fma, mul,
 // v_div_fmas, v_div_fixup) and hipcc does not share anything between two quotients of one divisor.

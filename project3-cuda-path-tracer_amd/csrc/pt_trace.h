@@ -43,7 +43,7 @@ struct KParams {
 };
 
 // SoA PathSegment buffer: 11 arrays of `cap` = kSeg * segCap 4-byte elements, array k at base + k*cap
-// (0-2 origin, 3-5 direction, 6-8 throughput, 9 pixelIndex, 10 remainingBounces); inside every array
+// (0-2 origin, 3-5 direction, 6-8 throughput, 9 pixelIndex, 10 remainingBounces | batch index << 8); inside every array
 // segment s owns [s*segCap, (s+1)*segCap) and is filled from its start.
 struct PathSoA {
     float *base;

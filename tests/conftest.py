@@ -16,14 +16,20 @@ def pytest_configure(config):
 
 
 @pytest.fixture(scope="session")
-def oracle():
+def built():
+    """Incremental `make` of every native piece (no-op when the shipped .so files are current)."""
+    import __graft_entry__ as ge
+    return ge.build()
+
+
+@pytest.fixture(scope="session")
+def oracle(built):
     import oracle as orc  # oracle/oracle.py (test infrastructure)
     orc.lib()
     return orc
 
 
 @pytest.fixture(scope="session")
-def pt():
+def pt(built):
     """The product: ctypes binding over the C-ABI (include/pt_amd.h)."""
-    import __graft_entry__ as ge
-    return ge.load_package()
+    return built
