@@ -112,7 +112,10 @@ def main():
         frame, bufs, shard_flag = None, None, 0
     stream = torch.cuda.current_stream()
 
-    B = max(1, min(args.batch, 16))
+    # path buffers grow with the batch (44 B x 8 octant-worst-case x 2 ping-pong x 3 slots per path): keep them
+    # under ~48 GB, i.e. batch 8 up to 1080p frames and batch 1 for a 4096x4096 frame on one GPU
+    n_local = ptdist.local_pixel_count(W, H, rank, world)
+    B = max(1, min(args.batch, 16, int(48e9 // (max(n_local, 1) * 44 * 8 * 2 * 3))))
 
     def init(flags, pipeline):
         pt.pathtraceFree()
