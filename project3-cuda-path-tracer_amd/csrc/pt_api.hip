@@ -93,6 +93,10 @@ struct State {
     size_t ldsBytes = 0;
     long long iterations = 0;
     long long seq = 0;      // iterations enqueued since pt_init: slot = seq % nslots
+    // host buffer of pt_readback, page-locked on first use so the per-iteration D2H copy of the reference protocol
+    // (src/pathtrace.cu:170-171) runs at PCIe rate instead of through a pageable staging copy
+    void *pinnedHost = nullptr;
+    size_t pinnedBytes = 0;
     // kernel timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> evBounce;
     double msBounce = 0;
@@ -310,6 +314,7 @@ void pt_free(void) {
         if (sl.evCommitted) (void)hipEventDestroy(sl.evCommitted);
         if (sl.stream) (void)hipStreamDestroy(sl.stream);
     }
+    if (S.pinnedHost) (void)hipHostUnregister(S.pinnedHost);
     if (S.ownImage && S.image) (void)hipFree(S.image);
     if (S.dgeoms) (void)hipFree(S.dgeoms);
     if (S.dmats) (void)hipFree(S.dmats);
@@ -488,7 +493,18 @@ int pt_readback(float *rgb_sum_host) {
                    rowFloats * sizeof(float));
         return PT_OK;
     }
-    HIPCHECK(hipMemcpyAsync(rgb_sum_host, S.image, (size_t)S.P * 3 * sizeof(float), hipMemcpyDeviceToHost, S.stream));
+    const size_t bytes = (size_t)S.P * 3 * sizeof(float);
+    if (S.pinnedHost != rgb_sum_host || S.pinnedBytes != bytes) {
+        if (S.pinnedHost) (void)hipHostUnregister(S.pinnedHost);
+        S.pinnedHost = nullptr;
+        if (hipHostRegister(rgb_sum_host, bytes, hipHostRegisterDefault) == hipSuccess) {
+            S.pinnedHost = rgb_sum_host;
+            S.pinnedBytes = bytes;
+        } else {
+            (void)hipGetLastError();   // not fatal: fall back to a pageable copy
+        }
+    }
+    HIPCHECK(hipMemcpyAsync(rgb_sum_host, S.image, bytes, hipMemcpyDeviceToHost, S.stream));
     HIPCHECK(hipStreamSynchronize(S.stream));
     return PT_OK;
 }
