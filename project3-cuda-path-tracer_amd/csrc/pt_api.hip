@@ -418,7 +418,7 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     HIPCHECK(hipMemcpy(S.dgeoms, hg.data(), hg.size() * sizeof(GeomDev), hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(S.dmats, hm.data(), hm.size() * sizeof(MaterialDev), hipMemcpyHostToDevice));
 
-    S.ldsBytes = sizeof(MaterialDev) * nmats + sizeof(int) * ((ngeoms + 3) & ~3) +
+    S.ldsBytes = sizeof(MaterialDev) * nmats + sizeof(GeomHitDev) * ngeoms +
                  (kWaves * kOct + kOct + kSeg + kSeg + 2 + 2) * sizeof(uint32_t);
     if (S.ldsBytes > 160 * 1024) return fail(PT_ERR_INVALID, "pt_init: scene does not fit the 160 KiB LDS (%zu B)", S.ldsBytes);
     if (S.ldsBytes > 64 * 1024) {

@@ -212,7 +212,7 @@ __device__ __forceinline__ void slabQuotients(float o, float d, float &t1, float
 // rays (EARLY_MISS is set for the camera-ray bounce); results are identical either way.
 // CAM_ORIGIN: the ray starts at the camera, whose object-space position is precomputed (GeomDev::camObj).
 template <bool EARLY_MISS, bool CAM_ORIGIN = false>
-__device__ __forceinline__ float boxIntersectionTest(const GeomDev &g, F3 ro, F3 rd, F3 &P, F3 &N, bool &outside) {
+__device__ __forceinline__ float boxIntersectionTest(const GeomDev &g, F3 ro, F3 rd, F3 &P, F3 &nsrc, bool &outside) {
     const F3 qo = CAM_ORIGIN ? f3(g.camObj[0], g.camObj[1], g.camObj[2]) : mulMV(g.inv, ro, 1.0f);
     const F3 qdu = mulMV(g.inv, rd, 0.0f);
     if (EARLY_MISS) {
@@ -257,7 +257,7 @@ __device__ __forceinline__ float boxIntersectionTest(const GeomDev &g, F3 ro, F3
         const F3 tmin_n = f3(tmin_axis == 0 ? tmin_nv : 0.0f, tmin_axis == 1 ? tmin_nv : 0.0f,
                              tmin_axis == 2 ? tmin_nv : 0.0f);
         P = mulMV(g.xf, getPointOnRay(qo, qd, tmin), 1.0f);
-        N = normalize(mulMV(g.xf, tmin_n, 0.0f));
+        nsrc = tmin_n;   // normal = normalize(transform * (tmin_n, 0)): hitNormal(), evaluated for the nearest hit only
         return length(ro - P);
     }
     return -1.0f;
@@ -282,7 +282,7 @@ __device__ __forceinline__ bool sphereCertainMiss(const GeomDev &g, F3 org, F3 d
 
 // src/intersections.h:101-143 (pow(radius, 2) == 0.25f in the float overload nvcc selects)
 template <bool CAM_ORIGIN = false>
-__device__ __forceinline__ float sphereIntersectionTest(const GeomDev &g, F3 ro_w, F3 rd_w, F3 &P, F3 &N,
+__device__ __forceinline__ float sphereIntersectionTest(const GeomDev &g, F3 ro_w, F3 rd_w, F3 &P, F3 &nsrc,
                                                         bool &outside) {
     F3 ro = CAM_ORIGIN ? f3(g.camObj[0], g.camObj[1], g.camObj[2]) : mulMV(g.inv, ro_w, 1.0f);
     F3 rd = normalize(mulMV(g.inv, rd_w, 0.0f));
@@ -305,10 +305,31 @@ __device__ __forceinline__ float sphereIntersectionTest(const GeomDev &g, F3 ro_
     }
     F3 obj = getPointOnRay(ro, rd, t);
     P = mulMV(g.xf, obj, 1.0f);
-    N = normalize(mulMV(g.invT, obj, 0.0f));
-    if (!outside) N = -N;
+    nsrc = obj;      // normal = +-normalize(invTranspose * (obj, 0)): hitNormal(), evaluated for the nearest hit only
     return length(ro_w - P);
 }
+
+// The surface normal of a hit, from what the two tests leave in `nsrc` (src/intersections.h:85 and :137-140).
+// The reference computes it for every primitive a ray hits; only the nearest hit's normal is ever used, so the
+// kernels evaluate it once, after the nearest-hit loop -- same inputs, same operations, same bits.
+// `m` = rows 0-2 of invTranspose (sphere) or transform (cube), as mulMV expects them.
+__device__ __forceinline__ F3 hitNormal(const float *m, bool sphere, F3 nsrc, bool outside) {
+    const F3 n = normalize(mulMV(m, nsrc, 0.0f));
+    return (sphere && !outside) ? -n : n;
+}
+__device__ __forceinline__ F3 hitNormal(const GeomDev &g, F3 nsrc, bool outside) {
+    return hitNormal(g.type == 0 ? g.invT : g.xf, g.type == 0, nsrc, outside);
+}
+
+// Per-geom record staged in LDS for the per-lane lookups that follow the nearest-hit loop: the matrix of the normal
+// (12 floats), the material index and the type; 64 B, read with ds_read_b128.
+struct GeomHitDev {
+    float nm[12];
+    int   material;
+    int   type;
+    int   pad0, pad1;
+};
+static_assert(sizeof(GeomHitDev) == 64, "GeomHitDev is 4 x 16 B");
 
 // src/interactions.h:10-42
 __device__ __forceinline__ F3 calculateRandomDirectionInHemisphere(F3 normal, Rng &rng) {

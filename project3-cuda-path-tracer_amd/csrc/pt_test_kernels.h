@@ -28,10 +28,12 @@ __global__ void k_test_intersect(const GeomDev *geoms, const int *gidx, const fl
     bool o = outside[i] != 0;
     // odd lanes take the early-miss variant so both instantiations are checked against the golden vectors
     // the certain-miss shortcut must agree with the full test on every golden vector
+    F3 nsrc = f3(0, 0, 0);
     const bool cull = G.type == 0 && sphereCertainMiss(G, ro, rd, dot(rd, rd));
-    if (cull && sphereIntersectionTest(G, ro, rd, P, N, o) != -1.0f) { t[i] = __builtin_nanf(""); return; }
-    t[i] = G.type == 0 ? (cull ? -1.0f : sphereIntersectionTest(G, ro, rd, P, N, o))
-         : ((i & 1) ? boxIntersectionTest<true>(G, ro, rd, P, N, o) : boxIntersectionTest<false>(G, ro, rd, P, N, o));
+    if (cull && sphereIntersectionTest(G, ro, rd, P, nsrc, o) != -1.0f) { t[i] = __builtin_nanf(""); return; }
+    t[i] = G.type == 0 ? (cull ? -1.0f : sphereIntersectionTest(G, ro, rd, P, nsrc, o))
+         : ((i & 1) ? boxIntersectionTest<true>(G, ro, rd, P, nsrc, o) : boxIntersectionTest<false>(G, ro, rd, P, nsrc, o));
+    if (t[i] != -1.0f) N = hitNormal(G, nsrc, o);   // the normal is an output of the reference's tests: same values here
     p3[3 * i] = P.x; p3[3 * i + 1] = P.y; p3[3 * i + 2] = P.z;
     n3[3 * i] = N.x; n3[3 * i + 1] = N.y; n3[3 * i + 2] = N.z;
     outside[i] = o ? 1 : 0;
@@ -64,7 +66,7 @@ __global__ void k_sweep_sphere_cull(const GeomDev *geoms, int ngeoms, unsigned l
             ++nc;
             F3 P, N;
             bool o;
-            if (sphereIntersectionTest(G, org, dir, P, N, o) != -1.0f) ++nv;
+            if (sphereIntersectionTest(G, org, dir, P, N, o) != -1.0f) ++nv;   // (N receives the normal source here)
         }
     }
     if (nc) atomicAdd(culled, (unsigned long long)nc);

@@ -108,15 +108,15 @@ __global__ __launch_bounds__(kBlock, 5) void k_bounce(KParams prm, int iter, int
                                                    PathSoA in, PathSoA out, Ctrl *ctrl,
                                                    const GeomDev *__restrict__ ggeoms,
                                                    const MaterialDev *__restrict__ gmats, float *contrib) {
-    // LDS: the material table and the geom -> material map (indexed per lane by the nearest hit), and the
-    // compaction scratch.  Geometry itself is wave-uniform in the nearest-hit loop, so it is fetched through the
+    // LDS: the material table and the per-geom hit records (normal matrix, material, type: indexed per lane by
+    // the nearest hit), and the compaction scratch.  Geometry itself is wave-uniform in the nearest-hit loop, so it is fetched through the
     // scalar path (s_load into SGPRs, used directly as VALU operands): measured against an LDS-staged copy
     // read back with ds_read_b128 broadcasts this is 5 % faster on Cornell (7 geoms) and 11 % on the 70-geom
     // scene, and it frees ~40 VGPRs.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     MaterialDev *smats = reinterpret_cast<MaterialDev *>(smem);
-    int *s_geomMat = reinterpret_cast<int *>(smem + sizeof(MaterialDev) * prm.nmats);
-    uint32_t *s_misc = reinterpret_cast<uint32_t *>(smem + sizeof(MaterialDev) * prm.nmats + sizeof(int) * ((prm.ngeoms + 3) & ~3));
+    GeomHitDev *s_geomHit = reinterpret_cast<GeomHitDev *>(smem + sizeof(MaterialDev) * prm.nmats);
+    uint32_t *s_misc = reinterpret_cast<uint32_t *>(smem + sizeof(MaterialDev) * prm.nmats + sizeof(GeomHitDev) * prm.ngeoms);
     uint32_t *s_wave = s_misc;                       // [kWaves][kOct] alive count per wave and octant
     uint32_t *s_base = s_wave + kWaves * kOct;       // [kOct]   first output slot of this tile per octant
     uint32_t *s_segcnt = s_base + kOct;              // [kSeg]   paths per input segment
@@ -159,7 +159,15 @@ __global__ __launch_bounds__(kBlock, 5) void k_bounce(KParams prm, int iter, int
         float4 *mdst = reinterpret_cast<float4 *>(smats);
         const int m16 = prm.nmats * (int)(sizeof(MaterialDev) / 16);
         for (int i = threadIdx.x; i < m16; i += kBlock) mdst[i] = msrc[i];
-        for (int i = threadIdx.x; i < prm.ngeoms; i += kBlock) s_geomMat[i] = ggeoms[i].material;
+        for (int i = threadIdx.x; i < prm.ngeoms * 16; i += kBlock) {   // 16 dwords per GeomHitDev
+            const int g = i >> 4, k = i & 15;
+            const GeomDev &G = ggeoms[g];
+            uint32_t v = 0;
+            if (k < 12) v = __float_as_uint(G.type == 0 ? G.invT[k] : G.xf[k]);
+            else if (k == 12) v = (uint32_t)G.material;
+            else if (k == 13) v = (uint32_t)G.type;
+            reinterpret_cast<uint32_t *>(s_geomHit)[i] = v;
+        }
     }
     __syncthreads();
 
@@ -203,7 +211,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_bounce(KParams prm, int iter, int
             // nearest hit, geoms in file order, strict '<' so the first geom wins ties (S3)
             float tbest = 0.0f;
             int hit = -1;
-            F3 P = f3(0, 0, 0), N = f3(0, 0, 0);
+            F3 P = f3(0, 0, 0), nsrc = f3(0, 0, 0);
             bool outside = false;
             const float dd = dot(dir, dir);
             for (int g = 0; g < prm.ngeoms; ++g) {
@@ -218,13 +226,15 @@ __global__ __launch_bounds__(kBlock, 5) void k_bounce(KParams prm, int iter, int
                     t = boxIntersectionTest<true, FIRST>(G, org, dir, p, n, o);
                 }
                 if (t > 0.0f && (hit < 0 || t < tbest)) {
-                    tbest = t; hit = g; P = p; N = n; outside = o;
+                    tbest = t; hit = g; P = p; nsrc = n; outside = o;
                 }
             }
             if (hit < 0) {
                 missed = true;                                   // S4: background is black
             } else {
-                const MaterialDev &M = smats[s_geomMat[hit]];
+                const GeomHitDev &GH = s_geomHit[hit];               // per-lane geom: LDS lookup
+                const F3 N = hitNormal(GH.nm, GH.type == 0, nsrc, outside);
+                const MaterialDev &M = smats[GH.material];
                 const F3 mcol = f3(M.color[0], M.color[1], M.color[2]);
                 if (M.emittance > 0.0f) {                        // S5: emitter ends the path
                     lightHit = true;
