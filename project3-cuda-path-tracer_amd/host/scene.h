@@ -9,10 +9,10 @@
 
 class Scene {
 private:
-    std::ifstream fp_in;
-    int loadMaterial(std::string materialid);
-    int loadGeom(std::string objectid);
-    int loadCamera();
+    std::ifstream fp_in;                          // the scene file while it is being parsed
+    int loadMaterial(std::string materialid);     // MATERIAL block: exactly 7 keyword lines
+    int loadGeom(std::string objectid);           // OBJECT block: type, material, TRANS/ROTAT/SCALE up to a blank line
+    int loadCamera();                             // CAMERA block: 5 keyword lines + EYE/VIEW/UP up to a blank line
     bool verbose;
 
 public:
@@ -24,7 +24,7 @@ public:
     // RES override used by the headless driver; recomputes fov.x like src/scene.cpp:133-136
     void setResolution(int w, int h);
 
-    std::vector<Geom> geoms;
-    std::vector<Material> materials;
-    RenderState state;
+    std::vector<Geom> geoms;            // in file order = intersection order (first geom wins distance ties)
+    std::vector<Material> materials;    // indexed by Geom::materialid
+    RenderState state;                  // camera, iteration count, depth, output name, host image
 };
