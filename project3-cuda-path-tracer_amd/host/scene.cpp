@@ -32,7 +32,7 @@ void deriveFov(Camera &camera, float fovy) {
 }  // namespace
 
 Scene::Scene(std::string filename, bool verbose_) : verbose(verbose_) {
-    if (verbose) std::cout << "Reading scene from " << filename << " ..." << std::endl;
+    if (verbose) std::cout << "Reading scene from " << filename << " ..." << std::endl << " " << std::endl;
     state.iterations = 0;
     state.traceDepth = 0;
     state.camera.resolution.x = state.camera.resolution.y = 0;
@@ -47,9 +47,12 @@ Scene::Scene(std::string filename, bool verbose_) : verbose(verbose_) {
         safeGetline(fp_in, line);
         if (line.empty()) continue;
         const Tokens tokens = tokenizeString(line);
+        bool block = true;
         if (tokens.size() >= 2 && key(tokens, "MATERIAL")) loadMaterial(tokens[1]);
         else if (tokens.size() >= 2 && key(tokens, "OBJECT")) loadGeom(tokens[1]);
         else if (key(tokens, "CAMERA")) loadCamera();
+        else block = false;
+        if (block && verbose) std::cout << " " << std::endl;
     }
 }
 
@@ -60,6 +63,7 @@ int Scene::loadMaterial(std::string materialid) {
         std::cout << "ERROR: MATERIAL ID does not match expected number of materials" << std::endl;
         return -1;
     }
+    if (verbose) std::cout << "Loading Material " << materials.size() << "..." << std::endl;
     Material m;
     m.specular.exponent = m.hasReflective = m.hasRefractive = m.indexOfRefraction = m.emittance = 0.0f;
     std::string line;
@@ -79,6 +83,7 @@ int Scene::loadMaterial(std::string materialid) {
 }
 
 int Scene::loadCamera() {
+    if (verbose) std::cout << "Loading Camera ..." << std::endl;
     Camera &camera = state.camera;
     float fovy = 0;
     std::string line;
@@ -101,6 +106,7 @@ int Scene::loadCamera() {
     }
     deriveFov(camera, fovy);
     state.image.assign((size_t)camera.resolution.x * camera.resolution.y, lin::vec3());
+    if (verbose) std::cout << "Loaded camera!" << std::endl;
     return 1;
 }
 
@@ -109,19 +115,26 @@ int Scene::loadGeom(std::string objectid) {
         std::cout << "ERROR: OBJECT ID does not match expected number of geoms" << std::endl;
         return -1;
     }
+    if (verbose) std::cout << "Loading Geom " << geoms.size() << "..." << std::endl;
     Geom g;
     g.type = SPHERE;
     g.materialid = 0;
     std::string line;
     safeGetline(fp_in, line);
     if (!line.empty() && fp_in.good()) {
-        if (line == "sphere") g.type = SPHERE;
-        else if (line == "cube") g.type = CUBE;
+        if (line == "sphere") {
+            if (verbose) std::cout << "Creating new sphere..." << std::endl;
+            g.type = SPHERE;
+        } else if (line == "cube") {
+            if (verbose) std::cout << "Creating new cube..." << std::endl;
+            g.type = CUBE;
+        }
     }
     safeGetline(fp_in, line);
     if (!line.empty() && fp_in.good()) {
         const Tokens t = tokenizeString(line);
         if (t.size() >= 2) g.materialid = atoi(t[1].c_str());
+        if (verbose) std::cout << "Connecting Geom " << objectid << " to Material " << g.materialid << "..." << std::endl;
     }
     for (safeGetline(fp_in, line); !line.empty() && fp_in.good(); safeGetline(fp_in, line)) {
         const Tokens t = tokenizeString(line);
