@@ -389,7 +389,8 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     // process at most ceil(tiles / kSub) tiles, and tiles <= ceil(nLocal/256) + kSeg (one partial tile per input
     // segment).  Worst case (every ray in one octant) is provisioned: 8x the live paths, 325 MB per buffer at 720p.
     S.maxBatch = o.max_batch > 0 ? o.max_batch : 1;
-    if ((long long)S.nLocal * S.maxBatch > (1ll << 30)) return fail(PT_ERR_INVALID, "pt_init: max_batch x pixels too large");
+    // slots are 32-bit: kSeg * segCap ~ 8 x paths must stay below 2^31
+    if ((long long)S.nLocal * S.maxBatch > (1ll << 27)) return fail(PT_ERR_INVALID, "pt_init: max_batch x pixels too large (limit 2^27 paths per batch)");
     S.numTilesMax = (int)(((long long)S.nLocal * S.maxBatch + kBlock - 1) / kBlock) + kSeg;
     S.segCap = ((S.numTilesMax + kSub - 1) / kSub) * kBlock;
     k.segCap = S.segCap;
