@@ -154,6 +154,8 @@ void pack_geom(const PtGeom &g, GeomDev &d, const float *eye = nullptr) {
     const bool ok = std::isfinite(r2) && std::isfinite(kk) && kk < 0.5 && smin > 0;
     d.cullR2 = ok ? (float)r2 : INFINITY;      // infinite radius: never culled
     d.cullK = ok ? (float)kk : 0.0f;
+    d.rect[0] = d.rect[1] = 0;                 // whole frame until pt_init projects the primitive (project_geom)
+    d.rect[2] = d.rect[3] = 0x7fffffff;
     if (eye) {   // ptd::mulMV(inv, eye, 1) in the same operation order (this file is built with -ffp-contract=off)
         const float *m = d.inv;
         for (int r = 0; r < 3; ++r) {
@@ -171,6 +173,57 @@ void pack_material(const PtMaterial &m, MaterialDev &d) {
     d.hasRefractive = m.hasRefractive;
     d.ior = m.indexOfRefraction;
     d.emittance = m.emittance;
+}
+
+// Pixel rectangle from which camera rays can reach a primitive: project the 8 corners of its object-space unit cube
+// (which contains the unit-diameter sphere as well) in double precision.  A camera ray is
+//     eye + lambda * (view - right * pixLenX * (px - W/2) - up * pixLenY * (py - H/2)),   px in [x, x+1], py in [y, y+1],
+// so a world point Q lies on the ray through continuous pixel (px, py) iff  Q - eye = M * (lambda, lambda sx, lambda sy)
+// with M = [view | -pixLenX right | -pixLenY up].  The convex hull of the projected corners contains the projection of
+// the primitive; its bounding rectangle is widened by 2 pixels.  Any corner not strictly in front of the eye, or a
+// singular M, disables the culling for this primitive (whole frame).
+void project_geom(const PtGeom &g, const KParams &k, int rect[4]) {
+    rect[0] = rect[1] = 0;
+    rect[2] = k.W - 1;
+    rect[3] = k.H - 1;
+    const double M[3][3] = {{k.view[0], -(double)k.pixLenX * k.right[0], -(double)k.pixLenY * k.up[0]},
+                            {k.view[1], -(double)k.pixLenX * k.right[1], -(double)k.pixLenY * k.up[1]},
+                            {k.view[2], -(double)k.pixLenX * k.right[2], -(double)k.pixLenY * k.up[2]}};
+    const double det = M[0][0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) +
+                       M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0]);
+    double scale = 0;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) scale = std::max(scale, std::fabs(M[r][c]));
+    if (!(std::fabs(det) > 1e-12 * scale * scale * scale) || !std::isfinite(det)) return;
+    double xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
+    for (int corner = 0; corner < 8; ++corner) {
+        const double o[3] = {(corner & 1) ? 0.5 : -0.5, (corner & 2) ? 0.5 : -0.5, (corner & 4) ? 0.5 : -0.5};
+        double q[3];
+        for (int r = 0; r < 3; ++r)
+            q[r] = (double)g.transform[0 + r] * o[0] + (double)g.transform[4 + r] * o[1] + (double)g.transform[8 + r] * o[2] +
+                   (double)g.transform[12 + r] - (double)k.pos[r];
+        // Cramer: (lambda, lambda sx, lambda sy) = M^-1 q
+        double c[3];
+        for (int col = 0; col < 3; ++col) {
+            double A[3][3];
+            for (int r = 0; r < 3; ++r)
+                for (int cc = 0; cc < 3; ++cc) A[r][cc] = cc == col ? q[r] : M[r][cc];
+            c[col] = (A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
+                      A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0])) / det;
+        }
+        const double dist = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+        const double vlen = std::sqrt((double)k.view[0] * k.view[0] + (double)k.view[1] * k.view[1] + (double)k.view[2] * k.view[2]);
+        if (!(c[0] * vlen > 1e-3 * dist) || !std::isfinite(c[0])) return;     // corner not clearly in front of the eye
+        const double px = c[1] / c[0] + k.halfW, py = c[2] / c[0] + k.halfH;
+        if (!std::isfinite(px) || !std::isfinite(py)) return;
+        xmin = std::min(xmin, px); xmax = std::max(xmax, px);
+        ymin = std::min(ymin, py); ymax = std::max(ymax, py);
+    }
+    auto clampi = [](double v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : (int)v); };
+    rect[0] = clampi(std::floor(xmin) - 2, 0, k.W);
+    rect[1] = clampi(std::floor(ymin) - 2, 0, k.H);
+    rect[2] = clampi(std::ceil(xmax) + 2, -1, k.W - 1);
+    rect[3] = clampi(std::ceil(ymax) + 2, -1, k.H - 1);
 }
 
 // host mirrors of the glm ops used for the camera basis (same op order as ptd::)
@@ -412,7 +465,16 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
 
     std::vector<GeomDev> hg(ngeoms ? ngeoms : 1);
     std::vector<MaterialDev> hm(nmats ? nmats : 1);
-    for (int i = 0; i < ngeoms; ++i) pack_geom(geoms[i], hg[i], k.pos);
+    k.sceneRect[0] = k.sceneRect[1] = 0x7fffffff;   // empty union: a scene without primitives is never entered
+    k.sceneRect[2] = k.sceneRect[3] = -1;
+    for (int i = 0; i < ngeoms; ++i) {
+        pack_geom(geoms[i], hg[i], k.pos);
+        project_geom(geoms[i], k, hg[i].rect);
+        k.sceneRect[0] = std::min(k.sceneRect[0], hg[i].rect[0]);
+        k.sceneRect[1] = std::min(k.sceneRect[1], hg[i].rect[1]);
+        k.sceneRect[2] = std::max(k.sceneRect[2], hg[i].rect[2]);
+        k.sceneRect[3] = std::max(k.sceneRect[3], hg[i].rect[3]);
+    }
     for (int i = 0; i < nmats; ++i) pack_material(mats[i], hm[i]);
     HIPCHECK(hipMalloc(&S.dgeoms, hg.size() * sizeof(GeomDev)));
     HIPCHECK(hipMalloc(&S.dmats, hm.size() * sizeof(MaterialDev)));

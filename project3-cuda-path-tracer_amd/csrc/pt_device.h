@@ -68,8 +68,12 @@ struct GeomDev {
     // same operation order: every camera ray of the first bounce shares it
     float camObj[3];
     float pad2;
+    // Pixels whose camera rays can reach this primitive: inclusive bounds [x0, y0, x1, y1] of the projection of its
+    // object-space unit cube, widened by 2 pixels (host, double precision); the whole frame when a corner is not in
+    // front of the eye.  Camera rays of other pixels skip the primitive (first bounce only).
+    int   rect[4];
 };
-static_assert(sizeof(GeomDev) == 192, "GeomDev is 12 x 16 B");
+static_assert(sizeof(GeomDev) == 208, "GeomDev is 13 x 16 B");
 
 struct MaterialDev {
     float color[3];

@@ -40,6 +40,7 @@ struct KParams {
     int   ngeoms, nmats;
     int   traceDepth;
     int   segCap;       // capacity (paths) of one segment of a path buffer, multiple of kBlock
+    int   sceneRect[4]; // union of the primitives' pixel rectangles (GeomDev::rect): camera rays outside miss everything
 };
 
 // SoA PathSegment buffer: 11 arrays of `cap` = kSeg * segCap 4-byte elements, array k at base + k*cap
@@ -54,10 +55,10 @@ struct PathSoA {
 };
 
 // ---- camera ray of the j-th pixel of this shard (spec S2) ------------------------------------------
-__device__ __forceinline__ void cameraRay(const KParams &prm, int iter, int j, int &pix, F3 &org, F3 &dir) {
+__device__ __forceinline__ void cameraRay(const KParams &prm, int iter, int j, int &pix, int &x, int &y, F3 &org, F3 &dir) {
     const int lr = j / prm.W;
-    const int x = j - lr * prm.W;
-    const int y = lr * prm.shardCount + prm.shardRank;
+    x = j - lr * prm.W;
+    y = lr * prm.shardCount + prm.shardRank;
     pix = x + y * prm.W;
     Rng rng = makeSeededRandomEngine(iter, pix, 0);
     const float jx = u01(rng);
@@ -77,9 +78,9 @@ __device__ __forceinline__ void cameraRay(const KParams &prm, int iter, int j, i
 __global__ __launch_bounds__(kBlock) void k_debug_camera_rays(KParams prm, int iter, float *o3, float *d3, int *pixOut) {
     const int j = blockIdx.x * kBlock + threadIdx.x;
     if (j >= prm.nLocal) return;
-    int pix;
+    int pix, x, y;
     F3 org, dir;
-    cameraRay(prm, iter, j, pix, org, dir);
+    cameraRay(prm, iter, j, pix, x, y, org, dir);
     o3[3 * j] = org.x; o3[3 * j + 1] = org.y; o3[3 * j + 2] = org.z;
     d3[3 * j] = dir.x; d3[3 * j + 1] = dir.y; d3[3 * j + 2] = dir.z;
     pixOut[j] = pix;
@@ -193,10 +194,11 @@ __global__ __launch_bounds__(kBlock, 5) void k_bounce(KParams prm, int iter, int
         F3 org = f3(0, 0, 0), dir = f3(0, 0, 1), col = f3(0, 0, 0);
         int pix = 0, rem = 0;
         int itb = 0;                                            // which iteration of the batch this path belongs to
+        int px = 0, py = 0;                                     // pixel coordinates (FIRST only)
         if (valid) {
             if (FIRST) {
                 itb = (int)(idx / (uint32_t)prm.nLocal);
-                cameraRay(prm, iter + itb, (int)(idx - (uint32_t)itb * (uint32_t)prm.nLocal), pix, org, dir);
+                cameraRay(prm, iter + itb, (int)(idx - (uint32_t)itb * (uint32_t)prm.nLocal), pix, px, py, org, dir);
                 col = f3(1.0f, 1.0f, 1.0f);
                 rem = prm.traceDepth;
             } else {
@@ -215,12 +217,18 @@ __global__ __launch_bounds__(kBlock, 5) void k_bounce(KParams prm, int iter, int
             F3 P = f3(0, 0, 0), nsrc = f3(0, 0, 0);
             bool outside = false;
             const float dd = dot(dir, dir);
-            for (int g = 0; g < prm.ngeoms; ++g) {
+            // Camera rays (FIRST): a primitive is reachable only from the pixels inside the projection of its bounding
+            // cube (GeomDev::rect, 2-pixel margin >> any rounding of the reference's tests), and nothing is reachable
+            // outside the union of those rectangles -- at 16:9 more than half of Cornell's camera rays.
+            const bool inScene = !FIRST || (px >= prm.sceneRect[0] && px <= prm.sceneRect[2] &&
+                                            py >= prm.sceneRect[1] && py <= prm.sceneRect[3]);
+            for (int g = 0; inScene && g < prm.ngeoms; ++g) {
                 const GeomDev &G = ggeoms[g];
                 const int type = G.type;
                 F3 p, n;
                 bool o = false;
                 float t = -1.0f;
+                if (FIRST && (px < G.rect[0] || px > G.rect[2] || py < G.rect[1] || py > G.rect[3])) continue;
                 if (type == 0) {
                     if (!sphereCertainMiss(G, org, dir, dd)) t = sphereIntersectionTest<FIRST>(G, org, dir, p, n, o);
                 } else {

@@ -180,3 +180,18 @@ def test_headless_driver_renders_the_reference_protocol(gpu, oracle, tmp_path):
     want = (np.clip(img.reshape(64, 96, 3) / np.float32(5), 0, 1) * np.float32(255)).astype(np.uint8)[:, ::-1]
     assert np.array_equal(got, want)
     assert os.path.getsize(base + ".hdr") > 4 * 96 * 64
+
+
+@pytest.mark.parametrize("eye,view,up,fovy", [
+    ((0, 5, 4.9), (0, 0, -1), (0, 1, 0), 45.0),          # inside the room: every wall's bounding cube surrounds the eye
+    ((0, 5, 30), (0.02, -0.01, -1), (0, 1, 0), 12.0),    # far away, narrow: the room covers a small pixel rectangle
+    ((12, 9, 9), (-1.2, -0.5, -1), (0.05, 1, 0), 30.0),  # oblique, non-unit view, skewed up: partly off-screen
+    ((0, 5, 10.5), (0, 0, 1), (0, 1, 0), 45.0),          # looking away: everything behind the camera
+    ((-4.99, 5, 0), (1, 0.2, 0.1), (0, 1, 0), 50.0),     # eye almost touching the left wall
+    ((0, 9.6, 0), (0, -1, 0.001), (0, 0, -1), 40.0),     # just below the light, looking down
+])
+def test_camera_ray_pixel_rectangles_never_cull_a_hit(gpu, oracle, eye, view, up, fovy):
+    # first-bounce culling by projected bounding cubes (GeomDev::rect / KParams::sceneRect) must be invisible
+    z = oracle.Scene(os.path.join(SCENES, "cornell_glass.txt"))
+    sc = _scene(gpu, oracle, z.geoms, z.materials, (150, 90), 6, eye=eye, view=view, up=up, fovy=fovy)
+    _compare(gpu, oracle, sc, [1, 2], max_batch=2)
