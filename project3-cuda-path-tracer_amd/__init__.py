@@ -48,6 +48,7 @@ ABI_SYMBOLS = [
     "pt_scan_exclusive_i32", "pt_compact_nonzero_i32", "pt_test_utilhash", "pt_test_rng",
     "pt_test_intersect", "pt_test_hemisphere", "pt_test_sincos", "pt_test_reflect_refract",
     "pt_test_slab_quotients", "pt_test_slab_quotients_sweep", "pt_test_sphere_cull_sweep",
+    "pt_test_unscaled_sqrt_sweep",
 ]
 
 
@@ -110,6 +111,7 @@ def lib():
         L.pt_test_slab_quotients.argtypes = [vp, vp, i32, vp, vp, vp, vp]
         L.pt_test_slab_quotients_sweep.argtypes = [C.c_uint64, i64, C.POINTER(C.c_uint64)]
         L.pt_test_sphere_cull_sweep.argtypes = [vp, i32, C.c_uint64, i64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.pt_test_unscaled_sqrt_sweep.argtypes = [C.POINTER(C.c_uint64)]
         _lib = L
     return _lib
 
@@ -348,6 +350,12 @@ def test_slab_quotients_sweep(seed, pairs):
     m = C.c_uint64(0)
     _check(lib().pt_test_slab_quotients_sweep(seed, pairs, C.byref(m)))
     return int(m.value)
+
+
+def test_unscaled_sqrt_sweep():
+    m = (C.c_uint64 * 2)()
+    _check(lib().pt_test_unscaled_sqrt_sweep(m))
+    return [int(v) for v in m]
 
 
 def test_sphere_cull_sweep(geoms, seed, rays):

@@ -173,6 +173,9 @@ void pack_material(const PtMaterial &m, MaterialDev &d) {
     d.hasRefractive = m.hasRefractive;
     d.ior = m.indexOfRefraction;
     d.emittance = m.emittance;
+    d.invIor = 1.0f / d.ior;
+    const float q = (1.0f - d.ior) / (1.0f + d.ior);
+    d.r0 = q * q;
 }
 
 // Pixel rectangle from which camera rays can reach a primitive: project the 8 corners of its object-space unit cube
@@ -857,6 +860,22 @@ int pt_test_slab_quotients_sweep(uint64_t seed, int64_t pairs, uint64_t *mismatc
     unsigned long long h = 0;
     HIPCHECK(hipMemcpy(&h, m.p, 8, hipMemcpyDeviceToHost));
     *mismatches = h;
+    return PT_OK;
+}
+
+int pt_test_unscaled_sqrt_sweep(uint64_t mismatches[2]) {
+    NEED_GPU();
+    if (!mismatches) return fail(PT_ERR_INVALID, "pt_test_unscaled_sqrt_sweep: bad argument");
+    DevBuf<unsigned long long> m;
+    int rc = m.alloc(2);
+    if (rc) return rc;
+    HIPCHECK(hipMemset(m.p, 0, 16));
+    hipLaunchKernelGGL(k_sweep_unscaled_sqrt, dim3(1 << 14), dim3(256), 0, 0, m.p);   // 2^22 threads x 2^10 patterns
+    HIPCHECK(hipDeviceSynchronize());
+    unsigned long long h[2];
+    HIPCHECK(hipMemcpy(h, m.p, 16, hipMemcpyDeviceToHost));
+    mismatches[0] = h[0];
+    mismatches[1] = h[1];
     return PT_OK;
 }
 

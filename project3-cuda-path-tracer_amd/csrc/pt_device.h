@@ -36,6 +36,23 @@ __device__ __forceinline__ F3 cross(F3 x, F3 y) {
 __device__ __forceinline__ F3 normalize(F3 a) { return a * (1.0f / __builtin_sqrtf(dot(a, a))); }
 // glm/detail/func_geometric.inl:95-100
 __device__ __forceinline__ float length(F3 a) { return __builtin_sqrtf(dot(a, a)); }
+
+// ---- correctly rounded sqrt without its range handling ------------------------------------------------
+// hipcc expands a correctly rounded fp32 sqrt into 16 VALU instructions; seven of them only act near the exponent
+// limits (operands below 2^-96 are pre-scaled by 2^32 and the root by 2^-16; +-0 / +inf are passed through).
+// sqrtUnscaled issues the remaining nine -- v_sqrt_f32, its two neighbours and their fma residuals -- and is
+// bit-identical to __builtin_sqrtf for  x == +-0  or  2^-96 <= x < inf
+// (tests/test_gpu_parity.py::test_unscaled_sqrt_exhaustive compares EVERY float of that range).  It is used where
+// the operand is inside that range by construction; behind a run-time range test the compare + branch + copies cost
+// what the shorter sequence saves (measured: no change in SQ_INSTS_VALU), so normalize / length keep the plain form.
+__device__ __forceinline__ float sqrtUnscaled(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sd = __uint_as_float(__float_as_uint(s) - 1u), su = __uint_as_float(__float_as_uint(s) + 1u);
+    const float rd = __builtin_fmaf(-sd, s, x), ru = __builtin_fmaf(-su, s, x);
+    float r = 0.0f >= rd ? sd : s;
+    r = 0.0f < ru ? su : r;
+    return r;
+}
 // glm/detail/func_geometric.inl:176-179 : I - N * dot(N, I) * 2
 __device__ __forceinline__ F3 reflect(F3 I, F3 N) { return I - (N * dot(N, I)) * 2.0f; }
 // glm/detail/func_geometric.inl:193-200.  NaN when k < 0 (sqrt of a negative times 0): callers test k.
@@ -79,7 +96,9 @@ struct MaterialDev {
     float color[3];
     float specColor[3];
     float hasReflective, hasRefractive, ior, emittance;
-    float pad0, pad1;
+    // per-material constants of the dielectric branch, evaluated once on the host with the same IEEE operations the
+    // shader would issue per path: 1.0f / ior and Schlick's r0 = ((1 - ior) / (1 + ior))^2
+    float invIor, r0;
 };
 static_assert(sizeof(MaterialDev) == 48, "MaterialDev is 3 x 16 B");
 
@@ -339,8 +358,10 @@ static_assert(sizeof(GeomHitDev) == 80, "GeomHitDev is 5 x 16 B");
 
 // src/interactions.h:10-42
 __device__ __forceinline__ F3 calculateRandomDirectionInHemisphere(F3 normal, Rng &rng) {
-    float up = __builtin_sqrtf(u01(rng));
-    float over = __builtin_sqrtf(1 - up * up);
+    // u01 is 0 or at least 2^-31, and 1 - up*up is 0 or at least 2^-24 (up*up <= 1 is a float): both operands are
+    // inside sqrtUnscaled's range by construction
+    float up = sqrtUnscaled(u01(rng));
+    float over = sqrtUnscaled(1 - up * up);
     float around = u01(rng) * kTwoPi;
     F3 notNormal;
     if (__builtin_fabsf(normal.x) < kSqrtOneThird) {

@@ -260,15 +260,13 @@ __global__ __launch_bounds__(kBlock, 5) void k_bounce(KParams prm, int iter, int
                     const F3 scol = f3(M.specColor[0], M.specColor[1], M.specColor[2]);
                     F3 ndir, norg;
                     if (M.hasRefractive > 0.0f) {
-                        const float ior = M.ior;
-                        const float eta = outside ? 1.0f / ior : ior;
+                        const float eta = outside ? M.invIor : M.ior;
                         const float c = dot(N, dir);
                         const float k = 1.0f - eta * eta * (1.0f - c * c);
                         const float u = u01(rng);
                         bool doReflect = true;
                         if (k >= 0.0f) {
-                            float r0 = (1.0f - ior) / (1.0f + ior);
-                            r0 = r0 * r0;
+                            const float r0 = M.r0;
                             const float cosx = outside ? -c : __builtin_sqrtf(k);
                             const float w = 1.0f - cosx;
                             const float w2 = w * w;

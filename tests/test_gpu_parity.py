@@ -102,6 +102,15 @@ def test_slab_quotients_equal_ieee_division(gpu):
     assert gpu.test_slab_quotients_sweep(12345, 1 << 30) == 0        # 2^30 more pairs on the device
 
 
+def test_unscaled_sqrt_exhaustive(gpu):
+    # The hemisphere sampler issues the compiler's correctly rounded sqrt WITHOUT the instructions that only act near
+    # the exponent limits (pt_device.h: sqrtUnscaled); its operands (u01 and 1 - up^2) are 0 or >= 2^-31 by
+    # construction.  Compared with __builtin_sqrtf on every fp32 bit pattern of the range +-0, [2^-96, inf).
+    bad, checked = gpu.test_unscaled_sqrt_sweep()
+    assert checked == 2 + ((0x7f800000 - 0x0f800000))      # +-0 and every positive float from 2^-96 up to FLT_MAX
+    assert bad == 0
+
+
 def test_sphere_culling_never_rejects_a_hit(gpu, oracle):
     # sphereCertainMiss is a sufficient condition for the reference's `radicand < 0` exit; 2^28 rays (dense in
     # grazing cases, origins 1/64 .. 64 units away) against uniform spheres, ellipsoids, tiny and huge ones
