@@ -46,9 +46,30 @@ def init_process_group(backend=None):
 
 
 def make_gather_buffers(block, world, rank, dst=0):
-    """Receive buffers at the destination rank (one block per rank)."""
+    """Receive buffers at the destination rank: one block per rank, views of ONE contiguous (world, block) tensor so
+    that the rows can be interleaved into the frame with a single strided copy."""
     import torch
-    return [torch.empty_like(block) for _ in range(world)] if rank == dst else None
+    if rank != dst:
+        return None
+    recv = torch.empty((world, block.numel()), dtype=block.dtype, device=block.device)
+    return list(recv.unbind(0))
+
+
+def _interleave_rows(bufs, frame, width, height, world):
+    """frame row y = row y // world of rank y % world's block."""
+    per = height // world
+    base = bufs[0]
+    contiguous = all(b.data_ptr() == base.data_ptr() + r * base.numel() * base.element_size() for r, b in enumerate(bufs))
+    if height % world == 0 and contiguous and base.numel() == per * width * 3:
+        import torch
+        recv = torch.as_strided(base, (per, world, width * 3), (width * 3, base.numel(), 1))
+        frame.view(per, world, width * 3).copy_(recv)      # one kernel instead of `world`
+        return
+    rows_view = frame.view(height, width * 3)
+    for r in range(world):
+        n = len(shard_rows(height, r, world))
+        if n:
+            rows_view[r::world].copy_(bufs[r][:n * width * 3].view(n, width * 3))
 
 
 _use_reduce_fallback = False   # set on the first failure of dist.gather (all ranks fail alike: same library)
@@ -73,11 +94,7 @@ def gather_frame(block, bufs, frame, width, height, dst=0):
         try:
             dist.gather(block, bufs if rank == dst else None, dst=dst)
             if rank == dst:
-                rows_view = frame.view(height, width * 3)
-                for r in range(world):
-                    n = len(shard_rows(height, r, world))
-                    if n:
-                        rows_view[r::world].copy_(bufs[r][:n * width * 3].view(n, width * 3))
+                _interleave_rows(bufs, frame, width, height, world)
             return frame
         except (RuntimeError, NotImplementedError, ValueError):
             _use_reduce_fallback = True

@@ -56,14 +56,15 @@ def _worker(rank, world, port, res, iters, out_path):
     torch.distributed.destroy_process_group()
 
 
-def test_two_ranks_gloo_assemble_the_frame_bit_exactly(tmp_path):
+@pytest.mark.parametrize("res", [(48, 37), (48, 36)])      # ragged shards (19 / 18 rows: per-rank copies) and even ones (one strided copy)
+def test_two_ranks_gloo_assemble_the_frame_bit_exactly(tmp_path, res):
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     out = str(tmp_path / "ok.npy")
-    mp.spawn(_worker, args=(2, port, (48, 37), [1, 2, 3], out), nprocs=2, join=True)   # 37 rows: ragged shards (19 / 18)
+    mp.spawn(_worker, args=(2, port, res, [1, 2, 3], out), nprocs=2, join=True)
     assert np.load(out)[0] == 1
 
 
