@@ -37,14 +37,17 @@ ACCUM_BYTES = 24               # accumulator read + write of one emitter hit (ve
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)          # BASELINE config C2: 64 spp
-    ap.add_argument("--warmup", type=int, default=128)         # ~14 ms: clocks and first-touch pages settle
+    ap.add_argument("--steps", type=int, default=None,
+                    help="iterations timed; default = the spp of the BASELINE config: 64 (C2, 1 GPU), 5000 (C3, N GPUs)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed iterations first (default 128, N GPUs: 256)")
     ap.add_argument("--scene", default=os.path.join(ROOT, "scenes", "cornell.txt"))
     ap.add_argument("--res", type=int, nargs=2, default=[1280, 720])
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--cpu-spp", type=int, default=40, help="spp of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--pipeline", type=int, default=0, help="batches in flight (PtOptions.pipeline_depth; 0 = library default 3)")
-    ap.add_argument("--batch", type=int, default=8, help="iterations traced as one wavefront per pt_iterate_batch call")
+    ap.add_argument("--batch", type=int, default=8,
+                    help="iterations traced as one wavefront per pt_iterate_batch call on ONE GPU; N GPUs trace N x as many "
+                         "(at most 32), so that a launch keeps covering the same number of paths when the rows are sharded")
     ap.add_argument("--pmc-traffic-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"),
                     help="HBM bytes per bounce-kernel launch from a rocprofv3 --pmc run (profiles/README.md)")
     return ap.parse_args()
@@ -83,6 +86,10 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
         args.gpus = world
+    if args.steps is None:
+        args.steps = 64 if world == 1 else 5000
+    if args.warmup is None:
+        args.warmup = 128 if world == 1 else 256
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the hot path has no CPU fallback)")
     # BENCH_BACKEND=gloo lets the N > 1 path be rehearsed with several ranks on ONE GPU (RCCL needs one
@@ -115,7 +122,8 @@ def main():
     # path buffers grow with the batch (44 B x 8 octant-worst-case x 2 ping-pong x 3 slots per path): keep them
     # under ~48 GB, i.e. batch 8 up to 1080p frames and batch 1 for a 4096x4096 frame on one GPU
     n_local = ptdist.local_pixel_count(W, H, rank, world)
-    B = max(1, min(args.batch, 16, int(48e9 // (max(n_local, 1) * 44 * 8 * 2 * 3))))
+    B = max(1, min(args.batch * world, 32 if world > 1 else pt.PT_MAX_BATCH, pt.PT_MAX_BATCH,
+                   int(48e9 // (max(n_local, 1) * 44 * 8 * 2 * 3))))
 
     def init(flags, pipeline):
         pt.pathtraceFree()

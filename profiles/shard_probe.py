@@ -10,7 +10,7 @@ scene = pt.Scene(os.path.join(ROOT, "scenes", "cornell.txt"))
 scene.set_resolution(1280, 720)
 P = 1280 * 720
 for world in (1, 2, 4, 8):
-    for depth_pipe, batch in ((1, 1), (3, 1), (2, 2), (3, 2), (2, 4), (3, 4), (2, 8), (3, 8)):
+    for depth_pipe, batch in ((3, 1), (3, 4), (3, 8), (3, 16), (3, 32), (3, 64), (2, 64)):
         acc = torch.zeros(P * 3, device="cuda")
         pt.pathtraceFree()
         pt.pathtraceInit(scene, shard_rank=0, shard_count=world, stream=torch.cuda.current_stream().cuda_stream,
@@ -18,7 +18,7 @@ for world in (1, 2, 4, 8):
         for it in range(1, 1 + 4 * batch, batch):
             pt.pathtrace_batch(None, 0, it, batch)
         torch.cuda.synchronize()
-        N = 128
+        N = 256
         t0 = time.perf_counter()
         for it in range(100, 100 + N, batch):
             pt.pathtrace_batch(None, 0, it, batch)

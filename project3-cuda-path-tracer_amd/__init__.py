@@ -38,6 +38,7 @@ CAMERA_DTYPE = np.dtype([
 assert GEOM_DTYPE.itemsize == 236 and MATERIAL_DTYPE.itemsize == 44 and CAMERA_DTYPE.itemsize == 52
 
 PT_MAX_DEPTH = 62
+PT_MAX_BATCH = 64
 PT_FLAG_KERNEL_TIMING = 1
 PT_FLAG_ACCUM_SHARD_ROWS = 2
 
@@ -238,6 +239,12 @@ def sync():
 
 
 def readback(npixels):
+    """Un-normalised running sum of the WHOLE frame (W*H*3 floats; with PT_FLAG_ACCUM_SHARD_ROWS the other shards'
+    rows are zero).  `npixels` must be the frame's pixel count: pt_readback always writes that many."""
+    if _scene is not None:
+        res = _scene.camera["resolution"][0]
+        if int(res[0]) * int(res[1]) != npixels:
+            raise PtError("readback: the frame has %d pixels, not %d" % (int(res[0]) * int(res[1]), npixels))
     out = np.empty(npixels * 3, np.float32)
     _check(lib().pt_readback(_p(out)))
     return out

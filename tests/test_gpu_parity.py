@@ -289,6 +289,31 @@ def test_batched_iterations_equal_sequential_iterations(gpu, oracle, batches):
     assert cnt.iterations == sum(batches) and cnt.live[3] == live
 
 
+def test_largest_batch_and_row_shard_equal_sequential_iterations(gpu, oracle):
+    # what an 8-GPU run does on every rank: PT_MAX_BATCH iterations of its row shard as one wavefront, packed accumulator
+    res, depth, world, rank = (96, 64), 6, 8, 3
+    sc = gpu.Scene(os.path.join(SCENES, "cornell.txt"))
+    sc.set_resolution(*res)
+    ref = oracle.Renderer(sc.camera.view(oracle.CAMERA_DTYPE), sc.geoms.view(oracle.GEOM_DTYPE),
+                          sc.materials.view(oracle.MATERIAL_DTYPE), depth)
+    want = np.zeros(res[0] * res[1] * 3, np.float32)
+    gpu.pathtraceFree()
+    gpu.pathtraceInit(sc, traceDepth=depth, max_batch=gpu.PT_MAX_BATCH, pipeline_depth=3, shard_rank=rank,
+                      shard_count=world, flags=gpu.PT_FLAG_ACCUM_SHARD_ROWS)
+    it = 1
+    for count in (gpu.PT_MAX_BATCH, 5, gpu.PT_MAX_BATCH):
+        gpu.pathtrace_batch(None, 0, it, count)
+        for k in range(count):
+            ref.iterate(it + k, want)
+        it += count
+    got = gpu.readback(res[0] * res[1]).reshape(res[1], res[0] * 3)      # pt_readback scatters the shard's rows into a zeroed frame
+    gpu.pathtraceFree()
+    mine = np.arange(res[1]) % world == rank
+    want = want.reshape(res[1], res[0] * 3)
+    assert np.array_equal(got[mine].view(np.uint32), want[mine].view(np.uint32)) and want[mine].max() > 0
+    assert not got[~mine].any()
+
+
 def test_rgba8_conversion_matches_reference_formula(gpu, oracle):
     sc = gpu.Scene(os.path.join(SCENES, "cornell.txt"))
     sc.set_resolution(64, 48)
