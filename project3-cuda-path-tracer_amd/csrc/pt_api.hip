@@ -879,6 +879,19 @@ int pt_test_unscaled_sqrt_sweep(uint64_t mismatches[2]) {
     return PT_OK;
 }
 
+#ifdef PT_PROBE
+// profiles/probe_phases.py: read (and clear) the phase counters of a -DPT_PROBE build
+int pt_probe_read(uint64_t out[16]) {
+    NEED_GPU();
+    unsigned long long h[16], z[16] = {0};
+    HIPCHECK(hipDeviceSynchronize());
+    HIPCHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(ptd::g_probe), sizeof h));
+    HIPCHECK(hipMemcpyToSymbol(HIP_SYMBOL(ptd::g_probe), z, sizeof z));
+    for (int i = 0; i < 16; ++i) out[i] = h[i];
+    return PT_OK;
+}
+#endif
+
 int pt_test_hemisphere(const float *normals3, const int32_t *iid3, int n, float *out3) {
     NEED_GPU();
     if (n <= 0) return PT_OK;

@@ -12,6 +12,21 @@
 
 namespace ptd {
 
+// Instrumentation for profiles/probe_phases.py (built with -DPT_PROBE only): wave-level executions and active lanes
+// of the phases of the two intersection tests.  g_probe[2k] += 1 per wave that enters phase k, g_probe[2k+1] += lanes.
+#ifdef PT_PROBE
+__device__ unsigned long long g_probe[16];
+__device__ __forceinline__ void probe(int k) {
+    const unsigned long long m = __ballot(1);
+    if (__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) == 0) {
+        atomicAdd(&g_probe[2 * k], 1ull);
+        atomicAdd(&g_probe[2 * k + 1], (unsigned long long)__popcll(m));
+    }
+}
+#else
+__device__ __forceinline__ void probe(int) {}
+#endif
+
 struct F3 {
     float x, y, z;
 };
@@ -236,6 +251,7 @@ __device__ __forceinline__ void slabQuotients(float o, float d, float &t1, float
 // CAM_ORIGIN: the ray starts at the camera, whose object-space position is precomputed (GeomDev::camObj).
 template <bool EARLY_MISS, bool CAM_ORIGIN = false>
 __device__ __forceinline__ float boxIntersectionTest(const GeomDev &g, F3 ro, F3 rd, F3 &P, F3 &nsrc, bool &outside) {
+    probe(0);
     const F3 qo = CAM_ORIGIN ? f3(g.camObj[0], g.camObj[1], g.camObj[2]) : mulMV(g.inv, ro, 1.0f);
     const F3 qdu = mulMV(g.inv, rd, 0.0f);
     if (EARLY_MISS) {
@@ -244,6 +260,7 @@ __device__ __forceinline__ float boxIntersectionTest(const GeomDev &g, F3 ro, F3
                           (qo.z > 0.5f && qdu.z > 0.0f) || (qo.z < -0.5f && qdu.z < 0.0f);
         if (away) return -1.0f;
     }
+    probe(1);
     const F3 qd = normalize(qdu);
     float tmin = -1e38f, tmax = 1e38f;
     // the slab normal n (zero except n[xyz] = +-1) is tracked as axis + value instead of a vector
@@ -270,6 +287,7 @@ __device__ __forceinline__ float boxIntersectionTest(const GeomDev &g, F3 ro, F3
         }
     }
     if (tmax >= tmin && tmax > 0) {
+        probe(2);
         outside = true;
         if (tmin <= 0) {
             tmin = tmax;
@@ -307,11 +325,13 @@ __device__ __forceinline__ bool sphereCertainMiss(const GeomDev &g, F3 org, F3 d
 template <bool CAM_ORIGIN = false>
 __device__ __forceinline__ float sphereIntersectionTest(const GeomDev &g, F3 ro_w, F3 rd_w, F3 &P, F3 &nsrc,
                                                         bool &outside) {
+    probe(4);
     F3 ro = CAM_ORIGIN ? f3(g.camObj[0], g.camObj[1], g.camObj[2]) : mulMV(g.inv, ro_w, 1.0f);
     F3 rd = normalize(mulMV(g.inv, rd_w, 0.0f));
     float vDotDirection = dot(ro, rd);
     float radicand = vDotDirection * vDotDirection - (dot(ro, ro) - 0.25f);
     if (radicand < 0) return -1.0f;
+    probe(5);
     float squareRoot = __builtin_sqrtf(radicand);
     float firstTerm = -vDotDirection;
     float t1 = firstTerm + squareRoot;
@@ -326,6 +346,7 @@ __device__ __forceinline__ float sphereIntersectionTest(const GeomDev &g, F3 ro_
         t = t1 < t2 ? t2 : t1;  // max(t1, t2)
         outside = false;
     }
+    probe(6);
     F3 obj = getPointOnRay(ro, rd, t);
     P = mulMV(g.xf, obj, 1.0f);
     nsrc = obj;      // normal = +-normalize(invTranspose * (obj, 0)): hitNormal(), evaluated for the nearest hit only

@@ -211,6 +211,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_bounce(KParams prm, int iter, int
                 itb = packed >> 8;
             }
 
+            if (!FIRST) probe(7);                                   // tiles (waves with at least one valid path) and valid paths
             // nearest hit, geoms in file order, strict '<' so the first geom wins ties (S3)
             float tbest = 0.0f;
             int hit = -1;
@@ -230,6 +231,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_bounce(KParams prm, int iter, int
                 float t = -1.0f;
                 if (FIRST && (px < G.rect[0] || px > G.rect[2] || py < G.rect[1] || py > G.rect[3])) continue;
                 if (type == 0) {
+                    probe(3);
                     if (!sphereCertainMiss(G, org, dir, dd)) t = sphereIntersectionTest<FIRST>(G, org, dir, p, n, o);
                 } else {
                     t = boxIntersectionTest<true, FIRST>(G, org, dir, p, n, o);
