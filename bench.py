@@ -38,7 +38,8 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None,
-                    help="iterations timed; default = the spp of the BASELINE config: 64 (C2, 1 GPU), 5000 (C3, N GPUs)")
+                    help="iterations timed; default 1024 on one GPU (16 x the 64 spp of BASELINE config C2: the 5.5 ms a "
+                         "single 64-spp render takes is too short a timed region), 5000 on N GPUs (C3)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed iterations first (default 128, N GPUs: 256)")
     ap.add_argument("--scene", default=os.path.join(ROOT, "scenes", "cornell.txt"))
     ap.add_argument("--res", type=int, nargs=2, default=[1280, 720])
@@ -87,7 +88,7 @@ def main():
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
         args.gpus = world
     if args.steps is None:
-        args.steps = 64 if world == 1 else 5000
+        args.steps = 1024 if world == 1 else 5000
     if args.warmup is None:
         args.warmup = 128 if world == 1 else 256
     if not torch.cuda.is_available():
@@ -119,11 +120,11 @@ def main():
         frame, bufs, shard_flag = None, None, 0
     stream = torch.cuda.current_stream()
 
-    # path buffers grow with the batch (44 B x 8 octant-worst-case x 2 ping-pong x 3 slots per path): keep them
-    # under ~48 GB, i.e. batch 8 up to 1080p frames and batch 1 for a 4096x4096 frame on one GPU
+    # path buffers grow with the batch (44 B x 16 class-worst-case x 2 ping-pong x 3 slots per path): keep them
+    # under ~96 GB, i.e. batch 8 up to 1080p frames and batch 1 for a 4096x4096 frame on one GPU
     n_local = ptdist.local_pixel_count(W, H, rank, world)
     B = max(1, min(args.batch * world, 32 if world > 1 else pt.PT_MAX_BATCH, pt.PT_MAX_BATCH,
-                   int(48e9 // (max(n_local, 1) * 44 * 8 * 2 * 3))))
+                   int(96e9 // (max(n_local, 1) * 44 * 16 * 2 * 3))))
 
     def init(flags, pipeline):
         pt.pathtraceFree()

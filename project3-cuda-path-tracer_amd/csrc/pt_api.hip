@@ -443,10 +443,10 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     // Path buffers: kSeg = kOct x kSub segments.  A segment receives survivors only from the workgroups with one
     // value of blockIdx % kSub; tiles are blockIdx-strided and the grid is a multiple of kSub, so those workgroups
     // process at most ceil(tiles / kSub) tiles, and tiles <= ceil(nLocal/256) + kSeg (one partial tile per input
-    // segment).  Worst case (every ray in one octant) is provisioned: 8x the live paths, 325 MB per buffer at 720p.
+    // segment).  Worst case (every ray in one class) is provisioned: kCls = 16x the live paths, 650 MB per buffer at 720p.
     S.maxBatch = o.max_batch > 0 ? o.max_batch : 1;
-    // slots are 32-bit: kSeg * segCap ~ 8 x paths must stay below 2^31
-    if ((long long)S.nLocal * S.maxBatch > (1ll << 27)) return fail(PT_ERR_INVALID, "pt_init: max_batch x pixels too large (limit 2^27 paths per batch)");
+    // slots are 32-bit: kSeg * segCap ~ 16 x paths must stay below 2^31
+    if ((long long)S.nLocal * S.maxBatch > (1ll << 26)) return fail(PT_ERR_INVALID, "pt_init: max_batch x pixels too large (limit 2^26 paths per batch)");
     S.numTilesMax = (int)(((long long)S.nLocal * S.maxBatch + kBlock - 1) / kBlock) + kSeg;
     S.segCap = ((S.numTilesMax + kSub - 1) / kSub) * kBlock;
     k.segCap = S.segCap;
@@ -479,13 +479,20 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
         k.sceneRect[3] = std::max(k.sceneRect[3], hg[i].rect[3]);
     }
     for (int i = 0; i < nmats; ++i) pack_material(mats[i], hm[i]);
+    int nsph = 0;
+    for (int i = 0; i < ngeoms; ++i)
+        if (geoms[i].type == PT_SPHERE) {
+            if (nsph < kBinSpheresMax) k.binSphere[nsph] = i;
+            ++nsph;
+        }
+    k.nBinSpheres = nsph <= kBinSpheresMax ? nsph : 0;
     HIPCHECK(hipMalloc(&S.dgeoms, hg.size() * sizeof(GeomDev)));
     HIPCHECK(hipMalloc(&S.dmats, hm.size() * sizeof(MaterialDev)));
     HIPCHECK(hipMemcpy(S.dgeoms, hg.data(), hg.size() * sizeof(GeomDev), hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(S.dmats, hm.data(), hm.size() * sizeof(MaterialDev), hipMemcpyHostToDevice));
 
     S.ldsBytes = sizeof(MaterialDev) * nmats + sizeof(GeomHitDev) * ngeoms +
-                 (kWaves * kOct + kOct + kSeg + kSeg + 2 + 2) * sizeof(uint32_t);
+                 (kWaves * kCls + kCls + kSeg + kSeg + 2 + 2) * sizeof(uint32_t);
     if (S.ldsBytes > 160 * 1024) return fail(PT_ERR_INVALID, "pt_init: scene does not fit the 160 KiB LDS (%zu B)", S.ldsBytes);
     if (S.ldsBytes > 64 * 1024) {
         HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bounce<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.ldsBytes));

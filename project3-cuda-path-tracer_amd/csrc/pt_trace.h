@@ -13,9 +13,11 @@ constexpr int kNumArrays = 11;       // SoA PathSegment: origin3, dir3, throughp
 constexpr int kMaxDepthSlots = PT_MAX_DEPTH + 2;
 
 // ---- device control block ------------------------------------------------------------------------
-constexpr int kOct = 8;              // direction octants: paths are binned by the signs of their new direction
-constexpr int kSub = 4;              // append-counter shards per octant (workgroup blockIdx % kSub)
-constexpr int kSeg = kOct * kSub;    // path buffers are split into kSeg segments with one append counter each
+constexpr int kOct = 8;              // direction octants: paths are binned by the signs of their new direction ...
+constexpr int kCls = 2 * kOct;       // ... and by "may hit a sphere" (bit 3): 16 classes
+constexpr int kSub = 4;              // append-counter shards per class (workgroup blockIdx % kSub)
+constexpr int kSeg = kCls * kSub;    // path buffers are split into kSeg segments with one append counter each
+constexpr int kBinSpheresMax = 4;    // scenes with more spheres do not bin by sphere candidacy (every path is a candidate)
 constexpr int kCtrPad = 32;          // one counter per 128-byte line: same-line atomics serialise at the memory side
 
 struct Ctrl {
@@ -41,6 +43,8 @@ struct KParams {
     int   traceDepth;
     int   segCap;       // capacity (paths) of one segment of a path buffer, multiple of kBlock
     int   sceneRect[4]; // union of the primitives' pixel rectangles (GeomDev::rect): camera rays outside miss everything
+    int   nBinSpheres;  // 1..kBinSpheresMax: the scene's spheres, survivors are binned by whether they can hit one; 0: off
+    int   binSphere[kBinSpheresMax];   // their geom indices
 };
 
 // SoA PathSegment buffer: 11 arrays of `cap` = kSeg * segCap 4-byte elements, array k at base + k*cap
@@ -88,15 +92,18 @@ __global__ __launch_bounds__(kBlock) void k_debug_camera_rays(KParams prm, int i
 
 // ---- one bounce: intersect + shade + accumulate + compact (spec S3-S8) -----------------------------
 // Persistent workgroups walk the 256-path tiles of the bounce's queue (the kSeg input segments laid
-// end to end), blockIdx-strided.  Survivors are BINNED BY DIRECTION OCTANT while they are compacted:
-//   segment   = octant(new direction) * kSub + blockIdx % kSub,
-//   rank      = exclusive scan of the lane's octant flag inside the wave (ballot + mbcnt) plus the earlier
-//               waves' totals through LDS = workgroup-level exclusive scan per octant,
-//   base      = ONE atomicAdd per non-empty octant of the tile on that segment's counter (8 lanes, one
-//               instruction).
-// A tile of the next bounce therefore holds rays of a single direction octant, which turns the exact
-// early-miss of the box test (pt_device.h) into a wave-uniform branch for axis-aligned boxes.  Queue order
-// never influences results: RNG and accumulator are keyed on the pixel index.
+// end to end), blockIdx-strided.  Survivors are BINNED BY CLASS while they are compacted:
+//   class     = octant(new direction) | sphereCandidate << 3, where sphereCandidate = the new ray is not a certain
+//               miss (sphereCertainMiss) of every sphere of the scene (scenes with 1..kBinSpheresMax spheres; else 1),
+//   segment   = class * kSub + blockIdx % kSub,
+//   rank      = position among the wave's lanes of the same class (four bit ballots -> same-class mask -> mbcnt) plus
+//               the earlier waves' totals through LDS = workgroup-level exclusive scan per class,
+//   base      = ONE atomicAdd per non-empty class of the tile on that segment's counter (16 lanes, one instruction).
+// A tile of the next bounce therefore holds rays of a single direction octant, which turns the exact early-miss of
+// the box test (pt_device.h) into a wave-uniform branch for axis-aligned boxes, and either sphere candidates only
+// -- whose sphere tests then run with full waves instead of a few lanes -- or paths that skip the spheres altogether
+// (the flag is a sufficient condition for the reference's own miss, evaluated on the very ray that is stored).
+// Queue order never influences results: RNG and accumulator are keyed on the pixel index.
 // No workgroup ever waits for another one, so there is no residency / dispatch-order assumption.
 // A segment receives survivors of the tiles of the workgroups with one value of blockIdx % kSub only,
 // i.e. at most ceil(tiles / kSub) * 256 <= segCap paths (see pt_init).
@@ -104,8 +111,12 @@ __global__ __launch_bounds__(kBlock) void k_debug_camera_rays(KParams prm, int i
 // FIRST = true is bounce 1 fused with camera-ray generation (spec S2): tile T holds the paths
 // j = 256 T + lane of this shard's pixel list and the ray is built in registers, so the first bounce
 // reads no path state at all.
+//
+// Six workgroups per CU (6 waves per SIMD, <= 85 VGPRs, a dozen cold spills): measured against 5 / 7 / 8 resident waves
+// this is the optimum (93.9 vs 90.7 / 78.1 / 62.8 G paths/s) -- more waves hide the tile-start loads and the compaction's
+// atomic round trip, beyond 6 the spills reach the intersection loop.
 template <bool FIRST>
-__global__ __launch_bounds__(kBlock, 5) void k_bounce(KParams prm, int iter, int batch, int depth, int lastBounce, int parity,
+__global__ __launch_bounds__(kBlock, 6) void k_bounce(KParams prm, int iter, int batch, int depth, int lastBounce, int parity,
                                                    PathSoA in, PathSoA out, Ctrl *ctrl,
                                                    const GeomDev *__restrict__ ggeoms,
                                                    const MaterialDev *__restrict__ gmats, float *contrib) {
@@ -118,9 +129,9 @@ __global__ __launch_bounds__(kBlock, 5) void k_bounce(KParams prm, int iter, int
     MaterialDev *smats = reinterpret_cast<MaterialDev *>(smem);
     GeomHitDev *s_geomHit = reinterpret_cast<GeomHitDev *>(smem + sizeof(MaterialDev) * prm.nmats);
     uint32_t *s_misc = reinterpret_cast<uint32_t *>(smem + sizeof(MaterialDev) * prm.nmats + sizeof(GeomHitDev) * prm.ngeoms);
-    uint32_t *s_wave = s_misc;                       // [kWaves][kOct] alive count per wave and octant
-    uint32_t *s_base = s_wave + kWaves * kOct;       // [kOct]   first output slot of this tile per octant
-    uint32_t *s_segcnt = s_base + kOct;              // [kSeg]   paths per input segment
+    uint32_t *s_wave = s_misc;                       // [kWaves][kCls] survivors per wave and class (zero between tiles)
+    uint32_t *s_base = s_wave + kWaves * kCls;       // [kCls]   first output slot of this tile per class
+    uint32_t *s_segcnt = s_base + kCls;              // [kSeg]   paths per input segment
     uint32_t *s_segpre = s_segcnt + kSeg;            // [kSeg+2] tile prefix per input segment, [kSeg+1] = live paths
 
     if (lastBounce) {   // re-arm the next iteration: nobody touches the other parity's counters now
@@ -153,6 +164,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_bounce(KParams prm, int iter, int
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctrl->sum_live[depth], (unsigned long long)nLive);
     if (blockIdx.x >= numTiles) return;
+    if (threadIdx.x < kWaves * kCls) s_wave[threadIdx.x] = 0u;
 
     // stage the materials in LDS once per (persistent) workgroup, 16 B per lane per step
     {
@@ -178,18 +190,22 @@ __global__ __launch_bounds__(kBlock, 5) void k_bounce(KParams prm, int iter, int
     for (uint32_t T = blockIdx.x; T < numTiles; T += gridDim.x) {
         bool valid;
         uint32_t idx = 0;
+        bool sphereTile = true;             // wave-uniform: this tile's paths may hit a sphere
         if (FIRST) {
             idx = T * kBlock + threadIdx.x;                     // position in this shard's pixel list
             valid = idx < nLive;
         } else {
             // global tile -> (segment, local tile)
             while (T >= s_segpre[sgIn + 1]) ++sgIn;
+            sgIn = (uint32_t)__builtin_amdgcn_readfirstlane((int)sgIn);
             const uint32_t local = (T - s_segpre[sgIn]) * kBlock + threadIdx.x;
             valid = local < s_segcnt[sgIn];
             idx = sgIn * (uint32_t)prm.segCap + local;
+            sphereTile = ((sgIn / kSub) & 8u) != 0u;
         }
 
         bool alive = false;
+        bool sphereCand = true;                                 // class bit 3 of a survivor
         bool lightHit = false, missed = false;
         F3 org = f3(0, 0, 0), dir = f3(0, 0, 1), col = f3(0, 0, 0);
         int pix = 0, rem = 0;
@@ -231,6 +247,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_bounce(KParams prm, int iter, int
                 float t = -1.0f;
                 if (FIRST && (px < G.rect[0] || px > G.rect[2] || py < G.rect[1] || py > G.rect[3])) continue;
                 if (type == 0) {
+                    if (!sphereTile) continue;                   // binned as a certain miss of every sphere
                     probe(3);
                     if (!sphereCertainMiss(G, org, dir, dd)) t = sphereIntersectionTest<FIRST>(G, org, dir, p, n, o);
                 } else {
@@ -303,45 +320,52 @@ __global__ __launch_bounds__(kBlock, 5) void k_bounce(KParams prm, int iter, int
                     org = norg;
                     dir = ndir;
                     alive = true;
+                    if (prm.nBinSpheres > 0) {                   // class bit 3: can the new ray hit a sphere at all?
+                        const float ndd = dot(ndir, ndir);
+                        sphereCand = false;
+                        for (int sI = 0; sI < prm.nBinSpheres; ++sI)
+                            sphereCand = sphereCand || !sphereCertainMiss(ggeoms[prm.binSphere[sI]], norg, ndir, ndd);
+                    }
                 }
             }
         }
         waveLight += (uint32_t)__popcll(__ballot(lightHit));
         waveMiss += (uint32_t)__popcll(__ballot(missed));
 
-        if (!lastBounce) {                                       // S8: compaction into `out`, binned by octant
+        if (!lastBounce) {                                       // S8: compaction into `out`, binned by class
             const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-            const int oct = (dir.x < 0.0f ? 1 : 0) | (dir.y < 0.0f ? 2 : 0) | (dir.z < 0.0f ? 4 : 0);
-            uint32_t rank = 0, myCount = 0;
-#pragma unroll
-            for (int k = 0; k < kOct; ++k) {
-                const unsigned long long m = __ballot(alive && oct == k);
-                const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                if (oct == k) rank = r;
-                if (lane == k) myCount = (uint32_t)__popcll(m);
-            }
-            if (lane < kOct) s_wave[wave * kOct + lane] = myCount;
+            uint32_t *wv = s_wave;
+            // same-class mask of this lane from four bit ballots (the sign compares already are the ballots)
+            const unsigned long long ba = __ballot(alive);
+            const unsigned long long b0 = __ballot(dir.x < 0.0f), b1 = __ballot(dir.y < 0.0f), b2 = __ballot(dir.z < 0.0f);
+            const unsigned long long b3 = __ballot(sphereCand);
+            const bool c0 = dir.x < 0.0f, c1 = dir.y < 0.0f, c2 = dir.z < 0.0f;
+            const uint32_t cls = (c0 ? 1u : 0u) | (c1 ? 2u : 0u) | (c2 ? 4u : 0u) | (sphereCand ? 8u : 0u);
+            const unsigned long long same = ba & (c0 ? b0 : ~b0) & (c1 ? b1 : ~b1) & (c2 ? b2 : ~b2) & (sphereCand ? b3 : ~b3);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(same >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)same, 0u));
+            if (alive && rank == 0u) wv[wave * kCls + cls] = (uint32_t)__popcll(same);   // the class's first lane
             __syncthreads();
-            if (threadIdx.x < kOct) {
+            if (threadIdx.x < kCls) {
                 uint32_t total = 0;
 #pragma unroll
-                for (int w = 0; w < kWaves; ++w) total += s_wave[w * kOct + threadIdx.x];
+                for (int w = 0; w < kWaves; ++w) total += wv[w * kCls + threadIdx.x];
                 const uint32_t oseg = threadIdx.x * kSub + (blockIdx.x % kSub);
                 s_base[threadIdx.x] = total ? atomicAdd(&ctrl->seg_count[parity][depth + 1][oseg][0], total) : 0u;
             }
             __syncthreads();
             if (alive) {
                 uint32_t waveOff = 0;
-                for (int w = 0; w < wave; ++w) waveOff += s_wave[w * kOct + oct];
-                const uint32_t oseg = (uint32_t)oct * kSub + (blockIdx.x % kSub);
-                const uint32_t slot = oseg * (uint32_t)prm.segCap + s_base[oct] + waveOff + rank;
+                for (int w = 0; w < wave; ++w) waveOff += wv[w * kCls + cls];
+                const uint32_t oseg = cls * kSub + (blockIdx.x % kSub);
+                const uint32_t slot = oseg * (uint32_t)prm.segCap + s_base[cls] + waveOff + rank;
                 out.a(0)[slot] = org.x; out.a(1)[slot] = org.y; out.a(2)[slot] = org.z;
                 out.a(3)[slot] = dir.x; out.a(4)[slot] = dir.y; out.a(5)[slot] = dir.z;
                 out.a(6)[slot] = col.x; out.a(7)[slot] = col.y; out.a(8)[slot] = col.z;
                 out.pix()[slot] = pix;
                 out.rem()[slot] = (rem - 1) | (itb << 8);
             }
-            __syncthreads();   // s_wave / s_base are rewritten by the next tile
+            __syncthreads();   // every wave has read this tile's counts: each wave clears its own row for the next tile
+            if (lane < kCls) wv[wave * kCls + lane] = 0u;
         }
     }
     if ((threadIdx.x & 63) == 0) {
