@@ -126,7 +126,7 @@ void pack_geom(const PtGeom &g, GeomDev &d, const float *eye = nullptr) {
         }
     d.type = g.type;
     d.material = g.materialid;
-    // sphere culling data (sphereCertainMiss): bounds smax >= sigma_max, smin <= sigma_min of the 3x3 part
+    // bounding-ball culling data (ptd::certainMiss): bounds smax >= sigma_max, smin <= sigma_min of the 3x3 part
     double A[3][3], Ai[3][3];
     for (int c = 0; c < 3; ++c)
         for (int r = 0; r < 3; ++r) { A[c][r] = g.transform[c * 4 + r]; Ai[c][r] = g.inverseTransform[c * 4 + r]; }
@@ -150,8 +150,10 @@ void pack_geom(const PtGeom &g, GeomDev &d, const float *eye = nullptr) {
         smin = froi > 0 ? 1.0 / std::sqrt(froi) : 0.0;
     }
     d.centre[0] = g.transform[12]; d.centre[1] = g.transform[13]; d.centre[2] = g.transform[14];
-    const double r2 = 0.25 * smax * smax * (1 + 1e-3), kk = smin > 0 ? 1e-4 * (smax / smin) * (smax / smin) : INFINITY;
+    const double rho2 = g.type == PT_SPHERE ? 0.25 : 0.75;       // object-space bounding ball: the sphere / the cube's corners
+    const double r2 = rho2 * smax * smax * (1 + 1e-3), kk = smin > 0 ? 1e-4 * (smax / smin) * (smax / smin) : INFINITY;
     const bool ok = std::isfinite(r2) && std::isfinite(kk) && kk < 0.5 && smin > 0;
+    d.boundR = (float)(std::sqrt(rho2) * smax);
     d.cullR2 = ok ? (float)r2 : INFINITY;      // infinite radius: never culled
     d.cullK = ok ? (float)kk : 0.0f;
     d.rect[0] = d.rect[1] = 0;                 // whole frame until pt_init projects the primitive (project_geom)
@@ -479,13 +481,34 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
         k.sceneRect[3] = std::max(k.sceneRect[3], hg[i].rect[3]);
     }
     for (int i = 0; i < nmats; ++i) pack_material(mats[i], hm[i]);
-    int nsph = 0;
-    for (int i = 0; i < ngeoms; ++i)
-        if (geoms[i].type == PT_SPHERE) {
-            if (nsph < kBinSpheresMax) k.binSphere[nsph] = i;
-            ++nsph;
+    // Small primitives the queue is binned by (k_bounce): the spheres when there are at most kBinMax of them, then the
+    // cubes whose bounding ball is small against the scene's (<= 0.3 of its radius), smallest first.  A choice that only
+    // steers which tiles skip which tests; results never depend on it.
+    {
+        double cm[3] = {0, 0, 0}, sceneR = 0;
+        for (int i = 0; i < ngeoms; ++i)
+            for (int a = 0; a < 3; ++a) cm[a] += hg[i].centre[a] / std::max(ngeoms, 1);
+        for (int i = 0; i < ngeoms; ++i) {
+            const double dx = hg[i].centre[0] - cm[0], dy = hg[i].centre[1] - cm[1], dz = hg[i].centre[2] - cm[2];
+            const double r = std::sqrt(dx * dx + dy * dy + dz * dz) + hg[i].boundR;
+            if (std::isfinite(r)) sceneR = std::max(sceneR, r);
         }
-    k.nBinSpheres = nsph <= kBinSpheresMax ? nsph : 0;
+        int nsph = 0;
+        for (int i = 0; i < ngeoms; ++i) nsph += geoms[i].type == PT_SPHERE;
+        std::vector<std::pair<double, int>> cand;
+        for (int i = 0; i < ngeoms; ++i) {
+            if (!std::isfinite(hg[i].cullR2)) continue;                       // never culled: cannot take part
+            const double r = hg[i].boundR;
+            if (geoms[i].type == PT_SPHERE) { if (nsph <= kBinMax) cand.emplace_back(-1.0, i); }   // spheres first
+            else if (r <= 0.3 * sceneR) cand.emplace_back(r, i);
+        }
+        std::sort(cand.begin(), cand.end());
+        k.nBinned = 0;
+        for (size_t c = 0; c < cand.size() && k.nBinned < kBinMax; ++c) {
+            k.binGeom[k.nBinned++] = cand[c].second;
+            hg[cand[c].second].binned = 1;
+        }
+    }
     HIPCHECK(hipMalloc(&S.dgeoms, hg.size() * sizeof(GeomDev)));
     HIPCHECK(hipMalloc(&S.dmats, hm.size() * sizeof(MaterialDev)));
     HIPCHECK(hipMemcpy(S.dgeoms, hg.data(), hg.size() * sizeof(GeomDev), hipMemcpyHostToDevice));

@@ -91,15 +91,18 @@ struct GeomDev {
     float invT[12];  // invTranspose
     int   type;      // 0 sphere, 1 cube (src/sceneStructs.h:8-11)
     int   material;
-    // conservative world-space culling of spheres (sphereCertainMiss): centre, 0.25 smax^2 (1 + 1e-3),
-    // 1e-4 (smax / smin)^2 with smax / smin bounds of the transform's singular values
+    // conservative world-space culling (certainMiss) against the primitive's bounding ball: centre, rho^2 smax^2 (1 + 1e-3)
+    // with rho^2 = 1/4 (sphere) or 3/4 (cube: half its diagonal), 1e-4 (smax / smin)^2 with smax / smin bounds of the
+    // transform's singular values
     float cullR2, cullK;
     float centre[3];
-    float pad;
+    float boundR;    // radius of the bounding ball, rho smax (host bookkeeping: which primitives are small)
     // object-space camera position multiplyMV(inverseTransform, (eye, 1)), evaluated once on the host with the
     // same operation order: every camera ray of the first bounce shares it
     float camObj[3];
-    float pad2;
+    // 1: a small primitive the queue is binned by (KParams::binGeom): tiles of paths that certainly miss all of them
+    // skip it
+    int   binned;
     // Pixels whose camera rays can reach this primitive: inclusive bounds [x0, y0, x1, y1] of the projection of its
     // object-space unit cube, widened by 2 pixels (host, double precision); the whole frame when a corner is not in
     // front of the eye.  Camera rays of other pixels skip the primitive (first bounce only).
@@ -304,17 +307,19 @@ __device__ __forceinline__ float boxIntersectionTest(const GeomDev &g, F3 ro, F3
     return -1.0f;
 }
 
-// Certain miss of a (possibly non-uniformly scaled) sphere, decided in WORLD space for ~20 instructions
-// instead of the ~80 of the object-space test.  Not an approximation of the result but a sufficient
-// condition for the reference's own `radicand < 0` exit (src/intersections.h:114-116):
-//   the unit sphere's image lies inside the world ball of radius smax/2 around `centre`; if the ray's
-//   squared distance from the centre exceeds  0.25 smax^2 (1 + 1e-3) + 1e-4 (smax/smin)^2 |o - c|^2
-//   then in object space  perp^2 - 0.25 > 1e-4 |ro|^2, i.e. the exact radicand is below -1e-4 |ro|^2,
-//   while every rounding in the reference's evaluation (transform, normalize, two dots) perturbs its
-//   radicand by less than ~2e-6 |ro|^2.  The margin is 50x, so the reference returns -1 there too.
+// Certain miss of a primitive, decided in WORLD space against its bounding ball for ~20 instructions.  Not an
+// approximation of the result but a sufficient condition for the reference's own miss:
+//   the image of the object-space ball of radius rho (1/2: the sphere itself; sqrt(3)/2: the cube's corners) lies inside
+//   the world ball of radius rho smax around `centre`; if the ray's squared distance from the centre exceeds
+//   rho^2 smax^2 (1 + 1e-3) + 1e-4 (smax/smin)^2 |o - c|^2  then in object space  perp^2 - rho^2 > 1e-4 |ro|^2.
+//   Sphere: the exact radicand is below -1e-4 |ro|^2, while every rounding in the reference's evaluation (transform,
+//   normalize, two dots) perturbs its radicand by less than ~2e-6 |ro|^2 -- `radicand < 0` exits (intersections.h:114).
+//   Cube: the line clears the cube by c >= 5e-5 |ro| object units, so the entry parameter of one slab exceeds the exit
+//   parameter of another by >= 2c, a relative gap >= 1e-4 of quotients the reference evaluates to ~1e-6 -- its
+//   `tmax >= tmin` fails (intersections.h:70).  The margin is 50x either way, and tests sweep 2^28 rays dense in grazes.
 // dd = dot(dir, dir) (the world direction is only approximately unit) is hoisted out of the geom loop.
 // NaN / inf operands fail the comparison, i.e. fall through to the full test.
-__device__ __forceinline__ bool sphereCertainMiss(const GeomDev &g, F3 org, F3 dir, float dd) {
+__device__ __forceinline__ bool certainMiss(const GeomDev &g, F3 org, F3 dir, float dd) {
     const F3 oc = org - f3(g.centre[0], g.centre[1], g.centre[2]);
     const float oo = dot(oc, oc);
     const float od = dot(oc, dir);

@@ -29,8 +29,11 @@ __global__ void k_test_intersect(const GeomDev *geoms, const int *gidx, const fl
     // odd lanes take the early-miss variant so both instantiations are checked against the golden vectors
     // the certain-miss shortcut must agree with the full test on every golden vector
     F3 nsrc = f3(0, 0, 0);
-    const bool cull = G.type == 0 && sphereCertainMiss(G, ro, rd, dot(rd, rd));
-    if (cull && sphereIntersectionTest(G, ro, rd, P, nsrc, o) != -1.0f) { t[i] = __builtin_nanf(""); return; }
+    const bool cull = certainMiss(G, ro, rd, dot(rd, rd));
+    if (cull && (G.type == 0 ? sphereIntersectionTest(G, ro, rd, P, nsrc, o) : boxIntersectionTest<false>(G, ro, rd, P, nsrc, o)) != -1.0f) {
+        t[i] = __builtin_nanf("");
+        return;
+    }
     t[i] = G.type == 0 ? (cull ? -1.0f : sphereIntersectionTest(G, ro, rd, P, nsrc, o))
          : ((i & 1) ? boxIntersectionTest<true>(G, ro, rd, P, nsrc, o) : boxIntersectionTest<false>(G, ro, rd, P, nsrc, o));
     if (t[i] != -1.0f) N = hitNormal(G, nsrc, o);   // the normal is an output of the reference's tests: same values here
@@ -38,8 +41,8 @@ __global__ void k_test_intersect(const GeomDev *geoms, const int *gidx, const fl
     n3[3 * i] = N.x; n3[3 * i + 1] = N.y; n3[3 * i + 2] = N.z;
     outside[i] = o ? 1 : 0;
 }
-// sphereCertainMiss soundness sweep: pseudo-random rays (origins up to ~60 units away, aimed near the sphere
-// so that grazing cases are dense) against every sphere of `geoms`; counts culled rays and VIOLATIONS
+// certainMiss soundness sweep: pseudo-random rays (origins up to ~60 units away, aimed near the primitive's bounding
+// ball so that grazing cases are dense) against every primitive of `geoms`; counts culled rays and VIOLATIONS
 // (culled although the full test returns a hit).
 __global__ void k_sweep_sphere_cull(const GeomDev *geoms, int ngeoms, unsigned long long seed, int per_thread,
                                     unsigned long long *culled, unsigned long long *violations) {
@@ -52,21 +55,21 @@ __global__ void k_sweep_sphere_cull(const GeomDev *geoms, int ngeoms, unsigned l
             u[j] = (float)(x >> 40) * (1.0f / 16777216.0f);
         }
         const GeomDev G = geoms[(blockIdx.x + k) % ngeoms];
-        if (G.type != 0) continue;
         const F3 c = f3(G.centre[0], G.centre[1], G.centre[2]);
         const float dist = __builtin_exp2f(u[0] * 12.0f - 6.0f);                 // 1/64 .. 64 units
         const F3 od = normalize(f3(u[1] - 0.5f, u[2] - 0.5f, u[3] - 0.5f));
         const F3 org = c + od * dist;
         // aim at a point within ~1.3 bounding radii of the centre: hits, grazes and near misses
-        const float R = __builtin_sqrtf(G.cullR2 * 4.0f) * 0.5f;
+        const float R = __builtin_sqrtf(G.cullR2);
         const F3 tgt = c + f3(u[4] - 0.5f, u[5] - 0.5f, u[6] - 0.5f) * (2.6f * R);
         F3 dir = normalize(tgt - org);
         if (u[7] < 0.1f) dir = -dir;
-        if (sphereCertainMiss(G, org, dir, dot(dir, dir))) {
+        if (certainMiss(G, org, dir, dot(dir, dir))) {
             ++nc;
             F3 P, N;
             bool o;
-            if (sphereIntersectionTest(G, org, dir, P, N, o) != -1.0f) ++nv;   // (N receives the normal source here)
+            const float t = G.type == 0 ? sphereIntersectionTest(G, org, dir, P, N, o) : boxIntersectionTest<false>(G, org, dir, P, N, o);
+            if (t != -1.0f) ++nv;   // (N receives the normal source here)
         }
     }
     if (nc) atomicAdd(culled, (unsigned long long)nc);

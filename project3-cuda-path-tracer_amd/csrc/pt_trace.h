@@ -14,10 +14,10 @@ constexpr int kMaxDepthSlots = PT_MAX_DEPTH + 2;
 
 // ---- device control block ------------------------------------------------------------------------
 constexpr int kOct = 8;              // direction octants: paths are binned by the signs of their new direction ...
-constexpr int kCls = 2 * kOct;       // ... and by "may hit a sphere" (bit 3): 16 classes
+constexpr int kCls = 2 * kOct;       // ... and by "may hit a small primitive" (bit 3): 16 classes
 constexpr int kSub = 4;              // append-counter shards per class (workgroup blockIdx % kSub)
 constexpr int kSeg = kCls * kSub;    // path buffers are split into kSeg segments with one append counter each
-constexpr int kBinSpheresMax = 4;    // scenes with more spheres do not bin by sphere candidacy (every path is a candidate)
+constexpr int kBinMax = 4;           // at most this many small primitives take part in the binning
 constexpr int kCtrPad = 32;          // one counter per 128-byte line: same-line atomics serialise at the memory side
 
 struct Ctrl {
@@ -43,8 +43,8 @@ struct KParams {
     int   traceDepth;
     int   segCap;       // capacity (paths) of one segment of a path buffer, multiple of kBlock
     int   sceneRect[4]; // union of the primitives' pixel rectangles (GeomDev::rect): camera rays outside miss everything
-    int   nBinSpheres;  // 1..kBinSpheresMax: the scene's spheres, survivors are binned by whether they can hit one; 0: off
-    int   binSphere[kBinSpheresMax];   // their geom indices
+    int   nBinned;      // 1..kBinMax small primitives (spheres, small cubes): survivors are binned by whether they can
+    int   binGeom[kBinMax];   // hit one of them (certainMiss of each); 0: off, every path counts as a candidate
 };
 
 // SoA PathSegment buffer: 11 arrays of `cap` = kSeg * segCap 4-byte elements, array k at base + k*cap
@@ -93,16 +93,18 @@ __global__ __launch_bounds__(kBlock) void k_debug_camera_rays(KParams prm, int i
 // ---- one bounce: intersect + shade + accumulate + compact (spec S3-S8) -----------------------------
 // Persistent workgroups walk the 256-path tiles of the bounce's queue (the kSeg input segments laid
 // end to end), blockIdx-strided.  Survivors are BINNED BY CLASS while they are compacted:
-//   class     = octant(new direction) | sphereCandidate << 3, where sphereCandidate = the new ray is not a certain
-//               miss (sphereCertainMiss) of every sphere of the scene (scenes with 1..kBinSpheresMax spheres; else 1),
+//   class     = octant(new direction) | candidate << 3, where candidate = the new ray is not a certain miss
+//               (certainMiss: bounding ball with a 50x safety margin) of every SMALL primitive of the scene -- its
+//               spheres and the cubes much smaller than the scene, at most kBinMax, chosen by pt_init,
 //   segment   = class * kSub + blockIdx % kSub,
 //   rank      = position among the wave's lanes of the same class (four bit ballots -> same-class mask -> mbcnt) plus
 //               the earlier waves' totals through LDS = workgroup-level exclusive scan per class,
 //   base      = ONE atomicAdd per non-empty class of the tile on that segment's counter (16 lanes, one instruction).
 // A tile of the next bounce therefore holds rays of a single direction octant, which turns the exact early-miss of
-// the box test (pt_device.h) into a wave-uniform branch for axis-aligned boxes, and either sphere candidates only
-// -- whose sphere tests then run with full waves instead of a few lanes -- or paths that skip the spheres altogether
-// (the flag is a sufficient condition for the reference's own miss, evaluated on the very ray that is stored).
+// the box test (pt_device.h) into a wave-uniform branch for axis-aligned boxes, and either candidates only -- whose
+// tests of the small primitives then run with full waves instead of a few lanes -- or paths that skip the small
+// primitives altogether (the flag is a sufficient condition for the reference's own miss, evaluated on the very ray
+// that is stored).
 // Queue order never influences results: RNG and accumulator are keyed on the pixel index.
 // No workgroup ever waits for another one, so there is no residency / dispatch-order assumption.
 // A segment receives survivors of the tiles of the workgroups with one value of blockIdx % kSub only,
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(kBlock, 6) void k_bounce(KParams prm, int iter, int
     for (uint32_t T = blockIdx.x; T < numTiles; T += gridDim.x) {
         bool valid;
         uint32_t idx = 0;
-        bool sphereTile = true;             // wave-uniform: this tile's paths may hit a sphere
+        bool smallTile = true;              // wave-uniform: this tile's paths may hit a small (binned) primitive
         if (FIRST) {
             idx = T * kBlock + threadIdx.x;                     // position in this shard's pixel list
             valid = idx < nLive;
@@ -201,11 +203,11 @@ __global__ __launch_bounds__(kBlock, 6) void k_bounce(KParams prm, int iter, int
             const uint32_t local = (T - s_segpre[sgIn]) * kBlock + threadIdx.x;
             valid = local < s_segcnt[sgIn];
             idx = sgIn * (uint32_t)prm.segCap + local;
-            sphereTile = ((sgIn / kSub) & 8u) != 0u;
+            smallTile = ((sgIn / kSub) & 8u) != 0u;
         }
 
         bool alive = false;
-        bool sphereCand = true;                                 // class bit 3 of a survivor
+        bool smallCand = true;                                  // class bit 3 of a survivor
         bool lightHit = false, missed = false;
         F3 org = f3(0, 0, 0), dir = f3(0, 0, 1), col = f3(0, 0, 0);
         int pix = 0, rem = 0;
@@ -246,10 +248,10 @@ __global__ __launch_bounds__(kBlock, 6) void k_bounce(KParams prm, int iter, int
                 bool o = false;
                 float t = -1.0f;
                 if (FIRST && (px < G.rect[0] || px > G.rect[2] || py < G.rect[1] || py > G.rect[3])) continue;
+                if (!FIRST && !smallTile && G.binned) continue;  // this tile's paths certainly miss every binned primitive
                 if (type == 0) {
-                    if (!sphereTile) continue;                   // binned as a certain miss of every sphere
                     probe(3);
-                    if (!sphereCertainMiss(G, org, dir, dd)) t = sphereIntersectionTest<FIRST>(G, org, dir, p, n, o);
+                    if (!certainMiss(G, org, dir, dd)) t = sphereIntersectionTest<FIRST>(G, org, dir, p, n, o);
                 } else {
                     t = boxIntersectionTest<true, FIRST>(G, org, dir, p, n, o);
                 }
@@ -320,11 +322,11 @@ __global__ __launch_bounds__(kBlock, 6) void k_bounce(KParams prm, int iter, int
                     org = norg;
                     dir = ndir;
                     alive = true;
-                    if (prm.nBinSpheres > 0) {                   // class bit 3: can the new ray hit a sphere at all?
+                    if (prm.nBinned > 0) {                       // class bit 3: can the new ray hit a small primitive at all?
                         const float ndd = dot(ndir, ndir);
-                        sphereCand = false;
-                        for (int sI = 0; sI < prm.nBinSpheres; ++sI)
-                            sphereCand = sphereCand || !sphereCertainMiss(ggeoms[prm.binSphere[sI]], norg, ndir, ndd);
+                        smallCand = false;
+                        for (int sI = 0; sI < prm.nBinned; ++sI)
+                            smallCand = smallCand || !certainMiss(ggeoms[prm.binGeom[sI]], norg, ndir, ndd);
                     }
                 }
             }
@@ -338,10 +340,10 @@ __global__ __launch_bounds__(kBlock, 6) void k_bounce(KParams prm, int iter, int
             // same-class mask of this lane from four bit ballots (the sign compares already are the ballots)
             const unsigned long long ba = __ballot(alive);
             const unsigned long long b0 = __ballot(dir.x < 0.0f), b1 = __ballot(dir.y < 0.0f), b2 = __ballot(dir.z < 0.0f);
-            const unsigned long long b3 = __ballot(sphereCand);
+            const unsigned long long b3 = __ballot(smallCand);
             const bool c0 = dir.x < 0.0f, c1 = dir.y < 0.0f, c2 = dir.z < 0.0f;
-            const uint32_t cls = (c0 ? 1u : 0u) | (c1 ? 2u : 0u) | (c2 ? 4u : 0u) | (sphereCand ? 8u : 0u);
-            const unsigned long long same = ba & (c0 ? b0 : ~b0) & (c1 ? b1 : ~b1) & (c2 ? b2 : ~b2) & (sphereCand ? b3 : ~b3);
+            const uint32_t cls = (c0 ? 1u : 0u) | (c1 ? 2u : 0u) | (c2 ? 4u : 0u) | (smallCand ? 8u : 0u);
+            const unsigned long long same = ba & (c0 ? b0 : ~b0) & (c1 ? b1 : ~b1) & (c2 ? b2 : ~b2) & (smallCand ? b3 : ~b3);
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(same >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)same, 0u));
             if (alive && rank == 0u) wv[wave * kCls + cls] = (uint32_t)__popcll(same);   // the class's first lane
             __syncthreads();

@@ -112,7 +112,7 @@ def test_unscaled_sqrt_exhaustive(gpu):
 
 
 def test_sphere_culling_never_rejects_a_hit(gpu, oracle):
-    # sphereCertainMiss is a sufficient condition for the reference's `radicand < 0` exit; 2^28 rays (dense in
+    # certainMiss is a sufficient condition for the reference's `radicand < 0` exit; 2^28 rays (dense in
     # grazing cases, origins 1/64 .. 64 units away) against uniform spheres, ellipsoids, tiny and huge ones
     geoms = np.concatenate([
         oracle.make_geom(0, 0, (-1, 4, -1), (0, 0, 0), (3, 3, 3)),            # Cornell sphere
@@ -125,6 +125,25 @@ def test_sphere_culling_never_rejects_a_hit(gpu, oracle):
     culled, bad = gpu.test_sphere_cull_sweep(geoms, 2024, 1 << 28)
     assert bad == 0
     assert culled > (1 << 28) // 10           # the shortcut actually fires (most sweep rays are aimed at the sphere)
+
+
+def test_cube_culling_never_rejects_a_hit(gpu, oracle):
+    # the same bounding-ball test decides which queue tiles skip the scene's small cubes (k_bounce bins survivors by
+    # it): it must imply the reference's own miss for cubes of every shape -- the Cornell light and walls, thin plates
+    # seen edge-on, rotated and sheared-looking boxes, tiny and huge ones
+    geoms = np.concatenate([
+        oracle.make_geom(1, 0, (0, 10, 0), (0, 0, 0), (3, 0.3, 3)),           # Cornell light
+        oracle.make_geom(1, 0, (0, 5, -5), (0, 90, 0), (0.01, 10, 10)),       # Cornell back wall (1000:1)
+        oracle.make_geom(1, 0, (1, 2, 3), (30, 45, 60), (1, 2, 3)),
+        oracle.make_geom(1, 0, (0, 0, 0), (0, 0, 0), (1, 1, 1)),              # the unit cube itself
+        oracle.make_geom(1, 0, (2.5, 6, -2), (10, 20, 30), (0.05, 0.05, 0.05)),
+        oracle.make_geom(1, 0, (-3, 1, 2), (75, -20, 130), (8, 0.5, 3)),
+        oracle.make_geom(1, 0, (100, -50, 25), (45, 45, 45), (40, 40, 40)),
+        oracle.make_geom(1, 0, (0.5, 0.25, -0.75), (0, 0, 45), (2, 2, 0.2)),
+    ]).view(gpu.GEOM_DTYPE)
+    culled, bad = gpu.test_sphere_cull_sweep(geoms, 77, 1 << 28)
+    assert bad == 0
+    assert culled > (1 << 28) // 10
 
 
 def test_reflect_refract_bit_exact(gpu):
