@@ -89,7 +89,8 @@ struct State {
     MaterialDev *dmats = nullptr;
     int numTilesMax = 0;    // upper bound of tiles in one bounce queue (incl. one partial tile per segment)
     int segCap = 0;         // paths per segment; a path buffer holds kSeg * segCap paths per array
-    int grid = 0;
+    int grid = 0;           // persistent grid of k_bounce<false>
+    int gridFirst = 0;      // ... and of k_bounce<true> (its own register budget, hence its own residency)
     size_t ldsBytes = 0;
     long long iterations = 0;
     long long seq = 0;      // iterations enqueued since pt_init: slot = seq % nslots
@@ -167,6 +168,17 @@ void pack_geom(const PtGeom &g, GeomDev &d, const float *eye = nullptr) {
         }
     }
 }
+// n / d for every n < 2^27 as (n * magic) >> shift: with s = ceil(log2 d), shift = 28 + s and magic = ceil(2^shift / d)
+// (< 2^29) the error e = magic * d - 2^shift is below d <= 2^s, so n * e < 2^(27 + s) < 2^shift and the quotient is exact
+// (Granlund-Montgomery); n * magic < 2^56 fits the 64-bit product.
+void magic_divisor(uint32_t d, uint32_t &magic, uint32_t &shift) {
+    if (d <= 1) { magic = 1; shift = 0; return; }
+    uint32_t s = 0;
+    while ((1ull << s) < d) ++s;
+    shift = 28 + s;
+    magic = (uint32_t)(((1ull << shift) + d - 1) / d);
+}
+
 void pack_material(const PtMaterial &m, MaterialDev &d) {
     memset(&d, 0, sizeof d);
     d.color[0] = m.color.x; d.color[1] = m.color.y; d.color[2] = m.color.z;
@@ -264,7 +276,7 @@ int launch_bounce(Slot &sl, int iter, int batch, int depth, bool lastBounce, flo
         HIPCHECK(hipEventRecord(e0, sl.stream));
     }
     if (depth == 1)
-        hipLaunchKernelGGL(k_bounce<true>, dim3(S.grid), dim3(kBlock), S.ldsBytes, sl.stream, S.prm, iter, batch, depth,
+        hipLaunchKernelGGL(k_bounce<true>, dim3(S.gridFirst), dim3(kBlock), S.ldsBytes, sl.stream, S.prm, iter, batch, depth,
                            lastBounce ? 1 : 0, sl.parity, in, out, sl.ctrl, S.dgeoms, S.dmats, contrib);
     else
         hipLaunchKernelGGL(k_bounce<false>, dim3(S.grid), dim3(kBlock), S.ldsBytes, sl.stream, S.prm, iter, batch, depth,
@@ -430,6 +442,16 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     k.W = Wd; k.H = H;
     k.shardRank = o.shard_rank; k.shardCount = o.shard_count;
     k.nLocal = S.nLocal;
+    magic_divisor((uint32_t)Wd, k.magicW, k.shiftW);
+    magic_divisor((uint32_t)std::max(S.nLocal, 1), k.magicN, k.shiftN);
+    for (uint32_t d : {(uint32_t)Wd, (uint32_t)std::max(S.nLocal, 1)}) {       // self-check on the edges of every quotient range
+        uint32_t m, sh;
+        magic_divisor(d, m, sh);
+        for (uint64_t q = 0; q * d < (1ull << 27); q = q < 64 ? q + 1 : q * 2 + 1)
+            for (uint64_t n : {q * d, q * d + d - 1})
+                if (n < (1ull << 27) && (uint32_t)((n * m) >> sh) != (uint32_t)(n / d))
+                    return fail(PT_ERR_INVALID, "pt_init: magic division self-check failed for d=%u n=%llu", d, (unsigned long long)n);
+    }
     k.ngeoms = ngeoms; k.nmats = nmats;
     k.traceDepth = traceDepth;
 
@@ -521,11 +543,15 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
         HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bounce<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.ldsBytes));
         HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bounce<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.ldsBytes));
     }
-    int rc = persistent_grid(reinterpret_cast<const void *>(k_bounce<false>), S.ldsBytes, &S.grid);
-    if (rc) return rc;
-    if (S.grid > S.numTilesMax) S.grid = S.numTilesMax;
-    S.grid = (S.grid / kSub) * kSub;      // T % kSub == blockIdx % kSub for every tile T of a workgroup
-    if (S.grid < kSub) S.grid = kSub;
+    for (int first = 0; first < 2; ++first) {
+        int &grid = first ? S.gridFirst : S.grid;
+        int rc = persistent_grid(first ? reinterpret_cast<const void *>(k_bounce<true>) : reinterpret_cast<const void *>(k_bounce<false>),
+                                 S.ldsBytes, &grid);
+        if (rc) return rc;
+        if (grid > S.numTilesMax) grid = S.numTilesMax;
+        grid = (grid / kSub) * kSub;      // T % kSub == blockIdx % kSub for every tile T of a workgroup
+        if (grid < kSub) grid = kSub;
+    }
     HIPCHECK(hipDeviceSynchronize());
     S.init = true;
     g_err.clear();

@@ -43,6 +43,9 @@ struct KParams {
     int   traceDepth;
     int   segCap;       // capacity (paths) of one segment of a path buffer, multiple of kBlock
     int   sceneRect[4]; // union of the primitives' pixel rectangles (GeomDev::rect): camera rays outside miss everything
+    // n / W and n / nLocal for n < 2^27 as (n * magic) >> shift (exact, see pt_init): the two divisions of the
+    // camera-ray bounce cost ~50 instructions each when the compiler expands them
+    uint32_t magicW, shiftW, magicN, shiftN;
     int   nBinned;      // 1..kBinMax small primitives (spheres, small cubes): survivors are binned by whether they can
     int   binGeom[kBinMax];   // hit one of them (certainMiss of each); 0: off, every path counts as a candidate
 };
@@ -58,12 +61,19 @@ struct PathSoA {
     __host__ __device__ __forceinline__ int *rem() const { return reinterpret_cast<int *>(base + (size_t)10 * cap); }
 };
 
+__device__ __forceinline__ uint32_t fastDiv(uint32_t n, uint32_t magic, uint32_t shift) {
+    return (uint32_t)(((unsigned long long)n * magic) >> shift);
+}
+
 // ---- camera ray of the j-th pixel of this shard (spec S2) ------------------------------------------
-__device__ __forceinline__ void cameraRay(const KParams &prm, int iter, int j, int &pix, int &x, int &y, F3 &org, F3 &dir) {
-    const int lr = j / prm.W;
+// pixel coordinates and global pixel index of the shard's j-th pixel
+__device__ __forceinline__ void shardPixel(const KParams &prm, int j, int &pix, int &x, int &y) {
+    const int lr = (int)fastDiv((uint32_t)j, prm.magicW, prm.shiftW);
     x = j - lr * prm.W;
     y = lr * prm.shardCount + prm.shardRank;
     pix = x + y * prm.W;
+}
+__device__ __forceinline__ void cameraRayAt(const KParams &prm, int iter, int pix, int x, int y, F3 &org, F3 &dir) {
     Rng rng = makeSeededRandomEngine(iter, pix, 0);
     const float jx = u01(rng);
     const float jy = u01(rng);
@@ -76,6 +86,10 @@ __device__ __forceinline__ void cameraRay(const KParams &prm, int iter, int j, i
     const F3 right = f3(prm.right[0], prm.right[1], prm.right[2]);
     org = f3(prm.pos[0], prm.pos[1], prm.pos[2]);
     dir = normalize((view - right * a) - up * b);
+}
+__device__ __forceinline__ void cameraRay(const KParams &prm, int iter, int j, int &pix, int &x, int &y, F3 &org, F3 &dir) {
+    shardPixel(prm, j, pix, x, y);
+    cameraRayAt(prm, iter, pix, x, y, org, dir);
 }
 
 // camera rays alone, for pt_debug_trace_paths(bounces = 0)
@@ -114,11 +128,12 @@ __global__ __launch_bounds__(kBlock) void k_debug_camera_rays(KParams prm, int i
 // j = 256 T + lane of this shard's pixel list and the ray is built in registers, so the first bounce
 // reads no path state at all.
 //
-// Six workgroups per CU (6 waves per SIMD, <= 85 VGPRs, a dozen cold spills): measured against 5 / 7 / 8 resident waves
+// Six workgroups per CU (6 waves per SIMD, <= 85 VGPRs, a few cold spills): measured against 5 / 7 / 8 resident waves
 // this is the optimum (93.9 vs 90.7 / 78.1 / 62.8 G paths/s) -- more waves hide the tile-start loads and the compaction's
-// atomic round trip, beyond 6 the spills reach the intersection loop.
+// atomic round trip, beyond 6 the spills reach the intersection loop.  The camera-ray bounce reads no path state and
+// would spill inside its intersection loop at 85 registers: it runs with five.
 template <bool FIRST>
-__global__ __launch_bounds__(kBlock, 6) void k_bounce(KParams prm, int iter, int batch, int depth, int lastBounce, int parity,
+__global__ __launch_bounds__(kBlock, FIRST ? 5 : 6) void k_bounce(KParams prm, int iter, int batch, int depth, int lastBounce, int parity,
                                                    PathSoA in, PathSoA out, Ctrl *ctrl,
                                                    const GeomDev *__restrict__ ggeoms,
                                                    const MaterialDev *__restrict__ gmats, float *contrib) {
@@ -214,9 +229,16 @@ __global__ __launch_bounds__(kBlock, 6) void k_bounce(KParams prm, int iter, int
         int itb = 0;                                            // which iteration of the batch this path belongs to
         int px = 0, py = 0;                                     // pixel coordinates (FIRST only)
         if (valid) {
+            // Camera rays (FIRST): a primitive is reachable only from the pixels inside the projection of its bounding
+            // cube (GeomDev::rect, 2-pixel margin >> any rounding of the reference's tests), and nothing is reachable
+            // outside the union of those rectangles -- at 16:9 more than half of Cornell's camera rays, which are not
+            // even generated: they are misses whatever their jitter.
+            bool inScene = true;
             if (FIRST) {
-                itb = (int)(idx / (uint32_t)prm.nLocal);
-                cameraRay(prm, iter + itb, (int)(idx - (uint32_t)itb * (uint32_t)prm.nLocal), pix, px, py, org, dir);
+                itb = (int)fastDiv(idx, prm.magicN, prm.shiftN);
+                shardPixel(prm, (int)(idx - (uint32_t)itb * (uint32_t)prm.nLocal), pix, px, py);
+                inScene = px >= prm.sceneRect[0] && px <= prm.sceneRect[2] && py >= prm.sceneRect[1] && py <= prm.sceneRect[3];
+                if (inScene) cameraRayAt(prm, iter + itb, pix, px, py, org, dir);
                 col = f3(1.0f, 1.0f, 1.0f);
                 rem = prm.traceDepth;
             } else {
@@ -236,11 +258,6 @@ __global__ __launch_bounds__(kBlock, 6) void k_bounce(KParams prm, int iter, int
             F3 P = f3(0, 0, 0), nsrc = f3(0, 0, 0);
             bool outside = false;
             const float dd = dot(dir, dir);
-            // Camera rays (FIRST): a primitive is reachable only from the pixels inside the projection of its bounding
-            // cube (GeomDev::rect, 2-pixel margin >> any rounding of the reference's tests), and nothing is reachable
-            // outside the union of those rectangles -- at 16:9 more than half of Cornell's camera rays.
-            const bool inScene = !FIRST || (px >= prm.sceneRect[0] && px <= prm.sceneRect[2] &&
-                                            py >= prm.sceneRect[1] && py <= prm.sceneRect[3]);
             for (int g = 0; inScene && g < prm.ngeoms; ++g) {
                 const GeomDev &G = ggeoms[g];
                 const int type = G.type;
