@@ -1,0 +1,98 @@
+"""The N > 1 data path with the HIP kernels: every rank renders its row shard on the GPU into a packed torch
+accumulator (PT_FLAG_ACCUM_SHARD_ROWS), the SAME `gather_frame` bench.py uses assembles the frame at rank 0, and
+rank 0 compares it bit for bit with the unsharded CPU oracle.
+
+The GPU box has one card and RCCL wants one card per rank, so the collective runs over gloo here (what
+BENCH_BACKEND=gloo does for bench.py); the rest -- sharding, packed accumulation, batching, the caller's stream,
+the interleave at rank 0 -- is the code the 8-GPU run executes."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, SCENES
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, res, batches, out_path):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch
+    import __graft_entry__ as ge
+    pt = ge.load_package()
+    ptdist = ge.load_submodule("distributed")
+    ptdist.init_process_group("gloo")
+    torch.cuda.set_device(0)
+    W, H = res
+    depth = 6
+    sc = pt.Scene(os.path.join(SCENES, "cornell_glass.txt"))
+    sc.set_resolution(W, H)
+    accum = torch.zeros(ptdist.padded_block_floats(W, H, world), dtype=torch.float32, device="cuda")
+    frame = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda") if rank == 0 else None
+    bufs = ptdist.make_gather_buffers(accum, world, rank)
+    pt.pathtraceInit(sc, shard_rank=rank, shard_count=world, stream=torch.cuda.current_stream().cuda_stream,
+                     accum_dev=accum.data_ptr(), device=0, flags=pt.PT_FLAG_ACCUM_SHARD_ROWS, traceDepth=depth,
+                     pipeline_depth=3, max_batch=max(batches))
+    ok, it = True, 1
+    if rank == 0:
+        import oracle as orc
+        ref = orc.Renderer(sc.camera.view(orc.CAMERA_DTYPE), sc.geoms.view(orc.GEOM_DTYPE),
+                           sc.materials.view(orc.MATERIAL_DTYPE), depth)
+        want = np.zeros(W * H * 3, np.float32)
+    for n in batches:
+        pt.pathtrace_batch(None, 0, it, n)
+        ptdist.gather_frame(accum, bufs, frame, W, H, dst=0)       # after every committed batch, like bench.py
+        if rank == 0:
+            for k in range(n):
+                ref.iterate(it + k, want)
+            got = frame.cpu().numpy()
+            ok = ok and np.array_equal(got.view(np.uint32), want.view(np.uint32)) and want.max() > 0
+        it += n
+    pt.pathtraceFree()
+    if rank == 0:
+        np.save(out_path, np.array([1 if ok else 0]))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,res", [(2, (96, 54)), (3, (80, 50))])      # even shards (one strided copy) and ragged ones
+def test_ranks_render_their_rows_on_the_gpu_and_gather_the_frame(pt, tmp_path, world, res):
+    if pt.device_count() < 1:
+        pytest.fail("no HIP device: GPU tests must run on the MI355X box")
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "ok.npy")
+    mp.spawn(_worker, args=(world, port, res, [4, 1, 7], out), nprocs=world, join=True)
+    assert np.load(out)[0] == 1
+
+
+def test_bench_two_ranks_contract(pt):
+    # bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, one process per rank), gloo
+    # standing in for RCCL because both ranks share the box's single GPU
+    if pt.device_count() < 1:
+        pytest.fail("no HIP device: GPU tests must run on the MI355X box")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "48", "--warmup", "16"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                          # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 48 and d["warmup"] == 16 and d["scaling"] == "strong"
+    assert "cpu_baseline" not in d and d["value"] > 0
+    assert "rows sharded y%2" in d["config"]["workload"] and d["config"]["iterations_per_wavefront_batch"] == 32
