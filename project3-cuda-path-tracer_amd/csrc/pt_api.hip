@@ -551,6 +551,15 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
         if (grid > S.numTilesMax) grid = S.numTilesMax;
         grid = (grid / kSub) * kSub;      // T % kSub == blockIdx % kSub for every tile T of a workgroup
         if (grid < kSub) grid = kSub;
+        // Camera-ray bounce: tile T covers pixels 256 T ... of the row-major frame, and a workgroup owns the tiles
+        // b, b + grid, ...  When the grid is a multiple of the tiles per row (1280 workgroups, 5 tiles per 1280-pixel
+        // row) every workgroup stays in ONE column band of the frame, and the bands outside the scene rectangle finish
+        // 15x earlier than the others.  A grid coprime to the tiles per row walks every workgroup through all bands.
+        if (first && Wd % kBlock == 0) {
+            const int perRow = Wd / kBlock;
+            auto gcd = [](int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; };
+            while (grid > kSub && gcd(grid, perRow) != 1) grid -= kSub;
+        }
     }
     HIPCHECK(hipDeviceSynchronize());
     S.init = true;
