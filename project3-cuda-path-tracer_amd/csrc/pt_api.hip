@@ -537,7 +537,7 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     HIPCHECK(hipMemcpy(S.dmats, hm.data(), hm.size() * sizeof(MaterialDev), hipMemcpyHostToDevice));
 
     S.ldsBytes = sizeof(MaterialDev) * nmats + sizeof(GeomHitDev) * ngeoms +
-                 (kWaves * kCls + kCls + kSeg + kSeg + 2 + 2) * sizeof(uint32_t);
+                 (kWaves * kCls + kCls + kSeg + kSeg + 2 + 2 * PT_MAX_BATCH + 2) * sizeof(uint32_t);
     if (S.ldsBytes > 160 * 1024) return fail(PT_ERR_INVALID, "pt_init: scene does not fit the 160 KiB LDS (%zu B)", S.ldsBytes);
     if (S.ldsBytes > 64 * 1024) {
         HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bounce<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.ldsBytes));

@@ -156,12 +156,19 @@ __device__ __forceinline__ uint32_t mod_m31(uint64_t p) {
     return q >= m ? q - m : q;
 }
 // src/pathtrace.cu:41-45
-__device__ __forceinline__ Rng makeSeededRandomEngine(int iter, int index, int depth) {
-    uint32_t h = utilhash((1u << 31) | ((uint32_t)depth << 22) | (uint32_t)iter) ^ utilhash((uint32_t)index);
-    uint32_t x = mod_m31(h);
+// the iteration/depth half of the seed: the same word for every pixel of a launch (per iteration of its batch), so the
+// render kernel hashes it once per workgroup into LDS instead of once per path
+__device__ __forceinline__ uint32_t iterationHash(int iter, int depth) {
+    return utilhash((1u << 31) | ((uint32_t)depth << 22) | (uint32_t)iter);
+}
+__device__ __forceinline__ Rng makeSeededRandomEngineHashed(uint32_t iterHash, int index) {
+    uint32_t x = mod_m31(iterHash ^ utilhash((uint32_t)index));
     Rng r;
     r.x = x == 0u ? 1u : x;
     return r;
+}
+__device__ __forceinline__ Rng makeSeededRandomEngine(int iter, int index, int depth) {
+    return makeSeededRandomEngineHashed(iterationHash(iter, depth), index);
 }
 __device__ __forceinline__ Rng seedEngine(uint32_t h) {
     uint32_t x = mod_m31(h);

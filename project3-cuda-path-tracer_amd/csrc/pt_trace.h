@@ -73,8 +73,9 @@ __device__ __forceinline__ void shardPixel(const KParams &prm, int j, int &pix, 
     y = lr * prm.shardCount + prm.shardRank;
     pix = x + y * prm.W;
 }
-__device__ __forceinline__ void cameraRayAt(const KParams &prm, int iter, int pix, int x, int y, F3 &org, F3 &dir) {
-    Rng rng = makeSeededRandomEngine(iter, pix, 0);
+// iterHash0 = iterationHash(iter, 0): camera jitter draws from the depth-0 stream of (iter, pixel)
+__device__ __forceinline__ void cameraRayAt(const KParams &prm, uint32_t iterHash0, int pix, int x, int y, F3 &org, F3 &dir) {
+    Rng rng = makeSeededRandomEngineHashed(iterHash0, pix);
     const float jx = u01(rng);
     const float jy = u01(rng);
     const float sx = ((float)x + jx) - prm.halfW;
@@ -89,7 +90,7 @@ __device__ __forceinline__ void cameraRayAt(const KParams &prm, int iter, int pi
 }
 __device__ __forceinline__ void cameraRay(const KParams &prm, int iter, int j, int &pix, int &x, int &y, F3 &org, F3 &dir) {
     shardPixel(prm, j, pix, x, y);
-    cameraRayAt(prm, iter, pix, x, y, org, dir);
+    cameraRayAt(prm, iterationHash(iter, 0), pix, x, y, org, dir);
 }
 
 // camera rays alone, for pt_debug_trace_paths(bounces = 0)
@@ -150,6 +151,7 @@ __global__ __launch_bounds__(kBlock, FIRST ? 5 : 6) void k_bounce(KParams prm, i
     uint32_t *s_base = s_wave + kWaves * kCls;       // [kCls]   first output slot of this tile per class
     uint32_t *s_segcnt = s_base + kCls;              // [kSeg]   paths per input segment
     uint32_t *s_segpre = s_segcnt + kSeg;            // [kSeg+2] tile prefix per input segment, [kSeg+1] = live paths
+    uint32_t *s_iterHash = s_segpre + kSeg + 2;      // [2][PT_MAX_BATCH] iterationHash(iter + b, depth) and (iter + b, 0)
 
     if (lastBounce) {   // re-arm the next iteration: nobody touches the other parity's counters now
         uint32_t *other = &ctrl->seg_count[parity ^ 1][0][0][0];
@@ -182,6 +184,10 @@ __global__ __launch_bounds__(kBlock, FIRST ? 5 : 6) void k_bounce(KParams prm, i
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctrl->sum_live[depth], (unsigned long long)nLive);
     if (blockIdx.x >= numTiles) return;
     if (threadIdx.x < kWaves * kCls) s_wave[threadIdx.x] = 0u;
+    if (threadIdx.x < 2 * PT_MAX_BATCH) {
+        const int b = threadIdx.x % PT_MAX_BATCH;
+        s_iterHash[threadIdx.x] = iterationHash(iter + b, threadIdx.x < PT_MAX_BATCH ? depth : 0);
+    }
 
     // stage the materials in LDS once per (persistent) workgroup, 16 B per lane per step
     {
@@ -238,7 +244,7 @@ __global__ __launch_bounds__(kBlock, FIRST ? 5 : 6) void k_bounce(KParams prm, i
                 itb = (int)fastDiv(idx, prm.magicN, prm.shiftN);
                 shardPixel(prm, (int)(idx - (uint32_t)itb * (uint32_t)prm.nLocal), pix, px, py);
                 inScene = px >= prm.sceneRect[0] && px <= prm.sceneRect[2] && py >= prm.sceneRect[1] && py <= prm.sceneRect[3];
-                if (inScene) cameraRayAt(prm, iter + itb, pix, px, py, org, dir);
+                if (inScene) cameraRayAt(prm, s_iterHash[PT_MAX_BATCH + itb], pix, px, py, org, dir);
                 col = f3(1.0f, 1.0f, 1.0f);
                 rem = prm.traceDepth;
             } else {
@@ -294,7 +300,7 @@ __global__ __launch_bounds__(kBlock, FIRST ? 5 : 6) void k_bounce(KParams prm, i
                         px[0] = c.x; px[1] = c.y; px[2] = c.z;
                     }
                 } else if (!lastBounce) {                        // S6 scatter (S7: skipped on the last bounce)
-                    Rng rng = makeSeededRandomEngine(iter + itb, pix, depth);
+                    Rng rng = makeSeededRandomEngineHashed(s_iterHash[itb], pix);
                     const F3 scol = f3(M.specColor[0], M.specColor[1], M.specColor[2]);
                     F3 ndir, norg;
                     if (M.hasRefractive > 0.0f) {
