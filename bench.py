@@ -191,12 +191,18 @@ def main():
     launches = max(int(cnt.bounce_launches), 1)
     avg_ms = cnt.bounce_kernel_ms / launches
     achieved = bounce_bytes / launches / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    # PMC counters of the bounce kernel from the committed rocprofv3 passes -- only when they were collected on this
+    # very configuration (frame, depth and iterations per launch), else null
     traffic, pmc = None, {}
     try:
         pmc = json.load(open(args.pmc_traffic_json))
-        traffic = pmc.get("hbm_bytes_per_bounce_launch")
+        here = ["%s %dx%d" % (os.path.relpath(args.scene, ROOT), W, H), " %d bounces" % D]
+        if world == 1 and pmc.get("workload") == here and pmc.get("iterations_per_wavefront_batch") == B:
+            traffic = pmc.get("hbm_bytes_per_bounce_launch")
+        else:
+            pmc = {}
     except Exception:
-        pass
+        pmc = {}
 
     if rank == 0:
         nominal = P * D * args.steps

@@ -128,6 +128,15 @@ def main():
             pj["valu_wave_insts_per_bounce_launch"] = kb["SQ_INSTS_VALU"]
             pj["valu_issue_bound_ms_per_launch"] = kb["SQ_INSTS_VALU"] * 4.0 / (1024 * 2.4e9) * 1e3
             pj["lds_bank_conflict_cycles_per_launch"] = kb.get("SQ_LDS_BANK_CONFLICT")
+        # which bench configuration the counters belong to: bench.py reports them only for the same one
+        try:
+            for line in open(os.path.join(src, "pmc_fetch.log")):
+                if line.startswith("{"):
+                    b = json.loads(line)
+                    pj["workload"] = b["config"]["workload"].split(",")[0:1] + b["config"]["workload"].split(",")[2:3]
+                    pj["iterations_per_wavefront_batch"] = b["config"]["iterations_per_wavefront_batch"]
+        except (OSError, ValueError, KeyError):
+            pass
         json.dump(pj, open(os.path.join(HERE, "pmc_traffic.json"), "w"), indent=1)
     if "SQ_LDS_BANK_CONFLICT" in kb:
         out["k_bounce"]["lds_bank_conflict_cycles_per_launch"] = kb["SQ_LDS_BANK_CONFLICT"]

@@ -17,7 +17,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libpt_amd.so")
+# PT_AMD_LIB: another build of the same library (A/B measurements of kernel variants); never a different backend
+LIB_PATH = os.environ.get("PT_AMD_LIB") or os.path.join(HERE, "csrc", "libpt_amd.so")
 HOST_LIB_PATH = os.path.join(HERE, "host", "libpt_host.so")
 
 # byte-identical to reference src/sceneStructs.h:18-47 (include/pt_amd.h PtGeom/PtMaterial/PtCamera)

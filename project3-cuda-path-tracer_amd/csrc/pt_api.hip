@@ -91,6 +91,7 @@ struct State {
     int segCap = 0;         // paths per segment; a path buffer holds kSeg * segCap paths per array
     int grid = 0;           // persistent grid of k_bounce<false>
     int gridFirst = 0;      // ... and of k_bounce<true> (its own register budget, hence its own residency)
+    bool many = false;      // more than kBinMax spheres: the k_bounce<., true> variants (per-lane sphere lists)
     size_t ldsBytes = 0;
     long long iterations = 0;
     long long seq = 0;      // iterations enqueued since pt_init: slot = seq % nslots
@@ -275,12 +276,15 @@ int launch_bounce(Slot &sl, int iter, int batch, int depth, bool lastBounce, flo
         HIPCHECK(hipEventCreate(&e1));
         HIPCHECK(hipEventRecord(e0, sl.stream));
     }
-    if (depth == 1)
-        hipLaunchKernelGGL(k_bounce<true>, dim3(S.gridFirst), dim3(kBlock), S.ldsBytes, sl.stream, S.prm, iter, batch, depth,
-                           lastBounce ? 1 : 0, sl.parity, in, out, sl.ctrl, S.dgeoms, S.dmats, contrib);
-    else
-        hipLaunchKernelGGL(k_bounce<false>, dim3(S.grid), dim3(kBlock), S.ldsBytes, sl.stream, S.prm, iter, batch, depth,
-                           lastBounce ? 1 : 0, sl.parity, in, out, sl.ctrl, S.dgeoms, S.dmats, contrib);
+#define PT_LAUNCH_BOUNCE(FIRST_, MANY_, GRID_)                                                                              \
+    hipLaunchKernelGGL((k_bounce<FIRST_, MANY_>), dim3(GRID_), dim3(kBlock), S.ldsBytes, sl.stream, S.prm, iter, batch, depth, \
+                       lastBounce ? 1 : 0, sl.parity, in, out, sl.ctrl, S.dgeoms, S.dmats, contrib)
+    if (depth == 1) {
+        if (S.many) PT_LAUNCH_BOUNCE(true, true, S.gridFirst); else PT_LAUNCH_BOUNCE(true, false, S.gridFirst);
+    } else {
+        if (S.many) PT_LAUNCH_BOUNCE(false, true, S.grid); else PT_LAUNCH_BOUNCE(false, false, S.grid);
+    }
+#undef PT_LAUNCH_BOUNCE
     if (e0) {
         HIPCHECK(hipEventRecord(e1, sl.stream));
         S.evBounce.emplace_back(e0, e1);
@@ -464,7 +468,7 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
         S.ownImage = true;
         HIPCHECK(hipMemsetAsync(S.image, 0, n * 3 * sizeof(float), S.stream));
     }
-    // Path buffers: kSeg = kOct x kSub segments.  A segment receives survivors only from the workgroups with one
+    // Path buffers: kSeg = kCls x kSub segments.  A segment receives survivors only from the workgroups with one
     // value of blockIdx % kSub; tiles are blockIdx-strided and the grid is a multiple of kSub, so those workgroups
     // process at most ceil(tiles / kSub) tiles, and tiles <= ceil(nLocal/256) + kSeg (one partial tile per input
     // segment).  Worst case (every ray in one class) is provisioned: kCls = 16x the live paths, 650 MB per buffer at 720p.
@@ -536,29 +540,45 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     HIPCHECK(hipMemcpy(S.dgeoms, hg.data(), hg.size() * sizeof(GeomDev), hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(S.dmats, hm.data(), hm.size() * sizeof(MaterialDev), hipMemcpyHostToDevice));
 
-    S.ldsBytes = sizeof(MaterialDev) * nmats + sizeof(GeomHitDev) * ngeoms +
-                 (kWaves * kCls + kCls + kSeg + kSeg + 2 + 2 * PT_MAX_BATCH + 2) * sizeof(uint32_t);
+    int nspheres = 0;
+    for (int i = 0; i < ngeoms; ++i) nspheres += geoms[i].type == PT_SPHERE;
+    S.many = nspheres > kBinMax;
+    if (S.many && ngeoms > 65535) return fail(PT_ERR_INVALID, "pt_init: more than 65535 primitives");
+    S.ldsBytes = sizeof(MaterialDev) * nmats + sizeof(GeomHitDev) * ngeoms + kMiscWords * sizeof(uint32_t) +
+                 (S.many ? (size_t)ngeoms * kSphRowFloats * sizeof(float) + (size_t)kListMax * kBlock * sizeof(uint16_t) : 0);
     if (S.ldsBytes > 160 * 1024) return fail(PT_ERR_INVALID, "pt_init: scene does not fit the 160 KiB LDS (%zu B)", S.ldsBytes);
+    const void *kFirst = S.many ? reinterpret_cast<const void *>(k_bounce<true, true>) : reinterpret_cast<const void *>(k_bounce<true, false>);
+    const void *kNext = S.many ? reinterpret_cast<const void *>(k_bounce<false, true>) : reinterpret_cast<const void *>(k_bounce<false, false>);
     if (S.ldsBytes > 64 * 1024) {
-        HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bounce<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.ldsBytes));
-        HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bounce<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.ldsBytes));
+        HIPCHECK(hipFuncSetAttribute(kFirst, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.ldsBytes));
+        HIPCHECK(hipFuncSetAttribute(kNext, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.ldsBytes));
     }
     for (int first = 0; first < 2; ++first) {
         int &grid = first ? S.gridFirst : S.grid;
-        int rc = persistent_grid(first ? reinterpret_cast<const void *>(k_bounce<true>) : reinterpret_cast<const void *>(k_bounce<false>),
-                                 S.ldsBytes, &grid);
+        int rc = persistent_grid(first ? kFirst : kNext, S.ldsBytes, &grid);
         if (rc) return rc;
         if (grid > S.numTilesMax) grid = S.numTilesMax;
         grid = (grid / kSub) * kSub;      // T % kSub == blockIdx % kSub for every tile T of a workgroup
         if (grid < kSub) grid = kSub;
-        // Camera-ray bounce: tile T covers pixels 256 T ... of the row-major frame, and a workgroup owns the tiles
-        // b, b + grid, ...  When the grid is a multiple of the tiles per row (1280 workgroups, 5 tiles per 1280-pixel
-        // row) every workgroup stays in ONE column band of the frame, and the bands outside the scene rectangle finish
-        // 15x earlier than the others.  A grid coprime to the tiles per row walks every workgroup through all bands.
-        if (first && Wd % kBlock == 0) {
-            const int perRow = Wd / kBlock;
-            auto gcd = [](int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; };
-            while (grid > kSub && gcd(grid, perRow) != 1) grid -= kSub;
+    }
+    // Camera-ray bounce: tile T covers pixels 256 T ... of the row-major frame and a workgroup owns the tiles b, b + grid,
+    // ...  When the grid shares a factor with the tiles per row (1280 workgroups, 5 tiles per 1280-pixel row) a workgroup
+    // stays in few column bands of the frame, and the bands outside the scene rectangle finish 15x earlier than the
+    // others.  Either the grid can be made coprime to the tiles per row (both must stay multiples of kSub, so only for an
+    // odd tile count per row), or the kernel rotates the k-th tile of a workgroup k bands to the right inside its row,
+    // which needs a grid that is a multiple of the tiles per row (k_bounce<true, .>).
+    S.prm.tilesPerRow = 0;
+    if (Wd % kBlock == 0 && Wd / kBlock > 1) {
+        const int perRow = Wd / kBlock;
+        auto gcd = [](int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; };
+        if (gcd(perRow, kSub) == 1) {
+            for (int tries = 0; tries < 64 && S.gridFirst > kSub && gcd(S.gridFirst, perRow) != 1; ++tries) S.gridFirst -= kSub;
+        } else {
+            const int unit = perRow / gcd(perRow, kSub) * kSub;        // lcm(perRow, kSub)
+            if (S.gridFirst >= 4 * unit) {
+                S.gridFirst = S.gridFirst / unit * unit;
+                S.prm.tilesPerRow = perRow;
+            }
         }
     }
     HIPCHECK(hipDeviceSynchronize());

@@ -333,13 +333,14 @@ __device__ __forceinline__ bool certainMiss(const GeomDev &g, F3 org, F3 dir, fl
     return oo * dd - od * od > (g.cullR2 + g.cullK * oo) * dd;
 }
 
-// src/intersections.h:101-143 (pow(radius, 2) == 0.25f in the float overload nvcc selects)
-template <bool CAM_ORIGIN = false>
-__device__ __forceinline__ float sphereIntersectionTest(const GeomDev &g, F3 ro_w, F3 rd_w, F3 &P, F3 &nsrc,
-                                                        bool &outside) {
-    probe(4);
-    F3 ro = CAM_ORIGIN ? f3(g.camObj[0], g.camObj[1], g.camObj[2]) : mulMV(g.inv, ro_w, 1.0f);
-    F3 rd = normalize(mulMV(g.inv, rd_w, 0.0f));
+// src/intersections.h:101-143 (pow(radius, 2) == 0.25f in the float overload nvcc selects).
+// `inv`, `xf`: rows 0-2 of inverseTransform / transform as mulMV expects them -- SGPR operands when the sphere is
+// wave-uniform (GeomDev through the scalar path), registers when every lane tests its own sphere (k_bounce<., MANY>).
+// `camObj`: the precomputed object-space origin of a camera ray, or nullptr.
+__device__ __forceinline__ float sphereIntersectionTestM(const float *inv, const float *xf, const float *camObj, F3 ro_w, F3 rd_w,
+                                                         F3 &P, F3 &nsrc, bool &outside) {
+    F3 ro = camObj ? f3(camObj[0], camObj[1], camObj[2]) : mulMV(inv, ro_w, 1.0f);
+    F3 rd = normalize(mulMV(inv, rd_w, 0.0f));
     float vDotDirection = dot(ro, rd);
     float radicand = vDotDirection * vDotDirection - (dot(ro, ro) - 0.25f);
     if (radicand < 0) return -1.0f;
@@ -360,9 +361,15 @@ __device__ __forceinline__ float sphereIntersectionTest(const GeomDev &g, F3 ro_
     }
     probe(6);
     F3 obj = getPointOnRay(ro, rd, t);
-    P = mulMV(g.xf, obj, 1.0f);
+    P = mulMV(xf, obj, 1.0f);
     nsrc = obj;      // normal = +-normalize(invTranspose * (obj, 0)): hitNormal(), evaluated for the nearest hit only
     return length(ro_w - P);
+}
+template <bool CAM_ORIGIN = false>
+__device__ __forceinline__ float sphereIntersectionTest(const GeomDev &g, F3 ro_w, F3 rd_w, F3 &P, F3 &nsrc,
+                                                        bool &outside) {
+    probe(4);
+    return sphereIntersectionTestM(g.inv, g.xf, CAM_ORIGIN ? g.camObj : nullptr, ro_w, rd_w, P, nsrc, outside);
 }
 
 // The surface normal of a hit, from what the two tests leave in `nsrc` (src/intersections.h:85 and :137-140).

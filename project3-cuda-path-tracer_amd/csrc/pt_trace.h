@@ -18,6 +18,12 @@ constexpr int kCls = 2 * kOct;       // ... and by "may hit a small primitive" (
 constexpr int kSub = 4;              // append-counter shards per class (workgroup blockIdx % kSub)
 constexpr int kSeg = kCls * kSub;    // path buffers are split into kSeg segments with one append counter each
 constexpr int kBinMax = 4;           // at most this many small primitives take part in the binning
+// k_bounce<., MANY> (scenes with more than kBinMax spheres): LDS words of the fixed scratch, floats per staged sphere
+// record (inverseTransform rows, transform rows, 16 B of padding), spheres a lane can record per tile
+constexpr int kMiscWords = kWaves * kCls + kCls + kSeg + (kSeg + 2) + 2 * PT_MAX_BATCH + 2;
+static_assert(kMiscWords % 4 == 0, "the sphere records that follow are read as float4");
+constexpr int kSphRowFloats = 28;
+constexpr int kListMax = 8;
 constexpr int kCtrPad = 32;          // one counter per 128-byte line: same-line atomics serialise at the memory side
 
 struct Ctrl {
@@ -46,6 +52,7 @@ struct KParams {
     // n / W and n / nLocal for n < 2^27 as (n * magic) >> shift (exact, see pt_init): the two divisions of the
     // camera-ray bounce cost ~50 instructions each when the compiler expands them
     uint32_t magicW, shiftW, magicN, shiftN;
+    int   tilesPerRow;  // W / 256 when that is exact and the camera-ray grid is a multiple of it (see k_bounce), else 0
     int   nBinned;      // 1..kBinMax small primitives (spheres, small cubes): survivors are binned by whether they can
     int   binGeom[kBinMax];   // hit one of them (certainMiss of each); 0: off, every path counts as a candidate
 };
@@ -123,7 +130,8 @@ __global__ __launch_bounds__(kBlock) void k_debug_camera_rays(KParams prm, int i
 // Queue order never influences results: RNG and accumulator are keyed on the pixel index.
 // No workgroup ever waits for another one, so there is no residency / dispatch-order assumption.
 // A segment receives survivors of the tiles of the workgroups with one value of blockIdx % kSub only,
-// i.e. at most ceil(tiles / kSub) * 256 <= segCap paths (see pt_init).
+// i.e. at most ceil(tiles / kSub) * 256 <= segCap paths (see pt_init: the grid is a multiple of kSub).
+// (Deriving the shard from the tile index instead, T % kSub, measured 3 % slower.)
 //
 // FIRST = true is bounce 1 fused with camera-ray generation (spec S2): tile T holds the paths
 // j = 256 T + lane of this shard's pixel list and the ray is built in registers, so the first bounce
@@ -133,8 +141,15 @@ __global__ __launch_bounds__(kBlock) void k_debug_camera_rays(KParams prm, int i
 // this is the optimum (93.9 vs 90.7 / 78.1 / 62.8 G paths/s) -- more waves hide the tile-start loads and the compaction's
 // atomic round trip, beyond 6 the spills reach the intersection loop.  The camera-ray bounce reads no path state and
 // would spill inside its intersection loop at 85 registers: it runs with five.
-template <bool FIRST>
-__global__ __launch_bounds__(kBlock, FIRST ? 5 : 6) void k_bounce(KParams prm, int iter, int batch, int depth, int lastBounce, int parity,
+//
+// MANY (scenes with more than kBinMax spheres, e.g. the 64-sphere configuration): the wave-uniform loop over the
+// spheres only runs the cheap bounding-ball test and RECORDS the spheres a lane may hit (a handful out of 64, and a
+// different handful for every lane of a wave of incoherent rays: testing them in place ran the full sphere test 21
+// times per wave with 1.8 active lanes).  After the loop, pass k tests every lane's k-th recorded sphere, each lane with
+// its own matrices from LDS -- 3-4 passes with tens of active lanes.  Same tests on the same operands; the nearest hit is
+// chosen by (distance, then file order), which is what the in-order loop with its strict `<` computes.
+template <bool FIRST, bool MANY>
+__global__ __launch_bounds__(kBlock, (FIRST || MANY) ? 5 : 6) void k_bounce(KParams prm, int iter, int batch, int depth, int lastBounce, int parity,
                                                    PathSoA in, PathSoA out, Ctrl *ctrl,
                                                    const GeomDev *__restrict__ ggeoms,
                                                    const MaterialDev *__restrict__ gmats, float *contrib) {
@@ -152,6 +167,8 @@ __global__ __launch_bounds__(kBlock, FIRST ? 5 : 6) void k_bounce(KParams prm, i
     uint32_t *s_segcnt = s_base + kCls;              // [kSeg]   paths per input segment
     uint32_t *s_segpre = s_segcnt + kSeg;            // [kSeg+2] tile prefix per input segment, [kSeg+1] = live paths
     uint32_t *s_iterHash = s_segpre + kSeg + 2;      // [2][PT_MAX_BATCH] iterationHash(iter + b, depth) and (iter + b, 0)
+    float *s_sph = reinterpret_cast<float *>(s_misc + kMiscWords);                    // MANY: [ngeoms][kSphRowFloats]
+    uint16_t *s_list = reinterpret_cast<uint16_t *>(s_sph + (size_t)prm.ngeoms * kSphRowFloats);   // MANY: [kListMax][kBlock]
 
     if (lastBounce) {   // re-arm the next iteration: nobody touches the other parity's counters now
         uint32_t *other = &ctrl->seg_count[parity ^ 1][0][0][0];
@@ -205,17 +222,35 @@ __global__ __launch_bounds__(kBlock, FIRST ? 5 : 6) void k_bounce(KParams prm, i
             else if (k == 13) v = (uint32_t)G.type;
             reinterpret_cast<uint32_t *>(s_geomHit)[i] = v;
         }
+        if (MANY) {
+            for (int i = threadIdx.x; i < prm.ngeoms * 24; i += kBlock) {
+                const int g = i / 24, k = i - g * 24;
+                s_sph[g * kSphRowFloats + k] = k < 12 ? ggeoms[g].inv[k] : ggeoms[g].xf[k - 12];
+            }
+        }
     }
     __syncthreads();
 
     uint32_t waveLight = 0, waveMiss = 0;   // wave-uniform tallies, flushed once at the end
     uint32_t sgIn = 0;                      // input segment of the current tile (tiles are visited in increasing order)
+    uint32_t firstK = 0;                    // FIRST: how many tiles this workgroup has processed
     for (uint32_t T = blockIdx.x; T < numTiles; T += gridDim.x) {
         bool valid;
         uint32_t idx = 0;
         bool smallTile = true;              // wave-uniform: this tile's paths may hit a small (binned) primitive
         if (FIRST) {
-            idx = T * kBlock + threadIdx.x;                     // position in this shard's pixel list
+            // Tile T = b + k grid covers a 256-pixel block of the row-major pixel list.  With W a multiple of 256 a row
+            // is `perRow` whole tiles, the grid is a multiple of perRow (pt_init), and a workgroup would stay in ONE
+            // column band of the frame -- outside the scene rectangle its tiles cost 15x less than inside.  So the k-th
+            // tile of a workgroup is rotated k bands to the right inside its row: a bijection on the row's tiles
+            // (they share k), which walks every workgroup through all bands.
+            uint32_t pixTile = T;
+            if (prm.tilesPerRow > 1) {
+                const uint32_t c = T % (uint32_t)prm.tilesPerRow;
+                pixTile = T - c + (c + firstK) % (uint32_t)prm.tilesPerRow;
+                ++firstK;
+            }
+            idx = pixTile * kBlock + threadIdx.x;               // position in this shard's pixel list
             valid = idx < nLive;
         } else {
             // global tile -> (segment, local tile)
@@ -264,6 +299,7 @@ __global__ __launch_bounds__(kBlock, FIRST ? 5 : 6) void k_bounce(KParams prm, i
             F3 P = f3(0, 0, 0), nsrc = f3(0, 0, 0);
             bool outside = false;
             const float dd = dot(dir, dir);
+            int nCand = 0;                                       // MANY: spheres recorded by this lane
             for (int g = 0; inScene && g < prm.ngeoms; ++g) {
                 const GeomDev &G = ggeoms[g];
                 const int type = G.type;
@@ -274,12 +310,41 @@ __global__ __launch_bounds__(kBlock, FIRST ? 5 : 6) void k_bounce(KParams prm, i
                 if (!FIRST && !smallTile && G.binned) continue;  // this tile's paths certainly miss every binned primitive
                 if (type == 0) {
                     probe(3);
-                    if (!certainMiss(G, org, dir, dd)) t = sphereIntersectionTest<FIRST>(G, org, dir, p, n, o);
+                    if (!certainMiss(G, org, dir, dd)) {
+                        if (MANY && nCand < kListMax) {
+                            s_list[nCand * kBlock + threadIdx.x] = (uint16_t)g;
+                            ++nCand;
+                        } else {                                 // (MANY: the lane's list is full -- test in place)
+                            t = sphereIntersectionTest<FIRST>(G, org, dir, p, n, o);
+                        }
+                    }
                 } else {
                     t = boxIntersectionTest<true, FIRST>(G, org, dir, p, n, o);
                 }
                 if (t > 0.0f && (hit < 0 || t < tbest)) {
                     tbest = t; hit = g; P = p; nsrc = n; outside = o;
+                }
+            }
+            if (MANY) {
+                for (int k = 0; __ballot(k < nCand) != 0ull; ++k) {          // wave-uniform trip count
+                    if (k < nCand) {
+                        const int g = s_list[k * kBlock + threadIdx.x];
+                        const float4 *row = reinterpret_cast<const float4 *>(s_sph + g * kSphRowFloats);
+                        float m[24];
+#pragma unroll
+                        for (int q = 0; q < 6; ++q) {
+                            const float4 v = row[q];
+                            m[4 * q] = v.x; m[4 * q + 1] = v.y; m[4 * q + 2] = v.z; m[4 * q + 3] = v.w;
+                        }
+                        F3 p, n;
+                        bool o = false;
+                        probe(4);
+                        const float t = sphereIntersectionTestM(m, m + 12, nullptr, org, dir, p, n, o);
+                        // a recorded sphere may precede, in file order, the primitive that holds the record so far
+                        if (t > 0.0f && (hit < 0 || t < tbest || (t == tbest && g < hit))) {
+                            tbest = t; hit = g; P = p; nsrc = n; outside = o;
+                        }
+                    }
                 }
             }
             if (hit < 0) {
