@@ -81,7 +81,9 @@ typedef struct PtOptions {
     int32_t pipeline_depth;   /* iterations kept in flight on internal streams: 0 = default (3), 1 = none, max 4.
                                  Results do not depend on it: radiance is committed in iteration order. */
     int32_t max_batch;        /* largest `count` pt_iterate_batch will be given (sizes the path buffers: they grow
-                                 linearly with it); 0 = 1, max PT_MAX_BATCH */
+                                 linearly with it -- 704 B per path and slot, i.e. 0.65 GB per iteration of a
+                                 1280x720 frame and slot -- and pixels x max_batch must stay below 2^26);
+                                 0 = 1, max PT_MAX_BATCH */
     void   *stream;           /* hipStream_t to enqueue on; NULL = the default stream */
     float  *accum_dev;        /* optional caller-owned device accumulator, W*H*3 floats (or the shard's rows only
                                  with PT_FLAG_ACCUM_SHARD_ROWS), zeroed by the caller (e.g. a torch tensor that
