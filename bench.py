@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--pipeline", type=int, default=0, help="batches in flight (PtOptions.pipeline_depth; 0 = library default 3)")
     ap.add_argument("--batch", type=int, default=16,
                     help="iterations traced as one wavefront per pt_iterate_batch call on ONE GPU; N GPUs trace N x as many "
-                         "(at most 32), so that a launch keeps covering the same number of paths when the rows are sharded")
+                         "(at most 64), so that a launch keeps covering the same number of paths when the rows are sharded")
     ap.add_argument("--pmc-traffic-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"),
                     help="HBM bytes per bounce-kernel launch from a rocprofv3 --pmc run (profiles/README.md)")
     return ap.parse_args()
@@ -123,7 +123,7 @@ def main():
     # path buffers grow with the batch (44 B x 16 class-worst-case x 2 ping-pong x 3 slots per path): keep them
     # under ~128 GB of the 288: batch 16 at 1280x720 (62 GB), 14 at 1080p, 1 for a 4096x4096 frame on one GPU
     n_local = ptdist.local_pixel_count(W, H, rank, world)
-    B = max(1, min(args.batch * world if world > 1 else args.batch, 32 if world > 1 else pt.PT_MAX_BATCH, pt.PT_MAX_BATCH,
+    B = max(1, min(args.batch * world, pt.PT_MAX_BATCH,
                    int(128e9 // (max(n_local, 1) * 44 * 16 * 2 * 3))))
 
     def init(flags, pipeline):

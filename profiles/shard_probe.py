@@ -10,7 +10,7 @@ scene = pt.Scene(os.path.join(ROOT, "scenes", "cornell.txt"))
 scene.set_resolution(1280, 720)
 P = 1280 * 720
 for world in (1, 2, 4, 8):
-    for depth_pipe, batch in ((3, 1), (3, 4), (3, 8), (3, 16), (3, 32), (3, 64), (2, 64)):
+    for depth_pipe, batch in ((3, 8), (3, 16), (3, 32), (3, 64)):
         acc = torch.zeros(P * 3, device="cuda")
         pt.pathtraceFree()
         pt.pathtraceInit(scene, shard_rank=0, shard_count=world, stream=torch.cuda.current_stream().cuda_stream,
