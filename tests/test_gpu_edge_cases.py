@@ -126,6 +126,23 @@ def test_two_hundred_spheres_in_lds_and_scalar_path(gpu, oracle):
     _compare(gpu, oracle, sc, [1, 2])
 
 
+def test_coincident_and_nested_spheres_keep_file_order(gpu, oracle):
+    # Sphere-heavy scenes record a lane's candidate spheres (8 per lane, in-place test beyond) and test them after the
+    # loop over the primitives: 12 COINCIDENT spheres with different materials (equal distances: the first in file order
+    # must win, whether it was recorded or tested in place), 10 nested ones around them, a cube in between the indices.
+    geoms = [oracle.make_geom(1, 1, (0, -1, 0), (0, 0, 0), (30, 1, 30)), oracle.make_geom(0, 0, (0, 12, 0), (0, 0, 0), (6, 1, 6))]
+    for k in range(12):
+        geoms.append(oracle.make_geom(0, 1 + k % 3, (0, 4, 0), (0, 0, 0), (3, 3, 3)))
+    geoms.append(oracle.make_geom(1, 2, (0, 4, 0), (0, 0, 0), (3, 3, 3)))              # a cube circumscribing them
+    for k in range(10):
+        geoms.append(oracle.make_geom(0, 3, (0, 4, 0), (10 * k, 5 * k, 0), (3.2 + 0.4 * k, 3.2 + 0.3 * k, 3.2 + 0.5 * k)))
+    mats = np.concatenate([_mat(oracle, emit=4.0), _mat(oracle, (.8, .8, .8)), _mat(oracle, (.9, .3, .3), refl=1.0, spec=(.9, .9, .9)),
+                           _mat(oracle, (.95, .95, .95), refr=1.0, ior=1.5, spec=(.95, .95, .95))])
+    sc = _scene(gpu, oracle, np.concatenate(geoms), mats, (96, 64), 10, eye=(0, 5, 14))
+    _compare(gpu, oracle, sc, [1, 2, 3], max_batch=1)
+    _compare(gpu, oracle, sc, [1, 2, 3], max_batch=4, pipeline_depth=2)
+
+
 def test_full_baseline_frame_is_bit_identical(gpu, oracle):
     # BASELINE config C2 at its real size (1280x720, depth 8), 2 spp: every one of the 2.7 M floats
     sc = gpu.Scene(os.path.join(SCENES, "cornell.txt"))
