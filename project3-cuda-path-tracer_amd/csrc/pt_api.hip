@@ -568,6 +568,7 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     // odd tile count per row), or the kernel rotates the k-th tile of a workgroup k bands to the right inside its row,
     // which needs a grid that is a multiple of the tiles per row (k_bounce<true, .>).
     S.prm.tilesPerRow = 0;
+    S.prm.wholeRowTiles = Wd % kBlock == 0 ? 1 : 0;
     if (Wd % kBlock == 0 && Wd / kBlock > 1) {
         const int perRow = Wd / kBlock;
         auto gcd = [](int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; };

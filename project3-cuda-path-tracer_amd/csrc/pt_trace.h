@@ -53,6 +53,7 @@ struct KParams {
     // camera-ray bounce cost ~50 instructions each when the compiler expands them
     uint32_t magicW, shiftW, magicN, shiftN;
     int   tilesPerRow;  // W / 256 when that is exact and the camera-ray grid is a multiple of it (see k_bounce), else 0
+    int   wholeRowTiles; // W % 256 == 0: a camera-ray tile is 256 pixels of one row
     int   nBinned;      // 1..kBinMax small primitives (spheres, small cubes): survivors are binned by whether they can
     int   binGeom[kBinMax];   // hit one of them (certainMiss of each); 0: off, every path counts as a candidate
 };
@@ -252,6 +253,20 @@ __global__ __launch_bounds__(kBlock, (FIRST || MANY) ? 5 : 6) void k_bounce(KPar
             }
             idx = pixTile * kBlock + threadIdx.x;               // position in this shard's pixel list
             valid = idx < nLive;
+            // A tile of whole-tile rows is 256 pixels of ONE row: when it lies outside the scene rectangle altogether,
+            // all its camera rays are misses -- tally them and take the next tile (no rays, no compaction, no barrier;
+            // the test is the same for the four waves of the workgroup).
+            if (prm.wholeRowTiles) {
+                const uint32_t idx0 = pixTile * kBlock;
+                const int itb0 = (int)fastDiv(idx0, prm.magicN, prm.shiftN);
+                int pix0, x0, y0;
+                shardPixel(prm, (int)(idx0 - (uint32_t)itb0 * (uint32_t)prm.nLocal), pix0, x0, y0);
+                if (y0 < prm.sceneRect[1] || y0 > prm.sceneRect[3] || x0 + (kBlock - 1) < prm.sceneRect[0] || x0 > prm.sceneRect[2]) {
+                    const uint32_t w0 = idx0 + (threadIdx.x & ~63u);                  // this wave's first path
+                    waveMiss += w0 >= nLive ? 0u : (nLive - w0 < 64u ? nLive - w0 : 64u);
+                    continue;
+                }
+            }
         } else {
             // global tile -> (segment, local tile)
             while (T >= s_segpre[sgIn + 1]) ++sgIn;
