@@ -96,7 +96,8 @@ typedef struct PtOptions {
 typedef struct PtCounters {
     int64_t live[PT_MAX_DEPTH + 2]; /* live[d] = paths entering bounce d (d = 1..depth), summed over   */
     int64_t light_hits;             /*           every iteration since pt_init / pt_counters_reset      */
-    int64_t misses;
+    int64_t misses;                 /* traced paths that hit nothing (diagnostic: paths of the last bounce that certainly
+                                       cannot reach an emitter are not traced and appear in neither tally)          */
     int64_t iterations;
     int64_t bounce_launches;        /* bounce-kernel launches covered by bounce_kernel_ms               */
     double  bounce_kernel_ms;       /* sum of HIP-event durations (PT_FLAG_KERNEL_TIMING only)          */

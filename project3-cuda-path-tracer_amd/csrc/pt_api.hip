@@ -535,6 +535,9 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
             hg[cand[c].second].binned = 1;
         }
     }
+    k.emittersBinned = k.nBinned > 0 ? 1 : 0;
+    for (int i = 0; i < ngeoms; ++i)
+        if (mats[geoms[i].materialid].emittance > 0.0f && !hg[i].binned) k.emittersBinned = 0;
     HIPCHECK(hipMalloc(&S.dgeoms, hg.size() * sizeof(GeomDev)));
     HIPCHECK(hipMalloc(&S.dmats, hm.size() * sizeof(MaterialDev)));
     HIPCHECK(hipMemcpy(S.dgeoms, hg.data(), hg.size() * sizeof(GeomDev), hipMemcpyHostToDevice));

@@ -54,6 +54,7 @@ struct KParams {
     uint32_t magicW, shiftW, magicN, shiftN;
     int   tilesPerRow;  // W / 256 when that is exact and the camera-ray grid is a multiple of it (see k_bounce), else 0
     int   wholeRowTiles; // W % 256 == 0: a camera-ray tile is 256 pixels of one row
+    int   emittersBinned; // every primitive with an emissive material is one of binGeom[]
     int   nBinned;      // 1..kBinMax small primitives (spheres, small cubes): survivors are binned by whether they can
     int   binGeom[kBinMax];   // hit one of them (certainMiss of each); 0: off, every path counts as a candidate
 };
@@ -275,6 +276,9 @@ __global__ __launch_bounds__(kBlock, (FIRST || MANY) ? 5 : 6) void k_bounce(KPar
             valid = local < s_segcnt[sgIn];
             idx = sgIn * (uint32_t)prm.segCap + local;
             smallTile = ((sgIn / kSub) & 8u) != 0u;
+            // The last bounce only asks whether a path ends on an emitter (S7: no scatter).  When every emitter of the scene
+            // is a binned small primitive, the paths of a non-candidate tile certainly miss all of them: nothing to add.
+            if (lastBounce && prm.emittersBinned && !smallTile) continue;
         }
 
         bool alive = false;
