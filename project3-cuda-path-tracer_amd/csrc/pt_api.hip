@@ -160,6 +160,28 @@ void pack_geom(const PtGeom &g, GeomDev &d, const float *eye = nullptr) {
     d.cullK = ok ? (float)kk : 0.0f;
     d.rect[0] = d.rect[1] = 0;                 // whole frame until pt_init projects the primitive (project_geom)
     d.rect[2] = d.rect[3] = 0x7fffffff;
+    if (g.type == PT_CUBE) {
+        // ptd::normalize(ptd::mulMV(xf, +-e_axis, 0)) operation by operation (this file is built with -ffp-contract=off;
+        // host sqrt and division are correctly rounded like the device's): the six normals hitNormalCube() looks up
+        const float *m = d.xf;
+        for (int axis = 0; axis < 3; ++axis)
+            for (int pos = 0; pos < 2; ++pos) {
+                float v[3] = {0.0f, 0.0f, 0.0f};
+                v[axis] = pos ? 1.0f : -1.0f;
+                float r[3];
+                for (int c = 0; c < 3; ++c) {
+                    const float a0 = m[0 + c] * v[0], a1 = m[3 + c] * v[1], a2 = m[6 + c] * v[2], a3 = m[9 + c] * 0.0f;
+                    const float s01 = a0 + a1, s23 = a2 + a3;
+                    r[c] = s01 + s23;
+                }
+                const float xx = r[0] * r[0], yy = r[1] * r[1], zz = r[2] * r[2];
+                const float xy = xx + yy;
+                const float dt = xy + zz;                       // glm dot: (x*x + y*y) + z*z
+                const float inv = 1.0f / std::sqrt(dt);         // glm::inversesqrt
+                float *out = d.cubeN + 3 * (2 * axis + pos);
+                out[0] = r[0] * inv; out[1] = r[1] * inv; out[2] = r[2] * inv;
+            }
+    }
     if (eye) {   // ptd::mulMV(inv, eye, 1) in the same operation order (this file is built with -ffp-contract=off)
         const float *m = d.inv;
         for (int r = 0; r < 3; ++r) {

@@ -107,8 +107,12 @@ struct GeomDev {
     // object-space unit cube, widened by 2 pixels (host, double precision); the whole frame when a corner is not in
     // front of the eye.  Camera rays of other pixels skip the primitive (first bounce only).
     int   rect[4];
+    // cube: its six possible surface normals normalize(multiplyMV(transform, (+-e_axis, 0))), entry axis * 2 + (sign > 0),
+    // evaluated once on the host with the operations hitNormal() would issue per hit (src/intersections.h:85)
+    float cubeN[18];
+    float pad3[2];
 };
-static_assert(sizeof(GeomDev) == 208, "GeomDev is 13 x 16 B");
+static_assert(sizeof(GeomDev) == 288, "GeomDev is 18 x 16 B");
 
 struct MaterialDev {
     float color[3];
@@ -375,26 +379,38 @@ __device__ __forceinline__ float sphereIntersectionTest(const GeomDev &g, F3 ro_
 // The surface normal of a hit, from what the two tests leave in `nsrc` (src/intersections.h:85 and :137-140).
 // The reference computes it for every primitive a ray hits; only the nearest hit's normal is ever used, so the
 // kernels evaluate it once, after the nearest-hit loop -- same inputs, same operations, same bits.
-// `m` = rows 0-2 of invTranspose (sphere) or transform (cube), as mulMV expects them.
-__device__ __forceinline__ F3 hitNormal(const float *m, bool sphere, F3 nsrc, bool outside) {
-    const F3 n = normalize(mulMV(m, nsrc, 0.0f));
-    return (sphere && !outside) ? -n : n;
+// Sphere: `m` = rows 0-2 of invTranspose as mulMV expects them, nsrc = the object-space hit point.
+// Cube: nsrc = +-e_axis, so the normal is one of six vectors per cube, which pack_geom (pt_api.hip) evaluates with the
+// very operations of normalize(mulMV(transform, nsrc, 0)): a table lookup instead of 52 instructions per hit.
+__device__ __forceinline__ F3 hitNormalSphere(const float *invT, F3 nsrc, bool outside) {
+    const F3 n = normalize(mulMV(invT, nsrc, 0.0f));
+    return outside ? n : -n;
+}
+__device__ __forceinline__ F3 hitNormalCube(const float *cubeN, F3 nsrc) {
+    const int axis = nsrc.x != 0.0f ? 0 : (nsrc.y != 0.0f ? 1 : 2);
+    const float v = nsrc.x + nsrc.y + nsrc.z;                     // the one non-zero component, +-1
+    const float *n = cubeN + 3 * (2 * axis + (v > 0.0f ? 1 : 0));
+    // (a hit without an exit slab -- a ray of NaNs -- leaves nsrc = 0, and the reference normalises the zero vector)
+    const bool ok = v != 0.0f;
+    const float nan = __builtin_nanf("");
+    return f3(ok ? n[0] : nan, ok ? n[1] : nan, ok ? n[2] : nan);          // (selects: adding 0 would turn -0 into +0)
 }
 __device__ __forceinline__ F3 hitNormal(const GeomDev &g, F3 nsrc, bool outside) {
-    return hitNormal(g.type == 0 ? g.invT : g.xf, g.type == 0, nsrc, outside);
+    return g.type == 0 ? hitNormalSphere(g.invT, nsrc, outside) : hitNormalCube(g.cubeN, nsrc);
 }
 
-// Per-geom record staged in LDS for the per-lane lookups that follow the nearest-hit loop: the matrix of the normal
-// (12 floats), the material index and the type, read with ds_read_b128.  Lanes of a wave index different geoms, so
-// the row stride is 64 + 16 B (one access width of padding): consecutive rows start 20 banks apart and up to 16
-// different rows are conflict-free (64-B rows collide two ways: SQ_LDS_BANK_CONFLICT 20 % of LDS cycles -> 0).
+// Per-geom record staged in LDS for the per-lane lookups that follow the nearest-hit loop: the sphere's normal matrix
+// (12 floats), the material index, the type and the cube's six normals.  Lanes of a wave index different geoms, so the
+// row stride is 128 + 16 B (one access width of padding): consecutive rows start 4 banks apart and 8 different rows
+// are conflict-free (64-B rows collided two ways: SQ_LDS_BANK_CONFLICT 20 % of LDS cycles).
 struct GeomHitDev {
     float nm[12];
     int   material;
     int   type;
-    int   pad[6];
+    float cubeN[18];
+    int   pad[4];
 };
-static_assert(sizeof(GeomHitDev) == 80, "GeomHitDev is 5 x 16 B");
+static_assert(sizeof(GeomHitDev) == 144, "GeomHitDev is 9 x 16 B");
 
 // src/interactions.h:10-42
 __device__ __forceinline__ F3 calculateRandomDirectionInHemisphere(F3 normal, Rng &rng) {

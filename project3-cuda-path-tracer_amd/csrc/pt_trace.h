@@ -219,9 +219,10 @@ __global__ __launch_bounds__(kBlock, (FIRST || MANY) ? 5 : 6) void k_bounce(KPar
             const int g = i / kHitWords, k = i - g * kHitWords;
             const GeomDev &G = ggeoms[g];
             uint32_t v = 0;
-            if (k < 12) v = __float_as_uint(G.type == 0 ? G.invT[k] : G.xf[k]);
+            if (k < 12) v = __float_as_uint(G.invT[k]);
             else if (k == 12) v = (uint32_t)G.material;
             else if (k == 13) v = (uint32_t)G.type;
+            else if (k < 32) v = __float_as_uint(G.cubeN[k - 14]);
             reinterpret_cast<uint32_t *>(s_geomHit)[i] = v;
         }
         if (MANY) {
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(kBlock, (FIRST || MANY) ? 5 : 6) void k_bounce(KPar
                 missed = true;                                   // S4: background is black
             } else {
                 const GeomHitDev &GH = s_geomHit[hit];               // per-lane geom: LDS lookup
-                const F3 N = hitNormal(GH.nm, GH.type == 0, nsrc, outside);
+                const F3 N = GH.type == 0 ? hitNormalSphere(GH.nm, nsrc, outside) : hitNormalCube(GH.cubeN, nsrc);
                 const MaterialDev &M = smats[GH.material];
                 const F3 mcol = f3(M.color[0], M.color[1], M.color[2]);
                 if (M.emittance > 0.0f) {                        // S5: emitter ends the path
