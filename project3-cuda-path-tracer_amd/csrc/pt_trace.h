@@ -387,7 +387,8 @@ __global__ __launch_bounds__(kBlock, (FIRST || MANY) ? 5 : 6) void k_bounce(KPar
                 } else if (!lastBounce) {                        // S6 scatter (S7: skipped on the last bounce)
                     Rng rng = makeSeededRandomEngineHashed(s_iterHash[itb], pix);
                     const F3 scol = f3(M.specColor[0], M.specColor[1], M.specColor[2]);
-                    F3 ndir, norg;
+                    F3 ndir = dir, norg;
+                    bool diffuse = false;                        // the hemisphere is sampled at one place, after the branches
                     if (M.hasRefractive > 0.0f) {
                         const float eta = outside ? M.invIor : M.ior;
                         const float c = dot(N, dir);
@@ -418,15 +419,16 @@ __global__ __launch_bounds__(kBlock, (FIRST || MANY) ? 5 : 6) void k_bounce(KPar
                             ndir = reflect(dir, N);
                             col = col * scol;
                         } else {
-                            ndir = calculateRandomDirectionInHemisphere(N, rng);
+                            diffuse = true;
                             col = col * mcol;
                         }
                         norg = P + N * 0.001f;
                     } else {
-                        ndir = calculateRandomDirectionInHemisphere(N, rng);
+                        diffuse = true;
                         col = col * mcol;
                         norg = P + N * 0.001f;
                     }
+                    if (diffuse) ndir = calculateRandomDirectionInHemisphere(N, rng);
                     org = norg;
                     dir = ndir;
                     alive = true;
