@@ -139,10 +139,10 @@ __global__ __launch_bounds__(kBlock) void k_debug_camera_rays(KParams prm, int i
 // j = 256 T + lane of this shard's pixel list and the ray is built in registers, so the first bounce
 // reads no path state at all.
 //
-// Six workgroups per CU (6 waves per SIMD, <= 85 VGPRs, a few cold spills): measured against 5 / 7 / 8 resident waves
-// this is the optimum (93.9 vs 90.7 / 78.1 / 62.8 G paths/s) -- more waves hide the tile-start loads and the compaction's
-// atomic round trip, beyond 6 the spills reach the intersection loop.  The camera-ray bounce reads no path state and
-// would spill inside its intersection loop at 85 registers: it runs with five.
+// Registers: built without the SLP vectoriser the kernel needs 63 VGPRs and spills nothing (with it: 80 + 10 spilled for
+// 8 % fewer instructions -- slower, see the Makefile), so eight waves per SIMD fit; a launch brings six workgroups per
+// CU (persistent_grid) and leaves the other two slots to the launches of the neighbouring batches.  The launch bounds
+// only cap the sphere-list variants (81 VGPRs).
 //
 // MANY (scenes with more than kBinMax spheres, e.g. the 64-sphere configuration): the wave-uniform loop over the
 // spheres only runs the cheap bounding-ball test and RECORDS the spheres a lane may hit (a handful out of 64, and a
