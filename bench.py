@@ -5,7 +5,7 @@ Metric (BASELINE.json): Mpaths/s, paths = pixels x bounces x spp (NOMINAL segmen
 1280x720, 8 bounces.  One "step" = one iteration (1 spp) of the whole frame: camera rays, 8 fused
 intersect+shade+compact bounces, ordered accumulation.  Steps are issued as wavefront batches of
 --batch iterations (pt_iterate_batch: their paths share the 8 launches; results are identical to
-one call per iteration) with up to 3 batches in flight on internal streams.  Scene, accumulator
+one call per iteration) with 2 batches in flight on internal streams.  Scene, accumulator
 and path state are resident in HBM before the timed region.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
@@ -45,10 +45,10 @@ def parse():
     ap.add_argument("--res", type=int, nargs=2, default=[1280, 720])
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--cpu-spp", type=int, default=40, help="spp of the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--pipeline", type=int, default=0, help="batches in flight (PtOptions.pipeline_depth; 0 = library default 3)")
-    ap.add_argument("--batch", type=int, default=16,
+    ap.add_argument("--pipeline", type=int, default=2, help="batches in flight (PtOptions.pipeline_depth; 0 = library default 3)")
+    ap.add_argument("--batch", type=int, default=32,
                     help="iterations traced as one wavefront per pt_iterate_batch call on ONE GPU; N GPUs trace N x as many "
-                         "(at most 64), so that a launch keeps covering the same number of paths when the rows are sharded")
+                         "(at most 64), so that a launch keeps covering as many paths when the rows are sharded")
     ap.add_argument("--pmc-traffic-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"),
                     help="HBM bytes per bounce-kernel launch from a rocprofv3 --pmc run (profiles/README.md)")
     return ap.parse_args()
@@ -120,11 +120,11 @@ def main():
         frame, bufs, shard_flag = None, None, 0
     stream = torch.cuda.current_stream()
 
-    # path buffers grow with the batch (44 B x 16 class-worst-case x 2 ping-pong x 3 slots per path): keep them
-    # under ~128 GB of the 288: batch 16 at 1280x720 (62 GB), 14 at 1080p, 1 for a 4096x4096 frame on one GPU
+    # path buffers grow with the batch (44 B x 16 class-worst-case x 2 ping-pong x slots per path): keep them
+    # under ~128 GB of the 288: batch 32 with 2 slots at 1280x720 (83 GB), 21 at 1080p, 2 for a 4096x4096 frame on one GPU
     n_local = ptdist.local_pixel_count(W, H, rank, world)
     B = max(1, min(args.batch * world, pt.PT_MAX_BATCH,
-                   int(128e9 // (max(n_local, 1) * 44 * 16 * 2 * 3))))
+                   int(128e9 // (max(n_local, 1) * 44 * 16 * 2 * (args.pipeline if args.pipeline > 0 else 3)))))
 
     def init(flags, pipeline):
         pt.pathtraceFree()

@@ -5,7 +5,7 @@ TAG=${1:-x}
 OUT=$PWD/gpurun_out/valu_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python3 $PWD/bench.py --steps 16 --warmup 16 --cpu-spp 0 --pipeline 1 --batch ${BATCH:-16} ${BENCH_ARGS:-}"
+BENCH="python3 $PWD/bench.py --steps 16 --warmup 16 --cpu-spp 0 --pipeline 1 --batch ${BATCH:-32} ${BENCH_ARGS:-}"
 cd /tmp
 rocprofv3 --pmc ${PMC:-SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VMEM SQ_INSTS_LDS GRBM_GUI_ACTIVE} --output-format csv -d $OUT/pmc -- $BENCH > $OUT/pmc.log 2>&1 || { echo "pmc failed"; tail -5 $OUT/pmc.log; exit 1; }
 python3 - "$OUT" <<'PY'

@@ -161,8 +161,22 @@ void pack_geom(const PtGeom &g, GeomDev &d, const float *eye = nullptr) {
     d.rect[0] = d.rect[1] = 0;                 // whole frame until pt_init projects the primitive (project_geom)
     d.rect[2] = d.rect[3] = 0x7fffffff;
     if (g.type == PT_CUBE) {
-        // ptd::normalize(ptd::mulMV(xf, +-e_axis, 0)) operation by operation (this file is built with -ffp-contract=off;
-        // host sqrt and division are correctly rounded like the device's): the six normals hitNormalCube() looks up
+        // Per face: ptd::normalize(ptd::mulMV(xf, +-e_axis, 0)) and ptd::hemisphereFrame of that normal, operation by
+        // operation (this file is built with -ffp-contract=off; host sqrt and division are correctly rounded like the
+        // device's): what cubeFrameVector() looks up.
+        struct V { float x, y, z; };
+        auto normalize = [](V a) {
+            const float xx = a.x * a.x, yy = a.y * a.y, zz = a.z * a.z;
+            const float xy = xx + yy;
+            const float dt = xy + zz;                                 // glm dot: (x*x + y*y) + z*z
+            const float inv = 1.0f / std::sqrt(dt);                   // glm::inversesqrt
+            return V{a.x * inv, a.y * inv, a.z * inv};
+        };
+        auto cross = [](V x, V y) {                                   // glm/detail/func_geometric.inl:134-143
+            const float a0 = x.y * y.z, a1 = y.y * x.z, b0 = x.z * y.x, b1 = y.z * x.x, c0 = x.x * y.y, c1 = y.x * x.y;
+            return V{a0 - a1, b0 - b1, c0 - c1};
+        };
+        const float kSqrtOneThird = 0.5773502691896257645091487805019574556476f;   // src/utilities.h:15
         const float *m = d.xf;
         for (int axis = 0; axis < 3; ++axis)
             for (int pos = 0; pos < 2; ++pos) {
@@ -174,12 +188,17 @@ void pack_geom(const PtGeom &g, GeomDev &d, const float *eye = nullptr) {
                     const float s01 = a0 + a1, s23 = a2 + a3;
                     r[c] = s01 + s23;
                 }
-                const float xx = r[0] * r[0], yy = r[1] * r[1], zz = r[2] * r[2];
-                const float xy = xx + yy;
-                const float dt = xy + zz;                       // glm dot: (x*x + y*y) + z*z
-                const float inv = 1.0f / std::sqrt(dt);         // glm::inversesqrt
-                float *out = d.cubeN + 3 * (2 * axis + pos);
-                out[0] = r[0] * inv; out[1] = r[1] * inv; out[2] = r[2] * inv;
+                const V n = normalize(V{r[0], r[1], r[2]});
+                V notNormal;
+                if (std::fabs(n.x) < kSqrtOneThird) notNormal = V{1, 0, 0};
+                else if (std::fabs(n.y) < kSqrtOneThird) notNormal = V{0, 1, 0};
+                else notNormal = V{0, 0, 1};
+                const V p1 = normalize(cross(n, notNormal));
+                const V p2 = normalize(cross(n, p1));
+                float *out = d.cubeFrame + 9 * (2 * axis + pos);
+                out[0] = n.x; out[1] = n.y; out[2] = n.z;
+                out[3] = p1.x; out[4] = p1.y; out[5] = p1.z;
+                out[6] = p2.x; out[7] = p2.y; out[8] = p2.z;
             }
     }
     if (eye) {   // ptd::mulMV(inv, eye, 1) in the same operation order (this file is built with -ffp-contract=off)

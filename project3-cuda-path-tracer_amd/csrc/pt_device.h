@@ -107,12 +107,14 @@ struct GeomDev {
     // object-space unit cube, widened by 2 pixels (host, double precision); the whole frame when a corner is not in
     // front of the eye.  Camera rays of other pixels skip the primitive (first bounce only).
     int   rect[4];
-    // cube: its six possible surface normals normalize(multiplyMV(transform, (+-e_axis, 0))), entry axis * 2 + (sign > 0),
-    // evaluated once on the host with the operations hitNormal() would issue per hit (src/intersections.h:85)
-    float cubeN[18];
+    // cube: for each of its six faces (entry axis * 2 + (sign > 0)) the surface normal
+    // normalize(multiplyMV(transform, (+-e_axis, 0))) (src/intersections.h:85) and the two tangent directions the
+    // hemisphere sampler derives from a normal (src/interactions.h:22-35), 9 floats per face, evaluated once on the host
+    // with the operations the kernels would issue per hit
+    float cubeFrame[54];
     float pad3[2];
 };
-static_assert(sizeof(GeomDev) == 288, "GeomDev is 18 x 16 B");
+static_assert(sizeof(GeomDev) == 432, "GeomDev is 27 x 16 B");
 
 struct MaterialDev {
     float color[3];
@@ -381,44 +383,49 @@ __device__ __forceinline__ float sphereIntersectionTest(const GeomDev &g, F3 ro_
 // kernels evaluate it once, after the nearest-hit loop -- same inputs, same operations, same bits.
 // Sphere: `m` = rows 0-2 of invTranspose as mulMV expects them, nsrc = the object-space hit point.
 // Cube: nsrc = +-e_axis, so the normal is one of six vectors per cube, which pack_geom (pt_api.hip) evaluates with the
-// very operations of normalize(mulMV(transform, nsrc, 0)): a table lookup instead of 52 instructions per hit.
+// very operations of normalize(mulMV(transform, nsrc, 0)): a table lookup instead of 52 instructions per hit.  The
+// table also holds the hemisphere sampler's two tangent directions of each face (functions of the normal alone).
 __device__ __forceinline__ F3 hitNormalSphere(const float *invT, F3 nsrc, bool outside) {
     const F3 n = normalize(mulMV(invT, nsrc, 0.0f));
     return outside ? n : -n;
 }
-__device__ __forceinline__ F3 hitNormalCube(const float *cubeN, F3 nsrc) {
+// face index of a cube hit (axis * 2 + (sign > 0)); ok = false for a hit without an exit slab -- a ray of NaNs -- which
+// leaves nsrc = 0: the reference then normalises the zero vector, i.e. every derived vector is NaN
+__device__ __forceinline__ int cubeFace(F3 nsrc, bool &ok) {
     const int axis = nsrc.x != 0.0f ? 0 : (nsrc.y != 0.0f ? 1 : 2);
     const float v = nsrc.x + nsrc.y + nsrc.z;                     // the one non-zero component, +-1
-    const float *n = cubeN + 3 * (2 * axis + (v > 0.0f ? 1 : 0));
-    // (a hit without an exit slab -- a ray of NaNs -- leaves nsrc = 0, and the reference normalises the zero vector)
-    const bool ok = v != 0.0f;
+    ok = v != 0.0f;
+    return 2 * axis + (v > 0.0f ? 1 : 0);
+}
+// entry `which` (0 normal, 1 and 2 the sampler's tangents) of a face of the table (selects: adding 0 would turn -0 into +0)
+__device__ __forceinline__ F3 cubeFrameVector(const float *cubeFrame, int face, int which, bool ok) {
+    const float *n = cubeFrame + 9 * face + 3 * which;
     const float nan = __builtin_nanf("");
-    return f3(ok ? n[0] : nan, ok ? n[1] : nan, ok ? n[2] : nan);          // (selects: adding 0 would turn -0 into +0)
+    return f3(ok ? n[0] : nan, ok ? n[1] : nan, ok ? n[2] : nan);
 }
 __device__ __forceinline__ F3 hitNormal(const GeomDev &g, F3 nsrc, bool outside) {
-    return g.type == 0 ? hitNormalSphere(g.invT, nsrc, outside) : hitNormalCube(g.cubeN, nsrc);
+    if (g.type == 0) return hitNormalSphere(g.invT, nsrc, outside);
+    bool ok;
+    const int face = cubeFace(nsrc, ok);
+    return cubeFrameVector(g.cubeFrame, face, 0, ok);
 }
 
 // Per-geom record staged in LDS for the per-lane lookups that follow the nearest-hit loop: the sphere's normal matrix
-// (12 floats), the material index, the type and the cube's six normals.  Lanes of a wave index different geoms, so the
-// row stride is 128 + 16 B (one access width of padding): consecutive rows start 4 banks apart and 8 different rows
-// are conflict-free (64-B rows collided two ways: SQ_LDS_BANK_CONFLICT 20 % of LDS cycles).
+// (12 floats), the material index, the type and the cube's six face frames.  Lanes of a wave index different geoms, so
+// the row stride is 76 words: consecutive rows start 12 banks apart and 8 different rows are conflict-free
+// (64-B rows collided two ways: SQ_LDS_BANK_CONFLICT 20 % of LDS cycles).
 struct GeomHitDev {
     float nm[12];
     int   material;
     int   type;
-    float cubeN[18];
-    int   pad[4];
+    float cubeFrame[54];
+    int   pad[8];
 };
-static_assert(sizeof(GeomHitDev) == 144, "GeomHitDev is 9 x 16 B");
+static_assert(sizeof(GeomHitDev) == 304, "GeomHitDev is 19 x 16 B");
 
-// src/interactions.h:10-42
-__device__ __forceinline__ F3 calculateRandomDirectionInHemisphere(F3 normal, Rng &rng) {
-    // u01 is 0 or at least 2^-31, and 1 - up*up is 0 or at least 2^-24 (up*up <= 1 is a float): both operands are
-    // inside sqrtUnscaled's range by construction
-    float up = sqrtUnscaled(u01(rng));
-    float over = sqrtUnscaled(1 - up * up);
-    float around = u01(rng) * kTwoPi;
+// src/interactions.h:10-42, in three parts: the tangent frame is a function of the normal alone (for a cube face it
+// comes from GeomDev::cubeFrame), the draws are two random numbers, the combination is the reference's last line.
+__device__ __forceinline__ void hemisphereFrame(F3 normal, F3 &p1, F3 &p2) {
     F3 notNormal;
     if (__builtin_fabsf(normal.x) < kSqrtOneThird) {
         notNormal = f3(1, 0, 0);
@@ -427,11 +434,30 @@ __device__ __forceinline__ F3 calculateRandomDirectionInHemisphere(F3 normal, Rn
     } else {
         notNormal = f3(0, 0, 1);
     }
-    F3 p1 = normalize(cross(normal, notNormal));
-    F3 p2 = normalize(cross(normal, p1));
+    p1 = normalize(cross(normal, notNormal));
+    p2 = normalize(cross(normal, p1));
+}
+// the sample's coordinates in that frame: `up` along the normal, (c, s) * over across it (two draws: up, then the angle)
+__device__ __forceinline__ void hemisphereDraws(Rng &rng, float &up, float &cOver, float &sOver) {
+    // u01 is 0 or at least 2^-31, and 1 - up*up is 0 or at least 2^-24 (up*up <= 1 is a float): both operands are
+    // inside sqrtUnscaled's range by construction
+    up = sqrtUnscaled(u01(rng));
+    const float over = sqrtUnscaled(1 - up * up);
+    const float around = u01(rng) * kTwoPi;
     float s, c;
     sincosPoly(around, s, c);
-    return (normal * up + p1 * (c * over)) + p2 * (s * over);
+    cOver = c * over;
+    sOver = s * over;
+}
+__device__ __forceinline__ F3 hemisphereCombine(F3 normal, F3 p1, F3 p2, float up, float cOver, float sOver) {
+    return (normal * up + p1 * cOver) + p2 * sOver;
+}
+__device__ __forceinline__ F3 calculateRandomDirectionInHemisphere(F3 normal, Rng &rng) {
+    float up, cOver, sOver;
+    hemisphereDraws(rng, up, cOver, sOver);
+    F3 p1, p2;
+    hemisphereFrame(normal, p1, p2);
+    return hemisphereCombine(normal, p1, p2, up, cOver, sOver);
 }
 
 }  // namespace ptd

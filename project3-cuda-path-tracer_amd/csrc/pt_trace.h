@@ -222,7 +222,7 @@ __global__ __launch_bounds__(kBlock, (FIRST || MANY) ? 5 : 6) void k_bounce(KPar
             if (k < 12) v = __float_as_uint(G.invT[k]);
             else if (k == 12) v = (uint32_t)G.material;
             else if (k == 13) v = (uint32_t)G.type;
-            else if (k < 32) v = __float_as_uint(G.cubeN[k - 14]);
+            else if (k < 14 + 54) v = __float_as_uint(G.cubeFrame[k - 14]);
             reinterpret_cast<uint32_t *>(s_geomHit)[i] = v;
         }
         if (MANY) {
@@ -371,7 +371,10 @@ __global__ __launch_bounds__(kBlock, (FIRST || MANY) ? 5 : 6) void k_bounce(KPar
                 missed = true;                                   // S4: background is black
             } else {
                 const GeomHitDev &GH = s_geomHit[hit];               // per-lane geom: LDS lookup
-                const F3 N = GH.type == 0 ? hitNormalSphere(GH.nm, nsrc, outside) : hitNormalCube(GH.cubeN, nsrc);
+                const bool isSphere = GH.type == 0;
+                bool faceOk = true;
+                const int face = isSphere ? 0 : cubeFace(nsrc, faceOk);
+                const F3 N = isSphere ? hitNormalSphere(GH.nm, nsrc, outside) : cubeFrameVector(GH.cubeFrame, face, 0, faceOk);
                 const MaterialDev &M = smats[GH.material];
                 const F3 mcol = f3(M.color[0], M.color[1], M.color[2]);
                 if (M.emittance > 0.0f) {                        // S5: emitter ends the path
@@ -428,7 +431,18 @@ __global__ __launch_bounds__(kBlock, (FIRST || MANY) ? 5 : 6) void k_bounce(KPar
                         col = col * mcol;
                         norg = P + N * 0.001f;
                     }
-                    if (diffuse) ndir = calculateRandomDirectionInHemisphere(N, rng);
+                    if (diffuse) {
+                        float up, cOver, sOver;
+                        hemisphereDraws(rng, up, cOver, sOver);
+                        F3 p1, p2;                                // the sampler's tangent frame: computed for a sphere, looked up for a cube face
+                        if (isSphere) {
+                            hemisphereFrame(N, p1, p2);
+                        } else {
+                            p1 = cubeFrameVector(GH.cubeFrame, face, 1, faceOk);
+                            p2 = cubeFrameVector(GH.cubeFrame, face, 2, faceOk);
+                        }
+                        ndir = hemisphereCombine(N, p1, p2, up, cOver, sOver);
+                    }
                     org = norg;
                     dir = ndir;
                     alive = true;

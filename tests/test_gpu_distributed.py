@@ -95,4 +95,4 @@ def test_bench_two_ranks_contract(pt):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 48 and d["warmup"] == 16 and d["scaling"] == "strong"
     assert "cpu_baseline" not in d and d["value"] > 0
-    assert "rows sharded y%2" in d["config"]["workload"] and d["config"]["iterations_per_wavefront_batch"] == 32     # 16 x N
+    assert "rows sharded y%2" in d["config"]["workload"] and d["config"]["iterations_per_wavefront_batch"] == 64     # 32 x N, at most 64
