@@ -176,9 +176,10 @@ int pt_test_sphere_cull_sweep(const PtGeom *geoms, int ngeoms, uint64_t seed, in
 int pt_test_slab_quotients(const float *o, const float *d, int n, float *t1, float *t2, float *ref1, float *ref2);
 int pt_test_slab_quotients_sweep(uint64_t seed, int64_t pairs, uint64_t *mismatches);
 /* sqrtUnscaled (the correctly rounded sqrt without its exponent-range handling, used by the hemisphere sampler)
- * next to the compiler's sqrt on every fp32 bit pattern of its range (+-0 and [2^-96, inf)):
- * mismatches[0] must be 0, mismatches[1] = number of patterns checked. */
-int pt_test_unscaled_sqrt_sweep(uint64_t mismatches[2]);
+ * next to the compiler's sqrt on every fp32 bit pattern of its range (+-0 and [2^-96, inf)), and inverseSqrtNearOne
+ * (the re-normalisation of getPointOnRay) next to 1.0f / sqrtf on every bit pattern: mismatches[0] and [2] must be 0,
+ * [1] = patterns inside sqrtUnscaled's range, [3] = patterns on inverseSqrtNearOne's short path (513). */
+int pt_test_unscaled_sqrt_sweep(uint64_t mismatches[4]);
 int pt_test_hemisphere(const float *normals3, const int32_t *iter_index_depth3, int n, float *out3);
 int pt_test_sincos(const float *x, int n, float *s, float *c);
 int pt_test_reflect_refract(const float *I3, const float *N3, const float *eta, int n, float *refl3,

@@ -361,7 +361,7 @@ def test_slab_quotients_sweep(seed, pairs):
 
 
 def test_unscaled_sqrt_sweep():
-    m = (C.c_uint64 * 2)()
+    m = (C.c_uint64 * 4)()
     _check(lib().pt_test_unscaled_sqrt_sweep(m))
     return [int(v) for v in m]
 

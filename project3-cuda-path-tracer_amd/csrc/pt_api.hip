@@ -996,34 +996,20 @@ int pt_test_slab_quotients_sweep(uint64_t seed, int64_t pairs, uint64_t *mismatc
     return PT_OK;
 }
 
-int pt_test_unscaled_sqrt_sweep(uint64_t mismatches[2]) {
+int pt_test_unscaled_sqrt_sweep(uint64_t mismatches[4]) {
     NEED_GPU();
     if (!mismatches) return fail(PT_ERR_INVALID, "pt_test_unscaled_sqrt_sweep: bad argument");
     DevBuf<unsigned long long> m;
-    int rc = m.alloc(2);
+    int rc = m.alloc(4);
     if (rc) return rc;
-    HIPCHECK(hipMemset(m.p, 0, 16));
+    HIPCHECK(hipMemset(m.p, 0, 32));
     hipLaunchKernelGGL(k_sweep_unscaled_sqrt, dim3(1 << 14), dim3(256), 0, 0, m.p);   // 2^22 threads x 2^10 patterns
     HIPCHECK(hipDeviceSynchronize());
-    unsigned long long h[2];
-    HIPCHECK(hipMemcpy(h, m.p, 16, hipMemcpyDeviceToHost));
-    mismatches[0] = h[0];
-    mismatches[1] = h[1];
+    unsigned long long h[4];
+    HIPCHECK(hipMemcpy(h, m.p, 32, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 4; ++i) mismatches[i] = h[i];
     return PT_OK;
 }
-
-#ifdef PT_PROBE
-// profiles/probe_phases.py: read (and clear) the phase counters of a -DPT_PROBE build
-int pt_probe_read(uint64_t out[16]) {
-    NEED_GPU();
-    unsigned long long h[16], z[16] = {0};
-    HIPCHECK(hipDeviceSynchronize());
-    HIPCHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(ptd::g_probe), sizeof h));
-    HIPCHECK(hipMemcpyToSymbol(HIP_SYMBOL(ptd::g_probe), z, sizeof z));
-    for (int i = 0; i < 16; ++i) out[i] = h[i];
-    return PT_OK;
-}
-#endif
 
 int pt_test_hemisphere(const float *normals3, const int32_t *iid3, int n, float *out3) {
     NEED_GPU();

@@ -108,20 +108,28 @@ __global__ void k_sweep_slab_quotients(unsigned long long seed, int per_thread, 
     }
     if (bad) atomicAdd(mismatches, (unsigned long long)bad);
 }
-// sqrtUnscaled next to the compiler's correctly rounded sqrt on EVERY fp32 bit pattern of its range (thread t checks
-// patterns t, t + stride, ...): bad[0] counts bit mismatches (NaN == NaN), bad[1] the patterns inside the range.
+// sqrtUnscaled next to the compiler's correctly rounded sqrt on EVERY fp32 bit pattern of its range, and
+// inverseSqrtNearOne next to 1.0f / sqrtf on every bit pattern at all (thread t checks patterns t, t + stride, ...):
+// bad[0] / bad[2] count bit mismatches (NaN == NaN), bad[1] the patterns inside sqrtUnscaled's range, bad[3] the
+// patterns that took inverseSqrtNearOne's short path.
 __global__ void k_sweep_unscaled_sqrt(unsigned long long *bad) {
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
-    unsigned int b0 = 0, n = 0;
+    unsigned int b0 = 0, n = 0, b2 = 0, n3 = 0;
     for (unsigned long long bits = tid; bits < (1ull << 32); bits += stride) {
         const float x = __uint_as_float((uint32_t)bits);
+        const float r = __builtin_sqrtf(x);
+        const float q = inverseSqrtNearOne(x), qr = 1.0f / r;
+        b2 += (__float_as_uint(q) == __float_as_uint(qr) || (q != q && qr != qr)) ? 0u : 1u;
+        n3 += (unsigned)((int)(uint32_t)bits - 0x3f800000 + 256) <= 512u ? 1u : 0u;
         if (!(x == 0.0f || (x >= 0x1p-96f && x < __builtin_inff()))) continue;
-        const float a = sqrtUnscaled(x), r = __builtin_sqrtf(x);
+        const float a = sqrtUnscaled(x);
         b0 += (__float_as_uint(a) == __float_as_uint(r) || (a != a && r != r)) ? 0u : 1u;
         ++n;
     }
     if (b0) atomicAdd(&bad[0], (unsigned long long)b0);
     atomicAdd(&bad[1], (unsigned long long)n);
+    if (b2) atomicAdd(&bad[2], (unsigned long long)b2);
+    if (n3) atomicAdd(&bad[3], (unsigned long long)n3);
 }
 __global__ void k_test_hemisphere(const float *nrm, const int *iid, int n, float *out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -106,9 +106,12 @@ def test_unscaled_sqrt_exhaustive(gpu):
     # The hemisphere sampler issues the compiler's correctly rounded sqrt WITHOUT the instructions that only act near
     # the exponent limits (pt_device.h: sqrtUnscaled); its operands (u01 and 1 - up^2) are 0 or >= 2^-31 by
     # construction.  Compared with __builtin_sqrtf on every fp32 bit pattern of the range +-0, [2^-96, inf).
-    bad, checked = gpu.test_unscaled_sqrt_sweep()
+    bad, checked, bad_inv, short_path = gpu.test_unscaled_sqrt_sweep()
     assert checked == 2 + ((0x7f800000 - 0x0f800000))      # +-0 and every positive float from 2^-96 up to FLT_MAX
     assert bad == 0
+    # inverseSqrtNearOne (getPointOnRay's re-normalisation: integer arithmetic within 256 ulps of 1, sqrt + division
+    # elsewhere) against 1.0f / sqrtf(x) on all 2^32 bit patterns
+    assert bad_inv == 0 and short_path == 513
 
 
 def test_sphere_culling_never_rejects_a_hit(gpu, oracle):
