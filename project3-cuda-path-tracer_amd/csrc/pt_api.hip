@@ -126,6 +126,7 @@ void pack_geom(const PtGeom &g, GeomDev &d, const float *eye = nullptr) {
             d.xf[c * 3 + r] = g.transform[c * 4 + r];
             d.invT[c * 3 + r] = g.invTranspose[c * 4 + r];
         }
+    for (int r = 0; r < 3; ++r) d.invZ[r] = d.inv[9 + r] * 0.0f;
     d.type = g.type;
     d.material = g.materialid;
     // bounding-ball culling data (ptd::certainMiss): bounds smax >= sigma_max, smin <= sigma_min of the 3x3 part

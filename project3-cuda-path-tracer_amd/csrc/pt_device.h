@@ -112,9 +112,12 @@ struct GeomDev {
     // hemisphere sampler derives from a normal (src/interactions.h:22-35), 9 floats per face, evaluated once on the host
     // with the operations the kernels would issue per hit
     float cubeFrame[54];
-    float pad3[2];
+    // inverseTransform's translation column times 0.0f (a signed zero each, or NaN): the w = 0 products of a direction
+    // transform, multiplyMV(inverseTransform, (d, 0)), evaluated once instead of once per ray
+    float invZ[3];
+    float pad3[3];
 };
-static_assert(sizeof(GeomDev) == 432, "GeomDev is 27 x 16 B");
+static_assert(sizeof(GeomDev) == 448, "GeomDev is 28 x 16 B");
 
 struct MaterialDev {
     float color[3];
@@ -134,6 +137,15 @@ __device__ __forceinline__ F3 mulMV(const float *m, F3 v, float w) {
     r.x = (m[0] * v.x + m[3] * v.y) + (m[6] * v.z + m[9] * w);
     r.y = (m[1] * v.x + m[4] * v.y) + (m[7] * v.z + m[10] * w);
     r.z = (m[2] * v.x + m[5] * v.y) + (m[8] * v.z + m[11] * w);
+    return r;
+}
+
+// mulMV(m, v, 0) with the three products m[9 + r] * 0.0f supplied (z0): same sums, three multiplications less
+__device__ __forceinline__ F3 mulMV0(const float *m, const float *z0, F3 v) {
+    F3 r;
+    r.x = (m[0] * v.x + m[3] * v.y) + (m[6] * v.z + z0[0]);
+    r.y = (m[1] * v.x + m[4] * v.y) + (m[7] * v.z + z0[1]);
+    r.z = (m[2] * v.x + m[5] * v.y) + (m[8] * v.z + z0[2]);
     return r;
 }
 
@@ -290,7 +302,7 @@ template <bool EARLY_MISS, bool CAM_ORIGIN = false>
 __device__ __forceinline__ float boxIntersectionTest(const GeomDev &g, F3 ro, F3 rd, F3 &P, F3 &nsrc, bool &outside) {
     probe(0);
     const F3 qo = CAM_ORIGIN ? f3(g.camObj[0], g.camObj[1], g.camObj[2]) : mulMV(g.inv, ro, 1.0f);
-    const F3 qdu = mulMV(g.inv, rd, 0.0f);
+    const F3 qdu = mulMV0(g.inv, g.invZ, rd);
     if (EARLY_MISS) {
         const bool away = (qo.x > 0.5f && qdu.x > 0.0f) || (qo.x < -0.5f && qdu.x < 0.0f) ||
                           (qo.y > 0.5f && qdu.y > 0.0f) || (qo.y < -0.5f && qdu.y < 0.0f) ||
@@ -361,13 +373,13 @@ __device__ __forceinline__ bool certainMiss(const GeomDev &g, F3 org, F3 dir, fl
 }
 
 // src/intersections.h:101-143 (pow(radius, 2) == 0.25f in the float overload nvcc selects).
-// `inv`, `xf`: rows 0-2 of inverseTransform / transform as mulMV expects them -- SGPR operands when the sphere is
+// `inv`, `invZ`, `xf`: rows 0-2 of inverseTransform (and its w = 0 products, GeomDev::invZ) / transform as mulMV expects them -- SGPR operands when the sphere is
 // wave-uniform (GeomDev through the scalar path), registers when every lane tests its own sphere (k_bounce<., MANY>).
 // `camObj`: the precomputed object-space origin of a camera ray, or nullptr.
-__device__ __forceinline__ float sphereIntersectionTestM(const float *inv, const float *xf, const float *camObj, F3 ro_w, F3 rd_w,
-                                                         F3 &P, F3 &nsrc, bool &outside) {
+__device__ __forceinline__ float sphereIntersectionTestM(const float *inv, const float *invZ, const float *xf, const float *camObj,
+                                                         F3 ro_w, F3 rd_w, F3 &P, F3 &nsrc, bool &outside) {
     F3 ro = camObj ? f3(camObj[0], camObj[1], camObj[2]) : mulMV(inv, ro_w, 1.0f);
-    F3 rd = normalize(mulMV(inv, rd_w, 0.0f));
+    F3 rd = normalize(mulMV0(inv, invZ, rd_w));
     float vDotDirection = dot(ro, rd);
     float radicand = vDotDirection * vDotDirection - (dot(ro, ro) - 0.25f);
     if (radicand < 0) return -1.0f;
@@ -396,7 +408,7 @@ template <bool CAM_ORIGIN = false>
 __device__ __forceinline__ float sphereIntersectionTest(const GeomDev &g, F3 ro_w, F3 rd_w, F3 &P, F3 &nsrc,
                                                         bool &outside) {
     probe(4);
-    return sphereIntersectionTestM(g.inv, g.xf, CAM_ORIGIN ? g.camObj : nullptr, ro_w, rd_w, P, nsrc, outside);
+    return sphereIntersectionTestM(g.inv, g.invZ, g.xf, CAM_ORIGIN ? g.camObj : nullptr, ro_w, rd_w, P, nsrc, outside);
 }
 
 // The surface normal of a hit, from what the two tests leave in `nsrc` (src/intersections.h:85 and :137-140).

@@ -19,7 +19,7 @@ constexpr int kSub = 4;              // append-counter shards per class (workgro
 constexpr int kSeg = kCls * kSub;    // path buffers are split into kSeg segments with one append counter each
 constexpr int kBinMax = 4;           // at most this many small primitives take part in the binning
 // k_bounce<., MANY> (scenes with more than kBinMax spheres): LDS words of the fixed scratch, floats per staged sphere
-// record (inverseTransform rows, transform rows, 16 B of padding), spheres a lane can record per tile
+// record (inverseTransform rows, transform rows, GeomDev::invZ, 4 B of padding), spheres a lane can record per tile
 constexpr int kMiscWords = kWaves * kCls + kCls + kSeg + (kSeg + 2) + 2 * PT_MAX_BATCH + 2;
 static_assert(kMiscWords % 4 == 0, "the sphere records that follow are read as float4");
 constexpr int kSphRowFloats = 28;
@@ -226,9 +226,9 @@ __global__ __launch_bounds__(kBlock, (FIRST || MANY) ? 5 : 6) void k_bounce(KPar
             reinterpret_cast<uint32_t *>(s_geomHit)[i] = v;
         }
         if (MANY) {
-            for (int i = threadIdx.x; i < prm.ngeoms * 24; i += kBlock) {
-                const int g = i / 24, k = i - g * 24;
-                s_sph[g * kSphRowFloats + k] = k < 12 ? ggeoms[g].inv[k] : ggeoms[g].xf[k - 12];
+            for (int i = threadIdx.x; i < prm.ngeoms * 27; i += kBlock) {
+                const int g = i / 27, k = i - g * 27;
+                s_sph[g * kSphRowFloats + k] = k < 12 ? ggeoms[g].inv[k] : (k < 24 ? ggeoms[g].xf[k - 12] : ggeoms[g].invZ[k - 24]);
             }
         }
     }
@@ -350,16 +350,16 @@ __global__ __launch_bounds__(kBlock, (FIRST || MANY) ? 5 : 6) void k_bounce(KPar
                     if (k < nCand) {
                         const int g = s_list[k * kBlock + threadIdx.x];
                         const float4 *row = reinterpret_cast<const float4 *>(s_sph + g * kSphRowFloats);
-                        float m[24];
+                        float m[28];
 #pragma unroll
-                        for (int q = 0; q < 6; ++q) {
+                        for (int q = 0; q < 7; ++q) {
                             const float4 v = row[q];
                             m[4 * q] = v.x; m[4 * q + 1] = v.y; m[4 * q + 2] = v.z; m[4 * q + 3] = v.w;
                         }
                         F3 p, n;
                         bool o = false;
                         probe(4);
-                        const float t = sphereIntersectionTestM(m, m + 12, nullptr, org, dir, p, n, o);
+                        const float t = sphereIntersectionTestM(m, m + 24, m + 12, nullptr, org, dir, p, n, o);
                         // a recorded sphere may precede, in file order, the primitive that holds the record so far
                         if (t > 0.0f && (hit < 0 || t < tbest || (t == tbest && g < hit))) {
                             tbest = t; hit = g; P = p; nsrc = n; outside = o;
