@@ -143,10 +143,12 @@ def test_cube_culling_never_rejects_a_hit(gpu, oracle):
         oracle.make_geom(1, 0, (-3, 1, 2), (75, -20, 130), (8, 0.5, 3)),
         oracle.make_geom(1, 0, (100, -50, 25), (45, 45, 45), (40, 40, 40)),
         oracle.make_geom(1, 0, (0.5, 0.25, -0.75), (0, 0, 45), (2, 2, 0.2)),
+        oracle.make_geom(1, 0, (-2, 3, 1), (20, 70, -35), (5, 0.1, 5)),       # 50:1 plate, near the anisotropy limit of the test
+        oracle.make_geom(1, 0, (4, -1, 2), (-60, 15, 80), (0.12, 6, 0.12)),   # 50:1 rod
     ]).view(gpu.GEOM_DTYPE)
     culled, bad = gpu.test_sphere_cull_sweep(geoms, 77, 1 << 28)
     assert bad == 0
-    assert culled > (1 << 28) // 10
+    assert culled > (1 << 28) // 16            # (the elongated shapes carry wide margins and are rarely culled)
 
 
 def test_reflect_refract_bit_exact(gpu):
