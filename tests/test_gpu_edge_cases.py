@@ -197,6 +197,12 @@ def test_headless_driver_renders_the_reference_protocol(gpu, oracle, tmp_path):
     want = (np.clip(img.reshape(64, 96, 3) / np.float32(5), 0, 1) * np.float32(255)).astype(np.uint8)[:, ::-1]
     assert np.array_equal(got, want)
     assert os.path.getsize(base + ".hdr") > 4 * 96 * 64
+    # --batch: iterations traced 4 at a time through the C ABI, one D2H copy before the save -- the same file, byte for byte
+    r = subprocess.run([exe, os.path.join(SCENES, "cornell.txt"), "--res", "96", "64", "--iterations", "5", "--depth", "8",
+                        "--out", base + "_b", "--batch", "4"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "one D2H copy" in r.stdout
+    assert open(base + "_b.png", "rb").read() == open(base + ".png", "rb").read()
 
 
 @pytest.mark.parametrize("eye,view,up,fovy", [
