@@ -303,11 +303,14 @@ __global__ __launch_bounds__(kBlock, (FIRST || MANY) ? 5 : 6) void k_bounce(KPar
                 col = f3(1.0f, 1.0f, 1.0f);
                 rem = prm.traceDepth;
             } else {
-                org = f3(in.a(0)[idx], in.a(1)[idx], in.a(2)[idx]);
-                dir = f3(in.a(3)[idx], in.a(4)[idx], in.a(5)[idx]);
-                col = f3(in.a(6)[idx], in.a(7)[idx], in.a(8)[idx]);
-                pix = in.pix()[idx];
-                const int packed = in.rem()[idx];               // remainingBounces | batch index << 8
+                // one running pointer through the 11 arrays (stride = cap): the array bases then need no registers of their own
+                const float *src = in.base + idx;
+                const size_t cap = (size_t)in.cap;
+                org.x = *src; src += cap; org.y = *src; src += cap; org.z = *src; src += cap;
+                dir.x = *src; src += cap; dir.y = *src; src += cap; dir.z = *src; src += cap;
+                col.x = *src; src += cap; col.y = *src; src += cap; col.z = *src; src += cap;
+                pix = __float_as_int(*src); src += cap;
+                const int packed = __float_as_int(*src);        // remainingBounces | batch index << 8
                 rem = packed & 0xff;
                 itb = packed >> 8;
             }
@@ -484,11 +487,13 @@ __global__ __launch_bounds__(kBlock, (FIRST || MANY) ? 5 : 6) void k_bounce(KPar
                 for (int w = 0; w < wave; ++w) waveOff += wv[w * kCls + cls];
                 const uint32_t oseg = cls * kSub + (blockIdx.x % kSub);
                 const uint32_t slot = oseg * (uint32_t)prm.segCap + s_base[cls] + waveOff + rank;
-                out.a(0)[slot] = org.x; out.a(1)[slot] = org.y; out.a(2)[slot] = org.z;
-                out.a(3)[slot] = dir.x; out.a(4)[slot] = dir.y; out.a(5)[slot] = dir.z;
-                out.a(6)[slot] = col.x; out.a(7)[slot] = col.y; out.a(8)[slot] = col.z;
-                out.pix()[slot] = pix;
-                out.rem()[slot] = (rem - 1) | (itb << 8);
+                float *dst = out.base + slot;
+                const size_t ocap = (size_t)out.cap;
+                *dst = org.x; dst += ocap; *dst = org.y; dst += ocap; *dst = org.z; dst += ocap;
+                *dst = dir.x; dst += ocap; *dst = dir.y; dst += ocap; *dst = dir.z; dst += ocap;
+                *dst = col.x; dst += ocap; *dst = col.y; dst += ocap; *dst = col.z; dst += ocap;
+                *dst = __int_as_float(pix); dst += ocap;
+                *dst = __int_as_float((rem - 1) | (itb << 8));
             }
             __syncthreads();   // every wave has read this tile's counts: each wave clears its own row for the next tile
             if (lane < kCls) wv[wave * kCls + lane] = 0u;
