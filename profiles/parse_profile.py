@@ -4,7 +4,7 @@
     profiles/<tag>_kernel_stats.csv      verbatim rocprofv3 --kernel-trace --stats summary
     profiles/<tag>_one_iteration.txt     per-dispatch durations of one iteration (per-bounce)
     profiles/<tag>_pmc_summary.json      PMC counters per kernel, per dispatch
-    profiles/pmc_traffic.json            {"hbm_bytes_per_bounce_launch": ...} read by bench.py
+    profiles/pmc_traffic.json            HBM bytes / VALU instructions per launch and per iteration of its batch, read by bench.py
 
 HBM traffic per launch = FETCH_SIZE * 1024 * read_factor + WRITE_SIZE * 1024 (both counters are in KiB).
 read_factor = 2 on gfx950 for coalesced streams (MI355X_MICROARCH.md, section HBM).  It was CALIBRATED on
@@ -119,24 +119,27 @@ def main():
         traffic = kb["FETCH_SIZE"] * 1024.0 * rf_used + kb["WRITE_SIZE"] * 1024.0
         out["k_bounce"]["hbm_bytes_per_launch"] = traffic
         out["k_bounce"]["read_factor_used"] = rf_used
-        pj = {"hbm_bytes_per_bounce_launch": round(traffic, 1), "read_factor_used": rf_used,
+        pj = {"hbm_bytes_per_launch": round(traffic, 1), "read_factor_used": rf_used,
               "read_factor_calibrated": rf, "write_factor_calibrated": cal.get("write_factor"),
               "source": "profiles/%s_pmc_summary.json" % args.tag}
-        if "SQ_INSTS_VALU" in kb:
-            # a wave64 VALU instruction occupies its SIMD for 4 cycles (SQ_ACTIVE_INST_VALU ~= SQ_INSTS_VALU quad-cycles);
-            # 1024 SIMDs at 2.4 GHz -> the time the launch needs if the VALUs never idle
-            pj["valu_wave_insts_per_bounce_launch"] = kb["SQ_INSTS_VALU"]
-            pj["valu_issue_bound_ms_per_launch"] = kb["SQ_INSTS_VALU"] * 4.0 / (1024 * 2.4e9) * 1e3
-            pj["lds_bank_conflict_cycles_per_launch"] = kb.get("SQ_LDS_BANK_CONFLICT")
-        # which bench configuration the counters belong to: bench.py reports them only for the same one
+        # which bench configuration the counters belong to: bench.py reports them only for the same one, scaled by the
+        # iterations a launch carries (the figures are stored per iteration of a launch's batch)
+        ipl = None
         try:
             for line in open(os.path.join(src, "pmc_fetch.log")):
                 if line.startswith("{"):
                     b = json.loads(line)
-                    pj["workload"] = b["config"]["workload"].split(",")[0:1] + b["config"]["workload"].split(",")[2:3]
-                    pj["iterations_per_wavefront_batch"] = b["config"]["iterations_per_wavefront_batch"]
+                    pj["workload"] = b["config"]["workload"].split(", ")[0:2]
+                    ipl = b["roofline"]["iterations_per_launch"]
         except (OSError, ValueError, KeyError):
             pass
+        if ipl:
+            pj["iterations_per_launch"] = ipl
+            pj["hbm_bytes_per_launch_iteration"] = traffic / ipl
+            if "SQ_INSTS_VALU" in kb:
+                pj["valu_wave_insts_per_launch_iteration"] = kb["SQ_INSTS_VALU"] / ipl
+                pj["salu_insts_per_launch_iteration"] = kb.get("SQ_INSTS_SALU", 0.0) / ipl
+                pj["lds_bank_conflict_cycles_per_launch"] = kb.get("SQ_LDS_BANK_CONFLICT")
         json.dump(pj, open(os.path.join(HERE, "pmc_traffic.json"), "w"), indent=1)
     if "SQ_LDS_BANK_CONFLICT" in kb:
         out["k_bounce"]["lds_bank_conflict_cycles_per_launch"] = kb["SQ_LDS_BANK_CONFLICT"]

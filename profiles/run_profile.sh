@@ -3,12 +3,12 @@
 # Writes raw output under gpurun_out/prof_<tag>/ ; copy the summaries into profiles/ afterwards.
 set -o pipefail
 TAG=${1:-r01}
-STEPS=${2:-1024}
+STEPS=${2:-32}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 # one iteration in flight: a dispatch then owns the GPU, so its duration and counters are the kernel's own
-BENCH="python3 $PWD/bench.py --steps $STEPS --warmup 128 --cpu-spp 0 --pipeline ${PIPELINE:-1} --batch ${BATCH:-32}"
+BENCH="python3 $PWD/bench.py --steps $STEPS --warmup 4 --cpu-spp 0 --pipeline ${PIPELINE:-1} --batch ${BATCH:-32} ${BENCH_ARGS:-}"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1 || { echo "trace failed"; tail -5 $OUT/trace.log; exit 1; }
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH > $OUT/pmc_fetch.log 2>&1 || { echo "pmc fetch failed"; tail -5 $OUT/pmc_fetch.log; exit 1; }

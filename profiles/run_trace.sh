@@ -5,7 +5,7 @@ TAG=${1:-x}
 OUT=$PWD/gpurun_out/trace_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python3 $PWD/bench.py --steps 4 --warmup 2 --cpu-spp 0 --pipeline 1 --batch ${BATCH:-32} ${BENCH_ARGS:-}"
+BENCH="python3 $PWD/bench.py --steps 2 --warmup 1 --cpu-spp 0 --pipeline 1 --batch ${BATCH:-32} ${BENCH_ARGS:-}"
 cd /tmp
 rocprofv3 --kernel-trace --output-format csv -d $OUT/t -- $BENCH > $OUT/t.log 2>&1 || { echo "trace failed"; tail -5 $OUT/t.log; exit 1; }
 python3 - "$OUT" <<'PY'

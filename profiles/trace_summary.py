@@ -2,7 +2,7 @@ import csv, glob, sys
 f = glob.glob(sys.argv[1]+'/*/*kernel_trace.csv')[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
-idx = [i for i,r in enumerate(rows) if 'generate' in r['Kernel_Name'] or 'k_bounce<true>' in r['Kernel_Name']]
+idx = [i for i,r in enumerate(rows) if 'generate' in r['Kernel_Name'] or 'k_bounce<true' in r['Kernel_Name']]
 i0 = idx[len(idx)//2]
 prev_end=None
 n = (idx[len(idx)//2+1]-i0+1) if len(idx) > len(idx)//2+1 else 10

@@ -2,8 +2,10 @@
 
 Image rows are dealt to the ranks like cards (row y -> rank y % world), which balances the black
 border rows and the bright light rows.  Every rank accumulates ONLY its own rows, packed
-(PT_FLAG_ACCUM_SHARD_ROWS), and the frame is assembled at rank 0 once per iteration by a single
-collective: a gather of the row blocks (RCCL over xGMI on the GPUs, gloo in the CPU tests).
+(PT_FLAG_ACCUM_SHARD_ROWS), and the frame is assembled at rank 0 by a single collective -- a gather of the
+row blocks (RCCL over xGMI on the GPUs, gloo in the CPU tests) -- issued by the caller after every iteration
+(BASELINE config C3 as written; bench.py --collective-every 1) or after every wavefront batch of iterations
+(--collective-every batch: accumulation is additive, so the frame at rank 0 is the same whenever it is assembled).
 
 Why a gather and not the reduce(sum) of zero-padded full frames that BASELINE.json sketches: the rows
 are disjoint, so the reduce would add x + 0 + ... + 0 -- the same result (both are bit-identical to a
@@ -37,7 +39,11 @@ def init_process_group(backend=None):
         return 0, 1
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC, the only kind this driver supports) is read when the HSA runtime
+    # starts, i.e. at the first GPU call of the process: the caller exports it before touching the GPU (bench.py does
+    # so at its very top); setting it here would be too late.
+    if backend == "nccl" and os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") != "0":
+        raise RuntimeError("export HSA_ENABLE_IPC_MODE_LEGACY=0 before the first GPU call (RCCL needs dmabuf IPC here)")
     kw = {}
     if backend == "nccl":
         kw["device_id"] = torch.device("cuda", torch.cuda.current_device())
@@ -72,33 +78,32 @@ def _interleave_rows(bufs, frame, width, height, world):
             rows_view[r::world].copy_(bufs[r][:n * width * 3].view(n, width * 3))
 
 
-_use_reduce_fallback = False   # set on the first failure of dist.gather (all ranks fail alike: same library)
-
-
-def gather_frame(block, bufs, frame, width, height, dst=0):
+def gather_frame(block, bufs, frame, width, height, dst=0, collective="gather"):
     """The data path's single collective: rank `dst` receives every rank's packed rows and interleaves
     them into `frame` (H*W*3 floats).  `block` is this rank's packed accumulator, padded to
     padded_block_floats(); it keeps accumulating, the collective only reads it.
 
-    Should the backend refuse `gather` (it is built from grouped send/recv), the exchange falls back to
-    the reduce(sum) of zero-padded full frames that BASELINE.json names: same result, world x the bytes."""
-    global _use_reduce_fallback
+    `collective` is chosen by the caller, once, identically on every rank (a command-line option in bench.py);
+    nothing here switches it at run time, and an error of the backend propagates -- a failed RCCL collective
+    leaves the communicator unusable, so there is nothing to fall back to:
+      "gather"  every rank sends its 1/world of the frame straight to `dst` (default);
+      "reduce"  the reduce(sum) of zero-padded full frames that BASELINE.json sketches: same bits (x + 0 is
+                exact), world x the bytes."""
     import torch
     import torch.distributed as dist
+    if collective not in ("gather", "reduce"):
+        raise ValueError("gather_frame: collective must be 'gather' or 'reduce', not %r" % (collective,))
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     if world == 1:
         frame.copy_(block[:frame.numel()])
         return frame
-    if not _use_reduce_fallback:
-        try:
-            dist.gather(block, bufs if rank == dst else None, dst=dst)
-            if rank == dst:
-                _interleave_rows(bufs, frame, width, height, world)
-            return frame
-        except (RuntimeError, NotImplementedError, ValueError):
-            _use_reduce_fallback = True
-    # reduce(sum) of full frames: this rank's rows in place, zeros elsewhere (x + 0 is exact)
+    if collective == "gather":
+        dist.gather(block, bufs if rank == dst else None, dst=dst)
+        if rank == dst:
+            _interleave_rows(bufs, frame, width, height, world)
+        return frame
+    # reduce(sum) of full frames: this rank's rows in place, zeros elsewhere
     full = torch.zeros(height * width * 3, dtype=block.dtype, device=block.device)
     n = len(shard_rows(height, rank, world))
     if n:

@@ -68,7 +68,7 @@ def test_two_ranks_gloo_assemble_the_frame_bit_exactly(tmp_path, res):
     assert np.load(out)[0] == 1
 
 
-def _worker_fallback(rank, world, port, out_path):
+def _worker_reduce(rank, world, port, out_path):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     sys.path.insert(0, ROOT)
@@ -76,27 +76,26 @@ def _worker_fallback(rank, world, port, out_path):
     import __graft_entry__ as ge
     ptdist = ge.load_submodule("distributed")
     ptdist.init_process_group("gloo")
-    ptdist._use_reduce_fallback = True                          # what a backend without gather ends up using
     W, H = 5, 7
     block = torch.zeros(ptdist.padded_block_floats(W, H, world))
     rows = list(ptdist.shard_rows(H, rank, world))
     vals = torch.arange(H * W * 3, dtype=torch.float32).view(H, W * 3)[rows].reshape(-1)
     block[:vals.numel()] = vals
     frame = torch.full((H * W * 3,), -1.0) if rank == 0 else None
-    ptdist.gather_frame(block, None, frame, W, H, dst=0)
+    ptdist.gather_frame(block, None, frame, W, H, dst=0, collective="reduce")   # the collective BASELINE.json sketches
     if rank == 0:
         np.save(out_path, np.array([int(torch.equal(frame, torch.arange(H * W * 3, dtype=torch.float32)))]))
     torch.distributed.destroy_process_group()
 
 
-def test_reduce_fallback_assembles_the_same_frame(tmp_path):
+def test_reduce_collective_assembles_the_same_frame(tmp_path):
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     out = str(tmp_path / "ok.npy")
-    mp.spawn(_worker_fallback, args=(3, port, out), nprocs=3, join=True)
+    mp.spawn(_worker_reduce, args=(3, port, out), nprocs=3, join=True)
     assert np.load(out)[0] == 1
 
 

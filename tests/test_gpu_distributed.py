@@ -75,24 +75,51 @@ def test_ranks_render_their_rows_on_the_gpu_and_gather_the_frame(pt, tmp_path, w
     assert np.load(out)[0] == 1
 
 
-def test_bench_two_ranks_contract(pt):
-    # bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, one process per rank), gloo
-    # standing in for RCCL because both ranks share the box's single GPU
+def _single_rank_frame(pt, iterations, batch):
+    """The unsharded 1280x720 Cornell render of iterations 1..iterations on this process's GPU (running sum)."""
+    sc = pt.Scene(os.path.join(SCENES, "cornell.txt"))
+    sc.set_resolution(1280, 720)
+    pt.pathtraceFree()
+    pt.pathtraceInit(sc, traceDepth=8, pipeline_depth=2, max_batch=batch)
+    it = 1
+    while it <= iterations:
+        n = min(batch, iterations - it + 1)
+        pt.pathtrace_batch(None, 0, it, n)
+        it += n
+    got = pt.readback(1280 * 720)
+    pt.pathtraceFree()
+    return got
+
+
+@pytest.mark.parametrize("every,extra", [("batch", []), ("1", ["--batch", "4"]), ("batch", ["--collective", "reduce", "--batch", "8"])])
+def test_bench_two_ranks_contract(pt, tmp_path, every, extra):
+    # bench.py --gpus 2 WITHOUT a torchrun environment: it starts its two ranks itself (torch.distributed.run as a
+    # child, one process per rank -- exactly what the driver launches); gloo stands in for RCCL because both ranks
+    # share the box's single GPU.  Rank 0's assembled 1280x720 frame must equal the single-rank render BIT FOR BIT,
+    # with the collective after every batch, after every iteration, and as the reduce of zero-padded frames.
     if pt.device_count() < 1:
         pytest.fail("no HIP device: GPU tests must run on the MI355X box")
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
     env = dict(os.environ, BENCH_BACKEND="gloo")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
-                        "--gpus", "2", "--steps", "48", "--warmup", "16"],
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    dump = str(tmp_path / "frame.npy")
+    steps, warmup = 3, 1
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", str(steps), "--warmup", str(warmup),
+                        "--collective-every", every, "--per-iteration-sample", "1", "--dump-frame", dump] + extra,
                        capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                          # rank 0 only
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 48 and d["warmup"] == 16 and d["scaling"] == "strong"
+    B = int(extra[extra.index("--batch") + 1]) if "--batch" in extra else 32
+    assert d["n_gpus"] == 2 and d["steps"] == steps and d["warmup"] == warmup and d["scaling"] == "strong"
     assert "cpu_baseline" not in d and d["value"] > 0
-    assert "rows sharded y%2" in d["config"]["workload"] and d["config"]["iterations_per_wavefront_batch"] == 64     # 32 x N, at most 64
+    assert "rows sharded y%2" in d["config"]["workload"] and d["config"]["iterations_per_step"] == B
+    assert d["config"]["collective_every"] == every
+    assert d["config"]["iterations_per_wavefront_batch"] == (B if every == "batch" else 1)
+    if every == "batch":
+        assert d["config"]["per_iteration_collective"]["value"] > 0   # config C3 as written, timed beside it
+    got = np.load(dump)
+    want = _single_rank_frame(pt, (steps + warmup) * B, B)
+    assert want.max() > 0
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
