@@ -38,12 +38,22 @@ struct Stamp {
     unsigned pad[2];
 };
 
-enum Op { FMA, MUL, ADD, CNDMASK, PKFMA, RCP, SQRT, RSQ, MIX_SALU, MIX_KERNEL, DEP_FMA, NUM_OPS };
+enum Op { FMA, MUL, ADD, CNDMASK, PKFMA, RCP, SQRT, RSQ, MIX_SALU, MIX_KERNEL, DEP_FMA, CNDMASK_S, CMP_CND, CMP_SGPR, MAD64, MULLO, MULHI,
+          DIVSCALE, DIVFMAS, DIVFIXUP, LSHLADD64, CVT, READLANE, SAVEEXEC, BRANCH_NT, DSREAD, BPERMUTE, PKMUL, NOP_MIX, BRANCH_SCC_NT, BRANCH_TAKEN, BRANCH_NT_SPARSE, EXEC0_FMA, MOV, ADDU32, CMP_VCC, CND_FMA, NUM_OPS };
 static const char *kOpName[NUM_OPS] = {"v_fma_f32", "v_mul_f32", "v_add_f32", "v_cndmask_b32", "v_pk_fma_f32", "v_rcp_f32", "v_sqrt_f32",
                                        "v_rsq_f32", "v_fma_f32 + s_add_u32 (2:1)", "mix fma/mul/add/cndmask/cmp + salu + 1/16 rcp",
-                                       "v_fma_f32 dependent chain"};
+                                       "v_fma_f32 dependent chain", "v_cndmask_b32 (sgpr-pair mask)", "v_cmp_lt_f32 vcc + v_cndmask_b32 vcc (pairs)",
+                                       "v_cmp_lt_f32 -> sgpr pair", "v_mad_u64_u32", "v_mul_lo_u32", "v_mul_hi_u32", "v_div_scale_f32", "v_div_fmas_f32",
+                                       "v_div_fixup_f32", "v_lshl_add_u64", "v_cvt_f32_u32", "v_readlane_b32 + v_writelane_b32 (pairs)",
+                                       "6 v_fma_f32 + s_and_saveexec_b64 + s_or_b64 exec (per group; cycles per v_fma)", "7 v_fma_f32 + s_cbranch_execz not taken (per group; cycles per v_fma)",
+                                       "8 VALU + ds_read_b32 + s_waitcnt (per group; cycles per VALU)", "8 VALU + ds_bpermute_b32 + s_waitcnt (per group; cycles per VALU)", "v_pk_mul_f32",
+                                       "v_fma_f32 + s_nop 0 (1:1)", "7 v_fma_f32 + s_cmp + s_cbranch_scc1 not taken (per group; cycles per v_fma)",
+                                       "7 v_fma_f32 + s_cbranch_execnz taken, to the next instruction (per group; cycles per v_fma)",
+                                       "31 v_fma_f32 + s_cbranch_execz not taken (per 4 groups; cycles per v_fma)",
+                                       "v_fma_f32 with EXEC = 0 (6 of 8; s_mov exec around them; cycles per v_fma)", "v_mov_b32", "v_add_u32",
+                                       "v_cmp_lt_f32 -> vcc", "v_cndmask_b32 vcc + v_fma_f32 alternating"};
 // vector instructions per unrolled block (what the cycles are divided by)
-static const int kVecPerBlock[NUM_OPS] = {64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64};
+static const int kVecPerBlock[NUM_OPS] = {64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 48, 56, 64, 64, 64, 64, 56, 56, 62, 64, 64, 64, 64, 64};
 
 #define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 
@@ -60,6 +70,12 @@ __global__ __launch_bounds__(1024) void k_rate(int iters, Stamp *out, float *sin
     }
     float2v px = {x, x}, py = {y, y};
     unsigned s0 = blockIdx.x, s1 = 1;
+    unsigned long long smask = 0x5555555555555555ull | blockIdx.x, smask2 = 0;
+    unsigned long long q[8];
+    unsigned ix = threadIdx.x * 2654435761u + 12345u, iy = blockIdx.x * 40503u + 7u;
+    const unsigned ldsaddr = (threadIdx.x & 63) * 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) q[i] = (unsigned long long)ix * (i + 3);
     if (threadIdx.x == 0) lds[0] = x;   // touch the allocation
     __syncthreads();
     const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
@@ -80,7 +96,7 @@ __global__ __launch_bounds__(1024) void k_rate(int iters, Stamp *out, float *sin
                 REP8(X)
 #undef X
             } else if (OP == CNDMASK) {
-#define X(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(y) : "vcc");
+#define X(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(y));
                 REP8(X)
 #undef X
             } else if (OP == PKFMA) {
@@ -124,6 +140,132 @@ __global__ __launch_bounds__(1024) void k_rate(int iters, Stamp *out, float *sin
                 if (u & 1) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[7]));
                 else asm volatile("v_sub_f32 %0, %1, %0" : "+v"(a[7]) : "v"(y));
                 asm volatile("s_add_u32 %0, %0, 1" : "+s"(s1) : : "scc");
+            } else if (OP == CNDMASK_S) {
+#define X(i) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a[i]) : "v"(y), "s"(smask));
+                REP8(X)
+#undef X
+            } else if (OP == CMP_CND) {   // 4 pairs: the select depends on the compare through vcc
+#define X(i) asm volatile("v_cmp_lt_f32 vcc, %1, %2\n\tv_cndmask_b32 %0, %0, %2, vcc" : "+v"(a[i]) : "v"(a[i + 4]), "v"(y) : "vcc");
+                X(0) X(1) X(2) X(3)
+#undef X
+            } else if (OP == CMP_SGPR) {
+#define X(i) asm volatile("v_cmp_lt_f32_e64 %0, %1, %2" : "=s"(smask) : "v"(a[i]), "v"(y));
+                REP8(X)
+#undef X
+            } else if (OP == MAD64) {
+#define X(i) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(q[i]) : "v"(ix), "v"(iy) : "vcc");
+                REP8(X)
+#undef X
+            } else if (OP == MULLO) {
+#define X(i) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[i]) : "v"(ix));
+                REP8(X)
+#undef X
+            } else if (OP == MULHI) {
+#define X(i) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(a[i]) : "v"(ix));
+                REP8(X)
+#undef X
+            } else if (OP == DIVSCALE) {
+#define X(i) asm volatile("v_div_scale_f32 %0, vcc, %1, %1, %0" : "+v"(a[i]) : "v"(y) : "vcc");
+                REP8(X)
+#undef X
+            } else if (OP == DIVFMAS) {
+#define X(i) asm volatile("v_div_fmas_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(x), "v"(y));
+                REP8(X)
+#undef X
+            } else if (OP == DIVFIXUP) {
+#define X(i) asm volatile("v_div_fixup_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(x), "v"(y));
+                REP8(X)
+#undef X
+            } else if (OP == LSHLADD64) {
+#define X(i) asm volatile("v_lshl_add_u64 %0, %0, 2, %1" : "+v"(q[i]) : "v"(q[(i + 1) & 7]));
+                REP8(X)
+#undef X
+            } else if (OP == CVT) {
+#define X(i) asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(a[i]));
+                REP8(X)
+#undef X
+            } else if (OP == READLANE) {
+#define X(i) asm volatile("v_readlane_b32 %1, %0, 3\n\tv_writelane_b32 %0, %1, 5" : "+v"(a[i]), "=s"(s1));
+                X(0) X(1) X(2) X(3)
+#undef X
+            } else if (OP == SAVEEXEC) {
+#define X(i) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(x), "v"(y));
+                asm volatile("s_and_saveexec_b64 %0, %1" : "=s"(smask2) : "s"(smask) : "scc", "exec");
+                X(0) X(1) X(2)
+                asm volatile("s_or_b64 exec, exec, %0" : : "s"(smask2) : "scc", "exec");
+                X(3) X(4) X(5)
+#undef X
+            } else if (OP == BRANCH_NT) {
+#define X(i) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(x), "v"(y));
+                X(0) X(1) X(2) X(3)
+                asm volatile("s_cbranch_execz 1f\n1:" : : : "scc");
+                X(4) X(5) X(6)
+#undef X
+            } else if (OP == DSREAD) {
+#define X(i) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(x), "v"(y));
+                float t;
+                asm volatile("ds_read_b32 %0, %1" : "=v"(t) : "v"(ldsaddr));
+                X(0) X(1) X(2) X(3) X(4) X(5) X(6)
+                asm volatile("s_waitcnt lgkmcnt(0)\n\tv_add_f32 %0, %1, %0" : "+v"(a[7]) : "v"(t));
+#undef X
+            } else if (OP == BPERMUTE) {
+#define X(i) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(x), "v"(y));
+                float t;
+                asm volatile("ds_bpermute_b32 %0, %1, %2" : "=v"(t) : "v"(ldsaddr), "v"(a[7]));
+                X(0) X(1) X(2) X(3) X(4) X(5) X(6)
+                asm volatile("s_waitcnt lgkmcnt(0)\n\tv_add_f32 %0, %1, %0" : "+v"(a[7]) : "v"(t));
+#undef X
+            } else if (OP == PKMUL) {
+#define X(i) asm volatile("v_pk_mul_f32 %0, %1, %0" : "+v"(p[i]) : "v"(px));
+                REP8(X)
+#undef X
+            } else if (OP == NOP_MIX) {
+#define X(i) asm volatile("v_fma_f32 %0, %1, %2, %0\n\ts_nop 0" : "+v"(a[i]) : "v"(x), "v"(y));
+                REP8(X)
+#undef X
+            } else if (OP == BRANCH_SCC_NT) {
+#define X(i) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(x), "v"(y));
+                X(0) X(1) X(2) X(3)
+                asm volatile("s_cmp_eq_u32 %0, 0x7fffffff\n\ts_cbranch_scc1 1f\n1:" : : "s"(s1) : "scc");
+                X(4) X(5) X(6)
+#undef X
+            } else if (OP == BRANCH_TAKEN) {
+#define X(i) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(x), "v"(y));
+                X(0) X(1) X(2) X(3)
+                asm volatile("s_cbranch_execnz 1f\n1:" : : : "scc");
+                X(4) X(5) X(6)
+#undef X
+            } else if (OP == BRANCH_NT_SPARSE) {
+#define X(i) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(x), "v"(y));
+                X(0) X(1) X(2) X(3)
+                if ((u & 3) == 0) asm volatile("s_cbranch_execz 1f\n1:" : : : "scc");
+                else X(7)
+                X(4) X(5) X(6)
+#undef X
+            } else if (OP == EXEC0_FMA) {
+#define X(i) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(x), "v"(y));
+                X(0)
+                asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 0" : "=s"(smask2) : : "exec");
+                X(1) X(2) X(3) X(4) X(5) X(6)
+                asm volatile("s_mov_b64 exec, %0" : : "s"(smask2) : "exec");
+                X(7)
+#undef X
+            } else if (OP == MOV) {
+#define X(i) asm volatile("v_mov_b32 %0, %1" : "=v"(a[i]) : "v"(a[(i + 1) & 7]));
+                REP8(X)
+#undef X
+            } else if (OP == ADDU32) {
+#define X(i) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(ix));
+                REP8(X)
+#undef X
+            } else if (OP == CMP_VCC) {
+#define X(i) asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(a[i]), "v"(y) : "vcc");
+                REP8(X)
+#undef X
+            } else if (OP == CND_FMA) {
+#define X(i) asm volatile("v_cndmask_b32 %0, %0, %2, vcc\n\tv_fma_f32 %1, %2, %3, %1" : "+v"(a[i]), "+v"(a[i + 4]) : "v"(y), "v"(x));
+                X(0) X(1) X(2) X(3)
+#undef X
             } else if (OP == DEP_FMA) {
 #define X(i) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[0]) : "v"(x), "v"(y));
                 REP8(X)
@@ -135,7 +277,8 @@ __global__ __launch_bounds__(1024) void k_rate(int iters, Stamp *out, float *sin
     const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
     float s = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) s += a[i] + p[i].x + p[i].y;
+    for (int i = 0; i < 8; ++i) s += a[i] + p[i].x + p[i].y + (float)q[i];
+    s += (float)smask + (float)smask2;
     if (s == 12345.678f) sink[0] = s + (float)s0 + (float)s1;   // keep everything alive
     if ((threadIdx.x & 63) == 0) {
         unsigned hwid, xcc;
@@ -155,13 +298,17 @@ void launch(int grid, int threads, size_t lds, int iters, Stamp *d, float *sink)
 
 typedef void (*LaunchFn)(int, int, size_t, int, Stamp *, float *);
 static LaunchFn kLaunch[NUM_OPS] = {launch<FMA>, launch<MUL>, launch<ADD>, launch<CNDMASK>, launch<PKFMA>, launch<RCP>, launch<SQRT>,
-                                    launch<RSQ>, launch<MIX_SALU>, launch<MIX_KERNEL>, launch<DEP_FMA>};
+                                    launch<RSQ>, launch<MIX_SALU>, launch<MIX_KERNEL>, launch<DEP_FMA>, launch<CNDMASK_S>, launch<CMP_CND>,
+                                    launch<CMP_SGPR>, launch<MAD64>, launch<MULLO>, launch<MULHI>, launch<DIVSCALE>, launch<DIVFMAS>,
+                                    launch<DIVFIXUP>, launch<LSHLADD64>, launch<CVT>, launch<READLANE>, launch<SAVEEXEC>, launch<BRANCH_NT>,
+                                    launch<DSREAD>, launch<BPERMUTE>, launch<PKMUL>, launch<NOP_MIX>, launch<BRANCH_SCC_NT>,
+                                    launch<BRANCH_TAKEN>, launch<BRANCH_NT_SPARSE>, launch<EXEC0_FMA>, launch<MOV>, launch<ADDU32>, launch<CMP_VCC>, launch<CND_FMA>};
 
 int main() {
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
-    const int iters = 4096;
+    const int iters = 2048;
     Stamp *d;
     float *sink;
     CHECK(hipMalloc(&d, sizeof(Stamp) * cus * 2 * 16));
@@ -171,7 +318,7 @@ int main() {
     CHECK(hipEventCreate(&e1));
     printf("{\"device\": \"%s\", \"cus\": %d, \"clock_mhz_prop\": %d, \"iters\": %d, \"unrolled_vector_instructions\": 64,\n \"rows\": [\n", prop.name, cus,
            prop.clockRate / 1000, iters);
-    const int wavesPerSimd[] = {1, 2, 3, 4, 6, 8};
+    const int wavesPerSimd[] = {1, 2, 4, 6, 8};
     bool firstRow = true;
     for (int op = 0; op < NUM_OPS; ++op) {
         for (int w : wavesPerSimd) {
@@ -207,7 +354,7 @@ int main() {
             std::sort(clk.begin(), clk.end());
             const double medTicks = cyc[cyc.size() / 2];
             const double medClk = clk.empty() ? 0 : clk[clk.size() / 2];
-            const double vec = (double)iters * 8 * (kVecPerBlock[op] / 8);
+            const double vec = (double)iters * kVecPerBlock[op];
             // s_memtime ticks at the shader clock on gfx950 (MI355X_MICROARCH.md, per-instruction constants)
             const double cycPerInstWave = medTicks / vec;
             const double cycPerInstSimd = cycPerInstWave / w;

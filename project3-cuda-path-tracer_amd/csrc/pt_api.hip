@@ -19,7 +19,9 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -63,12 +65,14 @@ constexpr int kMaxSlots = 4;
 // One in-flight iteration: its own stream, path buffers, counters and deferred-radiance buffer.
 struct Slot {
     hipStream_t stream = nullptr;
-    float *pathbuf[2] = {nullptr, nullptr};
+    float *pathbuf[2] = {nullptr, nullptr};      // two path pools (ping-pong by bounce), poolChunks * kChunk paths per array
+    unsigned long long *chunkList[2] = {nullptr, nullptr}; // per pool: [kSeg][poolChunks] chunk lists of the queue it holds
+    uint32_t gen[2] = {0, 0};      // per pool: serial number of the launch that filled it (tags the chunk-list entries)
     Ctrl *ctrl = nullptr;
     float *contrib = nullptr;      // maxBatch x W*H*3, zero between batches
     hipEvent_t evDone = nullptr;       // all bounce launches of the slot's current iteration finished
     hipEvent_t evCommitted = nullptr;  // k_commit consumed (and re-zeroed) `contrib`
-    int parity = 0;                // which half of Ctrl::seg_count the slot's next iteration uses
+    int parity = 0;                // which half of Ctrl::cursor the slot's next batch uses
 };
 
 struct State {
@@ -88,13 +92,14 @@ struct State {
     GeomDev *dgeoms = nullptr;
     MaterialDev *dmats = nullptr;
     int numTilesMax = 0;    // upper bound of tiles in one bounce queue (incl. one partial tile per segment)
-    int segCap = 0;         // paths per segment; a path buffer holds kSeg * segCap paths per array
+    int poolChunks = 0;     // chunks per path pool (incl. the trash chunk 0); a pool holds poolChunks * kChunk paths per array
     int grid = 0;           // persistent grid of k_bounce<false>
     int gridFirst = 0;      // ... and of k_bounce<true> (its own register budget, hence its own residency)
     bool many = false;      // more than kBinMax spheres: the k_bounce<., true> variants (per-lane sphere lists)
     size_t ldsBytes = 0;
     long long iterations = 0;
     long long seq = 0;      // iterations enqueued since pt_init: slot = seq % nslots
+    uint32_t launchSerial = 0;   // bounce launches since pt_init
     // host buffer of pt_readback, page-locked on first use so the per-iteration D2H copy of the reference protocol
     // (src/pathtrace.cu:170-171) runs at PCIe rate instead of through a pageable staging copy
     void *pinnedHost = nullptr;
@@ -111,11 +116,18 @@ int count_devices() {
     return n;
 }
 
-PathSoA soa(float *base, int cap) {
-    PathSoA s;
-    s.base = base;
-    s.cap = cap > 0 ? cap : 1;
-    return s;
+int reset_ctrl(Ctrl *dev, hipStream_t st) {
+    HIPCHECK(hipMemsetAsync(dev, 0, sizeof(Ctrl), st));
+    HIPCHECK(hipStreamSynchronize(st));
+    return PT_OK;
+}
+
+PathPool pool(const Slot &sl, int which) {
+    PathPool p;
+    p.base = sl.pathbuf[which];
+    p.list = sl.chunkList[which];
+    p.cap = (uint32_t)S.poolChunks << S.prm.chunkShift;
+    return p;
 }
 
 void pack_geom(const PtGeom &g, GeomDev &d, const float *eye = nullptr) {
@@ -310,8 +322,12 @@ int resolve_events(std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, double &ms
 }
 
 int launch_bounce(Slot &sl, int iter, int batch, int depth, bool lastBounce, float *contrib) {
-    const PathSoA in = soa(sl.pathbuf[(depth - 1) & 1], kSeg * S.segCap);
-    const PathSoA out = soa(sl.pathbuf[depth & 1], kSeg * S.segCap);
+    const PathPool in = pool(sl, (depth - 1) & 1);
+    const PathPool out = pool(sl, depth & 1);
+    // chunk-list entries carry the serial number of the launch that wrote them (never 0)
+    const uint32_t genIn = sl.gen[(depth - 1) & 1];
+    if (++S.launchSerial == 0u) ++S.launchSerial;
+    const uint32_t genOut = sl.gen[depth & 1] = S.launchSerial;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (S.flags & PT_FLAG_KERNEL_TIMING) {
         HIPCHECK(hipEventCreate(&e0));
@@ -320,7 +336,7 @@ int launch_bounce(Slot &sl, int iter, int batch, int depth, bool lastBounce, flo
     }
 #define PT_LAUNCH_BOUNCE(FIRST_, MANY_, GRID_)                                                                              \
     hipLaunchKernelGGL((k_bounce<FIRST_, MANY_>), dim3(GRID_), dim3(kBlock), S.ldsBytes, sl.stream, S.prm, iter, batch, depth, \
-                       lastBounce ? 1 : 0, sl.parity, in, out, sl.ctrl, S.dgeoms, S.dmats, contrib)
+                       lastBounce ? 1 : 0, sl.parity, genIn, genOut, in, out, sl.ctrl, S.dgeoms, S.dmats, contrib)
     if (depth == 1) {
         if (S.many) PT_LAUNCH_BOUNCE(true, true, S.gridFirst); else PT_LAUNCH_BOUNCE(true, false, S.gridFirst);
     } else {
@@ -339,6 +355,60 @@ int launch_bounce(Slot &sl, int iter, int batch, int depth, bool lastBounce, flo
     return PT_OK;
 }
 
+// scan library workspace: one per stream (calls on different streams may overlap; calls on one stream are ordered, so
+// they can share the tile descriptors).  ScanCtrl::error is STICKY: only the ticket is reset between calls, and pt_sync
+// (or the next scan / compact call on the stream, through an asynchronous copy it checks on entry) reports it.
+struct ScanWs {
+    ScanCtrl *ctrl = nullptr;
+    unsigned long long *desc = nullptr;
+    long long tiles = 0;
+    uint32_t *hostErr = nullptr;     // pinned mirror of ctrl->error, refreshed behind every call
+    hipEvent_t copied = nullptr;
+};
+std::map<hipStream_t, ScanWs> g_scan;
+
+int scan_ws(hipStream_t st, long long tiles, ScanWs **out) {
+    ScanWs &W = g_scan[st];
+    if (!W.ctrl) {
+        HIPCHECK(hipMalloc(&W.ctrl, sizeof(ScanCtrl)));
+        HIPCHECK(hipMemset(W.ctrl, 0, sizeof(ScanCtrl)));
+        HIPCHECK(hipHostMalloc(&W.hostErr, sizeof(uint32_t), hipHostMallocDefault));
+        *W.hostErr = 0;
+        HIPCHECK(hipEventCreateWithFlags(&W.copied, hipEventDisableTiming));
+    } else {
+        // the previous call's fault word, if its copy has landed (never blocks)
+        if (hipEventQuery(W.copied) == hipSuccess && *W.hostErr)
+            return fail(PT_ERR_DEVICE, "device fault: look-back timeout in an earlier scan / compact call on this stream (its result is void)");
+        (void)hipGetLastError();
+    }
+    if (tiles > W.tiles) {
+        // the stream may still be reading the old descriptors
+        HIPCHECK(hipStreamSynchronize(st));
+        if (W.desc) HIPCHECK(hipFree(W.desc));
+        W.desc = nullptr;
+        long long cap = tiles < 1024 ? 1024 : tiles;
+        HIPCHECK(hipMalloc(&W.desc, (size_t)(cap + (cap + kGroup - 1) / kGroup) * 8));
+        W.tiles = cap;
+    }
+    *out = &W;
+    return PT_OK;
+}
+// behind a scan / compact launch: mirror the fault word for the next call's (and pt_sync's) check
+int scan_epilogue(hipStream_t st, ScanWs &W) {
+    HIPCHECK(hipMemcpyAsync(W.hostErr, &W.ctrl->error, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipEventRecord(W.copied, st));
+    return PT_OK;
+}
+int scan_fault_check() {   // after a device-wide synchronisation
+    for (auto &kv : g_scan)
+        if (kv.second.hostErr) {
+            uint32_t err = 0;
+            HIPCHECK(hipMemcpy(&err, &kv.second.ctrl->error, sizeof err, hipMemcpyDeviceToHost));
+            if (err) return fail(PT_ERR_DEVICE, "device fault: scan look-back timeout (pt_scan_exclusive_i32 / pt_compact_nonzero_i32 results are void)");
+        }
+    return PT_OK;
+}
+
 // wait for every stream the renderer uses
 int sync_all() {
     for (int i = 0; i < S.nslots; ++i) HIPCHECK(hipStreamSynchronize(S.slot[i].stream));
@@ -352,28 +422,10 @@ int check_device_fault() {
     for (int i = 0; i < S.nslots; ++i) {
         uint32_t err = 0;
         HIPCHECK(hipMemcpy(&err, &S.slot[i].ctrl->error, sizeof err, hipMemcpyDeviceToHost));
-        if (err) return fail(PT_ERR_DEVICE, "device fault flag set");
+        if (err) return fail(PT_ERR_DEVICE, "device fault 0x%x:%s%s (results of this render are void; re-init)", err,
+                             (err & kFaultPoolExhausted) ? " path pool exhausted" : "", (err & kFaultReserveTimeout) ? " chunk reservation timed out" : "");
     }
-    return PT_OK;
-}
-
-// scan library workspace
-struct ScanWs {
-    ScanCtrl *ctrl = nullptr;
-    unsigned long long *desc = nullptr;
-    long long tiles = 0;
-} W;
-
-int scan_ws(long long tiles) {
-    if (!W.ctrl) HIPCHECK(hipMalloc(&W.ctrl, sizeof(ScanCtrl)));
-    if (tiles > W.tiles) {
-        if (W.desc) HIPCHECK(hipFree(W.desc));
-        W.desc = nullptr;
-        long long cap = tiles < 1024 ? 1024 : tiles;
-        HIPCHECK(hipMalloc(&W.desc, (size_t)(cap + (cap + kGroup - 1) / kGroup) * 8));
-        W.tiles = cap;
-    }
-    return PT_OK;
+    return scan_fault_check();
 }
 
 int persistent_grid(const void *kernel, size_t lds, int *grid) {
@@ -387,7 +439,9 @@ int persistent_grid(const void *kernel, size_t lds, int *grid) {
     // Six workgroups per CU even when eight would fit (63 VGPRs): a launch alone is fastest with six (0.158 ms against
     // 0.173 with eight: fewer, longer strides balance better), and the two free wave slots per SIMD go to the launches
     // of the neighbouring batches that run beside it.
-    if (perCU > 6) perCU = 6;
+    int cap = 6;
+    if (const char *e = getenv("PT_AMD_BLOCKS_PER_CU")) cap = atoi(e);   // experiments only
+    if (perCU > cap) perCU = cap;
     *grid = prop.multiProcessorCount * perCU;
     return PT_OK;
 }
@@ -425,8 +479,10 @@ void pt_free(void) {
     S.evBounce.clear();
     for (int i = 0; i < kMaxSlots; ++i) {
         Slot &sl = S.slot[i];
-        for (int k = 0; k < 2; ++k)
+        for (int k = 0; k < 2; ++k) {
             if (sl.pathbuf[k]) (void)hipFree(sl.pathbuf[k]);
+            if (sl.chunkList[k]) (void)hipFree(sl.chunkList[k]);
+        }
         if (sl.ctrl) (void)hipFree(sl.ctrl);
         if (sl.contrib) (void)hipFree(sl.contrib);
         if (sl.evDone) (void)hipEventDestroy(sl.evDone);
@@ -513,26 +569,44 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
         S.ownImage = true;
         HIPCHECK(hipMemsetAsync(S.image, 0, n * 3 * sizeof(float), S.stream));
     }
-    // Path buffers: kSeg = kCls x kSub segments.  A segment receives survivors only from the workgroups with one
-    // value of blockIdx % kSub; tiles are blockIdx-strided and the grid is a multiple of kSub, so those workgroups
-    // process at most ceil(tiles / kSub) tiles, and tiles <= ceil(nLocal/256) + kSeg (one partial tile per input
-    // segment).  Worst case (every ray in one class) is provisioned: kCls = 16x the live paths, 650 MB per buffer at 720p.
+    // Path pools: a bounce's queue is kSeg = kCls x kSub segments, each a list of chunks handed out on demand, one ahead of
+    // their use (ptk::reserveRun).  At most nLocal * maxBatch paths are alive; every segment may end in a partly filled
+    // chunk and holds one chunk installed ahead: ceil(paths / chunk) + 2 kSeg chunks always suffice, whatever the
+    // distribution over the classes (+ the trash chunk 0).  Chunk size: ~1/1024 of the paths (a power of two, at least
+    // 2048), so that the slack stays around 10 % while a chunk outlasts the appends of one memory round trip.
     S.maxBatch = o.max_batch > 0 ? o.max_batch : 1;
-    // slots are 32-bit: kSeg * segCap ~ 16 x paths must stay below 2^31
-    if ((long long)S.nLocal * S.maxBatch > (1ll << 26)) return fail(PT_ERR_INVALID, "pt_init: max_batch x pixels too large (limit 2^26 paths per batch)");
-    S.numTilesMax = (int)(((long long)S.nLocal * S.maxBatch + kBlock - 1) / kBlock) + kSeg;
-    S.segCap = ((S.numTilesMax + kSub - 1) / kSub) * kBlock;
-    k.segCap = S.segCap;
-    const size_t cap = (size_t)kSeg * S.segCap;
+    // slots are 32-bit element indices with 32-bit byte offsets: paths per pool must stay below 2^30
+    const long long maxPaths = (long long)S.nLocal * S.maxBatch;
+    if (maxPaths > (1ll << 29)) return fail(PT_ERR_INVALID, "pt_init: max_batch x pixels too large (limit 2^29 paths per batch)");
+    S.numTilesMax = (int)((maxPaths + kBlock - 1) / kBlock) + kSeg;
+    k.chunkShift = kMinChunkShift;
+    while (k.chunkShift < 17 && (maxPaths >> k.chunkShift) > 1024) ++k.chunkShift;
+    if (const char *e = getenv("PT_AMD_CHUNK_SHIFT")) {      // experiments only
+        const int v = atoi(e);
+        if (v >= kMinChunkShift && v <= 20) k.chunkShift = v;
+    }
+    const long long chunkPaths = 1ll << k.chunkShift;
+    S.poolChunks = (int)((maxPaths + chunkPaths - 1) / chunkPaths) + 2 * kSeg + 1;
+    if (const char *e = getenv("PT_AMD_POOL_CHUNKS")) {      // tests only: an undersized pool must fail loudly (PT_ERR_DEVICE)
+        const int v = atoi(e);
+        if (v >= kSeg + 2) S.poolChunks = v;
+    }
+    k.poolChunks = S.poolChunks;
+    const size_t cap = (size_t)S.poolChunks << k.chunkShift;
     // Iterations are independent (RNG keyed on pixel/iteration/depth), so up to `nslots` of them are in flight
     // on their own streams; the small late-bounce launches of one overlap the big early launches of the next.
     S.nslots = o.pipeline_depth > 0 ? o.pipeline_depth : 3;
     for (int i = 0; i < S.nslots; ++i) {
         Slot &sl = S.slot[i];
         HIPCHECK(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
-        for (int b = 0; b < 2; ++b) HIPCHECK(hipMalloc(&sl.pathbuf[b], cap * kNumArrays * sizeof(float)));
+        for (int b = 0; b < 2; ++b) {
+            HIPCHECK(hipMalloc(&sl.pathbuf[b], cap * kNumArrays * sizeof(float)));
+            HIPCHECK(hipMalloc(&sl.chunkList[b], (size_t)kSeg * S.poolChunks * sizeof(unsigned long long)));
+            HIPCHECK(hipMemset(sl.chunkList[b], 0, (size_t)kSeg * S.poolChunks * sizeof(unsigned long long)));
+        }
         HIPCHECK(hipMalloc(&sl.ctrl, sizeof(Ctrl)));
-        HIPCHECK(hipMemset(sl.ctrl, 0, sizeof(Ctrl)));
+        int rcc = reset_ctrl(sl.ctrl, nullptr);
+        if (rcc) return rcc;
         HIPCHECK(hipMalloc(&sl.contrib, (size_t)S.maxBatch * S.P * 3 * sizeof(float)));
         HIPCHECK(hipMemset(sl.contrib, 0, (size_t)S.maxBatch * S.P * 3 * sizeof(float)));
         HIPCHECK(hipEventCreateWithFlags(&sl.evDone, hipEventDisableTiming));
@@ -674,7 +748,11 @@ int pt_iterate_batch(int frame, int first_iter, int count, void *rgba8_dev) {
 int pt_iterate(int frame, int iter, void *rgba8_dev) { return pt_iterate_batch(frame, iter, 1, rgba8_dev); }
 
 int pt_sync(void) {
-    if (!S.init) return fail(PT_ERR_NOT_INIT, "pt_sync before pt_init");
+    if (!S.init) {
+        if (g_scan.empty()) return fail(PT_ERR_NOT_INIT, "pt_sync before pt_init");
+        HIPCHECK(hipDeviceSynchronize());          // the scan library alone: report its sticky fault word
+        return scan_fault_check();
+    }
     return check_device_fault();
 }
 
@@ -732,7 +810,7 @@ int pt_counters(PtCounters *out) {
     if (rc) return rc;
     memset(out, 0, sizeof *out);
     static Ctrl h;   // 0.5 MB: keep it off the stack
-    bool fault = false;
+    uint32_t faultBits = 0;
     for (int i = 0; i < S.nslots; ++i) {
         HIPCHECK(hipMemcpy(&h, S.slot[i].ctrl, sizeof h, hipMemcpyDeviceToHost));
         for (int d = 0; d < kMaxDepthSlots; ++d) out->live[d] += (int64_t)h.sum_live[d];
@@ -740,14 +818,15 @@ int pt_counters(PtCounters *out) {
             out->light_hits += (int64_t)h.light_hits[sg][0];
             out->misses += (int64_t)h.misses[sg][0];
         }
-        fault = fault || h.error != 0;
+        faultBits |= h.error;
     }
     out->iterations = S.iterations;
     out->bounce_launches = S.nBounce;
     out->bounce_kernel_ms = S.msBounce;
     out->raygen_kernel_ms = 0.0;   // camera rays are generated inside the first bounce launch
     out->raygen_launches = 0;
-    if (fault) return fail(PT_ERR_DEVICE, "device fault flag set");
+    if (faultBits) return fail(PT_ERR_DEVICE, "device fault 0x%x:%s%s (results of this render are void; re-init)", faultBits,
+                               (faultBits & kFaultPoolExhausted) ? " path pool exhausted" : "", (faultBits & kFaultReserveTimeout) ? " chunk reservation timed out" : "");
     return PT_OK;
 }
 
@@ -760,7 +839,15 @@ int pt_counters_reset(void) {
     S.msBounce = 0;
     S.nBounce = 0;
     S.iterations = 0;
-    for (int i = 0; i < S.nslots; ++i) HIPCHECK(hipMemset(S.slot[i].ctrl, 0, sizeof(Ctrl)));
+    for (int i = 0; i < S.nslots; ++i) {
+        // the sticky fault word survives a counter reset
+        uint32_t err = 0;
+        HIPCHECK(hipMemcpy(&err, &S.slot[i].ctrl->error, sizeof err, hipMemcpyDeviceToHost));
+        rc = reset_ctrl(S.slot[i].ctrl, nullptr);
+        if (rc) return rc;
+        S.slot[i].parity = 0;
+        if (err) HIPCHECK(hipMemcpy(&S.slot[i].ctrl->error, &err, sizeof err, hipMemcpyHostToDevice));
+    }
     return PT_OK;
 }
 
@@ -790,31 +877,51 @@ int pt_debug_trace_paths(int iter, int bounces, float *origin3, float *dir3, flo
             for (size_t i = 0; i < (size_t)nl * 3; ++i) color3[i] = 1.0f;
         return PT_OK;
     }
-    HIPCHECK(hipMemsetAsync(&sl.ctrl->seg_count[0][0][0][0], 0, sizeof(sl.ctrl->seg_count), sl.stream));
+    // private run on slot 0: re-arm its cursors, trace, read the queue entering bounce `bounces + 1`, re-arm again
+    uint32_t err = 0;
+    HIPCHECK(hipMemcpy(&err, &sl.ctrl->error, sizeof err, hipMemcpyDeviceToHost));
+    rc = reset_ctrl(sl.ctrl, sl.stream);
+    if (rc) return rc;
     for (int d = 1; d <= bounces; ++d) {
         rc = launch_bounce(sl, iter, 1, d, false, nullptr);  // no radiance, survivors always written
         if (rc) return rc;
     }
-    // gather the kSeg segments of the queue entering bounce `bounces + 1`, then sort by pixel index
-    uint32_t segn[kSeg];
-    for (int sg = 0; sg < kSeg; ++sg)
-        HIPCHECK(hipMemcpyAsync(&segn[sg], &sl.ctrl->seg_count[sl.parity][bounces + 1][sg][0], 4, hipMemcpyDeviceToHost, sl.stream));
-    HIPCHECK(hipMemsetAsync(&sl.ctrl->seg_count[0][0][0][0], 0, sizeof(sl.ctrl->seg_count), sl.stream));
     HIPCHECK(hipStreamSynchronize(sl.stream));
+    // gather the kSeg segments (chunk lists) of that queue, then sort by pixel index
+    static Ctrl h;
+    HIPCHECK(hipMemcpy(&h, sl.ctrl, sizeof h, hipMemcpyDeviceToHost));
+    rc = reset_ctrl(sl.ctrl, sl.stream);
+    if (rc) return rc;
+    err |= h.error;
+    if (err) HIPCHECK(hipMemcpy(&sl.ctrl->error, &err, sizeof err, hipMemcpyHostToDevice));
+    if (h.error) return fail(PT_ERR_DEVICE, "pt_debug_trace_paths: device fault 0x%x", h.error);
+    const PathPool pb = pool(sl, bounces & 1);
+    const uint32_t gen = sl.gen[bounces & 1];
+    std::vector<unsigned long long> lists((size_t)kSeg * S.poolChunks);
+    HIPCHECK(hipMemcpy(lists.data(), pb.list, lists.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    uint32_t segn[kSeg];
     size_t n = 0;
-    for (int sg = 0; sg < kSeg; ++sg) n += segn[sg];
+    for (int sg = 0; sg < kSeg; ++sg) {
+        segn[sg] = h.pos[sl.parity][bounces + 1][sg][0];
+        n += segn[sg];
+    }
     *count = (int32_t)n;
     if (n == 0) return PT_OK;
-    const PathSoA sb = soa(sl.pathbuf[bounces & 1], kSeg * S.segCap);
+    const uint32_t chunkPaths = 1u << S.prm.chunkShift;
     std::vector<float> cols[kNumArrays];
     for (int k = 0; k < kNumArrays; ++k) {
         cols[k].resize(n);
         size_t off = 0;
-        for (int sg = 0; sg < kSeg; ++sg) {
-            if (segn[sg])
-                HIPCHECK(hipMemcpy(cols[k].data() + off, sb.a(k) + (size_t)sg * S.segCap, (size_t)segn[sg] * 4, hipMemcpyDeviceToHost));
-            off += segn[sg];
-        }
+        for (int sg = 0; sg < kSeg; ++sg)
+            for (uint32_t done = 0, j = 0; done < segn[sg]; done += chunkPaths, ++j) {
+                const uint32_t m = std::min<uint32_t>(chunkPaths, segn[sg] - done);
+                const unsigned long long e = lists[(size_t)sg * S.poolChunks + j];
+                const uint32_t c = j == 0 ? 1u + (uint32_t)sg : (uint32_t)e;
+                if (c == 0 || c >= (uint32_t)S.poolChunks || (j != 0 && (uint32_t)(e >> 32) != gen))
+                    return fail(PT_ERR_DEVICE, "pt_debug_trace_paths: corrupt chunk list");
+                HIPCHECK(hipMemcpy(cols[k].data() + off, pb.a(k) + ((size_t)c << S.prm.chunkShift), (size_t)m * 4, hipMemcpyDeviceToHost));
+                off += m;
+            }
     }
     const int *pixcol = reinterpret_cast<const int *>(cols[9].data());
     std::vector<size_t> order(n);
@@ -838,10 +945,12 @@ int pt_scan_exclusive_i32(const int32_t *in_dev, int32_t *out_dev, int64_t n, vo
     if (count_devices() < 1) return fail(PT_ERR_NO_GPU, "no HIP device");
     const long long tiles = (n + kScanTile - 1) / kScanTile;
     if (tiles > 0x7fffffffll) return fail(PT_ERR_INVALID, "pt_scan_exclusive_i32: n too large");
-    int rc = scan_ws(tiles);
-    if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    HIPCHECK(hipMemsetAsync(W.ctrl, 0, sizeof(ScanCtrl), st));
+    ScanWs *wp = nullptr;
+    int rc = scan_ws(st, tiles, &wp);
+    if (rc) return rc;
+    ScanWs &W = *wp;
+    HIPCHECK(hipMemsetAsync(&W.ctrl->ticket, 0, sizeof(uint32_t), st));     // the error word stays (sticky)
     const long long words = tiles + (tiles + kGroup - 1) / kGroup;
     HIPCHECK(hipMemsetAsync(W.desc, 0, (size_t)words * 8, st));
     int grid = 0;
@@ -851,7 +960,7 @@ int pt_scan_exclusive_i32(const int32_t *in_dev, int32_t *out_dev, int64_t n, vo
     hipLaunchKernelGGL(k_scan_exclusive, dim3(grid), dim3(kBlock), 0, st, in_dev, out_dev, (long long)n, W.ctrl, W.desc,
                        W.desc + tiles);
     HIPCHECK(hipGetLastError());
-    return PT_OK;
+    return scan_epilogue(st, W);
 }
 
 int pt_compact_nonzero_i32(const int32_t *in_dev, int32_t *out_dev, int64_t n, int64_t *count_dev, void *stream) {
@@ -859,10 +968,12 @@ int pt_compact_nonzero_i32(const int32_t *in_dev, int32_t *out_dev, int64_t n, i
     if (count_devices() < 1) return fail(PT_ERR_NO_GPU, "no HIP device");
     const long long tiles = (n + kBlock - 1) / kBlock;
     if (tiles > 0x7fffffffll) return fail(PT_ERR_INVALID, "pt_compact_nonzero_i32: n too large");
-    int rc = scan_ws(tiles ? tiles : 1);
-    if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    HIPCHECK(hipMemsetAsync(W.ctrl, 0, sizeof(ScanCtrl), st));
+    ScanWs *wp = nullptr;
+    int rc = scan_ws(st, tiles ? tiles : 1, &wp);
+    if (rc) return rc;
+    ScanWs &W = *wp;
+    HIPCHECK(hipMemsetAsync(&W.ctrl->ticket, 0, sizeof(uint32_t), st));     // the error word stays (sticky)
     const long long words = tiles + (tiles + kGroup - 1) / kGroup;
     HIPCHECK(hipMemsetAsync(W.desc, 0, (size_t)(words ? words : 1) * 8, st));
     int grid = 0;
@@ -873,7 +984,7 @@ int pt_compact_nonzero_i32(const int32_t *in_dev, int32_t *out_dev, int64_t n, i
     hipLaunchKernelGGL(k_compact_nonzero, dim3(grid), dim3(kBlock), 0, st, in_dev, out_dev, (long long)n, W.ctrl, W.desc,
                        W.desc + tiles, reinterpret_cast<long long *>(count_dev));
     HIPCHECK(hipGetLastError());
-    return PT_OK;
+    return scan_epilogue(st, W);
 }
 
 // ---- primitive tests over host arrays ------------------------------------------------------------------

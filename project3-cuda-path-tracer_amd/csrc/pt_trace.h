@@ -18,25 +18,34 @@ constexpr int kCls = 2 * kOct;       // ... and by "may hit a small primitive" (
 constexpr int kSub = 4;              // append-counter shards per class (workgroup blockIdx % kSub)
 constexpr int kSeg = kCls * kSub;    // path buffers are split into kSeg segments with one append counter each
 constexpr int kBinMax = 4;           // at most this many small primitives take part in the binning
+// Path state lives in POOLS of fixed-size chunks (2^chunkShift paths each, chosen by pt_init): a segment of a bounce's
+// queue is a list of chunks, handed out by an atomic bump counter while the segment is filled, so a pool is sized for the
+// paths that can be alive (pixels x batch, plus two chunks of slack per segment) and not for the worst case of every path
+// in one class.
+constexpr int kMinChunkShift = 11;   // chunks hold at least 2048 paths: a multiple of the tile size, so a tile never straddles two
 // k_bounce<., MANY> (scenes with more than kBinMax spheres): LDS words of the fixed scratch, floats per staged sphere
 // record (inverseTransform rows, transform rows, GeomDev::invZ, 4 B of padding), spheres a lane can record per tile
-constexpr int kMiscWords = kWaves * kCls + kCls + kSeg + (kSeg + 2) + 2 * PT_MAX_BATCH + 2;
+constexpr int kMiscWords = kWaves * kCls + 5 * kCls + kSeg + (kSeg + 2) + 2 * PT_MAX_BATCH + 2;
 static_assert(kMiscWords % 4 == 0, "the sphere records that follow are read as float4");
 constexpr int kSphRowFloats = 28;
 constexpr int kListMax = 8;
 constexpr int kCtrPad = 32;          // one counter per 128-byte line: same-line atomics serialise at the memory side
 
 struct Ctrl {
-    // seg_count[p][d][s][0] = paths in segment s entering bounce d of an iteration with parity p.
-    // The last bounce launch of an iteration zeroes the OTHER parity, i.e. re-arms the next iteration,
-    // so an iteration needs neither a memset nor a separate re-arm launch.
-    uint32_t seg_count[2][kMaxDepthSlots][kSeg][kCtrPad];
+    // pos[p][d][s][0] = paths appended to segment s of the queue ENTERING bounce d of a batch with parity p (a run of
+    // survivors reserves its place with ONE atomic add, see reserveRun), bump[p][d][0] = chunks handed out for that queue.
+    // The last bounce launch of a batch zeroes the OTHER parity, i.e. re-arms the next batch of the slot, so a batch
+    // needs neither a memset nor a separate re-arm launch.
+    uint32_t pos[2][kMaxDepthSlots][kSeg][kCtrPad];
+    uint32_t bump[2][kMaxDepthSlots][kCtrPad];
     // never zeroed by an iteration
-    uint32_t error;                    // sticky device fault (scan-library look-back timeout)
+    uint32_t error;                    // sticky device fault: kFault* bits (pool exhausted, chunk-list poll timeout)
     uint32_t pad[kCtrPad - 1];
     unsigned long long sum_live[kMaxDepthSlots];
     unsigned long long light_hits[kOct][kCtrPad / 2], misses[kOct][kCtrPad / 2];
 };
+constexpr uint32_t kFaultPoolExhausted = 1u, kFaultReserveTimeout = 2u;
+constexpr int kReservePollLimit = 1 << 14;    // polls (each a memory round trip) for a chunk-list entry; a real wait is a few
 
 // Camera constants derived once on the host (spec S2)
 struct KParams {
@@ -47,7 +56,8 @@ struct KParams {
     int   nLocal;       // pixels rendered by this shard
     int   ngeoms, nmats;
     int   traceDepth;
-    int   segCap;       // capacity (paths) of one segment of a path buffer, multiple of kBlock
+    int   poolChunks;   // chunks of a path pool (chunk 0 is the trash chunk: never handed out, written only after a fault)
+    int   chunkShift;   // log2(paths per chunk), >= kMinChunkShift
     int   sceneRect[4]; // union of the primitives' pixel rectangles (GeomDev::rect): camera rays outside miss everything
     // n / W and n / nLocal for n < 2^27 as (n * magic) >> shift (exact, see pt_init): the two divisions of the
     // camera-ray bounce cost ~50 instructions each when the compiler expands them
@@ -59,16 +69,90 @@ struct KParams {
     int   binGeom[kBinMax];   // hit one of them (certainMiss of each); 0: off, every path counts as a candidate
 };
 
-// SoA PathSegment buffer: 11 arrays of `cap` = kSeg * segCap 4-byte elements, array k at base + k*cap
-// (0-2 origin, 3-5 direction, 6-8 throughput, 9 pixelIndex, 10 remainingBounces | batch index << 8); inside every array
-// segment s owns [s*segCap, (s+1)*segCap) and is filled from its start.
-struct PathSoA {
-    float *base;
-    int    cap;
+// SoA PathSegment pool: 11 arrays of `cap` = poolChunks << chunkShift 4-byte elements, array k at base + k*cap
+// (0-2 origin, 3-5 direction, 6-8 throughput, 9 pixelIndex, 10 remainingBounces | batch index << 8); chunk c owns
+// [c << chunkShift, (c + 1) << chunkShift) of every array.
+// list[s * poolChunks + j] = {generation : 32 | chunk : 32} of the j-th chunk (j >= 1) of segment s of the queue the pool
+// holds; the generation is the serial number of the launch that filled the queue, so entries of earlier launches read as
+// "not there yet" without any clearing.  The 0-th chunk of segment s is always chunk 1 + s.
+struct PathPool {
+    float              *base;
+    unsigned long long *list;
+    uint32_t            cap;
     __host__ __device__ __forceinline__ float *a(int k) const { return base + (size_t)k * cap; }
-    __host__ __device__ __forceinline__ int *pix() const { return reinterpret_cast<int *>(base + (size_t)9 * cap); }
-    __host__ __device__ __forceinline__ int *rem() const { return reinterpret_cast<int *>(base + (size_t)10 * cap); }
 };
+
+// element `slot` of an array whose (wave-uniform) base pointer is `arr`: uniform 64-bit base + 32-bit byte offset, which
+// is the addressing form of global_load/store with an SGPR base (no 64-bit vector arithmetic per access)
+__device__ __forceinline__ float ldSlot(const float *arr, uint32_t byteOff) {
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(arr) + byteOff);
+}
+__device__ __forceinline__ void stSlot(float *arr, uint32_t byteOff, float v) {
+    *reinterpret_cast<float *>(reinterpret_cast<char *>(arr) + byteOff) = v;
+}
+
+// Reserve room for a run of `total` (0..256) paths at the end of segment `oseg`: ONE atomic add on the segment's position
+// counter -- a reservation never closes the segment for the others.  Position p lies in the segment's (p >> chunkShift)-th
+// chunk.  Chunks are installed ONE AHEAD of their use: the run that contains the first slot of the segment's k-th chunk
+// takes a chunk from the pool's bump counter and publishes it as the (k+1)-th (the run at position 0 does so for the 1st;
+// the 0-th is static), i.e. a whole chunk's worth of appends before anybody needs it.  A run then looks up the one or two
+// chunks it lies in (`cacheK`/`cacheC`: the lane's last lookup, which the next tiles mostly repeat); should an entry not be
+// there yet -- the installer's own add is less than a memory round trip old -- it is polled.  Installing comes before
+// looking up and waits for nothing, so every poll ends; it is bounded all the same: a timeout or an exhausted pool sets
+// the sticky fault word and directs the run to the trash chunk 0 (in bounds; results void; the host reports PT_ERR_DEVICE).
+// The loop is WAVE-UNIFORM with one poll per lane and trip: a lane never spins inside a trip, whatever the compiler
+// makes of the branches.
+// The run occupies  [base0, base0 + split)  and  [base1, base1 + total - split).
+__device__ __forceinline__ void reserveRun(uint32_t *pos, uint32_t *bump, unsigned long long *segList, uint32_t oseg,
+                                           uint32_t poolChunks, uint32_t shift, uint32_t gen, uint32_t total, uint32_t *fault,
+                                           uint32_t &cacheK, uint32_t &cacheC, uint32_t &base0, uint32_t &split, uint32_t &base1) {
+    base0 = base1 = 0u;
+    split = total;
+    const uint32_t p = total ? atomicAdd(pos, total) : 0u;
+    const uint32_t k0 = p >> shift, k1 = (p + (total ? total - 1u : 0u)) >> shift;
+    if (total && ((p & ((1u << shift) - 1u)) == 0u || k1 != k0)) { // this run holds the first slot of chunk k1: install the one after it
+        const uint32_t kNew = k1 + 1u;
+        uint32_t x = (uint32_t)kSeg + 1u + atomicAdd(bump, 1u);
+        if (x >= poolChunks) {
+            atomicOr(fault, kFaultPoolExhausted);
+            x = 0u;
+        }
+        if (kNew < poolChunks)
+            __hip_atomic_store(&segList[kNew], ((unsigned long long)gen << 32) | x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    uint32_t c0 = 1u + oseg, c1 = 0u;                              // chunk of k0 (k0 == 0: static), chunk of k1
+    bool need0 = total && k0 != 0u, need1 = total && k1 != k0;
+    if (need0 && cacheK == k0) { c0 = cacheC; need0 = false; }
+    for (int polls = 0; __ballot(need0 || need1) != 0ull; ++polls) {
+        if (need0) {
+            const unsigned long long e = k0 < poolChunks ? __hip_atomic_load(&segList[k0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                         : ((unsigned long long)gen << 32);
+            if ((uint32_t)(e >> 32) == gen) { c0 = (uint32_t)e; need0 = false; }
+        }
+        if (need1) {
+            const unsigned long long e = k1 < poolChunks ? __hip_atomic_load(&segList[k1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                         : ((unsigned long long)gen << 32);
+            if ((uint32_t)(e >> 32) == gen) { c1 = (uint32_t)e; need1 = false; }
+        }
+        if (polls > kReservePollLimit && (need0 || need1)) {
+            atomicOr(fault, kFaultReserveTimeout);
+            if (need0) c0 = 0u;
+            if (need1) c1 = 0u;
+            need0 = need1 = false;
+        }
+    }
+    if (total) {
+        const uint32_t mask = (1u << shift) - 1u;
+        base0 = (c0 << shift) + (p & mask);
+        if (k1 != k0) {
+            split = ((k0 + 1u) << shift) - p;
+            base1 = c1 << shift;
+            cacheK = k1; cacheC = c1;
+        } else {
+            cacheK = k0; cacheC = c0;
+        }
+    }
+}
 
 __device__ __forceinline__ uint32_t fastDiv(uint32_t n, uint32_t magic, uint32_t shift) {
     return (uint32_t)(((unsigned long long)n * magic) >> shift);
@@ -131,8 +215,8 @@ __global__ __launch_bounds__(kBlock) void k_debug_camera_rays(KParams prm, int i
 // that is stored).
 // Queue order never influences results: RNG and accumulator are keyed on the pixel index.
 // No workgroup ever waits for another one, so there is no residency / dispatch-order assumption.
-// A segment receives survivors of the tiles of the workgroups with one value of blockIdx % kSub only,
-// i.e. at most ceil(tiles / kSub) * 256 <= segCap paths (see pt_init: the grid is a multiple of kSub).
+// A segment receives survivors of the tiles of the workgroups with one value of blockIdx % kSub only; its paths live in
+// chunks of the output pool handed out on demand (reserveRun), so any distribution over the classes fits.
 // (Deriving the shard from the tile index instead, T % kSub, measured 3 % slower.)
 //
 // FIRST = true is bounce 1 fused with camera-ray generation (spec S2): tile T holds the paths
@@ -152,7 +236,8 @@ __global__ __launch_bounds__(kBlock) void k_debug_camera_rays(KParams prm, int i
 // chosen by (distance, then file order), which is what the in-order loop with its strict `<` computes.
 template <bool FIRST, bool MANY>
 __global__ __launch_bounds__(kBlock, (FIRST || MANY) ? 5 : 6) void k_bounce(KParams prm, int iter, int batch, int depth, int lastBounce, int parity,
-                                                   PathSoA in, PathSoA out, Ctrl *ctrl,
+                                                   uint32_t genIn, uint32_t genOut,
+                                                   PathPool in, PathPool out, Ctrl *ctrl,
                                                    const GeomDev *__restrict__ ggeoms,
                                                    const MaterialDev *__restrict__ gmats, float *contrib) {
     // LDS: the material table and the per-geom hit records (normal matrix, material, type: indexed per lane by
@@ -165,17 +250,19 @@ __global__ __launch_bounds__(kBlock, (FIRST || MANY) ? 5 : 6) void k_bounce(KPar
     GeomHitDev *s_geomHit = reinterpret_cast<GeomHitDev *>(smem + sizeof(MaterialDev) * prm.nmats);
     uint32_t *s_misc = reinterpret_cast<uint32_t *>(smem + sizeof(MaterialDev) * prm.nmats + sizeof(GeomHitDev) * prm.ngeoms);
     uint32_t *s_wave = s_misc;                       // [kWaves][kCls] survivors per wave and class (zero between tiles)
-    uint32_t *s_base = s_wave + kWaves * kCls;       // [kCls]   first output slot of this tile per class
-    uint32_t *s_segcnt = s_base + kCls;              // [kSeg]   paths per input segment
+    uint32_t *s_base = s_wave + kWaves * kCls;       // [5][kCls] this tile's output run per class: first slot, paths before the
+                                                     //           chunk boundary, first slot behind it; the class's last chunk lookup (reserveRun)
+    uint32_t *s_segcnt = s_base + 5 * kCls;          // [kSeg]   paths per input segment
     uint32_t *s_segpre = s_segcnt + kSeg;            // [kSeg+2] tile prefix per input segment, [kSeg+1] = live paths
     uint32_t *s_iterHash = s_segpre + kSeg + 2;      // [2][PT_MAX_BATCH] iterationHash(iter + b, depth) and (iter + b, 0)
     float *s_sph = reinterpret_cast<float *>(s_misc + kMiscWords);                    // MANY: [ngeoms][kSphRowFloats]
     uint16_t *s_list = reinterpret_cast<uint16_t *>(s_sph + (size_t)prm.ngeoms * kSphRowFloats);   // MANY: [kListMax][kBlock]
 
     if (lastBounce) {   // re-arm the next iteration: nobody touches the other parity's counters now
-        uint32_t *other = &ctrl->seg_count[parity ^ 1][0][0][0];
-        const int nwords = (prm.traceDepth + 2) * kSeg * kCtrPad;
-        for (int i = blockIdx.x * kBlock + threadIdx.x; i < nwords; i += gridDim.x * kBlock) other[i] = 0u;
+        uint32_t *other = &ctrl->pos[parity ^ 1][0][0][0];
+        const int nwords = (prm.traceDepth + 2) * kSeg;
+        for (int i = blockIdx.x * kBlock + threadIdx.x; i < nwords; i += gridDim.x * kBlock) other[i * kCtrPad] = 0u;
+        if (blockIdx.x == 0 && threadIdx.x < kMaxDepthSlots) ctrl->bump[parity ^ 1][threadIdx.x][0] = 0u;
     }
     // input queue: segment s holds s_cnt[s] paths = tiles [s_pre[s], s_pre[s+1]) of the global tile index
     uint32_t nLive, numTiles;
@@ -184,7 +271,7 @@ __global__ __launch_bounds__(kBlock, (FIRST || MANY) ? 5 : 6) void k_bounce(KPar
         numTiles = (nLive + kBlock - 1) / kBlock;
     } else {
         if (threadIdx.x < 64) {          // wave 0: exclusive scan of the kSeg tile counts
-            const uint32_t c = threadIdx.x < kSeg ? ctrl->seg_count[parity][depth][threadIdx.x][0] : 0u;
+            const uint32_t c = threadIdx.x < kSeg ? ctrl->pos[parity][depth][threadIdx.x][0] : 0u;
             const uint32_t t = (c + kBlock - 1) / kBlock;
             uint32_t inc = t, sum = c;
 #pragma unroll
@@ -203,6 +290,7 @@ __global__ __launch_bounds__(kBlock, (FIRST || MANY) ? 5 : 6) void k_bounce(KPar
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctrl->sum_live[depth], (unsigned long long)nLive);
     if (blockIdx.x >= numTiles) return;
     if (threadIdx.x < kWaves * kCls) s_wave[threadIdx.x] = 0u;
+    if (threadIdx.x < kCls) s_base[3 * kCls + threadIdx.x] = 0xffffffffu;   // no chunk looked up yet
     if (threadIdx.x < 2 * PT_MAX_BATCH) {
         const int b = threadIdx.x % PT_MAX_BATCH;
         s_iterHash[threadIdx.x] = iterationHash(iter + b, threadIdx.x < PT_MAX_BATCH ? depth : 0);
@@ -275,7 +363,17 @@ __global__ __launch_bounds__(kBlock, (FIRST || MANY) ? 5 : 6) void k_bounce(KPar
             sgIn = (uint32_t)__builtin_amdgcn_readfirstlane((int)sgIn);
             const uint32_t local = (T - s_segpre[sgIn]) * kBlock + threadIdx.x;
             valid = local < s_segcnt[sgIn];
-            idx = sgIn * (uint32_t)prm.segCap + local;
+            // the tile's chunk (a chunk is a multiple of the tile size): j-th chunk of the segment, wave-uniform lookup
+            // (entries were written by the previous launch; the 0-th chunk of a segment is static)
+            const uint32_t q0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)((T - s_segpre[sgIn]) * kBlock));
+            const uint32_t j = q0 >> prm.chunkShift;
+            uint32_t chunk = 1u + sgIn;
+            if (j != 0u) {
+                const unsigned long long e = j < (uint32_t)prm.poolChunks ? in.list[(size_t)sgIn * (uint32_t)prm.poolChunks + j] : 0ull;
+                chunk = (uint32_t)(e >> 32) == genIn ? (uint32_t)e : 0u;
+                chunk = chunk < (uint32_t)prm.poolChunks ? chunk : 0u;
+            }
+            idx = (chunk << prm.chunkShift) + (local - (j << prm.chunkShift));
             smallTile = ((sgIn / kSub) & 8u) != 0u;
             // The last bounce only asks whether a path ends on an emitter (S7: no scatter).  When every emitter of the scene
             // is a binned small primitive, the paths of a non-candidate tile certainly miss all of them: nothing to add.
@@ -303,14 +401,15 @@ __global__ __launch_bounds__(kBlock, (FIRST || MANY) ? 5 : 6) void k_bounce(KPar
                 col = f3(1.0f, 1.0f, 1.0f);
                 rem = prm.traceDepth;
             } else {
-                // one running pointer through the 11 arrays (stride = cap): the array bases then need no registers of their own
-                const float *src = in.base + idx;
+                // one running (scalar) pointer through the 11 arrays (stride = cap) + the lane's 32-bit byte offset
+                const float *src = in.base;
                 const size_t cap = (size_t)in.cap;
-                org.x = *src; src += cap; org.y = *src; src += cap; org.z = *src; src += cap;
-                dir.x = *src; src += cap; dir.y = *src; src += cap; dir.z = *src; src += cap;
-                col.x = *src; src += cap; col.y = *src; src += cap; col.z = *src; src += cap;
-                pix = __float_as_int(*src); src += cap;
-                const int packed = __float_as_int(*src);        // remainingBounces | batch index << 8
+                const uint32_t off = idx * 4u;
+                org.x = ldSlot(src, off); src += cap; org.y = ldSlot(src, off); src += cap; org.z = ldSlot(src, off); src += cap;
+                dir.x = ldSlot(src, off); src += cap; dir.y = ldSlot(src, off); src += cap; dir.z = ldSlot(src, off); src += cap;
+                col.x = ldSlot(src, off); src += cap; col.y = ldSlot(src, off); src += cap; col.z = ldSlot(src, off); src += cap;
+                pix = __float_as_int(ldSlot(src, off)); src += cap;
+                const int packed = __float_as_int(ldSlot(src, off));        // remainingBounces | batch index << 8
                 rem = packed & 0xff;
                 itb = packed >> 8;
             }
@@ -479,21 +578,28 @@ __global__ __launch_bounds__(kBlock, (FIRST || MANY) ? 5 : 6) void k_bounce(KPar
 #pragma unroll
                 for (int w = 0; w < kWaves; ++w) total += wv[w * kCls + threadIdx.x];
                 const uint32_t oseg = threadIdx.x * kSub + (blockIdx.x % kSub);
-                s_base[threadIdx.x] = total ? atomicAdd(&ctrl->seg_count[parity][depth + 1][oseg][0], total) : 0u;
+                uint32_t b0, sp, b1;
+                reserveRun(&ctrl->pos[parity][depth + 1][oseg][0], &ctrl->bump[parity][depth + 1][0],
+                           out.list + (size_t)oseg * (uint32_t)prm.poolChunks, oseg, (uint32_t)prm.poolChunks, (uint32_t)prm.chunkShift, genOut,
+                           total, &ctrl->error, s_base[3 * kCls + threadIdx.x], s_base[4 * kCls + threadIdx.x], b0, sp, b1);
+                s_base[threadIdx.x] = b0;
+                s_base[kCls + threadIdx.x] = sp;
+                s_base[2 * kCls + threadIdx.x] = b1;
             }
             __syncthreads();
             if (alive) {
                 uint32_t waveOff = 0;
                 for (int w = 0; w < wave; ++w) waveOff += wv[w * kCls + cls];
-                const uint32_t oseg = cls * kSub + (blockIdx.x % kSub);
-                const uint32_t slot = oseg * (uint32_t)prm.segCap + s_base[cls] + waveOff + rank;
-                float *dst = out.base + slot;
+                const uint32_t r = waveOff + rank, sp = s_base[kCls + cls];
+                const uint32_t slot = r < sp ? s_base[cls] + r : s_base[2 * kCls + cls] + (r - sp);
+                float *dst = out.base;
                 const size_t ocap = (size_t)out.cap;
-                *dst = org.x; dst += ocap; *dst = org.y; dst += ocap; *dst = org.z; dst += ocap;
-                *dst = dir.x; dst += ocap; *dst = dir.y; dst += ocap; *dst = dir.z; dst += ocap;
-                *dst = col.x; dst += ocap; *dst = col.y; dst += ocap; *dst = col.z; dst += ocap;
-                *dst = __int_as_float(pix); dst += ocap;
-                *dst = __int_as_float((rem - 1) | (itb << 8));
+                const uint32_t off = slot * 4u;
+                stSlot(dst, off, org.x); dst += ocap; stSlot(dst, off, org.y); dst += ocap; stSlot(dst, off, org.z); dst += ocap;
+                stSlot(dst, off, dir.x); dst += ocap; stSlot(dst, off, dir.y); dst += ocap; stSlot(dst, off, dir.z); dst += ocap;
+                stSlot(dst, off, col.x); dst += ocap; stSlot(dst, off, col.y); dst += ocap; stSlot(dst, off, col.z); dst += ocap;
+                stSlot(dst, off, __int_as_float(pix)); dst += ocap;
+                stSlot(dst, off, __int_as_float((rem - 1) | (itb << 8)));
             }
             __syncthreads();   // every wave has read this tile's counts: each wave clears its own row for the next tile
             if (lane < kCls) wv[wave * kCls + lane] = 0u;
