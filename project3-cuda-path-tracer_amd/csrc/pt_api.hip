@@ -140,6 +140,7 @@ void pack_geom(const PtGeom &g, GeomDev &d, const float *eye = nullptr) {
         }
     for (int r = 0; r < 3; ++r) d.invZ[r] = d.inv[9 + r] * 0.0f;
     d.type = g.type;
+    d.flags = g.type == PT_CUBE ? 1 : 0;    // bit 1 (binned) is set by pt_init
     d.material = g.materialid;
     // bounding-ball culling data (ptd::certainMiss): bounds smax >= sigma_max, smin <= sigma_min of the 3x3 part
     double A[3][3], Ai[3][3];
@@ -334,9 +335,14 @@ int launch_bounce(Slot &sl, int iter, int batch, int depth, bool lastBounce, flo
         HIPCHECK(hipEventCreate(&e1));
         HIPCHECK(hipEventRecord(e0, sl.stream));
     }
-#define PT_LAUNCH_BOUNCE(FIRST_, MANY_, GRID_)                                                                              \
-    hipLaunchKernelGGL((k_bounce<FIRST_, MANY_>), dim3(GRID_), dim3(kBlock), S.ldsBytes, sl.stream, S.prm, iter, batch, depth, \
-                       lastBounce ? 1 : 0, sl.parity, genIn, genOut, in, out, sl.ctrl, S.dgeoms, S.dmats, contrib)
+    BounceArgs ba;
+    ba.prm = S.prm;
+    ba.iter = iter; ba.batch = batch; ba.depth = depth; ba.lastBounce = lastBounce ? 1 : 0; ba.parity = sl.parity;
+    ba.genIn = genIn; ba.genOut = genOut;
+    ba.in = in; ba.out = out;
+    ba.ctrl = sl.ctrl; ba.ggeoms = S.dgeoms; ba.gmats = S.dmats; ba.contrib = contrib;
+#define PT_LAUNCH_BOUNCE(FIRST_, MANY_, GRID_) \
+    hipLaunchKernelGGL((k_bounce<FIRST_, MANY_>), dim3(GRID_), dim3(kBlock), S.ldsBytes, sl.stream, ba)
     if (depth == 1) {
         if (S.many) PT_LAUNCH_BOUNCE(true, true, S.gridFirst); else PT_LAUNCH_BOUNCE(true, false, S.gridFirst);
     } else {
@@ -652,6 +658,7 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
         for (size_t c = 0; c < cand.size() && k.nBinned < kBinMax; ++c) {
             k.binGeom[k.nBinned++] = cand[c].second;
             hg[cand[c].second].binned = 1;
+            hg[cand[c].second].flags |= 2;
         }
     }
     k.emittersBinned = k.nBinned > 0 ? 1 : 0;

@@ -8,6 +8,7 @@
 // evaluation of the same functions.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 namespace ptd {
@@ -82,42 +83,60 @@ __device__ __forceinline__ F3 refract(F3 I, F3 N, float eta) {
 constexpr float kTwoPi = 6.2831853071795864769252867665590057683943f;
 constexpr float kSqrtOneThird = 0.5773502691896257645091487805019574556476f;
 
-// ---- scene data as staged in LDS -------------------------------------------------------------
+// ---- scene data ------------------------------------------------------------------------------------
+// Scalar data of the kernels is read through CONSTANT-address-space pointers (always s_load -> SGPR operands), and the
+// pointers are "laundered" through an empty asm where a phase of the kernel starts: the loads then cannot be hoisted
+// out of the tile / primitive loops, whose live ranges would otherwise pile up in SGPRs (round 1: 106 SGPRs and up to
+// 51 spilled to VGPR lanes, six workgroups per CU instead of eight).
+#define PT_CAS __attribute__((address_space(4)))
+template <typename T>
+__device__ __forceinline__ const PT_CAS T *launder(const PT_CAS T *p) {
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
 // Rows 0..2 of the three column-major mat4 of a Geom (the w row is never used: multiplyMV clips
-// to vec3, src/intersections.h:33-35).  m[col*3 + row].
+// to vec3, src/intersections.h:33-35).  m[col*3 + row].  Laid out by phase of the nearest-hit loop, each group
+// 16- or 8-dword aligned so that it arrives in one scalar load.
 struct GeomDev {
+    // ---- 0x00: the test (one s_load_dwordx16)
     float inv[12];   // inverseTransform
-    float xf[12];    // transform
-    float invT[12];  // invTranspose
-    int   type;      // 0 sphere, 1 cube (src/sceneStructs.h:8-11)
-    int   material;
-    // conservative world-space culling (certainMiss) against the primitive's bounding ball: centre, rho^2 smax^2 (1 + 1e-3)
-    // with rho^2 = 1/4 (sphere) or 3/4 (cube: half its diagonal), 1e-4 (smax / smin)^2 with smax / smin bounds of the
-    // transform's singular values
-    float cullR2, cullK;
-    float centre[3];
-    float boundR;    // radius of the bounding ball, rho smax (host bookkeeping: which primitives are small)
+    // inverseTransform's translation column times 0.0f (a signed zero each, or NaN): the w = 0 products of a direction
+    // transform, multiplyMV(inverseTransform, (d, 0)), evaluated once instead of once per ray
+    float invZ[3];
+    int   flags;     // bit 0: type (0 sphere, 1 cube), bit 1: binned
+    // ---- 0x40: camera rays (first bounce only)
     // object-space camera position multiplyMV(inverseTransform, (eye, 1)), evaluated once on the host with the
     // same operation order: every camera ray of the first bounce shares it
     float camObj[3];
-    // 1: a small primitive the queue is binned by (KParams::binGeom): tiles of paths that certainly miss all of them
-    // skip it
-    int   binned;
+    int   pad0;
     // Pixels whose camera rays can reach this primitive: inclusive bounds [x0, y0, x1, y1] of the projection of its
     // object-space unit cube, widened by 2 pixels (host, double precision); the whole frame when a corner is not in
     // front of the eye.  Camera rays of other pixels skip the primitive (first bounce only).
     int   rect[4];
+    // ---- 0x60: conservative world-space culling (certainMiss) against the primitive's bounding ball: centre, rho^2 smax^2 (1 + 1e-3)
+    // with rho^2 = 1/4 (sphere) or 3/4 (cube: half its diagonal), 1e-4 (smax / smin)^2 with smax / smin bounds of the
+    // transform's singular values
+    float centre[3];
+    float cullR2, cullK;
+    float boundR;    // radius of the bounding ball, rho smax (host bookkeeping: which primitives are small)
+    int   type;      // 0 sphere, 1 cube (src/sceneStructs.h:8-11)
+    int   material;
+    // ---- 0x80: a hit
+    float xf[12];    // transform
+    float invT[12];  // invTranspose
     // cube: for each of its six faces (entry axis * 2 + (sign > 0)) the surface normal
     // normalize(multiplyMV(transform, (+-e_axis, 0))) (src/intersections.h:85) and the two tangent directions the
     // hemisphere sampler derives from a normal (src/interactions.h:22-35), 9 floats per face, evaluated once on the host
     // with the operations the kernels would issue per hit
     float cubeFrame[54];
-    // inverseTransform's translation column times 0.0f (a signed zero each, or NaN): the w = 0 products of a direction
-    // transform, multiplyMV(inverseTransform, (d, 0)), evaluated once instead of once per ray
-    float invZ[3];
-    float pad3[3];
+    // 1: a small primitive the queue is binned by (KParams::binGeom): tiles of paths that certainly miss all of them
+    // skip it (mirrored in flags)
+    int   binned;
+    int   pad1;
 };
 static_assert(sizeof(GeomDev) == 448, "GeomDev is 28 x 16 B");
+static_assert(offsetof(GeomDev, camObj) == 64 && offsetof(GeomDev, centre) == 96 && offsetof(GeomDev, xf) == 128, "scalar-load groups");
 
 struct MaterialDev {
     float color[3];
@@ -132,7 +151,8 @@ static_assert(sizeof(MaterialDev) == 48, "MaterialDev is 3 x 16 B");
 // multiplyMV (src/intersections.h:33-35) = vec3(m * v), glm/detail/type_mat4x4.inl:617-628:
 // (m0*v0 + m1*v1) + (m2*v2 + m3*v3).  The products with w = 0 / w = 1 are kept as IEEE ops
 // (x*1 folds exactly; x*0 keeps its signed zero), so signed zeros match the reference too.
-__device__ __forceinline__ F3 mulMV(const float *m, F3 v, float w) {
+template <typename P>
+__device__ __forceinline__ F3 mulMV(P m, F3 v, float w) {
     F3 r;
     r.x = (m[0] * v.x + m[3] * v.y) + (m[6] * v.z + m[9] * w);
     r.y = (m[1] * v.x + m[4] * v.y) + (m[7] * v.z + m[10] * w);
@@ -141,7 +161,8 @@ __device__ __forceinline__ F3 mulMV(const float *m, F3 v, float w) {
 }
 
 // mulMV(m, v, 0) with the three products m[9 + r] * 0.0f supplied (z0): same sums, three multiplications less
-__device__ __forceinline__ F3 mulMV0(const float *m, const float *z0, F3 v) {
+template <typename P, typename Q>
+__device__ __forceinline__ F3 mulMV0(P m, Q z0, F3 v) {
     F3 r;
     r.x = (m[0] * v.x + m[3] * v.y) + (m[6] * v.z + z0[0]);
     r.y = (m[1] * v.x + m[4] * v.y) + (m[7] * v.z + z0[1]);
@@ -298,8 +319,8 @@ __device__ __forceinline__ void slabQuotients(float o, float d, float &t1, float
 // the six correctly rounded divisions.  It only pays when whole waves take it, i.e. for coherent
 // rays (EARLY_MISS is set for the camera-ray bounce); results are identical either way.
 // CAM_ORIGIN: the ray starts at the camera, whose object-space position is precomputed (GeomDev::camObj).
-template <bool EARLY_MISS, bool CAM_ORIGIN = false>
-__device__ __forceinline__ float boxIntersectionTest(const GeomDev &g, F3 ro, F3 rd, F3 &P, F3 &nsrc, bool &outside) {
+template <bool EARLY_MISS, bool CAM_ORIGIN = false, typename GD>
+__device__ __forceinline__ float boxIntersectionTest(const GD &g, F3 ro, F3 rd, F3 &P, F3 &nsrc, bool &outside) {
     probe(0);
     const F3 qo = CAM_ORIGIN ? f3(g.camObj[0], g.camObj[1], g.camObj[2]) : mulMV(g.inv, ro, 1.0f);
     const F3 qdu = mulMV0(g.inv, g.invZ, rd);
@@ -365,7 +386,8 @@ __device__ __forceinline__ float boxIntersectionTest(const GeomDev &g, F3 ro, F3
 //   `tmax >= tmin` fails (intersections.h:70).  The margin is 50x either way, and tests sweep 2^28 rays dense in grazes.
 // dd = dot(dir, dir) (the world direction is only approximately unit) is hoisted out of the geom loop.
 // NaN / inf operands fail the comparison, i.e. fall through to the full test.
-__device__ __forceinline__ bool certainMiss(const GeomDev &g, F3 org, F3 dir, float dd) {
+template <typename GD>
+__device__ __forceinline__ bool certainMiss(const GD &g, F3 org, F3 dir, float dd) {
     const F3 oc = org - f3(g.centre[0], g.centre[1], g.centre[2]);
     const float oo = dot(oc, oc);
     const float od = dot(oc, dir);
@@ -376,9 +398,10 @@ __device__ __forceinline__ bool certainMiss(const GeomDev &g, F3 org, F3 dir, fl
 // `inv`, `invZ`, `xf`: rows 0-2 of inverseTransform (and its w = 0 products, GeomDev::invZ) / transform as mulMV expects them -- SGPR operands when the sphere is
 // wave-uniform (GeomDev through the scalar path), registers when every lane tests its own sphere (k_bounce<., MANY>).
 // `camObj`: the precomputed object-space origin of a camera ray, or nullptr.
-__device__ __forceinline__ float sphereIntersectionTestM(const float *inv, const float *invZ, const float *xf, const float *camObj,
+template <bool CAM_ORIGIN, typename P1, typename P2, typename P3, typename P4>
+__device__ __forceinline__ float sphereIntersectionTestM(P1 inv, P2 invZ, P3 xf, P4 camObj,
                                                          F3 ro_w, F3 rd_w, F3 &P, F3 &nsrc, bool &outside) {
-    F3 ro = camObj ? f3(camObj[0], camObj[1], camObj[2]) : mulMV(inv, ro_w, 1.0f);
+    F3 ro = CAM_ORIGIN ? f3(camObj[0], camObj[1], camObj[2]) : mulMV(inv, ro_w, 1.0f);
     F3 rd = normalize(mulMV0(inv, invZ, rd_w));
     float vDotDirection = dot(ro, rd);
     float radicand = vDotDirection * vDotDirection - (dot(ro, ro) - 0.25f);
@@ -404,11 +427,11 @@ __device__ __forceinline__ float sphereIntersectionTestM(const float *inv, const
     nsrc = obj;      // normal = +-normalize(invTranspose * (obj, 0)): hitNormal(), evaluated for the nearest hit only
     return length(ro_w - P);
 }
-template <bool CAM_ORIGIN = false>
-__device__ __forceinline__ float sphereIntersectionTest(const GeomDev &g, F3 ro_w, F3 rd_w, F3 &P, F3 &nsrc,
+template <bool CAM_ORIGIN = false, typename GD>
+__device__ __forceinline__ float sphereIntersectionTest(const GD &g, F3 ro_w, F3 rd_w, F3 &P, F3 &nsrc,
                                                         bool &outside) {
     probe(4);
-    return sphereIntersectionTestM(g.inv, g.invZ, g.xf, CAM_ORIGIN ? g.camObj : nullptr, ro_w, rd_w, P, nsrc, outside);
+    return sphereIntersectionTestM<CAM_ORIGIN>(g.inv, g.invZ, g.xf, g.camObj, ro_w, rd_w, P, nsrc, outside);
 }
 
 // The surface normal of a hit, from what the two tests leave in `nsrc` (src/intersections.h:85 and :137-140).

@@ -234,76 +234,102 @@ __global__ __launch_bounds__(kBlock) void k_debug_camera_rays(KParams prm, int i
 // times per wave with 1.8 active lanes).  After the loop, pass k tests every lane's k-th recorded sphere, each lane with
 // its own matrices from LDS -- 3-4 passes with tens of active lanes.  Same tests on the same operands; the nearest hit is
 // chosen by (distance, then file order), which is what the in-order loop with its strict `<` computes.
+// Everything a launch needs, passed BY VALUE as the kernel's single argument and read back, phase by phase, from the
+// kernarg segment through a laundered constant-address-space pointer (see launder() in pt_device.h): a field then lives
+// in SGPRs from the s_load of the phase that uses it to its last use there, instead of from the kernel's entry to its
+// end (the compiler hoists kernel arguments and everything derived from them out of the tile loop and then spills).
+struct BounceArgs {
+    KParams prm;
+    int iter, batch, depth, lastBounce, parity;
+    uint32_t genIn, genOut;             // serial numbers of the launches that filled / fill the input / output pool
+    PathPool in, out;
+    Ctrl *ctrl;
+    const GeomDev *ggeoms;
+    const MaterialDev *gmats;
+    float *contrib;
+};
+typedef const PT_CAS BounceArgs *ArgsPtr;
+typedef const PT_CAS GeomDev *GeomPtr;
+
 template <bool FIRST, bool MANY>
-__global__ __launch_bounds__(kBlock, (FIRST || MANY) ? 5 : 6) void k_bounce(KParams prm, int iter, int batch, int depth, int lastBounce, int parity,
-                                                   uint32_t genIn, uint32_t genOut,
-                                                   PathPool in, PathPool out, Ctrl *ctrl,
-                                                   const GeomDev *__restrict__ ggeoms,
-                                                   const MaterialDev *__restrict__ gmats, float *contrib) {
+__global__ __launch_bounds__(kBlock, MANY ? 5 : 8) void k_bounce(BounceArgs argsByValue) {
+    (void)argsByValue;
+    const ArgsPtr kargs = (ArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
     // LDS: the material table and the per-geom hit records (normal matrix, material, type: indexed per lane by
     // the nearest hit), and the compaction scratch.  Geometry itself is wave-uniform in the nearest-hit loop, so it is fetched through the
     // scalar path (s_load into SGPRs, used directly as VALU operands): measured against an LDS-staged copy
     // read back with ds_read_b128 broadcasts this is 5 % faster on Cornell (7 geoms) and 11 % on the 70-geom
     // scene, and it frees ~40 VGPRs.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    MaterialDev *smats = reinterpret_cast<MaterialDev *>(smem);
-    GeomHitDev *s_geomHit = reinterpret_cast<GeomHitDev *>(smem + sizeof(MaterialDev) * prm.nmats);
-    uint32_t *s_misc = reinterpret_cast<uint32_t *>(smem + sizeof(MaterialDev) * prm.nmats + sizeof(GeomHitDev) * prm.ngeoms);
-    uint32_t *s_wave = s_misc;                       // [kWaves][kCls] survivors per wave and class (zero between tiles)
-    uint32_t *s_base = s_wave + kWaves * kCls;       // [5][kCls] this tile's output run per class: first slot, paths before the
-                                                     //           chunk boundary, first slot behind it; the class's last chunk lookup (reserveRun)
-    uint32_t *s_segcnt = s_base + 5 * kCls;          // [kSeg]   paths per input segment
-    uint32_t *s_segpre = s_segcnt + kSeg;            // [kSeg+2] tile prefix per input segment, [kSeg+1] = live paths
-    uint32_t *s_iterHash = s_segpre + kSeg + 2;      // [2][PT_MAX_BATCH] iterationHash(iter + b, depth) and (iter + b, 0)
-    float *s_sph = reinterpret_cast<float *>(s_misc + kMiscWords);                    // MANY: [ngeoms][kSphRowFloats]
-    uint16_t *s_list = reinterpret_cast<uint16_t *>(s_sph + (size_t)prm.ngeoms * kSphRowFloats);   // MANY: [kListMax][kBlock]
-
-    if (lastBounce) {   // re-arm the next iteration: nobody touches the other parity's counters now
-        uint32_t *other = &ctrl->pos[parity ^ 1][0][0][0];
-        const int nwords = (prm.traceDepth + 2) * kSeg;
-        for (int i = blockIdx.x * kBlock + threadIdx.x; i < nwords; i += gridDim.x * kBlock) other[i * kCtrPad] = 0u;
-        if (blockIdx.x == 0 && threadIdx.x < kMaxDepthSlots) ctrl->bump[parity ^ 1][threadIdx.x][0] = 0u;
-    }
-    // input queue: segment s holds s_cnt[s] paths = tiles [s_pre[s], s_pre[s+1]) of the global tile index
-    uint32_t nLive, numTiles;
-    if (FIRST) {
-        nLive = (uint32_t)prm.nLocal * (uint32_t)batch;     // `batch` consecutive iterations share one wavefront
-        numTiles = (nLive + kBlock - 1) / kBlock;
-    } else {
-        if (threadIdx.x < 64) {          // wave 0: exclusive scan of the kSeg tile counts
-            const uint32_t c = threadIdx.x < kSeg ? ctrl->pos[parity][depth][threadIdx.x][0] : 0u;
-            const uint32_t t = (c + kBlock - 1) / kBlock;
-            uint32_t inc = t, sum = c;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t up = __shfl_up(inc, o, 64), us = __shfl_up(sum, o, 64);
-                if ((int)threadIdx.x >= o) { inc += up; sum += us; }
-            }
-            if (threadIdx.x < kSeg) { s_segcnt[threadIdx.x] = c; s_segpre[threadIdx.x + 1] = inc; }
-            if (threadIdx.x == 0) s_segpre[0] = 0;
-            if (threadIdx.x == 63) s_segpre[kSeg + 1] = sum;   // total live paths
-        }
-        __syncthreads();
-        numTiles = s_segpre[kSeg];
-        nLive = s_segpre[kSeg + 1];
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctrl->sum_live[depth], (unsigned long long)nLive);
-    if (blockIdx.x >= numTiles) return;
-    if (threadIdx.x < kWaves * kCls) s_wave[threadIdx.x] = 0u;
-    if (threadIdx.x < kCls) s_base[3 * kCls + threadIdx.x] = 0xffffffffu;   // no chunk looked up yet
-    if (threadIdx.x < 2 * PT_MAX_BATCH) {
-        const int b = threadIdx.x % PT_MAX_BATCH;
-        s_iterHash[threadIdx.x] = iterationHash(iter + b, threadIdx.x < PT_MAX_BATCH ? depth : 0);
-    }
-
-    // stage the materials in LDS once per (persistent) workgroup, 16 B per lane per step
+    MaterialDev *smats;
+    GeomHitDev *s_geomHit;
+    uint32_t *s_misc;
     {
-        const float4 *msrc = reinterpret_cast<const float4 *>(gmats);
+        const ArgsPtr A = launder(kargs);
+        const int nmats = A->prm.nmats, ngeoms = A->prm.ngeoms;
+        smats = reinterpret_cast<MaterialDev *>(smem);
+        s_geomHit = reinterpret_cast<GeomHitDev *>(smem + sizeof(MaterialDev) * nmats);
+        s_misc = reinterpret_cast<uint32_t *>(smem + sizeof(MaterialDev) * nmats + sizeof(GeomHitDev) * ngeoms);
+    }
+    uint32_t *const s_wave = s_misc;                       // [kWaves][kCls] survivors per wave and class (zero between tiles)
+    uint32_t *const s_base = s_wave + kWaves * kCls;       // [5][kCls] this tile's output run per class: first slot, paths before the
+                                                           //           chunk boundary, first slot behind it; the class's last chunk lookup (reserveRun)
+    uint32_t *const s_segcnt = s_base + 5 * kCls;          // [kSeg]   paths per input segment
+    uint32_t *const s_segpre = s_segcnt + kSeg;            // [kSeg+2] tile prefix per input segment, [kSeg+1] = live paths
+    uint32_t *const s_iterHash = s_segpre + kSeg + 2;      // [2][PT_MAX_BATCH] iterationHash(iter + b, depth) and (iter + b, 0)
+    float *const s_sph = reinterpret_cast<float *>(s_misc + kMiscWords);                    // MANY: [ngeoms][kSphRowFloats]
+
+    uint32_t nLive, numTiles;
+    {
+        const ArgsPtr A = launder(kargs);
+        Ctrl *const ctrl = A->ctrl;
+        const int depth = A->depth, parity = A->parity;
+        if (A->lastBounce) {   // re-arm the slot's next batch: nobody touches the other parity's counters now
+            uint32_t *other = &ctrl->pos[parity ^ 1][0][0][0];
+            const int nwords = (A->prm.traceDepth + 2) * kSeg;
+            for (int i = blockIdx.x * kBlock + threadIdx.x; i < nwords; i += gridDim.x * kBlock) other[i * kCtrPad] = 0u;
+            if (blockIdx.x == 0 && threadIdx.x < kMaxDepthSlots) ctrl->bump[parity ^ 1][threadIdx.x][0] = 0u;
+        }
+        // input queue: segment s holds s_cnt[s] paths = tiles [s_pre[s], s_pre[s+1]) of the global tile index
+        if (FIRST) {
+            nLive = (uint32_t)A->prm.nLocal * (uint32_t)A->batch;     // `batch` consecutive iterations share one wavefront
+            numTiles = (nLive + kBlock - 1) / kBlock;
+        } else {
+            if (threadIdx.x < 64) {          // wave 0: exclusive scan of the kSeg tile counts
+                const uint32_t c = threadIdx.x < kSeg ? ctrl->pos[parity][depth][threadIdx.x][0] : 0u;
+                const uint32_t t = (c + kBlock - 1) / kBlock;
+                uint32_t inc = t, sum = c;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t up = __shfl_up(inc, o, 64), us = __shfl_up(sum, o, 64);
+                    if ((int)threadIdx.x >= o) { inc += up; sum += us; }
+                }
+                if (threadIdx.x < kSeg) { s_segcnt[threadIdx.x] = c; s_segpre[threadIdx.x + 1] = inc; }
+                if (threadIdx.x == 0) s_segpre[0] = 0;
+                if (threadIdx.x == 63) s_segpre[kSeg + 1] = sum;   // total live paths
+            }
+            __syncthreads();
+            numTiles = s_segpre[kSeg];
+            nLive = s_segpre[kSeg + 1];
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctrl->sum_live[depth], (unsigned long long)nLive);
+        if (blockIdx.x >= numTiles) return;
+        if (threadIdx.x < kWaves * kCls) s_wave[threadIdx.x] = 0u;
+        if (threadIdx.x < kCls) s_base[3 * kCls + threadIdx.x] = 0xffffffffu;   // no chunk looked up yet
+        if (threadIdx.x < 2 * PT_MAX_BATCH) {
+            const int b = threadIdx.x % PT_MAX_BATCH;
+            s_iterHash[threadIdx.x] = iterationHash(A->iter + b, threadIdx.x < PT_MAX_BATCH ? depth : 0);
+        }
+
+        // stage the materials in LDS once per (persistent) workgroup, 16 B per lane per step
+        const GeomDev *ggeoms = A->ggeoms;
+        const int ngeoms = A->prm.ngeoms;
+        const float4 *msrc = reinterpret_cast<const float4 *>(A->gmats);
         float4 *mdst = reinterpret_cast<float4 *>(smats);
-        const int m16 = prm.nmats * (int)(sizeof(MaterialDev) / 16);
+        const int m16 = A->prm.nmats * (int)(sizeof(MaterialDev) / 16);
         for (int i = threadIdx.x; i < m16; i += kBlock) mdst[i] = msrc[i];
         constexpr int kHitWords = (int)(sizeof(GeomHitDev) / 4);
-        for (int i = threadIdx.x; i < prm.ngeoms * kHitWords; i += kBlock) {
+        for (int i = threadIdx.x; i < ngeoms * kHitWords; i += kBlock) {
             const int g = i / kHitWords, k = i - g * kHitWords;
             const GeomDev &G = ggeoms[g];
             uint32_t v = 0;
@@ -314,7 +340,7 @@ __global__ __launch_bounds__(kBlock, (FIRST || MANY) ? 5 : 6) void k_bounce(KPar
             reinterpret_cast<uint32_t *>(s_geomHit)[i] = v;
         }
         if (MANY) {
-            for (int i = threadIdx.x; i < prm.ngeoms * 27; i += kBlock) {
+            for (int i = threadIdx.x; i < ngeoms * 27; i += kBlock) {
                 const int g = i / 27, k = i - g * 27;
                 s_sph[g * kSphRowFloats + k] = k < 12 ? ggeoms[g].inv[k] : (k < 24 ? ggeoms[g].xf[k - 12] : ggeoms[g].invZ[k - 24]);
             }
@@ -329,16 +355,21 @@ __global__ __launch_bounds__(kBlock, (FIRST || MANY) ? 5 : 6) void k_bounce(KPar
         bool valid;
         uint32_t idx = 0;
         bool smallTile = true;              // wave-uniform: this tile's paths may hit a small (binned) primitive
+        int lastBounce;
         if (FIRST) {
+            const ArgsPtr A = launder(kargs);
+            const PT_CAS KParams &prm = A->prm;
+            lastBounce = A->lastBounce;
             // Tile T = b + k grid covers a 256-pixel block of the row-major pixel list.  With W a multiple of 256 a row
             // is `perRow` whole tiles, the grid is a multiple of perRow (pt_init), and a workgroup would stay in ONE
             // column band of the frame -- outside the scene rectangle its tiles cost 15x less than inside.  So the k-th
             // tile of a workgroup is rotated k bands to the right inside its row: a bijection on the row's tiles
             // (they share k), which walks every workgroup through all bands.
             uint32_t pixTile = T;
-            if (prm.tilesPerRow > 1) {
-                const uint32_t c = T % (uint32_t)prm.tilesPerRow;
-                pixTile = T - c + (c + firstK) % (uint32_t)prm.tilesPerRow;
+            const uint32_t tilesPerRow = (uint32_t)prm.tilesPerRow;
+            if (tilesPerRow > 1) {
+                const uint32_t c = T % tilesPerRow;
+                pixTile = T - c + (c + firstK) % tilesPerRow;
                 ++firstK;
             }
             idx = pixTile * kBlock + threadIdx.x;               // position in this shard's pixel list
@@ -348,9 +379,12 @@ __global__ __launch_bounds__(kBlock, (FIRST || MANY) ? 5 : 6) void k_bounce(KPar
             // the test is the same for the four waves of the workgroup).
             if (prm.wholeRowTiles) {
                 const uint32_t idx0 = pixTile * kBlock;
-                const int itb0 = (int)fastDiv(idx0, prm.magicN, prm.shiftN);
-                int pix0, x0, y0;
-                shardPixel(prm, (int)(idx0 - (uint32_t)itb0 * (uint32_t)prm.nLocal), pix0, x0, y0);
+                const uint32_t nLocal = (uint32_t)prm.nLocal;
+                const uint32_t itb0 = fastDiv(idx0, prm.magicN, prm.shiftN);
+                const uint32_t j0 = idx0 - itb0 * nLocal;
+                const int lr0 = (int)fastDiv(j0, prm.magicW, prm.shiftW);
+                const int x0 = (int)j0 - lr0 * prm.W;
+                const int y0 = lr0 * prm.shardCount + prm.shardRank;
                 if (y0 < prm.sceneRect[1] || y0 > prm.sceneRect[3] || x0 + (kBlock - 1) < prm.sceneRect[0] || x0 > prm.sceneRect[2]) {
                     const uint32_t w0 = idx0 + (threadIdx.x & ~63u);                  // this wave's first path
                     waveMiss += w0 >= nLive ? 0u : (nLive - w0 < 64u ? nLive - w0 : 64u);
@@ -358,26 +392,29 @@ __global__ __launch_bounds__(kBlock, (FIRST || MANY) ? 5 : 6) void k_bounce(KPar
                 }
             }
         } else {
+            const ArgsPtr A = launder(kargs);
+            lastBounce = A->lastBounce;
             // global tile -> (segment, local tile)
             while (T >= s_segpre[sgIn + 1]) ++sgIn;
             sgIn = (uint32_t)__builtin_amdgcn_readfirstlane((int)sgIn);
             const uint32_t local = (T - s_segpre[sgIn]) * kBlock + threadIdx.x;
             valid = local < s_segcnt[sgIn];
-            // the tile's chunk (a chunk is a multiple of the tile size): j-th chunk of the segment, wave-uniform lookup
-            // (entries were written by the previous launch; the 0-th chunk of a segment is static)
-            const uint32_t q0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)((T - s_segpre[sgIn]) * kBlock));
-            const uint32_t j = q0 >> prm.chunkShift;
-            uint32_t chunk = 1u + sgIn;
-            if (j != 0u) {
-                const unsigned long long e = j < (uint32_t)prm.poolChunks ? in.list[(size_t)sgIn * (uint32_t)prm.poolChunks + j] : 0ull;
-                chunk = (uint32_t)(e >> 32) == genIn ? (uint32_t)e : 0u;
-                chunk = chunk < (uint32_t)prm.poolChunks ? chunk : 0u;
-            }
-            idx = (chunk << prm.chunkShift) + (local - (j << prm.chunkShift));
             smallTile = ((sgIn / kSub) & 8u) != 0u;
             // The last bounce only asks whether a path ends on an emitter (S7: no scatter).  When every emitter of the scene
             // is a binned small primitive, the paths of a non-candidate tile certainly miss all of them: nothing to add.
-            if (lastBounce && prm.emittersBinned && !smallTile) continue;
+            if (lastBounce && A->prm.emittersBinned && !smallTile) continue;
+            // the tile's chunk (a chunk is a multiple of the tile size): j-th chunk of the segment, wave-uniform lookup
+            // (entries were written by the previous launch; the 0-th chunk of a segment is static)
+            const uint32_t shift = (uint32_t)A->prm.chunkShift, poolChunks = (uint32_t)A->prm.poolChunks;
+            const uint32_t q0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)((T - s_segpre[sgIn]) * kBlock));
+            const uint32_t j = q0 >> shift;
+            uint32_t chunk = 1u + sgIn;
+            if (j != 0u) {
+                const unsigned long long e = j < poolChunks ? A->in.list[(size_t)sgIn * poolChunks + j] : 0ull;
+                chunk = (uint32_t)(e >> 32) == A->genIn ? (uint32_t)e : 0u;
+                chunk = chunk < poolChunks ? chunk : 0u;
+            }
+            idx = (chunk << shift) + (local - (j << shift));
         }
 
         bool alive = false;
@@ -394,16 +431,37 @@ __global__ __launch_bounds__(kBlock, (FIRST || MANY) ? 5 : 6) void k_bounce(KPar
             // even generated: they are misses whatever their jitter.
             bool inScene = true;
             if (FIRST) {
+                const ArgsPtr A = launder(kargs);
+                const PT_CAS KParams &prm = A->prm;
                 itb = (int)fastDiv(idx, prm.magicN, prm.shiftN);
-                shardPixel(prm, (int)(idx - (uint32_t)itb * (uint32_t)prm.nLocal), pix, px, py);
+                const int j = (int)(idx - (uint32_t)itb * (uint32_t)prm.nLocal);
+                const int lr = (int)fastDiv((uint32_t)j, prm.magicW, prm.shiftW);
+                px = j - lr * prm.W;
+                py = lr * prm.shardCount + prm.shardRank;
+                pix = px + py * prm.W;
                 inScene = px >= prm.sceneRect[0] && px <= prm.sceneRect[2] && py >= prm.sceneRect[1] && py <= prm.sceneRect[3];
-                if (inScene) cameraRayAt(prm, s_iterHash[PT_MAX_BATCH + itb], pix, px, py, org, dir);
+                if (inScene) {
+                    // camera ray (spec S2), jitter from the depth-0 stream of (iteration, pixel)
+                    Rng rng = makeSeededRandomEngineHashed(s_iterHash[PT_MAX_BATCH + itb], pix);
+                    const float jx = u01(rng);
+                    const float jy = u01(rng);
+                    const float sx = ((float)px + jx) - prm.halfW;
+                    const float sy = ((float)py + jy) - prm.halfH;
+                    const float a = prm.pixLenX * sx;
+                    const float b = prm.pixLenY * sy;
+                    const F3 view = f3(prm.view[0], prm.view[1], prm.view[2]);
+                    const F3 up = f3(prm.up[0], prm.up[1], prm.up[2]);
+                    const F3 right = f3(prm.right[0], prm.right[1], prm.right[2]);
+                    org = f3(prm.pos[0], prm.pos[1], prm.pos[2]);
+                    dir = normalize((view - right * a) - up * b);
+                }
                 col = f3(1.0f, 1.0f, 1.0f);
                 rem = prm.traceDepth;
             } else {
                 // one running (scalar) pointer through the 11 arrays (stride = cap) + the lane's 32-bit byte offset
-                const float *src = in.base;
-                const size_t cap = (size_t)in.cap;
+                const ArgsPtr A = launder(kargs);
+                const float *src = A->in.base;
+                const size_t cap = (size_t)A->in.cap;
                 const uint32_t off = idx * 4u;
                 org.x = ldSlot(src, off); src += cap; org.y = ldSlot(src, off); src += cap; org.z = ldSlot(src, off); src += cap;
                 dir.x = ldSlot(src, off); src += cap; dir.y = ldSlot(src, off); src += cap; dir.z = ldSlot(src, off); src += cap;
@@ -422,29 +480,35 @@ __global__ __launch_bounds__(kBlock, (FIRST || MANY) ? 5 : 6) void k_bounce(KPar
             bool outside = false;
             const float dd = dot(dir, dir);
             int nCand = 0;                                       // MANY: spheres recorded by this lane
-            for (int g = 0; inScene && g < prm.ngeoms; ++g) {
-                const GeomDev &G = ggeoms[g];
-                const int type = G.type;
-                F3 p, n;
-                bool o = false;
-                float t = -1.0f;
-                if (FIRST && (px < G.rect[0] || px > G.rect[2] || py < G.rect[1] || py > G.rect[3])) continue;
-                if (!FIRST && !smallTile && G.binned) continue;  // this tile's paths certainly miss every binned primitive
-                if (type == 0) {
-                    probe(3);
-                    if (!certainMiss(G, org, dir, dd)) {
-                        if (MANY && nCand < kListMax) {
-                            s_list[nCand * kBlock + threadIdx.x] = (uint16_t)g;
-                            ++nCand;
-                        } else {                                 // (MANY: the lane's list is full -- test in place)
-                            t = sphereIntersectionTest<FIRST>(G, org, dir, p, n, o);
+            uint16_t *const s_list = reinterpret_cast<uint16_t *>(s_sph + (size_t)(MANY ? launder(kargs)->prm.ngeoms : 0) * kSphRowFloats);   // MANY: [kListMax][kBlock]
+            if (inScene) {
+                const ArgsPtr A = launder(kargs);
+                const int ngeoms = A->prm.ngeoms;
+                const GeomPtr geoms = (GeomPtr)(A->ggeoms);
+                for (int g = 0; g < ngeoms; ++g) {
+                    const PT_CAS GeomDev &G = *(launder(geoms) + g);
+                    const int flags = G.flags;
+                    F3 p, n;
+                    bool o = false;
+                    float t = -1.0f;
+                    if (FIRST && (px < G.rect[0] || px > G.rect[2] || py < G.rect[1] || py > G.rect[3])) continue;
+                    if (!FIRST && !smallTile && (flags & 2)) continue;  // this tile's paths certainly miss every binned primitive
+                    if ((flags & 1) == 0) {
+                        probe(3);
+                        if (!certainMiss(G, org, dir, dd)) {
+                            if (MANY && nCand < kListMax) {
+                                s_list[nCand * kBlock + threadIdx.x] = (uint16_t)g;
+                                ++nCand;
+                            } else {                                 // (MANY: the lane's list is full -- test in place)
+                                t = sphereIntersectionTest<FIRST>(G, org, dir, p, n, o);
+                            }
                         }
+                    } else {
+                        t = boxIntersectionTest<true, FIRST>(G, org, dir, p, n, o);
                     }
-                } else {
-                    t = boxIntersectionTest<true, FIRST>(G, org, dir, p, n, o);
-                }
-                if (t > 0.0f && (hit < 0 || t < tbest)) {
-                    tbest = t; hit = g; P = p; nsrc = n; outside = o;
+                    if (t > 0.0f && (hit < 0 || t < tbest)) {
+                        tbest = t; hit = g; P = p; nsrc = n; outside = o;
+                    }
                 }
             }
             if (MANY) {
@@ -461,7 +525,7 @@ __global__ __launch_bounds__(kBlock, (FIRST || MANY) ? 5 : 6) void k_bounce(KPar
                         F3 p, n;
                         bool o = false;
                         probe(4);
-                        const float t = sphereIntersectionTestM(m, m + 24, m + 12, nullptr, org, dir, p, n, o);
+                        const float t = sphereIntersectionTestM<false>(m, m + 24, m + 12, m, org, dir, p, n, o);
                         // a recorded sphere may precede, in file order, the primitive that holds the record so far
                         if (t > 0.0f && (hit < 0 || t < tbest || (t == tbest && g < hit))) {
                             tbest = t; hit = g; P = p; nsrc = n; outside = o;
@@ -481,13 +545,15 @@ __global__ __launch_bounds__(kBlock, (FIRST || MANY) ? 5 : 6) void k_bounce(KPar
                 const F3 mcol = f3(M.color[0], M.color[1], M.color[2]);
                 if (M.emittance > 0.0f) {                        // S5: emitter ends the path
                     lightHit = true;
+                    const ArgsPtr A = launder(kargs);
+                    float *const contrib = A->contrib;
                     if (contrib) {
                         // Deferred accumulation: iterations overlap on several streams, so the radiance
                         // is parked in this iteration's own buffer (one path per pixel: race-free, no
                         // read) and k_commit adds it to the accumulator in iteration order.
                         const F3 c = (col * mcol) * M.emittance;
-                        float *px = contrib + 3 * ((size_t)itb * ((size_t)prm.W * prm.H) + (size_t)pix);
-                        px[0] = c.x; px[1] = c.y; px[2] = c.z;
+                        float *dst = contrib + 3 * ((size_t)itb * ((size_t)A->prm.W * A->prm.H) + (size_t)pix);
+                        dst[0] = c.x; dst[1] = c.y; dst[2] = c.z;
                     }
                 } else if (!lastBounce) {                        // S6 scatter (S7: skipped on the last bounce)
                     Rng rng = makeSeededRandomEngineHashed(s_iterHash[itb], pix);
@@ -548,11 +614,16 @@ __global__ __launch_bounds__(kBlock, (FIRST || MANY) ? 5 : 6) void k_bounce(KPar
                     org = norg;
                     dir = ndir;
                     alive = true;
-                    if (prm.nBinned > 0) {                       // class bit 3: can the new ray hit a small primitive at all?
-                        const float ndd = dot(ndir, ndir);
-                        smallCand = false;
-                        for (int sI = 0; sI < prm.nBinned; ++sI)
-                            smallCand = smallCand || !certainMiss(ggeoms[prm.binGeom[sI]], norg, ndir, ndd);
+                    {                                            // class bit 3: can the new ray hit a small primitive at all?
+                        const ArgsPtr A = launder(kargs);
+                        const int nBinned = A->prm.nBinned;
+                        if (nBinned > 0) {
+                            const GeomPtr geoms = (GeomPtr)(A->ggeoms);
+                            const float ndd = dot(ndir, ndir);
+                            smallCand = false;
+                            for (int sI = 0; sI < nBinned; ++sI)
+                                smallCand = smallCand || !certainMiss(*(launder(geoms) + A->prm.binGeom[sI]), norg, ndir, ndd);
+                        }
                     }
                 }
             }
@@ -574,26 +645,31 @@ __global__ __launch_bounds__(kBlock, (FIRST || MANY) ? 5 : 6) void k_bounce(KPar
             if (alive && rank == 0u) wv[wave * kCls + cls] = (uint32_t)__popcll(same);   // the class's first lane
             __syncthreads();
             if (threadIdx.x < kCls) {
+                const ArgsPtr A = launder(kargs);
+                Ctrl *const ctrl = A->ctrl;
+                const uint32_t poolChunks = (uint32_t)A->prm.poolChunks;
+                const int parity = A->parity, dnext = A->depth + 1;
                 uint32_t total = 0;
 #pragma unroll
                 for (int w = 0; w < kWaves; ++w) total += wv[w * kCls + threadIdx.x];
                 const uint32_t oseg = threadIdx.x * kSub + (blockIdx.x % kSub);
-                uint32_t b0, sp, b1;
-                reserveRun(&ctrl->pos[parity][depth + 1][oseg][0], &ctrl->bump[parity][depth + 1][0],
-                           out.list + (size_t)oseg * (uint32_t)prm.poolChunks, oseg, (uint32_t)prm.poolChunks, (uint32_t)prm.chunkShift, genOut,
-                           total, &ctrl->error, s_base[3 * kCls + threadIdx.x], s_base[4 * kCls + threadIdx.x], b0, sp, b1);
-                s_base[threadIdx.x] = b0;
+                uint32_t r0, sp, r1;
+                reserveRun(&ctrl->pos[parity][dnext][oseg][0], &ctrl->bump[parity][dnext][0], A->out.list + (size_t)oseg * poolChunks, oseg,
+                           poolChunks, (uint32_t)A->prm.chunkShift, A->genOut, total, &ctrl->error, s_base[3 * kCls + threadIdx.x],
+                           s_base[4 * kCls + threadIdx.x], r0, sp, r1);
+                s_base[threadIdx.x] = r0;
                 s_base[kCls + threadIdx.x] = sp;
-                s_base[2 * kCls + threadIdx.x] = b1;
+                s_base[2 * kCls + threadIdx.x] = r1;
             }
             __syncthreads();
             if (alive) {
+                const ArgsPtr A = launder(kargs);
                 uint32_t waveOff = 0;
                 for (int w = 0; w < wave; ++w) waveOff += wv[w * kCls + cls];
                 const uint32_t r = waveOff + rank, sp = s_base[kCls + cls];
                 const uint32_t slot = r < sp ? s_base[cls] + r : s_base[2 * kCls + cls] + (r - sp);
-                float *dst = out.base;
-                const size_t ocap = (size_t)out.cap;
+                float *dst = A->out.base;
+                const size_t ocap = (size_t)A->out.cap;
                 const uint32_t off = slot * 4u;
                 stSlot(dst, off, org.x); dst += ocap; stSlot(dst, off, org.y); dst += ocap; stSlot(dst, off, org.z); dst += ocap;
                 stSlot(dst, off, dir.x); dst += ocap; stSlot(dst, off, dir.y); dst += ocap; stSlot(dst, off, dir.z); dst += ocap;
@@ -606,6 +682,7 @@ __global__ __launch_bounds__(kBlock, (FIRST || MANY) ? 5 : 6) void k_bounce(KPar
         }
     }
     if ((threadIdx.x & 63) == 0) {
+        Ctrl *const ctrl = launder(kargs)->ctrl;
         const int shard = blockIdx.x % kOct;
         if (waveLight) atomicAdd(&ctrl->light_hits[shard][0], (unsigned long long)waveLight);
         if (waveMiss) atomicAdd(&ctrl->misses[shard][0], (unsigned long long)waveMiss);
