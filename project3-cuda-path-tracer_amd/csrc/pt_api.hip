@@ -442,10 +442,11 @@ int persistent_grid(const void *kernel, size_t lds, int *grid) {
     int perCU = 0;
     HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kernel, kBlock, lds));
     if (perCU < 1) perCU = 1;
-    // Six workgroups per CU even when eight would fit (63 VGPRs): a launch alone is fastest with six (0.158 ms against
-    // 0.173 with eight: fewer, longer strides balance better), and the two free wave slots per SIMD go to the launches
-    // of the neighbouring batches that run beside it.
-    int cap = 6;
+    // All four instantiations fit eight workgroups per CU (<= 80 SGPRs, <= 64 VGPRs; the sphere-list variants seven).  A
+    // launch that has the GPU to itself (pipeline_depth 1) is fastest with all of them (0.253 ms against 0.274 with six);
+    // with batches in flight on neighbouring streams six per launch is better (131.2 G paths/s against 128.9 with eight):
+    // the two free wave slots per SIMD go to the neighbouring batch's launches, which fill this launch's tail.
+    int cap = S.nslots > 1 ? 6 : 8;
     if (const char *e = getenv("PT_AMD_BLOCKS_PER_CU")) cap = atoi(e);   // experiments only
     if (perCU > cap) perCU = cap;
     *grid = prop.multiProcessorCount * perCU;

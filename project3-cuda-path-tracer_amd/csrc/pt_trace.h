@@ -234,6 +234,12 @@ __global__ __launch_bounds__(kBlock) void k_debug_camera_rays(KParams prm, int i
 // times per wave with 1.8 active lanes).  After the loop, pass k tests every lane's k-th recorded sphere, each lane with
 // its own matrices from LDS -- 3-4 passes with tens of active lanes.  Same tests on the same operands; the nearest hit is
 // chosen by (distance, then file order), which is what the in-order loop with its strict `<` computes.
+__device__ __forceinline__ uint32_t waveSum(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
 // Everything a launch needs, passed BY VALUE as the kernel's single argument and read back, phase by phase, from the
 // kernarg segment through a laundered constant-address-space pointer (see launder() in pt_device.h): a field then lives
 // in SGPRs from the s_load of the phase that uses it to its last use there, instead of from the kernel's entry to its
@@ -260,24 +266,18 @@ __global__ __launch_bounds__(kBlock, MANY ? 5 : 8) void k_bounce(BounceArgs args
     // scalar path (s_load into SGPRs, used directly as VALU operands): measured against an LDS-staged copy
     // read back with ds_read_b128 broadcasts this is 5 % faster on Cornell (7 geoms) and 11 % on the 70-geom
     // scene, and it frees ~40 VGPRs.
+    // Layout: the fixed-size scratch first (constant offsets), then the tables whose sizes depend on the scene.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    MaterialDev *smats;
-    GeomHitDev *s_geomHit;
-    uint32_t *s_misc;
-    {
-        const ArgsPtr A = launder(kargs);
-        const int nmats = A->prm.nmats, ngeoms = A->prm.ngeoms;
-        smats = reinterpret_cast<MaterialDev *>(smem);
-        s_geomHit = reinterpret_cast<GeomHitDev *>(smem + sizeof(MaterialDev) * nmats);
-        s_misc = reinterpret_cast<uint32_t *>(smem + sizeof(MaterialDev) * nmats + sizeof(GeomHitDev) * ngeoms);
-    }
+    uint32_t *const s_misc = reinterpret_cast<uint32_t *>(smem);
+    MaterialDev *const smats = reinterpret_cast<MaterialDev *>(smem + kMiscWords * sizeof(uint32_t));
+#define S_GEOMHIT(nmats_) (reinterpret_cast<GeomHitDev *>(smem + kMiscWords * sizeof(uint32_t) + sizeof(MaterialDev) * (nmats_)))
+#define S_SPH(nmats_, ngeoms_) (reinterpret_cast<float *>(smem + kMiscWords * sizeof(uint32_t) + sizeof(MaterialDev) * (nmats_) + sizeof(GeomHitDev) * (ngeoms_)))
     uint32_t *const s_wave = s_misc;                       // [kWaves][kCls] survivors per wave and class (zero between tiles)
     uint32_t *const s_base = s_wave + kWaves * kCls;       // [5][kCls] this tile's output run per class: first slot, paths before the
                                                            //           chunk boundary, first slot behind it; the class's last chunk lookup (reserveRun)
     uint32_t *const s_segcnt = s_base + 5 * kCls;          // [kSeg]   paths per input segment
     uint32_t *const s_segpre = s_segcnt + kSeg;            // [kSeg+2] tile prefix per input segment, [kSeg+1] = live paths
     uint32_t *const s_iterHash = s_segpre + kSeg + 2;      // [2][PT_MAX_BATCH] iterationHash(iter + b, depth) and (iter + b, 0)
-    float *const s_sph = reinterpret_cast<float *>(s_misc + kMiscWords);                    // MANY: [ngeoms][kSphRowFloats]
 
     uint32_t nLive, numTiles;
     {
@@ -324,6 +324,8 @@ __global__ __launch_bounds__(kBlock, MANY ? 5 : 8) void k_bounce(BounceArgs args
         // stage the materials in LDS once per (persistent) workgroup, 16 B per lane per step
         const GeomDev *ggeoms = A->ggeoms;
         const int ngeoms = A->prm.ngeoms;
+        GeomHitDev *const s_geomHit = S_GEOMHIT(A->prm.nmats);
+        float *const s_sph = S_SPH(A->prm.nmats, ngeoms);        // MANY: [ngeoms][kSphRowFloats]
         const float4 *msrc = reinterpret_cast<const float4 *>(A->gmats);
         float4 *mdst = reinterpret_cast<float4 *>(smats);
         const int m16 = A->prm.nmats * (int)(sizeof(MaterialDev) / 16);
@@ -348,18 +350,21 @@ __global__ __launch_bounds__(kBlock, MANY ? 5 : 8) void k_bounce(BounceArgs args
     }
     __syncthreads();
 
-    uint32_t waveLight = 0, waveMiss = 0;   // wave-uniform tallies, flushed once at the end
+    uint32_t nLight = 0, nMiss = 0;         // per-lane tallies (VGPRs are the less scarce kind here), reduced and flushed once at the end
     uint32_t sgIn = 0;                      // input segment of the current tile (tiles are visited in increasing order)
     uint32_t firstK = 0;                    // FIRST: how many tiles this workgroup has processed
     for (uint32_t T = blockIdx.x; T < numTiles; T += gridDim.x) {
+        // the lane id, opaque to the optimiser: the lane masks derived from it (tid < 16, wave > k, ...) are then
+        // recomputed where a tile needs them -- one v_cmp each -- instead of being hoisted out of the loop into SGPR pairs
+        // that live, spilled, across the whole tile
+        uint32_t tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
         bool valid;
         uint32_t idx = 0;
         bool smallTile = true;              // wave-uniform: this tile's paths may hit a small (binned) primitive
-        int lastBounce;
         if (FIRST) {
             const ArgsPtr A = launder(kargs);
             const PT_CAS KParams &prm = A->prm;
-            lastBounce = A->lastBounce;
             // Tile T = b + k grid covers a 256-pixel block of the row-major pixel list.  With W a multiple of 256 a row
             // is `perRow` whole tiles, the grid is a multiple of perRow (pt_init), and a workgroup would stay in ONE
             // column band of the frame -- outside the scene rectangle its tiles cost 15x less than inside.  So the k-th
@@ -372,8 +377,8 @@ __global__ __launch_bounds__(kBlock, MANY ? 5 : 8) void k_bounce(BounceArgs args
                 pixTile = T - c + (c + firstK) % tilesPerRow;
                 ++firstK;
             }
-            idx = pixTile * kBlock + threadIdx.x;               // position in this shard's pixel list
-            valid = idx < nLive;
+            idx = pixTile * kBlock + tid;                       // position in this shard's pixel list
+            valid = idx < (uint32_t)prm.nLocal * (uint32_t)A->batch;
             // A tile of whole-tile rows is 256 pixels of ONE row: when it lies outside the scene rectangle altogether,
             // all its camera rays are misses -- tally them and take the next tile (no rays, no compaction, no barrier;
             // the test is the same for the four waves of the workgroup).
@@ -386,23 +391,21 @@ __global__ __launch_bounds__(kBlock, MANY ? 5 : 8) void k_bounce(BounceArgs args
                 const int x0 = (int)j0 - lr0 * prm.W;
                 const int y0 = lr0 * prm.shardCount + prm.shardRank;
                 if (y0 < prm.sceneRect[1] || y0 > prm.sceneRect[3] || x0 + (kBlock - 1) < prm.sceneRect[0] || x0 > prm.sceneRect[2]) {
-                    const uint32_t w0 = idx0 + (threadIdx.x & ~63u);                  // this wave's first path
-                    waveMiss += w0 >= nLive ? 0u : (nLive - w0 < 64u ? nLive - w0 : 64u);
+                    nMiss += valid ? 1u : 0u;
                     continue;
                 }
             }
         } else {
             const ArgsPtr A = launder(kargs);
-            lastBounce = A->lastBounce;
             // global tile -> (segment, local tile)
             while (T >= s_segpre[sgIn + 1]) ++sgIn;
             sgIn = (uint32_t)__builtin_amdgcn_readfirstlane((int)sgIn);
-            const uint32_t local = (T - s_segpre[sgIn]) * kBlock + threadIdx.x;
+            const uint32_t local = (T - s_segpre[sgIn]) * kBlock + tid;
             valid = local < s_segcnt[sgIn];
             smallTile = ((sgIn / kSub) & 8u) != 0u;
             // The last bounce only asks whether a path ends on an emitter (S7: no scatter).  When every emitter of the scene
             // is a binned small primitive, the paths of a non-candidate tile certainly miss all of them: nothing to add.
-            if (lastBounce && A->prm.emittersBinned && !smallTile) continue;
+            if (A->lastBounce && A->prm.emittersBinned && !smallTile) continue;
             // the tile's chunk (a chunk is a multiple of the tile size): j-th chunk of the segment, wave-uniform lookup
             // (entries were written by the previous launch; the 0-th chunk of a segment is static)
             const uint32_t shift = (uint32_t)A->prm.chunkShift, poolChunks = (uint32_t)A->prm.poolChunks;
@@ -480,7 +483,13 @@ __global__ __launch_bounds__(kBlock, MANY ? 5 : 8) void k_bounce(BounceArgs args
             bool outside = false;
             const float dd = dot(dir, dir);
             int nCand = 0;                                       // MANY: spheres recorded by this lane
-            uint16_t *const s_list = reinterpret_cast<uint16_t *>(s_sph + (size_t)(MANY ? launder(kargs)->prm.ngeoms : 0) * kSphRowFloats);   // MANY: [kListMax][kBlock]
+            float *s_sph = nullptr;                              // MANY: [ngeoms][kSphRowFloats], then [kListMax][kBlock] lists
+            uint16_t *s_list = nullptr;
+            if (MANY) {
+                const ArgsPtr A = launder(kargs);
+                s_sph = S_SPH(A->prm.nmats, A->prm.ngeoms);
+                s_list = reinterpret_cast<uint16_t *>(s_sph + (size_t)A->prm.ngeoms * kSphRowFloats);
+            }
             if (inScene) {
                 const ArgsPtr A = launder(kargs);
                 const int ngeoms = A->prm.ngeoms;
@@ -497,7 +506,7 @@ __global__ __launch_bounds__(kBlock, MANY ? 5 : 8) void k_bounce(BounceArgs args
                         probe(3);
                         if (!certainMiss(G, org, dir, dd)) {
                             if (MANY && nCand < kListMax) {
-                                s_list[nCand * kBlock + threadIdx.x] = (uint16_t)g;
+                                s_list[nCand * kBlock + tid] = (uint16_t)g;
                                 ++nCand;
                             } else {                                 // (MANY: the lane's list is full -- test in place)
                                 t = sphereIntersectionTest<FIRST>(G, org, dir, p, n, o);
@@ -514,7 +523,7 @@ __global__ __launch_bounds__(kBlock, MANY ? 5 : 8) void k_bounce(BounceArgs args
             if (MANY) {
                 for (int k = 0; __ballot(k < nCand) != 0ull; ++k) {          // wave-uniform trip count
                     if (k < nCand) {
-                        const int g = s_list[k * kBlock + threadIdx.x];
+                        const int g = s_list[k * kBlock + tid];
                         const float4 *row = reinterpret_cast<const float4 *>(s_sph + g * kSphRowFloats);
                         float m[28];
 #pragma unroll
@@ -536,7 +545,7 @@ __global__ __launch_bounds__(kBlock, MANY ? 5 : 8) void k_bounce(BounceArgs args
             if (hit < 0) {
                 missed = true;                                   // S4: background is black
             } else {
-                const GeomHitDev &GH = s_geomHit[hit];               // per-lane geom: LDS lookup
+                const GeomHitDev &GH = S_GEOMHIT(launder(kargs)->prm.nmats)[hit];   // per-lane geom: LDS lookup
                 const bool isSphere = GH.type == 0;
                 bool faceOk = true;
                 const int face = isSphere ? 0 : cubeFace(nsrc, faceOk);
@@ -555,7 +564,7 @@ __global__ __launch_bounds__(kBlock, MANY ? 5 : 8) void k_bounce(BounceArgs args
                         float *dst = contrib + 3 * ((size_t)itb * ((size_t)A->prm.W * A->prm.H) + (size_t)pix);
                         dst[0] = c.x; dst[1] = c.y; dst[2] = c.z;
                     }
-                } else if (!lastBounce) {                        // S6 scatter (S7: skipped on the last bounce)
+                } else if (!launder(kargs)->lastBounce) {        // S6 scatter (S7: skipped on the last bounce)
                     Rng rng = makeSeededRandomEngineHashed(s_iterHash[itb], pix);
                     const F3 scol = f3(M.specColor[0], M.specColor[1], M.specColor[2]);
                     F3 ndir = dir, norg;
@@ -628,11 +637,11 @@ __global__ __launch_bounds__(kBlock, MANY ? 5 : 8) void k_bounce(BounceArgs args
                 }
             }
         }
-        waveLight += (uint32_t)__popcll(__ballot(lightHit));
-        waveMiss += (uint32_t)__popcll(__ballot(missed));
+        nLight += lightHit ? 1u : 0u;
+        nMiss += missed ? 1u : 0u;
 
-        if (!lastBounce) {                                       // S8: compaction into `out`, binned by class
-            const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        if (!launder(kargs)->lastBounce) {                       // S8: compaction into `out`, binned by class
+            const int wave = (int)(tid >> 6), lane = (int)(tid & 63u);
             uint32_t *wv = s_wave;
             // same-class mask of this lane from four bit ballots (the sign compares already are the ballots)
             const unsigned long long ba = __ballot(alive);
@@ -644,28 +653,29 @@ __global__ __launch_bounds__(kBlock, MANY ? 5 : 8) void k_bounce(BounceArgs args
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(same >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)same, 0u));
             if (alive && rank == 0u) wv[wave * kCls + cls] = (uint32_t)__popcll(same);   // the class's first lane
             __syncthreads();
-            if (threadIdx.x < kCls) {
+            if (tid < kCls) {
                 const ArgsPtr A = launder(kargs);
                 Ctrl *const ctrl = A->ctrl;
                 const uint32_t poolChunks = (uint32_t)A->prm.poolChunks;
                 const int parity = A->parity, dnext = A->depth + 1;
                 uint32_t total = 0;
 #pragma unroll
-                for (int w = 0; w < kWaves; ++w) total += wv[w * kCls + threadIdx.x];
-                const uint32_t oseg = threadIdx.x * kSub + (blockIdx.x % kSub);
+                for (int w = 0; w < kWaves; ++w) total += wv[w * kCls + tid];
+                const uint32_t oseg = tid * kSub + (blockIdx.x % kSub);
                 uint32_t r0, sp, r1;
                 reserveRun(&ctrl->pos[parity][dnext][oseg][0], &ctrl->bump[parity][dnext][0], A->out.list + (size_t)oseg * poolChunks, oseg,
-                           poolChunks, (uint32_t)A->prm.chunkShift, A->genOut, total, &ctrl->error, s_base[3 * kCls + threadIdx.x],
-                           s_base[4 * kCls + threadIdx.x], r0, sp, r1);
-                s_base[threadIdx.x] = r0;
-                s_base[kCls + threadIdx.x] = sp;
-                s_base[2 * kCls + threadIdx.x] = r1;
+                           poolChunks, (uint32_t)A->prm.chunkShift, A->genOut, total, &ctrl->error, s_base[3 * kCls + tid],
+                           s_base[4 * kCls + tid], r0, sp, r1);
+                s_base[tid] = r0;
+                s_base[kCls + tid] = sp;
+                s_base[2 * kCls + tid] = r1;
             }
             __syncthreads();
             if (alive) {
                 const ArgsPtr A = launder(kargs);
-                uint32_t waveOff = 0;
-                for (int w = 0; w < wave; ++w) waveOff += wv[w * kCls + cls];
+                // earlier waves' survivors of this class (kWaves = 4: three conditional terms, no loop)
+                const uint32_t w0 = wv[cls], w1 = wv[kCls + cls], w2 = wv[2 * kCls + cls];
+                const uint32_t waveOff = (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u);
                 const uint32_t r = waveOff + rank, sp = s_base[kCls + cls];
                 const uint32_t slot = r < sp ? s_base[cls] + r : s_base[2 * kCls + cls] + (r - sp);
                 float *dst = A->out.base;
@@ -681,6 +691,7 @@ __global__ __launch_bounds__(kBlock, MANY ? 5 : 8) void k_bounce(BounceArgs args
             if (lane < kCls) wv[wave * kCls + lane] = 0u;
         }
     }
+    const uint32_t waveLight = waveSum(nLight), waveMiss = waveSum(nMiss);
     if ((threadIdx.x & 63) == 0) {
         Ctrl *const ctrl = launder(kargs)->ctrl;
         const int shard = blockIdx.x % kOct;
@@ -688,6 +699,9 @@ __global__ __launch_bounds__(kBlock, MANY ? 5 : 8) void k_bounce(BounceArgs args
         if (waveMiss) atomicAdd(&ctrl->misses[shard][0], (unsigned long long)waveMiss);
     }
 }
+
+#undef S_GEOMHIT
+#undef S_SPH
 
 // ---- commit one iteration's radiance: image[pix] += contrib[pix]; contrib[pix] = 0 -------------------
 // Runs on the caller's stream, one launch per iteration in iteration order, so every pixel receives its
