@@ -187,11 +187,19 @@ __device__ __forceinline__ uint32_t utilhash(uint32_t a) {
 struct Rng {
     uint32_t x;
 };
-__device__ __forceinline__ uint32_t mod_m31(uint64_t p) {
+// p mod (2^31 - 1) for a 32-bit p: one fold, (p & m) + (p >> 31) <= m + 1, and one conditional subtraction
+__device__ __forceinline__ uint32_t mod_m31(uint32_t p) {
     const uint32_t m = 2147483647u;
-    uint64_t r = (p & m) + (p >> 31);       // p < 2^63  ->  r < 2^32 + 2^31
-    r = (r & m) + (r >> 31);                // r <= m + 2
-    uint32_t q = (uint32_t)r;
+    const uint32_t q = (p & m) + (p >> 31);
+    return q >= m ? q - m : q;
+}
+// 48271 x mod (2^31 - 1) for x < 2^31: the product is below 2^47, so its fold (p & m) + (p >> 31) stays below
+// 2^31 + 2^16 < 2 m: one 32 x 32 -> 64 multiply, 32-bit arithmetic from there (p >> 31 is one v_alignbit_b32)
+__device__ __forceinline__ uint32_t lcgStep(uint32_t x) {
+    const uint32_t m = 2147483647u;
+    const uint64_t p = (uint64_t)x * 48271ull;
+    const uint32_t lo = (uint32_t)p, hi = (uint32_t)(p >> 32);
+    const uint32_t q = (lo & m) + __builtin_amdgcn_alignbit(hi, lo, 31);
     return q >= m ? q - m : q;
 }
 // src/pathtrace.cu:41-45
@@ -218,7 +226,7 @@ __device__ __forceinline__ Rng seedEngine(uint32_t h) {
 // thrust::uniform_real_distribution<float>(0,1) (uniform_real_distribution.inl:71-79):
 // float(x - min) / (1.0f + float(max - min)) = float(x - 1) / 2^31 (both roundings give 2^31).
 __device__ __forceinline__ float u01(Rng &r) {
-    r.x = mod_m31((uint64_t)r.x * 48271ull);
+    r.x = lcgStep(r.x);
     return (float)(r.x - 1u) * 4.656612873077392578125e-10f;  // exact power-of-two scaling
 }
 
@@ -259,14 +267,12 @@ __device__ __forceinline__ void sincosPoly(float x, float &s, float &c) {
 // tests/test_gpu_parity.py::test_unscaled_sqrt_exhaustive compares it with 1.0f / sqrtf(x) on every fp32 bit pattern.
 __device__ __forceinline__ float inverseSqrtNearOne(float x) {
     const int b = (int)__float_as_uint(x) - 0x3f800000;           // ulps above (spacing 2^-23) or below (2^-24) one
-    float r;
-    if ((unsigned)(b + 256) <= 512u) {
-        const int above = 0x3f800000 - (b & ~1);                  // 1 - 2 floor(b/2) 2^-24
-        const int below = 0x3f800000 + ((((1 - b) >> 1) + 1) >> 1);   // 1 + ceil(ceil(k/2)/2) 2^-23, k = -b
-        r = __uint_as_float((uint32_t)(b >= 0 ? above : below));
-    } else {
-        r = 1.0f / __builtin_sqrtf(x);
-    }
+    // the closed form is evaluated for every lane (integer arithmetic, cannot trap); the general form is a one-sided,
+    // practically never taken fix-up -- one divergent region instead of an if / else pair
+    const int above = 0x3f800000 - (b & ~1);                      // 1 - 2 floor(b/2) 2^-24
+    const int below = 0x3f800000 + ((((1 - b) >> 1) + 1) >> 1);   // 1 + ceil(ceil(k/2)/2) 2^-23, k = -b
+    float r = __uint_as_float((uint32_t)(b >= 0 ? above : below));
+    if (!((unsigned)(b + 256) <= 512u)) r = 1.0f / __builtin_sqrtf(x);
     return r;
 }
 
@@ -288,22 +294,26 @@ __device__ __forceinline__ F3 getPointOnRay(F3 origin, F3 direction, float t) {
 // -0 and never tiny; the guard therefore only bounds |o| and |d|.
 typedef float float2v __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ void slabQuotients(float o, float d, float &t1, float &t2) {
+// The guarded sequence, evaluated whatever the operands (none of its instructions can trap); returns whether the guard
+// holds, i.e. whether t1, t2 ARE the quotients.
+__device__ __forceinline__ bool slabQuotientsFast(float o, float d, float &t1, float &t2) {
     const float a1 = -0.5f - o, a2 = +0.5f - o;
     const float ad = __builtin_fabsf(d);
-    const bool fast = __builtin_fabsf(o) <= 0x1p+39f && ad >= 0x1p-40f && ad <= 0x1p+40f;   // NaN fails all three
-    if (fast) {
-        float r = __builtin_amdgcn_rcpf(d);
-        r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
-        const float2v nd = {-d, -d}, rr = {r, r}, a = {a1, a2};
-        float2v q = a * rr;
-        q = __builtin_elementwise_fma(__builtin_elementwise_fma(nd, q, a), rr, q);
-        q = __builtin_elementwise_fma(__builtin_elementwise_fma(nd, q, a), rr, q);
-        t1 = q.x;
-        t2 = q.y;
-    } else {
-        t1 = a1 / d;
-        t2 = a2 / d;
+    const bool fast = (__builtin_fabsf(o) <= 0x1p+39f) & (ad >= 0x1p-40f) & (ad <= 0x1p+40f);   // NaN fails all three
+    float r = __builtin_amdgcn_rcpf(d);
+    r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+    const float2v nd = {-d, -d}, rr = {r, r}, a = {a1, a2};
+    float2v q = a * rr;
+    q = __builtin_elementwise_fma(__builtin_elementwise_fma(nd, q, a), rr, q);
+    q = __builtin_elementwise_fma(__builtin_elementwise_fma(nd, q, a), rr, q);
+    t1 = q.x;
+    t2 = q.y;
+    return fast;
+}
+__device__ __forceinline__ void slabQuotients(float o, float d, float &t1, float &t2) {
+    if (!slabQuotientsFast(o, d, t1, t2)) {
+        t1 = (-0.5f - o) / d;
+        t2 = (+0.5f - o) / d;
     }
 }
 
@@ -339,10 +349,24 @@ __device__ __forceinline__ float boxIntersectionTest(const GD &g, F3 ro, F3 rd, 
     float tmin_nv = 0.0f, tmax_nv = 0.0f;
     const float qoa[3] = {qo.x, qo.y, qo.z};
     const float qda[3] = {qd.x, qd.y, qd.z};
+    // the three axes' quotient pairs by the guarded sequence, and ONE practically never taken region that redoes the
+    // axes whose guard failed with the plain division (instead of an if / else per axis)
+    float t1a[3], t2a[3];
+    const bool ok0 = slabQuotientsFast(qoa[0], qda[0], t1a[0], t2a[0]);
+    const bool ok1 = slabQuotientsFast(qoa[1], qda[1], t1a[1], t2a[1]);
+    const bool ok2 = slabQuotientsFast(qoa[2], qda[2], t1a[2], t2a[2]);
+    if (!(ok0 & ok1 & ok2)) {
+        const bool ok[3] = {ok0, ok1, ok2};
+#pragma unroll
+        for (int xyz = 0; xyz < 3; ++xyz) {
+            const float p1 = (-0.5f - qoa[xyz]) / qda[xyz], p2 = (+0.5f - qoa[xyz]) / qda[xyz];
+            t1a[xyz] = ok[xyz] ? t1a[xyz] : p1;
+            t2a[xyz] = ok[xyz] ? t2a[xyz] : p2;
+        }
+    }
 #pragma unroll
     for (int xyz = 0; xyz < 3; ++xyz) {
-        float t1, t2;
-        slabQuotients(qoa[xyz], qda[xyz], t1, t2);
+        const float t1 = t1a[xyz], t2 = t2a[xyz];
         const float ta = t1 < t2 ? t1 : t2;  // glm::min, func_common.inl:409-414
         const float tb = t1 > t2 ? t1 : t2;  // glm::max, func_common.inl:430-435
         const float nv = t2 < t1 ? +1.0f : -1.0f;
