@@ -20,6 +20,7 @@
 #ifndef PT_AMD_H
 #define PT_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -61,7 +62,8 @@ typedef enum PtStatus {
     PT_ERR_INVALID = -1,      /* bad argument */
     PT_ERR_NOT_INIT = -2,     /* pt_iterate & co. before pt_init */
     PT_ERR_HIP = -3,          /* a HIP runtime call failed (replaces checkCUDAError, pathtrace.cu:21-39) */
-    PT_ERR_DEVICE = -4,       /* a kernel reported an internal fault (scan look-back timeout) */
+    PT_ERR_DEVICE = -4,       /* a kernel reported an internal fault (path pool exhausted, chunk-list or scan look-back
+                                 timeout): sticky, reported by pt_sync / pt_counters (and the next scan call); results void */
     PT_ERR_NO_GPU = -5        /* no HIP device: there is NO CPU fallback */
 } PtStatus;
 
@@ -80,9 +82,9 @@ typedef struct PtOptions {
     int32_t flags;            /* PT_FLAG_* */
     int32_t pipeline_depth;   /* iterations kept in flight on internal streams: 0 = default (3), 1 = none, max 4.
                                  Results do not depend on it: radiance is committed in iteration order. */
-    int32_t max_batch;        /* largest `count` pt_iterate_batch will be given (sizes the path buffers: they grow
-                                 linearly with it -- 704 B per path and slot, i.e. 0.65 GB per iteration of a
-                                 1280x720 frame and slot -- and pixels x max_batch must stay below 2^26);
+    int32_t max_batch;        /* largest `count` pt_iterate_batch will be given (sizes the path pools: two pools of
+                                 44 B x pixels x max_batch per slot plus ~10 % of chunk slack -- 81 MB per iteration of a
+                                 1280x720 frame and slot -- and pixels x max_batch must stay below 2^29);
                                  0 = 1, max PT_MAX_BATCH */
     void   *stream;           /* hipStream_t to enqueue on; NULL = the default stream */
     float  *accum_dev;        /* optional caller-owned device accumulator, W*H*3 floats (or the shard's rows only
@@ -123,12 +125,20 @@ int pt_iterate(int frame, int iter, void *rgba8_dev /* may be NULL (headless) */
  * pt_iterate(frame, iter, pbo) == pt_iterate_batch(frame, iter, 1, pbo). */
 int pt_iterate_batch(int frame, int first_iter, int count, void *rgba8_dev);
 
-/* Wait for the stream; reports device-side faults.  (checkCUDAError's sync, pathtrace.cu:23.) */
+/* Wait for every stream the renderer uses; reports device-side faults (PT_ERR_DEVICE).  (checkCUDAError's sync,
+ * pathtrace.cu:23.)  Without a renderer it reports the scan library's sticky fault word. */
 int pt_sync(void);
 
 /* Copy the un-normalised running sum (W*H*3 floats, index = x + y*W) to host: the D2H copy of
  * src/pathtrace.cu:170-171 into scene->state.image.  Synchronises. */
 int pt_readback(float *rgb_sum_host);
+
+/* Page-lock a caller-owned host buffer (e.g. scene->state.image) so that pt_readback into it runs at PCIe rate instead of
+ * through the runtime's pageable staging copy: the per-iteration D2H copy of the reference protocol (pathtrace.cu:170-171).
+ * The caller keeps the memory alive until pt_unpin_host / pt_free, which release the registration; one buffer at a time.
+ * Purely an optimisation: pt_readback works with any host pointer. */
+int pt_pin_host(void *host, size_t bytes);
+int pt_unpin_host(void);
 
 /* sendImageToPBO into a HOST buffer (W*H*4 bytes). Synchronises. */
 int pt_readback_rgba8(int iter, uint8_t *rgba_host);
@@ -152,7 +162,9 @@ int pt_debug_trace_paths(int iter, int bounces, float *origin3, float *dir3, flo
                          int32_t *pixelIndex, int32_t *count);
 
 /* ---- stream compaction library (the reference's empty stream_compaction/ stub, README.md:83-86):
- * work-efficient exclusive scan / compaction over DEVICE buffers, multi-block, any n >= 0. ---------- */
+ * work-efficient exclusive scan / compaction over DEVICE buffers, multi-block, any n >= 0.  Asynchronous on `stream`;
+ * calls on different streams use separate workspaces and may overlap.  A look-back timeout sets a sticky fault word:
+ * the next call on that stream and pt_sync return PT_ERR_DEVICE. ---------- */
 int pt_scan_exclusive_i32(const int32_t *in_dev, int32_t *out_dev, int64_t n, void *stream);
 /* keeps the non-zero elements in order; *count_dev (device) receives how many were kept */
 int pt_compact_nonzero_i32(const int32_t *in_dev, int32_t *out_dev, int64_t n, int64_t *count_dev,
@@ -180,6 +192,9 @@ int pt_test_slab_quotients_sweep(uint64_t seed, int64_t pairs, uint64_t *mismatc
  * (the re-normalisation of getPointOnRay) next to 1.0f / sqrtf on every bit pattern: mismatches[0] and [2] must be 0,
  * [1] = patterns inside sqrtUnscaled's range, [3] = patterns on inverseSqrtNearOne's short path (513). */
 int pt_test_unscaled_sqrt_sweep(uint64_t mismatches[4]);
+/* sets a device fault word by hand (1: the scan library's, 2: the renderer's; 0 clears them all), so that the reporting
+ * path can be tested */
+int pt_test_force_fault(int which);
 int pt_test_hemisphere(const float *normals3, const int32_t *iter_index_depth3, int n, float *out3);
 int pt_test_sincos(const float *x, int n, float *s, float *c);
 int pt_test_reflect_refract(const float *I3, const float *N3, const float *eta, int n, float *refl3,

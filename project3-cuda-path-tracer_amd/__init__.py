@@ -50,7 +50,7 @@ ABI_SYMBOLS = [
     "pt_scan_exclusive_i32", "pt_compact_nonzero_i32", "pt_test_utilhash", "pt_test_rng",
     "pt_test_intersect", "pt_test_hemisphere", "pt_test_sincos", "pt_test_reflect_refract",
     "pt_test_slab_quotients", "pt_test_slab_quotients_sweep", "pt_test_sphere_cull_sweep",
-    "pt_test_unscaled_sqrt_sweep",
+    "pt_test_unscaled_sqrt_sweep", "pt_pin_host", "pt_unpin_host", "pt_test_force_fault",
 ]
 
 
@@ -114,6 +114,9 @@ def lib():
         L.pt_test_slab_quotients_sweep.argtypes = [C.c_uint64, i64, C.POINTER(C.c_uint64)]
         L.pt_test_sphere_cull_sweep.argtypes = [vp, i32, C.c_uint64, i64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.pt_test_unscaled_sqrt_sweep.argtypes = [C.POINTER(C.c_uint64)]
+        L.pt_pin_host.argtypes = [vp, C.c_size_t]
+        L.pt_unpin_host.argtypes = []
+        L.pt_test_force_fault.argtypes = [i32]
         _lib = L
     return _lib
 
@@ -237,6 +240,11 @@ def pathtraceFree():
 
 def sync():
     _check(lib().pt_sync())
+
+
+def force_fault(which):
+    """Diagnostics: set a device fault word by hand (1 = scan library, 2 = renderer)."""
+    _check(lib().pt_test_force_fault(which))
 
 
 def readback(npixels):

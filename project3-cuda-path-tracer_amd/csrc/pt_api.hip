@@ -724,13 +724,21 @@ int pt_iterate_batch(int frame, int first_iter, int count, void *rgba8_dev) {
     if (count < 1 || count > S.maxBatch) return fail(PT_ERR_INVALID, "pt_iterate_batch: count must be 1..max_batch (%d)", S.maxBatch);
     if (first_iter < 1 || first_iter + count - 1 >= (1 << 22))
         return fail(PT_ERR_INVALID, "pt_iterate: iter must be 1..4194303 (seed bits, pathtrace.cu:43)");
+    // every argument is checked BEFORE anything is enqueued: a rejected call leaves the image and the counters untouched
+    if (rgba8_dev && (S.flags & PT_FLAG_ACCUM_SHARD_ROWS))
+        return fail(PT_ERR_INVALID, "pt_iterate: no PBO conversion from a row-sharded accumulator");
     Slot &sl = S.slot[S.seq % S.nslots];
     // the slot's radiance buffers must have been consumed by the commit of its previous batch
     HIPCHECK(hipStreamWaitEvent(sl.stream, sl.evCommitted, 0));
     const int D = S.prm.traceDepth;
     for (int d = 1; d <= D; ++d) {
         int rc = launch_bounce(sl, first_iter, count, d, d == D, sl.contrib);
-        if (rc) return rc;
+        if (rc) {
+            // a launch failed with part of the batch enqueued: counters, parity and radiance buffers are half-updated, so the
+            // renderer refuses further work until it is re-initialised (pt_free still releases everything)
+            if (d > 1) S.init = false;
+            return rc;
+        }
     }
     sl.parity ^= 1;   // the last launch re-armed the other half of the slot's counters
     HIPCHECK(hipEventRecord(sl.evDone, sl.stream));
@@ -743,7 +751,6 @@ int pt_iterate_batch(int frame, int first_iter, int count, void *rgba8_dev) {
     }
     HIPCHECK(hipEventRecord(sl.evCommitted, S.stream));
     if (rgba8_dev) {
-        if (S.flags & PT_FLAG_ACCUM_SHARD_ROWS) return fail(PT_ERR_INVALID, "pt_iterate: no PBO conversion from a row-sharded accumulator");
         hipLaunchKernelGGL(k_to_rgba8, dim3((S.P + kBlock - 1) / kBlock), dim3(kBlock), 0, S.stream, S.image, S.P,
                            first_iter + count - 1, reinterpret_cast<uchar4 *>(rgba8_dev));
         HIPCHECK(hipGetLastError());
@@ -779,20 +786,65 @@ int pt_readback(float *rgb_sum_host) {
                    rowFloats * sizeof(float));
         return PT_OK;
     }
+    // a plain copy: at PCIe rate into a buffer the caller has page-locked with pt_pin_host, through the runtime's
+    // pageable staging path otherwise.  The library never registers memory it does not own on its own initiative.
     const size_t bytes = (size_t)S.P * 3 * sizeof(float);
-    if (S.pinnedHost != rgb_sum_host || S.pinnedBytes != bytes) {
-        if (S.pinnedHost) (void)hipHostUnregister(S.pinnedHost);
-        S.pinnedHost = nullptr;
-        if (hipHostRegister(rgb_sum_host, bytes, hipHostRegisterDefault) == hipSuccess) {
-            S.pinnedHost = rgb_sum_host;
-            S.pinnedBytes = bytes;
-        } else {
-            (void)hipGetLastError();   // not fatal: fall back to a pageable copy
-        }
-    }
     HIPCHECK(hipMemcpyAsync(rgb_sum_host, S.image, bytes, hipMemcpyDeviceToHost, S.stream));
     HIPCHECK(hipStreamSynchronize(S.stream));
     return PT_OK;
+}
+
+int pt_pin_host(void *host, size_t bytes) {
+    if (!host || bytes == 0) return fail(PT_ERR_INVALID, "pt_pin_host: bad argument");
+    if (count_devices() < 1) return fail(PT_ERR_NO_GPU, "no HIP device");
+    if (S.pinnedHost) {
+        if (S.pinnedHost == host && S.pinnedBytes == bytes) return PT_OK;
+        (void)hipHostUnregister(S.pinnedHost);
+        S.pinnedHost = nullptr;
+    }
+    HIPCHECK(hipHostRegister(host, bytes, hipHostRegisterDefault));
+    S.pinnedHost = host;
+    S.pinnedBytes = bytes;
+    return PT_OK;
+}
+
+int pt_unpin_host(void) {
+    if (S.pinnedHost) {
+        (void)hipStreamSynchronize(S.stream);
+        HIPCHECK(hipHostUnregister(S.pinnedHost));
+        S.pinnedHost = nullptr;
+        S.pinnedBytes = 0;
+    }
+    return PT_OK;
+}
+
+int pt_test_force_fault(int which) {
+    if (count_devices() < 1) return fail(PT_ERR_NO_GPU, "no HIP device");
+    const uint32_t one = 1u;
+    if (which == 1) {            // the scan library's look-back timeout word (default stream's workspace)
+        ScanWs *wp = nullptr;
+        int rc = scan_ws(nullptr, 1, &wp);
+        if (rc) return rc;
+        HIPCHECK(hipMemcpy(&wp->ctrl->error, &one, sizeof one, hipMemcpyHostToDevice));
+        return scan_epilogue(nullptr, *wp);
+    }
+    if (which == 2) {            // the renderer's fault word
+        if (!S.init) return fail(PT_ERR_NOT_INIT, "pt_test_force_fault before pt_init");
+        HIPCHECK(hipMemcpy(&S.slot[0].ctrl->error, &one, sizeof one, hipMemcpyHostToDevice));
+        return PT_OK;
+    }
+    if (which == 0) {            // clear every fault word (what a fresh process / pt_init would start from)
+        HIPCHECK(hipDeviceSynchronize());
+        const uint32_t zero = 0u;
+        for (auto &kv : g_scan)
+            if (kv.second.ctrl) {
+                HIPCHECK(hipMemcpy(&kv.second.ctrl->error, &zero, sizeof zero, hipMemcpyHostToDevice));
+                *kv.second.hostErr = 0;
+            }
+        for (int i = 0; i < S.nslots; ++i) HIPCHECK(hipMemcpy(&S.slot[i].ctrl->error, &zero, sizeof zero, hipMemcpyHostToDevice));
+        return PT_OK;
+    }
+    return fail(PT_ERR_INVALID, "pt_test_force_fault: which must be 0 (clear), 1 or 2");
 }
 
 int pt_readback_rgba8(int iter, uint8_t *rgba_host) {

@@ -24,6 +24,10 @@ void pathtraceInit(Scene *scene) {
                          reinterpret_cast<const PtMaterial *>(scene->materials.data()), (int)scene->materials.size(),
                          scene->state.traceDepth, NULL),
                  "pathtraceInit");
+    // state.image is owned by the Scene and lives from Init to Free: page-lock it for the per-iteration copy below
+    // (an optimisation only; failure to register is not an error of the renderer)
+    if (!scene->state.image.empty())
+        (void)pt_pin_host(scene->state.image.data(), scene->state.image.size() * sizeof(scene->state.image[0]));
 }
 
 void pathtraceFree() {

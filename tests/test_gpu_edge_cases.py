@@ -218,3 +218,137 @@ def test_camera_ray_pixel_rectangles_never_cull_a_hit(gpu, oracle, eye, view, up
     z = oracle.Scene(os.path.join(SCENES, "cornell_glass.txt"))
     sc = _scene(gpu, oracle, z.geoms, z.materials, (150, 90), 6, eye=eye, view=view, up=up, fovy=fovy)
     _compare(gpu, oracle, sc, [1, 2], max_batch=2)
+
+
+# ----------------------------------------------------------------------------- chunked path pools
+def _one_class_scene(gpu, oracle, res, depth):
+    """Nearly every path in ONE class of the queue for several bounces: a narrow camera looks along (1, 1, -1) through a
+    stack of large index-1 "glass" slabs (Schlick r0 = 0, refraction leaves the direction unchanged: every survivor keeps
+    the camera ray's octant), an emitter behind them.  There is no small primitive, so the candidate bit is constant too."""
+    geoms = []
+    for k in range(3):                                   # 3 slabs = 6 refractions, the emitter ends the path at bounce 7
+        geoms.append(oracle.make_geom(1, 1, (4 + 3 * k, 4 + 3 * k, -4 - 3 * k), (0, 0, 0), (40, 40, 0.5)))
+    geoms.append(oracle.make_geom(1, 0, (30, 30, -30), (0, 0, 0), (80, 80, 1)))
+    mats = np.concatenate([_mat(oracle, emit=3.0), _mat(oracle, (.9, .95, .97), refr=1.0, ior=1.0, spec=(.9, .9, .9))])
+    return _scene(gpu, oracle, np.concatenate(geoms), mats, res, depth, eye=(0, 0, 0), view=(1, 1, -1), up=(0, 1, 0), fovy=8.0)
+
+
+def test_every_path_in_one_class_fits_the_pools(gpu, oracle):
+    # 512 x 512 x 4 iterations = 1 M paths = 512 chunks of 2048, and four segments (one class x four counter shards)
+    # receive practically all of them: the chunk lists grow on demand, far beyond an even split over the 64 segments
+    sc = _one_class_scene(gpu, oracle, (512, 512), 8)
+    W = H = 512
+    ref = oracle.Renderer(sc.camera.view(oracle.CAMERA_DTYPE), sc.geoms.view(oracle.GEOM_DTYPE),
+                          sc.materials.view(oracle.MATERIAL_DTYPE), sc.traceDepth)
+    want = np.zeros(W * H * 3, np.float32)
+    live = np.zeros(16, np.int64)
+    for it in range(1, 5):
+        c = ref.iterate(it, want)
+        live += np.array(c.live[:16])
+    gpu.pathtraceFree()
+    gpu.pathtraceInit(sc, max_batch=4, pipeline_depth=2)
+    gpu.pathtrace_batch(None, 0, 1, 4)
+    got = gpu.readback(W * H)
+    cnt = gpu.counters()
+    assert [int(cnt.live[d]) for d in range(1, 9)] == live[1:9].tolist()
+    assert live[5] > 0.9 * live[1]                       # the stack really keeps (nearly) every path alive ...
+    o, d, c, pix = gpu.debug_trace_paths(1, 3, W * H)
+    octant = (d[:, 0] < 0).astype(int) | ((d[:, 1] < 0).astype(int) << 1) | ((d[:, 2] < 0).astype(int) << 2)
+    assert np.bincount(octant, minlength=8).max() > 0.97 * len(d)      # ... and in one octant
+    gpu.pathtraceFree()
+    assert want.max() > 0 and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_undersized_pool_fails_loudly(gpu, oracle, monkeypatch):
+    # PT_AMD_POOL_CHUNKS (tests only) shrinks the pools below what the render needs: the kernels must stay in bounds,
+    # and the fault must surface as PT_ERR_DEVICE -- at pt_sync, at pt_counters, and stay sticky until the next pt_init
+    sc = _one_class_scene(gpu, oracle, (256, 256), 6)
+    monkeypatch.setenv("PT_AMD_POOL_CHUNKS", "70")        # 64 static chunks + 5: 256 x 256 paths need 32 more
+    gpu.pathtraceFree()
+    gpu.pathtraceInit(sc, pipeline_depth=1)
+    gpu.pathtrace(None, 0, 1, readback=False)
+    with pytest.raises(gpu.PtError, match="path pool exhausted"):
+        gpu.sync()
+    with pytest.raises(gpu.PtError, match="device fault"):
+        gpu.counters()
+    gpu.pathtrace(None, 0, 2, readback=False)             # still memory-safe, still flagged
+    with pytest.raises(gpu.PtError, match="device fault"):
+        gpu.sync()
+    monkeypatch.delenv("PT_AMD_POOL_CHUNKS")
+    _compare(gpu, oracle, sc, [1, 2])                     # a fresh pt_init with real pools renders correctly again
+
+
+def test_forced_fault_words_are_reported(gpu):
+    import torch
+    # renderer: a fault word set by hand is reported by pt_sync and pt_counters and survives a counter reset
+    sc = gpu.Scene(os.path.join(SCENES, "cornell.txt"))
+    sc.set_resolution(32, 32)
+    gpu.pathtraceFree()
+    gpu.pathtraceInit(sc)
+    gpu.sync()
+    gpu.force_fault(2)
+    with pytest.raises(gpu.PtError, match="device fault"):
+        gpu.sync()
+    gpu.counters_reset()
+    with pytest.raises(gpu.PtError, match="device fault"):
+        gpu.sync()
+    gpu.pathtraceFree()
+    # scan library: its look-back timeout word is sticky too -- the next call on the stream and pt_sync refuse
+    x = torch.ones(5000, dtype=torch.int32, device="cuda")
+    y = torch.empty_like(x)
+    gpu.scan_exclusive_dev(x.data_ptr(), y.data_ptr(), x.numel())
+    torch.cuda.synchronize()
+    assert int(y[-1]) == 4999
+    gpu.force_fault(1)
+    torch.cuda.synchronize()
+    with pytest.raises(gpu.PtError, match="look-back timeout"):
+        gpu.scan_exclusive_dev(x.data_ptr(), y.data_ptr(), x.numel())
+    with pytest.raises(gpu.PtError, match="look-back timeout"):
+        gpu.sync()
+    gpu.force_fault(0)                                    # (diagnostics: clear, so that the rest of the suite starts clean)
+    gpu.scan_exclusive_dev(x.data_ptr(), y.data_ptr(), x.numel())
+    gpu.sync()
+    assert int(y[-1]) == 4999
+
+
+def test_rejected_call_leaves_the_image_untouched(gpu, oracle):
+    # a PBO conversion cannot be served from a row-sharded accumulator: the call must be refused BEFORE anything is
+    # enqueued, so that a retry does not add the samples twice
+    import torch
+    sc = gpu.Scene(os.path.join(SCENES, "cornell.txt"))
+    sc.set_resolution(64, 48)
+    pbo = torch.zeros(64 * 48, dtype=torch.int32, device="cuda")
+    gpu.pathtraceFree()
+    gpu.pathtraceInit(sc, shard_rank=0, shard_count=2, flags=gpu.PT_FLAG_ACCUM_SHARD_ROWS)
+    with pytest.raises(gpu.PtError, match="row-sharded"):
+        gpu.pathtrace(pbo.data_ptr(), 0, 1, readback=False)
+    assert gpu.counters().iterations == 0 and not gpu.readback(64 * 48).any()
+    gpu.pathtrace(None, 0, 1, readback=False)
+    got = gpu.readback(64 * 48)
+    gpu.pathtraceFree()
+    ref = oracle.Renderer(sc.camera.view(oracle.CAMERA_DTYPE), sc.geoms.view(oracle.GEOM_DTYPE),
+                          sc.materials.view(oracle.MATERIAL_DTYPE), sc.traceDepth)
+    want = np.zeros(64 * 48 * 3, np.float32)
+    ref.iterate(1, want, 0, 2)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_large_frame_batches_of_eight(gpu):
+    # chunked pools: a 4096 x 4096 frame traces batches of 8 iterations on one GPU (134 M paths per launch: 12 GB of
+    # path state per slot, where the worst-case-per-class provisioning of round 1 allowed batches of 1-2)
+    sc = gpu.Scene(os.path.join(SCENES, "spheres64.txt"))
+    sc.set_resolution(4096, 4096)
+    P = 4096 * 4096
+    gpu.pathtraceFree()
+    gpu.pathtraceInit(sc, pipeline_depth=1, max_batch=8)
+    gpu.pathtrace_batch(None, 0, 1, 8)
+    a = gpu.readback(P)
+    c = gpu.counters()
+    assert int(c.live[1]) == 8 * P and c.light_hits > 0
+    gpu.pathtraceFree()
+    gpu.pathtraceInit(sc, pipeline_depth=1, max_batch=2)
+    for it in (1, 3, 5, 7):
+        gpu.pathtrace_batch(None, 0, it, 2)
+    b = gpu.readback(P)
+    gpu.pathtraceFree()
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and a.max() > 0
