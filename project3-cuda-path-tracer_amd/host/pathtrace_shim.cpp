@@ -5,7 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 
-#include "../../include/pt_amd.h"
+#include "pt_amd.h"
 
 static Scene *hst_scene = NULL;
 

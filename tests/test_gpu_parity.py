@@ -370,26 +370,79 @@ def test_api_protocol_and_errors(gpu):
     gpu.pathtraceFree()
 
 
-def test_statistics_against_reference_png(gpu):
-    # The reference's only end-to-end golden: img/REFERENCE_cornell.5000samp.png (staff solution).
-    # 200x200, 64 spp -> 8-bit means within 3 % of the PNG's, flat regions within 6 %.
-    z = np.load(os.path.join(GOLD, "reference_png_stats.npz"))
-    sc = gpu.Scene(os.path.join(SCENES, "cornell.txt"))
-    sc.set_resolution(200, 200)
+def _full_spec_blocks(gpu, name):
+    """The reference's shipped configuration (scene file as is: 800x800, 5000 iterations, depth 8 -- scenes/cornell.txt:53-56,
+    scenes/sphere.txt:13-16) on the HIP path -> 8-bit PNG values (saveImage + image.cpp: /samples, X mirror, clamp, x255,
+    truncate) -> 50x50 means of 16x16-pixel blocks, the form tests/golden/reference_png_stats.npz holds the staff renders in."""
+    sc = gpu.Scene(os.path.join(SCENES, name + ".txt"))
+    W, H = (int(v) for v in sc.camera["resolution"][0])
+    assert (W, H, sc.iterations, sc.traceDepth) == (800, 800, 5000, 8)
     gpu.pathtraceFree()
-    gpu.pathtraceInit(sc)
-    n = 64
-    for it in range(1, n + 1):
-        gpu.pathtrace(None, 0, it, readback=False)
-    img = gpu.readback(200 * 200).reshape(200, 200, 3) / np.float32(n)
+    gpu.pathtraceInit(sc, max_batch=64, pipeline_depth=2)
+    it = 1
+    while it <= sc.iterations:
+        k = min(64, sc.iterations - it + 1)
+        gpu.pathtrace_batch(None, 0, it, k)
+        it += k
+    img = gpu.readback(W * H).reshape(H, W, 3) / np.float32(sc.iterations)
     gpu.pathtraceFree()
     png = (np.clip(img, 0, 1) * np.float32(255)).astype(np.uint8)[:, ::-1].astype(np.float64)
+    return png, png.reshape(50, 16, 50, 16, 3).mean(axis=(1, 3))
+
+
+def test_full_spec_cornell_against_the_reference_png(gpu):
+    # The reference's only end-to-end golden: img/REFERENCE_cornell.5000samp.png (staff solution; the reference has no
+    # ray generation / scatterRay / accumulation to compare with, src/pathtrace.cu:160, src/interactions.h:77).  At
+    # 5000 spp the Monte-Carlo noise of a 256-pixel block mean is ~0.1 % -- below the PNG's own quantisation -- so what
+    # remains is the systematic difference between two implementations of the README's prose.  Measured (printed below,
+    # profiles/png_stats_probe.py): global means -0.1 / -0.2 / -0.3 %, the 921 smooth lit blocks 0.8 % on average,
+    # 1.9 % at the 95th percentile, 3.6 % at most; the bounds are twice that.
+    z = np.load(os.path.join(GOLD, "reference_png_stats.npz"))
+    png, blocks = _full_spec_blocks(gpu, "cornell")
+    ref = z["cornell"].astype(np.float64)
     mean = png.reshape(-1, 3).mean(axis=0)
-    assert np.all(np.abs(mean / z["cornell_mean"] - 1) < 0.03), (mean, z["cornell_mean"])
-    blocks = png.reshape(50, 4, 50, 4, 3).mean(axis=(1, 3))
+    print("global 8-bit mean", mean, "reference", z["cornell_mean"], "ratio", mean / z["cornell_mean"])
+    assert np.all(np.abs(mean / z["cornell_mean"] - 1) < 0.01), (mean, z["cornell_mean"])
+    # ALL 2500 block means: smooth lit blocks (the reference varies by < 20 % over the 3x3 neighbourhood) must agree
+    # closely; the others are silhouettes, where a sub-pixel difference of the edge position moves a block mean a lot
+    lum = ref.sum(-1)
+    pad = np.pad(ref, ((1, 1), (1, 1), (0, 0)), mode="edge")
+    nb = np.stack([pad[i:i + 50, j:j + 50] for i in range(3) for j in range(3)])
+    smooth = ((nb.max(0) - nb.min(0)).sum(-1) < 0.2 * np.maximum(lum, 1)) & (lum > 24)
+    rel = np.abs(blocks - ref).sum(-1) / np.maximum(lum, 1)
+    print("smooth lit blocks %d: mean %.4f p95 %.4f max %.4f; all lit blocks p95 %.4f" % (
+        smooth.sum(), rel[smooth].mean(), np.percentile(rel[smooth], 95), rel[smooth].max(), np.percentile(rel[lum > 24], 95)))
+    assert smooth.sum() > 800
+    assert rel[smooth].mean() < 0.016 and np.percentile(rel[smooth], 95) < 0.04 and rel[smooth].max() < 0.075
+    assert np.percentile(rel[lum > 24], 95) < 0.09                      # silhouette blocks included
+    dark = lum == 0
+    assert dark.sum() > 150 and not blocks[dark].any()                   # outside the box both are exactly black
     regions = {"back wall": (slice(20, 30), slice(20, 30)), "left wall": (slice(20, 30), slice(3, 8)),
                "right wall": (slice(20, 30), slice(42, 47)), "floor": (slice(42, 47), slice(20, 30)),
-               "ceiling": (slice(3, 6), slice(8, 15))}
+               "ceiling": (slice(3, 6), slice(8, 15)), "sphere": (slice(26, 32), slice(17, 23))}
     for name, (ys, xs) in regions.items():
-        ratio = blocks[ys, xs].mean() / z["cornell"][ys, xs].mean()
-        assert abs(ratio - 1) < 0.06, (name, ratio)
+        ratio = blocks[ys, xs].mean(axis=(0, 1)) / ref[ys, xs].mean(axis=(0, 1))
+        print("region %-10s ratio to the reference (r, g, b) %s" % (name, np.round(ratio, 3)))
+        # the sphere region is where the build-defined 50/50 mirror/diffuse mixture (SURVEY 3.4 S6) shows: within 3 % of
+        # the staff render in every channel (a pure mirror is 10-20 % darker there, SURVEY 4.3)
+        assert np.all(np.abs(ratio - 1) < 0.04), (name, ratio)
+
+
+def test_full_spec_sphere_against_the_reference_png(gpu):
+    # img/REFERENCE_sphere.5000samp.png: an emissive sphere (emittance 5 -> clamped to 255) on black.  Every path ends
+    # at its first bounce, so this pins camera rays + the sphere test + emission end to end.  The staff render's disc is
+    # ~3.5 pixels wider per side (SURVEY 4.3: an extra anti-aliasing blur): the interior and the centre must agree
+    # exactly, the footprint must lie inside the reference's, the total differs by that rim only.
+    z = np.load(os.path.join(GOLD, "reference_png_stats.npz"))
+    png, blocks = _full_spec_blocks(gpu, "sphere")
+    ref = z["sphere"].astype(np.float64)
+    assert np.array_equal(blocks[..., 0], blocks[..., 1]) and np.array_equal(blocks[..., 0], blocks[..., 2])
+    b, r = blocks[..., 0], ref[..., 0]
+    inside = r == 255
+    assert inside.sum() >= 30 and np.array_equal(b[inside], r[inside])                    # the same fully lit blocks
+    assert not b[r == 0].any()                                                            # nothing where the reference is black
+    cy, cx = (np.indices(b.shape) * b).sum(axis=(1, 2)) / b.sum()
+    ry, rx = (np.indices(r.shape) * r).sum(axis=(1, 2)) / r.sum()
+    print("centre of mass (block units) ours (%.3f, %.3f) reference (%.3f, %.3f); mass ratio %.4f" % (cy, cx, ry, rx, b.sum() / r.sum()))
+    assert abs(cy - ry) < 0.05 and abs(cx - rx) < 0.05
+    assert 0.88 < b.sum() / r.sum() < 0.93                                                # the rim of the wider staff disc
