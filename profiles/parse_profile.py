@@ -30,6 +30,18 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 
 
+def inst(name):
+    """instantiation of the bounce kernel: k_bounce<FIRST, MANY>"""
+    for tag in ("k_bounce<true, true>", "k_bounce<true, false>", "k_bounce<false, true>", "k_bounce<false, false>"):
+        if tag in name:
+            return tag
+    for mangled, tag in (("k_bounceILb1ELb1E", "k_bounce<true, true>"), ("k_bounceILb1ELb0E", "k_bounce<true, false>"),
+                         ("k_bounceILb0ELb1E", "k_bounce<false, true>"), ("k_bounceILb0ELb0E", "k_bounce<false, false>")):
+        if mangled in name:
+            return tag
+    return None
+
+
 def kind(name):
     if "k_bounce" in name:
         return "k_bounce"
@@ -52,6 +64,7 @@ def main():
     ap.add_argument("tag")
     ap.add_argument("--pixels", type=int, default=1280 * 720)
     ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--set-default", action="store_true", help="also write profiles/pmc_traffic.json (what bench.py reads): the headline configuration only")
     args = ap.parse_args()
     src = os.path.join(ROOT, "gpurun_out", "prof_" + args.tag)
     out = {}
@@ -68,6 +81,8 @@ def main():
             if k != "other":     # both k_bounce<true> and k_bounce<false> count as k_bounce
                 tot[k][0] += float(r["TotalDurationNs"])
                 tot[k][1] += int(r["Calls"])
+            if inst(r["Name"]):
+                out.setdefault("instantiations", {})[inst(r["Name"])] = {"trace_avg_ns": float(r["AverageNs"]), "trace_calls": int(r["Calls"])}
         for k, (ns, calls) in tot.items():
             out.setdefault(k, {})["trace_avg_ns"] = ns / max(calls, 1)
             out[k]["trace_calls"] = calls
@@ -81,6 +96,15 @@ def main():
             k = kind(r["Kernel_Name"])
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
             n[(k, r["Counter_Name"])] += 1
+            if inst(r["Kernel_Name"]):
+                ii = out.setdefault("instantiations", {}).setdefault(inst(r["Kernel_Name"]), {})
+                acc = ii.setdefault("_pmc_sum", {})
+                acc[r["Counter_Name"]] = acc.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+                cnt = ii.setdefault("_pmc_n", {})
+                cnt[r["Counter_Name"]] = cnt.get(r["Counter_Name"], 0) + 1
+                for col in ("VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size"):
+                    if col in r:
+                        ii[col] = r[col]
             per_dispatch[(p, int(r["Dispatch_Id"]))][r["Counter_Name"]] = float(r["Counter_Value"])
             per_dispatch[(p, int(r["Dispatch_Id"]))]["_kind"] = k
         for k in agg:
@@ -140,12 +164,28 @@ def main():
                 pj["valu_wave_insts_per_launch_iteration"] = kb["SQ_INSTS_VALU"] / ipl
                 pj["salu_insts_per_launch_iteration"] = kb.get("SQ_INSTS_SALU", 0.0) / ipl
                 pj["lds_bank_conflict_cycles_per_launch"] = kb.get("SQ_LDS_BANK_CONFLICT")
-        json.dump(pj, open(os.path.join(HERE, "pmc_traffic.json"), "w"), indent=1)
+        if args.set_default:
+            json.dump(pj, open(os.path.join(HERE, "pmc_traffic.json"), "w"), indent=1)
+        out["k_bounce"]["traffic"] = pj
     if "SQ_LDS_BANK_CONFLICT" in kb:
         out["k_bounce"]["lds_bank_conflict_cycles_per_launch"] = kb["SQ_LDS_BANK_CONFLICT"]
         out["k_bounce"]["lds_bank_conflict_fraction"] = kb["SQ_LDS_BANK_CONFLICT"] / max(kb.get("SQ_LDS_IDX_ACTIVE", 1.0), 1.0)
     if "SQ_WAVE_CYCLES" in kb:
         out["k_bounce"]["wave_wait_fraction"] = kb["SQ_WAIT_ANY"] / kb["SQ_WAVE_CYCLES"]
+    for ii in out.get("instantiations", {}).values():
+        sums, cnts = ii.pop("_pmc_sum", {}), ii.pop("_pmc_n", {})
+        if sums:
+            ii["pmc_per_dispatch"] = {c: v / cnts[c] for c, v in sums.items()}
+            pd = ii["pmc_per_dispatch"]
+            if "SQ_WAVE_CYCLES" in pd and "SQ_WAIT_ANY" in pd:
+                ii["wave_wait_fraction"] = pd["SQ_WAIT_ANY"] / pd["SQ_WAVE_CYCLES"]
+    # the bench line of the profiled command (trace pass), for the record
+    try:
+        for line in open(os.path.join(src, "trace.log")):
+            if line.startswith("{"):
+                out["bench_line_of_the_trace_pass"] = json.loads(line)
+    except (OSError, ValueError):
+        pass
     json.dump(out, open(os.path.join(HERE, args.tag + "_pmc_summary.json"), "w"), indent=1, sort_keys=True)
     print(json.dumps(out, indent=1, sort_keys=True))
 

@@ -1,13 +1,25 @@
-import csv, glob, sys
-f = glob.glob(sys.argv[1]+'/*/*kernel_trace.csv')[0]
+"""One batch (its 8 bounce launches + commit) from the middle of a rocprofv3 kernel trace: per-launch durations, gaps,
+grids and register counts.   python profiles/trace_summary.py <dir containing */*kernel_trace.csv>"""
+import csv, glob, re, sys
+f = glob.glob(sys.argv[1] + '/*/*kernel_trace.csv')[0]
 rows = list(csv.DictReader(open(f)))
-rows.sort(key=lambda r:int(r['Start_Timestamp']))
-idx = [i for i,r in enumerate(rows) if 'generate' in r['Kernel_Name'] or 'k_bounce<true' in r['Kernel_Name']]
-i0 = idx[len(idx)//2]
-prev_end=None
-n = (idx[len(idx)//2+1]-i0+1) if len(idx) > len(idx)//2+1 else 10
-for r in rows[i0:i0+n]:
-    st,en=int(r['Start_Timestamp']),int(r['End_Timestamp'])
-    print('%-34s dur %7d ns  gap %s  grid %s vgpr %s sgpr %s lds %s' % (r['Kernel_Name'].split('::')[-1].split('(')[0][:34], en-st, (st-prev_end) if prev_end else '-', r['Grid_Size_X'], r['VGPR_Count'], r['SGPR_Count'], r['LDS_Block_Size']))
-    prev_end=en
-print('iteration span ns:', int(rows[i0+n-1]['Start_Timestamp'])-int(rows[i0]['Start_Timestamp']))
+rows.sort(key=lambda r: int(r['Start_Timestamp']))
+
+
+def short(name):
+    m = re.search(r'(k_\w+(<[^>]*>)?)', name)
+    return m.group(1) if m else name[:40]
+
+
+idx = [i for i, r in enumerate(rows) if 'k_bounce<true' in r['Kernel_Name']]
+i0 = idx[len(idx) // 2]
+n = (idx[len(idx) // 2 + 1] - i0) if len(idx) > len(idx) // 2 + 1 else 10
+prev_end = None
+for r in rows[i0:i0 + n]:
+    st, en = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+    print('%-26s dur %8d ns  gap %6s  grid %7s wg %4s vgpr %3s sgpr %3s lds %6s scratch %s' % (
+        short(r['Kernel_Name']), en - st, (st - prev_end) if prev_end else '-', r.get('Grid_Size_X', r.get('Grid_Size')),
+        r.get('Workgroup_Size_X', r.get('Workgroup_Size')), r.get('VGPR_Count'), r.get('SGPR_Count'), r.get('LDS_Block_Size'),
+        r.get('Scratch_Size', r.get('Private_Segment_Size'))))
+    prev_end = en
+print('batch span ns (first launch start -> next batch\'s first launch start):', int(rows[i0 + n]['Start_Timestamp']) - int(rows[i0]['Start_Timestamp']) if i0 + n < len(rows) else 'n/a')

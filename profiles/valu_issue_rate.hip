@@ -39,7 +39,7 @@ struct Stamp {
 };
 
 enum Op { FMA, MUL, ADD, CNDMASK, PKFMA, RCP, SQRT, RSQ, MIX_SALU, MIX_KERNEL, DEP_FMA, CNDMASK_S, CMP_CND, CMP_SGPR, MAD64, MULLO, MULHI,
-          DIVSCALE, DIVFMAS, DIVFIXUP, LSHLADD64, CVT, READLANE, SAVEEXEC, BRANCH_NT, DSREAD, BPERMUTE, PKMUL, NOP_MIX, BRANCH_SCC_NT, BRANCH_TAKEN, BRANCH_NT_SPARSE, EXEC0_FMA, MOV, ADDU32, CMP_VCC, CND_FMA, NUM_OPS };
+          DIVSCALE, DIVFMAS, DIVFIXUP, LSHLADD64, CVT, READLANE, SAVEEXEC, BRANCH_NT, DSREAD, BPERMUTE, PKMUL, NOP_MIX, BRANCH_SCC_NT, BRANCH_TAKEN, BRANCH_NT_SPARSE, EXEC0_FMA, MOV, ADDU32, CMP_VCC, CND_FMA, MUL_S, FMA_S, ADD_S, MOV_S, ADD_LIT, ADD_INL, MULADD_S, NUM_OPS };
 static const char *kOpName[NUM_OPS] = {"v_fma_f32", "v_mul_f32", "v_add_f32", "v_cndmask_b32", "v_pk_fma_f32", "v_rcp_f32", "v_sqrt_f32",
                                        "v_rsq_f32", "v_fma_f32 + s_add_u32 (2:1)", "mix fma/mul/add/cndmask/cmp + salu + 1/16 rcp",
                                        "v_fma_f32 dependent chain", "v_cndmask_b32 (sgpr-pair mask)", "v_cmp_lt_f32 vcc + v_cndmask_b32 vcc (pairs)",
@@ -51,9 +51,12 @@ static const char *kOpName[NUM_OPS] = {"v_fma_f32", "v_mul_f32", "v_add_f32", "v
                                        "7 v_fma_f32 + s_cbranch_execnz taken, to the next instruction (per group; cycles per v_fma)",
                                        "31 v_fma_f32 + s_cbranch_execz not taken (per 4 groups; cycles per v_fma)",
                                        "v_fma_f32 with EXEC = 0 (6 of 8; s_mov exec around them; cycles per v_fma)", "v_mov_b32", "v_add_u32",
-                                       "v_cmp_lt_f32 -> vcc", "v_cndmask_b32 vcc + v_fma_f32 alternating"};
+                                       "v_cmp_lt_f32 -> vcc", "v_cndmask_b32 vcc + v_fma_f32 alternating",
+                                       "v_mul_f32 v, s, v (SGPR operand)", "v_fma_f32 v, s, v, v (SGPR operand)", "v_add_f32 v, s, v (SGPR operand)",
+                                       "v_mov_b32 v, s", "v_add_f32 v, literal, v", "v_add_f32 v, 0.5, v (inline constant)",
+                                       "v_mul_f32 v, s, v + v_add_f32 v, v, v alternating"};
 // vector instructions per unrolled block (what the cycles are divided by)
-static const int kVecPerBlock[NUM_OPS] = {64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 48, 56, 64, 64, 64, 64, 56, 56, 62, 64, 64, 64, 64, 64};
+static const int kVecPerBlock[NUM_OPS] = {64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 48, 56, 64, 64, 64, 64, 56, 56, 62, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64};
 
 #define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 
@@ -70,6 +73,8 @@ __global__ __launch_bounds__(1024) void k_rate(int iters, Stamp *out, float *sin
     }
     float2v px = {x, x}, py = {y, y};
     unsigned s0 = blockIdx.x, s1 = 1;
+    int sx = __builtin_amdgcn_readfirstlane(__float_as_int(x));   // a wave-uniform float in an SGPR
+    asm volatile("" : "+s"(sx));
     unsigned long long smask = 0x5555555555555555ull | blockIdx.x, smask2 = 0;
     unsigned long long q[8];
     unsigned ix = threadIdx.x * 2654435761u + 12345u, iy = blockIdx.x * 40503u + 7u;
@@ -266,6 +271,34 @@ __global__ __launch_bounds__(1024) void k_rate(int iters, Stamp *out, float *sin
 #define X(i) asm volatile("v_cndmask_b32 %0, %0, %2, vcc\n\tv_fma_f32 %1, %2, %3, %1" : "+v"(a[i]), "+v"(a[i + 4]) : "v"(y), "v"(x));
                 X(0) X(1) X(2) X(3)
 #undef X
+            } else if (OP == MUL_S) {
+#define X(i) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(a[i]) : "s"(sx));
+                REP8(X)
+#undef X
+            } else if (OP == FMA_S) {
+#define X(i) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "s"(sx), "v"(y));
+                REP8(X)
+#undef X
+            } else if (OP == ADD_S) {
+#define X(i) asm volatile("v_add_f32 %0, %1, %0" : "+v"(a[i]) : "s"(sx));
+                REP8(X)
+#undef X
+            } else if (OP == MOV_S) {
+#define X(i) asm volatile("v_mov_b32 %0, %1" : "=v"(a[i]) : "s"(sx));
+                REP8(X)
+#undef X
+            } else if (OP == ADD_LIT) {
+#define X(i) asm volatile("v_add_f32 %0, 0x3f8ccccd, %0" : "+v"(a[i]));
+                REP8(X)
+#undef X
+            } else if (OP == ADD_INL) {
+#define X(i) asm volatile("v_add_f32 %0, 0.5, %0" : "+v"(a[i]));
+                REP8(X)
+#undef X
+            } else if (OP == MULADD_S) {
+#define X(i) asm volatile("v_mul_f32 %0, %2, %0\n\tv_add_f32 %1, %3, %1" : "+v"(a[i]), "+v"(a[i + 4]) : "s"(sx), "v"(y));
+                X(0) X(1) X(2) X(3)
+#undef X
             } else if (OP == DEP_FMA) {
 #define X(i) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[0]) : "v"(x), "v"(y));
                 REP8(X)
@@ -302,7 +335,8 @@ static LaunchFn kLaunch[NUM_OPS] = {launch<FMA>, launch<MUL>, launch<ADD>, launc
                                     launch<CMP_SGPR>, launch<MAD64>, launch<MULLO>, launch<MULHI>, launch<DIVSCALE>, launch<DIVFMAS>,
                                     launch<DIVFIXUP>, launch<LSHLADD64>, launch<CVT>, launch<READLANE>, launch<SAVEEXEC>, launch<BRANCH_NT>,
                                     launch<DSREAD>, launch<BPERMUTE>, launch<PKMUL>, launch<NOP_MIX>, launch<BRANCH_SCC_NT>,
-                                    launch<BRANCH_TAKEN>, launch<BRANCH_NT_SPARSE>, launch<EXEC0_FMA>, launch<MOV>, launch<ADDU32>, launch<CMP_VCC>, launch<CND_FMA>};
+                                    launch<BRANCH_TAKEN>, launch<BRANCH_NT_SPARSE>, launch<EXEC0_FMA>, launch<MOV>, launch<ADDU32>, launch<CMP_VCC>, launch<CND_FMA>, launch<MUL_S>,
+                                    launch<FMA_S>, launch<ADD_S>, launch<MOV_S>, launch<ADD_LIT>, launch<ADD_INL>, launch<MULADD_S>};
 
 int main() {
     hipDeviceProp_t prop;
