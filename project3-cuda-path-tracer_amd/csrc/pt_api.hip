@@ -140,7 +140,7 @@ void pack_geom(const PtGeom &g, GeomDev &d, const float *eye = nullptr) {
         }
     for (int r = 0; r < 3; ++r) d.invZ[r] = d.inv[9 + r] * 0.0f;
     d.type = g.type;
-    d.flags = g.type == PT_CUBE ? 1 : 0;    // bit 1 (binned) is set by pt_init
+    d.flags = d.cullFlags = g.type == PT_CUBE ? 1 : 0;    // bit 1 (binned) is set by pt_init
     d.material = g.materialid;
     // bounding-ball culling data (ptd::certainMiss): bounds smax >= sigma_max, smin <= sigma_min of the 3x3 part
     double A[3][3], Ai[3][3];
@@ -660,6 +660,7 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
             k.binGeom[k.nBinned++] = cand[c].second;
             hg[cand[c].second].binned = 1;
             hg[cand[c].second].flags |= 2;
+            hg[cand[c].second].cullFlags |= 2;
         }
     }
     k.emittersBinned = k.nBinned > 0 ? 1 : 0;

@@ -120,7 +120,8 @@ struct GeomDev {
     float centre[3];
     float cullR2, cullK;
     float boundR;    // radius of the bounding ball, rho smax (host bookkeeping: which primitives are small)
-    int   type;      // 0 sphere, 1 cube (src/sceneStructs.h:8-11)
+    int   cullFlags; // = flags: the loop over the primitives reads THIS group first (type and binned bit, and for a sphere
+                     // everything the bounding-ball test needs: one scalar load per sphere), the test group only for a cube
     int   material;
     // ---- 0x80: a hit
     float xf[12];    // transform
@@ -133,7 +134,7 @@ struct GeomDev {
     // 1: a small primitive the queue is binned by (KParams::binGeom): tiles of paths that certainly miss all of them
     // skip it (mirrored in flags)
     int   binned;
-    int   pad1;
+    int   type;      // 0 sphere, 1 cube (src/sceneStructs.h:8-11)
 };
 static_assert(sizeof(GeomDev) == 448, "GeomDev is 28 x 16 B");
 static_assert(offsetof(GeomDev, camObj) == 64 && offsetof(GeomDev, centre) == 96 && offsetof(GeomDev, xf) == 128, "scalar-load groups");

@@ -256,6 +256,33 @@ struct BounceArgs {
 };
 typedef const PT_CAS BounceArgs *ArgsPtr;
 typedef const PT_CAS GeomDev *GeomPtr;
+// the culling group of a GeomDev (offset 0x60), as one 32-byte scalar load
+struct CullGroup {
+    float centre[3];
+    float cullR2, cullK, boundR;
+    int   cullFlags, material;
+};
+// ONE scalar load (inline asm: the compiler would split the group again, fetch the flags word first and the rest behind
+// the branch on it -- two serialised scalar-memory round trips per sphere)
+typedef int int8v __attribute__((ext_vector_type(8)));
+template <bool ONE_LOAD>
+__device__ __forceinline__ CullGroup loadCull(const PT_CAS GeomDev *g) {
+    CullGroup c;
+    if (!ONE_LOAD) {   // small scenes: field by field, the compiler places the loads (no 8-aligned SGPR tuple to find)
+        c.centre[0] = g->centre[0]; c.centre[1] = g->centre[1]; c.centre[2] = g->centre[2];
+        c.cullR2 = g->cullR2; c.cullK = g->cullK; c.boundR = g->boundR;
+        c.cullFlags = g->cullFlags; c.material = g->material;
+        return c;
+    }
+    int8v v;
+    asm volatile("s_load_dwordx8 %0, %1, 0x60\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(g) : "memory");
+    c.centre[0] = __int_as_float(v[0]); c.centre[1] = __int_as_float(v[1]); c.centre[2] = __int_as_float(v[2]);
+    c.cullR2 = __int_as_float(v[3]); c.cullK = __int_as_float(v[4]); c.boundR = __int_as_float(v[5]);
+    c.cullFlags = v[6]; c.material = v[7];
+    return c;
+}
+static_assert(offsetof(GeomDev, centre) == 0x60, "loadCull's offset");
+static_assert(sizeof(CullGroup) == 32 && offsetof(GeomDev, cullFlags) - offsetof(GeomDev, centre) == offsetof(CullGroup, cullFlags), "CullGroup mirrors GeomDev");
 
 template <bool FIRST, bool MANY>
 __global__ __launch_bounds__(kBlock, MANY ? 5 : 8) void k_bounce(BounceArgs argsByValue) {
@@ -495,8 +522,11 @@ __global__ __launch_bounds__(kBlock, MANY ? 5 : 8) void k_bounce(BounceArgs args
                 const int ngeoms = A->prm.ngeoms;
                 const GeomPtr geoms = (GeomPtr)(A->ggeoms);
                 for (int g = 0; g < ngeoms; ++g) {
-                    const PT_CAS GeomDev &G = *(launder(geoms) + g);
-                    const int flags = G.flags;
+                    // (sphere-heavy scenes: no laundering per primitive -- with 70 of them the compiler's own scheduling of
+                    // the scalar loads across iterations is worth more than the registers it costs; measured on C5)
+                    const PT_CAS GeomDev &G = *((MANY ? geoms : launder(geoms)) + g);
+                    const CullGroup cg = loadCull<MANY>(&G);
+                    const int flags = cg.cullFlags;
                     F3 p, n;
                     bool o = false;
                     float t = -1.0f;
@@ -504,7 +534,7 @@ __global__ __launch_bounds__(kBlock, MANY ? 5 : 8) void k_bounce(BounceArgs args
                     if (!FIRST && !smallTile && (flags & 2)) continue;  // this tile's paths certainly miss every binned primitive
                     if ((flags & 1) == 0) {
                         probe(3);
-                        if (!certainMiss(G, org, dir, dd)) {
+                        if (!certainMiss(cg, org, dir, dd)) {
                             if (MANY && nCand < kListMax) {
                                 s_list[nCand * kBlock + tid] = (uint16_t)g;
                                 ++nCand;
