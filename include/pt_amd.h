@@ -69,10 +69,14 @@ typedef enum PtStatus {
 
 enum {
     PT_FLAG_KERNEL_TIMING = 1,   /* bracket every bounce-kernel launch with HIP events (roofline measurement) */
-    PT_FLAG_ACCUM_SHARD_ROWS = 2 /* the accumulator holds ONLY this shard's rows, packed (local row lr = global row
+    PT_FLAG_ACCUM_SHARD_ROWS = 2,/* the accumulator holds ONLY this shard's rows, packed (local row lr = global row
                                     lr * shard_count + shard_rank; nLocal * 3 floats): what a multi-GPU run gathers
                                     at rank 0 instead of reducing zero-padded full frames.  pt_readback still returns
                                     a full frame (other rows zero). */
+    PT_FLAG_DIRECT_LIGHTING = 4  /* README.md:107-108: "a final ray directly to a random point on an emissive object": at the
+                                    last of the traceDepth bounces a diffuse scatter aims at a uniformly chosen point of a
+                                    uniformly chosen emissive primitive (cosine-weighted), and ONE more bounce collects what
+                                    that ray hits (traceDepth + 1 launches; traceDepth <= PT_MAX_DEPTH - 1) */
 };
 
 typedef struct PtOptions {
@@ -90,6 +94,13 @@ typedef struct PtOptions {
     float  *accum_dev;        /* optional caller-owned device accumulator, W*H*3 floats (or the shard's rows only
                                  with PT_FLAG_ACCUM_SHARD_ROWS), zeroed by the caller (e.g. a torch tensor that
                                  RCCL exchanges); NULL = owned by the library like dev_image (pathtrace.cu:71,80-81) */
+    /* README extras the reference names but does not implement; 0 = off = the reference's pinhole camera.
+     * Depth of field by jittering rays within an aperture (README.md:100-101): camera rays start at a uniformly sampled
+     * point of a lens disc of this radius around the eye and pass through the point their pinhole ray reaches at
+     * focal_distance along the view axis.  (Imperfect specular, README.md:171-185, needs no option: a material with
+     * REFL > 0 and SPECEX > 0 scatters into the Phong lobe of that exponent around the mirror direction.) */
+    float   lens_radius;
+    float   focal_distance;
 } PtOptions;
 
 #define PT_MAX_DEPTH 62
@@ -197,6 +208,7 @@ int pt_test_unscaled_sqrt_sweep(uint64_t mismatches[4]);
 int pt_test_force_fault(int which);
 int pt_test_hemisphere(const float *normals3, const int32_t *iter_index_depth3, int n, float *out3);
 int pt_test_sincos(const float *x, int n, float *s, float *c);
+int pt_test_pow(const float *x, const float *e, int n, float *out);   /* build-defined x^e of the imperfect-specular sampler */
 int pt_test_reflect_refract(const float *I3, const float *N3, const float *eta, int n, float *refl3,
                             float *refr3);
 

@@ -88,6 +88,9 @@ def lib():
         L.orc_render_create.restype = C.c_void_p
         L.orc_render_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]
         L.orc_render_free.argtypes = [C.c_void_p]
+        L.orc_render_set_extras.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_int]
+        L.orc_pow.argtypes = [C.c_float, C.c_float]
+        L.orc_pow.restype = C.c_float
         L.orc_render_iterate.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                          C.POINTER(Counters)]
         L.orc_render_dump_paths.restype = C.c_int
@@ -240,6 +243,9 @@ class Renderer:
         if getattr(self, "h", None):
             lib().orc_render_free(self.h)
             self.h = None
+
+    def set_extras(self, lens_radius=0.0, focal_distance=0.0, direct_lighting=False):
+        lib().orc_render_set_extras(self.h, C.c_float(lens_radius), C.c_float(focal_distance), 1 if direct_lighting else 0)
 
     def iterate(self, it, image, rank=0, count=1):
         c = Counters()

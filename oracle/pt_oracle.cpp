@@ -326,6 +326,56 @@ inline void sincos_poly(float x, float *s, float *c) {
     }
 }
 
+/* ---- build-defined x^e for 0 <= x <= 1, 0 < e <= 1 (imperfect specular: cos(theta) = xi^(1/(n+1)), GPU Gems 3 ch. 20
+ * eq. 7-9; the reference names the formula, README.md:171-185, and implements nothing).  exp2(e * log2(x)) with the
+ * cephes logf / exp2f polynomials; like sincos_poly, ONE sequence of fp32 operations used bit-identically by the HIP
+ * kernels (ptd::powPoly).  Relative error ~2e-6. */
+inline float pow_poly(float x, float e) {
+    if (!(x > 0.0f)) return 0.0f;
+    if (x >= 1.0f) return 1.0f;
+    /* x = m 2^k, m in [sqrt(1/2), sqrt(2)) */
+    uint32_t bits;
+    memcpy(&bits, &x, 4);
+    if (bits < 0x00800000u) return 0.0f;               /* subnormal xi (p ~ 1e-38 per draw): treated as 0 */
+    int k = (int)(bits >> 23) - 127;
+    uint32_t mb = (bits & 0x007fffffu) | 0x3f800000u;   /* m in [1, 2) */
+    float m;
+    memcpy(&m, &mb, 4);
+    if (m > 1.41421356f) { m = m * 0.5f; k += 1; }
+    float f = m - 1.0f;
+    float z = f * f;
+    float p = 7.0376836292e-2f;
+    p = p * f - 1.1514610310e-1f;
+    p = p * f + 1.1676998740e-1f;
+    p = p * f - 1.2420140846e-1f;
+    p = p * f + 1.4249322787e-1f;
+    p = p * f - 1.6668057665e-1f;
+    p = p * f + 2.0000714765e-1f;
+    p = p * f - 2.4999993993e-1f;
+    p = p * f + 3.3333331174e-1f;
+    float y = (f * z) * p;
+    y = y - 0.5f * z;
+    float ln = f + y;                                   /* ln(m) */
+    float l2 = ln * 1.44269504088896341f + (float)k;    /* log2(x) <= 0 */
+    float t = e * l2;
+    if (t < -126.0f) return 0.0f;
+    float nf = std::rint(t);
+    float g = t - nf;                                   /* [-0.5, 0.5] */
+    float q = 1.535336188319500e-4f;
+    q = q * g + 1.339887440266574e-3f;
+    q = q * g + 9.618437357674640e-3f;
+    q = q * g + 5.550332471162809e-2f;
+    q = q * g + 2.402264791363012e-1f;
+    q = q * g + 6.931472028550421e-1f;
+    float r = q * g + 1.0f;                             /* 2^g */
+    uint32_t rb;
+    memcpy(&rb, &r, 4);
+    rb += (uint32_t)((int)nf << 23);                    /* * 2^n, n in [-126, 0]: stays normal (r >= 0.70) or flushes below */
+    float out;
+    memcpy(&out, &rb, 4);
+    return out;
+}
+
 struct Ray {
     V3 origin, direction;
 };
@@ -447,6 +497,29 @@ V3 random_direction_in_hemisphere(V3 normal, uint32_t &rng) {
     return add(add(muls(normal, up), muls(p1, c * over)), muls(p2, s * over));
 }
 
+/* Imperfect specular (README.md:171-185 -> GPU Gems 3 ch. 20 eq. 7-9): a direction in the Phong lobe of exponent n around the
+ * mirror direction R: cos(theta) = xi1^(1/(n+1)), phi = 2 pi xi2, in the tangent frame the hemisphere sampler builds
+ * around a vector.  Build-defined detail: a sample below the surface falls back to R itself. */
+V3 random_direction_in_specular_lobe(V3 R, V3 normal, float invExpPlus1, uint32_t &rng) {
+    float cosT = pow_poly(rng_u01(rng), invExpPlus1);
+    float sinT = std::sqrt(1 - cosT * cosT);
+    float around = rng_u01(rng) * kTWO_PI;
+    V3 directionNotR;
+    if (std::fabs(R.x) < kSQRT_OF_ONE_THIRD) {
+        directionNotR = v3(1, 0, 0);
+    } else if (std::fabs(R.y) < kSQRT_OF_ONE_THIRD) {
+        directionNotR = v3(0, 1, 0);
+    } else {
+        directionNotR = v3(0, 0, 1);
+    }
+    V3 p1 = normalize3(cross3(R, directionNotR));
+    V3 p2 = normalize3(cross3(R, p1));
+    float s, c;
+    sincos_poly(around, &s, &c);
+    V3 d = add(add(muls(R, cosT), muls(p1, c * sinT)), muls(p2, s * sinT));
+    return dot3(d, normal) > 0.0f ? d : R;
+}
+
 }  // namespace
 
 /* ===================================================================== */
@@ -469,6 +542,11 @@ struct ORender {
     /* derived camera constants (spec S2) */
     V3 view, up, right, position;
     float pixLenX, pixLenY, halfW, halfH;
+    /* README extras, all off by default = the behaviour every other test pins */
+    float lensRadius, focalDistance;   /* thin lens (README.md:100-101); radius 0 = pinhole */
+    V3 viewN;                          /* normalize(view) */
+    int directLighting;                /* README.md:107-108: a final ray to a random point of an emissive object */
+    std::vector<int> emitters;         /* geoms with an emissive material, file order */
 };
 
 namespace {
@@ -634,13 +712,49 @@ Ray camera_ray(const ORender &R, int iter, int index) {
     Ray r;
     r.origin = R.position;
     r.direction = normalize3(sub(sub(R.view, muls(R.right, a)), muls(R.up, b)));
+    if (R.lensRadius > 0.0f) {
+        /* depth of field by jittering rays within an aperture (README.md:100-101, PBRT 6.2.3): the pinhole ray fixes the
+         * point in focus, at distance focalDistance along the view axis; the ray starts at a uniformly sampled point of
+         * the lens disc (two more draws of the depth-0 stream) and aims at it */
+        float lr = R.lensRadius * std::sqrt(rng_u01(rng));
+        float phi = rng_u01(rng) * kTWO_PI;
+        float s, c;
+        sincos_poly(phi, &s, &c);
+        float ft = R.focalDistance / dot3(r.direction, R.viewN);
+        V3 focus = add(R.position, muls(r.direction, ft));
+        r.origin = add(add(R.position, muls(R.right, lr * c)), muls(R.up, lr * s));
+        r.direction = normalize3(sub(focus, r.origin));
+    }
     return r;
 }
 
 enum Fate { ALIVE = 0, MISS = 1, LIGHT = 2 };
 
 /* One bounce of one path (spec S3-S6).  On LIGHT, `contrib` holds the radiance to add. */
-Fate bounce(const ORender &R, int iter, int index, int depth, Ray &ray, V3 &color, V3 &contrib) {
+/* diffuse scatter of the direct-lighting bounce: instead of a hemisphere sample, a ray to a uniformly chosen point of the
+ * (transformed) unit cube of a uniformly chosen emissive primitive, weighted by the cosine at the surface and by the
+ * share of the hemisphere the emitter's bounding ball covers, min(1, rho^2 / r^2) with rho^2 = |scale|^2 / 4 (a hemisphere
+ * sample would have found the light with about that probability) */
+static void scatter_to_light(const ORender &R, V3 n, V3 norg, V3 mcol, uint32_t &rng, V3 &ndir, V3 &color) {
+    int ne = (int)R.emitters.size();
+    int pick = (int)(rng_u01(rng) * (float)ne);
+    if (pick > ne - 1) pick = ne - 1;
+    const OGeom &L = R.geoms[R.emitters[pick]];
+    float ux = rng_u01(rng) - 0.5f;
+    float uy = rng_u01(rng) - 0.5f;
+    float uz = rng_u01(rng) - 0.5f;
+    V3 target = multiplyMV(m4_from(L.transform), v4(ux, uy, uz, 1.0f));
+    V3 toward = sub(target, norg);
+    ndir = normalize3(toward);
+    float w = dot3(n, ndir);
+    w = w > 0.0f ? w : 0.0f;
+    float rho2 = ((L.scale.x * L.scale.x + L.scale.y * L.scale.y) + L.scale.z * L.scale.z) * 0.25f;
+    float cover = rho2 / dot3(toward, toward);
+    cover = cover < 1.0f ? cover : 1.0f;
+    color = muls(mul(color, mcol), w * cover);
+}
+
+Fate bounce(const ORender &R, int iter, int index, int depth, Ray &ray, V3 &color, V3 &contrib, bool direct = false) {
     V3 p = v3(0, 0, 0), n = v3(0, 0, 0);
     bool outside = false;
     int g = nearest_hit(R, ray, p, n, outside);
@@ -685,18 +799,26 @@ Fate bounce(const ORender &R, int iter, int index, int depth, Ray &ray, V3 &colo
     } else if (m.hasReflective > 0.0f) {
         /* energy-conserving 50/50 mirror/diffuse mixture (spec S6) */
         float u = rng_u01(rng);
+        norg = add(p, muls(n, 0.001f));
         if (u < 0.5f) {
             ndir = reflect3(ray.direction, n);
+            if (m.specExponent > 0.0f)      /* SPECEX > 0: imperfect specular (README.md:171-185); 0 = the perfect mirror */
+                ndir = random_direction_in_specular_lobe(ndir, n, 1.0f / (m.specExponent + 1.0f), rng);
             color = mul(color, scol);
+        } else if (direct && !R.emitters.empty()) {
+            scatter_to_light(R, n, norg, mcol, rng, ndir, color);
         } else {
             ndir = random_direction_in_hemisphere(n, rng);
             color = mul(color, mcol);
         }
-        norg = add(p, muls(n, 0.001f));
     } else {
-        ndir = random_direction_in_hemisphere(n, rng);
-        color = mul(color, mcol);
         norg = add(p, muls(n, 0.001f));
+        if (direct && !R.emitters.empty()) {
+            scatter_to_light(R, n, norg, mcol, rng, ndir, color);
+        } else {
+            ndir = random_direction_in_hemisphere(n, rng);
+            color = mul(color, mcol);
+        }
     }
     ray.origin = norg;
     ray.direction = ndir;
@@ -834,8 +956,20 @@ ORender *orc_render_create(const OCamera *cam, const OGeom *geoms, int ngeoms, c
     R->pixLenY = (2.0f * ys) / (float)cam->resY;
     R->halfW = (float)cam->resX * 0.5f;
     R->halfH = (float)cam->resY * 0.5f;
+    R->lensRadius = 0.0f;
+    R->focalDistance = 0.0f;
+    R->viewN = normalize3(R->view);
+    R->directLighting = 0;
+    for (int i = 0; i < ngeoms; ++i)
+        if (mats[geoms[i].materialid].emittance > 0.0f) R->emitters.push_back(i);
     return R;
 }
+void orc_render_set_extras(ORender *R, float lensRadius, float focalDistance, int directLighting) {
+    R->lensRadius = lensRadius;
+    R->focalDistance = focalDistance;
+    R->directLighting = directLighting;
+}
+float orc_pow(float x, float e) { return pow_poly(x, e); }
 void orc_render_free(ORender *R) { delete R; }
 
 void orc_camera_ray(ORender *R, int iter, int index, float ray[6]) {
@@ -855,10 +989,12 @@ void orc_render_iterate(ORender *R, int iter, float *image, int shardRank, int s
             Ray ray = camera_ray(*R, iter, index);
             V3 color = v3(1, 1, 1);
             bool alive = true;
-            for (int d = 1; d <= R->traceDepth && alive; ++d) {
+            /* direct lighting: the last bounce aims its diffuse scatter at a light and one more bounce collects it */
+            const int nb = R->traceDepth + (R->directLighting ? 1 : 0);
+            for (int d = 1; d <= nb && alive; ++d) {
                 if (d < 64) local.live[d]++;
                 V3 contrib = v3(0, 0, 0);
-                Fate f = bounce(*R, iter, index, d, ray, color, contrib);
+                Fate f = bounce(*R, iter, index, d, ray, color, contrib, R->directLighting && d == R->traceDepth);
                 if (f == MISS) {
                     local.misses++;
                     alive = false;
@@ -888,7 +1024,7 @@ int orc_render_dump_paths(ORender *R, int iter, int bounces, int shardRank, int 
             bool alive = true;
             for (int d = 1; d <= bounces && alive; ++d) {
                 V3 contrib;
-                alive = bounce(*R, iter, index, d, ray, color, contrib) == ALIVE;
+                alive = bounce(*R, iter, index, d, ray, color, contrib, R->directLighting && d == R->traceDepth) == ALIVE;
             }
             if (!alive) continue;
             origin3[3 * n] = ray.origin.x; origin3[3 * n + 1] = ray.origin.y; origin3[3 * n + 2] = ray.origin.z;

@@ -103,6 +103,11 @@ typedef struct ORender ORender;
 ORender *orc_render_create(const OCamera *cam, const OGeom *geoms, int ngeoms,
                            const OMaterial *mats, int nmats, int traceDepth);
 void     orc_render_free(ORender *);
+/* README extras (the reference names them and implements none), all off after orc_render_create:
+ * thin lens (radius 0 = pinhole), direct lighting (the last bounce aims at a light, one more bounce collects).
+ * Imperfect specular needs no switch: it is driven by Material::specular.exponent (SPECEX) > 0. */
+void     orc_render_set_extras(ORender *, float lensRadius, float focalDistance, int directLighting);
+float    orc_pow(float x, float e);                             /* build-defined x^e, 0 <= x <= 1 */
 /* One iteration (iter is 1-based) over the rows y with y % shardCount == shardRank.
  * image = W*H*3 floats running sum (accumulated in place). */
 void     orc_render_iterate(ORender *, int iter, float *image, int shardRank, int shardCount,

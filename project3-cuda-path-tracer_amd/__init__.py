@@ -42,6 +42,7 @@ PT_MAX_DEPTH = 62
 PT_MAX_BATCH = 64
 PT_FLAG_KERNEL_TIMING = 1
 PT_FLAG_ACCUM_SHARD_ROWS = 2
+PT_FLAG_DIRECT_LIGHTING = 4
 
 # every symbol include/pt_amd.h declares
 ABI_SYMBOLS = [
@@ -50,14 +51,14 @@ ABI_SYMBOLS = [
     "pt_scan_exclusive_i32", "pt_compact_nonzero_i32", "pt_test_utilhash", "pt_test_rng",
     "pt_test_intersect", "pt_test_hemisphere", "pt_test_sincos", "pt_test_reflect_refract",
     "pt_test_slab_quotients", "pt_test_slab_quotients_sweep", "pt_test_sphere_cull_sweep",
-    "pt_test_unscaled_sqrt_sweep", "pt_pin_host", "pt_unpin_host", "pt_test_force_fault",
+    "pt_test_unscaled_sqrt_sweep", "pt_pin_host", "pt_unpin_host", "pt_test_force_fault", "pt_test_pow",
 ]
 
 
 class PtOptions(C.Structure):
     _fields_ = [("shard_rank", C.c_int32), ("shard_count", C.c_int32), ("device", C.c_int32),
                 ("flags", C.c_int32), ("pipeline_depth", C.c_int32), ("max_batch", C.c_int32),
-                ("stream", C.c_void_p), ("accum_dev", C.c_void_p)]
+                ("stream", C.c_void_p), ("accum_dev", C.c_void_p), ("lens_radius", C.c_float), ("focal_distance", C.c_float)]
 
 
 class PtCounters(C.Structure):
@@ -117,6 +118,7 @@ def lib():
         L.pt_pin_host.argtypes = [vp, C.c_size_t]
         L.pt_unpin_host.argtypes = []
         L.pt_test_force_fault.argtypes = [i32]
+        L.pt_test_pow.argtypes = [vp, vp, i32, vp]
         _lib = L
     return _lib
 
@@ -204,10 +206,14 @@ _scene = None
 
 
 def pathtraceInit(scene, shard_rank=0, shard_count=1, stream=0, accum_dev=0, device=-1, flags=0, traceDepth=None,
-                  pipeline_depth=0, max_batch=0):
-    """reference src/pathtrace.cu:75-85.  `scene` is borrowed until pathtraceFree()."""
+                  pipeline_depth=0, max_batch=0, lens_radius=0.0, focal_distance=0.0, direct_lighting=False):
+    """reference src/pathtrace.cu:75-85.  `scene` is borrowed until pathtraceFree().
+    lens_radius / focal_distance / direct_lighting: the README extras (depth of field, direct lighting), off by default."""
     global _scene
-    opt = PtOptions(shard_rank, shard_count, device, flags, pipeline_depth, max_batch, stream or None, accum_dev or None)
+    if direct_lighting:
+        flags |= PT_FLAG_DIRECT_LIGHTING
+    opt = PtOptions(shard_rank, shard_count, device, flags, pipeline_depth, max_batch, stream or None, accum_dev or None,
+                    lens_radius, focal_distance)
     geoms = np.ascontiguousarray(scene.geoms)
     mats = np.ascontiguousarray(scene.materials)
     cam = np.ascontiguousarray(scene.camera)
@@ -343,6 +349,14 @@ def test_sincos(x):
     s, c = np.empty_like(x), np.empty_like(x)
     _check(lib().pt_test_sincos(_p(x), x.size, _p(s), _p(c)))
     return s, c
+
+
+def test_pow(x, e):
+    x = np.ascontiguousarray(x, np.float32)
+    e = np.ascontiguousarray(e, np.float32)
+    out = np.empty_like(x)
+    _check(lib().pt_test_pow(_p(x), _p(e), x.size, _p(out)))
+    return out
 
 
 def test_reflect_refract(I, N, eta):

@@ -96,6 +96,7 @@ struct State {
     int grid = 0;           // persistent grid of k_bounce<false>
     int gridFirst = 0;      // ... and of k_bounce<true> (its own register budget, hence its own residency)
     bool many = false;      // more than kBinMax spheres: the k_bounce<., true> variants (per-lane sphere lists)
+    bool dof = false;       // thin-lens camera: the k_bounce<true, ., true> variants for the camera-ray bounce
     size_t ldsBytes = 0;
     long long iterations = 0;
     long long seq = 0;      // iterations enqueued since pt_init: slot = seq % nslots
@@ -246,6 +247,7 @@ void pack_material(const PtMaterial &m, MaterialDev &d) {
     d.invIor = 1.0f / d.ior;
     const float q = (1.0f - d.ior) / (1.0f + d.ior);
     d.r0 = q * q;
+    d.invSpecExp1 = m.specularExponent > 0.0f ? 1.0f / (m.specularExponent + 1.0f) : 0.0f;
 }
 
 // Pixel rectangle from which camera rays can reach a primitive: project the 8 corners of its object-space unit cube
@@ -343,12 +345,17 @@ int launch_bounce(Slot &sl, int iter, int batch, int depth, bool lastBounce, flo
     ba.ctrl = sl.ctrl; ba.ggeoms = S.dgeoms; ba.gmats = S.dmats; ba.contrib = contrib;
 #define PT_LAUNCH_BOUNCE(FIRST_, MANY_, GRID_) \
     hipLaunchKernelGGL((k_bounce<FIRST_, MANY_>), dim3(GRID_), dim3(kBlock), S.ldsBytes, sl.stream, ba)
-    if (depth == 1) {
+#define PT_LAUNCH_BOUNCE3(FIRST_, MANY_, DOF_, GRID_) \
+    hipLaunchKernelGGL((k_bounce<FIRST_, MANY_, DOF_>), dim3(GRID_), dim3(kBlock), S.ldsBytes, sl.stream, ba)
+    if (depth == 1 && S.dof) {
+        if (S.many) PT_LAUNCH_BOUNCE3(true, true, true, S.gridFirst); else PT_LAUNCH_BOUNCE3(true, false, true, S.gridFirst);
+    } else if (depth == 1) {
         if (S.many) PT_LAUNCH_BOUNCE(true, true, S.gridFirst); else PT_LAUNCH_BOUNCE(true, false, S.gridFirst);
     } else {
         if (S.many) PT_LAUNCH_BOUNCE(false, true, S.grid); else PT_LAUNCH_BOUNCE(false, false, S.grid);
     }
 #undef PT_LAUNCH_BOUNCE
+#undef PT_LAUNCH_BOUNCE3
     if (e0) {
         HIPCHECK(hipEventRecord(e1, sl.stream));
         S.evBounce.emplace_back(e0, e1);
@@ -508,7 +515,11 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     if (!cam || ngeoms < 0 || nmats < 0 || (ngeoms && !geoms) || (nmats && !mats))
         return fail(PT_ERR_INVALID, "pt_init: null argument");
     if (cam->resolution[0] <= 0 || cam->resolution[1] <= 0) return fail(PT_ERR_INVALID, "pt_init: bad resolution");
-    if (traceDepth < 1 || traceDepth > PT_MAX_DEPTH) return fail(PT_ERR_INVALID, "pt_init: traceDepth must be 1..%d", PT_MAX_DEPTH);
+    const bool direct = opts && (opts->flags & PT_FLAG_DIRECT_LIGHTING);
+    if (traceDepth < 1 || traceDepth + (direct ? 1 : 0) > PT_MAX_DEPTH)
+        return fail(PT_ERR_INVALID, "pt_init: traceDepth must be 1..%d", PT_MAX_DEPTH - (direct ? 1 : 0));
+    if (opts && (!(opts->lens_radius >= 0.0f) || (opts->lens_radius > 0.0f && !(opts->focal_distance > 0.0f))))
+        return fail(PT_ERR_INVALID, "pt_init: lens_radius must be >= 0 and focal_distance > 0 with a lens");
     if ((long long)cam->resolution[0] * cam->resolution[1] > (1ll << 30)) return fail(PT_ERR_INVALID, "pt_init: frame too large");
     for (int i = 0; i < ngeoms; ++i) {
         if (geoms[i].type != PT_SPHERE && geoms[i].type != PT_CUBE) return fail(PT_ERR_INVALID, "pt_init: geom %d has unknown type", i);
@@ -565,7 +576,25 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
                     return fail(PT_ERR_INVALID, "pt_init: magic division self-check failed for d=%u n=%llu", d, (unsigned long long)n);
     }
     k.ngeoms = ngeoms; k.nmats = nmats;
-    k.traceDepth = traceDepth;
+    // direct lighting: bounce `traceDepth` aims its diffuse scatter at a light and one more launch collects
+    k.traceDepth = traceDepth + (direct ? 1 : 0);
+    k.directDepth = direct ? traceDepth : 0;
+    k.nEmit = 0;
+    for (int i = 0; i < ngeoms && k.nEmit < kEmitMax; ++i)
+        if (mats[geoms[i].materialid].emittance > 0.0f) {
+            const PtVec3 sc = geoms[i].scale;
+            const float xx = sc.x * sc.x, yy = sc.y * sc.y, zz = sc.z * sc.z;
+            const float xy = xx + yy;
+            k.emitRho2[k.nEmit] = (xy + zz) * 0.25f;
+            k.emitGeom[k.nEmit++] = i;
+        }
+    k.lensRadius = o.lens_radius;
+    k.focalDistance = o.focal_distance;
+    {
+        const H3 vn = hnormalize(view);
+        k.viewN[0] = vn.x; k.viewN[1] = vn.y; k.viewN[2] = vn.z;
+    }
+    S.dof = o.lens_radius > 0.0f;
 
     if (o.accum_dev) {
         S.image = o.accum_dev;
@@ -627,6 +656,11 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     for (int i = 0; i < ngeoms; ++i) {
         pack_geom(geoms[i], hg[i], k.pos);
         project_geom(geoms[i], k, hg[i].rect);
+        if (S.dof) {        // rays start anywhere on the lens: the pinhole projection bounds nothing
+            hg[i].rect[0] = hg[i].rect[1] = 0;
+            hg[i].rect[2] = Wd - 1;
+            hg[i].rect[3] = H - 1;
+        }
         k.sceneRect[0] = std::min(k.sceneRect[0], hg[i].rect[0]);
         k.sceneRect[1] = std::min(k.sceneRect[1], hg[i].rect[1]);
         k.sceneRect[2] = std::max(k.sceneRect[2], hg[i].rect[2]);
@@ -678,7 +712,8 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     S.ldsBytes = sizeof(MaterialDev) * nmats + sizeof(GeomHitDev) * ngeoms + kMiscWords * sizeof(uint32_t) +
                  (S.many ? (size_t)ngeoms * kSphRowFloats * sizeof(float) + (size_t)kListMax * kBlock * sizeof(uint16_t) : 0);
     if (S.ldsBytes > 160 * 1024) return fail(PT_ERR_INVALID, "pt_init: scene does not fit the 160 KiB LDS (%zu B)", S.ldsBytes);
-    const void *kFirst = S.many ? reinterpret_cast<const void *>(k_bounce<true, true>) : reinterpret_cast<const void *>(k_bounce<true, false>);
+    const void *kFirst = S.dof ? (S.many ? reinterpret_cast<const void *>(k_bounce<true, true, true>) : reinterpret_cast<const void *>(k_bounce<true, false, true>))
+                               : (S.many ? reinterpret_cast<const void *>(k_bounce<true, true>) : reinterpret_cast<const void *>(k_bounce<true, false>));
     const void *kNext = S.many ? reinterpret_cast<const void *>(k_bounce<false, true>) : reinterpret_cast<const void *>(k_bounce<false, false>);
     if (S.ldsBytes > 64 * 1024) {
         HIPCHECK(hipFuncSetAttribute(kFirst, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.ldsBytes));
@@ -1195,6 +1230,19 @@ int pt_test_hemisphere(const float *normals3, const int32_t *iid3, int n, float 
     hipLaunchKernelGGL(k_test_hemisphere, GRID(n), a.p, b.p, n, o.p);
     HIPCHECK(hipDeviceSynchronize());
     DOWN(out3, o, (size_t)n * 3);
+    return PT_OK;
+}
+
+int pt_test_pow(const float *x, const float *e, int n, float *out) {
+    NEED_GPU();
+    if (n <= 0) return PT_OK;
+    DevBuf<float> a, b, o;
+    UP(a, x, n);
+    UP(b, e, n);
+    int rc = o.alloc(n); if (rc) return rc;
+    hipLaunchKernelGGL(k_test_pow, GRID(n), a.p, b.p, n, o.p);
+    HIPCHECK(hipDeviceSynchronize());
+    DOWN(out, o, n);
     return PT_OK;
 }
 

@@ -146,8 +146,11 @@ struct MaterialDev {
     // per-material constants of the dielectric branch, evaluated once on the host with the same IEEE operations the
     // shader would issue per path: 1.0f / ior and Schlick's r0 = ((1 - ior) / (1 + ior))^2
     float invIor, r0;
+    // imperfect specular (SPECEX > 0, reference README.md:171-185): 1.0f / (exponent + 1.0f), evaluated on the host; 0 = perfect mirror
+    float invSpecExp1;
+    float pad[3];
 };
-static_assert(sizeof(MaterialDev) == 48, "MaterialDev is 3 x 16 B");
+static_assert(sizeof(MaterialDev) == 64, "MaterialDev is 4 x 16 B");
 
 // multiplyMV (src/intersections.h:33-35) = vec3(m * v), glm/detail/type_mat4x4.inl:617-628:
 // (m0*v0 + m1*v1) + (m2*v2 + m3*v3).  The products with w = 0 / w = 1 are kept as IEEE ops
@@ -256,6 +259,46 @@ __device__ __forceinline__ void sincosPoly(float x, float &s, float &c) {
     float c0 = (k & 1) ? sr : cr;
     s = (k & 2) ? -s0 : s0;
     c = ((k + 1) & 2) ? -c0 : c0;
+}
+
+// Build-defined x^e for 0 <= x <= 1, 0 < e <= 1 (imperfect specular: cos(theta) = xi^(1/(n+1)), GPU Gems 3 ch. 20 eq. 7-9,
+// named by the reference's README.md:171-185): exp2(e * log2(x)) with the cephes logf / exp2f polynomials, operation for
+// operation the CPU oracle's pow_poly (relative error ~2e-6).
+__device__ __forceinline__ float powPoly(float x, float e) {
+    if (!(x > 0.0f)) return 0.0f;
+    if (x >= 1.0f) return 1.0f;
+    const uint32_t bits = __float_as_uint(x);
+    if (bits < 0x00800000u) return 0.0f;
+    int k = (int)(bits >> 23) - 127;
+    float m = __uint_as_float((bits & 0x007fffffu) | 0x3f800000u);
+    if (m > 1.41421356f) { m = m * 0.5f; k += 1; }
+    const float f = m - 1.0f;
+    const float z = f * f;
+    float p = 7.0376836292e-2f;
+    p = p * f - 1.1514610310e-1f;
+    p = p * f + 1.1676998740e-1f;
+    p = p * f - 1.2420140846e-1f;
+    p = p * f + 1.4249322787e-1f;
+    p = p * f - 1.6668057665e-1f;
+    p = p * f + 2.0000714765e-1f;
+    p = p * f - 2.4999993993e-1f;
+    p = p * f + 3.3333331174e-1f;
+    float y = (f * z) * p;
+    y = y - 0.5f * z;
+    const float ln = f + y;
+    const float l2 = ln * 1.44269504088896341f + (float)k;
+    const float t = e * l2;
+    if (t < -126.0f) return 0.0f;
+    const float nf = __builtin_rintf(t);
+    const float g = t - nf;
+    float q = 1.535336188319500e-4f;
+    q = q * g + 1.339887440266574e-3f;
+    q = q * g + 9.618437357674640e-3f;
+    q = q * g + 5.550332471162809e-2f;
+    q = q * g + 2.402264791363012e-1f;
+    q = q * g + 6.931472028550421e-1f;
+    const float r = q * g + 1.0f;
+    return __uint_as_float(__float_as_uint(r) + (uint32_t)((int)nf << 23));
 }
 
 // 1.0f / sqrtf(x), both correctly rounded, for x within 256 ulps of 1 without the square root and the division.
@@ -533,6 +576,20 @@ __device__ __forceinline__ void hemisphereDraws(Rng &rng, float &up, float &cOve
 }
 __device__ __forceinline__ F3 hemisphereCombine(F3 normal, F3 p1, F3 p2, float up, float cOver, float sOver) {
     return (normal * up + p1 * cOver) + p2 * sOver;
+}
+// Imperfect specular: a direction in the Phong lobe (1 / invExp1 - 1 = exponent) around the mirror direction R, in the tangent
+// frame the hemisphere sampler builds around a vector; a sample below the surface falls back to R (the oracle's
+// random_direction_in_specular_lobe, operation for operation).
+__device__ __forceinline__ F3 specularLobeDirection(F3 R, F3 normal, float invExp1, Rng &rng) {
+    const float cosT = powPoly(u01(rng), invExp1);
+    const float sinT = __builtin_sqrtf(1 - cosT * cosT);
+    const float around = u01(rng) * kTwoPi;
+    F3 p1, p2;
+    hemisphereFrame(R, p1, p2);
+    float s, c;
+    sincosPoly(around, s, c);
+    const F3 d = hemisphereCombine(R, p1, p2, cosT, c * sinT, s * sinT);
+    return dot(d, normal) > 0.0f ? d : R;
 }
 __device__ __forceinline__ F3 calculateRandomDirectionInHemisphere(F3 normal, Rng &rng) {
     float up, cOver, sOver;

@@ -6,6 +6,10 @@
 namespace ptk {
 
 // ---- primitive test kernels (device functions exactly as the render kernels use them) -------------------
+__global__ void k_test_pow(const float *x, const float *e, int n, float *out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = powPoly(x[i], e[i]);
+}
 __global__ void k_test_utilhash(const uint32_t *in, uint32_t *out, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = utilhash(in[i]);

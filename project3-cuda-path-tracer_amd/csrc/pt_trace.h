@@ -18,6 +18,7 @@ constexpr int kCls = 2 * kOct;       // ... and by "may hit a small primitive" (
 constexpr int kSub = 4;              // append-counter shards per class (workgroup blockIdx % kSub)
 constexpr int kSeg = kCls * kSub;    // path buffers are split into kSeg segments with one append counter each
 constexpr int kBinMax = 4;           // at most this many small primitives take part in the binning
+constexpr int kEmitMax = 8;          // emissive primitives the direct-lighting bounce chooses from
 // Path state lives in POOLS of fixed-size chunks (2^chunkShift paths each, chosen by pt_init): a segment of a bounce's
 // queue is a list of chunks, handed out by an atomic bump counter while the segment is filled, so a pool is sized for the
 // paths that can be alive (pixels x batch, plus two chunks of slack per segment) and not for the worst case of every path
@@ -67,6 +68,14 @@ struct KParams {
     int   emittersBinned; // every primitive with an emissive material is one of binGeom[]
     int   nBinned;      // 1..kBinMax small primitives (spheres, small cubes): survivors are binned by whether they can
     int   binGeom[kBinMax];   // hit one of them (certainMiss of each); 0: off, every path counts as a candidate
+    // ---- README extras, all off by default
+    float lensRadius, focalDistance;   // thin lens (depth of field, README.md:100-101); radius 0 = pinhole
+    float viewN[3];                    // normalize(view)
+    int   directDepth;                 // direct lighting (README.md:107-108): the bounce whose diffuse scatter aims at a light
+                                       // (= the scene's trace depth; traceDepth is then one more: the bounce that collects); 0 = off
+    int   nEmit;                       // emissive primitives the direct-lighting bounce samples, at most kEmitMax (file order)
+    int   emitGeom[kEmitMax];
+    float emitRho2[kEmitMax];          // |scale|^2 / 4 of each: squared radius of its bounding ball
 };
 
 // SoA PathSegment pool: 11 arrays of `cap` = poolChunks << chunkShift 4-byte elements, array k at base + k*cap
@@ -180,6 +189,16 @@ __device__ __forceinline__ void cameraRayAt(const KParams &prm, uint32_t iterHas
     const F3 right = f3(prm.right[0], prm.right[1], prm.right[2]);
     org = f3(prm.pos[0], prm.pos[1], prm.pos[2]);
     dir = normalize((view - right * a) - up * b);
+    if (prm.lensRadius > 0.0f) {     // thin lens, as in k_bounce<true, ., true>
+        const float lr = prm.lensRadius * __builtin_sqrtf(u01(rng));
+        const float phi = u01(rng) * kTwoPi;
+        float s, c;
+        sincosPoly(phi, s, c);
+        const float ft = prm.focalDistance / dot(dir, f3(prm.viewN[0], prm.viewN[1], prm.viewN[2]));
+        const F3 focus = org + dir * ft;
+        org = (org + right * (lr * c)) + up * (lr * s);
+        dir = normalize(focus - org);
+    }
 }
 __device__ __forceinline__ void cameraRay(const KParams &prm, int iter, int j, int &pix, int &x, int &y, F3 &org, F3 &dir) {
     shardPixel(prm, j, pix, x, y);
@@ -284,8 +303,11 @@ __device__ __forceinline__ CullGroup loadCull(const PT_CAS GeomDev *g) {
 static_assert(offsetof(GeomDev, centre) == 0x60, "loadCull's offset");
 static_assert(sizeof(CullGroup) == 32 && offsetof(GeomDev, cullFlags) - offsetof(GeomDev, centre) == offsetof(CullGroup, cullFlags), "CullGroup mirrors GeomDev");
 
-template <bool FIRST, bool MANY>
-__global__ __launch_bounds__(kBlock, MANY ? 5 : 8) void k_bounce(BounceArgs argsByValue) {
+// DOF (with FIRST only): camera rays start on a thin lens (README.md:100-101), so they share no origin (no precomputed
+// object-space camera position) and the pixel rectangles, which project the primitives through a pinhole, are not used.
+template <bool FIRST, bool MANY, bool DOF = false>
+__global__ __launch_bounds__(kBlock, (MANY || DOF) ? 5 : 8) void k_bounce(BounceArgs argsByValue) {
+    static_assert(FIRST || !DOF, "the lens only concerns the camera-ray bounce");
     (void)argsByValue;
     const ArgsPtr kargs = (ArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
     // LDS: the material table and the per-geom hit records (normal matrix, material, type: indexed per lane by
@@ -484,6 +506,18 @@ __global__ __launch_bounds__(kBlock, MANY ? 5 : 8) void k_bounce(BounceArgs args
                     const F3 right = f3(prm.right[0], prm.right[1], prm.right[2]);
                     org = f3(prm.pos[0], prm.pos[1], prm.pos[2]);
                     dir = normalize((view - right * a) - up * b);
+                    if (DOF) {
+                        // the pinhole ray fixes the point in focus; the ray starts at a uniformly sampled point of the lens
+                        // disc (two more draws of the depth-0 stream) and aims at it
+                        const float lr = prm.lensRadius * __builtin_sqrtf(u01(rng));
+                        const float phi = u01(rng) * kTwoPi;
+                        float s, c;
+                        sincosPoly(phi, s, c);
+                        const float ft = prm.focalDistance / dot(dir, f3(prm.viewN[0], prm.viewN[1], prm.viewN[2]));
+                        const F3 focus = org + dir * ft;
+                        org = (org + right * (lr * c)) + up * (lr * s);
+                        dir = normalize(focus - org);
+                    }
                 }
                 col = f3(1.0f, 1.0f, 1.0f);
                 rem = prm.traceDepth;
@@ -530,7 +564,7 @@ __global__ __launch_bounds__(kBlock, MANY ? 5 : 8) void k_bounce(BounceArgs args
                     F3 p, n;
                     bool o = false;
                     float t = -1.0f;
-                    if (FIRST && (px < G.rect[0] || px > G.rect[2] || py < G.rect[1] || py > G.rect[3])) continue;
+                    if (FIRST && !DOF && (px < G.rect[0] || px > G.rect[2] || py < G.rect[1] || py > G.rect[3])) continue;
                     if (!FIRST && !smallTile && (flags & 2)) continue;  // this tile's paths certainly miss every binned primitive
                     if ((flags & 1) == 0) {
                         probe(3);
@@ -539,11 +573,11 @@ __global__ __launch_bounds__(kBlock, MANY ? 5 : 8) void k_bounce(BounceArgs args
                                 s_list[nCand * kBlock + tid] = (uint16_t)g;
                                 ++nCand;
                             } else {                                 // (MANY: the lane's list is full -- test in place)
-                                t = sphereIntersectionTest<FIRST>(G, org, dir, p, n, o);
+                                t = sphereIntersectionTest<FIRST && !DOF>(G, org, dir, p, n, o);
                             }
                         }
                     } else {
-                        t = boxIntersectionTest<true, FIRST>(G, org, dir, p, n, o);
+                        t = boxIntersectionTest<true, FIRST && !DOF>(G, org, dir, p, n, o);
                     }
                     if (t > 0.0f && (hit < 0 || t < tbest)) {
                         tbest = t; hit = g; P = p; nsrc = n; outside = o;
@@ -627,18 +661,55 @@ __global__ __launch_bounds__(kBlock, MANY ? 5 : 8) void k_bounce(BounceArgs args
                         const float u = u01(rng);
                         if (u < 0.5f) {
                             ndir = reflect(dir, N);
+                            if (M.invSpecExp1 > 0.0f) ndir = specularLobeDirection(ndir, N, M.invSpecExp1, rng);   // SPECEX > 0
                             col = col * scol;
                         } else {
                             diffuse = true;
-                            col = col * mcol;
                         }
                         norg = P + N * 0.001f;
                     } else {
                         diffuse = true;
-                        col = col * mcol;
                         norg = P + N * 0.001f;
                     }
+                    bool toLight = false;
                     if (diffuse) {
+                        // direct lighting (README.md:107-108): at the scene's last bounce the diffuse scatter is a ray to a uniformly
+                        // chosen point of the (transformed) unit cube of a uniformly chosen emissive primitive, weighted by the
+                        // cosine at the surface; the launch after this one collects what it hits
+                        const ArgsPtr A = launder(kargs);
+                        toLight = A->prm.directDepth != 0 && A->depth == A->prm.directDepth && A->prm.nEmit > 0;
+                        if (toLight) {
+                            const int ne = A->prm.nEmit;
+                            int pick = (int)(u01(rng) * (float)ne);
+                            pick = pick > ne - 1 ? ne - 1 : pick;
+                            int e = A->prm.emitGeom[0];
+                            float rho2 = A->prm.emitRho2[0];
+#pragma unroll
+                            for (int q = 1; q < kEmitMax; ++q) {
+                                e = pick == q ? A->prm.emitGeom[q] : e;
+                                rho2 = pick == q ? A->prm.emitRho2[q] : rho2;
+                            }
+                            const float ux = u01(rng) - 0.5f;
+                            const float uy = u01(rng) - 0.5f;
+                            const float uz = u01(rng) - 0.5f;
+                            const float *xf = A->ggeoms[e].xf;              // per-lane primitive: vector loads
+                            float m[12];
+#pragma unroll
+                            for (int q = 0; q < 12; ++q) m[q] = xf[q];
+                            const F3 target = mulMV(m, f3(ux, uy, uz), 1.0f);
+                            const F3 toward = target - norg;
+                            ndir = normalize(toward);
+                            float w = dot(N, ndir);
+                            w = w > 0.0f ? w : 0.0f;
+                            // ... and by the share of the hemisphere the emitter's bounding ball covers, min(1, rho^2 / r^2)
+                            float cover = rho2 / dot(toward, toward);
+                            cover = cover < 1.0f ? cover : 1.0f;
+                            col = (col * mcol) * (w * cover);
+                        } else {
+                            col = col * mcol;
+                        }
+                    }
+                    if (diffuse && !toLight) {
                         float up, cOver, sOver;
                         hemisphereDraws(rng, up, cOver, sOver);
                         F3 p1, p2;                                // the sampler's tangent frame: computed for a sphere, looked up for a cube face

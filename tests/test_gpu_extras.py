@@ -1,0 +1,111 @@
+"""README extras on the HIP path against the oracle, bit for bit: imperfect specular driven by SPECEX
+(reference README.md:171-185), depth of field (:100-101), direct lighting (:107-108)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import SCENES
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu(pt):
+    if pt.device_count() < 1:
+        pytest.fail("no HIP device: GPU tests must run on the MI355X box")
+    return pt
+
+
+def _compare(gpu, oracle, sc, depth, iters, res, dump_bounces=(), **extras):
+    W, H = res
+    ref = oracle.Renderer(sc.camera.view(oracle.CAMERA_DTYPE), sc.geoms.view(oracle.GEOM_DTYPE),
+                          sc.materials.view(oracle.MATERIAL_DTYPE), depth)
+    ref.set_extras(**extras)
+    want = np.zeros(W * H * 3, np.float32)
+    live = np.zeros(64, np.int64)
+    gpu.pathtraceFree()
+    gpu.pathtraceInit(sc, traceDepth=depth, max_batch=4, pipeline_depth=2, **extras)
+    it = iters[0]
+    gpu.pathtrace_batch(None, 0, it, len(iters))
+    for k in iters:
+        live += np.array(ref.iterate(k, want).live[:64])
+    got = gpu.readback(W * H)
+    cnt = gpu.counters()
+    assert [int(cnt.live[d]) for d in range(1, depth + 3)] == live[1:depth + 3].tolist()
+    for b in dump_bounces:
+        o, d, c, pix = gpu.debug_trace_paths(iters[0], b, W * H)
+        wo, wd, wc, wpix = ref.dump_paths(iters[0], b)
+        assert np.array_equal(pix, wpix)
+        assert np.array_equal(o.view(np.uint32), wo.view(np.uint32)) and np.array_equal(d.view(np.uint32), wd.view(np.uint32))
+        assert np.array_equal(c.view(np.uint32), wc.view(np.uint32))
+    gpu.pathtraceFree()
+    assert want.max() > 0 and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    return got
+
+
+def test_pow_poly_bit_exact(gpu, oracle):
+    L = oracle.lib()
+    rng = np.random.default_rng(3)
+    x = np.concatenate([rng.uniform(0, 1, 20000), 2.0 ** rng.uniform(-31, 0, 20000), [0, 1, 1e-40, 0.5, 2 ** -31]]).astype(np.float32)
+    e = np.concatenate([1 / (rng.integers(0, 5000, 20000) + 1), rng.uniform(1e-4, 1, 20000), [0.5, 0.5, 0.5, 1.0, 1.0]]).astype(np.float32)
+    want = np.array([L.orc_pow(float(a), float(b)) for a, b in zip(x, e)], np.float32)
+    got = gpu.test_pow(x, e)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("exponent", [3.0, 40.0, 2000.0])
+def test_imperfect_specular(gpu, oracle, exponent):
+    sc = gpu.Scene(os.path.join(SCENES, "cornell.txt"))
+    sc.set_resolution(160, 120)
+    assert sc.materials["hasReflective"][4] > 0
+    sc.materials["specularExponent"][4] = exponent                   # SPECEX of the sphere's material
+    _compare(gpu, oracle, sc, 8, [1, 2, 3], (160, 120), dump_bounces=(1, 2))
+
+
+def test_imperfect_specular_changes_nothing_at_specex_zero(gpu, oracle):
+    sc = gpu.Scene(os.path.join(SCENES, "cornell.txt"))
+    sc.set_resolution(96, 64)
+    a = _compare(gpu, oracle, sc, 8, [1, 2], (96, 64))
+    sc.materials["specularExponent"][4] = 25.0
+    b = _compare(gpu, oracle, sc, 8, [1, 2], (96, 64))
+    assert not np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("scene,res", [("cornell.txt", (200, 120)), ("spheres64.txt", (96, 96))])
+def test_depth_of_field(gpu, oracle, scene, res):
+    sc = gpu.Scene(os.path.join(SCENES, scene))
+    sc.set_resolution(*res)
+    _compare(gpu, oracle, sc, 6, [1, 2, 3], res, dump_bounces=(0, 1), lens_radius=0.4, focal_distance=12.5)
+
+
+def test_direct_lighting(gpu, oracle):
+    sc = gpu.Scene(os.path.join(SCENES, "cornell_glass.txt"))
+    sc.set_resolution(160, 120)
+    got = _compare(gpu, oracle, sc, 3, [1, 2, 3, 4], (160, 120), dump_bounces=(3,), direct_lighting=True)
+    plain = _compare(gpu, oracle, sc, 3, [1, 2, 3, 4], (160, 120))
+    assert got.mean() > 1.2 * plain.mean()
+    with pytest.raises(gpu.PtError, match="traceDepth"):
+        gpu.pathtraceInit(sc, traceDepth=gpu.PT_MAX_DEPTH, direct_lighting=True)
+
+
+def test_all_extras_together_sharded(gpu, oracle):
+    sc = gpu.Scene(os.path.join(SCENES, "cornell.txt"))
+    sc.set_resolution(120, 90)
+    sc.materials["specularExponent"][4] = 12.0
+    extras = dict(lens_radius=0.25, focal_distance=11.0, direct_lighting=True)
+    W, H = 120, 90
+    ref = oracle.Renderer(sc.camera.view(oracle.CAMERA_DTYPE), sc.geoms.view(oracle.GEOM_DTYPE),
+                          sc.materials.view(oracle.MATERIAL_DTYPE), 4)
+    ref.set_extras(**extras)
+    want = np.zeros(W * H * 3, np.float32)
+    for it in (5, 6):
+        ref.iterate(it, want)
+    acc = np.zeros_like(want)
+    for r in range(3):
+        gpu.pathtraceFree()
+        gpu.pathtraceInit(sc, shard_rank=r, shard_count=3, traceDepth=4, max_batch=2, **extras)
+        gpu.pathtrace_batch(None, 0, 5, 2)
+        acc += gpu.readback(W * H)
+    gpu.pathtraceFree()
+    assert np.array_equal(acc.view(np.uint32), want.view(np.uint32))
