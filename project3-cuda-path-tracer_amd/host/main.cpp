@@ -4,6 +4,9 @@
 // output name <FILE>.<start time>.<N>samp.png, X mirrored, divided by the sample count.
 //
 //   pt_render SCENEFILE.txt [--res W H] [--iterations N] [--depth D] [--out BASENAME] [--hdr] [--batch B]
+//                           [--lens RADIUS FOCALDISTANCE] [--direct]
+// --lens / --direct switch on the README extras (depth of field, README.md:100-101; direct lighting, :107-108);
+// imperfect specular needs no switch, it is a material's SPECEX > 0 in the scene file (README.md:171-185).
 //
 // --batch B (B > 1) leaves the reference protocol where nothing can observe it: iterations are traced B at a time
 // through the C ABI (pt_iterate_batch) and the running sum is copied to the host once, before the image is saved,
@@ -27,6 +30,9 @@ static int width, height;
 static std::string outBase;
 static bool writeHdr = false;
 static int batch = 1;
+static float lensRadius = 0.0f, focalDistance = 0.0f;
+static bool directLighting = false;
+void pathtraceExtras(float lensRadius, float focalDistance, bool directLighting);   // pathtrace_shim.cpp
 
 static std::string currentTimeString() {
     time_t now;
@@ -82,6 +88,9 @@ static void renderBatched() {
     opt.device = -1;
     opt.max_batch = batch;
     opt.pipeline_depth = 2;        // two batches in flight are as fast as three and provision a third less memory
+    opt.lens_radius = lensRadius;
+    opt.focal_distance = focalDistance;
+    if (directLighting) opt.flags |= PT_FLAG_DIRECT_LIGHTING;
     check(pt_init((const PtCamera *)&renderState->camera, (const PtGeom *)scene->geoms.data(), (int)scene->geoms.size(),
                   (const PtMaterial *)scene->materials.data(), (int)scene->materials.size(), renderState->traceDepth, &opt),
           "pt_init");
@@ -99,7 +108,7 @@ static void renderBatched() {
 int main(int argc, char **argv) {
     startTimeString = currentTimeString();
     if (argc < 2) {
-        printf("Usage: %s SCENEFILE.txt [--res W H] [--iterations N] [--depth D] [--out BASENAME] [--hdr] [--batch B]\n", argv[0]);
+        printf("Usage: %s SCENEFILE.txt [--res W H] [--iterations N] [--depth D] [--out BASENAME] [--hdr] [--batch B] [--lens R F] [--direct]\n", argv[0]);
         return 1;
     }
     scene = new Scene(argv[1], true);
@@ -111,8 +120,11 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--out") && i + 1 < argc) outBase = argv[++i];
         else if (!strcmp(argv[i], "--hdr")) writeHdr = true;
         else if (!strcmp(argv[i], "--batch") && i + 1 < argc) batch = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--lens") && i + 2 < argc) { lensRadius = (float)atof(argv[i + 1]); focalDistance = (float)atof(argv[i + 2]); i += 2; }
+        else if (!strcmp(argv[i], "--direct")) directLighting = true;
         else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 1; }
     }
+    pathtraceExtras(lensRadius, focalDistance, directLighting);
     iteration = 0;
     width = renderState->camera.resolution.x;
     height = renderState->camera.resolution.y;

@@ -8,6 +8,8 @@
 #include "pt_amd.h"
 
 static Scene *hst_scene = NULL;
+static float extraLens = 0.0f, extraFocal = 0.0f;   // README extras (pathtraceExtras), off = the reference's renderer
+static bool extraDirect = false;
 
 static void checkPtError(int status, const char *msg) {
     if (status == PT_OK) return;
@@ -19,15 +21,29 @@ void pathtraceInit(Scene *scene) {
     hst_scene = scene;
     static_assert(sizeof(Geom) == sizeof(PtGeom) && sizeof(Material) == sizeof(PtMaterial) &&
                   sizeof(Camera) == sizeof(PtCamera), "layout contract of include/pt_amd.h");
+    PtOptions opt = PtOptions();        // all defaults = the reference's behaviour ...
+    opt.shard_count = 1;
+    opt.device = -1;
+    opt.lens_radius = extraLens;        // ... unless pathtraceExtras() switched a README extra on
+    opt.focal_distance = extraFocal;
+    if (extraDirect) opt.flags |= PT_FLAG_DIRECT_LIGHTING;
     checkPtError(pt_init(reinterpret_cast<const PtCamera *>(&scene->state.camera),
                          reinterpret_cast<const PtGeom *>(scene->geoms.data()), (int)scene->geoms.size(),
                          reinterpret_cast<const PtMaterial *>(scene->materials.data()), (int)scene->materials.size(),
-                         scene->state.traceDepth, NULL),
+                         scene->state.traceDepth, &opt),
                  "pathtraceInit");
     // state.image is owned by the Scene and lives from Init to Free: page-lock it for the per-iteration copy below
     // (an optimisation only; failure to register is not an error of the renderer)
     if (!scene->state.image.empty())
         (void)pt_pin_host(scene->state.image.data(), scene->state.image.size() * sizeof(scene->state.image[0]));
+}
+
+// Not a reference symbol: depth of field and direct lighting (README.md:100-101, :107-108) for the next pathtraceInit.
+// A host that never calls it gets exactly the reference's renderer.
+void pathtraceExtras(float lensRadius, float focalDistance, bool directLighting) {
+    extraLens = lensRadius;
+    extraFocal = focalDistance;
+    extraDirect = directLighting;
 }
 
 void pathtraceFree() {

@@ -109,3 +109,26 @@ def test_all_extras_together_sharded(gpu, oracle):
         acc += gpu.readback(W * H)
     gpu.pathtraceFree()
     assert np.array_equal(acc.view(np.uint32), want.view(np.uint32))
+
+
+def test_headless_driver_with_extras(gpu, oracle, tmp_path):
+    # pt_render --lens R F --direct: the shim's pathtraceExtras() (not a reference symbol) feeds PtOptions; both the
+    # per-iteration protocol and --batch must produce the oracle's picture
+    import subprocess
+    from test_host import _decode_png
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "project3-cuda-path-tracer_amd", "host", "pt_render")
+    sc = oracle.Scene(os.path.join(SCENES, "cornell.txt"))
+    sc.set_resolution(96, 64)
+    ref = oracle.Renderer(sc.camera, sc.geoms, sc.materials, 4)
+    ref.set_extras(lens_radius=0.3, focal_distance=12.0, direct_lighting=True)
+    img = np.zeros(96 * 64 * 3, np.float32)
+    for it in range(1, 5):
+        ref.iterate(it, img)
+    want = (np.clip(img.reshape(64, 96, 3) / np.float32(4), 0, 1) * np.float32(255)).astype(np.uint8)[:, ::-1]
+    for extra in ([], ["--batch", "4"]):
+        base = str(tmp_path / ("r" + str(len(extra))))
+        r = subprocess.run([exe, os.path.join(SCENES, "cornell.txt"), "--res", "96", "64", "--iterations", "4", "--depth", "4",
+                            "--out", base, "--lens", "0.3", "12", "--direct"] + extra, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert np.array_equal(_decode_png(base + ".png"), want)
