@@ -193,6 +193,10 @@ int pt_test_intersect(const PtGeom *geoms, int ngeoms, const int32_t *geom_index
  * of `geoms`; *violations = rays culled although the full test hits (must be 0), *culled = rays culled. */
 int pt_test_sphere_cull_sweep(const PtGeom *geoms, int ngeoms, uint64_t seed, int64_t rays, uint64_t *culled,
                               uint64_t *violations);
+/* wallCertainMiss (world-space culling of large cubes against their inflated bounding boxes, which classes the queue by
+ * the wall a path can still hit) soundness: as above, for the cubes of `geoms`. */
+int pt_test_wall_box_sweep(const PtGeom *geoms, int ngeoms, uint64_t seed, int64_t rays, uint64_t *culled,
+                           uint64_t *violations);
 /* slabQuotients (shared-reciprocal packed division of the box test) next to the compiler's correctly
  * rounded `/`: per-element outputs, and a device-side pseudo-random sweep that returns the number of
  * bit mismatches over `pairs` (o, d) pairs (must be 0). */

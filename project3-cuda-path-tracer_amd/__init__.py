@@ -51,7 +51,7 @@ ABI_SYMBOLS = [
     "pt_scan_exclusive_i32", "pt_compact_nonzero_i32", "pt_test_utilhash", "pt_test_rng",
     "pt_test_intersect", "pt_test_hemisphere", "pt_test_sincos", "pt_test_reflect_refract",
     "pt_test_slab_quotients", "pt_test_slab_quotients_sweep", "pt_test_sphere_cull_sweep",
-    "pt_test_unscaled_sqrt_sweep", "pt_pin_host", "pt_unpin_host", "pt_test_force_fault", "pt_test_pow",
+    "pt_test_unscaled_sqrt_sweep", "pt_pin_host", "pt_unpin_host", "pt_test_force_fault", "pt_test_pow", "pt_test_wall_box_sweep",
 ]
 
 
@@ -119,6 +119,7 @@ def lib():
         L.pt_unpin_host.argtypes = []
         L.pt_test_force_fault.argtypes = [i32]
         L.pt_test_pow.argtypes = [vp, vp, i32, vp]
+        L.pt_test_wall_box_sweep.argtypes = [vp, i32, C.c_uint64, i64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         _lib = L
     return _lib
 
@@ -392,6 +393,13 @@ def test_sphere_cull_sweep(geoms, seed, rays):
     geoms = np.ascontiguousarray(geoms)
     culled, bad = C.c_uint64(0), C.c_uint64(0)
     _check(lib().pt_test_sphere_cull_sweep(_p(geoms), len(geoms), seed, rays, C.byref(culled), C.byref(bad)))
+    return int(culled.value), int(bad.value)
+
+
+def test_wall_box_sweep(geoms, seed, rays):
+    geoms = np.ascontiguousarray(geoms)
+    culled, bad = C.c_uint64(0), C.c_uint64(0)
+    _check(lib().pt_test_wall_box_sweep(_p(geoms), len(geoms), seed, rays, C.byref(culled), C.byref(bad)))
     return int(culled.value), int(bad.value)
 
 

@@ -91,6 +91,7 @@ struct State {
     Slot slot[kMaxSlots];
     GeomDev *dgeoms = nullptr;
     MaterialDev *dmats = nullptr;
+    WallBox *dwalls = nullptr;
     int numTilesMax = 0;    // upper bound of tiles in one bounce queue (incl. one partial tile per segment)
     int poolChunks = 0;     // chunks per path pool (incl. the trash chunk 0); a pool holds poolChunks * kChunk paths per array
     int grid = 0;           // persistent grid of k_bounce<false>
@@ -225,6 +226,43 @@ void pack_geom(const PtGeom &g, GeomDev &d, const float *eye = nullptr) {
         }
     }
 }
+// World-space box of a cube, INFLATED for ptd::wallCertainMiss: the 8 corners of the unit cube through `transform` in double
+// precision, widened by delta = 4e-5 S, S = max(diagonal of the box, largest |coordinate|), and rounded outwards to float.
+// Why 4e-5: a scattered ray starts 1e-3 off the surface it leaves (spec S6), and the certificate has to be able to tell
+// that it leaves -- delta must stay below that offset for a scene of Cornell's size (S = 14: delta = 5.7e-4) -- while the
+// reference's own evaluation moves the boundary by ~2e-7 (|o| + S) (object-space transform, thin axis: products of
+// magnitude 100 |o| rounded to 2^-24, scaled back by 1/100), i.e. 1.2e-5 for |o| + S <= 60 = *omax: a margin of 47x.
+// Returns S (a negative value when the cube is not finite); *omax receives the largest |x| + |y| + |z| of a ray origin
+// for which that margin holds, 5 S - (largest |coordinate|).
+double wall_box(const PtGeom &g, WallBox &w, double *omax = nullptr) {
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int corner = 0; corner < 8; ++corner) {
+        const double o[3] = {(corner & 1) ? 0.5 : -0.5, (corner & 2) ? 0.5 : -0.5, (corner & 4) ? 0.5 : -0.5};
+        for (int r = 0; r < 3; ++r) {
+            const double q = (double)g.transform[0 + r] * o[0] + (double)g.transform[4 + r] * o[1] + (double)g.transform[8 + r] * o[2] +
+                             (double)g.transform[12 + r];
+            if (!std::isfinite(q)) return -1.0;
+            lo[r] = std::min(lo[r], q);
+            hi[r] = std::max(hi[r], q);
+        }
+    }
+    double diag = 0, big = 0;
+    for (int r = 0; r < 3; ++r) {
+        diag += (hi[r] - lo[r]) * (hi[r] - lo[r]);
+        big = std::max(big, std::max(std::fabs(lo[r]), std::fabs(hi[r])));
+    }
+    const double S_ = std::max(std::sqrt(diag), big);
+    const double delta = 4e-5 * S_;
+    if (omax) *omax = 5.0 * S_ - big;
+    memset(&w, 0, sizeof w);
+    for (int r = 0; r < 3; ++r) {
+        w.lo[r] = std::nextafter((float)(lo[r] - delta), -INFINITY);
+        w.hi[r] = std::nextafter((float)(hi[r] + delta), INFINITY);
+        if (!std::isfinite(w.lo[r]) || !std::isfinite(w.hi[r])) return -1.0;
+    }
+    return S_;
+}
+
 // n / d for every n < 2^27 as (n * magic) >> shift: with s = ceil(log2 d), shift = 28 + s and magic = ceil(2^shift / d)
 // (< 2^29) the error e = magic * d - 2^shift is below d <= 2^s, so n * e < 2^(27 + s) < 2^shift and the quotient is exact
 // (Granlund-Montgomery); n * magic < 2^56 fits the 64-bit product.
@@ -343,6 +381,7 @@ int launch_bounce(Slot &sl, int iter, int batch, int depth, bool lastBounce, flo
     ba.genIn = genIn; ba.genOut = genOut;
     ba.in = in; ba.out = out;
     ba.ctrl = sl.ctrl; ba.ggeoms = S.dgeoms; ba.gmats = S.dmats; ba.contrib = contrib;
+    ba.walls = S.dwalls;
 #define PT_LAUNCH_BOUNCE(FIRST_, MANY_, GRID_) \
     hipLaunchKernelGGL((k_bounce<FIRST_, MANY_>), dim3(GRID_), dim3(kBlock), S.ldsBytes, sl.stream, ba)
 #define PT_LAUNCH_BOUNCE3(FIRST_, MANY_, DOF_, GRID_) \
@@ -507,6 +546,7 @@ void pt_free(void) {
     if (S.ownImage && S.image) (void)hipFree(S.image);
     if (S.dgeoms) (void)hipFree(S.dgeoms);
     if (S.dmats) (void)hipFree(S.dmats);
+    if (S.dwalls) (void)hipFree(S.dwalls);
     S = State();
 }
 
@@ -697,6 +737,35 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
             hg[cand[c].second].cullFlags |= 2;
         }
     }
+    // Walls: the large cubes -- not binned, finite -- at most kWallMax of them, the largest first.  Survivors are classed by
+    // the one wall they can still hit (ptd::wallCertainMiss against the inflated world boxes computed here), so a tile of
+    // the next bounce tests one wall instead of all of them, and a survivor that can hit nothing at all ends at once.
+    // A choice that only steers which tiles skip which tests; results never depend on it.
+    std::vector<WallBox> hw(kWallMax);
+    {
+        std::vector<std::pair<double, int>> cand;
+        for (int i = 0; i < ngeoms; ++i)
+            if (geoms[i].type == PT_CUBE && !hg[i].binned) cand.emplace_back(-(double)hg[i].boundR, i);
+        std::sort(cand.begin(), cand.end());
+        k.nWalls = 0;
+        double omaxAll = INFINITY;
+        for (size_t c = 0; c < cand.size() && k.nWalls < kWallMax; ++c) {
+            WallBox wb;
+            double om = 0;
+            const double b = wall_box(geoms[cand[c].second], wb, &om);
+            if (b < 0) continue;
+            omaxAll = std::min(omaxAll, om);
+            hw[k.nWalls] = wb;
+            hg[cand[c].second].flags |= (k.nWalls + 1) << 2;
+            hg[cand[c].second].cullFlags |= (k.nWalls + 1) << 2;
+            ++k.nWalls;
+        }
+        if (const char *e = getenv("PT_AMD_NO_WALLS")) { if (atoi(e)) { for (int i = 0; i < ngeoms; ++i) { hg[i].flags &= 3; hg[i].cullFlags &= 3; } k.nWalls = 0; } }   // experiments only
+        k.wallOMax = k.nWalls > 0 ? (float)omaxAll : 0.0f;     // the margin must hold for every wall
+        k.allClassified = k.nWalls > 0 ? 1 : 0;
+        for (int i = 0; i < ngeoms; ++i)
+            if (!hg[i].binned && (hg[i].flags & 28) == 0) k.allClassified = 0;
+    }
     k.emittersBinned = k.nBinned > 0 ? 1 : 0;
     for (int i = 0; i < ngeoms; ++i)
         if (mats[geoms[i].materialid].emittance > 0.0f && !hg[i].binned) k.emittersBinned = 0;
@@ -704,6 +773,8 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     HIPCHECK(hipMalloc(&S.dmats, hm.size() * sizeof(MaterialDev)));
     HIPCHECK(hipMemcpy(S.dgeoms, hg.data(), hg.size() * sizeof(GeomDev), hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(S.dmats, hm.data(), hm.size() * sizeof(MaterialDev), hipMemcpyHostToDevice));
+    HIPCHECK(hipMalloc(&S.dwalls, hw.size() * sizeof(WallBox)));
+    HIPCHECK(hipMemcpy(S.dwalls, hw.data(), hw.size() * sizeof(WallBox), hipMemcpyHostToDevice));
 
     int nspheres = 0;
     for (int i = 0; i < ngeoms; ++i) nspheres += geoms[i].type == PT_SPHERE;
@@ -1159,6 +1230,44 @@ int pt_test_sphere_cull_sweep(const PtGeom *geoms, int ngeoms, uint64_t seed, in
     if (blocks < 1) blocks = 1;
     if (blocks > (1 << 20)) blocks = 1 << 20;
     hipLaunchKernelGGL(k_sweep_sphere_cull, dim3((unsigned)blocks), dim3(threads), 0, 0, dg.p, ngeoms, (unsigned long long)seed,
+                       per_thread, cnt.p, cnt.p + 1);
+    HIPCHECK(hipDeviceSynchronize());
+    unsigned long long h[2] = {0, 0};
+    HIPCHECK(hipMemcpy(h, cnt.p, 16, hipMemcpyDeviceToHost));
+    *culled = h[0];
+    *violations = h[1];
+    return PT_OK;
+}
+
+int pt_test_wall_box_sweep(const PtGeom *geoms, int ngeoms, uint64_t seed, int64_t rays, uint64_t *culled, uint64_t *violations) {
+    NEED_GPU();
+    if (!geoms || ngeoms < 1 || !culled || !violations || rays < 0) return fail(PT_ERR_INVALID, "pt_test_wall_box_sweep: bad argument");
+    std::vector<GeomDev> hg(ngeoms);
+    std::vector<WallBox> hw(ngeoms);
+    std::vector<float> omax(ngeoms);
+    for (int i = 0; i < ngeoms; ++i) {
+        if (geoms[i].type != PT_CUBE) return fail(PT_ERR_INVALID, "pt_test_wall_box_sweep: cubes only");
+        pack_geom(geoms[i], hg[i]);
+        double om = 0;
+        const double b = wall_box(geoms[i], hw[i], &om);
+        if (b < 0) return fail(PT_ERR_INVALID, "pt_test_wall_box_sweep: cube %d is not finite", i);
+        omax[i] = (float)om;                      // pt_init's bound, for a scene that consists of this wall alone
+    }
+    DevBuf<GeomDev> dg;
+    DevBuf<WallBox> dw;
+    DevBuf<float> dm;
+    DevBuf<unsigned long long> cnt;
+    UP(dg, hg.data(), ngeoms);
+    UP(dw, hw.data(), ngeoms);
+    UP(dm, omax.data(), ngeoms);
+    int rc = cnt.alloc(2);
+    if (rc) return rc;
+    HIPCHECK(hipMemset(cnt.p, 0, 16));
+    const int per_thread = 256, threads = 256;
+    long long blocks = (rays + (long long)per_thread * threads - 1) / ((long long)per_thread * threads);
+    if (blocks < 1) blocks = 1;
+    if (blocks > (1 << 20)) blocks = 1 << 20;
+    hipLaunchKernelGGL(k_sweep_wall_box, dim3((unsigned)blocks), dim3(threads), 0, 0, dg.p, dw.p, dm.p, ngeoms, (unsigned long long)seed,
                        per_thread, cnt.p, cnt.p + 1);
     HIPCHECK(hipDeviceSynchronize());
     unsigned long long h[2] = {0, 0};

@@ -104,7 +104,7 @@ struct GeomDev {
     // inverseTransform's translation column times 0.0f (a signed zero each, or NaN): the w = 0 products of a direction
     // transform, multiplyMV(inverseTransform, (d, 0)), evaluated once instead of once per ray
     float invZ[3];
-    int   flags;     // bit 0: type (0 sphere, 1 cube), bit 1: binned
+    int   flags;     // bit 0: type (0 sphere, 1 cube), bit 1: binned, bits 2-4: 1 + index among the scene's walls (0: not one)
     // ---- 0x40: camera rays (first bounce only)
     // object-space camera position multiplyMV(inverseTransform, (eye, 1)), evaluated once on the host with the
     // same operation order: every camera ray of the first bounce shares it
@@ -461,6 +461,34 @@ __device__ __forceinline__ bool certainMiss(const GD &g, F3 org, F3 dir, float d
     const float oo = dot(oc, oc);
     const float od = dot(oc, dir);
     return oo * dd - od * od > (g.cullR2 + g.cullK * oo) * dd;
+}
+
+// Certain miss of a LARGE cube (a "wall"), decided in world space against its axis-aligned bounding box for ~25
+// instructions: the classic slab test on the box INFLATED by delta = 4e-5 of its extent (wall_box in pt_api.hip, double
+// precision, rounded outwards), with approximate arithmetic (v_rcp_f32 reciprocals of the direction, supplied by the
+// caller).  Like certainMiss it is not an approximation of the result but a sufficient condition for the reference's own
+// miss (intersections.h:70: `tmax >= tmin && tmax > 0` fails):
+//   every computed t carries a relative error below 3e-7 (one subtraction, one reciprocal, one product), so
+//   `tmin - tmax > 1e-5 (|tmin| + |tmax|)` or `tmax < 0` implies that the exact line misses the inflated box, i.e. stays
+//   delta away from the cube itself; the reference's evaluation (transform to object space, normalisation, three
+//   divisions) moves that decision by less than ~2e-7 of the coordinates involved -- bounded by the caller, which
+//   only certifies rays whose origin lies within KParams::wallOMax of the world origin -- a margin of 40x and more
+//   (tests/test_gpu_parity.py::test_wall_boxes_never_reject_a_hit sweeps 2^28 rays dense in grazes, 0 violations).
+// Infinities (a direction component of 0) and NaNs fail the comparisons, i.e. fall through to the full test.
+struct WallBox {
+    float lo[3];
+    float hi[3];
+    float pad[2];
+};
+static_assert(sizeof(WallBox) == 32, "one s_load_dwordx8");
+template <typename WB>
+__device__ __forceinline__ bool wallCertainMiss(const WB &w, F3 o, F3 inv) {
+    const float tx1 = (w.lo[0] - o.x) * inv.x, tx2 = (w.hi[0] - o.x) * inv.x;
+    const float ty1 = (w.lo[1] - o.y) * inv.y, ty2 = (w.hi[1] - o.y) * inv.y;
+    const float tz1 = (w.lo[2] - o.z) * inv.z, tz2 = (w.hi[2] - o.z) * inv.z;
+    const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tx1, tx2), __builtin_fminf(ty1, ty2)), __builtin_fminf(tz1, tz2));
+    const float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx1, tx2), __builtin_fmaxf(ty1, ty2)), __builtin_fmaxf(tz1, tz2));
+    return (tmin - tmax > 1e-5f * (__builtin_fabsf(tmin) + __builtin_fabsf(tmax))) | (tmax < 0.0f);
 }
 
 // src/intersections.h:101-143 (pow(radius, 2) == 0.25f in the float overload nvcc selects).

@@ -80,6 +80,48 @@ __global__ void k_sweep_sphere_cull(const GeomDev *geoms, int ngeoms, unsigned l
     if (nv) atomicAdd(violations, (unsigned long long)nv);
 }
 
+// wallCertainMiss soundness sweep: pseudo-random rays against every cube of `geoms` and its inflated world box `walls`
+// (origins inside the |x| + |y| + |z| bound the render kernel certifies under, from touching the cube to far away; aimed at
+// points on and around the cube so that grazes, edge-on plates and corner passes are dense; directions with exact zeros
+// mixed in); counts certified misses and VIOLATIONS (certified although the full test returns a hit).
+__global__ void k_sweep_wall_box(const GeomDev *geoms, const WallBox *walls, const float *omax, int ngeoms, unsigned long long seed,
+                                 int per_thread, unsigned long long *culled, unsigned long long *violations) {
+    unsigned long long x = seed + (blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ull;
+    unsigned int nc = 0, nv = 0;
+    for (int k = 0; k < per_thread; ++k) {
+        float u[10];
+        for (int j = 0; j < 10; ++j) {
+            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+            u[j] = (float)(x >> 40) * (1.0f / 16777216.0f);
+        }
+        const int gi = (blockIdx.x + k) % ngeoms;
+        const GeomDev G = geoms[gi];
+        const WallBox W = walls[gi];
+        const F3 lo = f3(W.lo[0], W.lo[1], W.lo[2]), hi = f3(W.hi[0], W.hi[1], W.hi[2]);
+        const F3 c = (lo + hi) * 0.5f, h = (hi - lo) * 0.5f;
+        // a target on / near the box: inside it, or on a shell 0.9 .. 1.2 of its half extents (where the margin matters)
+        const float shell = u[9] < 0.5f ? 0.9f + 0.3f * u[8] : u[8];
+        const F3 tgt = c + f3((2 * u[0] - 1) * h.x, (2 * u[1] - 1) * h.y, (2 * u[2] - 1) * h.z) * shell;
+        const float dist = __builtin_exp2f(u[3] * 14.0f - 8.0f) * (h.x + h.y + h.z);     // 2^-8 .. 2^6 box sizes away
+        F3 od = normalize(f3(u[4] - 0.5f, u[5] - 0.5f, u[6] - 0.5f));
+        if (u[7] < 0.15f) od = f3(u[7] < 0.05f ? 1.0f : 0.0f, (u[7] >= 0.05f && u[7] < 0.1f) ? 1.0f : 0.0f, u[7] >= 0.1f ? 1.0f : 0.0f);   // axis-parallel
+        const F3 org = tgt + od * dist;
+        F3 dir = normalize(tgt - org);
+        if (u[7] > 0.9f) dir = -dir;
+        const float l1 = (__builtin_fabsf(org.x) + __builtin_fabsf(org.y)) + __builtin_fabsf(org.z);
+        if (!(l1 <= omax[gi])) continue;
+        const F3 inv = f3(__builtin_amdgcn_rcpf(dir.x), __builtin_amdgcn_rcpf(dir.y), __builtin_amdgcn_rcpf(dir.z));
+        if (wallCertainMiss(W, org, inv)) {
+            ++nc;
+            F3 P, N;
+            bool o;
+            if (boxIntersectionTest<false>(G, org, dir, P, N, o) != -1.0f) ++nv;
+        }
+    }
+    if (nc) atomicAdd(culled, (unsigned long long)nc);
+    if (nv) atomicAdd(violations, (unsigned long long)nv);
+}
+
 // slabQuotients vs the compiler's correctly rounded division; counts mismatching lanes
 __global__ void k_test_slab_quotients(const float *o, const float *d, int n, float *t1, float *t2, float *r1, float *r2) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;

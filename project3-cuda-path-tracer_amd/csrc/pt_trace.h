@@ -19,6 +19,7 @@ constexpr int kSub = 4;              // append-counter shards per class (workgro
 constexpr int kSeg = kCls * kSub;    // path buffers are split into kSeg segments with one append counter each
 constexpr int kBinMax = 4;           // at most this many small primitives take part in the binning
 constexpr int kEmitMax = 8;          // emissive primitives the direct-lighting bounce chooses from
+constexpr int kWallMax = 6;          // large cubes ("walls") whose world-space boxes class the survivors (wallCertainMiss)
 // Path state lives in POOLS of fixed-size chunks (2^chunkShift paths each, chosen by pt_init): a segment of a bounce's
 // queue is a list of chunks, handed out by an atomic bump counter while the segment is filled, so a pool is sized for the
 // paths that can be alive (pixels x batch, plus two chunks of slack per segment) and not for the worst case of every path
@@ -68,6 +69,12 @@ struct KParams {
     int   emittersBinned; // every primitive with an emissive material is one of binGeom[]
     int   nBinned;      // 1..kBinMax small primitives (spheres, small cubes): survivors are binned by whether they can
     int   binGeom[kBinMax];   // hit one of them (certainMiss of each); 0: off, every path counts as a candidate
+    // ---- walls: the scene's large cubes (non-binned, at most kWallMax).  With walls the three low class bits of a survivor
+    // are not its direction octant but WHICH wall it can still hit: 0..5 = that wall only (every other wall certified
+    // missed by wallCertainMiss), 6 = several or uncertified, 7 = none
+    int   nWalls;
+    int   allClassified;  // every primitive is a wall or binned: a survivor that certainly misses all of them is a miss, now
+    float wallOMax;       // certificates are only issued for ray origins with |x| + |y| + |z| <= wallOMax
     // ---- README extras, all off by default
     float lensRadius, focalDistance;   // thin lens (depth of field, README.md:100-101); radius 0 = pinhole
     float viewN[3];                    // normalize(view)
@@ -272,9 +279,11 @@ struct BounceArgs {
     const GeomDev *ggeoms;
     const MaterialDev *gmats;
     float *contrib;
+    const WallBox *walls;               // [prm.nWalls] inflated world-space boxes of the walls
 };
 typedef const PT_CAS BounceArgs *ArgsPtr;
 typedef const PT_CAS GeomDev *GeomPtr;
+typedef const PT_CAS WallBox *WallPtr;
 // the culling group of a GeomDev (offset 0x60), as one 32-byte scalar load
 struct CullGroup {
     float centre[3];
@@ -400,6 +409,7 @@ __global__ __launch_bounds__(kBlock, (MANY || DOF) ? 5 : 8) void k_bounce(Bounce
     __syncthreads();
 
     uint32_t nLight = 0, nMiss = 0;         // per-lane tallies (VGPRs are the less scarce kind here), reduced and flushed once at the end
+    uint32_t nEarly = 0;                    // survivors that certainly miss everything: ended at the scatter
     uint32_t sgIn = 0;                      // input segment of the current tile (tiles are visited in increasing order)
     uint32_t firstK = 0;                    // FIRST: how many tiles this workgroup has processed
     for (uint32_t T = blockIdx.x; T < numTiles; T += gridDim.x) {
@@ -411,6 +421,7 @@ __global__ __launch_bounds__(kBlock, (MANY || DOF) ? 5 : 8) void k_bounce(Bounce
         bool valid;
         uint32_t idx = 0;
         bool smallTile = true;              // wave-uniform: this tile's paths may hit a small (binned) primitive
+        uint32_t tileWall = 6u;             // wave-uniform: the one wall this tile's paths can hit (0..5), 6: any, 7: none
         if (FIRST) {
             const ArgsPtr A = launder(kargs);
             const PT_CAS KParams &prm = A->prm;
@@ -452,6 +463,7 @@ __global__ __launch_bounds__(kBlock, (MANY || DOF) ? 5 : 8) void k_bounce(Bounce
             const uint32_t local = (T - s_segpre[sgIn]) * kBlock + tid;
             valid = local < s_segcnt[sgIn];
             smallTile = ((sgIn / kSub) & 8u) != 0u;
+            tileWall = A->prm.nWalls > 0 ? (sgIn / kSub) & 7u : 6u;
             // The last bounce only asks whether a path ends on an emitter (S7: no scatter).  When every emitter of the scene
             // is a binned small primitive, the paths of a non-candidate tile certainly miss all of them: nothing to add.
             if (A->lastBounce && A->prm.emittersBinned && !smallTile) continue;
@@ -471,6 +483,7 @@ __global__ __launch_bounds__(kBlock, (MANY || DOF) ? 5 : 8) void k_bounce(Bounce
 
         bool alive = false;
         bool smallCand = true;                                  // class bit 3 of a survivor
+        uint32_t wallSel = 8u;                                  // class bits 0-2 of a survivor in a scene with walls (8: no walls: the octant)
         bool lightHit = false, missed = false;
         F3 org = f3(0, 0, 0), dir = f3(0, 0, 1), col = f3(0, 0, 0);
         int pix = 0, rem = 0;
@@ -566,6 +579,8 @@ __global__ __launch_bounds__(kBlock, (MANY || DOF) ? 5 : 8) void k_bounce(Bounce
                     float t = -1.0f;
                     if (FIRST && !DOF && (px < G.rect[0] || px > G.rect[2] || py < G.rect[1] || py > G.rect[3])) continue;
                     if (!FIRST && !smallTile && (flags & 2)) continue;  // this tile's paths certainly miss every binned primitive
+                    // ... and every wall but (at most) one
+                    if (!FIRST && tileWall != 6u && (flags & 28) != 0 && (uint32_t)((flags >> 2) & 7) != tileWall + 1u) continue;
                     if ((flags & 1) == 0) {
                         probe(3);
                         if (!certainMiss(cg, org, dir, dd)) {
@@ -735,6 +750,30 @@ __global__ __launch_bounds__(kBlock, (MANY || DOF) ? 5 : 8) void k_bounce(Bounce
                                 smallCand = smallCand || !certainMiss(*(launder(geoms) + A->prm.binGeom[sI]), norg, ndir, ndd);
                         }
                     }
+                    {                                            // class bits 0-2 with walls: which of them can the new ray still hit?
+                        const ArgsPtr A = launder(kargs);
+                        const int nWalls = A->prm.nWalls;
+                        if (nWalls > 0) {
+                            wallSel = 6u;
+                            const float l1 = (__builtin_fabsf(norg.x) + __builtin_fabsf(norg.y)) + __builtin_fabsf(norg.z);
+                            if (l1 <= A->prm.wallOMax) {          // (NaN fails)
+                                const F3 inv = f3(__builtin_amdgcn_rcpf(ndir.x), __builtin_amdgcn_rcpf(ndir.y), __builtin_amdgcn_rcpf(ndir.z));
+                                const WallPtr walls = (WallPtr)(A->walls);
+                                uint32_t possible = 0u;
+                                for (int w = 0; w < nWalls; ++w)
+                                    possible |= wallCertainMiss(*(launder(walls) + w), norg, inv) ? 0u : (1u << w);
+                                const int cnt = __popc(possible);
+                                wallSel = cnt == 1 ? (uint32_t)(__ffs((int)possible) - 1) : (cnt == 0 ? 7u : 6u);
+                                // nothing left to hit: the reference's nearest-hit loop would come back empty at the next bounce.
+                                // The path ends here and is tallied as what it is, a path that entered that bounce and missed.
+                                // (Not under pt_debug_trace_paths, which shows the queue as the oracle lists it.)
+                                if (cnt == 0 && !smallCand && A->prm.allClassified && A->contrib) {
+                                    alive = false;
+                                    ++nEarly;
+                                }
+                            }
+                        }
+                    }
                 }
             }
         }
@@ -746,9 +785,12 @@ __global__ __launch_bounds__(kBlock, (MANY || DOF) ? 5 : 8) void k_bounce(Bounce
             uint32_t *wv = s_wave;
             // same-class mask of this lane from four bit ballots (the sign compares already are the ballots)
             const unsigned long long ba = __ballot(alive);
-            const unsigned long long b0 = __ballot(dir.x < 0.0f), b1 = __ballot(dir.y < 0.0f), b2 = __ballot(dir.z < 0.0f);
+            // class bits 0-2: the wall the ray can still hit (scenes with walls) or the octant of its direction
+            const bool c0 = wallSel < 8u ? (wallSel & 1u) != 0u : dir.x < 0.0f;
+            const bool c1 = wallSel < 8u ? (wallSel & 2u) != 0u : dir.y < 0.0f;
+            const bool c2 = wallSel < 8u ? (wallSel & 4u) != 0u : dir.z < 0.0f;
+            const unsigned long long b0 = __ballot(c0), b1 = __ballot(c1), b2 = __ballot(c2);
             const unsigned long long b3 = __ballot(smallCand);
-            const bool c0 = dir.x < 0.0f, c1 = dir.y < 0.0f, c2 = dir.z < 0.0f;
             const uint32_t cls = (c0 ? 1u : 0u) | (c1 ? 2u : 0u) | (c2 ? 4u : 0u) | (smallCand ? 8u : 0u);
             const unsigned long long same = ba & (c0 ? b0 : ~b0) & (c1 ? b1 : ~b1) & (c2 ? b2 : ~b2) & (smallCand ? b3 : ~b3);
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(same >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)same, 0u));
@@ -792,12 +834,14 @@ __global__ __launch_bounds__(kBlock, (MANY || DOF) ? 5 : 8) void k_bounce(Bounce
             if (lane < kCls) wv[wave * kCls + lane] = 0u;
         }
     }
-    const uint32_t waveLight = waveSum(nLight), waveMiss = waveSum(nMiss);
+    const uint32_t waveLight = waveSum(nLight), waveEarly = waveSum(nEarly), waveMiss = waveSum(nMiss) + waveEarly;
     if ((threadIdx.x & 63) == 0) {
-        Ctrl *const ctrl = launder(kargs)->ctrl;
+        const ArgsPtr A = launder(kargs);
+        Ctrl *const ctrl = A->ctrl;
         const int shard = blockIdx.x % kOct;
         if (waveLight) atomicAdd(&ctrl->light_hits[shard][0], (unsigned long long)waveLight);
         if (waveMiss) atomicAdd(&ctrl->misses[shard][0], (unsigned long long)waveMiss);
+        if (waveEarly) atomicAdd(&ctrl->sum_live[A->depth + 1], (unsigned long long)waveEarly);   // they did enter the next bounce
     }
 }
 

@@ -151,6 +151,30 @@ def test_cube_culling_never_rejects_a_hit(gpu, oracle):
     assert culled > (1 << 28) // 16            # (the elongated shapes carry wide margins and are rarely culled)
 
 
+def test_wall_boxes_never_reject_a_hit(gpu, oracle):
+    # the world-space slab test against a large cube's inflated bounding box (ptd::wallCertainMiss) classes the queue by the
+    # one wall a path can still hit and ends paths that can hit nothing: it must imply the reference's own miss for every
+    # cube it may be handed -- the Cornell walls (1000:1 plates, one of them rotated by 90 degrees with its 4e-8 matrix
+    # entries), the light, rotated and oblique boxes, tiny and huge ones, far from the origin
+    geoms = np.concatenate([
+        oracle.make_geom(1, 0, (0, 0, 0), (0, 0, 90), (0.01, 10, 10)),        # Cornell floor
+        oracle.make_geom(1, 0, (0, 10, 0), (0, 0, 90), (0.01, 10, 10)),       # ceiling
+        oracle.make_geom(1, 0, (0, 5, -5), (0, 90, 0), (0.01, 10, 10)),       # back wall
+        oracle.make_geom(1, 0, (-5, 5, 0), (0, 0, 0), (0.01, 10, 10)),        # left wall
+        oracle.make_geom(1, 0, (0, 10, 0), (0, 0, 0), (3, 0.3, 3)),           # light
+        oracle.make_geom(1, 0, (1, 2, 3), (30, 45, 60), (1, 2, 3)),
+        oracle.make_geom(1, 0, (0, 0, 0), (0, 0, 0), (1, 1, 1)),              # the unit cube itself
+        oracle.make_geom(1, 0, (2.5, 6, -2), (10, 20, 30), (0.05, 0.05, 0.05)),
+        oracle.make_geom(1, 0, (-3, 1, 2), (75, -20, 130), (8, 0.5, 3)),
+        oracle.make_geom(1, 0, (100, -50, 25), (45, 45, 45), (40, 40, 40)),
+        oracle.make_geom(1, 0, (-2, 3, 1), (20, 70, -35), (5, 0.1, 5)),
+        oracle.make_geom(1, 0, (0, -1, 0), (0, 0, 0), (30, 1, 30)),           # a ground slab
+    ]).view(gpu.GEOM_DTYPE)
+    culled, bad = gpu.test_wall_box_sweep(geoms, 4242, 1 << 28)
+    assert bad == 0
+    assert culled > (1 << 28) // 16            # the certificate actually fires (most sweep rays are aimed at the cube)
+
+
 def test_reflect_refract_bit_exact(gpu):
     z = np.load(os.path.join(GOLD, "glm_ops.npz"))
     r1, r2 = gpu.test_reflect_refract(z["An"], z["Bn"], z["eta"])
