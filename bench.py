@@ -258,12 +258,15 @@ def main():
 
     iters_timed = args.steps * B
     live = [int(cnt.live[d]) for d in range(D + 2)]
+    # paths that actually travel through the path pools: a survivor that certainly misses everything ends at its scatter and
+    # is counted in live[d + 1] (it does enter that bounce and miss) without ever being written or read
+    moved = [int(cnt.live[d]) - int(cnt.ended_early[d]) for d in range(D + 2)]
     hits = int(cnt.light_hits)
-    # algorithmic HBM bytes of the bounce launches: read every live path (bounce 1 builds its camera
-    # rays in registers and reads nothing), write every survivor (nothing is written after the last
+    # algorithmic HBM bytes of the bounce launches: read every queued path (bounce 1 builds its camera
+    # rays in registers and reads nothing), write every queued survivor (nothing is written after the last
     # bounce), park the radiance of every emitter hit
-    bounce_bytes = sum(PATH_BYTES * live[d] for d in range(2, D + 1)) \
-        + sum(PATH_BYTES * live[d + 1] for d in range(1, D)) + ACCUM_BYTES * hits
+    bounce_bytes = sum(PATH_BYTES * moved[d] for d in range(2, D + 1)) \
+        + sum(PATH_BYTES * moved[d + 1] for d in range(1, D)) + ACCUM_BYTES * hits
     launches = max(int(cnt.bounce_launches), 1)
     iters_per_launch = maxb
     avg_ms = cnt.bounce_kernel_ms / launches
@@ -325,6 +328,7 @@ def main():
                        "batches_in_flight": args.pipeline if args.pipeline > 0 else 3,
                        "collective_every": None if world == 1 else every,
                        "live_segments_per_iteration": round(sum(live[1:D + 1]) / max(iters_timed, 1), 1),
+                       "queued_segments_per_iteration": round(sum(moved[1:D + 1]) / max(iters_timed, 1), 1),
                        "live_Msegments_per_s": round(sum(int(cntA.live[d]) for d in range(1, D + 1)) / dt / 1e6, 2)},
             "roofline": rf,
         }

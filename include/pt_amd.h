@@ -116,6 +116,9 @@ typedef struct PtCounters {
     double  bounce_kernel_ms;       /* sum of HIP-event durations (PT_FLAG_KERNEL_TIMING only)          */
     double  raygen_kernel_ms;
     int64_t raygen_launches;
+    int64_t ended_early[PT_MAX_DEPTH + 2]; /* of live[d]: paths whose scatter at bounce d - 1 certainly misses every primitive (scenes
+                                              whose primitives are all walls or binned): tallied as entering bounce d and missing,
+                                              which is what they do, but never written to or read from the path pools */
 } PtCounters;
 
 /* pathtraceInit: upload scene, allocate the accumulator and the SoA path-state buffers.

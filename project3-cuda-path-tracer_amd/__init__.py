@@ -64,7 +64,7 @@ class PtOptions(C.Structure):
 class PtCounters(C.Structure):
     _fields_ = [("live", C.c_int64 * (PT_MAX_DEPTH + 2)), ("light_hits", C.c_int64), ("misses", C.c_int64),
                 ("iterations", C.c_int64), ("bounce_launches", C.c_int64), ("bounce_kernel_ms", C.c_double),
-                ("raygen_kernel_ms", C.c_double), ("raygen_launches", C.c_int64)]
+                ("raygen_kernel_ms", C.c_double), ("raygen_launches", C.c_int64), ("ended_early", C.c_int64 * (PT_MAX_DEPTH + 2))]
 
 
 class PtError(RuntimeError):

@@ -980,7 +980,10 @@ int pt_counters(PtCounters *out) {
     uint32_t faultBits = 0;
     for (int i = 0; i < S.nslots; ++i) {
         HIPCHECK(hipMemcpy(&h, S.slot[i].ctrl, sizeof h, hipMemcpyDeviceToHost));
-        for (int d = 0; d < kMaxDepthSlots; ++d) out->live[d] += (int64_t)h.sum_live[d];
+        for (int d = 0; d < kMaxDepthSlots; ++d) {
+            out->live[d] += (int64_t)h.sum_live[d];
+            out->ended_early[d] += (int64_t)h.sum_early[d];
+        }
         for (int sg = 0; sg < kOct; ++sg) {
             out->light_hits += (int64_t)h.light_hits[sg][0];
             out->misses += (int64_t)h.misses[sg][0];

@@ -44,6 +44,7 @@ struct Ctrl {
     uint32_t error;                    // sticky device fault: kFault* bits (pool exhausted, chunk-list poll timeout)
     uint32_t pad[kCtrPad - 1];
     unsigned long long sum_live[kMaxDepthSlots];
+    unsigned long long sum_early[kMaxDepthSlots];   // of sum_live[d]: paths that ended at the scatter of bounce d - 1 (never enqueued)
     unsigned long long light_hits[kOct][kCtrPad / 2], misses[kOct][kCtrPad / 2];
 };
 constexpr uint32_t kFaultPoolExhausted = 1u, kFaultReserveTimeout = 2u;
@@ -841,7 +842,10 @@ __global__ __launch_bounds__(kBlock, (MANY || DOF) ? 5 : 8) void k_bounce(Bounce
         const int shard = blockIdx.x % kOct;
         if (waveLight) atomicAdd(&ctrl->light_hits[shard][0], (unsigned long long)waveLight);
         if (waveMiss) atomicAdd(&ctrl->misses[shard][0], (unsigned long long)waveMiss);
-        if (waveEarly) atomicAdd(&ctrl->sum_live[A->depth + 1], (unsigned long long)waveEarly);   // they did enter the next bounce
+        if (waveEarly) {
+            atomicAdd(&ctrl->sum_live[A->depth + 1], (unsigned long long)waveEarly);   // they did enter the next bounce
+            atomicAdd(&ctrl->sum_early[A->depth + 1], (unsigned long long)waveEarly);  // ... without being moved through memory
+        }
     }
 }
 
