@@ -191,17 +191,21 @@ def main():
         """`steps` steps of B iterations from `first_iter`.  every == "batch": one wavefront batch per step, the frame
         assembled at rank 0 after it; every == "1": B single-iteration calls per step, each followed by the collective."""
         it = first_iter
-        for _ in range(steps):
+        done = 0
+        while done < steps:
             if every == "batch":
-                pt.pathtrace_batch(None, 0, it, B)
+                n = min(fuse, steps - done)
+                pt.pathtrace_batch(None, 0, it, B * n)
                 if world > 1:
                     collect()
             else:
+                n = 1
                 for k in range(B):
                     pt.pathtrace(None, 0, it + k, readback=False)
                     if world > 1:
                         collect()
-            it += B
+            it += B * n
+            done += n
         return it
 
     def barrier():
@@ -222,7 +226,10 @@ def main():
         return dt
 
     every = args.collective_every
-    maxb = B if every == "batch" else 1
+    # N ranks share the frame's rows, so a rank's launches cover 1/N of the paths: with the collective once per batch, a rank
+    # traces `fuse` consecutive steps as ONE wavefront batch (at most PT_MAX_BATCH iterations), which keeps its launches fat
+    fuse = max(1, min(world, pt.PT_MAX_BATCH // B)) if every == "batch" else 1
+    maxb = B * fuse if every == "batch" else 1
     # ---- pass A: the headline number ----------------------------------------------------------
     init(0, args.pipeline, maxb)
     nxt = run_steps(1, args.warmup, every)
@@ -268,7 +275,7 @@ def main():
     bounce_bytes = sum(PATH_BYTES * moved[d] for d in range(2, D + 1)) \
         + sum(PATH_BYTES * moved[d + 1] for d in range(1, D)) + ACCUM_BYTES * hits
     launches = max(int(cnt.bounce_launches), 1)
-    iters_per_launch = maxb
+    iters_per_launch = maxb      # (N > 1: the last launch of a run may carry fewer steps; the PMC figures are N = 1 only)
     avg_ms = cnt.bounce_kernel_ms / launches
     achieved = bounce_bytes / launches / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     # PMC counters of the bounce kernel from the committed rocprofv3 passes.  They are stored PER ITERATION of a launch's

@@ -31,14 +31,14 @@ ROOT = os.path.dirname(HERE)
 
 
 def inst(name):
-    """instantiation of the bounce kernel: k_bounce<FIRST, MANY>"""
-    for tag in ("k_bounce<true, true>", "k_bounce<true, false>", "k_bounce<false, true>", "k_bounce<false, false>"):
-        if tag in name:
-            return tag
-    for mangled, tag in (("k_bounceILb1ELb1E", "k_bounce<true, true>"), ("k_bounceILb1ELb0E", "k_bounce<true, false>"),
-                         ("k_bounceILb0ELb1E", "k_bounce<false, true>"), ("k_bounceILb0ELb0E", "k_bounce<false, false>")):
-        if mangled in name:
-            return tag
+    """instantiation of the bounce kernel: k_bounce<FIRST, MANY, DOF>"""
+    import re
+    m = re.search(r"k_bounce<([^>]*)>", name)
+    if m:
+        return "k_bounce<%s>" % m.group(1)
+    m = re.search(r"k_bounceILb([01])ELb([01])E(?:Lb([01])E)?", name)
+    if m:
+        return "k_bounce<%s>" % ", ".join("true" if g == "1" else "false" for g in m.groups() if g is not None)
     return None
 
 
@@ -55,8 +55,8 @@ def kind(name):
 
 
 def load_pmc(d):
-    files = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))
-    return list(csv.DictReader(open(files[0]))) if files else []
+    files = sorted(glob.glob(os.path.join(d, "*", "*counter_collection.csv")), key=os.path.getmtime)   # gpurun MERGES runs: newest
+    return list(csv.DictReader(open(files[-1]))) if files else []
 
 
 def main():
@@ -69,7 +69,7 @@ def main():
     src = os.path.join(ROOT, "gpurun_out", "prof_" + args.tag)
     out = {}
 
-    stats = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))
+    stats = sorted(glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv")), key=os.path.getmtime)[-1:]
     if stats:
         shutil.copy(stats[0], os.path.join(HERE, args.tag + "_kernel_stats.csv"))
         txt = subprocess.run([sys.executable, os.path.join(HERE, "trace_summary.py"), os.path.join(src, "trace")],

@@ -1,7 +1,8 @@
 """One batch (its 8 bounce launches + commit) from the middle of a rocprofv3 kernel trace: per-launch durations, gaps,
 grids and register counts.   python profiles/trace_summary.py <dir containing */*kernel_trace.csv>"""
 import csv, glob, re, sys
-f = glob.glob(sys.argv[1] + '/*/*kernel_trace.csv')[0]
+import os
+f = sorted(glob.glob(sys.argv[1] + '/*/*kernel_trace.csv'), key=os.path.getmtime)[-1]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 

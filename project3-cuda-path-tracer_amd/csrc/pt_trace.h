@@ -375,9 +375,9 @@ __global__ __launch_bounds__(kBlock, (MANY || DOF) ? 5 : 8) void k_bounce(Bounce
         if (blockIdx.x >= numTiles) return;
         if (threadIdx.x < kWaves * kCls) s_wave[threadIdx.x] = 0u;
         if (threadIdx.x < kCls) s_base[3 * kCls + threadIdx.x] = 0xffffffffu;   // no chunk looked up yet
-        if (threadIdx.x < 2 * PT_MAX_BATCH) {
-            const int b = threadIdx.x % PT_MAX_BATCH;
-            s_iterHash[threadIdx.x] = iterationHash(A->iter + b, threadIdx.x < PT_MAX_BATCH ? depth : 0);
+        for (int i = threadIdx.x; i < 2 * PT_MAX_BATCH; i += kBlock) {
+            const int b = i % PT_MAX_BATCH;
+            s_iterHash[i] = iterationHash(A->iter + b, i < PT_MAX_BATCH ? depth : 0);
         }
 
         // stage the materials in LDS once per (persistent) workgroup, 16 B per lane per step
