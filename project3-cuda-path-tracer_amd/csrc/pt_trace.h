@@ -316,7 +316,7 @@ static_assert(sizeof(CullGroup) == 32 && offsetof(GeomDev, cullFlags) - offsetof
 // DOF (with FIRST only): camera rays start on a thin lens (README.md:100-101), so they share no origin (no precomputed
 // object-space camera position) and the pixel rectangles, which project the primitives through a pinhole, are not used.
 template <bool FIRST, bool MANY, bool DOF = false>
-__global__ __launch_bounds__(kBlock, (MANY || DOF) ? 5 : 8) void k_bounce(BounceArgs argsByValue) {
+__global__ __launch_bounds__(kBlock, DOF ? 5 : (MANY ? 7 : 8)) void k_bounce(BounceArgs argsByValue) {
     static_assert(FIRST || !DOF, "the lens only concerns the camera-ray bounce");
     (void)argsByValue;
     const ArgsPtr kargs = (ArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -555,7 +555,9 @@ __global__ __launch_bounds__(kBlock, (MANY || DOF) ? 5 : 8) void k_bounce(Bounce
             float tbest = 0.0f;
             int hit = -1;
             F3 P = f3(0, 0, 0), nsrc = f3(0, 0, 0);
-            bool outside = false;
+            // (an int, not a bool: a loop-carried per-lane flag would live in an SGPR pair and cost three mask operations at
+            // every merge point of the loop over the primitives; as a VGPR it costs one select per update)
+            int outsideI = 0;
             const float dd = dot(dir, dir);
             int nCand = 0;                                       // MANY: spheres recorded by this lane
             float *s_sph = nullptr;                              // MANY: [ngeoms][kSphRowFloats], then [kListMax][kBlock] lists
@@ -596,7 +598,7 @@ __global__ __launch_bounds__(kBlock, (MANY || DOF) ? 5 : 8) void k_bounce(Bounce
                         t = boxIntersectionTest<true, FIRST && !DOF>(G, org, dir, p, n, o);
                     }
                     if (t > 0.0f && (hit < 0 || t < tbest)) {
-                        tbest = t; hit = g; P = p; nsrc = n; outside = o;
+                        tbest = t; hit = g; P = p; nsrc = n; outsideI = o ? 1 : 0;
                     }
                 }
             }
@@ -617,7 +619,7 @@ __global__ __launch_bounds__(kBlock, (MANY || DOF) ? 5 : 8) void k_bounce(Bounce
                         const float t = sphereIntersectionTestM<false>(m, m + 24, m + 12, m, org, dir, p, n, o);
                         // a recorded sphere may precede, in file order, the primitive that holds the record so far
                         if (t > 0.0f && (hit < 0 || t < tbest || (t == tbest && g < hit))) {
-                            tbest = t; hit = g; P = p; nsrc = n; outside = o;
+                            tbest = t; hit = g; P = p; nsrc = n; outsideI = o ? 1 : 0;
                         }
                     }
                 }
@@ -629,6 +631,7 @@ __global__ __launch_bounds__(kBlock, (MANY || DOF) ? 5 : 8) void k_bounce(Bounce
                 const bool isSphere = GH.type == 0;
                 bool faceOk = true;
                 const int face = isSphere ? 0 : cubeFace(nsrc, faceOk);
+                const bool outside = outsideI != 0;
                 const F3 N = isSphere ? hitNormalSphere(GH.nm, nsrc, outside) : cubeFrameVector(GH.cubeFrame, face, 0, faceOk);
                 const MaterialDev &M = smats[GH.material];
                 const F3 mcol = f3(M.color[0], M.color[1], M.color[2]);
