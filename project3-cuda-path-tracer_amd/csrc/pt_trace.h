@@ -482,10 +482,12 @@ __global__ __launch_bounds__(kBlock, DOF ? 5 : (MANY ? 7 : 8)) void k_bounce(Bou
             idx = (chunk << shift) + (local - (j << shift));
         }
 
-        bool alive = false;
-        bool smallCand = true;                                  // class bit 3 of a survivor
+        // (per-lane flags that are set deep inside the divergent code and read after it are ints: as bools they would live in
+        // SGPR pairs and cost three mask operations at every join on the way out)
+        uint32_t aliveI = 0u;
+        uint32_t smallCandI = 1u;                               // class bit 3 of a survivor
         uint32_t wallSel = 8u;                                  // class bits 0-2 of a survivor in a scene with walls (8: no walls: the octant)
-        bool lightHit = false, missed = false;
+        uint32_t lightHitI = 0u, missedI = 0u;
         F3 org = f3(0, 0, 0), dir = f3(0, 0, 1), col = f3(0, 0, 0);
         int pix = 0, rem = 0;
         int itb = 0;                                            // which iteration of the batch this path belongs to
@@ -625,7 +627,7 @@ __global__ __launch_bounds__(kBlock, DOF ? 5 : (MANY ? 7 : 8)) void k_bounce(Bou
                 }
             }
             if (hit < 0) {
-                missed = true;                                   // S4: background is black
+                missedI = 1u;                                    // S4: background is black
             } else {
                 const GeomHitDev &GH = S_GEOMHIT(launder(kargs)->prm.nmats)[hit];   // per-lane geom: LDS lookup
                 const bool isSphere = GH.type == 0;
@@ -636,7 +638,7 @@ __global__ __launch_bounds__(kBlock, DOF ? 5 : (MANY ? 7 : 8)) void k_bounce(Bou
                 const MaterialDev &M = smats[GH.material];
                 const F3 mcol = f3(M.color[0], M.color[1], M.color[2]);
                 if (M.emittance > 0.0f) {                        // S5: emitter ends the path
-                    lightHit = true;
+                    lightHitI = 1u;
                     const ArgsPtr A = launder(kargs);
                     float *const contrib = A->contrib;
                     if (contrib) {
@@ -742,16 +744,17 @@ __global__ __launch_bounds__(kBlock, DOF ? 5 : (MANY ? 7 : 8)) void k_bounce(Bou
                     }
                     org = norg;
                     dir = ndir;
-                    alive = true;
+                    aliveI = 1u;
                     {                                            // class bit 3: can the new ray hit a small primitive at all?
                         const ArgsPtr A = launder(kargs);
                         const int nBinned = A->prm.nBinned;
                         if (nBinned > 0) {
                             const GeomPtr geoms = (GeomPtr)(A->ggeoms);
                             const float ndd = dot(ndir, ndir);
-                            smallCand = false;
+                            uint32_t cand = 0u;
                             for (int sI = 0; sI < nBinned; ++sI)
-                                smallCand = smallCand || !certainMiss(*(launder(geoms) + A->prm.binGeom[sI]), norg, ndir, ndd);
+                                cand |= certainMiss(*(launder(geoms) + A->prm.binGeom[sI]), norg, ndir, ndd) ? 0u : 1u;
+                            smallCandI = cand;
                         }
                     }
                     {                                            // class bits 0-2 with walls: which of them can the new ray still hit?
@@ -771,8 +774,8 @@ __global__ __launch_bounds__(kBlock, DOF ? 5 : (MANY ? 7 : 8)) void k_bounce(Bou
                                 // nothing left to hit: the reference's nearest-hit loop would come back empty at the next bounce.
                                 // The path ends here and is tallied as what it is, a path that entered that bounce and missed.
                                 // (Not under pt_debug_trace_paths, which shows the queue as the oracle lists it.)
-                                if (cnt == 0 && !smallCand && A->prm.allClassified && A->contrib) {
-                                    alive = false;
+                                if (cnt == 0 && smallCandI == 0u && A->prm.allClassified && A->contrib) {
+                                    aliveI = 0u;
                                     ++nEarly;
                                 }
                             }
@@ -781,8 +784,9 @@ __global__ __launch_bounds__(kBlock, DOF ? 5 : (MANY ? 7 : 8)) void k_bounce(Bou
                 }
             }
         }
-        nLight += lightHit ? 1u : 0u;
-        nMiss += missed ? 1u : 0u;
+        nLight += lightHitI;
+        nMiss += missedI;
+        const bool alive = aliveI != 0u, smallCand = smallCandI != 0u;
 
         if (!launder(kargs)->lastBounce) {                       // S8: compaction into `out`, binned by class
             const int wave = (int)(tid >> 6), lane = (int)(tid & 63u);
