@@ -582,11 +582,19 @@ __global__ __launch_bounds__(kBlock, DOF ? 5 : (MANY ? 7 : 8)) void k_bounce(Bou
                     F3 p, n;
                     bool o = false;
                     float t = -1.0f;
-                    if (FIRST && !DOF && (px < G.rect[0] || px > G.rect[2] || py < G.rect[1] || py > G.rect[3])) continue;
+                    // camera rays: only the lanes whose pixel lies in the primitive's rectangle take the test.  A predicate and a
+                    // wave-uniform skip, not a per-lane `continue`: the loop over the primitives stays a scalar loop
+                    bool inRect = true;
+                    if (FIRST && !DOF) {
+                        inRect = (px >= G.rect[0]) & (px <= G.rect[2]) & (py >= G.rect[1]) & (py <= G.rect[3]);
+                        if (__ballot(inRect) == 0ull) continue;
+                    }
                     if (!FIRST && !smallTile && (flags & 2)) continue;  // this tile's paths certainly miss every binned primitive
                     // ... and every wall but (at most) one
                     if (!FIRST && tileWall != 6u && (flags & 28) != 0 && (uint32_t)((flags >> 2) & 7) != tileWall + 1u) continue;
-                    if ((flags & 1) == 0) {
+                    if (!inRect) {
+                        // (not reachable from this pixel: t stays -1)
+                    } else if ((flags & 1) == 0) {
                         probe(3);
                         if (!certainMiss(cg, org, dir, dd)) {
                             if (MANY && nCand < kListMax) {
