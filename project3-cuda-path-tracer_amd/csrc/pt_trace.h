@@ -411,18 +411,83 @@ __global__ __launch_bounds__(kBlock, DOF ? 5 : (MANY ? 7 : 8)) void k_bounce(Bou
 
     uint32_t nLight = 0, nMiss = 0;         // per-lane tallies (VGPRs are the less scarce kind here), reduced and flushed once at the end
     uint32_t nEarly = 0;                    // survivors that certainly miss everything: ended at the scatter
-    uint32_t sgIn = 0;                      // input segment of the current tile (tiles are visited in increasing order)
+    uint32_t sgIn = 0;                      // input segment of the tile being set up (tiles are visited in increasing order)
     uint32_t firstK = 0;                    // FIRST: how many tiles this workgroup has processed
-    for (uint32_t T = blockIdx.x; T < numTiles; T += gridDim.x) {
+
+    // ---- later bounces: a tile's paths are requested ONE TILE AHEAD.  A workgroup's tiles form a chain of dependent
+    // latencies -- load 44 B per path, trace, reserve the output runs (an atomic round trip between two barriers), store --
+    // and with eight workgroups per CU all in the same chain the vector units idled half of the time (round 2 profile:
+    // 174 us for 15 k tiles at bounce 7 against 291 us for 53 k at bounce 2).  The loads of tile k + 1 are issued when
+    // tile k has been traced, just before its compaction: by then the tracing registers are dead (no extra VGPRs), and
+    // the loads fly while the workgroup waits at the barriers and for the atomics.
+    struct TileMeta {
+        bool valid;                         // this lane holds a path
+        uint32_t idx;                       // its slot in the input pool
+        bool smallTile;                     // wave-uniform: this tile's paths may hit a small (binned) primitive
+        uint32_t tileWall;                  // wave-uniform: the one wall this tile's paths can hit (0..5), 6: any, 7: none
+    };
+    struct PathRegs { F3 org, dir, col; int pix, packed; };
+    // tile T of the queue -> its segment, class and the lane's slot; false: the tile needs no work at all
+    auto setupTile = [&](uint32_t T, uint32_t tid, TileMeta &m) -> bool {
+        const ArgsPtr A = launder(kargs);
+        // global tile -> (segment, local tile)
+        while (T >= s_segpre[sgIn + 1]) ++sgIn;
+        sgIn = (uint32_t)__builtin_amdgcn_readfirstlane((int)sgIn);
+        const uint32_t local = (T - s_segpre[sgIn]) * kBlock + tid;
+        m.valid = local < s_segcnt[sgIn];
+        m.smallTile = ((sgIn / kSub) & 8u) != 0u;
+        m.tileWall = A->prm.nWalls > 0 ? (sgIn / kSub) & 7u : 6u;
+        // The last bounce only asks whether a path ends on an emitter (S7: no scatter).  When every emitter of the scene
+        // is a binned small primitive, the paths of a non-candidate tile certainly miss all of them: nothing to add.
+        if (A->lastBounce && A->prm.emittersBinned && !m.smallTile) return false;
+        // the tile's chunk (a chunk is a multiple of the tile size): j-th chunk of the segment, wave-uniform lookup
+        // (entries were written by the previous launch; the 0-th chunk of a segment is static)
+        const uint32_t shift = (uint32_t)A->prm.chunkShift, poolChunks = (uint32_t)A->prm.poolChunks;
+        const uint32_t q0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)((T - s_segpre[sgIn]) * kBlock));
+        const uint32_t j = q0 >> shift;
+        uint32_t chunk = 1u + sgIn;
+        if (j != 0u) {
+            const unsigned long long e = j < poolChunks ? A->in.list[(size_t)sgIn * poolChunks + j] : 0ull;
+            chunk = (uint32_t)(e >> 32) == A->genIn ? (uint32_t)e : 0u;
+            chunk = chunk < poolChunks ? chunk : 0u;
+        }
+        m.idx = (chunk << shift) + (local - (j << shift));
+        return true;
+    };
+    auto loadTile = [&](const TileMeta &m, PathRegs &r) {
+        if (m.valid) {
+            // one running (scalar) pointer through the 11 arrays (stride = cap) + the lane's 32-bit byte offset
+            const ArgsPtr A = launder(kargs);
+            const float *src = A->in.base;
+            const size_t cap = (size_t)A->in.cap;
+            const uint32_t off = m.idx * 4u;
+            r.org.x = ldSlot(src, off); src += cap; r.org.y = ldSlot(src, off); src += cap; r.org.z = ldSlot(src, off); src += cap;
+            r.dir.x = ldSlot(src, off); src += cap; r.dir.y = ldSlot(src, off); src += cap; r.dir.z = ldSlot(src, off); src += cap;
+            r.col.x = ldSlot(src, off); src += cap; r.col.y = ldSlot(src, off); src += cap; r.col.z = ldSlot(src, off); src += cap;
+            r.pix = __float_as_int(ldSlot(src, off)); src += cap;
+            r.packed = __float_as_int(ldSlot(src, off));            // remainingBounces | batch index << 8
+        }
+    };
+    // the first tile of this workgroup that needs work, and its paths
+    uint32_t T = blockIdx.x;
+    TileMeta nextMeta = {false, 0u, true, 6u};
+    PathRegs nextRegs = {f3(0, 0, 0), f3(0, 0, 1), f3(0, 0, 0), 0, 0};
+    if (!FIRST) {
+        while (T < numTiles && !setupTile(T, threadIdx.x, nextMeta)) T += gridDim.x;
+        if (T < numTiles) loadTile(nextMeta, nextRegs);
+    }
+    while (T < numTiles) {
         // the lane id, opaque to the optimiser: the lane masks derived from it (tid < 16, wave > k, ...) are then
         // recomputed where a tile needs them -- one v_cmp each -- instead of being hoisted out of the loop into SGPR pairs
         // that live, spilled, across the whole tile
         uint32_t tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
+        uint32_t Tnext = T + gridDim.x;     // FIRST: simply the next one
         bool valid;
         uint32_t idx = 0;
         bool smallTile = true;              // wave-uniform: this tile's paths may hit a small (binned) primitive
         uint32_t tileWall = 6u;             // wave-uniform: the one wall this tile's paths can hit (0..5), 6: any, 7: none
+        PathRegs cur = nextRegs;
         if (FIRST) {
             const ArgsPtr A = launder(kargs);
             const PT_CAS KParams &prm = A->prm;
@@ -453,33 +518,15 @@ __global__ __launch_bounds__(kBlock, DOF ? 5 : (MANY ? 7 : 8)) void k_bounce(Bou
                 const int y0 = lr0 * prm.shardCount + prm.shardRank;
                 if (y0 < prm.sceneRect[1] || y0 > prm.sceneRect[3] || x0 + (kBlock - 1) < prm.sceneRect[0] || x0 > prm.sceneRect[2]) {
                     nMiss += valid ? 1u : 0u;
+                    T = Tnext;
                     continue;
                 }
             }
         } else {
-            const ArgsPtr A = launder(kargs);
-            // global tile -> (segment, local tile)
-            while (T >= s_segpre[sgIn + 1]) ++sgIn;
-            sgIn = (uint32_t)__builtin_amdgcn_readfirstlane((int)sgIn);
-            const uint32_t local = (T - s_segpre[sgIn]) * kBlock + tid;
-            valid = local < s_segcnt[sgIn];
-            smallTile = ((sgIn / kSub) & 8u) != 0u;
-            tileWall = A->prm.nWalls > 0 ? (sgIn / kSub) & 7u : 6u;
-            // The last bounce only asks whether a path ends on an emitter (S7: no scatter).  When every emitter of the scene
-            // is a binned small primitive, the paths of a non-candidate tile certainly miss all of them: nothing to add.
-            if (A->lastBounce && A->prm.emittersBinned && !smallTile) continue;
-            // the tile's chunk (a chunk is a multiple of the tile size): j-th chunk of the segment, wave-uniform lookup
-            // (entries were written by the previous launch; the 0-th chunk of a segment is static)
-            const uint32_t shift = (uint32_t)A->prm.chunkShift, poolChunks = (uint32_t)A->prm.poolChunks;
-            const uint32_t q0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)((T - s_segpre[sgIn]) * kBlock));
-            const uint32_t j = q0 >> shift;
-            uint32_t chunk = 1u + sgIn;
-            if (j != 0u) {
-                const unsigned long long e = j < poolChunks ? A->in.list[(size_t)sgIn * poolChunks + j] : 0ull;
-                chunk = (uint32_t)(e >> 32) == A->genIn ? (uint32_t)e : 0u;
-                chunk = chunk < poolChunks ? chunk : 0u;
-            }
-            idx = (chunk << shift) + (local - (j << shift));
+            valid = nextMeta.valid;
+            idx = nextMeta.idx;
+            smallTile = nextMeta.smallTile;
+            tileWall = nextMeta.tileWall;
         }
 
         // (per-lane flags that are set deep inside the divergent code and read after it are ints: as bools they would live in
@@ -538,18 +585,10 @@ __global__ __launch_bounds__(kBlock, DOF ? 5 : (MANY ? 7 : 8)) void k_bounce(Bou
                 col = f3(1.0f, 1.0f, 1.0f);
                 rem = prm.traceDepth;
             } else {
-                // one running (scalar) pointer through the 11 arrays (stride = cap) + the lane's 32-bit byte offset
-                const ArgsPtr A = launder(kargs);
-                const float *src = A->in.base;
-                const size_t cap = (size_t)A->in.cap;
-                const uint32_t off = idx * 4u;
-                org.x = ldSlot(src, off); src += cap; org.y = ldSlot(src, off); src += cap; org.z = ldSlot(src, off); src += cap;
-                dir.x = ldSlot(src, off); src += cap; dir.y = ldSlot(src, off); src += cap; dir.z = ldSlot(src, off); src += cap;
-                col.x = ldSlot(src, off); src += cap; col.y = ldSlot(src, off); src += cap; col.z = ldSlot(src, off); src += cap;
-                pix = __float_as_int(ldSlot(src, off)); src += cap;
-                const int packed = __float_as_int(ldSlot(src, off));        // remainingBounces | batch index << 8
-                rem = packed & 0xff;
-                itb = packed >> 8;
+                org = cur.org; dir = cur.dir; col = cur.col;        // requested one tile ahead (loadTile)
+                pix = cur.pix;
+                rem = cur.packed & 0xff;                            // remainingBounces | batch index << 8
+                itb = cur.packed >> 8;
             }
 
             if (!FIRST) probe(7);                                   // tiles (waves with at least one valid path) and valid paths
@@ -794,6 +833,10 @@ __global__ __launch_bounds__(kBlock, DOF ? 5 : (MANY ? 7 : 8)) void k_bounce(Bou
         }
         nLight += lightHitI;
         nMiss += missedI;
+        if (!FIRST) {       // the next tile of this workgroup that needs work: its loads fly during the compaction below
+            while (Tnext < numTiles && !setupTile(Tnext, tid, nextMeta)) Tnext += gridDim.x;
+            if (Tnext < numTiles) loadTile(nextMeta, nextRegs);
+        }
         const bool alive = aliveI != 0u, smallCand = smallCandI != 0u;
 
         if (!launder(kargs)->lastBounce) {                       // S8: compaction into `out`, binned by class
@@ -849,6 +892,7 @@ __global__ __launch_bounds__(kBlock, DOF ? 5 : (MANY ? 7 : 8)) void k_bounce(Bou
             __syncthreads();   // every wave has read this tile's counts: each wave clears its own row for the next tile
             if (lane < kCls) wv[wave * kCls + lane] = 0u;
         }
+        T = Tnext;
     }
     const uint32_t waveLight = waveSum(nLight), waveEarly = waveSum(nEarly), waveMiss = waveSum(nMiss) + waveEarly;
     if ((threadIdx.x & 63) == 0) {
