@@ -1,15 +1,14 @@
 // pt_api.hip -- MI355X (gfx950 / CDNA4) path-tracing hot path + its C ABI (include/pt_amd.h).
 //
-// One iteration = camera-ray generation, then `traceDepth` launches of ONE fused persistent kernel
-// per bounce: nearest-hit over the scene (geometry through the scalar path, materials in LDS) -> shade/scatter
-// -> park emitter radiance ->
-// stream compaction of the survivors straight into the next bounce's SoA buffers (wave64
-// ballot/mbcnt ranks, LDS wave totals = workgroup-level exclusive scan; the workgroup's output range
-// is reserved with ONE atomic on one of 8 sharded segment counters).  No host round trip inside an
-// iteration: live counts stay on the device.  The multi-workgroup ORDERED scan (two-level decoupled
-// look-back) is the stream-compaction library in pt_compaction.h (pt_scan_exclusive_i32 /
-// pt_compact_nonzero_i32).  Files: pt_device.h (math), pt_trace.h (render kernels), pt_compaction.h,
-// pt_test_kernels.h (primitives for the parity tests), this file (host side + C ABI).
+// One iteration = `traceDepth` launches of ONE fused persistent kernel per bounce (the first builds its camera rays in
+// registers): nearest-hit over the scene (geometry through the scalar path, materials in LDS) -> shade/scatter -> park
+// emitter radiance -> stream compaction of the survivors straight into the next bounce's SoA path pool (wave64
+// ballot/mbcnt ranks, LDS wave totals = workgroup-level exclusive scan per class; the tile's output runs are reserved
+// with ONE atomic instruction on sharded position counters, chunks of the pool are handed out on demand).  No host
+// round trip inside an iteration: live counts stay on the device.  The multi-workgroup ORDERED scan (two-level decoupled
+// look-back) is the stream-compaction library in pt_compaction.h (pt_scan_exclusive_i32 / pt_compact_nonzero_i32).
+// Files: pt_device.h (math), pt_trace.h (render kernels), pt_compaction.h, pt_test_kernels.h (primitives for the parity
+// tests), this file (host side + C ABI).
 //
 // Replaces the unsolved pipeline of reference src/pathtrace.cu:133-167 (spec: SURVEY.md 3.4 S0-S9).
 // HBM layout, kernels, rooflines: DESIGN.md.

@@ -228,32 +228,37 @@ __global__ __launch_bounds__(kBlock) void k_debug_camera_rays(KParams prm, int i
 // ---- one bounce: intersect + shade + accumulate + compact (spec S3-S8) -----------------------------
 // Persistent workgroups walk the 256-path tiles of the bounce's queue (the kSeg input segments laid
 // end to end), blockIdx-strided.  Survivors are BINNED BY CLASS while they are compacted:
-//   class     = octant(new direction) | candidate << 3, where candidate = the new ray is not a certain miss
-//               (certainMiss: bounding ball with a 50x safety margin) of every SMALL primitive of the scene -- its
-//               spheres and the cubes much smaller than the scene, at most kBinMax, chosen by pt_init,
+//   class     = bits 0-2 | candidate << 3.  Bits 0-2: in a scene with walls, WHICH wall the new ray can still hit
+//               (wallCertainMiss of every wall, see KParams::nWalls; 6 = several, 7 = none), else the octant of its
+//               direction; candidate = the new ray is not a certain miss (certainMiss: bounding ball with a 50x safety
+//               margin) of every SMALL primitive of the scene -- its spheres and the cubes much smaller than the scene,
+//               at most kBinMax, chosen by pt_init,
 //   segment   = class * kSub + blockIdx % kSub,
 //   rank      = position among the wave's lanes of the same class (four bit ballots -> same-class mask -> mbcnt) plus
 //               the earlier waves' totals through LDS = workgroup-level exclusive scan per class,
-//   base      = ONE atomicAdd per non-empty class of the tile on that segment's counter (16 lanes, one instruction).
-// A tile of the next bounce therefore holds rays of a single direction octant, which turns the exact early-miss of
-// the box test (pt_device.h) into a wave-uniform branch for axis-aligned boxes, and either candidates only -- whose
-// tests of the small primitives then run with full waves instead of a few lanes -- or paths that skip the small
-// primitives altogether (the flag is a sufficient condition for the reference's own miss, evaluated on the very ray
-// that is stored).
+//   base      = ONE atomic add per non-empty class of the tile on that segment's position counter (16 lanes, one
+//               instruction; reserveRun).
+// A tile of the next bounce therefore holds paths that test ONE wall (or, without walls, rays of a single direction octant,
+// which turns the exact early-miss of the box test (pt_device.h) into a wave-uniform branch), and either candidates only --
+// whose tests of the small primitives then run with full waves instead of a few lanes -- or paths that skip the small
+// primitives altogether (both are sufficient conditions for the reference's own miss, evaluated on the very ray that is
+// stored).  A survivor that can hit nothing at all (scenes whose primitives are all walls or binned) ends at its scatter.
 // Queue order never influences results: RNG and accumulator are keyed on the pixel index.
-// No workgroup ever waits for another one, so there is no residency / dispatch-order assumption.
+// No workgroup ever waits for another one's work, so there is no residency / dispatch-order assumption (the one
+// cross-workgroup wait is reserveRun's bounded poll for a chunk-list entry published a chunk's worth of appends earlier).
 // A segment receives survivors of the tiles of the workgroups with one value of blockIdx % kSub only; its paths live in
 // chunks of the output pool handed out on demand (reserveRun), so any distribution over the classes fits.
-// (Deriving the shard from the tile index instead, T % kSub, measured 3 % slower.)
+// (Deriving the shard from the tile index instead, T % kSub, measured 3 % slower; 64-path tiles that a wave loads, traces
+// and compacts alone, without any barrier in the loop, 18 % slower: four times the atomics, runs a quarter as long.)
 //
 // FIRST = true is bounce 1 fused with camera-ray generation (spec S2): tile T holds the paths
 // j = 256 T + lane of this shard's pixel list and the ray is built in registers, so the first bounce
 // reads no path state at all.
 //
-// Registers: built without the SLP vectoriser the kernel needs 63 VGPRs and spills nothing (with it: 80 + 10 spilled for
-// 8 % fewer instructions -- slower, see the Makefile), so eight waves per SIMD fit; a launch brings six workgroups per
-// CU (persistent_grid) and leaves the other two slots to the launches of the neighbouring batches.  The launch bounds
-// only cap the sphere-list variants (81 VGPRs).
+// Registers: 78 SGPRs and at most 64 VGPRs without a spill in the four main instantiations, i.e. eight workgroups per
+// CU (DESIGN.md section 4 lists what it took: laundered constant-address-space access to the kernel's single by-value
+// argument and to the primitives, flags that cross divergent regions kept as ints, the bitwise early miss).  Built
+// without the SLP vectoriser (packed fp32 runs at half rate on gfx950: profiles/valu_issue_rate.json).
 //
 // MANY (scenes with more than kBinMax spheres, e.g. the 64-sphere configuration): the wave-uniform loop over the
 // spheres only runs the cheap bounding-ball test and RECORDS the spheres a lane may hit (a handful out of 64, and a
