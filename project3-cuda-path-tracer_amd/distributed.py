@@ -78,7 +78,7 @@ def _interleave_rows(bufs, frame, width, height, world):
             rows_view[r::world].copy_(bufs[r][:n * width * 3].view(n, width * 3))
 
 
-def gather_frame(block, bufs, frame, width, height, dst=0, collective="gather"):
+def gather_frame(block, bufs, frame, width, height, dst=0, collective="gather", always_collective=False):
     """The data path's single collective: rank `dst` receives every rank's packed rows and interleaves
     them into `frame` (H*W*3 floats).  `block` is this rank's packed accumulator, padded to
     padded_block_floats(); it keeps accumulating, the collective only reads it.
@@ -88,14 +88,15 @@ def gather_frame(block, bufs, frame, width, height, dst=0, collective="gather"):
     leaves the communicator unusable, so there is nothing to fall back to:
       "gather"  every rank sends its 1/world of the frame straight to `dst` (default);
       "reduce"  the reduce(sum) of zero-padded full frames that BASELINE.json sketches: same bits (x + 0 is
-                exact), world x the bytes."""
+                exact), world x the bytes.
+    `always_collective`: issue the collective even in a one-rank group (tests: the RCCL call path on a single GPU)."""
     import torch
     import torch.distributed as dist
     if collective not in ("gather", "reduce"):
         raise ValueError("gather_frame: collective must be 'gather' or 'reduce', not %r" % (collective,))
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
-    if world == 1:
+    if world == 1 and not (always_collective and dist.is_initialized()):
         frame.copy_(block[:frame.numel()])
         return frame
     if collective == "gather":

@@ -124,3 +124,55 @@ def test_bench_two_ranks_contract(pt, tmp_path, every, extra):
     want = _single_rank_frame(pt, (steps + warmup) * B, B)
     assert want.max() > 0
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def _rccl_single_rank(_index, port, out_path):
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    pt = ge.load_package()
+    ptdist = ge.load_submodule("distributed")
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", world_size=1, rank=0, device_id=torch.device("cuda", 0))
+    W, H = 160, 90
+    sc = pt.Scene(os.path.join(SCENES, "cornell.txt"))
+    sc.set_resolution(W, H)
+    accum = torch.zeros(ptdist.padded_block_floats(W, H, 1), dtype=torch.float32, device="cuda")
+    ok = True
+    for collective in ("gather", "reduce"):
+        accum.zero_()
+        frame = torch.full((W * H * 3,), -1.0, dtype=torch.float32, device="cuda")
+        bufs = ptdist.make_gather_buffers(accum, 1, 0)
+        pt.pathtraceInit(sc, shard_rank=0, shard_count=1, stream=torch.cuda.current_stream().cuda_stream,
+                         accum_dev=accum.data_ptr(), device=0, flags=pt.PT_FLAG_ACCUM_SHARD_ROWS, traceDepth=8, max_batch=4)
+        pt.pathtrace_batch(None, 0, 1, 4)
+        # the collective bench.py issues after every batch, through RCCL (backend "nccl" on ROCm) -- here in a one-rank group
+        ptdist.gather_frame(accum, bufs, frame, W, H, dst=0, collective=collective, always_collective=True)
+        t = torch.ones(1, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)                   # the timing reduction of bench.py
+        dist.barrier()
+        torch.cuda.synchronize()
+        want = pt.readback(W * H)
+        pt.pathtraceFree()
+        ok = ok and want.max() > 0 and np.array_equal(frame.cpu().numpy().view(np.uint32), want.view(np.uint32)) and float(t) == 1.0
+    np.save(out_path, np.array([1 if ok else 0]))
+    dist.destroy_process_group()
+
+
+def test_rccl_call_path_on_one_gpu(pt, tmp_path):
+    # The box has one GPU, so RCCL cannot move data between ranks here; what CAN run is everything else of the N > 1
+    # path on the real backend: communicator creation, gather / reduce / all_reduce / barrier kernels on the caller's
+    # stream, ordered behind the renderer's commits, in a one-rank group.
+    if pt.device_count() < 1:
+        pytest.fail("no HIP device: GPU tests must run on the MI355X box")
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "ok.npy")
+    mp.spawn(_rccl_single_rank, args=(port, out), nprocs=1, join=True)
+    assert np.load(out)[0] == 1

@@ -352,3 +352,31 @@ def test_large_frame_batches_of_eight(gpu):
     b = gpu.readback(P)
     gpu.pathtraceFree()
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and a.max() > 0
+
+
+def test_config_c4_frame_properties(gpu):
+    # BASELINE config C4 at its real size (cornell_glass, 1920x1080, depth 16; the oracle covers it at 240x135): path
+    # conservation per bounce, and three row shards traced as wavefront batches sum to the unsharded frame bit for bit
+    sc = gpu.Scene(os.path.join(SCENES, "cornell_glass.txt"))
+    sc.set_resolution(1920, 1080)
+    P = 1920 * 1080
+    gpu.pathtraceFree()
+    gpu.pathtraceInit(sc, traceDepth=16, pipeline_depth=2, max_batch=4)
+    gpu.pathtrace_batch(None, 0, 1, 4)
+    full = gpu.readback(P)
+    c = gpu.counters()
+    live = [int(c.live[d]) for d in range(18)]
+    assert live[1] == 4 * P and all(live[d + 1] <= live[d] for d in range(1, 16)) and live[16] > 0 and live[17] == 0
+    assert c.light_hits > 0 and c.misses > 0 and c.light_hits + c.misses <= 4 * P
+    early = sum(int(c.ended_early[d]) for d in range(18))
+    assert 0 < early < c.misses                               # the open front: paths that end at their scatter
+    acc = np.zeros_like(full)
+    for r in range(3):
+        gpu.pathtraceFree()
+        gpu.pathtraceInit(sc, traceDepth=16, shard_rank=r, shard_count=3, pipeline_depth=2, max_batch=2)
+        gpu.pathtrace_batch(None, 0, 1, 2)
+        gpu.pathtrace_batch(None, 0, 3, 2)
+        acc += gpu.readback(P)
+    gpu.pathtraceFree()
+    assert np.array_equal(acc.view(np.uint32), full.view(np.uint32))
+    assert np.isfinite(full).all() and full.min() >= 0 and full.max() > 0
