@@ -107,6 +107,7 @@ struct State {
     size_t pinnedBytes = 0;
     // kernel timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> evBounce;
+    std::vector<hipEvent_t> evFree;   // resolved timing events, reused (creating two per launch cost 1 % of a timed step)
     double msBounce = 0;
     long long nBounce = 0;
 } S;
@@ -354,8 +355,8 @@ int resolve_events(std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, double &ms
         HIPCHECK(hipEventElapsedTime(&t, pr.first, pr.second));
         ms += t;
         n += 1;
-        (void)hipEventDestroy(pr.first);
-        (void)hipEventDestroy(pr.second);
+        S.evFree.push_back(pr.first);
+        S.evFree.push_back(pr.second);
     }
     v.clear();
     return PT_OK;
@@ -370,8 +371,10 @@ int launch_bounce(Slot &sl, int iter, int batch, int depth, bool lastBounce, flo
     const uint32_t genOut = sl.gen[depth & 1] = S.launchSerial;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (S.flags & PT_FLAG_KERNEL_TIMING) {
-        HIPCHECK(hipEventCreate(&e0));
-        HIPCHECK(hipEventCreate(&e1));
+        for (hipEvent_t *e : {&e0, &e1}) {
+            if (!S.evFree.empty()) { *e = S.evFree.back(); S.evFree.pop_back(); }
+            else HIPCHECK(hipEventCreate(e));
+        }
         HIPCHECK(hipEventRecord(e0, sl.stream));
     }
     BounceArgs ba;
@@ -529,6 +532,8 @@ void pt_free(void) {
         (void)hipEventDestroy(pr.second);
     }
     S.evBounce.clear();
+    for (hipEvent_t e : S.evFree) (void)hipEventDestroy(e);
+    S.evFree.clear();
     for (int i = 0; i < kMaxSlots; ++i) {
         Slot &sl = S.slot[i];
         for (int k = 0; k < 2; ++k) {
@@ -980,8 +985,10 @@ int pt_counters(PtCounters *out) {
     for (int i = 0; i < S.nslots; ++i) {
         HIPCHECK(hipMemcpy(&h, S.slot[i].ctrl, sizeof h, hipMemcpyDeviceToHost));
         for (int d = 0; d < kMaxDepthSlots; ++d) {
-            out->live[d] += (int64_t)h.sum_live[d];
-            out->ended_early[d] += (int64_t)h.sum_early[d];
+            int64_t early = 0;
+            for (int sg = 0; sg < kOct; ++sg) early += (int64_t)h.early[d][sg][0];
+            out->live[d] += (int64_t)h.sum_live[d] + early;   // they did enter bounce d
+            out->ended_early[d] += early;                      // ... without being moved through memory
         }
         for (int sg = 0; sg < kOct; ++sg) {
             out->light_hits += (int64_t)h.light_hits[sg][0];

@@ -44,7 +44,9 @@ struct Ctrl {
     uint32_t error;                    // sticky device fault: kFault* bits (pool exhausted, chunk-list poll timeout)
     uint32_t pad[kCtrPad - 1];
     unsigned long long sum_live[kMaxDepthSlots];
-    unsigned long long sum_early[kMaxDepthSlots];   // of sum_live[d]: paths that ended at the scatter of bounce d - 1 (never enqueued)
+    // paths that ended at the scatter of bounce d - 1 (they enter bounce d and miss, but are never enqueued), sharded like
+    // the tallies below: every workgroup adds to them when it ends, and 2048 atomics on ONE address take ~100 us
+    unsigned long long early[kMaxDepthSlots][kOct][kCtrPad / 2];
     unsigned long long light_hits[kOct][kCtrPad / 2], misses[kOct][kCtrPad / 2];
 };
 constexpr uint32_t kFaultPoolExhausted = 1u, kFaultReserveTimeout = 2u;
@@ -899,17 +901,26 @@ __global__ __launch_bounds__(kBlock, DOF ? 5 : (MANY ? 7 : 8)) void k_bounce(Bou
         }
         T = Tnext;
     }
+    // tallies: lanes -> wave (shuffles) -> workgroup (LDS) -> ONE atomic per workgroup and tally on counters sharded 8 ways
+    // (every workgroup of a launch ends with these: unsharded, or one per wave, they serialise at the memory side)
     const uint32_t waveLight = waveSum(nLight), waveEarly = waveSum(nEarly), waveMiss = waveSum(nMiss) + waveEarly;
+    __syncthreads();                                   // (every wave is done with the scratch of its last tile)
+    if (threadIdx.x < 3) s_wave[threadIdx.x] = 0u;
+    __syncthreads();
     if ((threadIdx.x & 63) == 0) {
+        if (waveLight) atomicAdd(&s_wave[0], waveLight);
+        if (waveMiss) atomicAdd(&s_wave[1], waveMiss);
+        if (waveEarly) atomicAdd(&s_wave[2], waveEarly);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
         const ArgsPtr A = launder(kargs);
         Ctrl *const ctrl = A->ctrl;
         const int shard = blockIdx.x % kOct;
-        if (waveLight) atomicAdd(&ctrl->light_hits[shard][0], (unsigned long long)waveLight);
-        if (waveMiss) atomicAdd(&ctrl->misses[shard][0], (unsigned long long)waveMiss);
-        if (waveEarly) {
-            atomicAdd(&ctrl->sum_live[A->depth + 1], (unsigned long long)waveEarly);   // they did enter the next bounce
-            atomicAdd(&ctrl->sum_early[A->depth + 1], (unsigned long long)waveEarly);  // ... without being moved through memory
-        }
+        const uint32_t wgLight = s_wave[0], wgMiss = s_wave[1], wgEarly = s_wave[2];
+        if (wgLight) atomicAdd(&ctrl->light_hits[shard][0], (unsigned long long)wgLight);
+        if (wgMiss) atomicAdd(&ctrl->misses[shard][0], (unsigned long long)wgMiss);
+        if (wgEarly) atomicAdd(&ctrl->early[A->depth + 1][shard][0], (unsigned long long)wgEarly);
     }
 }
 
