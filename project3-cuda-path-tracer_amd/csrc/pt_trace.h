@@ -27,7 +27,7 @@ constexpr int kWallMax = 6;          // large cubes ("walls") whose world-space 
 constexpr int kMinChunkShift = 11;   // chunks hold at least 2048 paths: a multiple of the tile size, so a tile never straddles two
 // k_bounce<., MANY> (scenes with more than kBinMax spheres): LDS words of the fixed scratch, floats per staged sphere
 // record (inverseTransform rows, transform rows, GeomDev::invZ, 4 B of padding), spheres a lane can record per tile
-constexpr int kMiscWords = kWaves * kCls + 5 * kCls + kSeg + (kSeg + 2) + 2 * PT_MAX_BATCH + 2;
+constexpr int kMiscWords = 2 * kWaves * kCls + 5 * kCls + kSeg + (kSeg + 2) + 2 * PT_MAX_BATCH + 2;
 static_assert(kMiscWords % 4 == 0, "the sphere records that follow are read as float4");
 constexpr int kSphRowFloats = 28;
 constexpr int kListMax = 8;
@@ -323,7 +323,7 @@ static_assert(sizeof(CullGroup) == 32 && offsetof(GeomDev, cullFlags) - offsetof
 // DOF (with FIRST only): camera rays start on a thin lens (README.md:100-101), so they share no origin (no precomputed
 // object-space camera position) and the pixel rectangles, which project the primitives through a pinhole, are not used.
 template <bool FIRST, bool MANY, bool DOF = false>
-__global__ __launch_bounds__(kBlock, DOF ? 5 : (MANY ? 7 : 8)) void k_bounce(BounceArgs argsByValue) {
+__global__ __launch_bounds__(kBlock, DOF ? 5 : (MANY ? (FIRST ? 6 : 7) : 8)) void k_bounce(BounceArgs argsByValue) {
     static_assert(FIRST || !DOF, "the lens only concerns the camera-ray bounce");
     (void)argsByValue;
     const ArgsPtr kargs = (ArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(kBlock, DOF ? 5 : (MANY ? 7 : 8)) void k_bounce(Bou
 #define S_GEOMHIT(nmats_) (reinterpret_cast<GeomHitDev *>(smem + kMiscWords * sizeof(uint32_t) + sizeof(MaterialDev) * (nmats_)))
 #define S_SPH(nmats_, ngeoms_) (reinterpret_cast<float *>(smem + kMiscWords * sizeof(uint32_t) + sizeof(MaterialDev) * (nmats_) + sizeof(GeomHitDev) * (ngeoms_)))
     uint32_t *const s_wave = s_misc;                       // [kWaves][kCls] survivors per wave and class (zero between tiles)
-    uint32_t *const s_base = s_wave + kWaves * kCls;       // [5][kCls] this tile's output run per class: first slot, paths before the
+    uint32_t *const s_base = s_wave + 2 * kWaves * kCls;       // [5][kCls] this tile's output run per class: first slot, paths before the
                                                            //           chunk boundary, first slot behind it; the class's last chunk lookup (reserveRun)
     uint32_t *const s_segcnt = s_base + 5 * kCls;          // [kSeg]   paths per input segment
     uint32_t *const s_segpre = s_segcnt + kSeg;            // [kSeg+2] tile prefix per input segment, [kSeg+1] = live paths
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(kBlock, DOF ? 5 : (MANY ? 7 : 8)) void k_bounce(Bou
         }
         if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctrl->sum_live[depth], (unsigned long long)nLive);
         if (blockIdx.x >= numTiles) return;
-        if (threadIdx.x < kWaves * kCls) s_wave[threadIdx.x] = 0u;
+        if (threadIdx.x < 2 * kWaves * kCls) s_wave[threadIdx.x] = 0u;
         if (threadIdx.x < kCls) s_base[3 * kCls + threadIdx.x] = 0xffffffffu;   // no chunk looked up yet
         for (int i = threadIdx.x; i < 2 * PT_MAX_BATCH; i += kBlock) {
             const int b = i % PT_MAX_BATCH;
@@ -417,6 +417,7 @@ __global__ __launch_bounds__(kBlock, DOF ? 5 : (MANY ? 7 : 8)) void k_bounce(Bou
     __syncthreads();
 
     uint32_t nLight = 0, nMiss = 0;         // per-lane tallies (VGPRs are the less scarce kind here), reduced and flushed once at the end
+    uint32_t wvSel = 0;                     // which half of s_wave the current tile counts in (0 or kWaves * kCls)
     uint32_t nEarly = 0;                    // survivors that certainly miss everything: ended at the scatter
     uint32_t sgIn = 0;                      // input segment of the tile being set up (tiles are visited in increasing order)
     uint32_t firstK = 0;                    // FIRST: how many tiles this workgroup has processed
@@ -848,7 +849,7 @@ __global__ __launch_bounds__(kBlock, DOF ? 5 : (MANY ? 7 : 8)) void k_bounce(Bou
 
         if (!launder(kargs)->lastBounce) {                       // S8: compaction into `out`, binned by class
             const int wave = (int)(tid >> 6), lane = (int)(tid & 63u);
-            uint32_t *wv = s_wave;
+            uint32_t *wv = s_wave + wvSel;                       // this tile's half of the double-buffered counts
             // same-class mask of this lane from four bit ballots (the sign compares already are the ballots)
             const unsigned long long ba = __ballot(alive);
             // class bits 0-2: the wall the ray can still hit (scenes with walls) or the octant of its direction
@@ -896,8 +897,12 @@ __global__ __launch_bounds__(kBlock, DOF ? 5 : (MANY ? 7 : 8)) void k_bounce(Bou
                 stSlot(dst, off, __int_as_float(pix)); dst += ocap;
                 stSlot(dst, off, __int_as_float((rem - 1) | (itb << 8)));
             }
-            __syncthreads();   // every wave has read this tile's counts: each wave clears its own row for the next tile
-            if (lane < kCls) wv[wave * kCls + lane] = 0u;
+            // No third barrier: the counts are double-buffered.  The other half was last read in the previous tile, and every
+            // wave finished those reads before it arrived at THIS tile's first barrier, so each wave may now clear its own
+            // row of it for the next tile (its own next writes follow in program order; the other waves' next reads of that
+            // row come after the next tile's first barrier).  s_base is rewritten only after the next tile's first barrier.
+            wvSel ^= (uint32_t)(kWaves * kCls);
+            if (lane < kCls) s_wave[wvSel + wave * kCls + lane] = 0u;
         }
         T = Tnext;
     }
