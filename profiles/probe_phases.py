@@ -11,13 +11,14 @@ pt.LIB_PATH = os.path.join(ROOT, "project3-cuda-path-tracer_amd", "csrc", "libpt
 L = pt.lib()
 L.pt_probe_read.argtypes = [C.POINTER(C.c_uint64)]
 names = ["box: transform + early miss", "box: normalize + slabs", "box: hit phase", "sphere: cull test",
-         "sphere: transform + radicand", "sphere: roots", "sphere: hit phase", "tile (all bounces)"]
-for scene_name, res, depth in (("cornell.txt", (1280, 720), 8), ("cornell_glass.txt", (1920, 1080), 16), ("spheres64.txt", (1024, 1024), 8)):
+         "sphere: transform + radicand", "sphere: roots", "sphere: hit phase", "tile (later bounces)",
+         "tile (camera bounce, in scene)", "shading (a hit)", "scatter", "hemisphere sample", "bounding-ball certificate", "wall certificate"]
+for scene_name, res, depth in (("cornell.txt", (1280, 720), 1), ("cornell.txt", (1280, 720), 8), ("cornell_glass.txt", (1920, 1080), 16), ("spheres64.txt", (1024, 1024), 8)):
     sc = pt.Scene(os.path.join(ROOT, "scenes", scene_name))
     sc.set_resolution(*res)
     pt.pathtraceFree()
     pt.pathtraceInit(sc, traceDepth=depth, max_batch=8, pipeline_depth=3)
-    out = (C.c_uint64 * 16)()
+    out = (C.c_uint64 * 32)()
     L.pt_probe_read(out)
     for it in range(1, 33, 8):
         pt.pathtrace_batch(None, 0, it, 8)
@@ -26,6 +27,6 @@ for scene_name, res, depth in (("cornell.txt", (1280, 720), 8), ("cornell_glass.
     v = [int(x) for x in out]
     tiles = max(v[14], 1)
     print("%s %dx%d depth %d: %d wave-tiles after the first bounce (%.1f valid paths per wave); the FIRST bounce's phases are included in the counts below" % (scene_name, res[0], res[1], depth, v[14], v[15] / tiles))
-    for k in range(7):
+    for k in list(range(7)) + list(range(8, 14)):
         print("  %-30s %10d wave executions, %5.1f active lanes each" % (names[k], v[2 * k], v[2 * k + 1] / max(v[2 * k], 1)))
 pt.pathtraceFree()

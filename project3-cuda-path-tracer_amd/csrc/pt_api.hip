@@ -1337,6 +1337,19 @@ int pt_test_unscaled_sqrt_sweep(uint64_t mismatches[4]) {
     return PT_OK;
 }
 
+#ifdef PT_PROBE
+// instrumented build only (make probe): reads and clears the phase counters of pt_device.h
+extern "C" int pt_probe_read(uint64_t out[32]) {
+    NEED_GPU();
+    unsigned long long h[32], z[32] = {0};
+    HIPCHECK(hipDeviceSynchronize());
+    HIPCHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(ptd::g_probe), sizeof h));
+    HIPCHECK(hipMemcpyToSymbol(HIP_SYMBOL(ptd::g_probe), z, sizeof z));
+    for (int i = 0; i < 32; ++i) out[i] = h[i];
+    return PT_OK;
+}
+#endif
+
 int pt_test_hemisphere(const float *normals3, const int32_t *iid3, int n, float *out3) {
     NEED_GPU();
     if (n <= 0) return PT_OK;

@@ -16,7 +16,7 @@ namespace ptd {
 // Instrumentation for profiles/probe_phases.py (built with -DPT_PROBE only): wave-level executions and active lanes
 // of the phases of the two intersection tests.  g_probe[2k] += 1 per wave that enters phase k, g_probe[2k+1] += lanes.
 #ifdef PT_PROBE
-__device__ unsigned long long g_probe[16];
+__device__ unsigned long long g_probe[32];
 __device__ __forceinline__ void probe(int k) {
     const unsigned long long m = __ballot(1);
     if (__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) == 0) {

@@ -599,7 +599,7 @@ __global__ __launch_bounds__(kBlock, DOF ? 5 : (MANY ? (FIRST ? 6 : 7) : 8)) voi
                 itb = cur.packed >> 8;
             }
 
-            if (!FIRST) probe(7);                                   // tiles (waves with at least one valid path) and valid paths
+            if (FIRST) { if (inScene) probe(8); } else probe(7);                                   // tiles (waves with at least one valid path) and valid paths
             // nearest hit, geoms in file order, strict '<' so the first geom wins ties (S3)
             float tbest = 0.0f;
             int hit = -1;
@@ -684,6 +684,7 @@ __global__ __launch_bounds__(kBlock, DOF ? 5 : (MANY ? (FIRST ? 6 : 7) : 8)) voi
             if (hit < 0) {
                 missedI = 1u;                                    // S4: background is black
             } else {
+                probe(9);
                 const GeomHitDev &GH = S_GEOMHIT(launder(kargs)->prm.nmats)[hit];   // per-lane geom: LDS lookup
                 const bool isSphere = GH.type == 0;
                 bool faceOk = true;
@@ -705,6 +706,7 @@ __global__ __launch_bounds__(kBlock, DOF ? 5 : (MANY ? (FIRST ? 6 : 7) : 8)) voi
                         dst[0] = c.x; dst[1] = c.y; dst[2] = c.z;
                     }
                 } else if (!launder(kargs)->lastBounce) {        // S6 scatter (S7: skipped on the last bounce)
+                    probe(10);
                     Rng rng = makeSeededRandomEngineHashed(s_iterHash[itb], pix);
                     const F3 scol = f3(M.specColor[0], M.specColor[1], M.specColor[2]);
                     F3 ndir = dir, norg;
@@ -786,6 +788,7 @@ __global__ __launch_bounds__(kBlock, DOF ? 5 : (MANY ? (FIRST ? 6 : 7) : 8)) voi
                         }
                     }
                     if (diffuse && !toLight) {
+                        probe(11);
                         float up, cOver, sOver;
                         hemisphereDraws(rng, up, cOver, sOver);
                         F3 p1, p2;                                // the sampler's tangent frame: computed for a sphere, looked up for a cube face
@@ -807,8 +810,8 @@ __global__ __launch_bounds__(kBlock, DOF ? 5 : (MANY ? (FIRST ? 6 : 7) : 8)) voi
                             const GeomPtr geoms = (GeomPtr)(A->ggeoms);
                             const float ndd = dot(ndir, ndir);
                             uint32_t cand = 0u;
-                            for (int sI = 0; sI < nBinned; ++sI)
-                                cand |= certainMiss(*(launder(geoms) + A->prm.binGeom[sI]), norg, ndir, ndd) ? 0u : 1u;
+                            for (int sI = 0; sI < nBinned; ++sI) { probe(12);
+                                cand |= certainMiss(*(launder(geoms) + A->prm.binGeom[sI]), norg, ndir, ndd) ? 0u : 1u; }
                             smallCandI = cand;
                         }
                     }
@@ -822,8 +825,8 @@ __global__ __launch_bounds__(kBlock, DOF ? 5 : (MANY ? (FIRST ? 6 : 7) : 8)) voi
                                 const F3 inv = f3(__builtin_amdgcn_rcpf(ndir.x), __builtin_amdgcn_rcpf(ndir.y), __builtin_amdgcn_rcpf(ndir.z));
                                 const WallPtr walls = (WallPtr)(A->walls);
                                 uint32_t possible = 0u;
-                                for (int w = 0; w < nWalls; ++w)
-                                    possible |= wallCertainMiss(*(launder(walls) + w), norg, inv) ? 0u : (1u << w);
+                                for (int w = 0; w < nWalls; ++w) { probe(13);
+                                    possible |= wallCertainMiss(*(launder(walls) + w), norg, inv) ? 0u : (1u << w); }
                                 const int cnt = __popc(possible);
                                 wallSel = cnt == 1 ? (uint32_t)(__ffs((int)possible) - 1) : (cnt == 0 ? 7u : 6u);
                                 // nothing left to hit: the reference's nearest-hit loop would come back empty at the next bounce.
