@@ -85,6 +85,18 @@ def lib():
         L.orc_scene_image_name.argtypes = [C.c_void_p]
         L.orc_scene_image_name.restype = C.c_char_p
         L.orc_camera_set_resolution.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.orc_scene_num_meshes.argtypes = [C.c_void_p]
+        for name in ("orc_scene_mesh_geom", "orc_scene_mesh_ntris"):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_int]
+        L.orc_scene_mesh_tris.argtypes = [C.c_void_p, C.c_int]
+        L.orc_scene_mesh_tris.restype = C.c_void_p
+        L.orc_render_set_mesh.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.orc_mesh_intersect.restype = C.c_float
+        L.orc_mesh_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_mesh_margin.restype = C.c_float
+        L.orc_mesh_margin.argtypes = [C.c_void_p, C.c_int]
+        L.orc_mesh_triangle.argtypes = [C.c_void_p] * 6 + [C.POINTER(C.c_int)]
         L.orc_render_create.restype = C.c_void_p
         L.orc_render_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]
         L.orc_render_free.argtypes = [C.c_void_p]
@@ -201,6 +213,31 @@ def intersect(geom, ray6, sphere=None):
     return np.float32(t), p, n, int(o.value)
 
 
+def mesh_intersect(geom, tris, ray6):
+    """One ray against one mesh geom (tris: n x 9 floats, object space), brute force over every triangle.
+    Returns (t, p, n, outside, triangle); p, n, outside keep their sentinels on a miss, triangle = -1."""
+    g = np.ascontiguousarray(geom).reshape(-1)[:1]
+    tr = np.ascontiguousarray(tris, np.float32).reshape(-1, 9)
+    p = np.full(3, -7.0, np.float32)
+    n = np.full(3, -7.0, np.float32)
+    o, k = C.c_int(1), C.c_int(-1)
+    t = lib().orc_mesh_intersect(_p(g), _p(tr), len(tr), _p(f32(*ray6)), _p(p), _p(n), C.byref(o), C.byref(k))
+    return np.float32(t), p, n, int(o.value), int(k.value)
+
+
+def mesh_triangle(o, d, v0, v1, v2):
+    """The two-sided triangle test alone.  Returns (hit, (t, u, v), front); t, u, v are NaN where not evaluated."""
+    tuv = np.full(3, np.nan, np.float32)
+    front = C.c_int(0)
+    hit = lib().orc_mesh_triangle(_p(f32(*o)), _p(f32(*d)), _p(f32(*v0)), _p(f32(*v1)), _p(f32(*v2)), _p(tuv), C.byref(front))
+    return bool(hit), tuv, bool(front.value)
+
+
+def mesh_margin(tris):
+    tr = np.ascontiguousarray(tris, np.float32).reshape(-1, 9)
+    return np.float32(lib().orc_mesh_margin(_p(tr), len(tr)))
+
+
 def hemisphere_seeded(n, it, index, depth):
     o = np.empty(3, np.float32)
     lib().orc_hemisphere_seeded(_p(f32(*n)), it, index, depth, _p(o))
@@ -223,6 +260,11 @@ class Scene:
         self.iterations = L.orc_scene_iterations(h)
         self.depth = L.orc_scene_depth(h)
         self.image_name = L.orc_scene_image_name(h).decode()
+        self.meshes = {}            # geom index -> (ntris, 9) float32, object space
+        for i in range(L.orc_scene_num_meshes(h)):
+            nt = L.orc_scene_mesh_ntris(h, i)
+            self.meshes[L.orc_scene_mesh_geom(h, i)] = np.frombuffer(
+                C.string_at(L.orc_scene_mesh_tris(h, i), 36 * nt), np.float32).reshape(nt, 9).copy()
         L.orc_scene_free(h)
 
     def set_resolution(self, w, h):
@@ -230,7 +272,7 @@ class Scene:
 
 
 class Renderer:
-    def __init__(self, camera, geoms, materials, depth):
+    def __init__(self, camera, geoms, materials, depth, meshes=None):
         self.camera = np.ascontiguousarray(camera).copy()
         self.geoms = np.ascontiguousarray(geoms)
         self.materials = np.ascontiguousarray(materials)
@@ -238,6 +280,9 @@ class Renderer:
         self.W, self.H = (int(v) for v in self.camera["resolution"][0])
         self.h = lib().orc_render_create(_p(self.camera), _p(self.geoms), len(self.geoms),
                                          _p(self.materials), len(self.materials), depth)
+        for g, tris in (meshes or {}).items():
+            tr = np.ascontiguousarray(tris, np.float32).reshape(-1, 9)
+            lib().orc_render_set_mesh(self.h, int(g), _p(tr), len(tr))
 
     def __del__(self):
         if getattr(self, "h", None):

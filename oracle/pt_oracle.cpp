@@ -476,6 +476,168 @@ float sphere_intersection_test(const OGeom &sphere, const Ray &r, V3 &intersecti
     return length3(sub(r.origin, intersectionPoint));
 }
 
+/* ===================================================================== */
+/* triangle meshes (README.md:112-116, 236: object type "mesh")            */
+/* ===================================================================== */
+/* The reference names meshes and `glm::intersectRayTriangle` but holds no mesh code: the semantics below are build-defined.
+ *   - triangles live in OBJECT space (the OBJ file's coordinates); the ray is taken there like the sphere test does
+ *     (intersections.h:104-110): ro = multiplyMV(inverseTransform, (o, 1)), rd = normalize(multiplyMV(inverseTransform, (d, 0)));
+ *   - the triangle test is glm::intersectRayTriangle (glm/gtx/intersect.inl:36-72) op for op, made two-sided:
+ *     `a < epsilon` becomes `|a| < epsilon`, and a > 0 is the front (counter-clockwise) side, reported as `outside`;
+ *   - a triangle is only tested when the ray passes the slab test of the triangle's bounding box, inflated by a per-mesh
+ *     margin, and its hit only counts at or beyond that box's entry parameter.  Both hold for every geometrically true hit;
+ *     they make the rule local to (ray, triangle), so a bounding-volume hierarchy whose node boxes contain their triangles'
+ *     boxes visits exactly the triangles this loop accepts (fp32 subtraction, multiplication by a common factor and
+ *     comparison are monotone, so a ray that passes a box's test passes the test of every box containing it), and may skip
+ *     nodes whose entry parameter lies beyond the best hit so far: any traversal order gives THIS function's result;
+ *   - nearest = smallest object-space parameter t, ties to the lower triangle index; point and distance as the sphere test
+ *     does (getPointOnRay, transform, world distance); flat normal normalize(invTranspose * normalize(cross(e1, e2))),
+ *     negated on the back side. */
+const float kMeshEps = 1.1920928955078125e-07f;     /* std::numeric_limits<float>::epsilon(), intersect.inl:50 */
+const float kMeshUp = 1.00001f, kMeshDn = 0.99999f; /* relative slack of the slab comparison */
+
+struct OMesh {
+    int geom;
+    std::vector<float> tris;    /* 9 floats per triangle: v0, v1, v2 */
+    float margin;
+};
+
+float mesh_margin(const float *tris, int ntris) {
+    float maxAbs = 0.0f;
+    for (int i = 0; i < 9 * ntris; ++i) {
+        float a = std::fabs(tris[i]);
+        if (a > maxAbs) maxAbs = a;
+    }
+    float m = 1e-5f * maxAbs;
+    if (!(m >= 1e-30f)) m = 1e-30f;
+    return m;
+}
+
+inline float min2(float a, float b) { return a < b ? a : b; }
+inline float max2(float a, float b) { return a < b ? b : a; }
+
+void tri_box(const float *t, float m, V3 &lo, V3 &hi) {
+    lo = v3(min2(min2(t[0], t[3]), t[6]) - m, min2(min2(t[1], t[4]), t[7]) - m, min2(min2(t[2], t[5]), t[8]) - m);
+    hi = v3(max2(max2(t[0], t[3]), t[6]) + m, max2(max2(t[1], t[4]), t[7]) + m, max2(max2(t[2], t[5]), t[8]) + m);
+}
+
+inline float guarded_reciprocal(float d) {
+    float g = std::fabs(d) < 1e-30f ? std::copysign(1e-30f, d) : d;
+    return 1.0f / g;
+}
+
+/* the slab test of an axis-aligned box; inv = guarded reciprocals of the direction */
+bool mesh_slab(V3 lo, V3 hi, V3 o, V3 inv, float &tmin) {
+    float ax = (lo.x - o.x) * inv.x, bx = (hi.x - o.x) * inv.x;
+    float ay = (lo.y - o.y) * inv.y, by = (hi.y - o.y) * inv.y;
+    float az = (lo.z - o.z) * inv.z, bz = (hi.z - o.z) * inv.z;
+    float tn = max2(max2(min2(ax, bx), min2(ay, by)), min2(az, bz));
+    float tf = min2(min2(max2(ax, bx), max2(ay, by)), max2(az, bz));
+    tmin = tn * kMeshDn;
+    return tf * kMeshUp >= tmin && tf >= 0.0f;
+}
+
+/* glm::intersectRayTriangle, two-sided; e1 = v1 - v0, e2 = v2 - v0 */
+bool mesh_triangle(V3 o, V3 d, V3 v0, V3 e1, V3 e2, float &t, bool &front, float *uv = NULL) {
+    V3 p = cross3(d, e2);
+    float a = dot3(e1, p);
+    if (std::fabs(a) < kMeshEps) return false;
+    float f = 1.0f / a;
+    V3 s = sub(o, v0);
+    float u = f * dot3(s, p);
+    if (uv) uv[0] = u;
+    if (u < 0.0f) return false;
+    if (u > 1.0f) return false;
+    V3 q = cross3(s, e1);
+    float v = f * dot3(d, q);
+    if (uv) uv[1] = v;
+    if (v < 0.0f) return false;
+    if (v + u > 1.0f) return false;
+    t = f * dot3(e2, q);
+    front = a > 0.0f;
+    return t >= 0.0f;
+}
+
+float mesh_intersection_test(const OGeom &g, const OMesh &mesh, const Ray &r, V3 &intersectionPoint, V3 &normal,
+                             bool &outside, int *triOut = NULL) {
+    M4 inv = m4_from(g.inverseTransform);
+    M4 xf = m4_from(g.transform);
+    M4 invT = m4_from(g.invTranspose);
+    Ray rt;
+    rt.origin = multiplyMV(inv, v4(r.origin.x, r.origin.y, r.origin.z, 1.0f));
+    rt.direction = normalize3(multiplyMV(inv, v4(r.direction.x, r.direction.y, r.direction.z, 0.0f)));
+    V3 rinv = v3(guarded_reciprocal(rt.direction.x), guarded_reciprocal(rt.direction.y), guarded_reciprocal(rt.direction.z));
+    int best = -1;
+    float tbest = 0.0f;
+    bool bestFront = false;
+    int ntris = (int)(mesh.tris.size() / 9);
+    for (int i = 0; i < ntris; ++i) {
+        const float *tv = &mesh.tris[9 * (size_t)i];
+        V3 lo, hi;
+        tri_box(tv, mesh.margin, lo, hi);
+        float tmin;
+        if (!mesh_slab(lo, hi, rt.origin, rinv, tmin)) continue;
+        V3 v0 = v3(tv[0], tv[1], tv[2]);
+        V3 e1 = sub(v3(tv[3], tv[4], tv[5]), v0), e2 = sub(v3(tv[6], tv[7], tv[8]), v0);
+        float t;
+        bool front;
+        if (!mesh_triangle(rt.origin, rt.direction, v0, e1, e2, t, front)) continue;
+        if (!(t >= tmin)) continue;
+        if (best < 0 || t < tbest) {   /* (index order: an equal t keeps the lower index) */
+            best = i;
+            tbest = t;
+            bestFront = front;
+        }
+    }
+    if (triOut) *triOut = best;
+    if (best < 0) return -1;
+    const float *tv = &mesh.tris[9 * (size_t)best];
+    V3 v0 = v3(tv[0], tv[1], tv[2]);
+    V3 e1 = sub(v3(tv[3], tv[4], tv[5]), v0), e2 = sub(v3(tv[6], tv[7], tv[8]), v0);
+    V3 nobj = normalize3(cross3(e1, e2));
+    V3 obj = get_point_on_ray(rt, tbest);
+    intersectionPoint = multiplyMV(xf, v4(obj.x, obj.y, obj.z, 1.f));
+    normal = normalize3(multiplyMV(invT, v4(nobj.x, nobj.y, nobj.z, 0.f)));
+    outside = bestFront;
+    if (!outside) normal = neg(normal);
+    return length3(sub(r.origin, intersectionPoint));
+}
+
+/* Wavefront OBJ: `v x y z` and `f a b c ...` (a = i, i/j, i//k or i/j/k; 1-based, negative = relative to the vertices read
+ * so far); polygons are fanned from their first vertex; everything else is ignored.  false when the file cannot be read. */
+bool load_obj(const std::string &path, std::vector<float> &tris) {
+    std::ifstream fp(path.c_str());
+    if (!fp.is_open()) return false;
+    std::vector<float> verts;
+    std::string line;
+    while (std::getline(fp, line)) {
+        std::istringstream ss(line);
+        std::string key;
+        if (!(ss >> key)) continue;
+        if (key == "v") {
+            double x = 0, y = 0, z = 0;
+            ss >> x >> y >> z;
+            verts.push_back((float)x); verts.push_back((float)y); verts.push_back((float)z);
+        } else if (key == "f") {
+            std::vector<int> idx;
+            std::string tok;
+            while (ss >> tok) {
+                int i = atoi(tok.c_str());      /* stops at the first '/' */
+                int nv = (int)(verts.size() / 3);
+                int k = i > 0 ? i - 1 : nv + i;
+                if (i == 0 || k < 0 || k >= nv) { idx.clear(); break; }
+                idx.push_back(k);
+            }
+            for (size_t k = 2; k < idx.size(); ++k) {
+                const int tri[3] = {idx[0], idx[k - 1], idx[k]};
+                for (int c = 0; c < 3; ++c)
+                    for (int a = 0; a < 3; ++a) tris.push_back(verts[3 * (size_t)tri[c] + a]);
+            }
+        }
+    }
+    return true;
+}
+
 /* src/interactions.h:10-42 */
 V3 random_direction_in_hemisphere(V3 normal, uint32_t &rng) {
     float up = std::sqrt(rng_u01(rng));     /* cos(theta) */
@@ -532,6 +694,8 @@ struct OScene {
     int iterations;
     int traceDepth;
     std::string imageName;
+    std::string dir;                   /* directory of the scene file: `mesh <file>` paths are relative to it */
+    std::vector<OMesh> meshes;         /* geoms of type 2 */
 };
 
 struct ORender {
@@ -547,6 +711,8 @@ struct ORender {
     V3 viewN;                          /* normalize(view) */
     int directLighting;                /* README.md:107-108: a final ray to a random point of an emissive object */
     std::vector<int> emitters;         /* geoms with an emissive material, file order */
+    std::vector<OMesh> meshes;         /* triangle data of the geoms of type 2 */
+    std::vector<int> meshOf;           /* geom -> index into meshes, -1 */
 };
 
 namespace {
@@ -657,6 +823,20 @@ void load_geom(OScene &sc, std::ifstream &fp, const std::string &idtok) {
     if (!line.empty() && fp.good()) {
         if (strcmp(line.c_str(), "sphere") == 0) g.type = 0;
         else if (strcmp(line.c_str(), "cube") == 0) g.type = 1;
+        else {
+            /* README.md:236 names a third type, "mesh"; the file is build-defined: `mesh <path.obj>`, relative to the scene */
+            std::vector<std::string> t = tokenize(line);
+            if (t.size() >= 2 && t[0] == "mesh") {
+                OMesh m;
+                m.geom = id;
+                std::string path = t[1][0] == '/' ? t[1] : sc.dir + t[1];
+                if (load_obj(path, m.tris) && !m.tris.empty()) {
+                    m.margin = mesh_margin(m.tris.data(), (int)(m.tris.size() / 9));
+                    sc.meshes.push_back(m);
+                    g.type = 2;
+                }
+            }
+        }
     }
     safe_getline(fp, line);
     if (!line.empty() && fp.good()) {
@@ -685,8 +865,14 @@ int nearest_hit(const ORender &R, const Ray &ray, V3 &p, V3 &n, bool &outside) {
     for (int i = 0; i < (int)R.geoms.size(); ++i) {
         V3 tp = v3(0, 0, 0), tn = v3(0, 0, 0);
         bool to = false;
-        float t = R.geoms[i].type == 0 ? sphere_intersection_test(R.geoms[i], ray, tp, tn, to)
-                                       : box_intersection_test(R.geoms[i], ray, tp, tn, to);
+        float t;
+        if (R.geoms[i].type == 2) {
+            /* a mesh geom without triangle data is never hit */
+            t = i < (int)R.meshOf.size() && R.meshOf[i] >= 0 ? mesh_intersection_test(R.geoms[i], R.meshes[R.meshOf[i]], ray, tp, tn, to) : -1.0f;
+        } else {
+            t = R.geoms[i].type == 0 ? sphere_intersection_test(R.geoms[i], ray, tp, tn, to)
+                                     : box_intersection_test(R.geoms[i], ray, tp, tn, to);
+        }
         if (t > 0.0f && (hit < 0 || t < t_min)) {
             t_min = t;
             hit = i;
@@ -911,6 +1097,11 @@ OScene *orc_scene_load(const char *path) {
     memset(&sc->camera, 0, sizeof(OCamera));
     sc->iterations = 0;
     sc->traceDepth = 0;
+    {
+        std::string sp(path);
+        size_t slash = sp.find_last_of('/');
+        sc->dir = slash == std::string::npos ? std::string() : sp.substr(0, slash + 1);
+    }
     while (fp.good()) { /* scene.cpp:16-32 */
         std::string line;
         safe_getline(fp, line);
@@ -932,6 +1123,10 @@ const OCamera *orc_scene_camera(const OScene *s) { return &s->camera; }
 int orc_scene_iterations(const OScene *s) { return s->iterations; }
 int orc_scene_depth(const OScene *s) { return s->traceDepth; }
 const char *orc_scene_image_name(const OScene *s) { return s->imageName.c_str(); }
+int orc_scene_num_meshes(const OScene *s) { return (int)s->meshes.size(); }
+int orc_scene_mesh_geom(const OScene *s, int i) { return s->meshes[i].geom; }
+int orc_scene_mesh_ntris(const OScene *s, int i) { return (int)(s->meshes[i].tris.size() / 9); }
+const float *orc_scene_mesh_tris(const OScene *s, int i) { return s->meshes[i].tris.data(); }
 void orc_camera_set_resolution(OCamera *cam, int w, int h) {
     cam->resX = w;
     cam->resY = h;
@@ -960,9 +1155,50 @@ ORender *orc_render_create(const OCamera *cam, const OGeom *geoms, int ngeoms, c
     R->focalDistance = 0.0f;
     R->viewN = normalize3(R->view);
     R->directLighting = 0;
+    /* (direct lighting samples the unit cube of an emissive primitive: emissive meshes are not sampled) */
     for (int i = 0; i < ngeoms; ++i)
-        if (mats[geoms[i].materialid].emittance > 0.0f) R->emitters.push_back(i);
+        if (geoms[i].type != 2 && mats[geoms[i].materialid].emittance > 0.0f) R->emitters.push_back(i);
+    R->meshOf.assign(ngeoms, -1);
     return R;
+}
+void orc_render_set_mesh(ORender *R, int geom, const float *tris, int ntris) {
+    if (geom < 0 || geom >= (int)R->geoms.size() || ntris <= 0) return;
+    OMesh m;
+    m.geom = geom;
+    m.tris.assign(tris, tris + 9 * (size_t)ntris);
+    m.margin = mesh_margin(tris, ntris);
+    R->meshOf[geom] = (int)R->meshes.size();
+    R->meshes.push_back(m);
+}
+float orc_mesh_margin(const float *tris, int ntris) { return mesh_margin(tris, ntris); }
+/* the two-sided triangle test alone: returns hit; tuv = (t, u, v) as far as they were evaluated (glm's baryPosition is (u, v, t)) */
+int orc_mesh_triangle(const float o[3], const float d[3], const float v0[3], const float v1[3], const float v2[3], float tuv[3],
+                      int *front) {
+    V3 a = v3(v0[0], v0[1], v0[2]);
+    V3 e1 = sub(v3(v1[0], v1[1], v1[2]), a), e2 = sub(v3(v2[0], v2[1], v2[2]), a);
+    float t = tuv[0];
+    bool f = *front != 0;
+    bool hit = mesh_triangle(v3(o[0], o[1], o[2]), v3(d[0], d[1], d[2]), a, e1, e2, t, f, tuv + 1);
+    tuv[0] = t;
+    *front = f ? 1 : 0;
+    return hit ? 1 : 0;
+}
+float orc_mesh_intersect(const OGeom *g, const float *tris, int ntris, const float ray[6], float p[3], float n[3], int *outside,
+                         int *tri) {
+    OMesh m;
+    m.geom = 0;
+    m.tris.assign(tris, tris + 9 * (size_t)ntris);
+    m.margin = mesh_margin(tris, ntris);
+    Ray r;
+    r.origin = v3(ray[0], ray[1], ray[2]);
+    r.direction = v3(ray[3], ray[4], ray[5]);
+    V3 tp = v3(p[0], p[1], p[2]), tn = v3(n[0], n[1], n[2]);
+    bool to = *outside != 0;
+    float t = mesh_intersection_test(*g, m, r, tp, tn, to, tri);
+    p[0] = tp.x; p[1] = tp.y; p[2] = tp.z;
+    n[0] = tn.x; n[1] = tn.y; n[2] = tn.z;
+    *outside = to ? 1 : 0;
+    return t;
 }
 void orc_render_set_extras(ORender *R, float lensRadius, float focalDistance, int directLighting) {
     R->lensRadius = lensRadius;

@@ -32,7 +32,7 @@ typedef struct { float x, y, z; } OVec3;
 
 /* reference src/sceneStructs.h:18-27 (236 bytes, column-major mat4) */
 typedef struct {
-    int   type;            /* 0 = SPHERE, 1 = CUBE (sceneStructs.h:8-11) */
+    int   type;            /* 0 = SPHERE, 1 = CUBE (sceneStructs.h:8-11); 2 = MESH (README.md:236; build-defined, see below) */
     int   materialid;
     OVec3 translation, rotation, scale;
     float transform[16];
@@ -95,6 +95,11 @@ const OCamera   *orc_scene_camera(const OScene *);
 int     orc_scene_iterations(const OScene *);
 int     orc_scene_depth(const OScene *);
 const char *orc_scene_image_name(const OScene *);
+/* `mesh <file.obj>` objects (README.md:112-116, 236): triangle soup per mesh geom, 9 floats per triangle, object space */
+int     orc_scene_num_meshes(const OScene *);
+int     orc_scene_mesh_geom(const OScene *, int i);
+int     orc_scene_mesh_ntris(const OScene *, int i);
+const float *orc_scene_mesh_tris(const OScene *, int i);
 /* RES override: recomputes fov.x exactly as scene.cpp:133-136 does */
 void    orc_camera_set_resolution(OCamera *cam, int w, int h);
 
@@ -107,6 +112,16 @@ void     orc_render_free(ORender *);
  * thin lens (radius 0 = pinhole), direct lighting (the last bounce aims at a light, one more bounce collects).
  * Imperfect specular needs no switch: it is driven by Material::specular.exponent (SPECEX) > 0. */
 void     orc_render_set_extras(ORender *, float lensRadius, float focalDistance, int directLighting);
+/* triangles of a geom of type 2 (a mesh geom without triangles is never hit) */
+void     orc_render_set_mesh(ORender *, int geom, const float *tris, int ntris);
+/* one ray against one mesh: brute force over every triangle (the semantics; see pt_oracle.cpp).  *tri = winning triangle or -1;
+ * outputs keep their input values on a miss */
+float    orc_mesh_intersect(const OGeom *g, const float *tris, int ntris, const float ray[6], float p[3], float n[3],
+                            int *outside, int *tri);
+float    orc_mesh_margin(const float *tris, int ntris);
+/* the two-sided triangle test alone (glm/gtx/intersect.inl:36-72 on its front side): tuv = (t, u, v) as far as evaluated */
+int      orc_mesh_triangle(const float o[3], const float d[3], const float v0[3], const float v1[3], const float v2[3],
+                           float tuv[3], int *front);
 float    orc_pow(float x, float e);                             /* build-defined x^e, 0 <= x <= 1 */
 /* One iteration (iter is 1-based) over the rows y with y % shardCount == shardRank.
  * image = W*H*3 floats running sum (accumulated in place). */

@@ -2,7 +2,7 @@
  * ref_harness.cpp -- TEST INFRASTRUCTURE.  Thin extern "C" wrapper around the REFERENCE's own
  * sources, compiled where they lie under /root/reference (never copied):
  *     src/intersections.h, src/sceneStructs.h, src/utilities.{h,cpp}, src/scene.{h,cpp},
- *     external/include/glm (vendored glm 0.9.6.3)
+ *     external/include/glm (vendored glm 0.9.6.3; glm/gtx/intersect.inl for the triangle test README.md:116 names)
  * Built only in the authoring container by oracle/Makefile (target _ref) with plain g++;
  * <cuda_runtime.h> (src/sceneStructs.h:5) resolves to the real CUDA runtime header that ships
  * in this image with triton (no stand-in headers are written).  Output: oracle/_ref/libptref.so.
@@ -35,6 +35,7 @@ using std::pow; /* variant build: C++11 std::pow(float,int) -> double (what a no
 #include "intersections.h"
 #include "scene.h"
 #include <glm/gtc/matrix_inverse.hpp>
+#include <glm/gtx/intersect.hpp>
 
 static_assert(sizeof(Ray) == 24 && sizeof(Geom) == 236 && sizeof(Material) == 44 && sizeof(Camera) == 52,
               "reference layout (SURVEY section 7 step 1)");
@@ -94,6 +95,15 @@ void ref_reflect(const float *I, const float *N, float *out) {
 }
 void ref_refract(const float *I, const float *N, float eta, float *out) {
     put3(out, glm::refract(glm::vec3(I[0], I[1], I[2]), glm::vec3(N[0], N[1], N[2]), eta));
+}
+
+/* glm/gtx/intersect.inl:36-72, the triangle test README.md:116 points mesh loaders to */
+int ref_intersect_ray_triangle(const float *o, const float *d, const float *v0, const float *v1, const float *v2, float *bary) {
+    glm::vec3 b(bary[0], bary[1], bary[2]);
+    bool hit = glm::intersectRayTriangle(glm::vec3(o[0], o[1], o[2]), glm::vec3(d[0], d[1], d[2]), glm::vec3(v0[0], v0[1], v0[2]),
+                                         glm::vec3(v1[0], v1[1], v1[2]), glm::vec3(v2[0], v2[1], v2[2]), b);
+    put3(bary, b);
+    return hit ? 1 : 0;
 }
 
 /* src/utilities.cpp:65-72 + src/scene.cpp:82-85 */

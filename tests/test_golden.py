@@ -190,3 +190,24 @@ def test_to_rgba8_conversion(oracle):
     want = [[0, int(np.float32(0.5) / np.float32(3) * 255.0), 85], [170, 255, 0],
             [255, int(float(np.float32(2.999) / np.float32(3)) * 255.0), 0]]
     assert out[:, :3].tolist() == want and np.all(out[:, 3] == 0)
+
+
+def test_triangle_test_against_glm_intersect_ray_triangle(oracle):
+    """The oracle's two-sided triangle test (meshes, README.md:112-116) next to the reference's vendored
+    glm::intersectRayTriangle (glm/gtx/intersect.inl:36-72; vectors by oracle/gen_golden_mesh.py): where glm reports a hit the
+    restatement reports the same front-side hit with the same (u, v, t) bit for bit; where glm does not, it reports a miss or a
+    hit on the back side -- the only difference between the two (glm culls back faces, `a < epsilon`)."""
+    z = np.load(os.path.join(GOLD, "triangles.npz"))
+    n = len(z["hit"])
+    front_hits = back_hits = 0
+    for i in range(n):
+        hit, tuv, front = oracle.mesh_triangle(z["origin"][i], z["direction"][i], z["v"][i, 0], z["v"][i, 1], z["v"][i, 2])
+        if z["hit"][i]:
+            assert hit and front, i
+            got = np.array([tuv[1], tuv[2], tuv[0]], np.float32)       # glm's baryPosition is (u, v, t)
+            assert np.array_equal(bits(got), bits(z["bary"][i])), (i, got, z["bary"][i])
+            front_hits += 1
+        else:
+            assert (not hit) or (not front), i
+            back_hits += int(hit)
+    assert front_hits == int(z["hit"].sum()) and front_hits > 500 and back_hits > 500
