@@ -29,8 +29,9 @@ extern "C" {
 
 typedef struct PtVec3 { float x, y, z; } PtVec3;
 
-/* reference src/sceneStructs.h:8-11 */
-enum { PT_SPHERE = 0, PT_CUBE = 1 };
+/* reference src/sceneStructs.h:8-11; PT_MESH: the third object type of the scene format (README.md:236, "mesh"), which the
+ * reference's enum and loader do not have -- see pt_set_meshes */
+enum { PT_SPHERE = 0, PT_CUBE = 1, PT_MESH = 2 };
 
 /* reference src/sceneStructs.h:18-27 -- 236 bytes, mat4 column-major (m[col*4+row]) */
 typedef struct PtGeom {
@@ -121,6 +122,27 @@ typedef struct PtCounters {
                                               which is what they do, but never written to or read from the path pools */
 } PtCounters;
 
+/* Triangle meshes (README.md:112-116 "arbitrary mesh loading and rendering", README.md:236 object type "mesh"; the reference
+ * names them and `glm::intersectRayTriangle` and holds no mesh code, so the semantics are build-defined -- oracle/pt_oracle.cpp,
+ * mesh_intersection_test):
+ *   - a PtGeom of type PT_MESH carries its transform like any primitive; its triangles are in OBJECT space (the OBJ file's
+ *     coordinates), 9 floats each (v0, v1, v2), counter-clockwise = front ("outside");
+ *   - the ray is taken to object space like the sphere test does (src/intersections.h:104-110); the triangle test is
+ *     glm::intersectRayTriangle (glm/gtx/intersect.inl:36-72) made two-sided; a triangle is tested when the ray passes the
+ *     slab test of the triangle's bounding box (inflated by 1e-5 of the mesh's largest |coordinate|) and its hit counts at or
+ *     beyond that box's entry -- true of every geometric hit, and what lets a bounding-volume hierarchy return exactly the
+ *     brute-force result; nearest = smallest object-space t, ties to the lower triangle index; flat shading, the normal
+ *     negated on the back side; hit point and distance as the sphere test's (getPointOnRay, transform, world distance).
+ * pt_set_meshes registers the triangle soups of the scene's mesh geoms for the NEXT pt_init (copied; kept across pt_free, so the
+ * reference's Free -> Init restart re-initialises the same scene; pt_set_meshes(NULL, 0) clears them).  pt_init fails with
+ * PT_ERR_INVALID when a PT_MESH geom has no triangles or triangles are registered for a geom that is not a mesh. */
+typedef struct PtMesh {
+    int32_t geom;           /* index into pt_init's geoms */
+    int32_t ntris;
+    const float *tris;      /* ntris x 9 floats, finite */
+} PtMesh;
+int pt_set_meshes(const PtMesh *meshes, int nmeshes);
+
 /* pathtraceInit: upload scene, allocate the accumulator and the SoA path-state buffers.
  * Replaces reference src/pathtrace.cu:75-85.  Calling it twice without pt_free re-initialises. */
 int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMaterial *mats, int nmats,
@@ -200,6 +222,14 @@ int pt_test_sphere_cull_sweep(const PtGeom *geoms, int ngeoms, uint64_t seed, in
  * the wall a path can still hit) soundness: as above, for the cubes of `geoms`. */
 int pt_test_wall_box_sweep(const PtGeom *geoms, int ngeoms, uint64_t seed, int64_t rays, uint64_t *culled,
                            uint64_t *violations);
+/* Triangle meshes.  pt_test_mesh_intersect: `n` rays against ONE mesh geom on the GPU, through the hierarchy (flat = 0) or a
+ * plain list of its triangles (flat = 1: the brute-force rule); outputs keep their input values on a miss; culled[i] = 1 when
+ * the bounding-ball test (certainMiss) rejected the ray -- t[i] is NaN if the full test hits nevertheless (must not happen).
+ * pt_test_mesh_bvh (host only, no GPU needed): the hierarchy pt_init would build, 8 words per node (lo[3], skip, hi[3], tri);
+ * *nnodes in = capacity, out = node count (2 ntris - 1). */
+int pt_test_mesh_intersect(const PtGeom *geom, const float *tris, int ntris, int flat, const float *rays, int n, float *t,
+                           float *p3, float *n3, int32_t *outside, int32_t *culled);
+int pt_test_mesh_bvh(const float *tris, int ntris, uint32_t *nodes8, int *nnodes);
 /* slabQuotients (shared-reciprocal packed division of the box test) next to the compiler's correctly
  * rounded `/`: per-element outputs, and a device-side pseudo-random sweep that returns the number of
  * bit mismatches over `pairs` (o, d) pairs (must be 0). */

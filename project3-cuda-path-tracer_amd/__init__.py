@@ -52,6 +52,7 @@ ABI_SYMBOLS = [
     "pt_test_intersect", "pt_test_hemisphere", "pt_test_sincos", "pt_test_reflect_refract",
     "pt_test_slab_quotients", "pt_test_slab_quotients_sweep", "pt_test_sphere_cull_sweep",
     "pt_test_unscaled_sqrt_sweep", "pt_pin_host", "pt_unpin_host", "pt_test_force_fault", "pt_test_pow", "pt_test_wall_box_sweep",
+    "pt_set_meshes", "pt_test_mesh_intersect", "pt_test_mesh_bvh",
 ]
 
 
@@ -59,6 +60,10 @@ class PtOptions(C.Structure):
     _fields_ = [("shard_rank", C.c_int32), ("shard_count", C.c_int32), ("device", C.c_int32),
                 ("flags", C.c_int32), ("pipeline_depth", C.c_int32), ("max_batch", C.c_int32),
                 ("stream", C.c_void_p), ("accum_dev", C.c_void_p), ("lens_radius", C.c_float), ("focal_distance", C.c_float)]
+
+
+class PtMesh(C.Structure):
+    _fields_ = [("geom", C.c_int32), ("ntris", C.c_int32), ("tris", C.c_void_p)]
 
 
 class PtCounters(C.Structure):
@@ -120,6 +125,9 @@ def lib():
         L.pt_test_force_fault.argtypes = [i32]
         L.pt_test_pow.argtypes = [vp, vp, i32, vp]
         L.pt_test_wall_box_sweep.argtypes = [vp, i32, C.c_uint64, i64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.pt_set_meshes.argtypes = [C.POINTER(PtMesh), i32]
+        L.pt_test_mesh_intersect.argtypes = [vp, vp, i32, i32, vp, i32, vp, vp, vp, vp, vp]
+        L.pt_test_mesh_bvh.argtypes = [vp, i32, vp, C.POINTER(C.c_int)]
         _lib = L
     return _lib
 
@@ -159,6 +167,11 @@ def host_lib():
         H.pth_scene_image_name.restype = C.c_char_p
         H.pth_scene_set_resolution.argtypes = [vp, C.c_int, C.c_int]
         H.pth_scene_set_resolution.restype = None
+        H.pth_scene_num_meshes.argtypes = [vp]
+        for n in ("pth_scene_mesh_geom", "pth_scene_mesh_ntris"):
+            getattr(H, n).argtypes = [vp, C.c_int]
+        H.pth_scene_mesh_tris.argtypes = [vp, C.c_int]
+        H.pth_scene_mesh_tris.restype = vp
         for n in ("pth_save_png", "pth_save_hdr"):
             getattr(H, n).argtypes = [C.c_char_p, vp, C.c_int, C.c_int, C.c_float]
             getattr(H, n).restype = C.c_int
@@ -188,6 +201,12 @@ class Scene:
         self.iterations = H.pth_scene_iterations(h)
         self.traceDepth = H.pth_scene_depth(h)
         self.imageName = H.pth_scene_image_name(h).decode()
+        # `mesh <file.obj>` objects (README.md:236): geom index -> (ntris, 9) float32 triangles in object space
+        self.meshes = {}
+        for i in range(H.pth_scene_num_meshes(h)):
+            nt = H.pth_scene_mesh_ntris(h, i)
+            self.meshes[H.pth_scene_mesh_geom(h, i)] = np.frombuffer(
+                C.string_at(H.pth_scene_mesh_tris(h, i), 36 * nt), np.float32).reshape(nt, 9).copy()
         w, hh = (int(v) for v in self.camera["resolution"][0])
         self.image = np.zeros((hh, w, 3), np.float32)   # RenderState::image (src/sceneStructs.h:53)
 
@@ -219,8 +238,18 @@ def pathtraceInit(scene, shard_rank=0, shard_count=1, stream=0, accum_dev=0, dev
     mats = np.ascontiguousarray(scene.materials)
     cam = np.ascontiguousarray(scene.camera)
     depth = scene.traceDepth if traceDepth is None else traceDepth
+    set_meshes(getattr(scene, "meshes", None) or {})
     _check(lib().pt_init(_p(cam), _p(geoms), len(geoms), _p(mats), len(mats), depth, C.byref(opt)))
     _scene = scene
+
+
+def set_meshes(meshes):
+    """pt_set_meshes: {geom index: (ntris, 9) triangles in object space} for the next pathtraceInit (an empty dict clears)."""
+    keep = [(int(g), np.ascontiguousarray(t, np.float32).reshape(-1, 9)) for g, t in sorted(meshes.items())]
+    arr = (PtMesh * max(len(keep), 1))()
+    for i, (g, t) in enumerate(keep):
+        arr[i] = PtMesh(g, len(t), t.ctypes.data)
+    _check(lib().pt_set_meshes(arr, len(keep)))
 
 
 def pathtrace(pbo, frame, iteration, readback=True):
@@ -335,6 +364,31 @@ def test_intersect(geoms, geom_index, rays, sentinel=-7.0):
     o = np.ones(n, np.int32)
     _check(lib().pt_test_intersect(_p(geoms), len(geoms), _p(gi), _p(rays), n, _p(t), _p(p), _p(nn), _p(o)))
     return t, p, nn, o
+
+
+def test_mesh_intersect(geom, tris, rays, flat=False, sentinel=-7.0):
+    """Rays against one mesh geom on the GPU (hierarchy, or flat=True: plain triangle list).  Returns t, p, n, outside, culled."""
+    g = np.ascontiguousarray(geom).reshape(-1)[:1]
+    tr = np.ascontiguousarray(tris, np.float32).reshape(-1, 9)
+    rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+    n = len(rays)
+    t = np.empty(n, np.float32)
+    p = np.full((n, 3), sentinel, np.float32)
+    nn = np.full((n, 3), sentinel, np.float32)
+    o = np.ones(n, np.int32)
+    culled = np.zeros(n, np.int32)
+    _check(lib().pt_test_mesh_intersect(_p(g), _p(tr), len(tr), 1 if flat else 0, _p(rays), n, _p(t), _p(p), _p(nn), _p(o), _p(culled)))
+    return t, p, nn, o, culled
+
+
+def mesh_bvh(tris):
+    """The hierarchy pt_init builds for a mesh (host only): structured array of nodes (lo, skip, hi, tri)."""
+    tr = np.ascontiguousarray(tris, np.float32).reshape(-1, 9)
+    node = np.dtype([("lo", "<f4", 3), ("skip", "<u4"), ("hi", "<f4", 3), ("tri", "<i4")])
+    out = np.zeros(2 * len(tr), node)
+    n = C.c_int(len(out))
+    _check(lib().pt_test_mesh_bvh(_p(tr), len(tr), _p(out), C.byref(n)))
+    return out[:n.value]
 
 
 def test_hemisphere(normals, iter_index_depth):

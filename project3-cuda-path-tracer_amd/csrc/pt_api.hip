@@ -28,6 +28,7 @@
 #include "pt_compaction.h"
 #include "pt_test_kernels.h"
 #include "pt_trace.h"
+#include "pt_mesh.h"
 
 using namespace ptd;
 using namespace ptk;
@@ -91,6 +92,9 @@ struct State {
     GeomDev *dgeoms = nullptr;
     MaterialDev *dmats = nullptr;
     WallBox *dwalls = nullptr;
+    float4 *dMeshNodes = nullptr;   // ptd::MeshNode[] / MeshTri[] of every mesh of the scene (k_bounce<., ., ., true>)
+    float4 *dMeshTris = nullptr;
+    bool mesh = false;      // the scene holds triangle meshes: the k_bounce<., false, ., true> variants
     int numTilesMax = 0;    // upper bound of tiles in one bounce queue (incl. one partial tile per segment)
     int poolChunks = 0;     // chunks per path pool (incl. the trash chunk 0); a pool holds poolChunks * kChunk paths per array
     int grid = 0;           // persistent grid of k_bounce<false>
@@ -112,6 +116,15 @@ struct State {
     long long nBounce = 0;
 } S;
 
+// triangle soups registered by pt_set_meshes, consumed by the next pt_init (kept across pt_free: the reference's
+// Free -> Init restart protocol re-initialises the same scene)
+std::vector<ptm::HostMesh> g_meshes;
+const ptm::HostMesh *mesh_of(int geom) {
+    for (const ptm::HostMesh &m : g_meshes)
+        if (m.geom == geom) return &m;
+    return nullptr;
+}
+
 int count_devices() {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -132,7 +145,9 @@ PathPool pool(const Slot &sl, int which) {
     return p;
 }
 
-void pack_geom(const PtGeom &g, GeomDev &d, const float *eye = nullptr) {
+// `box`: the object-space bounds lo[3], hi[3] of the primitive -- nullptr = the unit cube [-0.5, 0.5]^3 of a sphere or cube,
+// a mesh passes the union of its (inflated) triangle boxes.
+void pack_geom(const PtGeom &g, GeomDev &d, const float *eye = nullptr, const float *box = nullptr) {
     memset(&d, 0, sizeof d);
     for (int c = 0; c < 4; ++c)
         for (int r = 0; r < 3; ++r) {
@@ -141,8 +156,9 @@ void pack_geom(const PtGeom &g, GeomDev &d, const float *eye = nullptr) {
             d.invT[c * 3 + r] = g.invTranspose[c * 4 + r];
         }
     for (int r = 0; r < 3; ++r) d.invZ[r] = d.inv[9 + r] * 0.0f;
-    d.type = g.type;
-    d.flags = d.cullFlags = g.type == PT_CUBE ? 1 : 0;    // bit 1 (binned) is set by pt_init
+    d.type = g.type == PT_CUBE ? 1 : 0;                   // (a mesh's normal is made like a sphere's: type 0, flags bit 5)
+    d.flags = d.cullFlags = g.type == PT_CUBE ? 1 : (g.type == PT_MESH ? 32 : 0);    // bit 1 (binned) is set by pt_init
+    d.meshRoot = ptd::kMeshEnd;                           // set by pt_init / the mesh tests
     d.material = g.materialid;
     // bounding-ball culling data (ptd::certainMiss): bounds smax >= sigma_max, smin <= sigma_min of the 3x3 part
     double A[3][3], Ai[3][3];
@@ -168,9 +184,28 @@ void pack_geom(const PtGeom &g, GeomDev &d, const float *eye = nullptr) {
         smin = froi > 0 ? 1.0 / std::sqrt(froi) : 0.0;
     }
     d.centre[0] = g.transform[12]; d.centre[1] = g.transform[13]; d.centre[2] = g.transform[14];
-    const double rho2 = g.type == PT_SPHERE ? 0.25 : 0.75;       // object-space bounding ball: the sphere / the cube's corners
+    double rho2 = g.type == PT_SPHERE ? 0.25 : 0.75;       // object-space bounding ball: the sphere / the cube's corners
+    bool boxOk = true;
+    if (box) {
+        // a mesh: the ball around the centre of its box.  The margins of certainMiss are relative to the ball; they cover the
+        // rounding of the object-space evaluation (relative to the distance from the object-space ORIGIN) only while the
+        // mesh is not far off its own origin: otherwise it is never culled.
+        double c[3], far = 0;
+        rho2 = 0;
+        for (int a = 0; a < 3; ++a) {
+            c[a] = 0.5 * ((double)box[a] + box[3 + a]);
+            const double h = 0.5 * ((double)box[3 + a] - box[a]);
+            rho2 += h * h;
+            far = std::max(far, std::max(std::fabs((double)box[a]), std::fabs((double)box[3 + a])));
+        }
+        rho2 *= 1 + 1e-6;                                  // (the centre is rounded to float below)
+        for (int r = 0; r < 3; ++r)
+            d.centre[r] = (float)((double)g.transform[0 + r] * c[0] + (double)g.transform[4 + r] * c[1] + (double)g.transform[8 + r] * c[2] +
+                                  (double)g.transform[12 + r]);
+        boxOk = std::isfinite(rho2) && rho2 > 0 && far <= 100.0 * std::sqrt(rho2);
+    }
     const double r2 = rho2 * smax * smax * (1 + 1e-3), kk = smin > 0 ? 1e-4 * (smax / smin) * (smax / smin) : INFINITY;
-    const bool ok = std::isfinite(r2) && std::isfinite(kk) && kk < 0.5 && smin > 0;
+    const bool ok = boxOk && std::isfinite(r2) && std::isfinite(kk) && kk < 0.5 && smin > 0;
     d.boundR = (float)(std::sqrt(rho2) * smax);
     d.cullR2 = ok ? (float)r2 : INFINITY;      // infinite radius: never culled
     d.cullK = ok ? (float)kk : 0.0f;
@@ -289,13 +324,13 @@ void pack_material(const PtMaterial &m, MaterialDev &d) {
 }
 
 // Pixel rectangle from which camera rays can reach a primitive: project the 8 corners of its object-space unit cube
-// (which contains the unit-diameter sphere as well) in double precision.  A camera ray is
+// (which contains the unit-diameter sphere as well; `box`: a mesh's object-space bounds instead) in double precision.  A camera ray is
 //     eye + lambda * (view - right * pixLenX * (px - W/2) - up * pixLenY * (py - H/2)),   px in [x, x+1], py in [y, y+1],
 // so a world point Q lies on the ray through continuous pixel (px, py) iff  Q - eye = M * (lambda, lambda sx, lambda sy)
 // with M = [view | -pixLenX right | -pixLenY up].  The convex hull of the projected corners contains the projection of
 // the primitive; its bounding rectangle is widened by 2 pixels.  Any corner not strictly in front of the eye, or a
 // singular M, disables the culling for this primitive (whole frame).
-void project_geom(const PtGeom &g, const KParams &k, int rect[4]) {
+void project_geom(const PtGeom &g, const KParams &k, int rect[4], const float *box = nullptr) {
     rect[0] = rect[1] = 0;
     rect[2] = k.W - 1;
     rect[3] = k.H - 1;
@@ -310,7 +345,9 @@ void project_geom(const PtGeom &g, const KParams &k, int rect[4]) {
     if (!(std::fabs(det) > 1e-12 * scale * scale * scale) || !std::isfinite(det)) return;
     double xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
     for (int corner = 0; corner < 8; ++corner) {
-        const double o[3] = {(corner & 1) ? 0.5 : -0.5, (corner & 2) ? 0.5 : -0.5, (corner & 4) ? 0.5 : -0.5};
+        double o[3] = {(corner & 1) ? 0.5 : -0.5, (corner & 2) ? 0.5 : -0.5, (corner & 4) ? 0.5 : -0.5};
+        if (box)                                           // a mesh: the corners of its object-space box
+            for (int a = 0; a < 3; ++a) o[a] = box[((corner >> a) & 1) ? 3 + a : a];
         double q[3];
         for (int r = 0; r < 3; ++r)
             q[r] = (double)g.transform[0 + r] * o[0] + (double)g.transform[4 + r] * o[1] + (double)g.transform[8 + r] * o[2] +
@@ -362,6 +399,17 @@ int resolve_events(std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, double &ms
     return PT_OK;
 }
 
+// The instantiation of k_bounce a launch takes: FIRST (camera rays), MANY (per-lane sphere lists: scenes with more than
+// kBinMax spheres and no mesh), DOF (thin lens: the camera-ray launch only), MESH (scenes with triangle meshes).
+template <bool F, bool M, bool D, bool ME>
+const void *kb() { return reinterpret_cast<const void *>(k_bounce<F, M, D, ME>); }
+const void *bounce_kernel(bool first, bool dof) {
+    if (S.mesh) return first ? (dof ? kb<true, false, true, true>() : kb<true, false, false, true>()) : kb<false, false, false, true>();
+    if (first && dof) return S.many ? kb<true, true, true, false>() : kb<true, false, true, false>();
+    if (first) return S.many ? kb<true, true, false, false>() : kb<true, false, false, false>();
+    return S.many ? kb<false, true, false, false>() : kb<false, false, false, false>();
+}
+
 int launch_bounce(Slot &sl, int iter, int batch, int depth, bool lastBounce, float *contrib) {
     const PathPool in = pool(sl, (depth - 1) & 1);
     const PathPool out = pool(sl, depth & 1);
@@ -384,19 +432,10 @@ int launch_bounce(Slot &sl, int iter, int batch, int depth, bool lastBounce, flo
     ba.in = in; ba.out = out;
     ba.ctrl = sl.ctrl; ba.ggeoms = S.dgeoms; ba.gmats = S.dmats; ba.contrib = contrib;
     ba.walls = S.dwalls;
-#define PT_LAUNCH_BOUNCE(FIRST_, MANY_, GRID_) \
-    hipLaunchKernelGGL((k_bounce<FIRST_, MANY_>), dim3(GRID_), dim3(kBlock), S.ldsBytes, sl.stream, ba)
-#define PT_LAUNCH_BOUNCE3(FIRST_, MANY_, DOF_, GRID_) \
-    hipLaunchKernelGGL((k_bounce<FIRST_, MANY_, DOF_>), dim3(GRID_), dim3(kBlock), S.ldsBytes, sl.stream, ba)
-    if (depth == 1 && S.dof) {
-        if (S.many) PT_LAUNCH_BOUNCE3(true, true, true, S.gridFirst); else PT_LAUNCH_BOUNCE3(true, false, true, S.gridFirst);
-    } else if (depth == 1) {
-        if (S.many) PT_LAUNCH_BOUNCE(true, true, S.gridFirst); else PT_LAUNCH_BOUNCE(true, false, S.gridFirst);
-    } else {
-        if (S.many) PT_LAUNCH_BOUNCE(false, true, S.grid); else PT_LAUNCH_BOUNCE(false, false, S.grid);
-    }
-#undef PT_LAUNCH_BOUNCE
-#undef PT_LAUNCH_BOUNCE3
+    ba.meshNodes = S.dMeshNodes; ba.meshTris = S.dMeshTris;
+    void *kargs[] = {&ba};
+    const bool first = depth == 1;
+    HIPCHECK(hipLaunchKernel(bounce_kernel(first, first && S.dof), dim3(first ? S.gridFirst : S.grid), dim3(kBlock), kargs, S.ldsBytes, sl.stream));
     if (e0) {
         HIPCHECK(hipEventRecord(e1, sl.stream));
         S.evBounce.emplace_back(e0, e1);
@@ -551,7 +590,28 @@ void pt_free(void) {
     if (S.dgeoms) (void)hipFree(S.dgeoms);
     if (S.dmats) (void)hipFree(S.dmats);
     if (S.dwalls) (void)hipFree(S.dwalls);
+    if (S.dMeshNodes) (void)hipFree(S.dMeshNodes);
+    if (S.dMeshTris) (void)hipFree(S.dMeshTris);
     S = State();
+}
+
+int pt_set_meshes(const PtMesh *meshes, int nmeshes) {
+    if (nmeshes < 0 || (nmeshes && !meshes)) return fail(PT_ERR_INVALID, "pt_set_meshes: null argument");
+    for (int i = 0; i < nmeshes; ++i) {
+        if (meshes[i].geom < 0 || meshes[i].ntris < 1 || !meshes[i].tris) return fail(PT_ERR_INVALID, "pt_set_meshes: mesh %d is empty", i);
+        for (int j = 0; j < i; ++j)
+            if (meshes[j].geom == meshes[i].geom) return fail(PT_ERR_INVALID, "pt_set_meshes: geom %d given twice", meshes[i].geom);
+        for (size_t q = 0; q < 9 * (size_t)meshes[i].ntris; ++q)
+            if (!std::isfinite(meshes[i].tris[q])) return fail(PT_ERR_INVALID, "pt_set_meshes: mesh %d holds a non-finite coordinate", i);
+    }
+    g_meshes.clear();
+    for (int i = 0; i < nmeshes; ++i) {
+        ptm::HostMesh m;
+        m.geom = meshes[i].geom;
+        m.tris.assign(meshes[i].tris, meshes[i].tris + 9 * (size_t)meshes[i].ntris);
+        g_meshes.push_back(std::move(m));
+    }
+    return PT_OK;
 }
 
 int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMaterial *mats, int nmats, int traceDepth,
@@ -566,9 +626,13 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
         return fail(PT_ERR_INVALID, "pt_init: lens_radius must be >= 0 and focal_distance > 0 with a lens");
     if ((long long)cam->resolution[0] * cam->resolution[1] > (1ll << 30)) return fail(PT_ERR_INVALID, "pt_init: frame too large");
     for (int i = 0; i < ngeoms; ++i) {
-        if (geoms[i].type != PT_SPHERE && geoms[i].type != PT_CUBE) return fail(PT_ERR_INVALID, "pt_init: geom %d has unknown type", i);
+        if (geoms[i].type != PT_SPHERE && geoms[i].type != PT_CUBE && geoms[i].type != PT_MESH) return fail(PT_ERR_INVALID, "pt_init: geom %d has unknown type", i);
+        if (geoms[i].type == PT_MESH && !mesh_of(i)) return fail(PT_ERR_INVALID, "pt_init: geom %d is a mesh without triangles (pt_set_meshes)", i);
         if (geoms[i].materialid < 0 || geoms[i].materialid >= nmats) return fail(PT_ERR_INVALID, "pt_init: geom %d references material %d", i, geoms[i].materialid);
     }
+    for (const ptm::HostMesh &m : g_meshes)
+        if (m.geom < 0 || m.geom >= ngeoms || geoms[m.geom].type != PT_MESH)
+            return fail(PT_ERR_INVALID, "pt_init: triangles registered for geom %d, which is not a mesh of this scene (pt_set_meshes)", m.geom);
     if (count_devices() < 1) return fail(PT_ERR_NO_GPU, "pt_init: no HIP device (this library has no CPU fallback)");
     pt_free();
 
@@ -625,7 +689,7 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     k.directDepth = direct ? traceDepth : 0;
     k.nEmit = 0;
     for (int i = 0; i < ngeoms && k.nEmit < kEmitMax; ++i)
-        if (mats[geoms[i].materialid].emittance > 0.0f) {
+        if (geoms[i].type != PT_MESH && mats[geoms[i].materialid].emittance > 0.0f) {   // (direct lighting samples unit cubes: not meshes)
             const PtVec3 sc = geoms[i].scale;
             const float xx = sc.x * sc.x, yy = sc.y * sc.y, zz = sc.z * sc.z;
             const float xy = xx + yy;
@@ -697,9 +761,23 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     std::vector<MaterialDev> hm(nmats ? nmats : 1);
     k.sceneRect[0] = k.sceneRect[1] = 0x7fffffff;   // empty union: a scene without primitives is never entered
     k.sceneRect[2] = k.sceneRect[3] = -1;
+    // triangle meshes: one node / triangle array for the scene, a hierarchy per mesh (pt_mesh.h)
+    std::vector<ptd::MeshNode> meshNodes;
+    std::vector<ptd::MeshTri> meshTris;
+    const bool flatMeshes = getenv("PT_AMD_MESH_FLAT") && atoi(getenv("PT_AMD_MESH_FLAT"));   // tests only: no hierarchy
     for (int i = 0; i < ngeoms; ++i) {
-        pack_geom(geoms[i], hg[i], k.pos);
-        project_geom(geoms[i], k, hg[i].rect);
+        float box[6];
+        const bool isMesh = geoms[i].type == PT_MESH;
+        uint32_t root = ptd::kMeshEnd;
+        if (isMesh) {
+            const ptm::HostMesh *hm_ = mesh_of(i);
+            root = (uint32_t)meshNodes.size();
+            ptm::appendMesh(hm_->tris.data(), (int)(hm_->tris.size() / 9), flatMeshes, meshNodes, meshTris, box);
+            if (meshNodes.size() >= (1ull << 31)) return fail(PT_ERR_INVALID, "pt_init: too many triangles");
+        }
+        pack_geom(geoms[i], hg[i], k.pos, isMesh ? box : nullptr);
+        hg[i].meshRoot = root;
+        project_geom(geoms[i], k, hg[i].rect, isMesh ? box : nullptr);
         if (S.dof) {        // rays start anywhere on the lens: the pinhole projection bounds nothing
             hg[i].rect[0] = hg[i].rect[1] = 0;
             hg[i].rect[2] = Wd - 1;
@@ -779,17 +857,23 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     HIPCHECK(hipMemcpy(S.dmats, hm.data(), hm.size() * sizeof(MaterialDev), hipMemcpyHostToDevice));
     HIPCHECK(hipMalloc(&S.dwalls, hw.size() * sizeof(WallBox)));
     HIPCHECK(hipMemcpy(S.dwalls, hw.data(), hw.size() * sizeof(WallBox), hipMemcpyHostToDevice));
+    S.mesh = !meshNodes.empty();
+    if (S.mesh) {
+        HIPCHECK(hipMalloc(&S.dMeshNodes, meshNodes.size() * sizeof(ptd::MeshNode)));
+        HIPCHECK(hipMalloc(&S.dMeshTris, meshTris.size() * sizeof(ptd::MeshTri)));
+        HIPCHECK(hipMemcpy(S.dMeshNodes, meshNodes.data(), meshNodes.size() * sizeof(ptd::MeshNode), hipMemcpyHostToDevice));
+        HIPCHECK(hipMemcpy(S.dMeshTris, meshTris.data(), meshTris.size() * sizeof(ptd::MeshTri), hipMemcpyHostToDevice));
+    }
 
     int nspheres = 0;
     for (int i = 0; i < ngeoms; ++i) nspheres += geoms[i].type == PT_SPHERE;
-    S.many = nspheres > kBinMax;
+    S.many = nspheres > kBinMax && !S.mesh;     // (the mesh variants test every sphere in place)
     if (S.many && ngeoms > 65535) return fail(PT_ERR_INVALID, "pt_init: more than 65535 primitives");
     S.ldsBytes = sizeof(MaterialDev) * nmats + sizeof(GeomHitDev) * ngeoms + kMiscWords * sizeof(uint32_t) +
                  (S.many ? (size_t)ngeoms * kSphRowFloats * sizeof(float) + (size_t)kListMax * kBlock * sizeof(uint16_t) : 0);
     if (S.ldsBytes > 160 * 1024) return fail(PT_ERR_INVALID, "pt_init: scene does not fit the 160 KiB LDS (%zu B)", S.ldsBytes);
-    const void *kFirst = S.dof ? (S.many ? reinterpret_cast<const void *>(k_bounce<true, true, true>) : reinterpret_cast<const void *>(k_bounce<true, false, true>))
-                               : (S.many ? reinterpret_cast<const void *>(k_bounce<true, true>) : reinterpret_cast<const void *>(k_bounce<true, false>));
-    const void *kNext = S.many ? reinterpret_cast<const void *>(k_bounce<false, true>) : reinterpret_cast<const void *>(k_bounce<false, false>);
+    const void *kFirst = bounce_kernel(true, S.dof);
+    const void *kNext = bounce_kernel(false, false);
     if (S.ldsBytes > 64 * 1024) {
         HIPCHECK(hipFuncSetAttribute(kFirst, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.ldsBytes));
         HIPCHECK(hipFuncSetAttribute(kNext, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.ldsBytes));
@@ -1219,6 +1303,56 @@ int pt_test_intersect(const PtGeom *geoms, int ngeoms, const int32_t *geom_index
     DOWN(p3, dp, (size_t)n * 3);
     DOWN(n3, dn, (size_t)n * 3);
     DOWN(outside, dout, n);
+    return PT_OK;
+}
+
+int pt_test_mesh_intersect(const PtGeom *geom, const float *tris, int ntris, int flat, const float *rays, int n, float *t,
+                           float *p3, float *n3, int32_t *outside, int32_t *culled) {
+    NEED_GPU();
+    if (!geom || !tris || ntris < 1 || geom->type != PT_MESH) return fail(PT_ERR_INVALID, "pt_test_mesh_intersect: bad argument");
+    if (n <= 0) return PT_OK;
+    std::vector<ptd::MeshNode> nodes;
+    std::vector<ptd::MeshTri> mt;
+    float box[6];
+    ptm::appendMesh(tris, ntris, flat != 0, nodes, mt, box);
+    GeomDev hg;
+    pack_geom(*geom, hg, nullptr, box);
+    hg.meshRoot = 0;
+    DevBuf<GeomDev> dg;
+    DevBuf<ptd::MeshNode> dn_;
+    DevBuf<ptd::MeshTri> dtr;
+    DevBuf<int> dout, dcull;
+    DevBuf<float> dr, dt, dp, dn;
+    UP(dg, &hg, 1);
+    UP(dn_, nodes.data(), nodes.size());
+    UP(dtr, mt.data(), mt.size());
+    UP(dr, rays, (size_t)n * 6);
+    UP(dp, p3, (size_t)n * 3);
+    UP(dn, n3, (size_t)n * 3);
+    UP(dout, outside, n);
+    int rc = dt.alloc(n); if (rc) return rc;
+    rc = dcull.alloc(n); if (rc) return rc;
+    hipLaunchKernelGGL(k_test_mesh, GRID(n), dg.p, reinterpret_cast<const float4 *>(dn_.p), reinterpret_cast<const float4 *>(dtr.p),
+                       dr.p, n, dt.p, dp.p, dn.p, dout.p, dcull.p);
+    HIPCHECK(hipDeviceSynchronize());
+    DOWN(t, dt, n);
+    DOWN(p3, dp, (size_t)n * 3);
+    DOWN(n3, dn, (size_t)n * 3);
+    DOWN(outside, dout, n);
+    DOWN(culled, dcull, n);
+    return PT_OK;
+}
+
+// host only: no GPU is touched
+int pt_test_mesh_bvh(const float *tris, int ntris, uint32_t *nodes8, int *nnodes) {
+    if (!tris || ntris < 1 || !nodes8 || !nnodes) return fail(PT_ERR_INVALID, "pt_test_mesh_bvh: bad argument");
+    std::vector<ptd::MeshNode> nodes;
+    std::vector<ptd::MeshTri> mt;
+    float box[6];
+    ptm::appendMesh(tris, ntris, false, nodes, mt, box);
+    if ((int)nodes.size() > *nnodes) return fail(PT_ERR_INVALID, "pt_test_mesh_bvh: %zu nodes do not fit %d", nodes.size(), *nnodes);
+    memcpy(nodes8, nodes.data(), nodes.size() * sizeof(ptd::MeshNode));
+    *nnodes = (int)nodes.size();
     return PT_OK;
 }
 

@@ -104,12 +104,13 @@ struct GeomDev {
     // inverseTransform's translation column times 0.0f (a signed zero each, or NaN): the w = 0 products of a direction
     // transform, multiplyMV(inverseTransform, (d, 0)), evaluated once instead of once per ray
     float invZ[3];
-    int   flags;     // bit 0: type (0 sphere, 1 cube), bit 1: binned, bits 2-4: 1 + index among the scene's walls (0: not one)
+    int   flags;     // bit 0: type (0 sphere, 1 cube), bit 1: binned, bits 2-4: 1 + index among the scene's walls (0: not one),
+                     // bit 5: a triangle mesh (bit 0 clear: shaded like a sphere, from an object-space normal vector)
     // ---- 0x40: camera rays (first bounce only)
     // object-space camera position multiplyMV(inverseTransform, (eye, 1)), evaluated once on the host with the
     // same operation order: every camera ray of the first bounce shares it
     float camObj[3];
-    int   pad0;
+    uint32_t meshRoot;   // a mesh's first node in the scene's node array (MeshNode)
     // Pixels whose camera rays can reach this primitive: inclusive bounds [x0, y0, x1, y1] of the projection of its
     // object-space unit cube, widened by 2 pixels (host, double precision); the whole frame when a corner is not in
     // front of the eye.  Camera rays of other pixels skip the primitive (first bounce only).
@@ -134,7 +135,7 @@ struct GeomDev {
     // 1: a small primitive the queue is binned by (KParams::binGeom): tiles of paths that certainly miss all of them
     // skip it (mirrored in flags)
     int   binned;
-    int   type;      // 0 sphere, 1 cube (src/sceneStructs.h:8-11)
+    int   type;      // 0 sphere, 1 cube (src/sceneStructs.h:8-11); a mesh is 0 here (its normal is made like a sphere's) and flags bit 5
 };
 static_assert(sizeof(GeomDev) == 448, "GeomDev is 28 x 16 B");
 static_assert(offsetof(GeomDev, camObj) == 64 && offsetof(GeomDev, centre) == 96 && offsetof(GeomDev, xf) == 128, "scalar-load groups");
@@ -529,6 +530,105 @@ __device__ __forceinline__ float sphereIntersectionTest(const GD &g, F3 ro_w, F3
                                                         bool &outside) {
     probe(4);
     return sphereIntersectionTestM<CAM_ORIGIN>(g.inv, g.invZ, g.xf, g.camObj, ro_w, rd_w, P, nsrc, outside);
+}
+
+// ---- triangle meshes (README.md:112-116, 236: object type "mesh"; build-defined, the reference holds no mesh code) ----
+// Semantics (include/pt_amd.h; the CPU oracle states them as a loop over every triangle): the ray goes to object space like the sphere test's; a triangle
+// is tested -- glm::intersectRayTriangle (glm/gtx/intersect.inl:36-72) made two-sided -- only when the ray passes the slab
+// test of the triangle's own bounding box (inflated by a per-mesh margin), and its hit counts only at or beyond that box's
+// entry parameter; nearest = smallest object-space t, ties to the lower triangle index.  Every part of that rule is local
+// to (ray, triangle), and fp32 subtraction, multiplication by a common factor and comparison are monotone: a ray that
+// passes a box's test passes the test of every box that contains it.  So the threaded bounding-volume hierarchy below
+// (node boxes = exact unions of their triangles' boxes) visits every triangle the brute-force rule accepts, and a node
+// whose entry parameter lies beyond the best hit so far cannot hold a better one: bit-identical results in any order.
+//
+// Nodes in depth-first order, 32 B each: an inner node is followed by its first child; `skip` is the next node when the
+// subtree is left (kMeshEnd after the mesh's last); a leaf (tri >= 0) is one triangle and its box.  No stack, no LDS.
+struct MeshNode {
+    float    lo[3];
+    uint32_t skip;
+    float    hi[3];
+    int32_t  tri;        // -1: inner node; else index into the triangle array
+};
+struct MeshTri {         // v0, e1 = v1 - v0, e2 = v2 - v0 (the subtractions glm does first, evaluated once on the host)
+    float v0[3], e1[3], e2[3], pad[3];
+};
+static_assert(sizeof(MeshNode) == 32 && sizeof(MeshTri) == 48, "two / three float4 loads");
+constexpr uint32_t kMeshEnd = 0xffffffffu;
+constexpr float kMeshEps = 1.1920928955078125e-07f;        // std::numeric_limits<float>::epsilon(), intersect.inl:50
+constexpr float kMeshUp = 1.00001f, kMeshDn = 0.99999f;    // relative slack of the slab comparison
+
+__device__ __forceinline__ float guardedReciprocal(float d) {
+    const float g = __builtin_fabsf(d) < 1e-30f ? __builtin_copysignf(1e-30f, d) : d;
+    return 1.0f / g;
+}
+
+// The triangle test; returns t (>= 0) or -1, `front` = the counter-clockwise side faces the ray.
+__device__ __forceinline__ bool meshTriangle(F3 o, F3 d, F3 v0, F3 e1, F3 e2, float &t, bool &front) {
+    const F3 p = cross(d, e2);
+    const float a = dot(e1, p);
+    if (__builtin_fabsf(a) < kMeshEps) return false;
+    const float f = 1.0f / a;
+    const F3 s = o - v0;
+    const float u = f * dot(s, p);
+    if (u < 0.0f) return false;
+    if (u > 1.0f) return false;
+    const F3 q = cross(s, e1);
+    const float v = f * dot(d, q);
+    if (v < 0.0f) return false;
+    if (v + u > 1.0f) return false;
+    t = f * dot(e2, q);
+    front = a > 0.0f;
+    return t >= 0.0f;
+}
+
+// One ray against one mesh.  `nodes` / `tris`: the scene's node and triangle arrays (per-lane loads: every lane walks its
+// own way through the hierarchy), `root`: the mesh's first node.  Outputs as the sphere test's (P world point, nsrc the
+// object-space vector the normal is made of -- here the unit face normal -- and `outside` = front side).
+// (NaN operands: every triangle test fails whatever the slab tests say -- a, or s, is NaN -- like in the oracle's loop.)
+template <bool CAM_ORIGIN = false, typename GD>
+__device__ __forceinline__ float meshIntersectionTest(const GD &g, const float4 *nodes, const float4 *tris, uint32_t root,
+                                                      F3 ro_w, F3 rd_w, F3 &P, F3 &nsrc, bool &outside) {
+    const F3 ro = CAM_ORIGIN ? f3(g.camObj[0], g.camObj[1], g.camObj[2]) : mulMV(g.inv, ro_w, 1.0f);
+    const F3 rd = normalize(mulMV0(g.inv, g.invZ, rd_w));
+    const F3 inv = f3(guardedReciprocal(rd.x), guardedReciprocal(rd.y), guardedReciprocal(rd.z));
+    int best = -1;
+    float tbest = 0.0f;
+    uint32_t bestFront = 0u;
+    uint32_t node = root;
+    while (node != kMeshEnd) {
+        const float4 n0 = nodes[2 * (size_t)node], n1 = nodes[2 * (size_t)node + 1];
+        const float ax = (n0.x - ro.x) * inv.x, bx = (n1.x - ro.x) * inv.x;
+        const float ay = (n0.y - ro.y) * inv.y, by = (n1.y - ro.y) * inv.y;
+        const float az = (n0.z - ro.z) * inv.z, bz = (n1.z - ro.z) * inv.z;
+        const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
+        const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
+        const float tmin = tn * kMeshDn;
+        const int tri = __float_as_int(n1.w);
+        // (a node whose entry parameter lies beyond the best hit cannot improve on it: accepted hits have t >= tmin)
+        const bool pass = (tf * kMeshUp >= tmin) & (tf >= 0.0f) & ((best < 0) | !(tmin > tbest));
+        if (pass && tri >= 0) {
+            const float4 a = tris[3 * (size_t)tri], b = tris[3 * (size_t)tri + 1], c = tris[3 * (size_t)tri + 2];
+            float t;
+            bool front;
+            if (meshTriangle(ro, rd, f3(a.x, a.y, a.z), f3(a.w, b.x, b.y), f3(b.z, b.w, c.x), t, front)) {
+                if ((t >= tmin) & ((best < 0) | (t < tbest) | ((t == tbest) & (tri < best)))) {
+                    best = tri;
+                    tbest = t;
+                    bestFront = front ? 1u : 0u;
+                }
+            }
+        }
+        node = (pass && tri < 0) ? node + 1u : __float_as_uint(n0.w);
+    }
+    if (best < 0) return -1.0f;
+    const float4 a = tris[3 * (size_t)best], b = tris[3 * (size_t)best + 1], c = tris[3 * (size_t)best + 2];
+    const F3 nobj = normalize(cross(f3(a.w, b.x, b.y), f3(b.z, b.w, c.x)));
+    const F3 obj = getPointOnRay(ro, rd, tbest);
+    P = mulMV(g.xf, obj, 1.0f);
+    nsrc = nobj;         // normal = +-normalize(invTranspose * (nobj, 0)): hitNormal(), evaluated for the nearest hit only
+    outside = bestFront != 0u;
+    return length(ro_w - P);
 }
 
 // The surface normal of a hit, from what the two tests leave in `nsrc` (src/intersections.h:85 and :137-140).

@@ -45,6 +45,27 @@ __global__ void k_test_intersect(const GeomDev *geoms, const int *gidx, const fl
     n3[3 * i] = N.x; n3[3 * i + 1] = N.y; n3[3 * i + 2] = N.z;
     outside[i] = o ? 1 : 0;
 }
+// rays against one triangle mesh: the render kernels' test, plus the verdict of the bounding-ball test
+__global__ void k_test_mesh(const GeomDev *geom, const float4 *nodes, const float4 *tris, const float *rays, int n, float *t,
+                            float *p3, float *n3, int *outside, int *culled) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const GeomDev G = *geom;
+    F3 ro = f3(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]);
+    F3 rd = f3(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
+    F3 P = f3(p3[3 * i], p3[3 * i + 1], p3[3 * i + 2]);
+    F3 N = f3(n3[3 * i], n3[3 * i + 1], n3[3 * i + 2]);
+    bool o = outside[i] != 0;
+    F3 nsrc = f3(0, 0, 0);
+    const bool cull = certainMiss(G, ro, rd, dot(rd, rd));
+    const float tt = meshIntersectionTest(G, nodes, tris, G.meshRoot, ro, rd, P, nsrc, o);
+    culled[i] = cull ? 1 : 0;
+    t[i] = cull && tt != -1.0f ? __builtin_nanf("") : tt;
+    if (tt != -1.0f) N = hitNormal(G, nsrc, o);
+    p3[3 * i] = P.x; p3[3 * i + 1] = P.y; p3[3 * i + 2] = P.z;
+    n3[3 * i] = N.x; n3[3 * i + 1] = N.y; n3[3 * i + 2] = N.z;
+    outside[i] = o ? 1 : 0;
+}
 // certainMiss soundness sweep: pseudo-random rays (origins up to ~60 units away, aimed near the primitive's bounding
 // ball so that grazing cases are dense) against every primitive of `geoms`; counts culled rays and VIOLATIONS
 // (culled although the full test returns a hit).

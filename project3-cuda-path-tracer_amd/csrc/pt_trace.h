@@ -288,6 +288,8 @@ struct BounceArgs {
     const MaterialDev *gmats;
     float *contrib;
     const WallBox *walls;               // [prm.nWalls] inflated world-space boxes of the walls
+    const float4 *meshNodes;            // MeshNode[] of every mesh of the scene (k_bounce<., ., ., true>), or nullptr
+    const float4 *meshTris;             // MeshTri[]
 };
 typedef const PT_CAS BounceArgs *ArgsPtr;
 typedef const PT_CAS GeomDev *GeomPtr;
@@ -322,8 +324,8 @@ static_assert(sizeof(CullGroup) == 32 && offsetof(GeomDev, cullFlags) - offsetof
 
 // DOF (with FIRST only): camera rays start on a thin lens (README.md:100-101), so they share no origin (no precomputed
 // object-space camera position) and the pixel rectangles, which project the primitives through a pinhole, are not used.
-template <bool FIRST, bool MANY, bool DOF = false>
-__global__ __launch_bounds__(kBlock, DOF ? 5 : (MANY ? (FIRST ? 6 : 7) : 8)) void k_bounce(BounceArgs argsByValue) {
+template <bool FIRST, bool MANY, bool DOF = false, bool MESH = false>
+__global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? (FIRST ? 6 : 7) : 8))) void k_bounce(BounceArgs argsByValue) {
     static_assert(FIRST || !DOF, "the lens only concerns the camera-ray bounce");
     (void)argsByValue;
     const ArgsPtr kargs = (ArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -641,6 +643,12 @@ __global__ __launch_bounds__(kBlock, DOF ? 5 : (MANY ? (FIRST ? 6 : 7) : 8)) voi
                     if (!FIRST && tileWall != 6u && (flags & 28) != 0 && (uint32_t)((flags >> 2) & 7) != tileWall + 1u) continue;
                     if (!inRect) {
                         // (not reachable from this pixel: t stays -1)
+                    } else if (MESH && (flags & 32) != 0) {
+                        // a triangle mesh: its bounding ball first, then every lane walks the mesh's hierarchy on its own
+                        if (!certainMiss(cg, org, dir, dd)) {
+                            const ArgsPtr A2 = launder(kargs);
+                            t = meshIntersectionTest<FIRST && !DOF>(G, A2->meshNodes, A2->meshTris, G.meshRoot, org, dir, p, n, o);
+                        }
                     } else if ((flags & 1) == 0) {
                         probe(3);
                         if (!certainMiss(cg, org, dir, dd)) {

@@ -24,6 +24,10 @@ const void *pth_scene_camera(void *s) { return &static_cast<Scene *>(s)->state.c
 int pth_scene_iterations(void *s) { return (int)static_cast<Scene *>(s)->state.iterations; }
 int pth_scene_depth(void *s) { return static_cast<Scene *>(s)->state.traceDepth; }
 const char *pth_scene_image_name(void *s) { return static_cast<Scene *>(s)->state.imageName.c_str(); }
+int pth_scene_num_meshes(void *s) { return (int)static_cast<Scene *>(s)->meshes.size(); }
+int pth_scene_mesh_geom(void *s, int i) { return static_cast<Scene *>(s)->meshes[i].geom; }
+int pth_scene_mesh_ntris(void *s, int i) { return (int)(static_cast<Scene *>(s)->meshes[i].tris.size() / 9); }
+const float *pth_scene_mesh_tris(void *s, int i) { return static_cast<Scene *>(s)->meshes[i].tris.data(); }
 void pth_scene_set_resolution(void *s, int w, int h) { static_cast<Scene *>(s)->setResolution(w, h); }
 
 // saveImage (reference src/main.cpp:49-70) on a W*H*3 running sum: /samples, X mirror, PNG

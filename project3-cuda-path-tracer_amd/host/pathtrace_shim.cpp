@@ -4,6 +4,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 #include "pt_amd.h"
 
@@ -27,6 +28,19 @@ void pathtraceInit(Scene *scene) {
     opt.lens_radius = extraLens;        // ... unless pathtraceExtras() switched a README extra on
     opt.focal_distance = extraFocal;
     if (extraDirect) opt.flags |= PT_FLAG_DIRECT_LIGHTING;
+    // `mesh` objects (README.md:236): their triangles go in before the geoms that refer to them.  (Built against the
+    // reference's own scene.h, whose loader knows no meshes, the shim registers none.)
+    std::vector<PtMesh> meshes;
+#ifdef PT_SCENE_HAS_MESHES
+    for (size_t i = 0; i < scene->meshes.size(); ++i) {
+        PtMesh m;
+        m.geom = scene->meshes[i].geom;
+        m.ntris = (int)(scene->meshes[i].tris.size() / 9);
+        m.tris = scene->meshes[i].tris.data();
+        meshes.push_back(m);
+    }
+#endif
+    checkPtError(pt_set_meshes(meshes.empty() ? NULL : meshes.data(), (int)meshes.size()), "pathtraceInit");
     checkPtError(pt_init(reinterpret_cast<const PtCamera *>(&scene->state.camera),
                          reinterpret_cast<const PtGeom *>(scene->geoms.data()), (int)scene->geoms.size(),
                          reinterpret_cast<const PtMaterial *>(scene->materials.data()), (int)scene->materials.size(),

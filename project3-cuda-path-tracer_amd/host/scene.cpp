@@ -2,6 +2,8 @@
 //   * MATERIAL / OBJECT ids must be sequential, otherwise the block is skipped with an ERROR line (:37,:149)
 //   * a MATERIAL block is exactly 7 lines, a CAMERA block 5 lines + EYE/VIEW/UP lines up to a blank line
 //   * the object type line must be exactly "sphere" or "cube" (:48-53); TRANS/ROTAT/SCALE up to a blank line
+//   * README.md:236 names a third object type, "mesh", which the reference's loader does not know: here the type line
+//     `mesh <file.obj>` (path relative to the scene file) loads a Wavefront OBJ into Scene::meshes (loadObj below)
 //   * the specular exponent keyword is SPECEX (:164) although the README says SPECX
 //   * CRLF / CR / LF line ends; '//' comment lines are simply unknown keywords
 // Unlike the reference, fields whose keyword is missing are zero instead of uninitialised.
@@ -10,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <sstream>
 #include <stdexcept>
 
 using utilityCore::safeGetline;
@@ -20,6 +23,42 @@ typedef std::vector<std::string> Tokens;
 bool key(const Tokens &t, const char *k) { return !t.empty() && t[0] == k; }
 float num(const Tokens &t, size_t i) { return i < t.size() ? (float)atof(t[i].c_str()) : 0.0f; }
 lin::vec3 triple(const Tokens &t) { return lin::vec3(num(t, 1), num(t, 2), num(t, 3)); }
+
+// Wavefront OBJ -> triangle soup.  `v x y z` and `f a b c ...` with a = i, i/j, i//k or i/j/k (1-based; negative = relative
+// to the vertices read so far); polygons are fanned from their first vertex; every other statement is ignored.
+bool loadObj(const std::string &path, std::vector<float> &tris) {
+    std::ifstream fp(path.c_str());
+    if (!fp.is_open()) return false;
+    std::vector<float> verts;
+    std::string line;
+    while (std::getline(fp, line)) {
+        std::istringstream ss(line);
+        std::string keyword;
+        if (!(ss >> keyword)) continue;
+        if (keyword == "v") {
+            double c[3] = {0, 0, 0};
+            ss >> c[0] >> c[1] >> c[2];
+            for (int a = 0; a < 3; ++a) verts.push_back((float)c[a]);
+        } else if (keyword == "f") {
+            const int nv = (int)(verts.size() / 3);
+            std::vector<int> corner;
+            std::string ref;
+            bool ok = true;
+            while (ss >> ref) {
+                const int i = atoi(ref.c_str());              // (reads up to the first '/')
+                const int k = i > 0 ? i - 1 : nv + i;
+                if (i == 0 || k < 0 || k >= nv) { ok = false; break; }
+                corner.push_back(k);
+            }
+            for (size_t k = 2; ok && k < corner.size(); ++k) {
+                const int tri[3] = {corner[0], corner[k - 1], corner[k]};
+                for (int c = 0; c < 3; ++c)
+                    for (int a = 0; a < 3; ++a) tris.push_back(verts[3 * (size_t)tri[c] + a]);
+            }
+        }
+    }
+    return true;
+}
 
 void deriveFov(Camera &camera, float fovy) {
     // reference src/scene.cpp:133-136
@@ -37,6 +76,10 @@ Scene::Scene(std::string filename, bool verbose_) : verbose(verbose_) {
     state.traceDepth = 0;
     state.camera.resolution.x = state.camera.resolution.y = 0;
     state.camera.fov.x = state.camera.fov.y = 0.0f;
+    {
+        const size_t slash = filename.find_last_of('/');
+        dir = slash == std::string::npos ? std::string() : filename.substr(0, slash + 1);
+    }
     fp_in.open(filename.c_str());
     if (!fp_in.is_open()) {
         std::cout << "Error reading from file - aborting!" << std::endl;
@@ -128,6 +171,20 @@ int Scene::loadGeom(std::string objectid) {
         } else if (line == "cube") {
             if (verbose) std::cout << "Creating new cube..." << std::endl;
             g.type = CUBE;
+        } else {
+            const Tokens t = tokenizeString(line);
+            if (t.size() >= 2 && t[0] == "mesh") {
+                Mesh m;
+                m.geom = (int)geoms.size();
+                const std::string path = t[1][0] == '/' ? t[1] : dir + t[1];
+                if (loadObj(path, m.tris) && !m.tris.empty()) {
+                    if (verbose) std::cout << "Creating new mesh (" << m.tris.size() / 9 << " triangles)..." << std::endl;
+                    g.type = MESH;
+                    meshes.push_back(m);
+                } else {
+                    std::cout << "ERROR: cannot read triangles from " << path << std::endl;
+                }
+            }
         }
     }
     safeGetline(fp_in, line);

@@ -7,6 +7,15 @@
 #include "sceneStructs.h"
 #include "utilities.h"
 
+// (tells pathtrace_shim.cpp that this Scene has `meshes`; the reference's own scene.h, which the shim also builds against, has not)
+#define PT_SCENE_HAS_MESHES 1
+
+// Triangles of one `mesh` object (README.md:112-116, 236), in the OBJ file's coordinates = the geom's object space.
+struct Mesh {
+    int geom;                   // index into Scene::geoms (a Geom of type MESH)
+    std::vector<float> tris;    // 9 floats per triangle: v0, v1, v2
+};
+
 class Scene {
 private:
     std::ifstream fp_in;                          // the scene file while it is being parsed
@@ -14,6 +23,7 @@ private:
     int loadGeom(std::string objectid);           // OBJECT block: type, material, TRANS/ROTAT/SCALE up to a blank line
     int loadCamera();                             // CAMERA block: 5 keyword lines + EYE/VIEW/UP up to a blank line
     bool verbose;
+    std::string dir;                              // directory of the scene file ("" or ending in '/'): mesh paths are relative to it
 
 public:
     // Throws std::runtime_error when the file cannot be opened (the reference prints
@@ -26,5 +36,6 @@ public:
 
     std::vector<Geom> geoms;            // in file order = intersection order (first geom wins distance ties)
     std::vector<Material> materials;    // indexed by Geom::materialid
+    std::vector<Mesh> meshes;           // one per Geom of type MESH, file order
     RenderState state;                  // camera, iteration count, depth, output name, host image
 };

@@ -17,6 +17,7 @@
 enum GeomType {
     SPHERE,   // unit-diameter sphere at the origin of object space
     CUBE,     // unit cube [-0.5, 0.5]^3 in object space
+    MESH,     // README.md:236 "mesh": a triangle soup in object space (Scene::meshes), not in the reference's enum
 };
 
 struct Ray {

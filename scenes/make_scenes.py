@@ -3,8 +3,10 @@
 cornell.txt / sphere.txt carry the same numeric content as the reference's example scenes
 (own layout and comments; tests/test_golden.py checks that the reference loader produced
 byte-identical structs from both).  cornell_glass.txt (BASELINE config C4) and spheres64.txt
-(config C5) are authored by this build as SURVEY.md section 8(d) specifies.
+(config C5) are authored by this build as SURVEY.md section 8(d) specifies.  cornell_mesh.txt / mesh_small.txt use the
+scene format's third object type, "mesh" (README.md:236), with OBJ files generated here under scenes/models/.
 """
+import math
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -83,8 +85,93 @@ def spheres64(seed=565):
     return s
 
 
+# ---- OBJ models (generated: no network, no third-party assets) ---------------------------------------------
+def icosphere(subdiv, radius=0.5):
+    """Unit-diameter icosphere: 20 * 4^subdiv counter-clockwise (outward) triangles."""
+    t = (1 + 5 ** 0.5) / 2
+    v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t),
+         (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
+    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6),
+         (7, 1, 8), (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7),
+         (9, 8, 1)]
+    norm = lambda p: tuple(radius * c / math.sqrt(sum(x * x for x in p)) for c in p)
+    v = [norm(p) for p in v]
+    for _ in range(subdiv):
+        mid, nf = {}, []
+
+        def m(a, b):
+            k = (min(a, b), max(a, b))
+            if k not in mid:
+                v.append(norm(tuple((v[a][c] + v[b][c]) / 2 for c in range(3))))
+                mid[k] = len(v) - 1
+            return mid[k]
+        for a, b, c in f:
+            ab, bc, ca = m(a, b), m(b, c), m(c, a)
+            nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        f = nf
+    return v, f
+
+
+def torus(nu, nv, R=0.35, r=0.15):
+    """Torus around the y axis as quads (the loaders fan them into triangles), outward counter-clockwise."""
+    v, f = [], []
+    for i in range(nu):
+        a = 2 * math.pi * i / nu
+        for j in range(nv):
+            b = 2 * math.pi * j / nv
+            v.append(((R + r * math.cos(b)) * math.cos(a), r * math.sin(b), -(R + r * math.cos(b)) * math.sin(a)))
+    for i in range(nu):
+        for j in range(nv):
+            a, b = i * nv + j, ((i + 1) % nu) * nv + j
+            c, d = ((i + 1) % nu) * nv + (j + 1) % nv, i * nv + (j + 1) % nv
+            f.append((a, b, c, d))
+    return v, f
+
+
+def write_obj(name, title, v, f):
+    os.makedirs(os.path.join(HERE, "models"), exist_ok=True)
+    with open(os.path.join(HERE, "models", name), "w") as fp:
+        fp.write(f"# {title} (generated by scenes/make_scenes.py)\n")
+        for p in v:
+            fp.write("v %.6f %.6f %.6f\n" % p)
+        for face in f:
+            fp.write("f " + " ".join(str(i + 1) for i in face) + "\n")
+
+
+def cornell_mesh():
+    mats = CORNELL_MATS + [GLASS]
+    s = "// Cornell box whose sphere is a 1280-triangle icosphere, plus a glass torus (object type \"mesh\", README.md:236)\n\n"
+    for i, m in enumerate(mats):
+        s += material(i, *m)
+    s += camera("800 800", 45, 5000, 8, "cornell_mesh")
+    for i, o in enumerate(CORNELL_OBJS[:6]):
+        s += obj(i, *o)
+    s += obj(6, "icosphere, where Cornell's sphere is", "mesh models/icosphere3.obj", 4, "-1 4 -1", "0 0 0", "3 3 3")
+    s += obj(7, "glass torus", "mesh models/torus.obj", 5, "2.2 2.2 1.5", "50 0 25", "4 4 4")
+    return s
+
+
+def mesh_small():
+    s = "// small mesh scene for the CPU oracle: an 80-triangle icosphere and a 128-triangle torus under a light\n\n"
+    for i, m in enumerate(CORNELL_MATS + [GLASS]):
+        s += material(i, *m)
+    s += camera("96 96", 45, 16, 6, "mesh_small")
+    s += obj(0, "ceiling light", "cube", 0, "0 10 0", "0 0 0", "6 .3 6")
+    s += obj(1, "floor", "cube", 1, "0 0 0", "0 0 0", "10 .01 10")
+    s += obj(2, "back wall", "cube", 2, "0 5 -5", "0 90 0", ".01 10 10")
+    s += obj(3, "icosphere (mirror mix)", "mesh models/icosphere1.obj", 4, "-1.5 3 0", "10 20 30", "4 3 4")
+    s += obj(4, "glass torus", "mesh models/torus_small.obj", 5, "2 3.5 1", "60 10 0", "5 5 5")
+    return s
+
+
 def main():
     w = lambda n, s: open(os.path.join(HERE, n), "w").write(s)
+    write_obj("icosphere3.obj", "icosphere, 3 subdivisions: 1280 triangles, diameter 1", *icosphere(3))
+    write_obj("icosphere1.obj", "icosphere, 1 subdivision: 80 triangles, diameter 1", *icosphere(1))
+    write_obj("torus.obj", "torus, 48 x 24 quads = 2304 triangles", *torus(48, 24))
+    write_obj("torus_small.obj", "torus, 8 x 8 quads = 128 triangles", *torus(8, 8))
+    w("cornell_mesh.txt", cornell_mesh())
+    w("mesh_small.txt", mesh_small())
     w("cornell.txt", cornell(CORNELL_MATS, "cornell", "Cornell box, same values as the reference's scenes/cornell.txt"))
     g = list(CORNELL_MATS)
     g[4] = GLASS

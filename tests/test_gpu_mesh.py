@@ -1,0 +1,199 @@
+"""Triangle meshes (scene-format object type "mesh", reference README.md:112-116, 236) on the HIP path against the oracle,
+bit for bit.  The reference holds no mesh code: the semantics are the oracle's brute-force loop over every triangle
+(oracle/pt_oracle.cpp, mesh_intersection_test; its triangle test is pinned against the reference's vendored
+glm::intersectRayTriangle in tests/test_golden.py).  The kernels walk a bounding-volume hierarchy instead; these tests hold
+them to the brute-force result per ray, per path and per pixel."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import SCENES
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu(pt):
+    if pt.device_count() < 1:
+        pytest.fail("no HIP device: GPU tests must run on the MI355X box")
+    return pt
+
+
+def mesh_rays(rng, geom, tris, n):
+    """Ray mix for one mesh geom: aimed at points of its triangles (hits, edges, vertices), origins inside its box, far
+    origins, grazes of its bounding ball, random misses; mostly unit directions, some not."""
+    xf = geom["transform"][0].reshape(4, 4).T.astype(np.float64)          # column-major mat4
+    to_world = lambda p: (xf[:3, :3] @ p.T).T + xf[:3, 3]
+    tr = tris.reshape(-1, 3, 3).astype(np.float64)
+    lo, hi = tr.reshape(-1, 3).min(0), tr.reshape(-1, 3).max(0)
+    centre_w = to_world(((lo + hi) / 2)[None])[0]
+    radius_w = np.linalg.norm(to_world(np.array([hi])) - centre_w)
+    rays = np.zeros((n, 6), np.float32)
+    for i in range(n):
+        kind = i % 8
+        t = tr[rng.integers(len(tr))]
+        if kind in (0, 1, 2):          # aimed at a point of a triangle (kind 1: on an edge, kind 2: at a vertex)
+            a, b = rng.uniform(0, 1, 2)
+            if a + b > 1:
+                a, b = 1 - a, 1 - b
+            if kind == 1:
+                b = 0.0
+            if kind == 2:
+                a = b = 0.0
+            tgt = to_world((t[0] + a * (t[1] - t[0]) + b * (t[2] - t[0]))[None])[0]
+            o = centre_w + rng.normal(size=3) * radius_w * rng.choice([1.5, 4, 40])
+            d = tgt - o
+        elif kind == 3:                # origin inside the mesh's box
+            o = to_world((lo + rng.uniform(0.2, 0.8, 3) * (hi - lo))[None])[0]
+            d = rng.normal(size=3)
+        elif kind == 4:                # grazing the bounding ball
+            o = centre_w + rng.normal(size=3) * radius_w * 6
+            u = rng.normal(size=3)
+            u -= u @ (centre_w - o) * (centre_w - o) / ((centre_w - o) @ (centre_w - o))
+            tgt = centre_w + u / np.linalg.norm(u) * radius_w * rng.uniform(0.9, 1.1)
+            d = tgt - o
+        elif kind == 5:                # axis-parallel direction with exact zeros
+            o = centre_w + rng.uniform(-1, 1, 3) * radius_w * 0.5
+            ax = rng.integers(3)
+            o[ax] += radius_w * 3 * rng.choice([-1, 1])
+            d = np.zeros(3)
+            d[ax] = -np.sign(o[ax] - centre_w[ax])
+        elif kind == 6:                # from a point just off the surface (a scattered ray's origin)
+            c = to_world(t.mean(0)[None])[0]
+            o = c + rng.normal(size=3) * 1e-3
+            d = rng.normal(size=3)
+        else:
+            o = rng.uniform(-12, 12, 3)
+            d = rng.normal(size=3)
+        nd = np.linalg.norm(d)
+        if nd > 0 and rng.random() < 0.85:
+            d = d / nd
+        rays[i, :3], rays[i, 3:] = o, d
+    return rays
+
+
+@pytest.mark.parametrize("flat", [False, True])
+def test_mesh_test_against_the_oracle_per_ray(gpu, oracle, flat):
+    sc = gpu.Scene(os.path.join(SCENES, "mesh_small.txt"))
+    rng = np.random.default_rng(1116)
+    hits = culled_total = 0
+    cases = [(sc.geoms[g:g + 1], sc.meshes[g]) for g in sorted(sc.meshes)]
+    # the same triangles under an anisotropic, rotated transform and far off their own origin
+    g2 = oracle.make_geom(2, 0, (3, -2, 1), (25, 70, -40), (0.7, 2.5, 1.2))
+    cases.append((g2, sc.meshes[3]))
+    cases.append((oracle.make_geom(2, 0, (0, 0, 0), (0, 0, 0), (1, 1, 1)), sc.meshes[4] + np.float32(3.0)))
+    for geom, tris in cases:
+        rays = mesh_rays(rng, geom, tris, 1536)
+        t, p, n, o, culled = gpu.test_mesh_intersect(geom, tris, rays, flat=flat)
+        assert not np.isnan(t[culled != 0]).any(), "the bounding-ball test rejected a ray the full test hits"
+        for i in range(len(rays)):
+            wt, wp, wn, wo, _ = oracle.mesh_intersect(geom.view(oracle.GEOM_DTYPE), tris, rays[i])
+            assert np.float32(t[i]).view(np.uint32) == np.float32(wt).view(np.uint32), (i, rays[i], t[i], wt)
+            assert np.array_equal(p[i].view(np.uint32), wp.view(np.uint32)) and o[i] == wo, (i, p[i], wp)
+            if wt != -1.0:
+                assert np.array_equal(n[i].view(np.uint32), wn.view(np.uint32)), (i, n[i], wn)
+                assert culled[i] == 0
+        hits += int((t > 0).sum())
+        culled_total += int(culled.sum())
+    assert hits > 1500 and culled_total > 300
+
+
+def _render_both(gpu, oracle, sc, depth, iters, res, dump_bounces=(), rank=0, count=1, **extras):
+    W, H = res
+    ref = oracle.Renderer(sc.camera.view(oracle.CAMERA_DTYPE), sc.geoms.view(oracle.GEOM_DTYPE),
+                          sc.materials.view(oracle.MATERIAL_DTYPE), depth, meshes=sc.meshes)
+    ref.set_extras(**extras)
+    want = np.zeros(W * H * 3, np.float32)
+    live = np.zeros(64, np.int64)
+    gpu.pathtraceFree()
+    gpu.pathtraceInit(sc, traceDepth=depth, max_batch=4, pipeline_depth=2, shard_rank=rank, shard_count=count, **extras)
+    gpu.pathtrace_batch(None, 0, iters[0], len(iters))
+    for k in iters:
+        live += np.array(ref.iterate(k, want, rank, count).live[:64])
+    got = gpu.readback(W * H)
+    cnt = gpu.counters()
+    assert [int(cnt.live[d]) for d in range(1, depth + 3)] == live[1:depth + 3].tolist()
+    for b in dump_bounces:
+        o, d, c, pix = gpu.debug_trace_paths(iters[0], b, W * H)
+        wo, wd, wc, wpix = ref.dump_paths(iters[0], b, rank, count)
+        assert np.array_equal(pix, wpix)
+        assert np.array_equal(o.view(np.uint32), wo.view(np.uint32)) and np.array_equal(d.view(np.uint32), wd.view(np.uint32))
+        assert np.array_equal(c.view(np.uint32), wc.view(np.uint32))
+    gpu.pathtraceFree()
+    assert want.max() > 0 and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    return got
+
+
+def test_mesh_scene_render_against_the_oracle(gpu, oracle):
+    sc = gpu.Scene(os.path.join(SCENES, "mesh_small.txt"))
+    assert sorted(sc.meshes) == [3, 4] and list(sc.geoms["type"]) == [1, 1, 1, 2, 2]
+    _render_both(gpu, oracle, sc, 6, [1, 2, 3], (96, 96), dump_bounces=(1, 2, 4))
+
+
+def test_mesh_scene_row_shards(gpu, oracle):
+    sc = gpu.Scene(os.path.join(SCENES, "mesh_small.txt"))
+    total = np.zeros(96 * 96 * 3, np.float32)
+    for rank in range(3):
+        total += _render_both(gpu, oracle, sc, 5, [7, 8], (96, 96), rank=rank, count=3)
+    whole = _render_both(gpu, oracle, sc, 5, [7, 8], (96, 96))
+    assert np.array_equal(total.view(np.uint32), whole.view(np.uint32))
+
+
+def test_mesh_scene_with_lens_and_direct_lighting(gpu, oracle):
+    sc = gpu.Scene(os.path.join(SCENES, "mesh_small.txt"))
+    sc.set_resolution(80, 64)
+    _render_both(gpu, oracle, sc, 4, [1, 2], (80, 64), dump_bounces=(1,), lens_radius=0.3, focal_distance=9.0)
+    _render_both(gpu, oracle, sc, 4, [1, 2], (80, 64), direct_lighting=True)
+
+
+def test_cornell_mesh_hierarchy_equals_triangle_list_at_full_size(gpu):
+    """cornell_mesh.txt (1280 + 2304 triangles) at 1280x720: the hierarchy's frame equals the plain triangle list's (the
+    brute-force rule on the device) bit for bit, and the path counts are conserved."""
+    sc = gpu.Scene(os.path.join(SCENES, "cornell_mesh.txt"))
+    sc.set_resolution(1280, 720)
+    frames, counts = [], []
+    for flat in ("0", "1"):
+        os.environ["PT_AMD_MESH_FLAT"] = flat
+        try:
+            gpu.pathtraceFree()
+            gpu.pathtraceInit(sc, traceDepth=8, max_batch=2, pipeline_depth=2)
+            gpu.pathtrace_batch(None, 0, 1, 2)
+            frames.append(gpu.readback(1280 * 720))
+            c = gpu.counters()
+            counts.append([int(c.live[d]) for d in range(1, 10)] + [int(c.light_hits), int(c.misses)])
+        finally:
+            del os.environ["PT_AMD_MESH_FLAT"]
+            gpu.pathtraceFree()
+    assert frames[0].max() > 0 and np.array_equal(frames[0].view(np.uint32), frames[1].view(np.uint32))
+    assert counts[0] == counts[1] and counts[0][0] == 2 * 1280 * 720
+    live = counts[0][:9]
+    assert all(a >= b for a, b in zip(live, live[1:]))
+
+
+def test_mesh_registration_errors(gpu):
+    sc = gpu.Scene(os.path.join(SCENES, "mesh_small.txt"))
+    gpu.pathtraceFree()
+    keep = dict(sc.meshes)
+    try:
+        sc.meshes = {3: keep[3]}                       # geom 4 is a mesh without triangles
+        with pytest.raises(gpu.PtError):
+            gpu.pathtraceInit(sc)
+        sc.meshes = dict(keep)
+        sc.meshes[1] = keep[3]                         # geom 1 is a cube
+        with pytest.raises(gpu.PtError):
+            gpu.pathtraceInit(sc)
+        bad = keep[3].copy()
+        bad[0, 0] = np.nan
+        with pytest.raises(gpu.PtError):
+            gpu.set_meshes({3: bad})
+    finally:
+        sc.meshes = keep
+        gpu.set_meshes({})
+        gpu.pathtraceFree()
+    plain = gpu.Scene(os.path.join(SCENES, "cornell.txt"))   # a scene without meshes after one with: nothing is left over
+    plain.set_resolution(64, 64)
+    gpu.pathtraceInit(plain, traceDepth=2)
+    gpu.pathtrace(None, 0, 1, readback=False)
+    gpu.sync()
+    gpu.pathtraceFree()

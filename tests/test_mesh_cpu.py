@@ -1,0 +1,181 @@
+"""Triangle meshes, CPU side (no GPU): the two OBJ / scene loaders (host library and oracle) agree; the oracle's mesh test
+behaves like the analytic primitives it approximates; the hierarchy the product builds (pt_test_mesh_bvh, host code) has the
+properties the traversal's equivalence with the brute-force rule rests on -- and a CPU walk of it, following the kernel's
+rule in fp32, returns the oracle's brute-force result."""
+import os
+
+import numpy as np
+
+from conftest import SCENES
+
+f32 = np.float32
+
+
+def test_loaders_agree_on_mesh_scenes(pt, oracle):
+    for name in ("mesh_small.txt", "cornell_mesh.txt"):
+        a = pt.Scene(os.path.join(SCENES, name))
+        b = oracle.Scene(os.path.join(SCENES, name))
+        assert a.geoms.tobytes() == b.geoms.tobytes() and a.materials.tobytes() == b.materials.tobytes()
+        assert sorted(a.meshes) == sorted(b.meshes) and len(a.meshes) == 2
+        for g in a.meshes:
+            assert a.geoms["type"][g] == 2 and a.meshes[g].tobytes() == b.meshes[g].tobytes()
+    assert pt.Scene(os.path.join(SCENES, "cornell_mesh.txt")).meshes[6].shape == (1280, 9)
+    assert pt.Scene(os.path.join(SCENES, "cornell_mesh.txt")).meshes[7].shape == (2304, 9)     # quads fanned into triangles
+
+
+def test_obj_statements(pt, oracle, tmp_path):
+    (tmp_path / "m.obj").write_text(
+        "# comment\no thing\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvn 0 0 1\nvt 0 0\n"
+        "f 1/1/1 2/1/1 3/1/1 4/1/1\n"          # a quad with texture / normal references: two triangles
+        "v 0 0 1\nf -1 1//1 2//1\n"            # negative = relative to the vertices read so far
+        "f 1 2 99\nf 1 2\ns off\n")            # out-of-range reference and a two-vertex face: ignored
+    (tmp_path / "s.txt").write_text(
+        "MATERIAL 0\nRGB 1 1 1\nSPECEX 0\nSPECRGB 0 0 0\nREFL 0\nREFR 0\nREFRIOR 0\nEMITTANCE 1\n\n"
+        "CAMERA\nRES 8 8\nFOVY 45\nITERATIONS 1\nDEPTH 2\nFILE x\nEYE 0 0 5\nVIEW 0 0 -1\nUP 0 1 0\n\n"
+        "OBJECT 0\nmesh m.obj\nmaterial 0\nTRANS 0 0 0\nROTAT 0 0 0\nSCALE 1 1 1\n\n"
+        "OBJECT 1\nmesh missing.obj\nmaterial 0\nTRANS 0 0 0\nROTAT 0 0 0\nSCALE 1 1 1\n\n")
+    want = np.array([[0, 0, 0, 1, 0, 0, 1, 1, 0], [0, 0, 0, 1, 1, 0, 0, 1, 0], [0, 0, 1, 0, 0, 0, 1, 0, 0]], f32)
+    for mod in (pt, oracle):
+        sc = mod.Scene(str(tmp_path / "s.txt"))
+        assert list(sc.meshes) == [0] and np.array_equal(sc.meshes[0], want)
+        assert list(sc.geoms["type"]) == [2, 0]       # an unreadable mesh file leaves the default type, like an unknown type line
+
+
+def _cube_mesh():
+    c = np.array([[x, y, z] for x in (-.5, .5) for y in (-.5, .5) for z in (-.5, .5)], f32)
+    quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]      # outward counter-clockwise
+    tris = []
+    for a, b, cc, d in quads:
+        tris += [np.concatenate([c[a], c[b], c[cc]]), np.concatenate([c[a], c[cc], c[d]])]
+    return np.array(tris, f32)
+
+
+def test_mesh_of_a_cube_matches_the_box_primitive(oracle):
+    tris = _cube_mesh()
+    rng = np.random.default_rng(5)
+    box = oracle.make_geom(1, 0, (1, 2, 3), (20, 30, 40), (2, 1, 3))
+    mesh = box.copy()
+    mesh["type"] = 2
+    hits = inside = 0
+    for i in range(600):
+        if i % 3 == 2:
+            o = np.array([1, 2, 3]) + rng.uniform(-0.3, 0.3, 3)                # inside
+        else:
+            o = rng.uniform(-8, 8, 3)
+        d = np.array([1, 2, 3]) + rng.uniform(-1.2, 1.2, 3) - o if i % 3 != 2 else rng.normal(size=3)
+        d = d / np.linalg.norm(d)
+        ray = np.concatenate([o, d]).astype(f32)
+        tb, pb, nb, ob = oracle.intersect(box, ray)
+        tm, pm, nm, om, tri = oracle.mesh_intersect(mesh, tris, ray)
+        assert (tb > 0) == (tm > 0), (i, tb, tm)
+        if tb > 0:
+            assert abs(tb - tm) < 1e-4 * max(1, tb) and np.allclose(pb, pm, atol=2e-4) and ob == om
+            assert np.allclose(nb, nm, atol=1e-4), (nb, nm)
+            hits += 1
+            inside += 1 - om
+    assert hits > 250 and inside > 100
+
+
+def test_icosphere_mesh_approximates_the_sphere(oracle):
+    sc = oracle.Scene(os.path.join(SCENES, "cornell_mesh.txt"))
+    tris = sc.meshes[6]
+    sph = oracle.make_geom(0, 0, (-1, 4, -1), (0, 0, 0), (3, 3, 3))
+    mesh = sph.copy()
+    mesh["type"] = 2
+    rng = np.random.default_rng(6)
+    n = 0
+    for _ in range(300):
+        o = rng.uniform(-9, 9, 3)
+        d = np.array([-1, 4, -1]) + rng.normal(size=3) * 0.6 - o
+        ray = np.concatenate([o, d / np.linalg.norm(d)]).astype(f32)
+        ts, ps, ns, os_ = oracle.intersect(sph, ray)
+        tm, pm, nm, om, tri = oracle.mesh_intersect(mesh, tris, ray)
+        if ts > 0 and tm > 0 and -(ray[3:] @ ns) > 0.5:                                # (away from the silhouette)
+            assert abs(ts - tm) < 0.03 and os_ == om and nm @ ns > 0.99          # 1280 facets of a radius-1.5 ball
+            n += 1
+    assert n > 150
+
+
+def test_hierarchy_invariants(pt):
+    sc = pt.Scene(os.path.join(SCENES, "cornell_mesh.txt"))
+    for tris in list(sc.meshes.values()) + [_cube_mesh(), _cube_mesh()[:1]]:
+        nt = len(tris)
+        nodes = pt.mesh_bvh(tris)
+        assert len(nodes) == 2 * nt - 1
+        END = 0xFFFFFFFF
+        margin = f32(1e-5) * np.abs(tris).max()
+        leaves = nodes[nodes["tri"] >= 0]
+        assert sorted(leaves["tri"].tolist()) == list(range(nt))                       # every triangle exactly once
+        v = tris.reshape(nt, 3, 3)
+        for nd in leaves:                                                              # a leaf's box IS the triangle's box
+            t = v[nd["tri"]]
+            assert np.array_equal(nd["lo"], t.min(0) - margin) and np.array_equal(nd["hi"], t.max(0) + margin)
+        # depth-first layout: the subtree of node i is [i, end_i); children are i + 1 and skip(i + 1)
+        end = lambda i: len(nodes) if nodes["skip"][i] == END else int(nodes["skip"][i])
+        depth = 0
+        stack = [(0, 1)]
+        while stack:
+            i, dpt = stack.pop()
+            depth = max(depth, dpt)
+            assert i < end(i) <= len(nodes)
+            if nodes["tri"][i] >= 0:
+                assert end(i) == i + 1
+                continue
+            l, r = i + 1, end(i + 1)
+            assert r < end(i) and end(r) == end(i)
+            for a in range(3):                                                         # exact union of the children
+                assert nodes["lo"][i][a] == min(nodes["lo"][l][a], nodes["lo"][r][a])
+                assert nodes["hi"][i][a] == max(nodes["hi"][l][a], nodes["hi"][r][a])
+            stack += [(l, dpt + 1), (r, dpt + 1)]
+        assert depth <= int(np.ceil(np.log2(max(nt, 1)))) + 1                          # median splits: balanced
+
+
+def _walk(nodes, tris, oracle, ro, rd):
+    """The kernel's traversal (ptd::meshIntersectionTest) in numpy fp32 on object-space rays; triangle test by the oracle."""
+    END = 0xFFFFFFFF
+    up, dn = f32(1.00001), f32(0.99999)
+    g = np.where(np.abs(rd) < f32(1e-30), np.copysign(f32(1e-30), rd), rd).astype(f32)
+    inv = (f32(1.0) / g).astype(f32)
+    best, tbest, node, visited = -1, f32(0), 0, 0
+    while node != END:
+        nd = nodes[node]
+        a = ((nd["lo"] - ro) * inv).astype(f32)
+        b = ((nd["hi"] - ro) * inv).astype(f32)
+        tn = np.max(np.minimum(a, b))
+        tf = np.min(np.maximum(a, b))
+        tmin = f32(tn * dn)
+        tri = int(nd["tri"])
+        ok = f32(tf * up) >= tmin and tf >= 0 and (best < 0 or not tmin > tbest)
+        visited += 1
+        if ok and tri >= 0:
+            v = tris[tri]
+            hit, tuv, front = oracle.mesh_triangle(ro, rd, v[0:3], v[3:6], v[6:9])
+            t = f32(tuv[0])
+            if hit and t >= tmin and (best < 0 or t < tbest or (t == tbest and tri < best)):
+                best, tbest = tri, t
+        node = node + 1 if (ok and tri < 0) else int(nd["skip"])
+    return best, tbest, visited
+
+
+def test_hierarchy_walk_equals_the_brute_force_rule(pt, oracle):
+    sc = pt.Scene(os.path.join(SCENES, "cornell_mesh.txt"))
+    ident = oracle.make_geom(2, 0, (0, 0, 0), (0, 0, 0), (1, 1, 1))       # identity: world space = object space
+    rng = np.random.default_rng(7)
+    for g in (6, 7):
+        tris = sc.meshes[g]
+        nodes = pt.mesh_bvh(tris)
+        hits = visited = 0
+        for i in range(400):
+            o = (rng.normal(size=3) * (0.2 if i % 4 == 0 else 2.0)).astype(f32)
+            tgt = tris[rng.integers(len(tris))].reshape(3, 3).mean(0) + rng.normal(size=3) * 0.02
+            d = (tgt - o) if i % 5 else rng.normal(size=3)
+            d = (d / np.linalg.norm(d)).astype(f32)
+            # (the oracle normalises once more in object space; feed it the direction it will actually use)
+            rd = oracle.normalize(d)
+            wt, wp, wn, wo, wtri = oracle.mesh_intersect(ident, tris, np.concatenate([o, d]))
+            best, tbest, vis = _walk(nodes, tris, oracle, o, rd)
+            assert best == wtri, (g, i, best, wtri)
+            hits += best >= 0
+            visited += vis
+        assert hits > 250
+        assert visited / 400 < 0.2 * len(nodes)          # ... and it is a hierarchy: a fraction of the nodes per ray
