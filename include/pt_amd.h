@@ -225,11 +225,12 @@ int pt_test_wall_box_sweep(const PtGeom *geoms, int ngeoms, uint64_t seed, int64
 /* Triangle meshes.  pt_test_mesh_intersect: `n` rays against ONE mesh geom on the GPU, through the hierarchy (flat = 0) or a
  * plain list of its triangles (flat = 1: the brute-force rule); outputs keep their input values on a miss; culled[i] = 1 when
  * the bounding-ball test (certainMiss) rejected the ray -- t[i] is NaN if the full test hits nevertheless (must not happen).
- * pt_test_mesh_bvh (host only, no GPU needed): the hierarchy pt_init would build, 8 words per node (lo[3], skip, hi[3], tri);
- * *nnodes in = capacity, out = node count (2 ntris - 1). */
+ * pt_test_mesh_bvh (host only, no GPU needed): the hierarchy pt_init would build -- the copy laid out for rays of direction
+ * octant `octant` (bit a set: the direction's component a is negative), nearer child first -- 8 words per node (lo[3], skip,
+ * hi[3], tri), links relative to the copy; *nnodes in = capacity, out = node count (2 ntris - 1). */
 int pt_test_mesh_intersect(const PtGeom *geom, const float *tris, int ntris, int flat, const float *rays, int n, float *t,
                            float *p3, float *n3, int32_t *outside, int32_t *culled);
-int pt_test_mesh_bvh(const float *tris, int ntris, uint32_t *nodes8, int *nnodes);
+int pt_test_mesh_bvh(const float *tris, int ntris, int octant, uint32_t *nodes8, int *nnodes);
 /* slabQuotients (shared-reciprocal packed division of the box test) next to the compiler's correctly
  * rounded `/`: per-element outputs, and a device-side pseudo-random sweep that returns the number of
  * bit mismatches over `pairs` (o, d) pairs (must be 0). */

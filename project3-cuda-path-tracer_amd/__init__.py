@@ -127,7 +127,7 @@ def lib():
         L.pt_test_wall_box_sweep.argtypes = [vp, i32, C.c_uint64, i64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.pt_set_meshes.argtypes = [C.POINTER(PtMesh), i32]
         L.pt_test_mesh_intersect.argtypes = [vp, vp, i32, i32, vp, i32, vp, vp, vp, vp, vp]
-        L.pt_test_mesh_bvh.argtypes = [vp, i32, vp, C.POINTER(C.c_int)]
+        L.pt_test_mesh_bvh.argtypes = [vp, i32, i32, vp, C.POINTER(C.c_int)]
         _lib = L
     return _lib
 
@@ -381,13 +381,14 @@ def test_mesh_intersect(geom, tris, rays, flat=False, sentinel=-7.0):
     return t, p, nn, o, culled
 
 
-def mesh_bvh(tris):
-    """The hierarchy pt_init builds for a mesh (host only): structured array of nodes (lo, skip, hi, tri)."""
+def mesh_bvh(tris, octant=0):
+    """The hierarchy pt_init builds for a mesh (host only), in the layout for rays of direction octant `octant` (bit a set:
+    component a negative): structured array of nodes (lo, skip, hi, tri)."""
     tr = np.ascontiguousarray(tris, np.float32).reshape(-1, 9)
     node = np.dtype([("lo", "<f4", 3), ("skip", "<u4"), ("hi", "<f4", 3), ("tri", "<i4")])
     out = np.zeros(2 * len(tr), node)
     n = C.c_int(len(out))
-    _check(lib().pt_test_mesh_bvh(_p(tr), len(tr), _p(out), C.byref(n)))
+    _check(lib().pt_test_mesh_bvh(_p(tr), len(tr), octant, _p(out), C.byref(n)))
     return out[:n.value]
 
 

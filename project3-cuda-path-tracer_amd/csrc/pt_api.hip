@@ -768,15 +768,16 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     for (int i = 0; i < ngeoms; ++i) {
         float box[6];
         const bool isMesh = geoms[i].type == PT_MESH;
-        uint32_t root = ptd::kMeshEnd;
+        uint32_t root = ptd::kMeshEnd, stride = 0;
         if (isMesh) {
             const ptm::HostMesh *hm_ = mesh_of(i);
             root = (uint32_t)meshNodes.size();
-            ptm::appendMesh(hm_->tris.data(), (int)(hm_->tris.size() / 9), flatMeshes, meshNodes, meshTris, box);
+            stride = ptm::appendMesh(hm_->tris.data(), (int)(hm_->tris.size() / 9), flatMeshes, meshNodes, meshTris, box);
             if (meshNodes.size() >= (1ull << 31)) return fail(PT_ERR_INVALID, "pt_init: too many triangles");
         }
         pack_geom(geoms[i], hg[i], k.pos, isMesh ? box : nullptr);
         hg[i].meshRoot = root;
+        if (isMesh) hg[i].meshStride = stride;
         project_geom(geoms[i], k, hg[i].rect, isMesh ? box : nullptr);
         if (S.dof) {        // rays start anywhere on the lens: the pinhole projection bounds nothing
             hg[i].rect[0] = hg[i].rect[1] = 0;
@@ -1314,10 +1315,11 @@ int pt_test_mesh_intersect(const PtGeom *geom, const float *tris, int ntris, int
     std::vector<ptd::MeshNode> nodes;
     std::vector<ptd::MeshTri> mt;
     float box[6];
-    ptm::appendMesh(tris, ntris, flat != 0, nodes, mt, box);
+    const uint32_t stride = ptm::appendMesh(tris, ntris, flat != 0, nodes, mt, box);
     GeomDev hg;
     pack_geom(*geom, hg, nullptr, box);
     hg.meshRoot = 0;
+    hg.meshStride = stride;
     DevBuf<GeomDev> dg;
     DevBuf<ptd::MeshNode> dn_;
     DevBuf<ptd::MeshTri> dtr;
@@ -1344,15 +1346,20 @@ int pt_test_mesh_intersect(const PtGeom *geom, const float *tris, int ntris, int
 }
 
 // host only: no GPU is touched
-int pt_test_mesh_bvh(const float *tris, int ntris, uint32_t *nodes8, int *nnodes) {
-    if (!tris || ntris < 1 || !nodes8 || !nnodes) return fail(PT_ERR_INVALID, "pt_test_mesh_bvh: bad argument");
+int pt_test_mesh_bvh(const float *tris, int ntris, int octant, uint32_t *nodes8, int *nnodes) {
+    if (!tris || ntris < 1 || !nodes8 || !nnodes || octant < 0 || octant > 7) return fail(PT_ERR_INVALID, "pt_test_mesh_bvh: bad argument");
     std::vector<ptd::MeshNode> nodes;
     std::vector<ptd::MeshTri> mt;
     float box[6];
-    ptm::appendMesh(tris, ntris, false, nodes, mt, box);
-    if ((int)nodes.size() > *nnodes) return fail(PT_ERR_INVALID, "pt_test_mesh_bvh: %zu nodes do not fit %d", nodes.size(), *nnodes);
-    memcpy(nodes8, nodes.data(), nodes.size() * sizeof(ptd::MeshNode));
-    *nnodes = (int)nodes.size();
+    const uint32_t stride = ptm::appendMesh(tris, ntris, false, nodes, mt, box);
+    if ((int)stride > *nnodes) return fail(PT_ERR_INVALID, "pt_test_mesh_bvh: %u nodes do not fit %d", stride, *nnodes);
+    // the copy of this octant, its links rebased to the copy's first node
+    for (uint32_t i = 0; i < stride; ++i) {
+        ptd::MeshNode n = nodes[(size_t)octant * stride + i];
+        if (n.skip != ptd::kMeshEnd) n.skip -= (uint32_t)octant * stride;
+        memcpy(nodes8 + 8 * (size_t)i, &n, sizeof n);
+    }
+    *nnodes = (int)stride;
     return PT_OK;
 }
 

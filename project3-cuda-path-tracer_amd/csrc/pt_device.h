@@ -131,7 +131,10 @@ struct GeomDev {
     // normalize(multiplyMV(transform, (+-e_axis, 0))) (src/intersections.h:85) and the two tangent directions the
     // hemisphere sampler derives from a normal (src/interactions.h:22-35), 9 floats per face, evaluated once on the host
     // with the operations the kernels would issue per hit
-    float cubeFrame[54];
+    union {
+        float cubeFrame[54];
+        uint32_t meshStride;   // a mesh: nodes per copy of its hierarchy; the copy for direction octant k starts at meshRoot + k * meshStride
+    };
     // 1: a small primitive the queue is binned by (KParams::binGeom): tiles of paths that certainly miss all of them
     // skip it (mirrored in flags)
     int   binned;
@@ -544,6 +547,8 @@ __device__ __forceinline__ float sphereIntersectionTest(const GD &g, F3 ro_w, F3
 //
 // Nodes in depth-first order, 32 B each: an inner node is followed by its first child; `skip` is the next node when the
 // subtree is left (kMeshEnd after the mesh's last); a leaf (tri >= 0) is one triangle and its box.  No stack, no LDS.
+// The hierarchy is stored once per sign octant of the ray direction, nearer child first (pt_mesh.h): a ray walks its
+// octant's copy front to back.
 struct MeshNode {
     float    lo[3];
     uint32_t skip;
@@ -588,14 +593,15 @@ __device__ __forceinline__ bool meshTriangle(F3 o, F3 d, F3 v0, F3 e1, F3 e2, fl
 // (NaN operands: every triangle test fails whatever the slab tests say -- a, or s, is NaN -- like in the oracle's loop.)
 template <bool CAM_ORIGIN = false, typename GD>
 __device__ __forceinline__ float meshIntersectionTest(const GD &g, const float4 *nodes, const float4 *tris, uint32_t root,
-                                                      F3 ro_w, F3 rd_w, F3 &P, F3 &nsrc, bool &outside) {
+                                                      uint32_t stride, F3 ro_w, F3 rd_w, F3 &P, F3 &nsrc, bool &outside) {
     const F3 ro = CAM_ORIGIN ? f3(g.camObj[0], g.camObj[1], g.camObj[2]) : mulMV(g.inv, ro_w, 1.0f);
     const F3 rd = normalize(mulMV0(g.inv, g.invZ, rd_w));
     const F3 inv = f3(guardedReciprocal(rd.x), guardedReciprocal(rd.y), guardedReciprocal(rd.z));
     int best = -1;
     float tbest = 0.0f;
     uint32_t bestFront = 0u;
-    uint32_t node = root;
+    const uint32_t octant = (rd.x < 0.0f ? 1u : 0u) | (rd.y < 0.0f ? 2u : 0u) | (rd.z < 0.0f ? 4u : 0u);
+    uint32_t node = root + octant * stride;
     while (node != kMeshEnd) {
         const float4 n0 = nodes[2 * (size_t)node], n1 = nodes[2 * (size_t)node + 1];
         const float ax = (n0.x - ro.x) * inv.x, bx = (n1.x - ro.x) * inv.x;

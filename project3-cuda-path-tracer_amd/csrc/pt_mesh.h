@@ -39,13 +39,17 @@ inline float max2(float a, float b) { return a < b ? b : a; }
 // Appends one mesh to the scene's node and triangle arrays.  Leaves are single triangles whose box is the triangle's
 // bounding box inflated by the margin -- the very box the semantics tests -- and an inner node's box is the exact union
 // of its children's (min / max of floats: no rounding), so box inclusion holds exactly, which is all the traversal's
-// equivalence with the brute-force rule needs.  Median split of the centroids along their widest axis; children in
-// that order; depth-first layout with skip links.  `flat`: no hierarchy, one leaf per triangle in index order (tests:
-// the brute-force rule on the device).  bbox receives the union of all leaf boxes (lo[3], hi[3]).
-inline void appendMesh(const float *tris, int ntris, bool flat, std::vector<MeshNode> &nodes, std::vector<MeshTri> &out,
-                       float bbox[6]) {
+// equivalence with the brute-force rule needs.  Median split of the centroids along their widest axis.
+//
+// The tree is laid out EIGHT times, once per sign octant of the ray direction, each in depth-first order with skip links
+// and with the child on the ray's near side of the split first: a ray walks the copy of its octant (root + octant *
+// stride) front to back, so the first hits prune most of what lies behind them, and the walk itself stays a loop over
+// consecutive nodes without a stack.  (The order of the visits never changes the result, only how much is pruned.)
+// Returns the stride = nodes per copy (2 ntris - 1).  `flat`: no hierarchy, ONE list of leaves in index order and
+// stride 0 (tests: the brute-force rule on the device).  bbox receives the union of all leaf boxes (lo[3], hi[3]).
+inline uint32_t appendMesh(const float *tris, int ntris, bool flat, std::vector<MeshNode> &nodes, std::vector<MeshTri> &out,
+                           float bbox[6]) {
     const float m = meshMargin(tris, ntris);
-    const uint32_t nodeBase = (uint32_t)nodes.size();
     const int triBase = (int)out.size();
     struct Leaf { float lo[3], hi[3], c[3]; int idx; };
     std::vector<Leaf> leaves((size_t)ntris);
@@ -68,28 +72,36 @@ inline void appendMesh(const float *tris, int ntris, bool flat, std::vector<Mesh
         }
         out.push_back(mt);
     }
-    auto leafNode = [&](const Leaf &L) {
-        MeshNode n;
-        for (int a = 0; a < 3; ++a) { n.lo[a] = L.lo[a]; n.hi[a] = L.hi[a]; }
-        n.skip = 0;
-        n.tri = triBase + L.idx;
-        return n;
-    };
     if (flat) {
+        const uint32_t nodeBase = (uint32_t)nodes.size();
         for (int i = 0; i < ntris; ++i) {
-            MeshNode n = leafNode(leaves[(size_t)i]);
+            MeshNode n;
+            for (int a = 0; a < 3; ++a) { n.lo[a] = leaves[(size_t)i].lo[a]; n.hi[a] = leaves[(size_t)i].hi[a]; }
+            n.tri = triBase + i;
             n.skip = i + 1 < ntris ? nodeBase + (uint32_t)i + 1u : kMeshEnd;
             nodes.push_back(n);
         }
-        return;
+        return 0u;
     }
-    // depth-first build over index ranges of `leaves` (recursion depth: ceil(log2 ntris) + 1)
-    struct Rec {
+    // the tree: node k has a box and either a triangle or two children (lower / upper half along `axis`)
+    struct TreeNode { float lo[3], hi[3]; int tri, left, right, axis, size; };
+    std::vector<TreeNode> tree;
+    tree.reserve(2 * (size_t)ntris);
+    struct Builder {
         std::vector<Leaf> &lv;
-        std::vector<MeshNode> &nodes;
-        decltype(leafNode) &mk;
-        void build(int lo, int hi) {
-            if (hi - lo == 1) { nodes.push_back(mk(lv[(size_t)lo])); return; }
+        std::vector<TreeNode> &tree;
+        int build(int lo, int hi) {                       // recursion depth: ceil(log2 ntris) + 1
+            const int me = (int)tree.size();
+            tree.push_back(TreeNode());
+            if (hi - lo == 1) {
+                TreeNode &n = tree[(size_t)me];
+                for (int a = 0; a < 3; ++a) { n.lo[a] = lv[(size_t)lo].lo[a]; n.hi[a] = lv[(size_t)lo].hi[a]; }
+                n.tri = lv[(size_t)lo].idx;
+                n.left = n.right = -1;
+                n.axis = 0;
+                n.size = 1;
+                return me;
+            }
             float cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
             for (int i = lo; i < hi; ++i)
                 for (int a = 0; a < 3; ++a) { cmin[a] = min2(cmin[a], lv[(size_t)i].c[a]); cmax[a] = max2(cmax[a], lv[(size_t)i].c[a]); }
@@ -100,35 +112,43 @@ inline void appendMesh(const float *tris, int ntris, bool flat, std::vector<Mesh
             std::nth_element(lv.begin() + lo, lv.begin() + mid, lv.begin() + hi, [axis](const Leaf &x, const Leaf &y) {
                 return x.c[axis] < y.c[axis] || (x.c[axis] == y.c[axis] && x.idx < y.idx);
             });
-            const size_t me = nodes.size();
-            MeshNode n;
-            memset(&n, 0, sizeof n);
-            n.tri = -1;
-            nodes.push_back(n);
-            const size_t left = nodes.size();
-            build(lo, mid);
-            const size_t right = nodes.size();
-            build(mid, hi);
+            const int l = build(lo, mid), r = build(mid, hi);
+            TreeNode &n = tree[(size_t)me];
             for (int a = 0; a < 3; ++a) {
-                nodes[me].lo[a] = min2(nodes[left].lo[a], nodes[right].lo[a]);
-                nodes[me].hi[a] = max2(nodes[left].hi[a], nodes[right].hi[a]);
+                n.lo[a] = min2(tree[(size_t)l].lo[a], tree[(size_t)r].lo[a]);
+                n.hi[a] = max2(tree[(size_t)l].hi[a], tree[(size_t)r].hi[a]);
+            }
+            n.tri = -1;
+            n.left = l; n.right = r;
+            n.axis = axis;
+            n.size = 1 + tree[(size_t)l].size + tree[(size_t)r].size;
+            return me;
+        }
+    } builder{leaves, tree};
+    builder.build(0, ntris);
+    const uint32_t stride = (uint32_t)tree.size();
+    for (int oct = 0; oct < 8; ++oct) {
+        const uint32_t base = (uint32_t)nodes.size(), end = base + stride;
+        // depth-first emission with an explicit stack of (tree node); a node's skip link = its position + its subtree size
+        std::vector<int> stack(1, 0);
+        while (!stack.empty()) {
+            const TreeNode &t = tree[(size_t)stack.back()];
+            stack.pop_back();
+            MeshNode n;
+            for (int a = 0; a < 3; ++a) { n.lo[a] = t.lo[a]; n.hi[a] = t.hi[a]; }
+            n.tri = t.tri >= 0 ? triBase + t.tri : -1;
+            const uint32_t next = (uint32_t)nodes.size() + (uint32_t)t.size;
+            n.skip = next < end ? next : kMeshEnd;
+            nodes.push_back(n);
+            if (t.tri < 0) {
+                const bool upperFirst = ((oct >> t.axis) & 1) != 0;       // the ray runs towards -axis: the upper half is nearer
+                const int first = upperFirst ? t.right : t.left, second = upperFirst ? t.left : t.right;
+                stack.push_back(second);
+                stack.push_back(first);
             }
         }
-    } rec{leaves, nodes, leafNode};
-    rec.build(0, ntris);
-    // skip links: the node after a node's subtree.  Subtree sizes follow from the layout: a leaf is 1 node, an inner node
-    // 1 + its two children's subtrees; one backwards pass.
-    const uint32_t end = (uint32_t)nodes.size();
-    std::vector<uint32_t> size(end - nodeBase);
-    for (uint32_t i = end; i-- > nodeBase;) {
-        if (nodes[i].tri >= 0) size[i - nodeBase] = 1;
-        else {
-            const uint32_t l = i + 1, r = l + size[l - nodeBase];
-            size[i - nodeBase] = 1 + size[l - nodeBase] + size[r - nodeBase];
-        }
-        const uint32_t next = i + size[i - nodeBase];
-        nodes[i].skip = next < end ? next : kMeshEnd;
     }
+    return stride;
 }
 
 }  // namespace ptm

@@ -58,7 +58,7 @@ __global__ void k_test_mesh(const GeomDev *geom, const float4 *nodes, const floa
     bool o = outside[i] != 0;
     F3 nsrc = f3(0, 0, 0);
     const bool cull = certainMiss(G, ro, rd, dot(rd, rd));
-    const float tt = meshIntersectionTest(G, nodes, tris, G.meshRoot, ro, rd, P, nsrc, o);
+    const float tt = meshIntersectionTest(G, nodes, tris, G.meshRoot, G.meshStride, ro, rd, P, nsrc, o);
     culled[i] = cull ? 1 : 0;
     t[i] = cull && tt != -1.0f ? __builtin_nanf("") : tt;
     if (tt != -1.0f) N = hitNormal(G, nsrc, o);

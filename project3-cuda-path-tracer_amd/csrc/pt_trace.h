@@ -647,7 +647,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? (FIRST ? 6 : 
                         // a triangle mesh: its bounding ball first, then every lane walks the mesh's hierarchy on its own
                         if (!certainMiss(cg, org, dir, dd)) {
                             const ArgsPtr A2 = launder(kargs);
-                            t = meshIntersectionTest<FIRST && !DOF>(G, A2->meshNodes, A2->meshTris, G.meshRoot, org, dir, p, n, o);
+                            t = meshIntersectionTest<FIRST && !DOF>(G, A2->meshNodes, A2->meshTris, G.meshRoot, G.meshStride, org, dir, p, n, o);
                         }
                     } else if ((flags & 1) == 0) {
                         probe(3);

@@ -98,9 +98,10 @@ def test_icosphere_mesh_approximates_the_sphere(oracle):
 
 def test_hierarchy_invariants(pt):
     sc = pt.Scene(os.path.join(SCENES, "cornell_mesh.txt"))
-    for tris in list(sc.meshes.values()) + [_cube_mesh(), _cube_mesh()[:1]]:
+    cases = [(t, o) for t in sc.meshes.values() for o in (0, 5)] + [(_cube_mesh(), o) for o in range(8)] + [(_cube_mesh()[:1], 3)]
+    for tris, octant in cases:
         nt = len(tris)
-        nodes = pt.mesh_bvh(tris)
+        nodes = pt.mesh_bvh(tris, octant)
         assert len(nodes) == 2 * nt - 1
         END = 0xFFFFFFFF
         margin = f32(1e-5) * np.abs(tris).max()
@@ -126,6 +127,10 @@ def test_hierarchy_invariants(pt):
             for a in range(3):                                                         # exact union of the children
                 assert nodes["lo"][i][a] == min(nodes["lo"][l][a], nodes["lo"][r][a])
                 assert nodes["hi"][i][a] == max(nodes["hi"][l][a], nodes["hi"][r][a])
+            # the first child is the nearer one for this octant along some axis: its centre does not lie behind the second's
+            cl = nodes["lo"][l] + nodes["hi"][l]
+            cr = nodes["lo"][r] + nodes["hi"][r]
+            assert any((cl[a] >= cr[a]) if (octant >> a) & 1 else (cl[a] <= cr[a]) for a in range(3))
             stack += [(l, dpt + 1), (r, dpt + 1)]
         assert depth <= int(np.ceil(np.log2(max(nt, 1)))) + 1                          # median splits: balanced
 
@@ -163,7 +168,7 @@ def test_hierarchy_walk_equals_the_brute_force_rule(pt, oracle):
     rng = np.random.default_rng(7)
     for g in (6, 7):
         tris = sc.meshes[g]
-        nodes = pt.mesh_bvh(tris)
+        copies = [pt.mesh_bvh(tris, o) for o in range(8)]
         hits = visited = 0
         for i in range(400):
             o = (rng.normal(size=3) * (0.2 if i % 4 == 0 else 2.0)).astype(f32)
@@ -173,9 +178,12 @@ def test_hierarchy_walk_equals_the_brute_force_rule(pt, oracle):
             # (the oracle normalises once more in object space; feed it the direction it will actually use)
             rd = oracle.normalize(d)
             wt, wp, wn, wo, wtri = oracle.mesh_intersect(ident, tris, np.concatenate([o, d]))
-            best, tbest, vis = _walk(nodes, tris, oracle, o, rd)
+            octant = int(rd[0] < 0) | int(rd[1] < 0) << 1 | int(rd[2] < 0) << 2
+            best, tbest, vis = _walk(copies[octant], tris, oracle, o, rd)
+            if i % 16 == 0:                       # ... and whatever copy a ray walks, the result is the same
+                assert _walk(copies[7 - octant], tris, oracle, o, rd)[:2] == (best, tbest)
             assert best == wtri, (g, i, best, wtri)
             hits += best >= 0
             visited += vis
         assert hits > 250
-        assert visited / 400 < 0.2 * len(nodes)          # ... and it is a hierarchy: a fraction of the nodes per ray
+        assert visited / 400 < 0.1 * len(copies[0])      # ... and it is a hierarchy: a fraction of the nodes per ray
