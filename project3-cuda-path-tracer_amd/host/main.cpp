@@ -91,6 +91,15 @@ static void renderBatched() {
     opt.lens_radius = lensRadius;
     opt.focal_distance = focalDistance;
     if (directLighting) opt.flags |= PT_FLAG_DIRECT_LIGHTING;
+    std::vector<PtMesh> meshes;        // `mesh` objects: their triangles first (like pathtrace_shim.cpp)
+    for (size_t i = 0; i < scene->meshes.size(); ++i) {
+        PtMesh m;
+        m.geom = scene->meshes[i].geom;
+        m.ntris = (int)(scene->meshes[i].tris.size() / 9);
+        m.tris = scene->meshes[i].tris.data();
+        meshes.push_back(m);
+    }
+    check(pt_set_meshes(meshes.empty() ? NULL : meshes.data(), (int)meshes.size()), "pt_set_meshes");
     check(pt_init((const PtCamera *)&renderState->camera, (const PtGeom *)scene->geoms.data(), (int)scene->geoms.size(),
                   (const PtMaterial *)scene->materials.data(), (int)scene->materials.size(), renderState->traceDepth, &opt),
           "pt_init");
