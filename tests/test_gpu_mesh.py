@@ -197,3 +197,24 @@ def test_mesh_registration_errors(gpu):
     gpu.pathtrace(None, 0, 1, readback=False)
     gpu.sync()
     gpu.pathtraceFree()
+
+
+def test_headless_driver_renders_a_mesh_scene(gpu, oracle, tmp_path):
+    # pt_render = the reference's main()/runCuda()/saveImage() over the shim (which registers the scene's meshes before
+    # pt_init), and its --batch path over the C ABI: both write the oracle's picture
+    import subprocess
+    from test_host import _decode_png
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "project3-cuda-path-tracer_amd", "host", "pt_render")
+    sc = oracle.Scene(os.path.join(SCENES, "mesh_small.txt"))
+    ref = oracle.Renderer(sc.camera, sc.geoms, sc.materials, 4, meshes=sc.meshes)
+    img = np.zeros(96 * 96 * 3, np.float32)
+    for it in range(1, 4):
+        ref.iterate(it, img)
+    want = (np.clip(img.reshape(96, 96, 3) / np.float32(3), 0, 1) * np.float32(255)).astype(np.uint8)[:, ::-1]
+    for extra in ([], ["--batch", "3"]):
+        base = str(tmp_path / ("m" + str(len(extra))))
+        r = subprocess.run([exe, os.path.join(SCENES, "mesh_small.txt"), "--iterations", "3", "--depth", "4", "--out", base] + extra,
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert np.array_equal(_decode_png(base + ".png"), want)
