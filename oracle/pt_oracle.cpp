@@ -747,6 +747,11 @@ std::vector<std::string> tokenize(const std::string &s) {
     return out;
 }
 inline float atoff(const std::string &s) { return (float)atof(s.c_str()); }
+/* the k-th token, "" when the line is too short (the reference indexes unchecked, src/scene.cpp:103-111,160-172: undefined there) */
+inline const std::string &tokk(const std::vector<std::string> &t, size_t k) {
+    static const std::string empty;
+    return k < t.size() ? t[k] : empty;
+}
 inline bool is(const std::vector<std::string> &t, const char *key) {
     return !t.empty() && strcmp(t[0].c_str(), key) == 0;
 }
@@ -776,12 +781,12 @@ void load_material(OScene &sc, std::ifstream &fp, const std::string &idtok) {
         safe_getline(fp, line);
         std::vector<std::string> t = tokenize(line);
         if (is(t, "RGB")) m.color = tok3(t);
-        else if (is(t, "SPECEX")) m.specExponent = atoff(t[1]);
+        else if (is(t, "SPECEX")) m.specExponent = atoff(tokk(t, 1));
         else if (is(t, "SPECRGB")) m.specColor = tok3(t);
-        else if (is(t, "REFL")) m.hasReflective = atoff(t[1]);
-        else if (is(t, "REFR")) m.hasRefractive = atoff(t[1]);
-        else if (is(t, "REFRIOR")) m.indexOfRefraction = atoff(t[1]);
-        else if (is(t, "EMITTANCE")) m.emittance = atoff(t[1]);
+        else if (is(t, "REFL")) m.hasReflective = atoff(tokk(t, 1));
+        else if (is(t, "REFR")) m.hasRefractive = atoff(tokk(t, 1));
+        else if (is(t, "REFRIOR")) m.indexOfRefraction = atoff(tokk(t, 1));
+        else if (is(t, "EMITTANCE")) m.emittance = atoff(tokk(t, 1));
     }
     sc.materials.push_back(m);
 }
@@ -794,11 +799,11 @@ void load_camera(OScene &sc, std::ifstream &fp) {
         std::string line;
         safe_getline(fp, line);
         std::vector<std::string> t = tokenize(line);
-        if (is(t, "RES")) { cam.resX = atoi(t[1].c_str()); cam.resY = atoi(t[2].c_str()); }
-        else if (is(t, "FOVY")) fovy = atoff(t[1]);
-        else if (is(t, "ITERATIONS")) sc.iterations = atoi(t[1].c_str());
-        else if (is(t, "DEPTH")) sc.traceDepth = atoi(t[1].c_str());
-        else if (is(t, "FILE")) sc.imageName = t[1];
+        if (is(t, "RES")) { cam.resX = atoi(tokk(t, 1).c_str()); cam.resY = atoi(tokk(t, 2).c_str()); }
+        else if (is(t, "FOVY")) fovy = atoff(tokk(t, 1));
+        else if (is(t, "ITERATIONS")) sc.iterations = atoi(tokk(t, 1).c_str());
+        else if (is(t, "DEPTH")) sc.traceDepth = atoi(tokk(t, 1).c_str());
+        else if (is(t, "FILE")) sc.imageName = tokk(t, 1);
     }
     std::string line;
     safe_getline(fp, line);
