@@ -127,7 +127,10 @@ __device__ __forceinline__ void reserveRun(uint32_t *pos, uint32_t *bump, unsign
                                            uint32_t &cacheK, uint32_t &cacheC, uint32_t &base0, uint32_t &split, uint32_t &base1) {
     base0 = base1 = 0u;
     split = total;
-    const uint32_t p = total ? atomicAdd(pos, total) : 0u;
+    uint32_t p = total ? atomicAdd(pos, total) : 0u;
+#if defined(PT_EXP) && (PT_EXP & 1)      // experiment: one more dependent memory round trip per reservation (how exposed is it?)
+    if (total) p += atomicAdd(pos + 1 + (p & 7u), 1u) >> 31;
+#endif
     const uint32_t k0 = p >> shift, k1 = (p + (total ? total - 1u : 0u)) >> shift;
     if (total && ((p & ((1u << shift) - 1u)) == 0u || k1 != k0)) { // this run holds the first slot of chunk k1: install the one after it
         const uint32_t kNew = k1 + 1u;
@@ -892,6 +895,10 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? (FIRST ? 6 : 
                 s_base[2 * kCls + tid] = r1;
             }
             __syncthreads();
+#if defined(PT_EXP) && (PT_EXP & 2)      // experiment: one more workgroup barrier per tile
+            asm volatile("" ::: "memory");
+            __syncthreads();
+#endif
             if (alive) {
                 const ArgsPtr A = launder(kargs);
                 // earlier waves' survivors of this class (kWaves = 4: three conditional terms, no loop)
