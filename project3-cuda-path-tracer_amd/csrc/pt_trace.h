@@ -501,6 +501,8 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? (FIRST ? 6 : 
         bool smallTile = true;              // wave-uniform: this tile's paths may hit a small (binned) primitive
         uint32_t tileWall = 6u;             // wave-uniform: the one wall this tile's paths can hit (0..5), 6: any, 7: none
         PathRegs cur = nextRegs;
+        int itb = 0;                                            // which iteration of the batch this path belongs to
+        int px = 0, py = 0;                                     // pixel coordinates (FIRST only)
         if (FIRST) {
             const ArgsPtr A = launder(kargs);
             const PT_CAS KParams &prm = A->prm;
@@ -534,6 +536,10 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? (FIRST ? 6 : 
                     T = Tnext;
                     continue;
                 }
+                // ... and its lanes' pixels follow from the tile's (wave-uniform) position: no per-lane divisions
+                px = x0 + (int)tid;
+                py = y0;
+                itb = (int)itb0;
             }
         } else {
             valid = nextMeta.valid;
@@ -550,8 +556,6 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? (FIRST ? 6 : 
         uint32_t lightHitI = 0u, missedI = 0u;
         F3 org = f3(0, 0, 0), dir = f3(0, 0, 1), col = f3(0, 0, 0);
         int pix = 0, rem = 0;
-        int itb = 0;                                            // which iteration of the batch this path belongs to
-        int px = 0, py = 0;                                     // pixel coordinates (FIRST only)
         if (valid) {
             // Camera rays (FIRST): a primitive is reachable only from the pixels inside the projection of its bounding
             // cube (GeomDev::rect, 2-pixel margin >> any rounding of the reference's tests), and nothing is reachable
@@ -561,11 +565,13 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? (FIRST ? 6 : 
             if (FIRST) {
                 const ArgsPtr A = launder(kargs);
                 const PT_CAS KParams &prm = A->prm;
-                itb = (int)fastDiv(idx, prm.magicN, prm.shiftN);
-                const int j = (int)(idx - (uint32_t)itb * (uint32_t)prm.nLocal);
-                const int lr = (int)fastDiv((uint32_t)j, prm.magicW, prm.shiftW);
-                px = j - lr * prm.W;
-                py = lr * prm.shardCount + prm.shardRank;
+                if (!prm.wholeRowTiles) {
+                    itb = (int)fastDiv(idx, prm.magicN, prm.shiftN);
+                    const int j = (int)(idx - (uint32_t)itb * (uint32_t)prm.nLocal);
+                    const int lr = (int)fastDiv((uint32_t)j, prm.magicW, prm.shiftW);
+                    px = j - lr * prm.W;
+                    py = lr * prm.shardCount + prm.shardRank;
+                }
                 pix = px + py * prm.W;
                 inScene = px >= prm.sceneRect[0] && px <= prm.sceneRect[2] && py >= prm.sceneRect[1] && py <= prm.sceneRect[3];
                 if (inScene) {
@@ -625,6 +631,14 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? (FIRST ? 6 : 
                 const ArgsPtr A = launder(kargs);
                 const int ngeoms = A->prm.ngeoms;
                 const GeomPtr geoms = (GeomPtr)(A->ggeoms);
+                // camera rays of whole-tile rows: a wave is 64 consecutive pixels of one row, so a primitive's rectangle is
+                // tested against the WAVE's span in scalar registers; lanes are told apart only where the span straddles an edge
+                const bool rowWave = FIRST && !DOF && A->prm.wholeRowTiles != 0;
+                int wx0 = 0, wy = 0;
+                if (rowWave) {
+                    wx0 = __builtin_amdgcn_readfirstlane(px - (int)(tid & 63u));
+                    wy = __builtin_amdgcn_readfirstlane(py);
+                }
                 for (int g = 0; g < ngeoms; ++g) {
                     // (sphere-heavy scenes: no laundering per primitive -- with 70 of them the compiler's own scheduling of
                     // the scalar loads across iterations is worth more than the registers it costs; measured on C5)
@@ -638,8 +652,14 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? (FIRST ? 6 : 
                     // wave-uniform skip, not a per-lane `continue`: the loop over the primitives stays a scalar loop
                     bool inRect = true;
                     if (FIRST && !DOF) {
-                        inRect = (px >= G.rect[0]) & (px <= G.rect[2]) & (py >= G.rect[1]) & (py <= G.rect[3]);
-                        if (__ballot(inRect) == 0ull) continue;
+                        if (rowWave) {
+                            const int rx0 = G.rect[0], ry0 = G.rect[1], rx1 = G.rect[2], ry1 = G.rect[3];
+                            if (wy < ry0 || wy > ry1 || wx0 + 63 < rx0 || wx0 > rx1) continue;
+                            if (wx0 < rx0 || wx0 + 63 > rx1) inRect = (px >= rx0) & (px <= rx1);
+                        } else {
+                            inRect = (px >= G.rect[0]) & (px <= G.rect[2]) & (py >= G.rect[1]) & (py <= G.rect[3]);
+                            if (__ballot(inRect) == 0ull) continue;
+                        }
                     }
                     if (!FIRST && !smallTile && (flags & 2)) continue;  // this tile's paths certainly miss every binned primitive
                     // ... and every wall but (at most) one
