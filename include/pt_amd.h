@@ -129,7 +129,8 @@ typedef struct PtCounters {
  *     coordinates), 9 floats each (v0, v1, v2), counter-clockwise = front ("outside");
  *   - the ray is taken to object space like the sphere test does (src/intersections.h:104-110); the triangle test is
  *     glm::intersectRayTriangle (glm/gtx/intersect.inl:36-72) made two-sided; a triangle is tested when the ray passes the
- *     slab test of the triangle's bounding box (inflated by 1e-5 of the mesh's largest |coordinate|) and its hit counts at or
+ *     slab test of the triangle's bounding box (inflated by 1e-5 of the mesh's largest |coordinate|; plane parameters
+ *     fma(plane, 1/d, -(o * 1/d)), compared with a relative slack of 1e-5) and its hit counts at or
  *     beyond that box's entry -- true of every geometric hit, and what lets a bounding-volume hierarchy return exactly the
  *     brute-force result; nearest = smallest object-space t, ties to the lower triangle index; flat shading, the normal
  *     negated on the back side; hit point and distance as the sphere test's (getPointOnRay, transform, world distance).

@@ -526,11 +526,13 @@ inline float guarded_reciprocal(float d) {
     return 1.0f / g;
 }
 
-/* the slab test of an axis-aligned box; inv = guarded reciprocals of the direction */
-bool mesh_slab(V3 lo, V3 hi, V3 o, V3 inv, float &tmin) {
-    float ax = (lo.x - o.x) * inv.x, bx = (hi.x - o.x) * inv.x;
-    float ay = (lo.y - o.y) * inv.y, by = (hi.y - o.y) * inv.y;
-    float az = (lo.z - o.z) * inv.z, bz = (hi.z - o.z) * inv.z;
+/* the slab test of an axis-aligned box; inv = guarded reciprocals of the direction, c = -(o * inv) per axis: the parameter of
+ * a plane x = lo is ONE fused multiply-add, fma(lo, inv, c) (a single rounding of lo * inv - fl(o * inv): still monotone in
+ * lo, which is what the hierarchy's equivalence rests on) */
+bool mesh_slab(V3 lo, V3 hi, V3 inv, V3 c, float &tmin) {
+    float ax = std::fmaf(lo.x, inv.x, c.x), bx = std::fmaf(hi.x, inv.x, c.x);
+    float ay = std::fmaf(lo.y, inv.y, c.y), by = std::fmaf(hi.y, inv.y, c.y);
+    float az = std::fmaf(lo.z, inv.z, c.z), bz = std::fmaf(hi.z, inv.z, c.z);
     float tn = max2(max2(min2(ax, bx), min2(ay, by)), min2(az, bz));
     float tf = min2(min2(max2(ax, bx), max2(ay, by)), max2(az, bz));
     tmin = tn * kMeshDn;
@@ -567,6 +569,7 @@ float mesh_intersection_test(const OGeom &g, const OMesh &mesh, const Ray &r, V3
     rt.origin = multiplyMV(inv, v4(r.origin.x, r.origin.y, r.origin.z, 1.0f));
     rt.direction = normalize3(multiplyMV(inv, v4(r.direction.x, r.direction.y, r.direction.z, 0.0f)));
     V3 rinv = v3(guarded_reciprocal(rt.direction.x), guarded_reciprocal(rt.direction.y), guarded_reciprocal(rt.direction.z));
+    V3 rc = v3(-(rt.origin.x * rinv.x), -(rt.origin.y * rinv.y), -(rt.origin.z * rinv.z));
     int best = -1;
     float tbest = 0.0f;
     bool bestFront = false;
@@ -576,7 +579,7 @@ float mesh_intersection_test(const OGeom &g, const OMesh &mesh, const Ray &r, V3
         V3 lo, hi;
         tri_box(tv, mesh.margin, lo, hi);
         float tmin;
-        if (!mesh_slab(lo, hi, rt.origin, rinv, tmin)) continue;
+        if (!mesh_slab(lo, hi, rinv, rc, tmin)) continue;
         V3 v0 = v3(tv[0], tv[1], tv[2]);
         V3 e1 = sub(v3(tv[3], tv[4], tv[5]), v0), e2 = sub(v3(tv[6], tv[7], tv[8]), v0);
         float t;

@@ -597,6 +597,9 @@ __device__ __forceinline__ float meshIntersectionTest(const GD &g, const float4 
     const F3 ro = CAM_ORIGIN ? f3(g.camObj[0], g.camObj[1], g.camObj[2]) : mulMV(g.inv, ro_w, 1.0f);
     const F3 rd = normalize(mulMV0(g.inv, g.invZ, rd_w));
     const F3 inv = f3(guardedReciprocal(rd.x), guardedReciprocal(rd.y), guardedReciprocal(rd.z));
+    // the parameter of a box plane x = lo is ONE fused multiply-add, fma(lo, inv, rc) with rc = -(ro * inv): a single rounding of
+    // lo * inv - fl(ro * inv), monotone in lo like the subtract-then-multiply form, at a third fewer instructions per node
+    const F3 rc = f3(-(ro.x * inv.x), -(ro.y * inv.y), -(ro.z * inv.z));
     int best = -1;
     float tbest = 0.0f;
     uint32_t bestFront = 0u;
@@ -604,9 +607,9 @@ __device__ __forceinline__ float meshIntersectionTest(const GD &g, const float4 
     uint32_t node = root + octant * stride;
     while (node != kMeshEnd) {
         const float4 n0 = nodes[2 * (size_t)node], n1 = nodes[2 * (size_t)node + 1];
-        const float ax = (n0.x - ro.x) * inv.x, bx = (n1.x - ro.x) * inv.x;
-        const float ay = (n0.y - ro.y) * inv.y, by = (n1.y - ro.y) * inv.y;
-        const float az = (n0.z - ro.z) * inv.z, bz = (n1.z - ro.z) * inv.z;
+        const float ax = __builtin_fmaf(n0.x, inv.x, rc.x), bx = __builtin_fmaf(n1.x, inv.x, rc.x);
+        const float ay = __builtin_fmaf(n0.y, inv.y, rc.y), by = __builtin_fmaf(n1.y, inv.y, rc.y);
+        const float az = __builtin_fmaf(n0.z, inv.z, rc.z), bz = __builtin_fmaf(n1.z, inv.z, rc.z);
         const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
         const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
         const float tmin = tn * kMeshDn;

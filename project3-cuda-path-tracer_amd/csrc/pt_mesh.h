@@ -105,13 +105,79 @@ inline uint32_t appendMesh(const float *tris, int ntris, bool flat, std::vector<
             float cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
             for (int i = lo; i < hi; ++i)
                 for (int a = 0; a < 3; ++a) { cmin[a] = min2(cmin[a], lv[(size_t)i].c[a]); cmax[a] = max2(cmax[a], lv[(size_t)i].c[a]); }
-            int axis = 0;
-            for (int a = 1; a < 3; ++a)
-                if (cmax[a] - cmin[a] > cmax[axis] - cmin[axis]) axis = a;
-            const int mid = lo + (hi - lo) / 2;
-            std::nth_element(lv.begin() + lo, lv.begin() + mid, lv.begin() + hi, [axis](const Leaf &x, const Leaf &y) {
-                return x.c[axis] < y.c[axis] || (x.c[axis] == y.c[axis] && x.idx < y.idx);
-            });
+            // Split by the surface-area heuristic over 16 bins of the centroids per axis (cost = area x count of the two
+            // sides; double precision: the choice only shapes the tree, it never reaches a result).  A split that leaves less
+            // than an eighth on one side, or no usable split, falls back to the median along the widest axis, which keeps the
+            // depth logarithmic.
+            const int count = hi - lo;
+            int axis = 0, mid = lo + count / 2;
+            bool byBins = false;
+            constexpr int kBins = 16;
+            auto binOf = [&](const Leaf &L, int a) {
+                const double w = (double)cmax[a] - (double)cmin[a];
+                const int b = (int)(((double)L.c[a] - (double)cmin[a]) / w * kBins);
+                return b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+            };
+            if (count > 4) {
+                double bestCost = INFINITY;
+                int bestBin = 0;
+                for (int a = 0; a < 3; ++a) {
+                    if (!((double)cmax[a] - (double)cmin[a] > 0)) continue;
+                    int cnt[kBins] = {0};
+                    double blo[kBins][3], bhi[kBins][3];
+                    for (int k = 0; k < kBins; ++k)
+                        for (int q = 0; q < 3; ++q) { blo[k][q] = INFINITY; bhi[k][q] = -INFINITY; }
+                    for (int i = lo; i < hi; ++i) {
+                        const Leaf &L = lv[(size_t)i];
+                        const int k = binOf(L, a);
+                        ++cnt[k];
+                        for (int q = 0; q < 3; ++q) { blo[k][q] = std::min(blo[k][q], (double)L.lo[q]); bhi[k][q] = std::max(bhi[k][q], (double)L.hi[q]); }
+                    }
+                    auto area = [](const double *l, const double *h) {
+                        const double x = h[0] - l[0], y = h[1] - l[1], z = h[2] - l[2];
+                        return x * y + y * z + z * x;
+                    };
+                    double rl[kBins][3], rh[kBins][3];      // boxes and counts of the bins k .. kBins - 1
+                    int rn[kBins];
+                    double cl[3] = {INFINITY, INFINITY, INFINITY}, ch[3] = {-INFINITY, -INFINITY, -INFINITY};
+                    int cn = 0;
+                    for (int k = kBins - 1; k >= 0; --k) {
+                        for (int q = 0; q < 3; ++q) { cl[q] = std::min(cl[q], blo[k][q]); ch[q] = std::max(ch[q], bhi[k][q]); }
+                        cn += cnt[k];
+                        for (int q = 0; q < 3; ++q) { rl[k][q] = cl[q]; rh[k][q] = ch[q]; }
+                        rn[k] = cn;
+                    }
+                    double ll[3] = {INFINITY, INFINITY, INFINITY}, lh[3] = {-INFINITY, -INFINITY, -INFINITY};
+                    int ln = 0;
+                    for (int k = 0; k + 1 < kBins; ++k) {          // left = bins 0 .. k
+                        for (int q = 0; q < 3; ++q) { ll[q] = std::min(ll[q], blo[k][q]); lh[q] = std::max(lh[q], bhi[k][q]); }
+                        ln += cnt[k];
+                        const int rnn = rn[k + 1];
+                        if (ln * 8 < count || rnn * 8 < count) continue;
+                        const double cost = area(ll, lh) * ln + area(rl[k + 1], rh[k + 1]) * rnn;
+                        if (cost < bestCost) {
+                            bestCost = cost;
+                            axis = a;
+                            bestBin = k;
+                            byBins = true;
+                        }
+                    }
+                }
+                if (byBins) {
+                    const int a = axis, kb = bestBin;
+                    const auto it = std::stable_partition(lv.begin() + lo, lv.begin() + hi, [&](const Leaf &L) { return binOf(L, a) <= kb; });
+                    mid = (int)(it - lv.begin());
+                }
+            }
+            if (!byBins) {
+                axis = 0;
+                for (int a = 1; a < 3; ++a)
+                    if (cmax[a] - cmin[a] > cmax[axis] - cmin[axis]) axis = a;
+                mid = lo + count / 2;
+                std::nth_element(lv.begin() + lo, lv.begin() + mid, lv.begin() + hi, [axis](const Leaf &x, const Leaf &y) {
+                    return x.c[axis] < y.c[axis] || (x.c[axis] == y.c[axis] && x.idx < y.idx);
+                });
+            }
             const int l = build(lo, mid), r = build(mid, hi);
             TreeNode &n = tree[(size_t)me];
             for (int a = 0; a < 3; ++a) {

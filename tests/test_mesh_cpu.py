@@ -132,7 +132,7 @@ def test_hierarchy_invariants(pt):
             cr = nodes["lo"][r] + nodes["hi"][r]
             assert any((cl[a] >= cr[a]) if (octant >> a) & 1 else (cl[a] <= cr[a]) for a in range(3))
             stack += [(l, dpt + 1), (r, dpt + 1)]
-        assert depth <= int(np.ceil(np.log2(max(nt, 1)))) + 1                          # median splits: balanced
+        assert depth <= 3 * int(np.ceil(np.log2(max(nt, 1)))) + 2                      # no side of a split below an eighth: logarithmic
 
 
 def _walk(nodes, tris, oracle, ro, rd):
@@ -141,11 +141,13 @@ def _walk(nodes, tris, oracle, ro, rd):
     up, dn = f32(1.00001), f32(0.99999)
     g = np.where(np.abs(rd) < f32(1e-30), np.copysign(f32(1e-30), rd), rd).astype(f32)
     inv = (f32(1.0) / g).astype(f32)
+    c = (-(ro * inv)).astype(f32)
+    fma = lambda x: (x.astype(np.float64) * inv.astype(np.float64) + c.astype(np.float64)).astype(f32)   # exact in fp64, rounded once
     best, tbest, node, visited = -1, f32(0), 0, 0
     while node != END:
         nd = nodes[node]
-        a = ((nd["lo"] - ro) * inv).astype(f32)
-        b = ((nd["hi"] - ro) * inv).astype(f32)
+        a = fma(nd["lo"])
+        b = fma(nd["hi"])
         tn = np.max(np.minimum(a, b))
         tf = np.min(np.maximum(a, b))
         tmin = f32(tn * dn)
