@@ -232,6 +232,10 @@ int pt_test_wall_box_sweep(const PtGeom *geoms, int ngeoms, uint64_t seed, int64
 int pt_test_mesh_intersect(const PtGeom *geom, const float *tris, int ntris, int flat, const float *rays, int n, float *t,
                            float *p3, float *n3, int32_t *outside, int32_t *culled);
 int pt_test_mesh_bvh(const float *tris, int ntris, int octant, uint32_t *nodes8, int *nnodes);
+/* certainMiss soundness for a mesh geom: `rays` pseudo-random rays dense in grazes of its bounding ball (origins 1/64 .. 64
+ * radii away); *violations = rays the bounding-ball test rejected although the walk hits (must be 0), *hits = rays that hit */
+int pt_test_mesh_cull_sweep(const PtGeom *geom, const float *tris, int ntris, uint64_t seed, int64_t rays, uint64_t *culled,
+                            uint64_t *violations, uint64_t *hits);
 /* slabQuotients (shared-reciprocal packed division of the box test) next to the compiler's correctly
  * rounded `/`: per-element outputs, and a device-side pseudo-random sweep that returns the number of
  * bit mismatches over `pairs` (o, d) pairs (must be 0). */

@@ -52,7 +52,7 @@ ABI_SYMBOLS = [
     "pt_test_intersect", "pt_test_hemisphere", "pt_test_sincos", "pt_test_reflect_refract",
     "pt_test_slab_quotients", "pt_test_slab_quotients_sweep", "pt_test_sphere_cull_sweep",
     "pt_test_unscaled_sqrt_sweep", "pt_pin_host", "pt_unpin_host", "pt_test_force_fault", "pt_test_pow", "pt_test_wall_box_sweep",
-    "pt_set_meshes", "pt_test_mesh_intersect", "pt_test_mesh_bvh",
+    "pt_set_meshes", "pt_test_mesh_intersect", "pt_test_mesh_bvh", "pt_test_mesh_cull_sweep",
 ]
 
 
@@ -128,6 +128,7 @@ def lib():
         L.pt_set_meshes.argtypes = [C.POINTER(PtMesh), i32]
         L.pt_test_mesh_intersect.argtypes = [vp, vp, i32, i32, vp, i32, vp, vp, vp, vp, vp]
         L.pt_test_mesh_bvh.argtypes = [vp, i32, i32, vp, C.POINTER(C.c_int)]
+        L.pt_test_mesh_cull_sweep.argtypes = [vp, vp, i32, C.c_uint64, i64] + [C.POINTER(C.c_uint64)] * 3
         _lib = L
     return _lib
 
@@ -379,6 +380,15 @@ def test_mesh_intersect(geom, tris, rays, flat=False, sentinel=-7.0):
     culled = np.zeros(n, np.int32)
     _check(lib().pt_test_mesh_intersect(_p(g), _p(tr), len(tr), 1 if flat else 0, _p(rays), n, _p(t), _p(p), _p(nn), _p(o), _p(culled)))
     return t, p, nn, o, culled
+
+
+def test_mesh_cull_sweep(geom, tris, seed, rays):
+    """Device sweep of the bounding-ball test of one mesh geom.  Returns (culled, violations, hits)."""
+    g = np.ascontiguousarray(geom).reshape(-1)[:1]
+    tr = np.ascontiguousarray(tris, np.float32).reshape(-1, 9)
+    c, v, h = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    _check(lib().pt_test_mesh_cull_sweep(_p(g), _p(tr), len(tr), seed, rays, C.byref(c), C.byref(v), C.byref(h)))
+    return c.value, v.value, h.value
 
 
 def mesh_bvh(tris, octant=0):

@@ -1345,6 +1345,45 @@ int pt_test_mesh_intersect(const PtGeom *geom, const float *tris, int ntris, int
     return PT_OK;
 }
 
+int pt_test_mesh_cull_sweep(const PtGeom *geom, const float *tris, int ntris, uint64_t seed, int64_t rays, uint64_t *culled,
+                            uint64_t *violations, uint64_t *hits) {
+    NEED_GPU();
+    if (!geom || !tris || ntris < 1 || geom->type != PT_MESH || !culled || !violations || !hits || rays < 0)
+        return fail(PT_ERR_INVALID, "pt_test_mesh_cull_sweep: bad argument");
+    std::vector<ptd::MeshNode> nodes;
+    std::vector<ptd::MeshTri> mt;
+    float box[6];
+    const uint32_t stride = ptm::appendMesh(tris, ntris, false, nodes, mt, box);
+    GeomDev hg;
+    pack_geom(*geom, hg, nullptr, box);
+    hg.meshRoot = 0;
+    hg.meshStride = stride;
+    if (!std::isfinite(hg.cullR2)) return fail(PT_ERR_INVALID, "pt_test_mesh_cull_sweep: this mesh is never culled");
+    DevBuf<GeomDev> dg;
+    DevBuf<ptd::MeshNode> dn_;
+    DevBuf<ptd::MeshTri> dtr;
+    DevBuf<unsigned long long> cnt;
+    UP(dg, &hg, 1);
+    UP(dn_, nodes.data(), nodes.size());
+    UP(dtr, mt.data(), mt.size());
+    int rc = cnt.alloc(3);
+    if (rc) return rc;
+    HIPCHECK(hipMemset(cnt.p, 0, 24));
+    const int per_thread = 64, threads = 256;
+    long long blocks = (rays + (long long)per_thread * threads - 1) / ((long long)per_thread * threads);
+    if (blocks < 1) blocks = 1;
+    if (blocks > (1 << 20)) blocks = 1 << 20;
+    hipLaunchKernelGGL(k_sweep_mesh_cull, dim3((unsigned)blocks), dim3(threads), 0, 0, dg.p, reinterpret_cast<const float4 *>(dn_.p),
+                       reinterpret_cast<const float4 *>(dtr.p), (unsigned long long)seed, per_thread, cnt.p, cnt.p + 1, cnt.p + 2);
+    HIPCHECK(hipDeviceSynchronize());
+    unsigned long long h[3] = {0, 0, 0};
+    HIPCHECK(hipMemcpy(h, cnt.p, 24, hipMemcpyDeviceToHost));
+    *culled = h[0];
+    *violations = h[1];
+    *hits = h[2];
+    return PT_OK;
+}
+
 // host only: no GPU is touched
 int pt_test_mesh_bvh(const float *tris, int ntris, int octant, uint32_t *nodes8, int *nnodes) {
     if (!tris || ntris < 1 || !nodes8 || !nnodes || octant < 0 || octant > 7) return fail(PT_ERR_INVALID, "pt_test_mesh_bvh: bad argument");

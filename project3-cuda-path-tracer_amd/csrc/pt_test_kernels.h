@@ -66,6 +66,40 @@ __global__ void k_test_mesh(const GeomDev *geom, const float4 *nodes, const floa
     n3[3 * i] = N.x; n3[3 * i + 1] = N.y; n3[3 * i + 2] = N.z;
     outside[i] = o ? 1 : 0;
 }
+// certainMiss soundness sweep for ONE mesh geom: rays as in k_sweep_sphere_cull (origins 1/64 .. 64 units from the bounding
+// ball's centre, aimed within ~1.3 radii of it: hits, grazes, near misses); a culled ray that the full walk hits is a violation
+__global__ void k_sweep_mesh_cull(const GeomDev *geom, const float4 *nodes, const float4 *tris, unsigned long long seed, int per_thread,
+                                  unsigned long long *culled, unsigned long long *violations, unsigned long long *hits) {
+    unsigned long long x = seed + (blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ull;
+    unsigned int nc = 0, nv = 0, nh = 0;
+    const GeomDev G = *geom;
+    const F3 c = f3(G.centre[0], G.centre[1], G.centre[2]);
+    const float R = __builtin_sqrtf(G.cullR2);
+    for (int k = 0; k < per_thread; ++k) {
+        float u[8];
+        for (int j = 0; j < 8; ++j) {
+            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+            u[j] = (float)(x >> 40) * (1.0f / 16777216.0f);
+        }
+        const float dist = R * __builtin_exp2f(u[0] * 12.0f - 6.0f);             // 1/64 .. 64 bounding radii
+        const F3 od = normalize(f3(u[1] - 0.5f, u[2] - 0.5f, u[3] - 0.5f));
+        const F3 org = c + od * dist;
+        const F3 tgt = c + f3(u[4] - 0.5f, u[5] - 0.5f, u[6] - 0.5f) * (2.6f * R);
+        F3 dir = normalize(tgt - org);
+        if (u[7] < 0.1f) dir = -dir;
+        const bool cull = certainMiss(G, org, dir, dot(dir, dir));
+        F3 P, N;
+        bool o;
+        // (every ray takes the walk: the hit count shows that the sweep does probe the mesh)
+        const float t = meshIntersectionTest(G, nodes, tris, G.meshRoot, G.meshStride, org, dir, P, N, o);
+        nc += cull ? 1u : 0u;
+        nh += t != -1.0f ? 1u : 0u;
+        nv += cull && t != -1.0f ? 1u : 0u;
+    }
+    if (nc) atomicAdd(culled, (unsigned long long)nc);
+    if (nv) atomicAdd(violations, (unsigned long long)nv);
+    if (nh) atomicAdd(hits, (unsigned long long)nh);
+}
 // certainMiss soundness sweep: pseudo-random rays (origins up to ~60 units away, aimed near the primitive's bounding
 // ball so that grazing cases are dense) against every primitive of `geoms`; counts culled rays and VIOLATIONS
 // (culled although the full test returns a hit).

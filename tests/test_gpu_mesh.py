@@ -99,6 +99,24 @@ def test_mesh_test_against_the_oracle_per_ray(gpu, oracle, flat):
     assert hits > 1500 and culled_total > 300
 
 
+def test_bounding_ball_never_rejects_a_mesh_hit(gpu, oracle):
+    """2^24 rays per case, dense in grazes of the bounding ball, origins 1/64 .. 64 radii away: the world-space test that
+    lets tiles skip a mesh (and classes the queue) never rejects a ray the full walk hits."""
+    sc = gpu.Scene(os.path.join(SCENES, "cornell_mesh.txt"))
+    cases = [(sc.geoms[g:g + 1], sc.meshes[g]) for g in sorted(sc.meshes)]
+    cases.append((oracle.make_geom(2, 0, (3, -2, 1), (25, 70, -40), (0.7, 2.5, 1.2)), sc.meshes[7]))     # anisotropic, rotated
+    cases.append((oracle.make_geom(2, 0, (0, 0, 0), (0, 0, 0), (1, 1, 1)), sc.meshes[6] + np.float32(20.0)))   # far off its origin
+    cases.append((oracle.make_geom(2, 0, (-4, 1, 2), (0, 45, 0), (40, 1.0, 40)), sc.meshes[6]))          # a 40:1 pancake
+    for k, (geom, tris) in enumerate(cases):
+        culled, violations, hits = gpu.test_mesh_cull_sweep(geom, tris, 565 + k, 1 << 24)
+        assert violations == 0, (k, violations)
+        assert hits > (1 << 24) // 50, (k, hits)
+        assert culled > (1 << 24) // (20 if k != 4 else 2000), (k, culled)      # (the pancake's margin term leaves little to cull)
+    # a transform too anisotropic for the test's margins switches the culling off altogether (never an unsound answer)
+    with pytest.raises(gpu.PtError):
+        gpu.test_mesh_cull_sweep(oracle.make_geom(2, 0, (0, 0, 0), (0, 0, 0), (40, 0.02, 40)), sc.meshes[6], 1, 1 << 10)
+
+
 def _render_both(gpu, oracle, sc, depth, iters, res, dump_bounces=(), rank=0, count=1, **extras):
     W, H = res
     ref = oracle.Renderer(sc.camera.view(oracle.CAMERA_DTYPE), sc.geoms.view(oracle.GEOM_DTYPE),
