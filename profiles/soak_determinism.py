@@ -8,7 +8,8 @@ import torch
 import __graft_entry__ as ge
 pt = ge.load_package()
 ref = None
-for scene_name, res, depth in (("cornell.txt", (1280, 720), 8), ("cornell_glass.txt", (960, 540), 16), ("spheres64.txt", (512, 512), 8)):
+for scene_name, res, depth in (("cornell.txt", (1280, 720), 8), ("cornell_glass.txt", (960, 540), 16), ("spheres64.txt", (512, 512), 8),
+                               ("cornell_mesh.txt", (640, 360), 8)):
     sc = pt.Scene(os.path.join(ROOT, "scenes", scene_name))
     sc.set_resolution(*res)
     digests = []

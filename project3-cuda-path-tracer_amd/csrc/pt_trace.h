@@ -631,14 +631,6 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? (FIRST ? 6 : 
                 const ArgsPtr A = launder(kargs);
                 const int ngeoms = A->prm.ngeoms;
                 const GeomPtr geoms = (GeomPtr)(A->ggeoms);
-                // camera rays of whole-tile rows: a wave is 64 consecutive pixels of one row, so a primitive's rectangle is
-                // tested against the WAVE's span in scalar registers; lanes are told apart only where the span straddles an edge
-                const bool rowWave = FIRST && !DOF && A->prm.wholeRowTiles != 0;
-                int wx0 = 0, wy = 0;
-                if (rowWave) {
-                    wx0 = __builtin_amdgcn_readfirstlane(px - (int)(tid & 63u));
-                    wy = __builtin_amdgcn_readfirstlane(py);
-                }
                 for (int g = 0; g < ngeoms; ++g) {
                     // (sphere-heavy scenes: no laundering per primitive -- with 70 of them the compiler's own scheduling of
                     // the scalar loads across iterations is worth more than the registers it costs; measured on C5)
@@ -651,15 +643,12 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? (FIRST ? 6 : 
                     // camera rays: only the lanes whose pixel lies in the primitive's rectangle take the test.  A predicate and a
                     // wave-uniform skip, not a per-lane `continue`: the loop over the primitives stays a scalar loop
                     bool inRect = true;
+                    // (testing the WAVE's pixel span against the rectangle in scalar registers instead -- a wave of whole-tile rows
+                    // is 64 consecutive pixels of one row -- saved 2 % of the vector instructions and cost 20 % more scalar ones:
+                    // 1.5 % slower, not kept)
                     if (FIRST && !DOF) {
-                        if (rowWave) {
-                            const int rx0 = G.rect[0], ry0 = G.rect[1], rx1 = G.rect[2], ry1 = G.rect[3];
-                            if (wy < ry0 || wy > ry1 || wx0 + 63 < rx0 || wx0 > rx1) continue;
-                            if (wx0 < rx0 || wx0 + 63 > rx1) inRect = (px >= rx0) & (px <= rx1);
-                        } else {
-                            inRect = (px >= G.rect[0]) & (px <= G.rect[2]) & (py >= G.rect[1]) & (py <= G.rect[3]);
-                            if (__ballot(inRect) == 0ull) continue;
-                        }
+                        inRect = (px >= G.rect[0]) & (px <= G.rect[2]) & (py >= G.rect[1]) & (py <= G.rect[3]);
+                        if (__ballot(inRect) == 0ull) continue;
                     }
                     if (!FIRST && !smallTile && (flags & 2)) continue;  // this tile's paths certainly miss every binned primitive
                     // ... and every wall but (at most) one
