@@ -236,3 +236,61 @@ def test_headless_driver_renders_a_mesh_scene(gpu, oracle, tmp_path):
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
         assert np.array_equal(_decode_png(base + ".png"), want)
+
+
+def _icosphere(subdiv, radius=0.5):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_scenes", os.path.join(SCENES, "make_scenes.py"))
+    ms = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ms)
+    v, f = ms.icosphere(subdiv, radius)
+    v = np.array(v, np.float32)
+    return np.array([np.concatenate([v[a], v[b], v[c]]) for a, b, c in f], np.float32)
+
+
+def test_scene_of_meshes_only_with_an_emissive_mesh(gpu, oracle):
+    """No cube, no sphere: the light is a mesh too (octant queue classes, no wall certificates, emitter inside the walk)."""
+    sc = gpu.Scene(os.path.join(SCENES, "mesh_small.txt"))
+    tris = _icosphere(1)
+    geoms = np.concatenate([oracle.make_geom(2, 0, (0, 6, 0), (0, 0, 0), (4, 1, 4)),            # emissive, flattened icosphere
+                            oracle.make_geom(2, 1, (0, 1.5, 0), (20, 40, 0), (3, 3, 3)),         # diffuse
+                            oracle.make_geom(2, 5, (2.5, 2.5, 1.5), (0, 0, 30), (2, 3, 2)),      # glass
+                            oracle.make_geom(2, 4, (-2.5, 2.0, 1.0), (0, 0, 0), (2, 2, 2))])     # mirror mix
+    sc.geoms = geoms.view(sc.geoms.dtype)
+    sc.meshes = {0: tris, 1: tris, 2: sc.meshes[4], 3: tris}
+    sc.set_resolution = None
+    got = _render_both(gpu, oracle, sc, 5, [1, 2, 3], (96, 96), dump_bounces=(1, 3))
+    assert (got > 0).mean() > 0.005      # (open space: most paths escape; the emitter itself and a few lucky bounces are lit)
+
+
+def test_twenty_thousand_triangles(gpu, oracle):
+    """A 20480-triangle icosphere: per-ray parity with the oracle's loop over every triangle, and a frame through the hierarchy
+    equal to the frame through the plain triangle list."""
+    tris = _icosphere(5)
+    assert tris.shape == (20480, 9)
+    geom = oracle.make_geom(2, 4, (-1, 4, -1), (10, 20, 30), (3, 2.5, 3))
+    rng = np.random.default_rng(2048)
+    rays = mesh_rays(rng, geom, tris, 384)
+    t, p, n, o, culled = gpu.test_mesh_intersect(geom, tris, rays)
+    hits = 0
+    for i in range(len(rays)):
+        wt, wp, wn, wo, _ = oracle.mesh_intersect(geom, tris, rays[i])
+        assert np.float32(t[i]).view(np.uint32) == np.float32(wt).view(np.uint32), (i, t[i], wt)
+        assert np.array_equal(p[i].view(np.uint32), wp.view(np.uint32)) and o[i] == wo
+        hits += wt > 0
+    assert hits > 150
+    sc = gpu.Scene(os.path.join(SCENES, "cornell_mesh.txt"))
+    sc.set_resolution(320, 240)
+    sc.meshes = {6: tris, 7: sc.meshes[7]}
+    frames = []
+    for flat in ("0", "1"):
+        os.environ["PT_AMD_MESH_FLAT"] = flat
+        try:
+            gpu.pathtraceFree()
+            gpu.pathtraceInit(sc, traceDepth=6, max_batch=2, pipeline_depth=2)
+            gpu.pathtrace_batch(None, 0, 1, 2)
+            frames.append(gpu.readback(320 * 240))
+        finally:
+            del os.environ["PT_AMD_MESH_FLAT"]
+            gpu.pathtraceFree()
+    assert frames[0].max() > 0 and np.array_equal(frames[0].view(np.uint32), frames[1].view(np.uint32))
