@@ -70,6 +70,7 @@ struct Slot {
     uint32_t gen[2] = {0, 0};      // per pool: serial number of the launch that filled it (tags the chunk-list entries)
     Ctrl *ctrl = nullptr;
     float *contrib = nullptr;      // maxBatch x W*H*3, zero between batches
+    uint32_t *hitMask = nullptr;   // ceil(maxBatch / 32) x W*H: which iterations of the batch wrote a pixel's `contrib`, zero between batches
     hipEvent_t evDone = nullptr;       // all bounce launches of the slot's current iteration finished
     hipEvent_t evCommitted = nullptr;  // k_commit consumed (and re-zeroed) `contrib`
     int parity = 0;                // which half of Ctrl::cursor the slot's next batch uses
@@ -430,7 +431,7 @@ int launch_bounce(Slot &sl, int iter, int batch, int depth, bool lastBounce, flo
     ba.iter = iter; ba.batch = batch; ba.depth = depth; ba.lastBounce = lastBounce ? 1 : 0; ba.parity = sl.parity;
     ba.genIn = genIn; ba.genOut = genOut;
     ba.in = in; ba.out = out;
-    ba.ctrl = sl.ctrl; ba.ggeoms = S.dgeoms; ba.gmats = S.dmats; ba.contrib = contrib;
+    ba.ctrl = sl.ctrl; ba.ggeoms = S.dgeoms; ba.gmats = S.dmats; ba.contrib = contrib; ba.hitMask = sl.hitMask;
     ba.walls = S.dwalls;
     ba.meshNodes = S.dMeshNodes; ba.meshTris = S.dMeshTris;
     void *kargs[] = {&ba};
@@ -581,6 +582,7 @@ void pt_free(void) {
         }
         if (sl.ctrl) (void)hipFree(sl.ctrl);
         if (sl.contrib) (void)hipFree(sl.contrib);
+        if (sl.hitMask) (void)hipFree(sl.hitMask);
         if (sl.evDone) (void)hipEventDestroy(sl.evDone);
         if (sl.evCommitted) (void)hipEventDestroy(sl.evCommitted);
         if (sl.stream) (void)hipStreamDestroy(sl.stream);
@@ -753,6 +755,8 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
         if (rcc) return rcc;
         HIPCHECK(hipMalloc(&sl.contrib, (size_t)S.maxBatch * S.P * 3 * sizeof(float)));
         HIPCHECK(hipMemset(sl.contrib, 0, (size_t)S.maxBatch * S.P * 3 * sizeof(float)));
+        HIPCHECK(hipMalloc(&sl.hitMask, (size_t)((S.maxBatch + 31) / 32) * S.P * sizeof(uint32_t)));
+        HIPCHECK(hipMemset(sl.hitMask, 0, (size_t)((S.maxBatch + 31) / 32) * S.P * sizeof(uint32_t)));
         HIPCHECK(hipEventCreateWithFlags(&sl.evDone, hipEventDisableTiming));
         HIPCHECK(hipEventCreateWithFlags(&sl.evCommitted, hipEventDisableTiming));
     }
@@ -941,7 +945,7 @@ int pt_iterate_batch(int frame, int first_iter, int count, void *rgba8_dev) {
     // commit on the caller's stream: commits are therefore ordered like the pt_iterate calls
     HIPCHECK(hipStreamWaitEvent(S.stream, sl.evDone, 0));
     if (S.nLocal > 0) {
-        hipLaunchKernelGGL(k_commit, dim3((S.nLocal + kBlock - 1) / kBlock), dim3(kBlock), 0, S.stream, S.prm, S.image, sl.contrib,
+        hipLaunchKernelGGL(k_commit, dim3((S.nLocal + kBlock - 1) / kBlock), dim3(kBlock), 0, S.stream, S.prm, S.image, sl.contrib, sl.hitMask,
                            count, (S.flags & PT_FLAG_ACCUM_SHARD_ROWS) ? 1 : 0);
         HIPCHECK(hipGetLastError());
     }

@@ -293,6 +293,7 @@ struct BounceArgs {
     const WallBox *walls;               // [prm.nWalls] inflated world-space boxes of the walls
     const float4 *meshNodes;            // MeshNode[] of every mesh of the scene (k_bounce<., ., ., true>), or nullptr
     const float4 *meshTris;             // MeshTri[]
+    uint32_t *hitMask;                  // [ceil(max_batch / 32)][W * H]: bit b of word w set = contrib[32 w + b][pix] was written
 };
 typedef const PT_CAS BounceArgs *ArgsPtr;
 typedef const PT_CAS GeomDev *GeomPtr;
@@ -722,8 +723,14 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? (FIRST ? 6 : 
                         // is parked in this iteration's own buffer (one path per pixel: race-free, no
                         // read) and k_commit adds it to the accumulator in iteration order.
                         const F3 c = (col * mcol) * M.emittance;
-                        float *dst = contrib + 3 * ((size_t)itb * ((size_t)A->prm.W * A->prm.H) + (size_t)pix);
+                        const size_t frame = (size_t)A->prm.W * A->prm.H;
+                        float *dst = contrib + 3 * ((size_t)itb * frame + (size_t)pix);
                         dst[0] = c.x; dst[1] = c.y; dst[2] = c.z;
+                        // ... and the pixel's mask says which iterations of the batch left something: k_commit then reads
+                        // 4 B per pixel and word instead of 12 B per pixel and iteration (one path per pixel and iteration: the
+                        // bits of a word come from different launches or lanes, hence the atomic; nobody waits for it)
+                        (void)__hip_atomic_fetch_or(A->hitMask + (size_t)(itb >> 5) * frame + (size_t)pix, 1u << (itb & 31), __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_AGENT);
                     }
                 } else if (!launder(kargs)->lastBounce) {        // S6 scatter (S7: skipped on the last bounce)
                     probe(10);
@@ -966,7 +973,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? (FIRST ? 6 : 
 // `compactRows`: the accumulator holds only this shard's rows (PT_FLAG_ACCUM_SHARD_ROWS), pixel j of the shard
 // at image[3j]; otherwise it is the full frame indexed by the global pixel index.
 // `batch` iterations were traced together; their radiance buffers are consumed in iteration order.
-__global__ __launch_bounds__(kBlock) void k_commit(KParams prm, float *image, float *contrib, int batch, int compactRows) {
+__global__ __launch_bounds__(kBlock) void k_commit(KParams prm, float *image, float *contrib, uint32_t *hitMask, int batch, int compactRows) {
     const int j = blockIdx.x * kBlock + threadIdx.x;
     if (j >= prm.nLocal) return;
     const int lr = j / prm.W;
@@ -974,15 +981,19 @@ __global__ __launch_bounds__(kBlock) void k_commit(KParams prm, float *image, fl
     const size_t pix = (size_t)x + (size_t)(lr * prm.shardCount + prm.shardRank) * prm.W;
     const size_t frame = (size_t)prm.W * prm.H;
     float *px = image + 3 * (compactRows ? (size_t)j : pix);
-    float ax = px[0], ay = px[1], az = px[2];
+    float ax = 0.0f, ay = 0.0f, az = 0.0f;
     bool dirty = false;
-    for (int b = 0; b < batch; ++b) {
-        float *c = contrib + 3 * ((size_t)b * frame + pix);
-        const float cx = c[0], cy = c[1], cz = c[2];
-        if (cx != 0.0f || cy != 0.0f || cz != 0.0f) {
-            ax += cx; ay += cy; az += cz;
+    for (int w = 0; w * 32 < batch; ++w) {
+        uint32_t m = hitMask[(size_t)w * frame + pix];
+        if (m == 0u) continue;
+        hitMask[(size_t)w * frame + pix] = 0u;
+        if (!dirty) { ax = px[0]; ay = px[1]; az = px[2]; dirty = true; }
+        while (m) {                                            // ascending bits = iteration order
+            const int b = w * 32 + __builtin_ctz(m);
+            m &= m - 1u;
+            float *c = contrib + 3 * ((size_t)b * frame + pix);
+            ax += c[0]; ay += c[1]; az += c[2];
             c[0] = 0.0f; c[1] = 0.0f; c[2] = 0.0f;
-            dirty = true;
         }
     }
     if (dirty) { px[0] = ax; px[1] = ay; px[2] = az; }
