@@ -461,10 +461,12 @@ __device__ __forceinline__ float boxIntersectionTest(const GD &g, F3 ro, F3 rd, 
 // NaN / inf operands fail the comparison, i.e. fall through to the full test.
 template <typename GD>
 __device__ __forceinline__ bool certainMiss(const GD &g, F3 org, F3 dir, float dd) {
+    // (fused multiply-adds on purpose: this is a sufficient condition with margins of 1e-3 / 1e-4, not one of the reference's
+    // operations -- 14 instructions instead of 20, and sphere-heavy scenes run it seventy times per tile)
     const F3 oc = org - f3(g.centre[0], g.centre[1], g.centre[2]);
-    const float oo = dot(oc, oc);
-    const float od = dot(oc, dir);
-    return oo * dd - od * od > (g.cullR2 + g.cullK * oo) * dd;
+    const float oo = __builtin_fmaf(oc.z, oc.z, __builtin_fmaf(oc.y, oc.y, oc.x * oc.x));
+    const float od = __builtin_fmaf(oc.z, dir.z, __builtin_fmaf(oc.y, dir.y, oc.x * dir.x));
+    return __builtin_fmaf(oo, dd, -(od * od)) > __builtin_fmaf(g.cullK, oo, g.cullR2) * dd;
 }
 
 // Certain miss of a LARGE cube (a "wall"), decided in world space against its axis-aligned bounding box for ~25
@@ -487,6 +489,9 @@ struct WallBox {
 static_assert(sizeof(WallBox) == 32, "one s_load_dwordx8");
 template <typename WB>
 __device__ __forceinline__ bool wallCertainMiss(const WB &w, F3 o, F3 inv) {
+    // (subtract, then multiply -- NOT fma(plane, inv, -(o * inv)): with a direction component of 0 the reciprocal is infinite
+    // and that form is inf - inf = NaN on EVERY plane of the axis, which min / max silently drop: the sweep below found false
+    // certificates for axis-parallel rays at once.  Here such an axis gives +-inf, or NaN only for an origin on the plane.)
     const float tx1 = (w.lo[0] - o.x) * inv.x, tx2 = (w.hi[0] - o.x) * inv.x;
     const float ty1 = (w.lo[1] - o.y) * inv.y, ty2 = (w.hi[1] - o.y) * inv.y;
     const float tz1 = (w.lo[2] - o.z) * inv.z, tz2 = (w.hi[2] - o.z) * inv.z;
