@@ -93,6 +93,8 @@ struct State {
     GeomDev *dgeoms = nullptr;
     MaterialDev *dmats = nullptr;
     WallBox *dwalls = nullptr;
+    SphereCull *dSphCull = nullptr; // sphere-heavy scenes: packed culling data of the spheres, and ...
+    int *dOtherIdx = nullptr;       // ... the indices of the other primitives (k_bounce<false, true, ...>)
     float4 *dMeshNodes = nullptr;   // ptd::MeshNode[] / MeshTri[] of every mesh of the scene (k_bounce<., ., ., true>)
     float4 *dMeshTris = nullptr;
     bool mesh = false;      // the scene holds triangle meshes: the k_bounce<., false, ., true> variants
@@ -432,6 +434,7 @@ int launch_bounce(Slot &sl, int iter, int batch, int depth, bool lastBounce, flo
     ba.genIn = genIn; ba.genOut = genOut;
     ba.in = in; ba.out = out;
     ba.ctrl = sl.ctrl; ba.ggeoms = S.dgeoms; ba.gmats = S.dmats; ba.contrib = contrib; ba.hitMask = sl.hitMask;
+    ba.sphCull = S.dSphCull; ba.otherIdx = S.dOtherIdx;
     ba.walls = S.dwalls;
     ba.meshNodes = S.dMeshNodes; ba.meshTris = S.dMeshTris;
     void *kargs[] = {&ba};
@@ -592,6 +595,8 @@ void pt_free(void) {
     if (S.dgeoms) (void)hipFree(S.dgeoms);
     if (S.dmats) (void)hipFree(S.dmats);
     if (S.dwalls) (void)hipFree(S.dwalls);
+    if (S.dSphCull) (void)hipFree(S.dSphCull);
+    if (S.dOtherIdx) (void)hipFree(S.dOtherIdx);
     if (S.dMeshNodes) (void)hipFree(S.dMeshNodes);
     if (S.dMeshTris) (void)hipFree(S.dMeshTris);
     S = State();
@@ -874,6 +879,36 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     for (int i = 0; i < ngeoms; ++i) nspheres += geoms[i].type == PT_SPHERE;
     S.many = nspheres > kBinMax && !S.mesh;     // (the mesh variants test every sphere in place)
     if (S.many && ngeoms > 65535) return fail(PT_ERR_INVALID, "pt_init: more than 65535 primitives");
+    if (S.many) {        // the later bounces take the spheres from a packed copy of their culling data (ptk::SphereCull)
+        std::vector<SphereCull> sc;
+        std::vector<int> other;
+        for (int i = 0; i < ngeoms; ++i) {
+            if (geoms[i].type == PT_SPHERE) {
+                SphereCull e;
+                memset(&e, 0, sizeof e);
+                for (int a = 0; a < 3; ++a) e.centre[a] = hg[i].centre[a];
+                e.cullR2 = hg[i].cullR2;
+                e.cullK = hg[i].cullK;
+                e.geom = i;
+                sc.push_back(e);
+            } else {
+                other.push_back(i);
+            }
+        }
+        if (sc.size() % 2) {
+            SphereCull e;
+            memset(&e, 0, sizeof e);
+            e.geom = -1;
+            sc.push_back(e);
+        }
+        k.nSphCull = (int)sc.size();
+        k.nOther = (int)other.size();
+        if (other.empty()) other.push_back(0);
+        HIPCHECK(hipMalloc(&S.dSphCull, sc.size() * sizeof(SphereCull)));
+        HIPCHECK(hipMemcpy(S.dSphCull, sc.data(), sc.size() * sizeof(SphereCull), hipMemcpyHostToDevice));
+        HIPCHECK(hipMalloc(&S.dOtherIdx, other.size() * sizeof(int)));
+        HIPCHECK(hipMemcpy(S.dOtherIdx, other.data(), other.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
     S.ldsBytes = sizeof(MaterialDev) * nmats + sizeof(GeomHitDev) * ngeoms + kMiscWords * sizeof(uint32_t) +
                  (S.many ? (size_t)ngeoms * kSphRowFloats * sizeof(float) + (size_t)kListMax * kBlock * sizeof(uint16_t) : 0);
     if (S.ldsBytes > 160 * 1024) return fail(PT_ERR_INVALID, "pt_init: scene does not fit the 160 KiB LDS (%zu B)", S.ldsBytes);

@@ -3,6 +3,8 @@
 // Header-only part of the single translation unit pt_api.hip (namespace ptk).
 #pragma once
 #include "../../include/pt_amd.h"
+#include <type_traits>
+
 #include "pt_common.h"
 #include "pt_device.h"
 
@@ -84,6 +86,8 @@ struct KParams {
     int   directDepth;                 // direct lighting (README.md:107-108): the bounce whose diffuse scatter aims at a light
                                        // (= the scene's trace depth; traceDepth is then one more: the bounce that collects); 0 = off
     int   nEmit;                       // emissive primitives the direct-lighting bounce samples, at most kEmitMax (file order)
+    int   nSphCull;                    // sphere-heavy scenes: entries of BounceArgs::sphCull (even: padded with geom = -1)
+    int   nOther;                      // ... and of BounceArgs::otherIdx
     int   emitGeom[kEmitMax];
     float emitRho2[kEmitMax];          // |scale|^2 / 4 of each: squared radius of its bounding ball
 };
@@ -281,6 +285,18 @@ __device__ __forceinline__ uint32_t waveSum(uint32_t v) {
 // kernarg segment through a laundered constant-address-space pointer (see launder() in pt_device.h): a field then lives
 // in SGPRs from the s_load of the phase that uses it to its last use there, instead of from the kernel's entry to its
 // end (the compiler hoists kernel arguments and everything derived from them out of the tile loop and then spills).
+// Sphere-heavy scenes, later bounces: the bounding-ball data of every sphere, packed (two per 64-byte scalar load instead of
+// one 32-byte load out of a 448-byte GeomDev per loop iteration -- the scalar cache's round trip per primitive was the
+// critical path of the loop over seventy of them).
+struct SphereCull {
+    float centre[3];
+    float cullR2, cullK;
+    int   geom;          // index of the sphere among the scene's primitives; -1: padding
+    int   pad[2];
+};
+static_assert(sizeof(SphereCull) == 32, "two per s_load_dwordx16");
+typedef int int16v __attribute__((ext_vector_type(16)));
+
 struct BounceArgs {
     KParams prm;
     int iter, batch, depth, lastBounce, parity;
@@ -294,6 +310,8 @@ struct BounceArgs {
     const float4 *meshNodes;            // MeshNode[] of every mesh of the scene (k_bounce<., ., ., true>), or nullptr
     const float4 *meshTris;             // MeshTri[]
     uint32_t *hitMask;                  // [ceil(max_batch / 32)][W * H]: bit b of word w set = contrib[32 w + b][pix] was written
+    const SphereCull *sphCull;          // sphere-heavy scenes (k_bounce<false, true, ...>): the spheres' culling data, packed
+    const int *otherIdx;                // ... and the indices of the primitives that are not spheres, file order
 };
 typedef const PT_CAS BounceArgs *ArgsPtr;
 typedef const PT_CAS GeomDev *GeomPtr;
@@ -628,11 +646,16 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? (FIRST ? 6 : 
                 s_sph = S_SPH(A->prm.nmats, A->prm.ngeoms);
                 s_list = reinterpret_cast<uint16_t *>(s_sph + (size_t)A->prm.ngeoms * kSphRowFloats);
             }
+            // Sphere-heavy scenes, later bounces: the spheres come from their packed culling data (order does not matter: the
+            // nearest hit is taken by (distance, file order)), AFTER the loop over the primitives that are not spheres.
+            constexpr bool PACKED = MANY && !FIRST;
             if (inScene) {
                 const ArgsPtr A = launder(kargs);
-                const int ngeoms = A->prm.ngeoms;
+                const int ngeoms = PACKED ? A->prm.nOther : A->prm.ngeoms;
                 const GeomPtr geoms = (GeomPtr)(A->ggeoms);
-                for (int g = 0; g < ngeoms; ++g) {
+                const PT_CAS int *otherIdx = (const PT_CAS int *)(A->otherIdx);
+                for (int gk = 0; gk < ngeoms; ++gk) {
+                    const int g = PACKED ? otherIdx[gk] : gk;
                     // (sphere-heavy scenes: no laundering per primitive -- with 70 of them the compiler's own scheduling of
                     // the scalar loads across iterations is worth more than the registers it costs; measured on C5)
                     const PT_CAS GeomDev &G = *((MANY ? geoms : launder(geoms)) + g);
@@ -662,7 +685,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? (FIRST ? 6 : 
                             const ArgsPtr A2 = launder(kargs);
                             t = meshIntersectionTest<FIRST && !DOF>(G, A2->meshNodes, A2->meshTris, G.meshRoot, G.meshStride, org, dir, p, n, o);
                         }
-                    } else if ((flags & 1) == 0) {
+                    } else if (!PACKED && (flags & 1) == 0) {          // (PACKED: no sphere comes this way)
                         probe(3);
                         if (!certainMiss(cg, org, dir, dd)) {
                             if (MANY && nCand < kListMax) {
@@ -675,12 +698,14 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? (FIRST ? 6 : 
                     } else {
                         t = boxIntersectionTest<true, FIRST && !DOF>(G, org, dir, p, n, o);
                     }
-                    if (t > 0.0f && (hit < 0 || t < tbest)) {
+                    // (PACKED: a sphere tested in place above may hold the record with a higher index: file order decides a tie)
+                    if (t > 0.0f && (hit < 0 || t < tbest || (PACKED && t == tbest && g < hit))) {
                         tbest = t; hit = g; P = p; nsrc = n; outsideI = o ? 1 : 0;
                     }
                 }
             }
-            if (MANY) {
+            // the spheres a lane recorded: pass k tests every lane's k-th sphere with that lane's own matrices from LDS
+            auto candidatePass = [&]() {
                 for (int k = 0; __ballot(k < nCand) != 0ull; ++k) {          // wave-uniform trip count
                     if (k < nCand) {
                         const int g = s_list[k * kBlock + tid];
@@ -700,6 +725,47 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? (FIRST ? 6 : 
                             tbest = t; hit = g; P = p; nsrc = n; outsideI = o ? 1 : 0;
                         }
                     }
+                }
+            };
+            if (MANY && !PACKED) candidatePass();
+            if (PACKED) {
+                // Rounds: a lane records up to kListMax spheres per round; one that meets more resumes, in the next round, at
+                // the first sphere it could not record (rare: rays through a dense cluster).  Two spheres per 64-byte scalar load.
+                const ArgsPtr A = launder(kargs);
+                const int nS = A->prm.nSphCull;
+                const PT_CAS SphereCull *sc = (const PT_CAS SphereCull *)(A->sphCull);
+                int resume = 0;
+                auto sweep = [&](auto firstRound) {
+                    constexpr bool kFirstRound = decltype(firstRound)::value;
+                    nCand = 0;
+                    int over = -1;
+                    for (int k = 0; k < nS; k += 2) {
+                        int16v v;
+                        asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(sc + k) : "memory");
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            CullGroup cg;
+                            cg.centre[0] = __int_as_float(v[8 * h]); cg.centre[1] = __int_as_float(v[8 * h + 1]); cg.centre[2] = __int_as_float(v[8 * h + 2]);
+                            cg.cullR2 = __int_as_float(v[8 * h + 3]); cg.cullK = __int_as_float(v[8 * h + 4]);
+                            const int g = v[8 * h + 5];
+                            if (g < 0) continue;                     // padding
+                            probe(3);
+                            if ((kFirstRound || k + h >= resume) && !certainMiss(cg, org, dir, dd)) {
+                                if (nCand < kListMax) {
+                                    s_list[nCand * kBlock + tid] = (uint16_t)g;
+                                    ++nCand;
+                                } else if (over < 0) {
+                                    over = k + h;
+                                }
+                            }
+                        }
+                    }
+                    candidatePass();
+                    resume = over < 0 ? 0x7fffffff : over;          // (a lane that recorded everything takes no further part)
+                    return __ballot(over >= 0) != 0ull;
+                };
+                if (inScene && sweep(std::true_type{})) {
+                    while (sweep(std::false_type{})) {}
                 }
             }
             if (hit < 0) {
