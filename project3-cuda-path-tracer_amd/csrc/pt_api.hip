@@ -94,7 +94,7 @@ struct State {
     MaterialDev *dmats = nullptr;
     WallBox *dwalls = nullptr;
     SphereCull *dSphCull = nullptr; // sphere-heavy scenes: packed culling data of the spheres, and ...
-    int *dOtherIdx = nullptr;       // ... the indices of the other primitives (k_bounce<false, true, ...>)
+    int *dClassIdx = nullptr;       // later bounces: per queue class, the primitives to look at (KParams::classOff)
     float4 *dMeshNodes = nullptr;   // ptd::MeshNode[] / MeshTri[] of every mesh of the scene (k_bounce<., ., ., true>)
     float4 *dMeshTris = nullptr;
     bool mesh = false;      // the scene holds triangle meshes: the k_bounce<., false, ., true> variants
@@ -434,7 +434,7 @@ int launch_bounce(Slot &sl, int iter, int batch, int depth, bool lastBounce, flo
     ba.genIn = genIn; ba.genOut = genOut;
     ba.in = in; ba.out = out;
     ba.ctrl = sl.ctrl; ba.ggeoms = S.dgeoms; ba.gmats = S.dmats; ba.contrib = contrib; ba.hitMask = sl.hitMask;
-    ba.sphCull = S.dSphCull; ba.otherIdx = S.dOtherIdx;
+    ba.sphCull = S.dSphCull; ba.classIdx = S.dClassIdx;
     ba.walls = S.dwalls;
     ba.meshNodes = S.dMeshNodes; ba.meshTris = S.dMeshTris;
     void *kargs[] = {&ba};
@@ -596,7 +596,7 @@ void pt_free(void) {
     if (S.dmats) (void)hipFree(S.dmats);
     if (S.dwalls) (void)hipFree(S.dwalls);
     if (S.dSphCull) (void)hipFree(S.dSphCull);
-    if (S.dOtherIdx) (void)hipFree(S.dOtherIdx);
+    if (S.dClassIdx) (void)hipFree(S.dClassIdx);
     if (S.dMeshNodes) (void)hipFree(S.dMeshNodes);
     if (S.dMeshTris) (void)hipFree(S.dMeshTris);
     S = State();
@@ -881,8 +881,7 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     if (S.many && ngeoms > 65535) return fail(PT_ERR_INVALID, "pt_init: more than 65535 primitives");
     if (S.many) {        // the later bounces take the spheres from a packed copy of their culling data (ptk::SphereCull)
         std::vector<SphereCull> sc;
-        std::vector<int> other;
-        for (int i = 0; i < ngeoms; ++i) {
+        for (int i = 0; i < ngeoms; ++i)
             if (geoms[i].type == PT_SPHERE) {
                 SphereCull e;
                 memset(&e, 0, sizeof e);
@@ -891,10 +890,7 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
                 e.cullK = hg[i].cullK;
                 e.geom = i;
                 sc.push_back(e);
-            } else {
-                other.push_back(i);
             }
-        }
         if (sc.size() % 2) {
             SphereCull e;
             memset(&e, 0, sizeof e);
@@ -902,12 +898,28 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
             sc.push_back(e);
         }
         k.nSphCull = (int)sc.size();
-        k.nOther = (int)other.size();
-        if (other.empty()) other.push_back(0);
         HIPCHECK(hipMalloc(&S.dSphCull, sc.size() * sizeof(SphereCull)));
         HIPCHECK(hipMemcpy(S.dSphCull, sc.data(), sc.size() * sizeof(SphereCull), hipMemcpyHostToDevice));
-        HIPCHECK(hipMalloc(&S.dOtherIdx, other.size() * sizeof(int)));
-        HIPCHECK(hipMemcpy(S.dOtherIdx, other.data(), other.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+    {   // Later bounces: which primitives a tile of queue class c looks at.  Class bit 3 = its paths may hit a binned primitive;
+        // bits 0-2 in a scene with walls = the one wall they can still hit (6: any, 7: none), else the direction octant.
+        std::vector<int> idx;
+        for (int c = 0; c < kCls; ++c) {
+            k.classOff[c] = (int)idx.size();
+            const bool small = (c & 8) != 0;
+            const int wall = k.nWalls > 0 ? (c & 7) : 6;
+            for (int i = 0; i < ngeoms; ++i) {
+                if (S.many && geoms[i].type == PT_SPHERE) continue;            // swept from their packed culling data
+                if (hg[i].binned && !small) continue;
+                const int w = (hg[i].flags >> 2) & 7;                          // 1 + index among the walls, 0: not one
+                if (w != 0 && wall != 6 && w != wall + 1) continue;
+                idx.push_back(i);
+            }
+        }
+        k.classOff[kCls] = (int)idx.size();
+        if (idx.empty()) idx.push_back(0);
+        HIPCHECK(hipMalloc(&S.dClassIdx, idx.size() * sizeof(int)));
+        HIPCHECK(hipMemcpy(S.dClassIdx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
     }
     S.ldsBytes = sizeof(MaterialDev) * nmats + sizeof(GeomHitDev) * ngeoms + kMiscWords * sizeof(uint32_t) +
                  (S.many ? (size_t)ngeoms * kSphRowFloats * sizeof(float) + (size_t)kListMax * kBlock * sizeof(uint16_t) : 0);

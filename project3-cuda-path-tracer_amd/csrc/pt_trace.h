@@ -87,7 +87,9 @@ struct KParams {
                                        // (= the scene's trace depth; traceDepth is then one more: the bounce that collects); 0 = off
     int   nEmit;                       // emissive primitives the direct-lighting bounce samples, at most kEmitMax (file order)
     int   nSphCull;                    // sphere-heavy scenes: entries of BounceArgs::sphCull (even: padded with geom = -1)
-    int   nOther;                      // ... and of BounceArgs::otherIdx
+    int   classOff[kCls + 1];          // later bounces: the primitives a tile of class c has to look at are classIdx[classOff[c] ..
+                                       // classOff[c + 1]) (BounceArgs::classIdx): not the binned ones unless the class says so, of the walls only
+                                       // the class's own, in sphere-heavy scenes no sphere (those come from sphCull)
     int   emitGeom[kEmitMax];
     float emitRho2[kEmitMax];          // |scale|^2 / 4 of each: squared radius of its bounding ball
 };
@@ -311,7 +313,7 @@ struct BounceArgs {
     const float4 *meshTris;             // MeshTri[]
     uint32_t *hitMask;                  // [ceil(max_batch / 32)][W * H]: bit b of word w set = contrib[32 w + b][pix] was written
     const SphereCull *sphCull;          // sphere-heavy scenes (k_bounce<false, true, ...>): the spheres' culling data, packed
-    const int *otherIdx;                // ... and the indices of the primitives that are not spheres, file order
+    const int *classIdx;                // later bounces: per queue class, the indices of the primitives to look at, file order (KParams::classOff)
 };
 typedef const PT_CAS BounceArgs *ArgsPtr;
 typedef const PT_CAS GeomDev *GeomPtr;
@@ -455,8 +457,8 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? (FIRST ? 6 : 
     struct TileMeta {
         bool valid;                         // this lane holds a path
         uint32_t idx;                       // its slot in the input pool
-        bool smallTile;                     // wave-uniform: this tile's paths may hit a small (binned) primitive
-        uint32_t tileWall;                  // wave-uniform: the one wall this tile's paths can hit (0..5), 6: any, 7: none
+        uint32_t cls;                       // wave-uniform: the tile's queue class: bit 3 = its paths may hit a binned primitive; bits 0-2 in a
+                                            // scene with walls = the one wall they can still hit (6: any, 7: none), else the direction octant
     };
     struct PathRegs { F3 org, dir, col; int pix, packed; };
     // tile T of the queue -> its segment, class and the lane's slot; false: the tile needs no work at all
@@ -467,11 +469,10 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? (FIRST ? 6 : 
         sgIn = (uint32_t)__builtin_amdgcn_readfirstlane((int)sgIn);
         const uint32_t local = (T - s_segpre[sgIn]) * kBlock + tid;
         m.valid = local < s_segcnt[sgIn];
-        m.smallTile = ((sgIn / kSub) & 8u) != 0u;
-        m.tileWall = A->prm.nWalls > 0 ? (sgIn / kSub) & 7u : 6u;
+        m.cls = sgIn / kSub;
         // The last bounce only asks whether a path ends on an emitter (S7: no scatter).  When every emitter of the scene
         // is a binned small primitive, the paths of a non-candidate tile certainly miss all of them: nothing to add.
-        if (A->lastBounce && A->prm.emittersBinned && !m.smallTile) return false;
+        if (A->lastBounce && A->prm.emittersBinned && (m.cls & 8u) == 0u) return false;
         // the tile's chunk (a chunk is a multiple of the tile size): j-th chunk of the segment, wave-uniform lookup
         // (entries were written by the previous launch; the 0-th chunk of a segment is static)
         const uint32_t shift = (uint32_t)A->prm.chunkShift, poolChunks = (uint32_t)A->prm.poolChunks;
@@ -502,7 +503,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? (FIRST ? 6 : 
     };
     // the first tile of this workgroup that needs work, and its paths
     uint32_t T = blockIdx.x;
-    TileMeta nextMeta = {false, 0u, true, 6u};
+    TileMeta nextMeta = {false, 0u, 0u};
     PathRegs nextRegs = {f3(0, 0, 0), f3(0, 0, 1), f3(0, 0, 0), 0, 0};
     if (!FIRST) {
         while (T < numTiles && !setupTile(T, threadIdx.x, nextMeta)) T += gridDim.x;
@@ -517,8 +518,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? (FIRST ? 6 : 
         uint32_t Tnext = T + gridDim.x;     // FIRST: simply the next one
         bool valid;
         uint32_t idx = 0;
-        bool smallTile = true;              // wave-uniform: this tile's paths may hit a small (binned) primitive
-        uint32_t tileWall = 6u;             // wave-uniform: the one wall this tile's paths can hit (0..5), 6: any, 7: none
+        uint32_t tileCls = 0u;              // wave-uniform: the tile's queue class (later bounces)
         PathRegs cur = nextRegs;
         int itb = 0;                                            // which iteration of the batch this path belongs to
         int px = 0, py = 0;                                     // pixel coordinates (FIRST only)
@@ -563,8 +563,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? (FIRST ? 6 : 
         } else {
             valid = nextMeta.valid;
             idx = nextMeta.idx;
-            smallTile = nextMeta.smallTile;
-            tileWall = nextMeta.tileWall;
+            tileCls = nextMeta.cls;
         }
 
         // (per-lane flags that are set deep inside the divergent code and read after it are ints: as bools they would live in
@@ -651,11 +650,12 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? (FIRST ? 6 : 
             constexpr bool PACKED = MANY && !FIRST;
             if (inScene) {
                 const ArgsPtr A = launder(kargs);
-                const int ngeoms = PACKED ? A->prm.nOther : A->prm.ngeoms;
+                // camera rays look at every primitive (their pixel rectangles sort them out); a later tile at the list of its class
+                const int gk0 = FIRST ? 0 : A->prm.classOff[tileCls], gk1 = FIRST ? A->prm.ngeoms : A->prm.classOff[tileCls + 1u];
                 const GeomPtr geoms = (GeomPtr)(A->ggeoms);
-                const PT_CAS int *otherIdx = (const PT_CAS int *)(A->otherIdx);
-                for (int gk = 0; gk < ngeoms; ++gk) {
-                    const int g = PACKED ? otherIdx[gk] : gk;
+                const PT_CAS int *classIdx = (const PT_CAS int *)(A->classIdx);
+                for (int gk = gk0; gk < gk1; ++gk) {
+                    const int g = FIRST ? gk : classIdx[gk];
                     // (sphere-heavy scenes: no laundering per primitive -- with 70 of them the compiler's own scheduling of
                     // the scalar loads across iterations is worth more than the registers it costs; measured on C5)
                     const PT_CAS GeomDev &G = *((MANY ? geoms : launder(geoms)) + g);
@@ -674,9 +674,8 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? (FIRST ? 6 : 
                         inRect = (px >= G.rect[0]) & (px <= G.rect[2]) & (py >= G.rect[1]) & (py <= G.rect[3]);
                         if (__ballot(inRect) == 0ull) continue;
                     }
-                    if (!FIRST && !smallTile && (flags & 2)) continue;  // this tile's paths certainly miss every binned primitive
-                    // ... and every wall but (at most) one
-                    if (!FIRST && tileWall != 6u && (flags & 28) != 0 && (uint32_t)((flags >> 2) & 7) != tileWall + 1u) continue;
+                    // (later bounces: the class's list holds no binned primitive its paths certainly miss, and of the walls only
+                    // the one they can still hit)
                     if (!inRect) {
                         // (not reachable from this pixel: t stays -1)
                     } else if (MESH && (flags & 32) != 0) {
