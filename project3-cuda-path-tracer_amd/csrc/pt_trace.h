@@ -656,8 +656,9 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? (FIRST ? 6 : 
                 const PT_CAS int *classIdx = (const PT_CAS int *)(A->classIdx);
                 for (int gk = gk0; gk < gk1; ++gk) {
                     const int g = FIRST ? gk : classIdx[gk];
-                    // (sphere-heavy scenes: no laundering per primitive -- with 70 of them the compiler's own scheduling of
-                    // the scalar loads across iterations is worth more than the registers it costs; measured on C5)
+                    // (sphere-heavy scenes: no laundering per primitive -- the camera-ray bounce still walks all seventy of them,
+                    // and the compiler's own scheduling of the scalar loads across iterations is worth more than the registers
+                    // it costs; measured on C5)
                     const PT_CAS GeomDev &G = *((MANY ? geoms : launder(geoms)) + g);
                     const CullGroup cg = loadCull<MANY>(&G);
                     const int flags = cg.cullFlags;
