@@ -63,8 +63,8 @@ typedef enum PtStatus {
     PT_ERR_INVALID = -1,      /* bad argument */
     PT_ERR_NOT_INIT = -2,     /* pt_iterate & co. before pt_init */
     PT_ERR_HIP = -3,          /* a HIP runtime call failed (replaces checkCUDAError, pathtrace.cu:21-39) */
-    PT_ERR_DEVICE = -4,       /* a kernel reported an internal fault (path pool exhausted, chunk-list or scan look-back
-                                 timeout): sticky, reported by pt_sync / pt_counters (and the next scan call); results void */
+    PT_ERR_DEVICE = -4,       /* a kernel reported an internal fault (path pool exhausted, chunk-list timeout): sticky,
+                                 reported by pt_sync / pt_counters; results void */
     PT_ERR_NO_GPU = -5        /* no HIP device: there is NO CPU fallback */
 } PtStatus;
 
@@ -163,7 +163,7 @@ int pt_iterate(int frame, int iter, void *rgba8_dev /* may be NULL (headless) */
 int pt_iterate_batch(int frame, int first_iter, int count, void *rgba8_dev);
 
 /* Wait for every stream the renderer uses; reports device-side faults (PT_ERR_DEVICE).  (checkCUDAError's sync,
- * pathtrace.cu:23.)  Without a renderer it reports the scan library's sticky fault word. */
+ * pathtrace.cu:23.)  Without a renderer it waits for the scan library's work on every stream. */
 int pt_sync(void);
 
 /* Copy the un-normalised running sum (W*H*3 floats, index = x + y*W) to host: the D2H copy of
@@ -199,9 +199,9 @@ int pt_debug_trace_paths(int iter, int bounces, float *origin3, float *dir3, flo
                          int32_t *pixelIndex, int32_t *count);
 
 /* ---- stream compaction library (the reference's empty stream_compaction/ stub, README.md:83-86):
- * work-efficient exclusive scan / compaction over DEVICE buffers, multi-block, any n >= 0.  Asynchronous on `stream`;
- * calls on different streams use separate workspaces and may overlap.  A look-back timeout sets a sticky fault word:
- * the next call on that stream and pt_sync return PT_ERR_DEVICE. ---------- */
+ * work-efficient exclusive scan / compaction over DEVICE buffers, multi-block, any n >= 0 (compaction: n < 2^32).
+ * Reduce-then-scan over at most 2048 chunks: three launches on `stream`, asynchronous, no workgroup waits for another;
+ * calls on different streams use separate workspaces and may overlap.  Sums wrap modulo 2^32 like int32 arithmetic. ---------- */
 int pt_scan_exclusive_i32(const int32_t *in_dev, int32_t *out_dev, int64_t n, void *stream);
 /* keeps the non-zero elements in order; *count_dev (device) receives how many were kept */
 int pt_compact_nonzero_i32(const int32_t *in_dev, int32_t *out_dev, int64_t n, int64_t *count_dev,
@@ -246,8 +246,7 @@ int pt_test_slab_quotients_sweep(uint64_t seed, int64_t pairs, uint64_t *mismatc
  * (the re-normalisation of getPointOnRay) next to 1.0f / sqrtf on every bit pattern: mismatches[0] and [2] must be 0,
  * [1] = patterns inside sqrtUnscaled's range, [3] = patterns on inverseSqrtNearOne's short path (513). */
 int pt_test_unscaled_sqrt_sweep(uint64_t mismatches[4]);
-/* sets a device fault word by hand (1: the scan library's, 2: the renderer's; 0 clears them all), so that the reporting
- * path can be tested */
+/* sets the renderer's device fault word by hand (2; 0 clears it in every slot), so that the reporting path can be tested */
 int pt_test_force_fault(int which);
 int pt_test_hemisphere(const float *normals3, const int32_t *iter_index_depth3, int n, float *out3);
 int pt_test_sincos(const float *x, int n, float *s, float *c);

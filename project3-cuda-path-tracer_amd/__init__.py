@@ -280,7 +280,7 @@ def sync():
 
 
 def force_fault(which):
-    """Diagnostics: set a device fault word by hand (1 = scan library, 2 = renderer)."""
+    """Diagnostics: set the renderer's device fault word by hand (2), or clear it (0)."""
     _check(lib().pt_test_force_fault(which))
 
 

@@ -452,58 +452,25 @@ int launch_bounce(Slot &sl, int iter, int batch, int depth, bool lastBounce, flo
     return PT_OK;
 }
 
-// scan library workspace: one per stream (calls on different streams may overlap; calls on one stream are ordered, so
-// they can share the tile descriptors).  ScanCtrl::error is STICKY: only the ticket is reset between calls, and pt_sync
-// (or the next scan / compact call on the stream, through an asynchronous copy it checks on entry) reports it.
+// scan library workspace: the chunk totals, one buffer per stream (calls on different streams may overlap; calls on one
+// stream are ordered, so they share it)
 struct ScanWs {
-    ScanCtrl *ctrl = nullptr;
-    unsigned long long *desc = nullptr;
-    long long tiles = 0;
-    uint32_t *hostErr = nullptr;     // pinned mirror of ctrl->error, refreshed behind every call
-    hipEvent_t copied = nullptr;
+    uint32_t *partial = nullptr;     // [kScanChunksMax + 1]
 };
 std::map<hipStream_t, ScanWs> g_scan;
 
-int scan_ws(hipStream_t st, long long tiles, ScanWs **out) {
+int scan_ws(hipStream_t st, ScanWs **out) {
     ScanWs &W = g_scan[st];
-    if (!W.ctrl) {
-        HIPCHECK(hipMalloc(&W.ctrl, sizeof(ScanCtrl)));
-        HIPCHECK(hipMemset(W.ctrl, 0, sizeof(ScanCtrl)));
-        HIPCHECK(hipHostMalloc(&W.hostErr, sizeof(uint32_t), hipHostMallocDefault));
-        *W.hostErr = 0;
-        HIPCHECK(hipEventCreateWithFlags(&W.copied, hipEventDisableTiming));
-    } else {
-        // the previous call's fault word, if its copy has landed (never blocks)
-        if (hipEventQuery(W.copied) == hipSuccess && *W.hostErr)
-            return fail(PT_ERR_DEVICE, "device fault: look-back timeout in an earlier scan / compact call on this stream (its result is void)");
-        (void)hipGetLastError();
-    }
-    if (tiles > W.tiles) {
-        // the stream may still be reading the old descriptors
-        HIPCHECK(hipStreamSynchronize(st));
-        if (W.desc) HIPCHECK(hipFree(W.desc));
-        W.desc = nullptr;
-        long long cap = tiles < 1024 ? 1024 : tiles;
-        HIPCHECK(hipMalloc(&W.desc, (size_t)(cap + (cap + kGroup - 1) / kGroup) * 8));
-        W.tiles = cap;
-    }
+    if (!W.partial) HIPCHECK(hipMalloc(&W.partial, (size_t)(kScanChunksMax + 1) * sizeof(uint32_t)));
     *out = &W;
     return PT_OK;
 }
-// behind a scan / compact launch: mirror the fault word for the next call's (and pt_sync's) check
-int scan_epilogue(hipStream_t st, ScanWs &W) {
-    HIPCHECK(hipMemcpyAsync(W.hostErr, &W.ctrl->error, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    HIPCHECK(hipEventRecord(W.copied, st));
-    return PT_OK;
-}
-int scan_fault_check() {   // after a device-wide synchronisation
-    for (auto &kv : g_scan)
-        if (kv.second.hostErr) {
-            uint32_t err = 0;
-            HIPCHECK(hipMemcpy(&err, &kv.second.ctrl->error, sizeof err, hipMemcpyDeviceToHost));
-            if (err) return fail(PT_ERR_DEVICE, "device fault: scan look-back timeout (pt_scan_exclusive_i32 / pt_compact_nonzero_i32 results are void)");
-        }
-    return PT_OK;
+// the array as chunks of whole tiles: at most kScanChunksMax of them
+void scan_chunks(long long n, long long *tilesPerChunk, int *chunks) {
+    const long long tiles = (n + kScanTile - 1) / kScanTile;
+    const long long per = (tiles + kScanChunksMax - 1) / kScanChunksMax;
+    *tilesPerChunk = per < 1 ? 1 : per;
+    *chunks = (int)((tiles + *tilesPerChunk - 1) / *tilesPerChunk);
 }
 
 // wait for every stream the renderer uses
@@ -522,7 +489,7 @@ int check_device_fault() {
         if (err) return fail(PT_ERR_DEVICE, "device fault 0x%x:%s%s (results of this render are void; re-init)", err,
                              (err & kFaultPoolExhausted) ? " path pool exhausted" : "", (err & kFaultReserveTimeout) ? " chunk reservation timed out" : "");
     }
-    return scan_fault_check();
+    return PT_OK;
 }
 
 int persistent_grid(const void *kernel, size_t lds, int *grid) {
@@ -1012,8 +979,8 @@ int pt_iterate(int frame, int iter, void *rgba8_dev) { return pt_iterate_batch(f
 int pt_sync(void) {
     if (!S.init) {
         if (g_scan.empty()) return fail(PT_ERR_NOT_INIT, "pt_sync before pt_init");
-        HIPCHECK(hipDeviceSynchronize());          // the scan library alone: report its sticky fault word
-        return scan_fault_check();
+        HIPCHECK(hipDeviceSynchronize());          // the scan library alone
+        return PT_OK;
     }
     return check_device_fault();
 }
@@ -1067,31 +1034,12 @@ int pt_unpin_host(void) {
 
 int pt_test_force_fault(int which) {
     if (count_devices() < 1) return fail(PT_ERR_NO_GPU, "no HIP device");
-    const uint32_t one = 1u;
-    if (which == 1) {            // the scan library's look-back timeout word (default stream's workspace)
-        ScanWs *wp = nullptr;
-        int rc = scan_ws(nullptr, 1, &wp);
-        if (rc) return rc;
-        HIPCHECK(hipMemcpy(&wp->ctrl->error, &one, sizeof one, hipMemcpyHostToDevice));
-        return scan_epilogue(nullptr, *wp);
-    }
-    if (which == 2) {            // the renderer's fault word
-        if (!S.init) return fail(PT_ERR_NOT_INIT, "pt_test_force_fault before pt_init");
-        HIPCHECK(hipMemcpy(&S.slot[0].ctrl->error, &one, sizeof one, hipMemcpyHostToDevice));
-        return PT_OK;
-    }
-    if (which == 0) {            // clear every fault word (what a fresh process / pt_init would start from)
-        HIPCHECK(hipDeviceSynchronize());
-        const uint32_t zero = 0u;
-        for (auto &kv : g_scan)
-            if (kv.second.ctrl) {
-                HIPCHECK(hipMemcpy(&kv.second.ctrl->error, &zero, sizeof zero, hipMemcpyHostToDevice));
-                *kv.second.hostErr = 0;
-            }
-        for (int i = 0; i < S.nslots; ++i) HIPCHECK(hipMemcpy(&S.slot[i].ctrl->error, &zero, sizeof zero, hipMemcpyHostToDevice));
-        return PT_OK;
-    }
-    return fail(PT_ERR_INVALID, "pt_test_force_fault: which must be 0 (clear), 1 or 2");
+    if (which != 0 && which != 2) return fail(PT_ERR_INVALID, "pt_test_force_fault: which must be 0 (clear) or 2 (the renderer's fault word)");
+    if (!S.init) return fail(PT_ERR_NOT_INIT, "pt_test_force_fault before pt_init");
+    HIPCHECK(hipDeviceSynchronize());
+    const uint32_t word = which == 2 ? 1u : 0u;
+    for (int i = 0; i < (which == 2 ? 1 : S.nslots); ++i) HIPCHECK(hipMemcpy(&S.slot[i].ctrl->error, &word, sizeof word, hipMemcpyHostToDevice));
+    return PT_OK;
 }
 
 int pt_readback_rgba8(int iter, uint8_t *rgba_host) {
@@ -1255,48 +1203,41 @@ int pt_scan_exclusive_i32(const int32_t *in_dev, int32_t *out_dev, int64_t n, vo
     if (n < 0 || (n > 0 && (!in_dev || !out_dev))) return fail(PT_ERR_INVALID, "pt_scan_exclusive_i32: bad argument");
     if (n == 0) return PT_OK;
     if (count_devices() < 1) return fail(PT_ERR_NO_GPU, "no HIP device");
-    const long long tiles = (n + kScanTile - 1) / kScanTile;
-    if (tiles > 0x7fffffffll) return fail(PT_ERR_INVALID, "pt_scan_exclusive_i32: n too large");
+    if (n > (1ll << 42)) return fail(PT_ERR_INVALID, "pt_scan_exclusive_i32: n too large");
     hipStream_t st = (hipStream_t)stream;
     ScanWs *wp = nullptr;
-    int rc = scan_ws(st, tiles, &wp);
+    int rc = scan_ws(st, &wp);
     if (rc) return rc;
-    ScanWs &W = *wp;
-    HIPCHECK(hipMemsetAsync(&W.ctrl->ticket, 0, sizeof(uint32_t), st));     // the error word stays (sticky)
-    const long long words = tiles + (tiles + kGroup - 1) / kGroup;
-    HIPCHECK(hipMemsetAsync(W.desc, 0, (size_t)words * 8, st));
-    int grid = 0;
-    rc = persistent_grid(reinterpret_cast<const void *>(k_scan_exclusive), 0, &grid);
-    if (rc) return rc;
-    if (grid > tiles) grid = (int)tiles;
-    hipLaunchKernelGGL(k_scan_exclusive, dim3(grid), dim3(kBlock), 0, st, in_dev, out_dev, (long long)n, W.ctrl, W.desc,
-                       W.desc + tiles);
+    long long per;
+    int chunks;
+    scan_chunks(n, &per, &chunks);
+    hipLaunchKernelGGL((k_scan_reduce<false>), dim3(chunks), dim3(kBlock), 0, st, in_dev, (long long)n, per, wp->partial);
+    hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(kBlock), 0, st, wp->partial, chunks, (long long *)nullptr);
+    hipLaunchKernelGGL(k_scan_apply, dim3(chunks), dim3(kBlock), 0, st, in_dev, out_dev, (long long)n, per, wp->partial);
     HIPCHECK(hipGetLastError());
-    return scan_epilogue(st, W);
+    return PT_OK;
 }
 
 int pt_compact_nonzero_i32(const int32_t *in_dev, int32_t *out_dev, int64_t n, int64_t *count_dev, void *stream) {
     if (n < 0 || !count_dev || (n > 0 && (!in_dev || !out_dev))) return fail(PT_ERR_INVALID, "pt_compact_nonzero_i32: bad argument");
     if (count_devices() < 1) return fail(PT_ERR_NO_GPU, "no HIP device");
-    const long long tiles = (n + kBlock - 1) / kBlock;
-    if (tiles > 0x7fffffffll) return fail(PT_ERR_INVALID, "pt_compact_nonzero_i32: n too large");
+    if (n > 0xffffffffll) return fail(PT_ERR_INVALID, "pt_compact_nonzero_i32: n too large (positions are 32-bit)");
     hipStream_t st = (hipStream_t)stream;
+    if (n == 0) {
+        HIPCHECK(hipMemsetAsync(count_dev, 0, sizeof(int64_t), st));
+        return PT_OK;
+    }
     ScanWs *wp = nullptr;
-    int rc = scan_ws(st, tiles ? tiles : 1, &wp);
+    int rc = scan_ws(st, &wp);
     if (rc) return rc;
-    ScanWs &W = *wp;
-    HIPCHECK(hipMemsetAsync(&W.ctrl->ticket, 0, sizeof(uint32_t), st));     // the error word stays (sticky)
-    const long long words = tiles + (tiles + kGroup - 1) / kGroup;
-    HIPCHECK(hipMemsetAsync(W.desc, 0, (size_t)(words ? words : 1) * 8, st));
-    int grid = 0;
-    rc = persistent_grid(reinterpret_cast<const void *>(k_compact_nonzero), 0, &grid);
-    if (rc) return rc;
-    if (grid > tiles) grid = (int)tiles;
-    if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(k_compact_nonzero, dim3(grid), dim3(kBlock), 0, st, in_dev, out_dev, (long long)n, W.ctrl, W.desc,
-                       W.desc + tiles, reinterpret_cast<long long *>(count_dev));
+    long long per;
+    int chunks;
+    scan_chunks(n, &per, &chunks);
+    hipLaunchKernelGGL((k_scan_reduce<true>), dim3(chunks), dim3(kBlock), 0, st, in_dev, (long long)n, per, wp->partial);
+    hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(kBlock), 0, st, wp->partial, chunks, reinterpret_cast<long long *>(count_dev));
+    hipLaunchKernelGGL(k_compact_apply, dim3(chunks), dim3(kBlock), 0, st, in_dev, out_dev, (long long)n, per, wp->partial);
     HIPCHECK(hipGetLastError());
-    return scan_epilogue(st, W);
+    return PT_OK;
 }
 
 // ---- primitive tests over host arrays ------------------------------------------------------------------
