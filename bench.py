@@ -242,7 +242,9 @@ def main():
     every = args.collective_every
     # N ranks share the frame's rows, so a rank's launches cover 1/N of the paths: with the collective once per batch, a rank
     # traces `fuse` consecutive steps as ONE wavefront batch (at most PT_MAX_BATCH iterations), which keeps its launches fat
-    fuse = max(1, min(world, pt.PT_MAX_BATCH // B)) if every == "batch" else 1
+    # -- but not so few batches that the two in flight never overlap: at least 8 per timed run (measured on a rank of 8 and of
+    # 4 at the driver's 20 steps: batches of 64 beat 128 and 256 by 2-5 %)
+    fuse = max(1, min(world, pt.PT_MAX_BATCH // B, max(1, args.steps // 8))) if every == "batch" else 1
     maxb = B * fuse if every == "batch" else 1
     # ---- pass A: the headline number ----------------------------------------------------------
     init(0, args.pipeline, maxb)

@@ -105,7 +105,7 @@ typedef struct PtOptions {
 } PtOptions;
 
 #define PT_MAX_DEPTH 62
-#define PT_MAX_BATCH 128
+#define PT_MAX_BATCH 256
 
 typedef struct PtCounters {
     int64_t live[PT_MAX_DEPTH + 2]; /* live[d] = paths entering bounce d (d = 1..depth), summed over   */

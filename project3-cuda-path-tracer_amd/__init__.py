@@ -39,7 +39,7 @@ CAMERA_DTYPE = np.dtype([
 assert GEOM_DTYPE.itemsize == 236 and MATERIAL_DTYPE.itemsize == 44 and CAMERA_DTYPE.itemsize == 52
 
 PT_MAX_DEPTH = 62
-PT_MAX_BATCH = 128
+PT_MAX_BATCH = 256
 PT_FLAG_KERNEL_TIMING = 1
 PT_FLAG_ACCUM_SHARD_ROWS = 2
 PT_FLAG_DIRECT_LIGHTING = 4

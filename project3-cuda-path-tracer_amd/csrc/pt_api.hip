@@ -648,6 +648,8 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     k.shardRank = o.shard_rank; k.shardCount = o.shard_count;
     k.nLocal = S.nLocal;
     magic_divisor((uint32_t)Wd, k.magicW, k.shiftW);
+    magic_divisor((uint32_t)o.shard_count, k.magicS, k.shiftS);
+    k.contribLocal = (o.shard_count > 1 && (long long)Wd * H < (1ll << 27)) ? 1 : 0;   // (the multiply-shift divisions hold below 2^27)
     magic_divisor((uint32_t)std::max(S.nLocal, 1), k.magicN, k.shiftN);
     for (uint32_t d : {(uint32_t)Wd, (uint32_t)std::max(S.nLocal, 1)}) {       // self-check on the edges of every quotient range
         uint32_t m, sh;
@@ -725,10 +727,12 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
         HIPCHECK(hipMalloc(&sl.ctrl, sizeof(Ctrl)));
         int rcc = reset_ctrl(sl.ctrl, nullptr);
         if (rcc) return rcc;
-        HIPCHECK(hipMalloc(&sl.contrib, (size_t)S.maxBatch * S.P * 3 * sizeof(float)));
-        HIPCHECK(hipMemset(sl.contrib, 0, (size_t)S.maxBatch * S.P * 3 * sizeof(float)));
-        HIPCHECK(hipMalloc(&sl.hitMask, (size_t)((S.maxBatch + 31) / 32) * S.P * sizeof(uint32_t)));
-        HIPCHECK(hipMemset(sl.hitMask, 0, (size_t)((S.maxBatch + 31) / 32) * S.P * sizeof(uint32_t)));
+        // radiance buffers and iteration masks: the frame's pixels, or only this shard's (KParams::contribLocal)
+        const size_t cpx = k.contribLocal ? (size_t)(S.nLocal > 0 ? S.nLocal : 1) : (size_t)S.P;
+        HIPCHECK(hipMalloc(&sl.contrib, (size_t)S.maxBatch * cpx * 3 * sizeof(float)));
+        HIPCHECK(hipMemset(sl.contrib, 0, (size_t)S.maxBatch * cpx * 3 * sizeof(float)));
+        HIPCHECK(hipMalloc(&sl.hitMask, (size_t)((S.maxBatch + 31) / 32) * cpx * sizeof(uint32_t)));
+        HIPCHECK(hipMemset(sl.hitMask, 0, (size_t)((S.maxBatch + 31) / 32) * cpx * sizeof(uint32_t)));
         HIPCHECK(hipEventCreateWithFlags(&sl.evDone, hipEventDisableTiming));
         HIPCHECK(hipEventCreateWithFlags(&sl.evCommitted, hipEventDisableTiming));
     }

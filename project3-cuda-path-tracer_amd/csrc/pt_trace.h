@@ -69,6 +69,9 @@ struct KParams {
     // n / W and n / nLocal for n < 2^27 as (n * magic) >> shift (exact, see pt_init): the two divisions of the
     // camera-ray bounce cost ~50 instructions each when the compiler expands them
     uint32_t magicW, shiftW, magicN, shiftN;
+    int   contribLocal; // the radiance buffers and iteration masks hold only this shard's pixels, indexed x + (y / shardCount) * W
+                        // (row shards of frames below 2^27 pixels): a rank of N then touches 1/N of the memory, not all of it
+    uint32_t magicS, shiftS;   // n / shardCount
     int   tilesPerRow;  // W / 256 when that is exact and the camera-ray grid is a multiple of it (see k_bounce), else 0
     int   wholeRowTiles; // W % 256 == 0: a camera-ray tile is 256 pixels of one row
     int   emittersBinned; // every primitive with an emissive material is one of binGeom[]
@@ -789,13 +792,21 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? (FIRST ? 6 : 
                         // is parked in this iteration's own buffer (one path per pixel: race-free, no
                         // read) and k_commit adds it to the accumulator in iteration order.
                         const F3 c = (col * mcol) * M.emittance;
-                        const size_t frame = (size_t)A->prm.W * A->prm.H;
-                        float *dst = contrib + 3 * ((size_t)itb * frame + (size_t)pix);
+                        // (index of the pixel in the radiance buffers: the frame's, or, for a row shard, the shard's own)
+                        size_t frame = (size_t)A->prm.W * A->prm.H;
+                        uint32_t cpix = (uint32_t)pix;
+                        if (A->prm.contribLocal) {
+                            const uint32_t y = fastDiv((uint32_t)pix, A->prm.magicW, A->prm.shiftW);
+                            const uint32_t lr = fastDiv(y, A->prm.magicS, A->prm.shiftS);
+                            cpix = (uint32_t)pix - (y - lr) * (uint32_t)A->prm.W;      // x + lr * W
+                            frame = (size_t)A->prm.nLocal;
+                        }
+                        float *dst = contrib + 3 * ((size_t)itb * frame + (size_t)cpix);
                         dst[0] = c.x; dst[1] = c.y; dst[2] = c.z;
                         // ... and the pixel's mask says which iterations of the batch left something: k_commit then reads
                         // 4 B per pixel and word instead of 12 B per pixel and iteration (one path per pixel and iteration: the
                         // bits of a word come from different launches or lanes, hence the atomic; nobody waits for it)
-                        (void)__hip_atomic_fetch_or(A->hitMask + (size_t)(itb >> 5) * frame + (size_t)pix, 1u << (itb & 31), __ATOMIC_RELAXED,
+                        (void)__hip_atomic_fetch_or(A->hitMask + (size_t)(itb >> 5) * frame + (size_t)cpix, 1u << (itb & 31), __ATOMIC_RELAXED,
                                                     __HIP_MEMORY_SCOPE_AGENT);
                     }
                 } else if (!launder(kargs)->lastBounce) {        // S6 scatter (S7: skipped on the last bounce)
@@ -1044,25 +1055,52 @@ __global__ __launch_bounds__(kBlock) void k_commit(KParams prm, float *image, fl
     if (j >= prm.nLocal) return;
     const int lr = j / prm.W;
     const int x = j - lr * prm.W;
-    const size_t pix = (size_t)x + (size_t)(lr * prm.shardCount + prm.shardRank) * prm.W;
-    const size_t frame = (size_t)prm.W * prm.H;
-    float *px = image + 3 * (compactRows ? (size_t)j : pix);
-    float ax = 0.0f, ay = 0.0f, az = 0.0f;
-    bool dirty = false;
-    for (int w = 0; w * 32 < batch; ++w) {
-        uint32_t m = hitMask[(size_t)w * frame + pix];
+    const size_t gpix = (size_t)x + (size_t)(lr * prm.shardCount + prm.shardRank) * prm.W;
+    const size_t pix = prm.contribLocal ? (size_t)j : gpix;                      // index in the radiance buffers / masks
+    const size_t frame = prm.contribLocal ? (size_t)prm.nLocal : (size_t)prm.W * prm.H;
+    float *px = image + 3 * (compactRows ? (size_t)j : gpix);
+    // the pixel's mask words first (independent loads), then its entries sixteen at a time -- their loads are in flight
+    // together, the additions stay in iteration order.  (A rank of 8 traces 256 iterations per batch: ~75 entries per lit pixel,
+    // one memory round trip each if taken one by one.)
+    constexpr int kWordsMax = (PT_MAX_BATCH + 31) / 32;
+    uint32_t mw[kWordsMax];
+    uint32_t any = 0u;
+#pragma unroll
+    for (int w = 0; w < kWordsMax; ++w) {
+        mw[w] = w * 32 < batch ? hitMask[(size_t)w * frame + pix] : 0u;
+        any |= mw[w];
+    }
+    if (any == 0u) return;
+    float ax = px[0], ay = px[1], az = px[2];
+#pragma unroll
+    for (int w = 0; w < kWordsMax; ++w) {
+        uint32_t m = mw[w];
         if (m == 0u) continue;
         hitMask[(size_t)w * frame + pix] = 0u;
-        if (!dirty) { ax = px[0]; ay = px[1]; az = px[2]; dirty = true; }
+        float *const base = contrib + 3 * ((size_t)(w * 32) * frame + pix);
         while (m) {                                            // ascending bits = iteration order
-            const int b = w * 32 + __builtin_ctz(m);
-            m &= m - 1u;
-            float *c = contrib + 3 * ((size_t)b * frame + pix);
-            ax += c[0]; ay += c[1]; az += c[2];
-            c[0] = 0.0f; c[1] = 0.0f; c[2] = 0.0f;
+            int b[16];
+            float v[16][3];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                b[q] = -1;
+                if (m) {
+                    b[q] = __builtin_ctz(m);
+                    m &= m - 1u;
+                    const float *c = base + 3 * (size_t)b[q] * frame;
+                    v[q][0] = c[0]; v[q][1] = c[1]; v[q][2] = c[2];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                if (b[q] >= 0) {
+                    ax += v[q][0]; ay += v[q][1]; az += v[q][2];
+                    float *c = base + 3 * (size_t)b[q] * frame;
+                    c[0] = 0.0f; c[1] = 0.0f; c[2] = 0.0f;
+                }
         }
     }
-    if (dirty) { px[0] = ax; px[1] = ay; px[2] = az; }
+    px[0] = ax; px[1] = ay; px[2] = az;
 }
 
 // ---- sendImageToPBO (reference src/pathtrace.cu:48-68) ---------------------------------------------

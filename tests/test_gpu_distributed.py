@@ -116,8 +116,8 @@ def test_bench_two_ranks_contract(pt, tmp_path, every, extra):
     assert "cpu_baseline" not in d and d["value"] > 0
     assert "rows sharded y%2" in d["config"]["workload"] and d["config"]["iterations_per_step"] == B
     assert d["config"]["collective_every"] == every
-    # with the collective per batch a rank fuses min(N, PT_MAX_BATCH // B) steps into one wavefront batch
-    assert d["config"]["iterations_per_wavefront_batch"] == (B * min(2, pt.PT_MAX_BATCH // B) if every == "batch" else 1)
+    # with the collective per batch a rank fuses min(N, PT_MAX_BATCH // B, steps // 8) steps (at least one) into one wavefront batch
+    assert d["config"]["iterations_per_wavefront_batch"] == (B * max(1, min(2, pt.PT_MAX_BATCH // B, steps // 8)) if every == "batch" else 1)
     if every == "batch":
         assert d["config"]["per_iteration_collective"]["value"] > 0   # config C3 as written, timed beside it
     got = np.load(dump)
