@@ -256,7 +256,8 @@ __global__ __launch_bounds__(kBlock) void k_debug_camera_rays(KParams prm, int i
 // which turns the exact early-miss of the box test (pt_device.h) into a wave-uniform branch), and either candidates only --
 // whose tests of the small primitives then run with full waves instead of a few lanes -- or paths that skip the small
 // primitives altogether (both are sufficient conditions for the reference's own miss, evaluated on the very ray that is
-// stored).  A survivor that can hit nothing at all (scenes whose primitives are all walls or binned) ends at its scatter.
+// stored): it loops over its class's own list of primitives (KParams::classOff).  A survivor that can hit nothing at all
+// (scenes whose primitives are all walls or binned) ends at its scatter.
 // Queue order never influences results: RNG and accumulator are keyed on the pixel index.
 // No workgroup ever waits for another one's work, so there is no residency / dispatch-order assumption (the one
 // cross-workgroup wait is reserveRun's bounded poll for a chunk-list entry published a chunk's worth of appends earlier).
