@@ -758,6 +758,10 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
         pack_geom(geoms[i], hg[i], k.pos, isMesh ? box : nullptr);
         hg[i].meshRoot = root;
         if (isMesh) hg[i].meshStride = stride;
+        if (geoms[i].type == PT_CUBE) {
+            if (k.nCubes >= 32767) return fail(PT_ERR_INVALID, "pt_init: more than 32767 cubes");
+            hg[i].frameSlot = (short)k.nCubes++;
+        }
         project_geom(geoms[i], k, hg[i].rect, isMesh ? box : nullptr);
         if (S.dof) {        // rays start anywhere on the lens: the pinhole projection bounds nothing
             hg[i].rect[0] = hg[i].rect[1] = 0;
@@ -892,8 +896,10 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
         HIPCHECK(hipMalloc(&S.dClassIdx, idx.size() * sizeof(int)));
         HIPCHECK(hipMemcpy(S.dClassIdx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
     }
-    S.ldsBytes = sizeof(MaterialDev) * nmats + sizeof(GeomHitDev) * ngeoms + kMiscWords * sizeof(uint32_t) +
-                 (S.many ? (size_t)ngeoms * kSphRowFloats * sizeof(float) + (size_t)kListMax * kBlock * sizeof(uint16_t) : 0);
+    S.ldsBytes = sizeof(MaterialDev) * nmats + kMiscWords * sizeof(uint32_t) +
+                 (S.many ? manyHitBytes(ngeoms) + (size_t)k.nCubes * 54 * sizeof(float) + manyFramePad(k.nCubes) +
+                               (size_t)ngeoms * kSphRowFloats * sizeof(float) + (size_t)kListMax * kBlock * sizeof(uint16_t)
+                         : sizeof(GeomHitDev) * ngeoms);
     if (S.ldsBytes > 160 * 1024) return fail(PT_ERR_INVALID, "pt_init: scene does not fit the 160 KiB LDS (%zu B)", S.ldsBytes);
     const void *kFirst = bounce_kernel(true, S.dof);
     const void *kNext = bounce_kernel(false, false);
@@ -1514,6 +1520,19 @@ int pt_test_unscaled_sqrt_sweep(uint64_t mismatches[4]) {
 }
 
 #ifdef PT_PROBE
+// instrumented build only (make probe): the residency census of k_bounce -- out[k] = number of CUs on which at most k
+// workgroups of it were ever resident together (k = 0..15); cleared by the call
+extern "C" int pt_probe_census(uint32_t out[16]) {
+    NEED_GPU();
+    static unsigned int h[4096], z[4096];
+    HIPCHECK(hipDeviceSynchronize());
+    HIPCHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(ptd::g_censusMax), sizeof h));
+    HIPCHECK(hipMemcpyToSymbol(HIP_SYMBOL(ptd::g_censusMax), z, sizeof z));
+    for (int k = 0; k < 16; ++k) out[k] = 0;
+    for (int i = 0; i < 4096; ++i)
+        if (h[i]) out[h[i] < 15 ? h[i] : 15]++;
+    return PT_OK;
+}
 // instrumented build only (make probe): reads and clears the phase counters of pt_device.h
 extern "C" int pt_probe_read(uint64_t out[32]) {
     NEED_GPU();

@@ -17,6 +17,25 @@ namespace ptd {
 // of the phases of the two intersection tests.  g_probe[2k] += 1 per wave that enters phase k, g_probe[2k+1] += lanes.
 #ifdef PT_PROBE
 __device__ unsigned long long g_probe[32];
+// residency census (MI355X_MICROARCH.md: "verify with a census kernel"): workgroups of k_bounce resident on each CU right
+// now and the most there ever were, keyed by (XCC, SE, SH, CU) from the hardware id registers
+__device__ unsigned int g_censusNow[4096], g_censusMax[4096];
+__device__ __forceinline__ unsigned censusKey() {
+    unsigned hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const unsigned cu = (hwid >> 8) & 15u, sh = (hwid >> 12) & 1u, se = (hwid >> 13) & 7u;
+    return ((xcc & 15u) << 8) | (se << 5) | (sh << 4) | cu;
+}
+__device__ __forceinline__ void censusEnter() {
+    if (threadIdx.x == 0) {
+        const unsigned k = censusKey();
+        atomicMax(&g_censusMax[k], atomicAdd(&g_censusNow[k], 1u) + 1u);
+    }
+}
+__device__ __forceinline__ void censusLeave() {
+    if (threadIdx.x == 0) atomicSub(&g_censusNow[censusKey()], 1u);
+}
 __device__ __forceinline__ void probe(int k) {
     const unsigned long long m = __ballot(1);
     if (__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) == 0) {
@@ -26,6 +45,8 @@ __device__ __forceinline__ void probe(int k) {
 }
 #else
 __device__ __forceinline__ void probe(int) {}
+__device__ __forceinline__ void censusEnter() {}
+__device__ __forceinline__ void censusLeave() {}
 #endif
 
 struct F3 {
@@ -137,7 +158,8 @@ struct GeomDev {
     };
     // 1: a small primitive the queue is binned by (KParams::binGeom): tiles of paths that certainly miss all of them
     // skip it (mirrored in flags)
-    int   binned;
+    short binned;
+    short frameSlot;   // a cube's ordinal among the scene's cubes (sphere-heavy scenes: its row in the LDS frame table)
     int   type;      // 0 sphere, 1 cube (src/sceneStructs.h:8-11); a mesh is 0 here (its normal is made like a sphere's) and flags bit 5
 };
 static_assert(sizeof(GeomDev) == 448, "GeomDev is 28 x 16 B");
@@ -689,6 +711,18 @@ struct GeomHitDev {
     int   pad[8];
 };
 static_assert(sizeof(GeomHitDev) == 304, "GeomHitDev is 19 x 16 B");
+// Sphere-heavy scenes: 304 B for each of seventy primitives (21 KB, together with the lanes' sphere lists and matrices 33 KB of
+// LDS per workgroup) admitted only FOUR workgroups per CU where the registers allow seven (residency census,
+// profiles/census.py).  There the record is 68 B -- 17 words: an odd stride, so lanes that index different primitives do not
+// collide -- and the face frames of the (few) cubes sit in a table of their own, addressed by `frame`.
+struct GeomHitSmall {
+    float nm[12];
+    int   material;
+    int   type;
+    int   frame;         // cubes: row of the frame table (54 floats each); others: 0
+    int   pad[2];
+};
+static_assert(sizeof(GeomHitSmall) == 68, "17 words");
 
 // src/interactions.h:10-42, in three parts: the tangent frame is a function of the normal alone (for a cube face it
 // comes from GeomDev::cubeFrame), the draws are two random numbers, the combination is the reference's last line.

@@ -89,6 +89,7 @@ struct KParams {
     int   directDepth;                 // direct lighting (README.md:107-108): the bounce whose diffuse scatter aims at a light
                                        // (= the scene's trace depth; traceDepth is then one more: the bounce that collects); 0 = off
     int   nEmit;                       // emissive primitives the direct-lighting bounce samples, at most kEmitMax (file order)
+    int   nCubes;                      // cubes of the scene (sphere-heavy scenes: rows of the LDS frame table)
     int   nSphCull;                    // sphere-heavy scenes: entries of BounceArgs::sphCull (even: padded with geom = -1)
     int   classOff[kCls + 1];          // later bounces: the primitives a tile of class c has to look at are classIdx[classOff[c] ..
                                        // classOff[c + 1]) (BounceArgs::classIdx): not the binned ones unless the class says so, of the walls only
@@ -303,6 +304,11 @@ struct SphereCull {
 static_assert(sizeof(SphereCull) == 32, "two per s_load_dwordx16");
 typedef int int16v __attribute__((ext_vector_type(16)));
 
+// LDS layout of the sphere-heavy variants: the 68-byte hit records are padded to a multiple of 16 B, and so is the frame table
+// (the sphere matrices behind them are read as float4)
+__host__ __device__ constexpr size_t manyHitBytes(int ngeoms) { return ((size_t)ngeoms * sizeof(GeomHitSmall) + 15) / 16 * 16; }
+__host__ __device__ constexpr size_t manyFramePad(int ncubes) { return (16 - ((size_t)ncubes * 54 * sizeof(float)) % 16) % 16; }
+
 struct BounceArgs {
     KParams prm;
     int iter, batch, depth, lastBounce, parity;
@@ -357,6 +363,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? (FIRST ? 6 : 
     static_assert(FIRST || !DOF, "the lens only concerns the camera-ray bounce");
     (void)argsByValue;
     const ArgsPtr kargs = (ArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    censusEnter();                       // (instrumented build only)
     // LDS: the material table and the per-geom hit records (normal matrix, material, type: indexed per lane by
     // the nearest hit), and the compaction scratch.  Geometry itself is wave-uniform in the nearest-hit loop, so it is fetched through the
     // scalar path (s_load into SGPRs, used directly as VALU operands): measured against an LDS-staged copy
@@ -367,7 +374,11 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? (FIRST ? 6 : 
     uint32_t *const s_misc = reinterpret_cast<uint32_t *>(smem);
     MaterialDev *const smats = reinterpret_cast<MaterialDev *>(smem + kMiscWords * sizeof(uint32_t));
 #define S_GEOMHIT(nmats_) (reinterpret_cast<GeomHitDev *>(smem + kMiscWords * sizeof(uint32_t) + sizeof(MaterialDev) * (nmats_)))
-#define S_SPH(nmats_, ngeoms_) (reinterpret_cast<float *>(smem + kMiscWords * sizeof(uint32_t) + sizeof(MaterialDev) * (nmats_) + sizeof(GeomHitDev) * (ngeoms_)))
+// sphere-heavy scenes (MANY): compact hit records, then the cubes' face frames, then the per-primitive matrices and the lanes' lists
+#define S_GEOMHIT_SMALL(nmats_) (reinterpret_cast<GeomHitSmall *>(smem + kMiscWords * sizeof(uint32_t) + sizeof(MaterialDev) * (nmats_)))
+#define S_FRAMES(nmats_, ngeoms_) (reinterpret_cast<float *>(smem + kMiscWords * sizeof(uint32_t) + sizeof(MaterialDev) * (nmats_) + manyHitBytes(ngeoms_)))
+#define S_SPH(nmats_, ngeoms_, ncubes_) (reinterpret_cast<float *>(smem + kMiscWords * sizeof(uint32_t) + sizeof(MaterialDev) * (nmats_) + \
+                                         (MANY ? manyHitBytes(ngeoms_) + (size_t)(ncubes_) * 54 * sizeof(float) + manyFramePad(ncubes_) : sizeof(GeomHitDev) * (ngeoms_))))
     uint32_t *const s_wave = s_misc;                       // [kWaves][kCls] survivors per wave and class (zero between tiles)
     uint32_t *const s_base = s_wave + 2 * kWaves * kCls;       // [5][kCls] this tile's output run per class: first slot, paths before the
                                                            //           chunk boundary, first slot behind it; the class's last chunk lookup (reserveRun)
@@ -421,13 +432,33 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? (FIRST ? 6 : 
         const GeomDev *ggeoms = A->ggeoms;
         const int ngeoms = A->prm.ngeoms;
         GeomHitDev *const s_geomHit = S_GEOMHIT(A->prm.nmats);
-        float *const s_sph = S_SPH(A->prm.nmats, ngeoms);        // MANY: [ngeoms][kSphRowFloats]
+        float *const s_sph = S_SPH(A->prm.nmats, ngeoms, A->prm.nCubes);   // MANY: [ngeoms][kSphRowFloats]
         const float4 *msrc = reinterpret_cast<const float4 *>(A->gmats);
         float4 *mdst = reinterpret_cast<float4 *>(smats);
         const int m16 = A->prm.nmats * (int)(sizeof(MaterialDev) / 16);
         for (int i = threadIdx.x; i < m16; i += kBlock) mdst[i] = msrc[i];
+        if (MANY) {
+            constexpr int kSmallWords = (int)(sizeof(GeomHitSmall) / 4);
+            uint32_t *const dst = reinterpret_cast<uint32_t *>(S_GEOMHIT_SMALL(A->prm.nmats));
+            for (int i = threadIdx.x; i < ngeoms * kSmallWords; i += kBlock) {
+                const int g = i / kSmallWords, k = i - g * kSmallWords;
+                const GeomDev &G = ggeoms[g];
+                uint32_t v = 0;
+                if (k < 12) v = __float_as_uint(G.invT[k]);
+                else if (k == 12) v = (uint32_t)G.material;
+                else if (k == 13) v = (uint32_t)G.type;
+                else if (k == 14) v = (uint32_t)(G.type == 1 ? (int)G.frameSlot : 0);
+                dst[i] = v;
+            }
+            float *const fr = S_FRAMES(A->prm.nmats, ngeoms);
+            for (int i = threadIdx.x; i < ngeoms * 54; i += kBlock) {       // (cubes only: a few of the primitives)
+                const int g = i / 54, k = i - g * 54;
+                const GeomDev &G = ggeoms[g];
+                if (G.type == 1) fr[(int)G.frameSlot * 54 + k] = G.cubeFrame[k];
+            }
+        }
         constexpr int kHitWords = (int)(sizeof(GeomHitDev) / 4);
-        for (int i = threadIdx.x; i < ngeoms * kHitWords; i += kBlock) {
+        for (int i = threadIdx.x; !MANY && i < ngeoms * kHitWords; i += kBlock) {
             const int g = i / kHitWords, k = i - g * kHitWords;
             const GeomDev &G = ggeoms[g];
             uint32_t v = 0;
@@ -646,7 +677,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? (FIRST ? 6 : 
             uint16_t *s_list = nullptr;
             if (MANY) {
                 const ArgsPtr A = launder(kargs);
-                s_sph = S_SPH(A->prm.nmats, A->prm.ngeoms);
+                s_sph = S_SPH(A->prm.nmats, A->prm.ngeoms, A->prm.nCubes);
                 s_list = reinterpret_cast<uint16_t *>(s_sph + (size_t)A->prm.ngeoms * kSphRowFloats);
             }
             // Sphere-heavy scenes, later bounces: the spheres come from their packed culling data (order does not matter: the
@@ -776,13 +807,24 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? (FIRST ? 6 : 
                 missedI = 1u;                                    // S4: background is black
             } else {
                 probe(9);
-                const GeomHitDev &GH = S_GEOMHIT(launder(kargs)->prm.nmats)[hit];   // per-lane geom: LDS lookup
-                const bool isSphere = GH.type == 0;
+                // per-lane primitive: LDS lookup of its hit record (sphere-heavy scenes: the compact record + the frame table)
+                int ghType, ghMaterial;
+                const float *ghNm, *ghFrame;
+                if (MANY) {
+                    const ArgsPtr A = launder(kargs);
+                    const GeomHitSmall &h = S_GEOMHIT_SMALL(A->prm.nmats)[hit];
+                    ghType = h.type; ghMaterial = h.material; ghNm = h.nm;
+                    ghFrame = S_FRAMES(A->prm.nmats, A->prm.ngeoms) + h.frame * 54;
+                } else {
+                    const GeomHitDev &h = S_GEOMHIT(launder(kargs)->prm.nmats)[hit];
+                    ghType = h.type; ghMaterial = h.material; ghNm = h.nm; ghFrame = h.cubeFrame;
+                }
+                const bool isSphere = ghType == 0;
                 bool faceOk = true;
                 const int face = isSphere ? 0 : cubeFace(nsrc, faceOk);
                 const bool outside = outsideI != 0;
-                const F3 N = isSphere ? hitNormalSphere(GH.nm, nsrc, outside) : cubeFrameVector(GH.cubeFrame, face, 0, faceOk);
-                const MaterialDev &M = smats[GH.material];
+                const F3 N = isSphere ? hitNormalSphere(ghNm, nsrc, outside) : cubeFrameVector(ghFrame, face, 0, faceOk);
+                const MaterialDev &M = smats[ghMaterial];
                 const F3 mcol = f3(M.color[0], M.color[1], M.color[2]);
                 if (M.emittance > 0.0f) {                        // S5: emitter ends the path
                     lightHitI = 1u;
@@ -900,8 +942,8 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? (FIRST ? 6 : 
                         if (isSphere) {
                             hemisphereFrame(N, p1, p2);
                         } else {
-                            p1 = cubeFrameVector(GH.cubeFrame, face, 1, faceOk);
-                            p2 = cubeFrameVector(GH.cubeFrame, face, 2, faceOk);
+                            p1 = cubeFrameVector(ghFrame, face, 1, faceOk);
+                            p2 = cubeFrameVector(ghFrame, face, 2, faceOk);
                         }
                         ndir = hemisphereCombine(N, p1, p2, up, cOver, sOver);
                     }
@@ -1018,6 +1060,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? (FIRST ? 6 : 
         }
         T = Tnext;
     }
+    censusLeave();
     // tallies: lanes -> wave (shuffles) -> workgroup (LDS) -> ONE atomic per workgroup and tally on counters sharded 8 ways
     // (every workgroup of a launch ends with these: unsharded, or one per wave, they serialise at the memory side)
     const uint32_t waveLight = waveSum(nLight), waveEarly = waveSum(nEarly), waveMiss = waveSum(nMiss) + waveEarly;
