@@ -94,6 +94,7 @@ struct State {
     MaterialDev *dmats = nullptr;
     WallBox *dwalls = nullptr;
     SphereCull *dSphCull = nullptr; // sphere-heavy scenes: packed culling data of the spheres, and ...
+    int *dRowOff = nullptr, *dRowIdx = nullptr;   // camera-ray bounce: per image row, the primitives whose pixel rectangle covers it
     int *dClassIdx = nullptr;       // later bounces: per queue class, the primitives to look at (KParams::classOff)
     float4 *dMeshNodes = nullptr;   // ptd::MeshNode[] / MeshTri[] of every mesh of the scene (k_bounce<., ., ., true>)
     float4 *dMeshTris = nullptr;
@@ -435,6 +436,7 @@ int launch_bounce(Slot &sl, int iter, int batch, int depth, bool lastBounce, flo
     ba.in = in; ba.out = out;
     ba.ctrl = sl.ctrl; ba.ggeoms = S.dgeoms; ba.gmats = S.dmats; ba.contrib = contrib; ba.hitMask = sl.hitMask;
     ba.sphCull = S.dSphCull; ba.classIdx = S.dClassIdx;
+    ba.rowOff = S.dRowOff; ba.rowIdx = S.dRowIdx;
     ba.walls = S.dwalls;
     ba.meshNodes = S.dMeshNodes; ba.meshTris = S.dMeshTris;
     void *kargs[] = {&ba};
@@ -564,6 +566,8 @@ void pt_free(void) {
     if (S.dwalls) (void)hipFree(S.dwalls);
     if (S.dSphCull) (void)hipFree(S.dSphCull);
     if (S.dClassIdx) (void)hipFree(S.dClassIdx);
+    if (S.dRowOff) (void)hipFree(S.dRowOff);
+    if (S.dRowIdx) (void)hipFree(S.dRowIdx);
     if (S.dMeshNodes) (void)hipFree(S.dMeshNodes);
     if (S.dMeshTris) (void)hipFree(S.dMeshTris);
     S = State();
@@ -892,6 +896,21 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
             }
         }
         k.classOff[kCls] = (int)idx.size();
+        // camera rays: per image row, the primitives whose pixel rectangle (project_geom) covers it
+        if (!S.dof && (long long)H * ngeoms < (1ll << 26)) {
+            std::vector<int> off(H + 1), ridx;
+            for (int y = 0; y < H; ++y) {
+                off[y] = (int)ridx.size();
+                for (int i = 0; i < ngeoms; ++i)
+                    if (y >= hg[i].rect[1] && y <= hg[i].rect[3] && hg[i].rect[0] <= hg[i].rect[2]) ridx.push_back(i);
+            }
+            off[H] = (int)ridx.size();
+            if (ridx.empty()) ridx.push_back(0);
+            HIPCHECK(hipMalloc(&S.dRowOff, off.size() * sizeof(int)));
+            HIPCHECK(hipMemcpy(S.dRowOff, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice));
+            HIPCHECK(hipMalloc(&S.dRowIdx, ridx.size() * sizeof(int)));
+            HIPCHECK(hipMemcpy(S.dRowIdx, ridx.data(), ridx.size() * sizeof(int), hipMemcpyHostToDevice));
+        }
         if (idx.empty()) idx.push_back(0);
         HIPCHECK(hipMalloc(&S.dClassIdx, idx.size() * sizeof(int)));
         HIPCHECK(hipMemcpy(S.dClassIdx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));

@@ -324,6 +324,8 @@ struct BounceArgs {
     uint32_t *hitMask;                  // [ceil(max_batch / 32)][W * H]: bit b of word w set = contrib[32 w + b][pix] was written
     const SphereCull *sphCull;          // sphere-heavy scenes (k_bounce<false, true, ...>): the spheres' culling data, packed
     const int *classIdx;                // later bounces: per queue class, the indices of the primitives to look at, file order (KParams::classOff)
+    const int *rowOff;                  // camera rays of whole-tile rows: the primitives whose pixel rectangle covers image row y are
+    const int *rowIdx;                  //   rowIdx[rowOff[y] .. rowOff[y + 1]), file order; nullptr: every primitive
 };
 typedef const PT_CAS BounceArgs *ArgsPtr;
 typedef const PT_CAS GeomDev *GeomPtr;
@@ -685,12 +687,27 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
             constexpr bool PACKED = MANY && !FIRST;
             if (inScene) {
                 const ArgsPtr A = launder(kargs);
-                // camera rays look at every primitive (their pixel rectangles sort them out); a later tile at the list of its class
-                const int gk0 = FIRST ? 0 : A->prm.classOff[tileCls], gk1 = FIRST ? A->prm.ngeoms : A->prm.classOff[tileCls + 1u];
+                // a later tile looks at the list of its class; a camera-ray tile of whole-tile rows (one image row) at the list of
+                // its row -- the primitives whose pixel rectangle covers that row -- and their rectangles sort the lanes out
+                int gk0, gk1;
+                const PT_CAS int *classIdx;
+                bool listed = !FIRST;
+                if (FIRST) {
+                    gk0 = 0; gk1 = A->prm.ngeoms;
+                    classIdx = (const PT_CAS int *)(A->rowIdx);
+                    if (!DOF && A->prm.wholeRowTiles && A->rowOff != nullptr) {
+                        const PT_CAS int *rowOff = (const PT_CAS int *)(A->rowOff);
+                        const int row = __builtin_amdgcn_readfirstlane(py);
+                        gk0 = rowOff[row]; gk1 = rowOff[row + 1];
+                        listed = true;
+                    }
+                } else {
+                    gk0 = A->prm.classOff[tileCls]; gk1 = A->prm.classOff[tileCls + 1u];
+                    classIdx = (const PT_CAS int *)(A->classIdx);
+                }
                 const GeomPtr geoms = (GeomPtr)(A->ggeoms);
-                const PT_CAS int *classIdx = (const PT_CAS int *)(A->classIdx);
                 for (int gk = gk0; gk < gk1; ++gk) {
-                    const int g = FIRST ? gk : classIdx[gk];
+                    const int g = listed ? classIdx[gk] : gk;
                     // (sphere-heavy scenes: no laundering per primitive -- the camera-ray bounce still walks all seventy of them,
                     // and the compiler's own scheduling of the scalar loads across iterations is worth more than the registers
                     // it costs; measured on C5)
