@@ -404,10 +404,11 @@ int resolve_events(std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, double &ms
 }
 
 // The instantiation of k_bounce a launch takes: FIRST (camera rays), MANY (per-lane sphere lists: scenes with more than
-// kBinMax spheres and no mesh), DOF (thin lens: the camera-ray launch only), MESH (scenes with triangle meshes).
+// kBinMax spheres), DOF (thin lens: the camera-ray launch only), MESH (scenes with triangle meshes).
 template <bool F, bool M, bool D, bool ME>
 const void *kb() { return reinterpret_cast<const void *>(k_bounce<F, M, D, ME>); }
 const void *bounce_kernel(bool first, bool dof) {
+    if (S.mesh && S.many) return first ? (dof ? kb<true, true, true, true>() : kb<true, true, false, true>()) : kb<false, true, false, true>();
     if (S.mesh) return first ? (dof ? kb<true, false, true, true>() : kb<true, false, false, true>()) : kb<false, false, false, true>();
     if (first && dof) return S.many ? kb<true, true, true, false>() : kb<true, false, true, false>();
     if (first) return S.many ? kb<true, true, false, false>() : kb<true, false, false, false>();
@@ -856,7 +857,7 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
 
     int nspheres = 0;
     for (int i = 0; i < ngeoms; ++i) nspheres += geoms[i].type == PT_SPHERE;
-    S.many = nspheres > kBinMax && !S.mesh;     // (the mesh variants test every sphere in place)
+    S.many = nspheres > kBinMax;
     if (S.many && ngeoms > 65535) return fail(PT_ERR_INVALID, "pt_init: more than 65535 primitives");
     if (S.many) {        // the later bounces take the spheres from a packed copy of their culling data (ptk::SphereCull)
         std::vector<SphereCull> sc;

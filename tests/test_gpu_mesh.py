@@ -294,3 +294,19 @@ def test_twenty_thousand_triangles(gpu, oracle):
             del os.environ["PT_AMD_MESH_FLAT"]
             gpu.pathtraceFree()
     assert frames[0].max() > 0 and np.array_equal(frames[0].view(np.uint32), frames[1].view(np.uint32))
+
+
+def test_sphere_heavy_scene_with_a_mesh(gpu, oracle):
+    """64 spheres AND a mesh: the sphere-heavy variants of the kernel (packed sphere sweep, per-lane lists) with the mesh walk."""
+    sc = gpu.Scene(os.path.join(SCENES, "spheres64.txt"))
+    sc.set_resolution(96, 72)
+    tris = _icosphere(1)
+    extra = oracle.make_geom(2, 4, (0.5, 5.0, 3.0), (15, 30, 45), (2.5, 2.0, 2.5))
+    small = gpu.Scene(os.path.join(SCENES, "mesh_small.txt")).meshes[4]
+    extra2 = oracle.make_geom(2, 5, (-2.0, 2.5, 3.5), (60, 0, 20), (3, 3, 3))
+    sc.geoms = np.concatenate([sc.geoms.view(oracle.GEOM_DTYPE), extra, extra2]).view(sc.geoms.dtype)
+    n = len(sc.geoms)
+    sc.meshes = {n - 2: tris, n - 1: small}
+    sc.set_resolution = None
+    _render_both(gpu, oracle, sc, 6, [1, 2, 3], (96, 72), dump_bounces=(1, 3))
+    _render_both(gpu, oracle, sc, 4, [5, 6], (96, 72), rank=1, count=2, lens_radius=0.2, focal_distance=8.0)
