@@ -176,6 +176,60 @@ def test_large_frame_properties(gpu):
     assert np.isfinite(full).all() and full.min() >= 0
 
 
+def test_config_c3_as_written_eight_row_shards(gpu):
+    # BASELINE config C3 as written -- cornell.txt at 1280x720, 5000 spp, depth 8, rows dealt to 8 ranks -- on one GPU: every
+    # rank's share (256 iterations per wavefront batch, as bench.py fuses them for 8 ranks) equals the rows of the unsharded
+    # 5000-spp render bit for bit, and so does a second unsharded render under another schedule
+    sc = gpu.Scene(os.path.join(SCENES, "cornell.txt"))
+    sc.set_resolution(1280, 720)
+    P, spp = 1280 * 720, 5000
+
+    def render(batch, pipe, **kw):
+        gpu.pathtraceFree()
+        gpu.pathtraceInit(sc, traceDepth=8, pipeline_depth=pipe, max_batch=batch, **kw)
+        it = 1
+        while it <= spp:
+            n = min(batch, spp - it + 1)
+            gpu.pathtrace_batch(None, 0, it, n)
+            it += n
+        return gpu.readback(P).reshape(720, 1280 * 3)
+
+    full = render(32, 2)
+    assert full.max() > 0 and np.array_equal(render(64, 3).view(np.uint32), full.view(np.uint32))
+    for r in range(8):
+        part = render(256, 2, shard_rank=r, shard_count=8, flags=gpu.PT_FLAG_ACCUM_SHARD_ROWS)
+        mine = np.arange(720) % 8 == r
+        assert np.array_equal(part[mine].view(np.uint32), full[mine].view(np.uint32)), r
+        assert not part[~mine].any()
+    c = gpu.counters()
+    assert int(c.live[1]) == spp * 1280 * 90
+    gpu.pathtraceFree()
+
+
+def test_config_c5_as_written_eight_row_shards(gpu):
+    # BASELINE config C5 as written -- spheres64 at 4096x4096, 16 spp, depth 8, rows dealt to 8 ranks -- on one GPU: every rank's
+    # share (packed accumulator, shard-local radiance buffers, batches of 8 fused like bench.py fuses them) scattered back
+    # into the frame equals the unsharded render bit for bit
+    sc = gpu.Scene(os.path.join(SCENES, "spheres64.txt"))
+    sc.set_resolution(4096, 4096)
+    P, spp = 4096 * 4096, 16
+    gpu.pathtraceFree()
+    gpu.pathtraceInit(sc, pipeline_depth=2, max_batch=8)
+    for it in range(1, spp + 1, 8):
+        gpu.pathtrace_batch(None, 0, it, 8)
+    full = gpu.readback(P).reshape(4096, 4096 * 3)
+    assert full.max() > 0
+    for r in range(8):
+        gpu.pathtraceFree()
+        gpu.pathtraceInit(sc, shard_rank=r, shard_count=8, pipeline_depth=2, max_batch=16, flags=gpu.PT_FLAG_ACCUM_SHARD_ROWS)
+        gpu.pathtrace_batch(None, 0, 1, spp)
+        part = gpu.readback(P).reshape(4096, 4096 * 3)
+        mine = np.arange(4096) % 8 == r
+        assert np.array_equal(part[mine].view(np.uint32), full[mine].view(np.uint32)), r
+        assert not part[~mine].any()
+    gpu.pathtraceFree()
+
+
 def test_headless_driver_renders_the_reference_protocol(gpu, oracle, tmp_path):
     # pt_render = main()/runCuda()/saveImage() of the reference (src/main.cpp:21-113) over the C++ shim:
     # Free -> Init at iteration 0, 1-based iterations with a D2H copy each, save at the end (X mirror, /samples)
