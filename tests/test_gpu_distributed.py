@@ -91,9 +91,10 @@ def _single_rank_frame(pt, iterations, batch):
     return got
 
 
-@pytest.mark.parametrize("every,extra", [("batch", []), ("1", ["--batch", "4"]), ("batch", ["--collective", "reduce", "--batch", "8"])])
-def test_bench_two_ranks_contract(pt, tmp_path, every, extra):
-    # bench.py --gpus 2 WITHOUT a torchrun environment: it starts its two ranks itself (torch.distributed.run as a
+@pytest.mark.parametrize("every,extra,ranks", [("batch", [], 2), ("1", ["--batch", "4"], 2), ("batch", ["--collective", "reduce", "--batch", "8"], 2),
+                                               ("batch", ["--batch", "16"], 4)])
+def test_bench_two_ranks_contract(pt, tmp_path, every, extra, ranks):
+    # bench.py --gpus 2 (and 4) WITHOUT a torchrun environment: it starts its ranks itself (torch.distributed.run as a
     # child, one process per rank -- exactly what the driver launches); gloo stands in for RCCL because both ranks
     # share the box's single GPU.  Rank 0's assembled 1280x720 frame must equal the single-rank render BIT FOR BIT,
     # with the collective after every batch, after every iteration, and as the reduce of zero-padded frames.
@@ -104,7 +105,7 @@ def test_bench_two_ranks_contract(pt, tmp_path, every, extra):
         env.pop(k, None)
     dump = str(tmp_path / "frame.npy")
     steps, warmup = 3, 1
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", str(steps), "--warmup", str(warmup),
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", str(steps), "--warmup", str(warmup),
                         "--collective-every", every, "--per-iteration-sample", "1", "--dump-frame", dump] + extra,
                        capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -112,12 +113,12 @@ def test_bench_two_ranks_contract(pt, tmp_path, every, extra):
     assert len(lines) == 1                                          # rank 0 only
     d = json.loads(lines[0])
     B = int(extra[extra.index("--batch") + 1]) if "--batch" in extra else 32
-    assert d["n_gpus"] == 2 and d["steps"] == steps and d["warmup"] == warmup and d["scaling"] == "strong"
+    assert d["n_gpus"] == ranks and d["steps"] == steps and d["warmup"] == warmup and d["scaling"] == "strong"
     assert "cpu_baseline" not in d and d["value"] > 0
-    assert "rows sharded y%2" in d["config"]["workload"] and d["config"]["iterations_per_step"] == B
+    assert "rows sharded y%%%d" % ranks in d["config"]["workload"] and d["config"]["iterations_per_step"] == B
     assert d["config"]["collective_every"] == every
     # with the collective per batch a rank fuses min(N, PT_MAX_BATCH // B, steps // 8) steps (at least one) into one wavefront batch
-    assert d["config"]["iterations_per_wavefront_batch"] == (B * max(1, min(2, pt.PT_MAX_BATCH // B, steps // 8)) if every == "batch" else 1)
+    assert d["config"]["iterations_per_wavefront_batch"] == (B * max(1, min(ranks, pt.PT_MAX_BATCH // B, steps // 8)) if every == "batch" else 1)
     if every == "batch":
         assert d["config"]["per_iteration_collective"]["value"] > 0   # config C3 as written, timed beside it
     got = np.load(dump)
