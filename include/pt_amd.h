@@ -74,6 +74,17 @@ enum {
                                     lr * shard_count + shard_rank; nLocal * 3 floats): what a multi-GPU run gathers
                                     at rank 0 instead of reducing zero-padded full frames.  pt_readback still returns
                                     a full frame (other rows zero). */
+    PT_FLAG_TRACE_AHEAD = 8,     /* for callers that keep the reference's protocol -- pathtrace(pbo, frame, iter) once per iteration
+                                    with iter = 1, 2, 3, ... (src/main.cpp:97-103): pt_iterate(frame, iter) traces iterations
+                                    iter .. iter + max_batch - 1 as ONE wavefront batch (iterations are independent: RNG keyed on
+                                    iteration / pixel / depth), commits iteration `iter` alone and parks the radiance of the others;
+                                    the calls for iter + 1, iter + 2, ... then only commit theirs, while the free slots of the
+                                    pipeline trace the batches that follow.  The accumulator after every call is bit-identical to
+                                    the one without the flag.  A call that does not continue the sequence (another iter, a
+                                    pt_iterate_batch with count > 1) discards what is parked and starts over; pt_init / pt_free
+                                    discard as well (the reference's camera-move restart, src/main.cpp:91-95).  Needs max_batch > 1
+                                    to have any effect.  PtCounters: `iterations` counts committed iterations; live / light_hits /
+                                    misses also cover the iterations traced ahead. */
     PT_FLAG_DIRECT_LIGHTING = 4  /* README.md:107-108: "a final ray directly to a random point on an emissive object": at the
                                     last of the traceDepth bounces a diffuse scatter aims at a uniformly chosen point of a
                                     uniformly chosen emissive primitive (cosine-weighted), and ONE more bounce collects what

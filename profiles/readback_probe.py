@@ -32,3 +32,26 @@ for pinned in (False, True):
     print("  pt_iterate + pt_readback: %.3f ms per iteration = %.2f G nominal paths/s" % (dt * 1e3, 1280 * 720 * 8 / dt / 1e9))
 L.pt_unpin_host()
 pt.pathtraceFree()
+# the same protocol served from batches traced ahead (PT_FLAG_TRACE_AHEAD, what the shim's pathtraceInit switches on), page-locked
+# buffer; and without the copy: what a caller pays per pt_iterate call
+for ahead, depth in ((32, 2), (32, 3), (64, 3)):
+    pt.pathtraceInit(sc, traceDepth=8, max_batch=ahead, pipeline_depth=depth, trace_ahead=True)
+    assert L.pt_pin_host(buf.ctypes.data, buf.nbytes) == 0
+    for it in range(1, 65):
+        L.pt_iterate(0, it, None)
+    pt.sync()
+    n = 1024
+    t0 = time.perf_counter()
+    for it in range(65, 65 + n):
+        L.pt_iterate(0, it, None)
+        L.pt_readback(buf.ctypes.data_as(C.c_void_p))
+    dt = (time.perf_counter() - t0) / n
+    print("trace ahead %d x %d slots: pt_iterate + pt_readback %.3f ms per iteration = %.2f G nominal paths/s" % (ahead, depth, dt * 1e3, 1280 * 720 * 8 / dt / 1e9))
+    t0 = time.perf_counter()
+    for it in range(65 + n, 65 + 2 * n):
+        L.pt_iterate(0, it, None)
+    pt.sync()
+    dt = (time.perf_counter() - t0) / n
+    print("                          pt_iterate alone          %.3f ms per iteration = %.2f G nominal paths/s" % (dt * 1e3, 1280 * 720 * 8 / dt / 1e9))
+    L.pt_unpin_host()
+    pt.pathtraceFree()

@@ -43,6 +43,7 @@ PT_MAX_BATCH = 256
 PT_FLAG_KERNEL_TIMING = 1
 PT_FLAG_ACCUM_SHARD_ROWS = 2
 PT_FLAG_DIRECT_LIGHTING = 4
+PT_FLAG_TRACE_AHEAD = 8
 
 # every symbol include/pt_amd.h declares
 ABI_SYMBOLS = [
@@ -227,12 +228,16 @@ _scene = None
 
 
 def pathtraceInit(scene, shard_rank=0, shard_count=1, stream=0, accum_dev=0, device=-1, flags=0, traceDepth=None,
-                  pipeline_depth=0, max_batch=0, lens_radius=0.0, focal_distance=0.0, direct_lighting=False):
+                  pipeline_depth=0, max_batch=0, lens_radius=0.0, focal_distance=0.0, direct_lighting=False, trace_ahead=False):
     """reference src/pathtrace.cu:75-85.  `scene` is borrowed until pathtraceFree().
-    lens_radius / focal_distance / direct_lighting: the README extras (depth of field, direct lighting), off by default."""
+    lens_radius / focal_distance / direct_lighting: the README extras (depth of field, direct lighting), off by default.
+    trace_ahead: PT_FLAG_TRACE_AHEAD -- pathtrace(pbo, frame, iter) called once per iteration draws on batches of max_batch
+    iterations traced ahead (same image, bit for bit)."""
     global _scene
     if direct_lighting:
         flags |= PT_FLAG_DIRECT_LIGHTING
+    if trace_ahead:
+        flags |= PT_FLAG_TRACE_AHEAD
     opt = PtOptions(shard_rank, shard_count, device, flags, pipeline_depth, max_batch, stream or None, accum_dev or None,
                     lens_radius, focal_distance)
     geoms = np.ascontiguousarray(scene.geoms)

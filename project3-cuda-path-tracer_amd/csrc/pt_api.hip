@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <string>
 #include <vector>
@@ -107,7 +108,12 @@ struct State {
     bool dof = false;       // thin-lens camera: the k_bounce<true, ., true> variants for the camera-ray bounce
     size_t ldsBytes = 0;
     long long iterations = 0;
-    long long seq = 0;      // iterations enqueued since pt_init: slot = seq % nslots
+    long long seq = 0;      // batches enqueued since pt_init: slot = seq % nslots
+    // PT_FLAG_TRACE_AHEAD: batches traced ahead of the pt_iterate calls that will ask for their iterations, oldest first.
+    // A parked batch occupies its slot (radiance buffers, iteration masks) until its last iteration is committed or it
+    // is discarded; the parked slots are the `ahead.size()` slots before seq % nslots in the rotation.
+    struct Parked { int slot, first, count, next; };   // iterations first .. first + count - 1, the next one to commit = first + next
+    std::deque<Parked> ahead;
     uint32_t launchSerial = 0;   // bounce launches since pt_init
     // host buffer of pt_readback, page-locked on first use so the per-iteration D2H copy of the reference protocol
     // (src/pathtrace.cu:170-171) runs at PCIe rate instead of through a pageable staging copy
@@ -514,6 +520,63 @@ int persistent_grid(const void *kernel, size_t lds, int *grid) {
     return PT_OK;
 }
 
+constexpr int kIterEnd = 1 << 22;     // iterations are 1 .. kIterEnd - 1 (seed bits, pathtrace.cu:43)
+
+// the bounce launches of iterations first_iter .. first_iter + count - 1 as one wavefront batch on the slot's stream; the
+// radiance they find is parked in the slot's buffers until a commit consumes it
+int trace_batch(Slot &sl, int first_iter, int count) {
+    // the slot's radiance buffers must have been consumed by the commit of its previous batch
+    HIPCHECK(hipStreamWaitEvent(sl.stream, sl.evCommitted, 0));
+    const int D = S.prm.traceDepth;
+    for (int d = 1; d <= D; ++d) {
+        int rc = launch_bounce(sl, first_iter, count, d, d == D, sl.contrib);
+        if (rc) {
+            // a launch failed with part of the batch enqueued: counters, parity and radiance buffers are half-updated, so the
+            // renderer refuses further work until it is re-initialised (pt_free still releases everything)
+            if (d > 1) S.init = false;
+            return rc;
+        }
+    }
+    sl.parity ^= 1;   // the last launch re-armed the other half of the slot's counters
+    HIPCHECK(hipEventRecord(sl.evDone, sl.stream));
+    return PT_OK;
+}
+
+// iterations [b0, b1) of the slot's batch of `count` into the accumulator (or nowhere: `discard`), on the caller's stream
+int commit_range(Slot &sl, int count, int b0, int b1, bool discard) {
+    if (S.nLocal > 0) {
+        hipLaunchKernelGGL(k_commit, dim3((S.nLocal + kBlock - 1) / kBlock), dim3(kBlock), 0, S.stream, S.prm, S.image, sl.contrib, sl.hitMask,
+                           count, (S.flags & PT_FLAG_ACCUM_SHARD_ROWS) ? 1 : 0, b0, b1, discard ? 1 : 0);
+        HIPCHECK(hipGetLastError());
+    }
+    return PT_OK;
+}
+
+// PT_FLAG_TRACE_AHEAD: trace the batch that starts at iteration `first` into the next slot of the rotation and park it
+int trace_ahead(int first) {
+    const int count = std::min(S.maxBatch, kIterEnd - first);
+    const int slot = (int)(S.seq % S.nslots);
+    int rc = trace_batch(S.slot[slot], first, count);
+    if (rc) return rc;
+    S.ahead.push_back({slot, first, count, 0});
+    S.seq += 1;
+    return PT_OK;
+}
+
+// ... and drop what is parked: the caller asked for something else.  The iterations not yet committed are consumed without
+// being added, which leaves the slots' buffers zeroed as every batch expects to find them.
+int discard_ahead() {
+    for (const State::Parked &p : S.ahead) {
+        Slot &sl = S.slot[p.slot];
+        HIPCHECK(hipStreamWaitEvent(S.stream, sl.evDone, 0));
+        int rc = commit_range(sl, p.count, p.next, p.count, true);
+        if (rc) return rc;
+        HIPCHECK(hipEventRecord(sl.evCommitted, S.stream));
+    }
+    S.ahead.clear();
+    return PT_OK;
+}
+
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
@@ -700,6 +763,7 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     // distribution over the classes (+ the trash chunk 0).  Chunk size: ~1/1024 of the paths (a power of two, at least
     // 2048), so that the slack stays around 10 % while a chunk outlasts the appends of one memory round trip.
     S.maxBatch = o.max_batch > 0 ? o.max_batch : 1;
+    if (S.maxBatch == 1) S.flags &= ~PT_FLAG_TRACE_AHEAD;   // nothing to trace ahead with: every call traces its own iteration
     // slots are 32-bit element indices with 32-bit byte offsets: paths per pool must stay below 2^30
     const long long maxPaths = (long long)S.nLocal * S.maxBatch;
     if (maxPaths > (1ll << 29)) return fail(PT_ERR_INVALID, "pt_init: max_batch x pixels too large (limit 2^29 paths per batch)");
@@ -966,40 +1030,59 @@ int pt_iterate_batch(int frame, int first_iter, int count, void *rgba8_dev) {
     (void)frame;  // always 0 in the reference (src/main.cpp:102)
     if (!S.init) return fail(PT_ERR_NOT_INIT, "pt_iterate before pt_init");
     if (count < 1 || count > S.maxBatch) return fail(PT_ERR_INVALID, "pt_iterate_batch: count must be 1..max_batch (%d)", S.maxBatch);
-    if (first_iter < 1 || first_iter + count - 1 >= (1 << 22))
+    if (first_iter < 1 || first_iter + count - 1 >= kIterEnd)
         return fail(PT_ERR_INVALID, "pt_iterate: iter must be 1..4194303 (seed bits, pathtrace.cu:43)");
     // every argument is checked BEFORE anything is enqueued: a rejected call leaves the image and the counters untouched
     if (rgba8_dev && (S.flags & PT_FLAG_ACCUM_SHARD_ROWS))
         return fail(PT_ERR_INVALID, "pt_iterate: no PBO conversion from a row-sharded accumulator");
-    Slot &sl = S.slot[S.seq % S.nslots];
-    // the slot's radiance buffers must have been consumed by the commit of its previous batch
-    HIPCHECK(hipStreamWaitEvent(sl.stream, sl.evCommitted, 0));
-    const int D = S.prm.traceDepth;
-    for (int d = 1; d <= D; ++d) {
-        int rc = launch_bounce(sl, first_iter, count, d, d == D, sl.contrib);
-        if (rc) {
-            // a launch failed with part of the batch enqueued: counters, parity and radiance buffers are half-updated, so the
-            // renderer refuses further work until it is re-initialised (pt_free still releases everything)
-            if (d > 1) S.init = false;
-            return rc;
+    int rc;
+    if ((S.flags & PT_FLAG_TRACE_AHEAD) && count == 1) {
+        // the reference's protocol, one call per iteration: the iteration comes out of a batch that was traced ahead
+        if (!S.ahead.empty() && S.ahead.front().first + S.ahead.front().next != first_iter) {
+            rc = discard_ahead();                    // not the iteration the parked batches continue with
+            if (rc) return rc;
         }
+        if (S.ahead.empty()) {
+            rc = trace_ahead(first_iter);
+            if (rc) return rc;
+        }
+        State::Parked &p = S.ahead.front();
+        Slot &sl = S.slot[p.slot];
+        HIPCHECK(hipStreamWaitEvent(S.stream, sl.evDone, 0));
+        rc = commit_range(sl, p.count, p.next, p.next + 1, false);
+        if (rc) return rc;
+        int after = p.first + p.count;               // first iteration behind the parked batches
+        if (++p.next == p.count) {
+            HIPCHECK(hipEventRecord(sl.evCommitted, S.stream));
+            S.ahead.pop_front();
+        }
+        // every free slot traces on: the GPU stays ahead of the caller by at least a batch
+        if (!S.ahead.empty()) after = S.ahead.back().first + S.ahead.back().count;
+        while ((int)S.ahead.size() < S.nslots && after < kIterEnd) {
+            rc = trace_ahead(after);
+            if (rc) return rc;
+            after = S.ahead.back().first + S.ahead.back().count;
+        }
+    } else {
+        if (!S.ahead.empty()) {
+            rc = discard_ahead();
+            if (rc) return rc;
+        }
+        Slot &sl = S.slot[S.seq % S.nslots];
+        rc = trace_batch(sl, first_iter, count);
+        if (rc) return rc;
+        // commit on the caller's stream: commits are therefore ordered like the pt_iterate calls
+        HIPCHECK(hipStreamWaitEvent(S.stream, sl.evDone, 0));
+        rc = commit_range(sl, count, 0, count, false);
+        if (rc) return rc;
+        HIPCHECK(hipEventRecord(sl.evCommitted, S.stream));
+        S.seq += 1;
     }
-    sl.parity ^= 1;   // the last launch re-armed the other half of the slot's counters
-    HIPCHECK(hipEventRecord(sl.evDone, sl.stream));
-    // commit on the caller's stream: commits are therefore ordered like the pt_iterate calls
-    HIPCHECK(hipStreamWaitEvent(S.stream, sl.evDone, 0));
-    if (S.nLocal > 0) {
-        hipLaunchKernelGGL(k_commit, dim3((S.nLocal + kBlock - 1) / kBlock), dim3(kBlock), 0, S.stream, S.prm, S.image, sl.contrib, sl.hitMask,
-                           count, (S.flags & PT_FLAG_ACCUM_SHARD_ROWS) ? 1 : 0);
-        HIPCHECK(hipGetLastError());
-    }
-    HIPCHECK(hipEventRecord(sl.evCommitted, S.stream));
     if (rgba8_dev) {
         hipLaunchKernelGGL(k_to_rgba8, dim3((S.P + kBlock - 1) / kBlock), dim3(kBlock), 0, S.stream, S.image, S.P,
                            first_iter + count - 1, reinterpret_cast<uchar4 *>(rgba8_dev));
         HIPCHECK(hipGetLastError());
     }
-    S.seq += 1;
     S.iterations += count;
     return PT_OK;
 }

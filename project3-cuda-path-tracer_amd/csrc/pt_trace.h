@@ -1055,8 +1055,12 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
             if (alive) {
                 const ArgsPtr A = launder(kargs);
                 // earlier waves' survivors of this class (kWaves = 4: three conditional terms, no loop)
-                const uint32_t w0 = wv[cls], w1 = wv[kCls + cls], w2 = wv[2 * kCls + cls];
-                const uint32_t waveOff = (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u);
+                uint32_t waveOff = 0u;
+#pragma unroll
+                for (int w = 0; w < kWaves - 1; ++w) {
+                    const uint32_t wq = wv[w * kCls + cls];
+                    waveOff += wave > w ? wq : 0u;
+                }
                 const uint32_t r = waveOff + rank, sp = s_base[kCls + cls];
                 const uint32_t slot = r < sp ? s_base[cls] + r : s_base[2 * kCls + cls] + (r - sp);
                 float *dst = A->out.base;
@@ -1111,7 +1115,11 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
 // `compactRows`: the accumulator holds only this shard's rows (PT_FLAG_ACCUM_SHARD_ROWS), pixel j of the shard
 // at image[3j]; otherwise it is the full frame indexed by the global pixel index.
 // `batch` iterations were traced together; their radiance buffers are consumed in iteration order.
-__global__ __launch_bounds__(kBlock) void k_commit(KParams prm, float *image, float *contrib, uint32_t *hitMask, int batch, int compactRows) {
+// [b0, b1) = the iterations of the batch this launch consumes (the whole batch: 0, batch); the others stay parked -- their
+// radiance entries and mask bits untouched -- for a later launch (PT_FLAG_TRACE_AHEAD: pt_iterate commits ONE iteration of a
+// batch that was traced ahead).  `discard`: consume without adding (a traced-ahead batch the caller did not come back for).
+__global__ __launch_bounds__(kBlock) void k_commit(KParams prm, float *image, float *contrib, uint32_t *hitMask, int batch, int compactRows,
+                                                   int b0, int b1, int discard) {
     const int j = blockIdx.x * kBlock + threadIdx.x;
     if (j >= prm.nLocal) return;
     const int lr = j / prm.W;
@@ -1124,11 +1132,18 @@ __global__ __launch_bounds__(kBlock) void k_commit(KParams prm, float *image, fl
     // together, the additions stay in iteration order.  (A rank of 8 traces 256 iterations per batch: ~75 entries per lit pixel,
     // one memory round trip each if taken one by one.)
     constexpr int kWordsMax = (PT_MAX_BATCH + 31) / 32;
-    uint32_t mw[kWordsMax];
+    uint32_t mw[kWordsMax], keep[kWordsMax];
     uint32_t any = 0u;
 #pragma unroll
     for (int w = 0; w < kWordsMax; ++w) {
-        mw[w] = w * 32 < batch ? hitMask[(size_t)w * frame + pix] : 0u;
+        // bits of word w inside [b0, b1)
+        const int lo = b0 - 32 * w, hi = b1 - 32 * w;
+        const uint32_t below = lo <= 0 ? 0u : (lo >= 32 ? 0xffffffffu : (1u << lo) - 1u);      // bits < lo
+        const uint32_t upto = hi <= 0 ? 0u : (hi >= 32 ? 0xffffffffu : (1u << hi) - 1u);        // bits < hi
+        const uint32_t range = upto & ~below;
+        const uint32_t word = (w * 32 < batch && range != 0u) ? hitMask[(size_t)w * frame + pix] : 0u;
+        mw[w] = word & range;
+        keep[w] = word & ~range;
         any |= mw[w];
     }
     if (any == 0u) return;
@@ -1137,7 +1152,7 @@ __global__ __launch_bounds__(kBlock) void k_commit(KParams prm, float *image, fl
     for (int w = 0; w < kWordsMax; ++w) {
         uint32_t m = mw[w];
         if (m == 0u) continue;
-        hitMask[(size_t)w * frame + pix] = 0u;
+        hitMask[(size_t)w * frame + pix] = keep[w];
         float *const base = contrib + 3 * ((size_t)(w * 32) * frame + pix);
         while (m) {                                            // ascending bits = iteration order
             int b[16];
@@ -1155,13 +1170,13 @@ __global__ __launch_bounds__(kBlock) void k_commit(KParams prm, float *image, fl
 #pragma unroll
             for (int q = 0; q < 16; ++q)
                 if (b[q] >= 0) {
-                    ax += v[q][0]; ay += v[q][1]; az += v[q][2];
+                    if (!discard) { ax += v[q][0]; ay += v[q][1]; az += v[q][2]; }
                     float *c = base + 3 * (size_t)b[q] * frame;
                     c[0] = 0.0f; c[1] = 0.0f; c[2] = 0.0f;
                 }
         }
     }
-    px[0] = ax; px[1] = ay; px[2] = az;
+    if (!discard) { px[0] = ax; px[1] = ay; px[2] = az; }
 }
 
 // ---- sendImageToPBO (reference src/pathtrace.cu:48-68) ---------------------------------------------

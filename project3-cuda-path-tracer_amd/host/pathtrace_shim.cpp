@@ -28,6 +28,20 @@ void pathtraceInit(Scene *scene) {
     opt.lens_radius = extraLens;        // ... unless pathtraceExtras() switched a README extra on
     opt.focal_distance = extraFocal;
     if (extraDirect) opt.flags |= PT_FLAG_DIRECT_LIGHTING;
+    // The reference's host calls pathtrace(pbo, frame, iter) once per iteration with iter = 1, 2, 3, ... (src/main.cpp:97-103):
+    // the library traces such a sequence in wavefront batches AHEAD of the calls (PT_FLAG_TRACE_AHEAD; same image after every
+    // call, bit for bit), so a call costs a commit instead of eight small dependent launches.  A camera move goes through
+    // pathtraceFree / pathtraceInit (src/main.cpp:91-95), which drops whatever was traced ahead.
+    // PT_AMD_TRACE_AHEAD=<iterations per batch> overrides (0 or 1: off, every call traces its own iteration).
+    int ahead = 32;
+    if (const char *e = getenv("PT_AMD_TRACE_AHEAD")) ahead = atoi(e);
+    if (scene->state.iterations < (unsigned)(ahead > 0 ? ahead : 0)) ahead = (int)scene->state.iterations;
+    if (ahead > PT_MAX_BATCH) ahead = PT_MAX_BATCH;
+    if (ahead > 1) {
+        opt.flags |= PT_FLAG_TRACE_AHEAD;
+        opt.max_batch = ahead;
+        opt.pipeline_depth = 2;         // one batch being consumed, one being traced (a third in flight only competes with the copy)
+    }
     // `mesh` objects (README.md:236): their triangles go in before the geoms that refer to them.  (Built against the
     // reference's own scene.h, whose loader knows no meshes, the shim registers none.)
     std::vector<PtMesh> meshes;
