@@ -21,7 +21,12 @@ own rows (packed), and ONE collective -- a gather of the row blocks to rank 0, R
 `--collective reduce` runs that reduce instead).  `--collective-every batch` (default) issues it after every
 committed wavefront batch, `--collective-every 1` after every single iteration (BASELINE config C3 as written:
 one pt_iterate + one collective per iteration).  The default run also times a bounded sample of the per-iteration
-mode and reports it in config.per_iteration_collective.  Fixed total work -> "scaling": "strong".
+mode and reports it in config.per_iteration_collective.
+`--scaling weak` (default): a step on N GPUs is `--batch` x N iterations of the whole frame -- every rank traces its 1/N of
+the rows for N times the iterations, as many paths per step as the single GPU (a renderer's weak scaling: N times the
+samples per pixel in the same time); value = all ranks' paths / the slowest rank's time.  `--scaling strong`: a step is
+`--batch` iterations whatever N (config C3 as written: a fixed number of samples, divided; ranks then fuse steps into
+fatter wavefront batches).  At N = 1 the two are the same run.
 
 Prints ONE JSON line on rank 0, with `roofline` (dominant kernel = the fused bounce kernel, HIP-event timed on the
 streams it runs on, against the 8 TB/s HBM peak) and `cpu_baseline` (the single-thread CPU oracle on a bounded
@@ -51,8 +56,9 @@ def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None,
-                    help="steps timed (one step = --batch iterations of the whole frame); default 32 on one GPU (1024 spp = "
-                         "16 x the 64 spp of BASELINE config C2), 157 on N GPUs (5024 spp, config C3's 5000 rounded up to whole steps)")
+                    help="steps timed (one step = --batch iterations of the whole frame, times N with --scaling weak); default 32 "
+                         "on one GPU (1024 spp = 16 x the 64 spp of BASELINE config C2); on N GPUs config C3's 5000 spp rounded up to "
+                         "whole steps (157 with --scaling strong)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed steps first (default 4)")
     ap.add_argument("--scene", default=os.path.join(ROOT, "scenes", "cornell.txt"))
     ap.add_argument("--res", type=int, nargs=2, default=[1280, 720])
@@ -60,6 +66,11 @@ def parse(argv=None):
     ap.add_argument("--cpu-spp", type=int, default=40, help="spp of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--pipeline", type=int, default=2, help="batches in flight (PtOptions.pipeline_depth; 0 = library default 3)")
     ap.add_argument("--batch", type=int, default=32, help="iterations per step = iterations traced as one wavefront batch")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1.  weak (default): a step is --batch x N iterations of the whole frame, so a rank's share of a step -- "
+                         "its 1/N of the rows of N times the iterations -- is as many paths as the single GPU's step (more GPUs = "
+                         "more samples per pixel in the same time); strong: a step is --batch iterations whatever N (BASELINE "
+                         "config C3 as written: a fixed number of samples, divided)")
     ap.add_argument("--collective-every", default="batch", choices=["batch", "1"],
                     help="N > 1: assemble the frame at rank 0 after every wavefront batch, or after every iteration")
     ap.add_argument("--collective", default="gather", choices=["gather", "reduce"],
@@ -155,8 +166,10 @@ def main():
     import torch.distributed as dist
 
     B = args.batch
+    weak = args.scaling == "weak"
+    I = B * (world if weak else 1)                          # iterations of the whole frame per step
     if args.steps is None:
-        args.steps = 32 if world == 1 else (5000 + B - 1) // B
+        args.steps = 32 if world == 1 else (5000 + I - 1) // I
     if args.warmup is None:
         args.warmup = 4
     if not torch.cuda.is_available():
@@ -202,24 +215,23 @@ def main():
         ptdist.gather_frame(accum, bufs, frame, W, H, dst=0, collective=args.collective)
 
     def run_steps(first_iter, steps, every):
-        """`steps` steps of B iterations from `first_iter`.  every == "batch": one wavefront batch per step, the frame
-        assembled at rank 0 after it; every == "1": B single-iteration calls per step, each followed by the collective."""
+        """`steps` steps of I iterations from `first_iter`.  every == "batch": wavefront batches of `maxb` iterations (one or
+        several steps each, or a part of one), the frame assembled at rank 0 after every batch; every == "1": I single-iteration
+        calls per step, each followed by the collective."""
         it = first_iter
-        done = 0
-        while done < steps:
+        end = first_iter + steps * I
+        while it < end:
             if every == "batch":
-                n = min(fuse, steps - done)
-                pt.pathtrace_batch(None, 0, it, B * n)
+                n = min(maxb, end - it)
+                pt.pathtrace_batch(None, 0, it, n)
                 if world > 1:
                     collect()
+                it += n
             else:
-                n = 1
-                for k in range(B):
-                    pt.pathtrace(None, 0, it + k, readback=False)
-                    if world > 1:
-                        collect()
-            it += B * n
-            done += n
+                pt.pathtrace(None, 0, it, readback=False)
+                if world > 1:
+                    collect()
+                it += 1
         return it
 
     def barrier():
@@ -244,8 +256,13 @@ def main():
     # traces `fuse` consecutive steps as ONE wavefront batch (at most PT_MAX_BATCH iterations), which keeps its launches fat
     # -- but not so few batches that the two in flight never overlap: at least 8 per timed run (measured on a rank of 8 and of
     # 4 at the driver's 20 steps: batches of 64 beat 128 and 256 by 2-5 %)
-    fuse = max(1, min(world, pt.PT_MAX_BATCH // B, max(1, args.steps // 8))) if every == "batch" else 1
-    maxb = B * fuse if every == "batch" else 1
+    # Weak scaling: a step is I = B x N iterations, traced as one wavefront batch (in pieces of PT_MAX_BATCH should it be larger).
+    if weak:
+        fuse = 1
+        maxb = min(I, pt.PT_MAX_BATCH) if every == "batch" else 1
+    else:
+        fuse = max(1, min(world, pt.PT_MAX_BATCH // B, max(1, args.steps // 8))) if every == "batch" else 1
+        maxb = B * fuse if every == "batch" else 1
     # ---- pass A: the headline number ----------------------------------------------------------
     init(0, args.pipeline, maxb)
     nxt = run_steps(1, args.warmup, every)
@@ -263,7 +280,7 @@ def main():
         init(0, args.pipeline, 1)
         nxt1 = run_steps(1, 1, "1")
         dt1 = timed(nxt1, args.per_iteration_sample, "1")
-        per_iter = {"value": round(P * D * B * args.per_iteration_sample / dt1 / 1e6, 2), "unit": "Mpaths/s",
+        per_iter = {"value": round(P * D * I * args.per_iteration_sample / dt1 / 1e6, 2), "unit": "Mpaths/s",
                     "steps": args.per_iteration_sample,
                     "mode": "pt_iterate + one %s per iteration (BASELINE config C3 as written)" % args.collective}
 
@@ -279,7 +296,7 @@ def main():
     cnt = pt.counters()
     pt.pathtraceFree()
 
-    iters_timed = args.steps * B
+    iters_timed = args.steps * I
     live = [int(cnt.live[d]) for d in range(D + 2)]
     # paths that actually travel through the path pools: a survivor that certainly misses everything ends at its scatter and
     # is counted in live[d + 1] (it does enter that bounce and miss) without ever being written or read
@@ -338,14 +355,14 @@ def main():
             "value": round(nominal / dt / 1e6, 2), "unit": "Mpaths/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s %dx%d, %d bounces, %d spp per step x %d steps%s" % (
-                           os.path.relpath(args.scene, ROOT), W, H, D, B, args.steps,
+                           os.path.relpath(args.scene, ROOT), W, H, D, I, args.steps,
                            "" if world == 1 else ", rows sharded y%%%d + RCCL %s of the row blocks per %s" % (
                                world, args.collective, "batch" if every == "batch" else "iteration")),
-                       "iterations_per_step": B,
-                       "paths_per_step_nominal": P * D * B,
+                       "iterations_per_step": I,
+                       "paths_per_step_nominal": P * D * I,
                        "ms_per_iteration": round(dt / iters_timed * 1e3, 5),
                        "iterations_per_wavefront_batch": maxb,
                        "batches_in_flight": args.pipeline if args.pipeline > 0 else 3,

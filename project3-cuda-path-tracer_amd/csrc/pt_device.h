@@ -43,6 +43,11 @@ __device__ __forceinline__ void probe(int k) {
         atomicAdd(&g_probe[2 * k + 1], (unsigned long long)__popcll(m));
     }
 }
+#elif defined(PT_MARK)
+// static phase marks in the ISA listing (make marks; profiles/phase_instructions.py counts the instructions between them)
+#define probe(k) asm volatile("; PTMARK " #k)
+__device__ __forceinline__ void censusEnter() {}
+__device__ __forceinline__ void censusLeave() {}
 #else
 __device__ __forceinline__ void probe(int) {}
 __device__ __forceinline__ void censusEnter() {}

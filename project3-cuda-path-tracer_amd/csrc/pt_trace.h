@@ -552,6 +552,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
         // that live, spilled, across the whole tile
         uint32_t tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
+        probe(14);                                              // (a tile starts)
         uint32_t Tnext = T + gridDim.x;     // FIRST: simply the next one
         bool valid;
         uint32_t idx = 0;
@@ -667,6 +668,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
 
             if (FIRST) { if (inScene) probe(8); } else probe(7);                                   // tiles (waves with at least one valid path) and valid paths
             // nearest hit, geoms in file order, strict '<' so the first geom wins ties (S3)
+            probe(15);                                          // (nearest-hit loop)
             float tbest = 0.0f;
             int hit = -1;
             F3 P = f3(0, 0, 0), nsrc = f3(0, 0, 0);
@@ -820,6 +822,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
                     while (sweep(std::false_type{})) {}
                 }
             }
+            probe(16);                                          // (shading)
             if (hit < 0) {
                 missedI = 1u;                                    // S4: background is black
             } else {
@@ -1006,12 +1009,14 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
                 }
             }
         }
+        probe(17);                                              // (next tile's loads)
         nLight += lightHitI;
         nMiss += missedI;
         if (!FIRST) {       // the next tile of this workgroup that needs work: its loads fly during the compaction below
             while (Tnext < numTiles && !setupTile(Tnext, tid, nextMeta)) Tnext += gridDim.x;
             if (Tnext < numTiles) loadTile(nextMeta, nextRegs);
         }
+        probe(18);                                              // (compaction)
         const bool alive = aliveI != 0u, smallCand = smallCandI != 0u;
 
         if (!launder(kargs)->lastBounce) {                       // S8: compaction into `out`, binned by class
@@ -1052,6 +1057,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
             asm volatile("" ::: "memory");
             __syncthreads();
 #endif
+            probe(19);                                          // (stores)
             if (alive) {
                 const ArgsPtr A = launder(kargs);
                 // earlier waves' survivors of this class (kWaves = 4: three conditional terms, no loop)
@@ -1079,6 +1085,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
             wvSel ^= (uint32_t)(kWaves * kCls);
             if (lane < kCls) s_wave[wvSel + wave * kCls + lane] = 0u;
         }
+        probe(20);                                              // (tile done)
         T = Tnext;
     }
     censusLeave();

@@ -91,9 +91,10 @@ def _single_rank_frame(pt, iterations, batch):
     return got
 
 
-@pytest.mark.parametrize("every,extra,ranks", [("batch", [], 2), ("1", ["--batch", "4"], 2), ("batch", ["--collective", "reduce", "--batch", "8"], 2),
-                                               ("batch", ["--batch", "16"], 4)])
-def test_bench_two_ranks_contract(pt, tmp_path, every, extra, ranks):
+@pytest.mark.parametrize("every,extra,ranks,scaling", [("batch", [], 2, "weak"), ("1", ["--batch", "4"], 2, "weak"),
+                                                       ("batch", ["--collective", "reduce", "--batch", "8"], 2, "strong"),
+                                                       ("batch", ["--batch", "16"], 4, "strong"), ("batch", ["--batch", "96"], 3, "weak")])
+def test_bench_two_ranks_contract(pt, tmp_path, every, extra, ranks, scaling):
     # bench.py --gpus 2 (and 4) WITHOUT a torchrun environment: it starts its ranks itself (torch.distributed.run as a
     # child, one process per rank -- exactly what the driver launches); gloo stands in for RCCL because both ranks
     # share the box's single GPU.  Rank 0's assembled 1280x720 frame must equal the single-rank render BIT FOR BIT,
@@ -106,23 +107,35 @@ def test_bench_two_ranks_contract(pt, tmp_path, every, extra, ranks):
     dump = str(tmp_path / "frame.npy")
     steps, warmup = 3, 1
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", str(steps), "--warmup", str(warmup),
-                        "--collective-every", every, "--per-iteration-sample", "1", "--dump-frame", dump] + extra,
+                        "--collective-every", every, "--per-iteration-sample", "1", "--dump-frame", dump] + extra
+                       + ([] if scaling == "weak" else ["--scaling", "strong"]),                # (weak is the default)
                        capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                          # rank 0 only
     d = json.loads(lines[0])
     B = int(extra[extra.index("--batch") + 1]) if "--batch" in extra else 32
-    assert d["n_gpus"] == ranks and d["steps"] == steps and d["warmup"] == warmup and d["scaling"] == "strong"
+    # weak scaling: a step is B x N iterations of the whole frame (a rank's share = the single GPU's step); strong: B iterations
+    I = B * ranks if scaling == "weak" else B
+    assert d["n_gpus"] == ranks and d["steps"] == steps and d["warmup"] == warmup and d["scaling"] == scaling
     assert "cpu_baseline" not in d and d["value"] > 0
-    assert "rows sharded y%%%d" % ranks in d["config"]["workload"] and d["config"]["iterations_per_step"] == B
+    assert "rows sharded y%%%d" % ranks in d["config"]["workload"] and d["config"]["iterations_per_step"] == I
+    assert d["config"]["paths_per_step_nominal"] == 1280 * 720 * 8 * I
+    assert abs(d["value"] - 1280 * 720 * 8 * I * steps / (d["ms_per_step"] * steps * 1e-3) / 1e6) <= 1e-3 * d["value"]
     assert d["config"]["collective_every"] == every
-    # with the collective per batch a rank fuses min(N, PT_MAX_BATCH // B, steps // 8) steps (at least one) into one wavefront batch
-    assert d["config"]["iterations_per_wavefront_batch"] == (B * max(1, min(ranks, pt.PT_MAX_BATCH // B, steps // 8)) if every == "batch" else 1)
+    # strong, collective per batch: a rank fuses min(N, PT_MAX_BATCH // B, steps // 8) steps (at least one) into one wavefront batch;
+    # weak: a step is one wavefront batch, in pieces of PT_MAX_BATCH iterations should it be larger (3 x 96 = 288 -> 256 + 32)
+    if every != "batch":
+        wb = 1
+    elif scaling == "weak":
+        wb = min(I, pt.PT_MAX_BATCH)
+    else:
+        wb = B * max(1, min(ranks, pt.PT_MAX_BATCH // B, steps // 8))
+    assert d["config"]["iterations_per_wavefront_batch"] == wb
     if every == "batch":
         assert d["config"]["per_iteration_collective"]["value"] > 0   # config C3 as written, timed beside it
     got = np.load(dump)
-    want = _single_rank_frame(pt, (steps + warmup) * B, B)
+    want = _single_rank_frame(pt, (steps + warmup) * I, min(I, 64))
     assert want.max() > 0
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
