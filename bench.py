@@ -376,8 +376,12 @@ def main():
             out["config"]["per_iteration_collective"] = per_iter
         if world == 1 and args.cpu_spp > 0:
             out["cpu_baseline"] = cpu_baseline(args, scene)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
+        # orderly exit: nobody leaves (and tears its HIP context down) while another rank still works
+        torch.cuda.synchronize()
+        dist.barrier()
+        del accum, frame, bufs
         dist.destroy_process_group()
 
 

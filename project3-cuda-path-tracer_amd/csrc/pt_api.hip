@@ -308,14 +308,15 @@ double wall_box(const PtGeom &g, WallBox &w, double *omax = nullptr) {
     return S_;
 }
 
-// n / d for every n < 2^27 as (n * magic) >> shift: with s = ceil(log2 d), shift = 28 + s and magic = ceil(2^shift / d)
-// (< 2^29) the error e = magic * d - 2^shift is below d <= 2^s, so n * e < 2^(27 + s) < 2^shift and the quotient is exact
-// (Granlund-Montgomery); n * magic < 2^56 fits the 64-bit product.
+// n / d for every n < 2^30 as (n * magic) >> shift: with s = ceil(log2 d), shift = 30 + s and magic = ceil(2^shift / d)
+// (< 2^31) the error e = magic * d - 2^shift is below d <= 2^s, so n * e < 2^(30 + s) = 2^shift and the quotient is exact
+// (Granlund-Montgomery); n * magic < 2^61 fits the 64-bit product.  (The camera-ray bounce divides path indices up to
+// pixels x max_batch <= 2^29 by the shard's pixel count; rounds 1-2 used shift = 28 + s, exact only below 2^28.)
 void magic_divisor(uint32_t d, uint32_t &magic, uint32_t &shift) {
     if (d <= 1) { magic = 1; shift = 0; return; }
     uint32_t s = 0;
     while ((1ull << s) < d) ++s;
-    shift = 28 + s;
+    shift = 30 + s;
     magic = (uint32_t)(((1ull << shift) + d - 1) / d);
 }
 
@@ -722,9 +723,9 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     for (uint32_t d : {(uint32_t)Wd, (uint32_t)std::max(S.nLocal, 1)}) {       // self-check on the edges of every quotient range
         uint32_t m, sh;
         magic_divisor(d, m, sh);
-        for (uint64_t q = 0; q * d < (1ull << 27); q = q < 64 ? q + 1 : q * 2 + 1)
-            for (uint64_t n : {q * d, q * d + d - 1})
-                if (n < (1ull << 27) && (uint32_t)((n * m) >> sh) != (uint32_t)(n / d))
+        for (uint64_t q = 0; q * d < (1ull << 30); q = q < 64 ? q + 1 : q * 2 + 1)
+            for (uint64_t n : {q * d, q * d + d - 1, (uint64_t)((1ull << 30) - 1) - q})
+                if (n < (1ull << 30) && (uint32_t)((n * m) >> sh) != (uint32_t)(n / d))
                     return fail(PT_ERR_INVALID, "pt_init: magic division self-check failed for d=%u n=%llu", d, (unsigned long long)n);
     }
     k.ngeoms = ngeoms; k.nmats = nmats;

@@ -66,7 +66,7 @@ struct KParams {
     int   poolChunks;   // chunks of a path pool (chunk 0 is the trash chunk: never handed out, written only after a fault)
     int   chunkShift;   // log2(paths per chunk), >= kMinChunkShift
     int   sceneRect[4]; // union of the primitives' pixel rectangles (GeomDev::rect): camera rays outside miss everything
-    // n / W and n / nLocal for n < 2^27 as (n * magic) >> shift (exact, see pt_init): the two divisions of the
+    // n / W and n / nLocal for n < 2^30 as (n * magic) >> shift (exact, see pt_init: magic_divisor): the two divisions of the
     // camera-ray bounce cost ~50 instructions each when the compiler expands them
     uint32_t magicW, shiftW, magicN, shiftN;
     int   contribLocal; // the radiance buffers and iteration masks hold only this shard's pixels, indexed x + (y / shardCount) * W
