@@ -32,6 +32,26 @@ for run in range(2):
     digests.append(hashlib.sha256(img.tobytes()).hexdigest()[:16])
     print("run %d: %d iterations in %.1f s = %.1f G nominal paths/s, mean %.3f, sha %s" % (
         run, total, dt, total * 1280 * 720 * 8 / dt / 1e9, float(img.mean()) / total, digests[-1]), flush=True)
+# ... and the same iterations through the reference's protocol, one pt_iterate call per iteration, served from batches traced
+# ahead (PT_FLAG_TRACE_AHEAD): the same frame, bit for bit
 pt.pathtraceFree()
-assert digests[0] == digests[1], digests
+pt.pathtraceInit(sc, traceDepth=8, max_batch=32, pipeline_depth=2, trace_ahead=True)
+L = pt.lib()
+t0 = time.time()
+first = 4194303 - total
+for it in range(first, first + total):
+    rc = L.pt_iterate(0, it, None)
+    assert rc == 0, pt.lib().pt_last_error()
+    if (it - first + 1) % 100000 == 0:
+        print("run 2 (trace-ahead, one call per iteration): %d iterations, %.1f s" % (it - first + 1, time.time() - t0), flush=True)
+pt.sync()
+dt = time.time() - t0
+c = pt.counters()
+assert c.iterations == total
+img = pt.readback(1280 * 720)
+digests.append(hashlib.sha256(img.tobytes()).hexdigest()[:16])
+print("run 2: %d pt_iterate calls in %.1f s = %.3f ms per call = %.1f G nominal paths/s, sha %s" % (
+    total, dt, dt / total * 1e3, total * 1280 * 720 * 8 / dt / 1e9, digests[-1]), flush=True)
+pt.pathtraceFree()
+assert digests[0] == digests[1] == digests[2], digests
 print("identical")
