@@ -1020,6 +1020,12 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
         const bool alive = aliveI != 0u, smallCand = smallCandI != 0u;
 
         if (!launder(kargs)->lastBounce) {                       // S8: compaction into `out`, binned by class
+            // The compaction is the tile's latency chain (barrier, reservation round trip, barrier, stores): its waves issue
+            // ahead of the ones that are tracing, so the chain is not stretched by instruction arbitration.  Measured
+            // (profiles/r02_priority_experiments.txt): a launch on its own 5-6 % shorter, the pipelined rate +0.5 % (Cornell)
+            // / +1.6 % (glass, depth 16) / +-0 (64 spheres); any level above 0 does; the reserving wave alone, or the window
+            // opened at the next tile's loads already, gain nothing.
+            __builtin_amdgcn_s_setprio(3);
             const int wave = (int)(tid >> 6), lane = (int)(tid & 63u);
             uint32_t *wv = s_wave + wvSel;                       // this tile's half of the double-buffered counts
             // same-class mask of this lane from four bit ballots (the sign compares already are the ballots)
@@ -1084,6 +1090,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
             // row come after the next tile's first barrier).  s_base is rewritten only after the next tile's first barrier.
             wvSel ^= (uint32_t)(kWaves * kCls);
             if (lane < kCls) s_wave[wvSel + wave * kCls + lane] = 0u;
+            __builtin_amdgcn_s_setprio(0);
         }
         probe(20);                                              // (tile done)
         T = Tnext;
