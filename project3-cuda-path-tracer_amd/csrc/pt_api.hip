@@ -341,7 +341,10 @@ void pack_material(const PtMaterial &m, MaterialDev &d) {
 // with M = [view | -pixLenX right | -pixLenY up].  The convex hull of the projected corners contains the projection of
 // the primitive; its bounding rectangle is widened by 2 pixels.  Any corner not strictly in front of the eye, or a
 // singular M, disables the culling for this primitive (whole frame).
-void project_geom(const PtGeom &g, const KParams &k, int rect[4], const float *box = nullptr) {
+// `hull` (optional): the eight projected corners (continuous pixel coordinates) when the rectangle is a real one, else empty
+void project_geom(const PtGeom &g, const KParams &k, int rect[4], const float *box = nullptr, std::vector<std::pair<double, double>> *hull = nullptr) {
+    if (hull) hull->clear();
+    std::vector<std::pair<double, double>> pts;
     rect[0] = rect[1] = 0;
     rect[2] = k.W - 1;
     rect[3] = k.H - 1;
@@ -379,12 +382,37 @@ void project_geom(const PtGeom &g, const KParams &k, int rect[4], const float *b
         if (!std::isfinite(px) || !std::isfinite(py)) return;
         xmin = std::min(xmin, px); xmax = std::max(xmax, px);
         ymin = std::min(ymin, py); ymax = std::max(ymax, py);
+        pts.emplace_back(px, py);
     }
+    if (hull) *hull = pts;
     auto clampi = [](double v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : (int)v); };
     rect[0] = clampi(std::floor(xmin) - 2, 0, k.W);
     rect[1] = clampi(std::floor(ymin) - 2, 0, k.H);
     rect[2] = clampi(std::ceil(xmax) + 2, -1, k.W - 1);
     rect[3] = clampi(std::ceil(ymax) + 2, -1, k.H - 1);
+}
+
+// Pixels of image row y from which camera rays can reach a primitive whose projected corners are `pts`: the projection of
+// the primitive lies in the convex hull of the points, a ray of row y passes the image plane at py in [y, y + 1], so the
+// candidates are the x-extent of  hull /\ {y - 2 <= py <= y + 3}  widened by 2 pixels (the rectangle's margins, per row).
+// The hull's extent inside a horizontal strip is attained at a vertex inside the strip or where an edge -- of the hull, but
+// taking every segment between two of the points only adds points of the hull -- crosses one of the strip's two borders.
+// false: the strip misses the hull.
+bool hull_row_span(const std::vector<std::pair<double, double>> &pts, int y, double &xmin, double &xmax) {
+    const double lo = (double)y - 2.0, hi = (double)y + 3.0;
+    xmin = INFINITY; xmax = -INFINITY;
+    for (size_t i = 0; i < pts.size(); ++i) {
+        if (pts[i].second >= lo && pts[i].second <= hi) { xmin = std::min(xmin, pts[i].first); xmax = std::max(xmax, pts[i].first); }
+        for (size_t j = i + 1; j < pts.size(); ++j)
+            for (double border : {lo, hi}) {
+                const double y0 = pts[i].second, y1 = pts[j].second;
+                if ((y0 < border) != (y1 < border)) {
+                    const double x = pts[i].first + (pts[j].first - pts[i].first) * ((border - y0) / (y1 - y0));
+                    xmin = std::min(xmin, x); xmax = std::max(xmax, x);
+                }
+            }
+    }
+    return xmin <= xmax;
 }
 
 // host mirrors of the glm ops used for the camera basis (same op order as ptd::)
@@ -815,6 +843,7 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     std::vector<ptd::MeshNode> meshNodes;
     std::vector<ptd::MeshTri> meshTris;
     const bool flatMeshes = getenv("PT_AMD_MESH_FLAT") && atoi(getenv("PT_AMD_MESH_FLAT"));   // tests only: no hierarchy
+    std::vector<std::vector<std::pair<double, double>>> hulls(ngeoms ? ngeoms : 1);   // projected corners per primitive (camera-ray culling)
     for (int i = 0; i < ngeoms; ++i) {
         float box[6];
         const bool isMesh = geoms[i].type == PT_MESH;
@@ -832,7 +861,7 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
             if (k.nCubes >= 32767) return fail(PT_ERR_INVALID, "pt_init: more than 32767 cubes");
             hg[i].frameSlot = (short)k.nCubes++;
         }
-        project_geom(geoms[i], k, hg[i].rect, isMesh ? box : nullptr);
+        project_geom(geoms[i], k, hg[i].rect, isMesh ? box : nullptr, &hulls[i]);
         if (S.dof) {        // rays start anywhere on the lens: the pinhole projection bounds nothing
             hg[i].rect[0] = hg[i].rect[1] = 0;
             hg[i].rect[2] = Wd - 1;
@@ -962,16 +991,29 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
             }
         }
         k.classOff[kCls] = (int)idx.size();
-        // camera rays: per image row, the primitives whose pixel rectangle (project_geom) covers it
-        if (!S.dof && (long long)H * ngeoms < (1ll << 26)) {
+        // camera rays: per image row, the primitives whose pixel rectangle (project_geom) covers it, each with the pixels of
+        // that row inside the convex hull of its projected corners (hull_row_span; the rectangle's columns when there is no
+        // hull): entries {primitive, x0 | x1 << 16}, file order
+        if (!S.dof && (long long)H * ngeoms < (1ll << 26) && Wd <= 32768) {
             std::vector<int> off(H + 1), ridx;
             for (int y = 0; y < H; ++y) {
-                off[y] = (int)ridx.size();
-                for (int i = 0; i < ngeoms; ++i)
-                    if (y >= hg[i].rect[1] && y <= hg[i].rect[3] && hg[i].rect[0] <= hg[i].rect[2]) ridx.push_back(i);
+                off[y] = (int)(ridx.size() / 2);
+                for (int i = 0; i < ngeoms; ++i) {
+                    if (!(y >= hg[i].rect[1] && y <= hg[i].rect[3] && hg[i].rect[0] <= hg[i].rect[2])) continue;
+                    int x0 = hg[i].rect[0], x1 = hg[i].rect[2];
+                    if (!hulls[i].empty()) {
+                        double xmin, xmax;
+                        if (!hull_row_span(hulls[i], y, xmin, xmax)) continue;
+                        x0 = std::max(x0, (int)std::max(std::floor(xmin) - 2.0, -1.0e9));
+                        x1 = std::min(x1, (int)std::min(std::ceil(xmax) + 2.0, 1.0e9));
+                        if (x0 > x1) continue;
+                    }
+                    ridx.push_back(i);
+                    ridx.push_back(x0 | (x1 << 16));
+                }
             }
-            off[H] = (int)ridx.size();
-            if (ridx.empty()) ridx.push_back(0);
+            off[H] = (int)(ridx.size() / 2);
+            if (ridx.empty()) { ridx.push_back(0); ridx.push_back(0); }
             HIPCHECK(hipMalloc(&S.dRowOff, off.size() * sizeof(int)));
             HIPCHECK(hipMemcpy(S.dRowOff, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice));
             HIPCHECK(hipMalloc(&S.dRowIdx, ridx.size() * sizeof(int)));

@@ -324,8 +324,9 @@ struct BounceArgs {
     uint32_t *hitMask;                  // [ceil(max_batch / 32)][W * H]: bit b of word w set = contrib[32 w + b][pix] was written
     const SphereCull *sphCull;          // sphere-heavy scenes (k_bounce<false, true, ...>): the spheres' culling data, packed
     const int *classIdx;                // later bounces: per queue class, the indices of the primitives to look at, file order (KParams::classOff)
-    const int *rowOff;                  // camera rays of whole-tile rows: the primitives whose pixel rectangle covers image row y are
-    const int *rowIdx;                  //   rowIdx[rowOff[y] .. rowOff[y + 1]), file order; nullptr: every primitive
+    const int *rowOff;                  // camera rays of whole-tile rows: the primitives that can be reached from image row y are the entries
+    const int *rowIdx;                  //   rowOff[y] .. rowOff[y + 1] of rowIdx, file order: pairs {primitive, x0 | x1 << 16} = the row's pixels
+                                        //   inside the hull of the primitive's projected corners (pt_init); rowOff == nullptr: every primitive
 };
 typedef const PT_CAS BounceArgs *ArgsPtr;
 typedef const PT_CAS GeomDev *GeomPtr;
@@ -693,6 +694,8 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
                 // its row -- the primitives whose pixel rectangle covers that row -- and their rectangles sort the lanes out
                 int gk0, gk1;
                 const PT_CAS int *classIdx;
+                typedef int int2v __attribute__((ext_vector_type(2)));
+                const PT_CAS int2v *rowList = nullptr;               // camera rays of a whole-tile row: {primitive, its pixel span in this row}
                 bool listed = !FIRST;
                 if (FIRST) {
                     gk0 = 0; gk1 = A->prm.ngeoms;
@@ -701,6 +704,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
                         const PT_CAS int *rowOff = (const PT_CAS int *)(A->rowOff);
                         const int row = __builtin_amdgcn_readfirstlane(py);
                         gk0 = rowOff[row]; gk1 = rowOff[row + 1];
+                        rowList = (const PT_CAS int2v *)(A->rowIdx);
                         listed = true;
                     }
                 } else {
@@ -709,7 +713,13 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
                 }
                 const GeomPtr geoms = (GeomPtr)(A->ggeoms);
                 for (int gk = gk0; gk < gk1; ++gk) {
-                    const int g = listed ? classIdx[gk] : gk;
+                    int g, span = 0;
+                    if (FIRST && listed) {
+                        const int2v e = rowList[gk];
+                        g = e.x; span = e.y;
+                    } else {
+                        g = listed ? classIdx[gk] : gk;
+                    }
                     // (sphere-heavy scenes: no laundering per primitive -- the camera-ray bounce still walks all seventy of them,
                     // and the compiler's own scheduling of the scalar loads across iterations is worth more than the registers
                     // it costs; measured on C5)
@@ -726,7 +736,8 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
                     // is 64 consecutive pixels of one row -- saved 2 % of the vector instructions and cost 20 % more scalar ones:
                     // 1.5 % slower, not kept)
                     if (FIRST && !DOF) {
-                        inRect = (px >= G.rect[0]) & (px <= G.rect[2]) & (py >= G.rect[1]) & (py <= G.rect[3]);
+                        if (listed) inRect = (px >= (span & 0xffff)) & (px <= (span >> 16));   // (the list is this row's)
+                        else inRect = (px >= G.rect[0]) & (px <= G.rect[2]) & (py >= G.rect[1]) & (py <= G.rect[3]);
                         if (__ballot(inRect) == 0ull) continue;
                     }
                     // (later bounces: the class's list holds no binned primitive its paths certainly miss, and of the walls only
