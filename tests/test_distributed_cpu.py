@@ -56,15 +56,17 @@ def _worker(rank, world, port, res, iters, out_path):
     torch.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize("res", [(48, 37), (48, 36)])      # ragged shards (19 / 18 rows: per-rank copies) and even ones (one strided copy)
-def test_two_ranks_gloo_assemble_the_frame_bit_exactly(tmp_path, res):
+# ragged shards (19 / 18 rows: per-rank copies) and even ones (one strided copy) on two ranks; and the world size of the real
+# run, eight ranks: 40 rows = five each (the strided copy), 27 rows = ragged with ranks that hold three or four rows
+@pytest.mark.parametrize("world,res", [(2, (48, 37)), (2, (48, 36)), (8, (32, 40)), (8, (24, 27))])
+def test_ranks_gloo_assemble_the_frame_bit_exactly(tmp_path, world, res):
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     out = str(tmp_path / "ok.npy")
-    mp.spawn(_worker, args=(2, port, res, [1, 2, 3], out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, port, res, [1, 2, 3], out), nprocs=world, join=True)
     assert np.load(out)[0] == 1
 
 
