@@ -747,8 +747,13 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     magic_divisor((uint32_t)Wd, k.magicW, k.shiftW);
     magic_divisor((uint32_t)o.shard_count, k.magicS, k.shiftS);
     k.contribLocal = (o.shard_count > 1 && (long long)Wd * H < (1ll << 27)) ? 1 : 0;   // (the multiply-shift divisions hold below 2^27)
-    magic_divisor((uint32_t)std::max(S.nLocal, 1), k.magicN, k.shiftN);
-    for (uint32_t d : {(uint32_t)Wd, (uint32_t)std::max(S.nLocal, 1)}) {       // self-check on the edges of every quotient range
+    // camera-ray tiles lie on rows padded to a multiple of the tile size (KParams::Wp)
+    k.Wp = (Wd + kBlock - 1) / kBlock * kBlock;
+    if ((long long)rows * k.Wp >= (1ll << 30)) return fail(PT_ERR_INVALID, "pt_init: frame too large (rows x padded width must stay below 2^30)");
+    k.nLocalPad = rows * k.Wp;
+    magic_divisor((uint32_t)k.Wp, k.magicWp, k.shiftWp);
+    magic_divisor((uint32_t)std::max(k.nLocalPad, 1), k.magicN, k.shiftN);
+    for (uint32_t d : {(uint32_t)Wd, (uint32_t)k.Wp, (uint32_t)std::max(k.nLocalPad, 1)}) {       // self-check on the edges of every quotient range
         uint32_t m, sh;
         magic_divisor(d, m, sh);
         for (uint64_t q = 0; q * d < (1ull << 30); q = q < 64 ? q + 1 : q * 2 + 1)
@@ -796,6 +801,8 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     // slots are 32-bit element indices with 32-bit byte offsets: paths per pool must stay below 2^30
     const long long maxPaths = (long long)S.nLocal * S.maxBatch;
     if (maxPaths > (1ll << 29)) return fail(PT_ERR_INVALID, "pt_init: max_batch x pixels too large (limit 2^29 paths per batch)");
+    if ((long long)k.nLocalPad * S.maxBatch >= (1ll << 30))     // (the camera-ray tiles' index space: rows padded to the tile size)
+        return fail(PT_ERR_INVALID, "pt_init: max_batch x rows x padded width too large (limit 2^30)");
     S.numTilesMax = (int)((maxPaths + kBlock - 1) / kBlock) + kSeg;
     k.chunkShift = kMinChunkShift;
     while (k.chunkShift < 17 && (maxPaths >> k.chunkShift) > 1024) ++k.chunkShift;
@@ -1049,9 +1056,8 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     // odd tile count per row), or the kernel rotates the k-th tile of a workgroup k bands to the right inside its row,
     // which needs a grid that is a multiple of the tiles per row (k_bounce<true, .>).
     S.prm.tilesPerRow = 0;
-    S.prm.wholeRowTiles = Wd % kBlock == 0 ? 1 : 0;
-    if (Wd % kBlock == 0 && Wd / kBlock > 1) {
-        const int perRow = Wd / kBlock;
+    if (S.prm.Wp / kBlock > 1) {
+        const int perRow = S.prm.Wp / kBlock;
         auto gcd = [](int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; };
         if (gcd(perRow, kSub) == 1) {
             for (int tries = 0; tries < 64 && S.gridFirst > kSub && gcd(S.gridFirst, perRow) != 1; ++tries) S.gridFirst -= kSub;

@@ -72,8 +72,13 @@ struct KParams {
     int   contribLocal; // the radiance buffers and iteration masks hold only this shard's pixels, indexed x + (y / shardCount) * W
                         // (row shards of frames below 2^27 pixels): a rank of N then touches 1/N of the memory, not all of it
     uint32_t magicS, shiftS;   // n / shardCount
-    int   tilesPerRow;  // W / 256 when that is exact and the camera-ray grid is a multiple of it (see k_bounce), else 0
-    int   wholeRowTiles; // W % 256 == 0: a camera-ray tile is 256 pixels of one row
+    // Camera-ray tiles are laid over rows PADDED to a multiple of the tile size (Wp = ceil(W / 256) * 256; lanes beyond W idle), so a
+    // tile is always 256 pixels of ONE row whatever the frame's width: its pixels follow from its wave-uniform position, it is
+    // skipped as a whole outside the scene rectangle, and it walks its row's own list of primitives (rowOff / rowIdx).
+    int   Wp;           // padded row width
+    int   nLocalPad;    // rows of this shard x Wp: the tile index space of one iteration; magicN / shiftN divide by it
+    uint32_t magicWp, shiftWp;   // n / Wp
+    int   tilesPerRow;  // Wp / 256 when the camera-ray grid is a multiple of it (see k_bounce), else 0
     int   emittersBinned; // every primitive with an emissive material is one of binGeom[]
     int   nBinned;      // 1..kBinMax small primitives (spheres, small cubes): survivors are binned by whether they can
     int   binGeom[kBinMax];   // hit one of them (certainMiss of each); 0: off, every path counts as a candidate
@@ -324,7 +329,7 @@ struct BounceArgs {
     uint32_t *hitMask;                  // [ceil(max_batch / 32)][W * H]: bit b of word w set = contrib[32 w + b][pix] was written
     const SphereCull *sphCull;          // sphere-heavy scenes (k_bounce<false, true, ...>): the spheres' culling data, packed
     const int *classIdx;                // later bounces: per queue class, the indices of the primitives to look at, file order (KParams::classOff)
-    const int *rowOff;                  // camera rays of whole-tile rows: the primitives that can be reached from image row y are the entries
+    const int *rowOff;                  // camera rays (a tile is 256 pixels of one row): the primitives that can be reached from image row y are the entries
     const int *rowIdx;                  //   rowOff[y] .. rowOff[y + 1] of rowIdx, file order: pairs {primitive, x0 | x1 << 16} = the row's pixels
                                         //   inside the hull of the primitive's projected corners (pt_init); rowOff == nullptr: every primitive
 };
@@ -403,7 +408,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
         // input queue: segment s holds s_cnt[s] paths = tiles [s_pre[s], s_pre[s+1]) of the global tile index
         if (FIRST) {
             nLive = (uint32_t)A->prm.nLocal * (uint32_t)A->batch;     // `batch` consecutive iterations share one wavefront
-            numTiles = (nLive + kBlock - 1) / kBlock;
+            numTiles = (uint32_t)A->prm.nLocalPad / kBlock * (uint32_t)A->batch;   // (tiles lie on padded rows)
         } else {
             if (threadIdx.x < 64) {          // wave 0: exclusive scan of the kSeg tile counts
                 const uint32_t c = threadIdx.x < kSeg ? ctrl->pos[parity][depth][threadIdx.x][0] : 0u;
@@ -556,7 +561,6 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
         probe(14);                                              // (a tile starts)
         uint32_t Tnext = T + gridDim.x;     // FIRST: simply the next one
         bool valid;
-        uint32_t idx = 0;
         uint32_t tileCls = 0u;              // wave-uniform: the tile's queue class (later bounces)
         PathRegs cur = nextRegs;
         int itb = 0;                                            // which iteration of the batch this path belongs to
@@ -564,11 +568,10 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
         if (FIRST) {
             const ArgsPtr A = launder(kargs);
             const PT_CAS KParams &prm = A->prm;
-            // Tile T = b + k grid covers a 256-pixel block of the row-major pixel list.  With W a multiple of 256 a row
-            // is `perRow` whole tiles, the grid is a multiple of perRow (pt_init), and a workgroup would stay in ONE
-            // column band of the frame -- outside the scene rectangle its tiles cost 15x less than inside.  So the k-th
-            // tile of a workgroup is rotated k bands to the right inside its row: a bijection on the row's tiles
-            // (they share k), which walks every workgroup through all bands.
+            // Tile T = b + k grid covers 256 pixels of one (padded) row.  A row is `perRow` tiles; when the grid is a multiple
+            // of perRow (pt_init) a workgroup would stay in ONE column band of the frame -- outside the scene rectangle
+            // its tiles cost 15x less than inside.  So the k-th tile of a workgroup is rotated k bands to the right inside its
+            // row: a bijection on the row's tiles (they share k), which walks every workgroup through all bands.
             uint32_t pixTile = T;
             const uint32_t tilesPerRow = (uint32_t)prm.tilesPerRow;
             if (tilesPerRow > 1) {
@@ -576,32 +579,26 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
                 pixTile = T - c + (c + firstK) % tilesPerRow;
                 ++firstK;
             }
-            idx = pixTile * kBlock + tid;                       // position in this shard's pixel list
-            valid = idx < (uint32_t)prm.nLocal * (uint32_t)A->batch;
-            // A tile of whole-tile rows is 256 pixels of ONE row: when it lies outside the scene rectangle altogether,
-            // all its camera rays are misses -- tally them and take the next tile (no rays, no compaction, no barrier;
-            // the test is the same for the four waves of the workgroup).
-            if (prm.wholeRowTiles) {
-                const uint32_t idx0 = pixTile * kBlock;
-                const uint32_t nLocal = (uint32_t)prm.nLocal;
-                const uint32_t itb0 = fastDiv(idx0, prm.magicN, prm.shiftN);
-                const uint32_t j0 = idx0 - itb0 * nLocal;
-                const int lr0 = (int)fastDiv(j0, prm.magicW, prm.shiftW);
-                const int x0 = (int)j0 - lr0 * prm.W;
-                const int y0 = lr0 * prm.shardCount + prm.shardRank;
-                if (y0 < prm.sceneRect[1] || y0 > prm.sceneRect[3] || x0 + (kBlock - 1) < prm.sceneRect[0] || x0 > prm.sceneRect[2]) {
-                    nMiss += valid ? 1u : 0u;
-                    T = Tnext;
-                    continue;
-                }
-                // ... and its lanes' pixels follow from the tile's (wave-uniform) position: no per-lane divisions
-                px = x0 + (int)tid;
-                py = y0;
-                itb = (int)itb0;
+            // the tile's (wave-uniform) position: iteration of the batch, row of the shard, first column -- no per-lane divisions
+            const uint32_t idx0 = pixTile * kBlock;
+            const uint32_t itb0 = fastDiv(idx0, prm.magicN, prm.shiftN);
+            const uint32_t j0 = idx0 - itb0 * (uint32_t)prm.nLocalPad;
+            const int lr0 = (int)fastDiv(j0, prm.magicWp, prm.shiftWp);
+            const int x0 = (int)j0 - lr0 * prm.Wp;
+            const int y0 = lr0 * prm.shardCount + prm.shardRank;
+            px = x0 + (int)tid;
+            py = y0;
+            itb = (int)itb0;
+            valid = px < prm.W;                                 // (lanes in the padding hold no pixel)
+            // When the tile lies outside the scene rectangle altogether, all its camera rays are misses -- tally them and take
+            // the next tile (no rays, no compaction, no barrier; the test is the same for the four waves of the workgroup).
+            if (y0 < prm.sceneRect[1] || y0 > prm.sceneRect[3] || x0 + (kBlock - 1) < prm.sceneRect[0] || x0 > prm.sceneRect[2]) {
+                nMiss += valid ? 1u : 0u;
+                T = Tnext;
+                continue;
             }
         } else {
             valid = nextMeta.valid;
-            idx = nextMeta.idx;
             tileCls = nextMeta.cls;
         }
 
@@ -622,13 +619,6 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
             if (FIRST) {
                 const ArgsPtr A = launder(kargs);
                 const PT_CAS KParams &prm = A->prm;
-                if (!prm.wholeRowTiles) {
-                    itb = (int)fastDiv(idx, prm.magicN, prm.shiftN);
-                    const int j = (int)(idx - (uint32_t)itb * (uint32_t)prm.nLocal);
-                    const int lr = (int)fastDiv((uint32_t)j, prm.magicW, prm.shiftW);
-                    px = j - lr * prm.W;
-                    py = lr * prm.shardCount + prm.shardRank;
-                }
                 pix = px + py * prm.W;
                 inScene = px >= prm.sceneRect[0] && px <= prm.sceneRect[2] && py >= prm.sceneRect[1] && py <= prm.sceneRect[3];
                 if (inScene) {
@@ -690,7 +680,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
             constexpr bool PACKED = MANY && !FIRST;
             if (inScene) {
                 const ArgsPtr A = launder(kargs);
-                // a later tile looks at the list of its class; a camera-ray tile of whole-tile rows (one image row) at the list of
+                // a later tile looks at the list of its class; a camera-ray tile (256 pixels of one image row) at the list of
                 // its row -- the primitives whose pixel rectangle covers that row -- and their rectangles sort the lanes out
                 int gk0, gk1;
                 const PT_CAS int *classIdx;
@@ -700,7 +690,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
                 if (FIRST) {
                     gk0 = 0; gk1 = A->prm.ngeoms;
                     classIdx = (const PT_CAS int *)(A->rowIdx);
-                    if (!DOF && A->prm.wholeRowTiles && A->rowOff != nullptr) {
+                    if (!DOF && A->rowOff != nullptr) {
                         const PT_CAS int *rowOff = (const PT_CAS int *)(A->rowOff);
                         const int row = __builtin_amdgcn_readfirstlane(py);
                         gk0 = rowOff[row]; gk1 = rowOff[row + 1];
@@ -732,7 +722,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
                     // camera rays: only the lanes whose pixel lies in the primitive's rectangle take the test.  A predicate and a
                     // wave-uniform skip, not a per-lane `continue`: the loop over the primitives stays a scalar loop
                     bool inRect = true;
-                    // (testing the WAVE's pixel span against the rectangle in scalar registers instead -- a wave of whole-tile rows
+                    // (testing the WAVE's pixel span against the rectangle in scalar registers instead -- a wave of a camera-ray tile
                     // is 64 consecutive pixels of one row -- saved 2 % of the vector instructions and cost 20 % more scalar ones:
                     // 1.5 % slower, not kept)
                     if (FIRST && !DOF) {
