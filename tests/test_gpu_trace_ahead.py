@@ -137,3 +137,59 @@ def test_pbo_conversion_uses_the_committed_image(gpu, oracle):
         rgba = pbo.cpu().numpy().reshape(-1, 4)
         assert np.array_equal(rgba, oracle.to_rgba8(want, it)), it
     gpu.pathtraceFree()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PT_SEQ_SEEDS", "12"))))      # PT_SEQ_SEEDS=<n>: a longer one-off run
+def test_random_call_sequences_equal_the_plain_protocol(gpu, seed):
+    # a random walk over the API -- next iteration, any iteration, explicit batches, read-backs, counter resets, re-initialisation --
+    # with trace-ahead on against the very same calls with it off (GPU against GPU: the image after every call must agree bit
+    # for bit, and so must the number of committed iterations)
+    rng = np.random.default_rng(9100 + seed)
+    res = (int(rng.choice([40, 256, 300])), int(rng.choice([24, 33])))
+    depth = int(rng.integers(2, 7))
+    sc = _scene(gpu, str(rng.choice(["cornell.txt", "cornell_glass.txt", "spheres64.txt", "mesh_small.txt"])), res)
+    max_batch, slots = int(rng.choice([2, 3, 8, 32])), int(rng.choice([1, 2, 3, 4]))
+    ops, it = [], 1
+    for _ in range(int(rng.integers(20, 60))):
+        r = rng.random()
+        if r < 0.55:
+            ops.append(("iter", it)); it += 1
+        elif r < 0.65:
+            it = int(rng.integers(1, 200)); ops.append(("iter", it)); it += 1
+        elif r < 0.75:
+            n = int(rng.integers(1, max_batch + 1)); ops.append(("batch", it, n)); it += n
+        elif r < 0.85:
+            ops.append(("read",))
+        elif r < 0.92:
+            ops.append(("reset",))
+        else:
+            ops.append(("init",)); it = 1
+    def play(ahead):
+        images, iters = [], []
+        gpu.pathtraceFree()
+        gpu.pathtraceInit(sc, traceDepth=depth, max_batch=max_batch, pipeline_depth=slots, trace_ahead=ahead)
+        for op in ops:
+            if op[0] == "iter":
+                gpu.pathtrace(None, 0, op[1], readback=False)
+            elif op[0] == "batch":
+                gpu.pathtrace_batch(None, 0, op[1], op[2])
+            elif op[0] == "read":
+                images.append(gpu.readback(res[0] * res[1]).copy())
+            elif op[0] == "reset":
+                iters.append(int(gpu.counters().iterations))
+                gpu.counters_reset()
+            else:
+                images.append(gpu.readback(res[0] * res[1]).copy())
+                gpu.pathtraceFree()
+                gpu.pathtraceInit(sc, traceDepth=depth, max_batch=max_batch, pipeline_depth=slots, trace_ahead=ahead)
+        images.append(gpu.readback(res[0] * res[1]).copy())
+        iters.append(int(gpu.counters().iterations))
+        gpu.pathtraceFree()
+        return images, iters
+    plain, n_plain = play(False)
+    ahead, n_ahead = play(True)
+    assert n_plain == n_ahead, (seed, ops)
+    assert len(plain) == len(ahead)
+    for k, (a, b) in enumerate(zip(plain, ahead)):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (seed, k, ops)
+    assert max(float(a.max()) for a in plain) > 0 or all(o[0] in ("read", "reset", "init") for o in ops)   # (something was rendered)
