@@ -14,7 +14,7 @@ import sys, numpy as np
 a = np.load("gpurun_out/ab/frame%s.npy" % sys.argv[1])
 for v in sys.argv[2:]:
     b = np.load("gpurun_out/ab/frame%s.npy" % v)
-    print("frame", v, "identical to", sys.argv[1], ":", bool(np.array_equal(a.view(np.uint32), b.view(np.uint32))))
+    print("frame", v, "identical to", sys.argv[1], ":", bool(np.array_equal(a.view(np.uint32), b.view(np.uint32))), "max rel diff %.2e" % float(np.max(np.abs(a - b) / np.maximum(np.abs(a), 1e-30))))
 PY
 rm -f gpurun_out/ab/frame*.npy
 cat $out
