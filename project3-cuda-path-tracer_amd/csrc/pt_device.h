@@ -37,6 +37,7 @@ __device__ __forceinline__ void censusLeave() {
     if (threadIdx.x == 0) atomicSub(&g_censusNow[censusKey()], 1u);
 }
 __device__ __forceinline__ void probe(int k) {
+    if (k >= 14) return;      // (14-20 are marks of the static listing only, PT_MARK: g_probe holds counters 0-13)
     const unsigned long long m = __ballot(1);
     if (__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) == 0) {
         atomicAdd(&g_probe[2 * k], 1ull);
