@@ -7,8 +7,13 @@ Metric (BASELINE.json): Mpaths/s, paths = pixels x bounces x spp (NOMINAL segmen
 One STEP = one pass of the hot path over one batch of input = `--batch` (32) consecutive iterations (spp) of the
 whole frame: camera rays, 8 fused intersect+shade+compact bounces, ordered accumulation, issued as ONE wavefront
 batch (pt_iterate_batch: the 32 iterations' paths share the 8 launches; results are identical to one call per
-iteration), with 2 batches in flight on internal streams.  So `--steps 20` times 640 iterations, and
-ms_per_step x steps is the timed wall.  Scene, accumulator and path state are resident in HBM before the timed region.
+iteration), with 2 batches in flight on internal streams.  So `--steps 20` times 640 iterations.  Scene, accumulator
+and path state are resident in HBM before the timed region.
+
+The timed block -- EXACTLY `--steps` steps between barrier + device synchronisation on both sides -- is repeated
+`--repeats` (15) times inside one run (a single block is ~27 ms; fifteen are ~0.4 s of GPU time): `ms_per_step` and
+`value` are the MEDIAN block's (ms_per_step x steps = that block's wall), `ms_per_step_min` / `_max` and `value_min` /
+`_max` give the spread over the blocks, `ms_per_step_blocks` lists them all.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
         N > 1 without a torchrun environment: bench.py starts its N ranks itself (a child `python -m
@@ -26,7 +31,11 @@ mode and reports it in config.per_iteration_collective.
 the rows for N times the iterations, as many paths per step as the single GPU (a renderer's weak scaling: N times the
 samples per pixel in the same time); value = all ranks' paths / the slowest rank's time.  `--scaling strong`: a step is
 `--batch` iterations whatever N (config C3 as written: a fixed number of samples, divided; ranks then fuse steps into
-fatter wavefront batches).  At N = 1 the two are the same run.
+fatter wavefront batches).  At N = 1 the two are the same run.  ONE N > 1 run reports all three readings of "N GPUs",
+each over whole steps: `value_weak`, `value_strong` (collective per wavefront batch) and `value_c3_as_written` (strong,
+one pt_iterate + one reduce(sum) of zero-padded full frames per ITERATION: BASELINE config C3 to the letter), plus
+`collective_bytes_per_call` and the collective's share of a step; `value` = the one `--scaling` names (default weak:
+per-GPU work fixed as N grows, which is what "scaling": "weak" in the line says).
 
 Prints ONE JSON line on rank 0, with `roofline` (dominant kernel = the fused bounce kernel, HIP-event timed on the
 streams it runs on, against the 8 TB/s HBM peak) and `cpu_baseline` (the single-thread CPU oracle on a bounded
@@ -56,10 +65,11 @@ def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None,
-                    help="steps timed (one step = --batch iterations of the whole frame, times N with --scaling weak); default 32 "
-                         "on one GPU (1024 spp = 16 x the 64 spp of BASELINE config C2); on N GPUs config C3's 5000 spp rounded up to "
-                         "whole steps (157 with --scaling strong)")
+                    help="steps per timed block (one step = --batch iterations of the whole frame, times N with --scaling weak); default 32 "
+                         "on one GPU (1024 spp = 16 x the 64 spp of BASELINE config C2), 20 on N GPUs")
     ap.add_argument("--warmup", type=int, default=None, help="untimed steps first (default 4)")
+    ap.add_argument("--repeats", type=int, default=15,
+                    help="how many times the timed block of --steps steps is repeated inside the run (median reported, min / max beside it)")
     ap.add_argument("--scene", default=os.path.join(ROOT, "scenes", "cornell.txt"))
     ap.add_argument("--res", type=int, nargs=2, default=[1280, 720])
     ap.add_argument("--depth", type=int, default=8)
@@ -76,7 +86,9 @@ def parse(argv=None):
     ap.add_argument("--collective", default="gather", choices=["gather", "reduce"],
                     help="N > 1: gather of the packed row blocks (default) or reduce(sum) of zero-padded full frames")
     ap.add_argument("--per-iteration-sample", type=int, default=2,
-                    help="N > 1 with --collective-every batch: also time this many steps in per-iteration mode (0 = skip)")
+                    help="N > 1: whole steps timed in the per-iteration mode of BASELINE config C3 (strong scaling, one pt_iterate + one "
+                         "reduce per iteration); 0 = skip")
+    ap.add_argument("--extra-passes", type=int, default=1, help="N > 1: 0 = only the pass `--scaling` names (no value_weak / value_strong pair)")
     ap.add_argument("--pmc-traffic-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"),
                     help="PMC counters per bounce-kernel launch from the rocprofv3 --pmc passes (profiles/README.md)")
     ap.add_argument("--valu-rate-json", default=os.path.join(ROOT, "profiles", "valu_issue_rate.json"),
@@ -98,38 +110,79 @@ def self_launch(args):
     sys.exit(r.returncode)
 
 
-def cpu_baseline(args, scene):
-    """Single-thread CPU oracle (oracle/, kind 'port') on a bounded sample of the same workload."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(args, scene, pt):
+    """Single-thread CPU oracle (oracle/, kind 'port') on a bounded sample of the same workload, pinned to ONE core; plus BASELINE
+    config C1 (scenes/sphere.txt 400x400, 1 spp, depth 4) in full."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as orc
-    W, H = args.res
-    ref = orc.Renderer(scene.camera.view(orc.CAMERA_DTYPE), scene.geoms.view(orc.GEOM_DTYPE),
-                       scene.materials.view(orc.MATERIAL_DTYPE), args.depth, meshes=getattr(scene, "meshes", None))
-    img = np.zeros(W * H * 3, np.float32)
-    K = 64                                                 # a probe first: every 64th row of one sample
-    t0 = time.perf_counter()
-    ref.iterate(1, img, 0, K)                              # (also warms the caches / pages the library in)
-    probe = time.perf_counter() - t0
-    if probe * K * args.cpu_spp <= 45.0:
+    pinned, saved = None, None
+    try:                                                   # one core for the whole baseline (restored afterwards)
+        saved = os.sched_getaffinity(0)
+        pinned = sorted(saved)[len(saved) // 2]
+        os.sched_setaffinity(0, {pinned})
+    except (AttributeError, OSError):
+        pinned = None
+    try:
+        W, H = args.res
+        ref = orc.Renderer(scene.camera.view(orc.CAMERA_DTYPE), scene.geoms.view(orc.GEOM_DTYPE),
+                           scene.materials.view(orc.MATERIAL_DTYPE), args.depth, meshes=getattr(scene, "meshes", None))
+        img = np.zeros(W * H * 3, np.float32)
+        K = 64                                                 # a probe first: every 64th row of one sample
         t0 = time.perf_counter()
-        for it in range(2, 2 + args.cpu_spp):
-            ref.iterate(it, img)
-        dt = time.perf_counter() - t0
-        pixels, what = W * H * args.cpu_spp, "%d spp" % args.cpu_spp
-    else:
-        # a slow scene (brute-force meshes): bound the sample to ~15 s of row slices (rows y with y % 64 == r) of sample 2
-        nslices = max(1, min(K - 1, int(15.0 / max(probe, 1e-3))))
-        t0 = time.perf_counter()
-        for r in range(1, 1 + nslices):
-            ref.iterate(2, img, r, K)
-        dt = time.perf_counter() - t0
-        pixels = sum((H - r + K - 1) // K for r in range(1, 1 + nslices)) * W
-        what = "%d of every %d rows of 1 spp" % (nslices, K)
+        ref.iterate(1, img, 0, K)                              # (also warms the caches / pages the library in)
+        probe = time.perf_counter() - t0
+        if probe * K * args.cpu_spp <= 45.0:
+            t0 = time.perf_counter()
+            for it in range(2, 2 + args.cpu_spp):
+                ref.iterate(it, img)
+            dt = time.perf_counter() - t0
+            pixels, what = W * H * args.cpu_spp, "%d spp" % args.cpu_spp
+        else:
+            # a slow scene (brute-force meshes): bound the sample to ~15 s of row slices (rows y with y % 64 == r) of sample 2
+            nslices = max(1, min(K - 1, int(15.0 / max(probe, 1e-3))))
+            t0 = time.perf_counter()
+            for r in range(1, 1 + nslices):
+                ref.iterate(2, img, r, K)
+            dt = time.perf_counter() - t0
+            pixels = sum((H - r + K - 1) // K for r in range(1, 1 + nslices)) * W
+            what = "%d of every %d rows of 1 spp" % (nslices, K)
+        # BASELINE config C1: scenes/sphere.txt at 400x400, 1 spp, depth 4, the whole thing -- it takes milliseconds, so it is run
+        # 15 times and the median is reported
+        c1 = None
+        c1_path = os.path.join(ROOT, "scenes", "sphere.txt")
+        if os.path.exists(c1_path):
+            s1 = pt.Scene(c1_path)
+            s1.set_resolution(400, 400)
+            r1 = orc.Renderer(s1.camera.view(orc.CAMERA_DTYPE), s1.geoms.view(orc.GEOM_DTYPE), s1.materials.view(orc.MATERIAL_DTYPE), 4)
+            i1 = np.zeros(400 * 400 * 3, np.float32)
+            ts = []
+            for k in range(15):
+                i1[:] = 0
+                t0 = time.perf_counter()
+                r1.iterate(1, i1)
+                ts.append(time.perf_counter() - t0)
+            ts.sort()
+            c1 = {"config": "scenes/sphere.txt 400x400, 1 spp, 4 bounces (BASELINE config C1, run in full)", "value": round(400 * 400 * 4 / ts[7] / 1e6, 2),
+                  "unit": "Mpaths/s", "ms": round(ts[7] * 1e3, 3), "ms_min": round(ts[0] * 1e3, 3), "ms_max": round(ts[-1] * 1e3, 3), "runs": 15}
+    finally:
+        if saved is not None and pinned is not None:
+            os.sched_setaffinity(0, saved)
     return {"value": round(pixels * args.depth / dt / 1e6, 3), "unit": "Mpaths/s", "cores": 1,
-            "kind": "port",
-            "sample": "%s of %s %dx%d depth %d (%.1f s, single thread, g++ -O2 -ffp-contract=off, host has %d cores)"
-                      % (what, os.path.basename(args.scene), W, H, args.depth, dt, os.cpu_count())}
+            "kind": "port", "cpu_model": cpu_model(), "host_cores": os.cpu_count(), "pinned_to_core": pinned,
+            "sample": "%s of %s %dx%d depth %d (%.1f s, single thread, g++ -O2 -ffp-contract=off)"
+                      % (what, os.path.basename(args.scene), W, H, args.depth, dt),
+            "c1": c1}
 
 
 def valu_issue_rate(path, waves_per_simd):
@@ -154,36 +207,94 @@ def valu_issue_rate(path, waves_per_simd):
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world == 1 and args.gpus > 1:
         self_launch(args)                                   # never returns
+    # Every exit path of a rank drains and frees the renderer BEFORE the process goes away (an exception between pt_iterate
+    # and pathtraceFree used to leave launches in flight at context teardown), and a failed rank exits non-zero.
+    ctx = {}
+    rc = 1
+    try:
+        run(args, ctx)
+        rc = 0
+    except SystemExit as e:
+        rc = e.code if isinstance(e.code, int) else (0 if e.code is None else 1)
+        if rc and not isinstance(e.code, int):
+            print(e.code, file=sys.stderr, flush=True)
+    except BaseException:
+        import traceback
+        traceback.print_exc()
+        rc = 1
+    finally:
+        cleanup(ctx, rc == 0)
+    sys.exit(rc)
+
+
+def cleanup(ctx, ok):
+    """Orderly exit of a rank: wait for its own GPU work, free the renderer, and -- when every rank got here in good order --
+    leave together: nobody tears its HIP context down while another rank still works (sync, barrier, tear-down).  A rank that
+    failed skips the barrier (the others may never reach it) and exits non-zero; the launcher then ends the others."""
+    torch = ctx.get("torch")
+    pt = ctx.get("pt")
+    try:
+        if torch is not None and torch.cuda.is_available():
+            torch.cuda.synchronize()
+    except Exception:
+        pass
+    try:
+        if pt is not None:
+            pt.pathtraceFree()                              # (synchronises the renderer's own streams first)
+    except Exception:
+        pass
+    dist = ctx.get("dist")
+    if dist is not None and dist.is_initialized():
+        try:
+            if ok:
+                dist.barrier()
+            for k in ("accum", "frame", "bufs"):
+                ctx.pop(k, None)
+            dist.destroy_process_group()
+        except Exception:
+            pass
+
+
+def run(args, ctx):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         args.gpus = world
 
     import numpy as np
     import torch
     import torch.distributed as dist
+    ctx["torch"] = torch
 
     B = args.batch
-    weak = args.scaling == "weak"
-    I = B * (world if weak else 1)                          # iterations of the whole frame per step
-    if args.steps is None:
-        args.steps = 32 if world == 1 else (5000 + I - 1) // I
     if args.warmup is None:
         args.warmup = 4
+    if args.steps is None:
+        args.steps = 32 if world == 1 else 20
+    if args.repeats < 1:
+        sys.exit("bench.py: --repeats must be at least 1")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the hot path has no CPU fallback)")
     # BENCH_BACKEND=gloo lets the N > 1 path be rehearsed with several ranks on ONE GPU (RCCL needs one
     # GPU per rank); the real runs use nccl = RCCL over xGMI.
     backend = os.environ.get("BENCH_BACKEND", "nccl")
-    device_index = local_rank % torch.cuda.device_count()
+    ngpu = torch.cuda.device_count()
+    if world > 1 and backend == "nccl" and ngpu < world:
+        # (local_rank % device_count would silently stack ranks on one device, which RCCL cannot serve)
+        sys.exit("bench.py: %d ranks need %d GPUs under RCCL (backend nccl), this node shows %d; BENCH_BACKEND=gloo rehearses "
+                 "several ranks on one GPU" % (world, world, ngpu))
+    device_index = local_rank % ngpu
     torch.cuda.set_device(device_index)
     import __graft_entry__ as ge
     pt = ge.load_package()
+    ctx["pt"] = pt
     ptdist = ge.load_submodule("distributed")
     if world > 1:
         ptdist.init_process_group(backend)
+        ctx["dist"] = dist
 
     W, H = args.res
     scene = pt.Scene(args.scene)
@@ -197,11 +308,12 @@ def main():
     if world > 1:
         accum = torch.zeros(ptdist.padded_block_floats(W, H, world), dtype=torch.float32, device="cuda")
         frame = torch.zeros(P * 3, dtype=torch.float32, device="cuda") if rank == 0 else None
-        bufs = ptdist.make_gather_buffers(accum, world, rank) if args.collective == "gather" else None
+        bufs = ptdist.make_gather_buffers(accum, world, rank)
         shard_flag = pt.PT_FLAG_ACCUM_SHARD_ROWS
     else:
         accum = torch.zeros(P * 3, dtype=torch.float32, device="cuda")
         frame, bufs, shard_flag = None, None, 0
+    ctx.update(accum=accum, frame=frame, bufs=bufs)
     stream = torch.cuda.current_stream()
 
     def init(flags, pipeline, max_batch):
@@ -210,11 +322,11 @@ def main():
                          accum_dev=accum.data_ptr(), device=device_index, flags=flags | shard_flag,
                          traceDepth=D, pipeline_depth=pipeline, max_batch=max_batch)
 
-    def collect():
+    def collect(collective):
         # the single collective of the data path: the row blocks travel to rank 0 over xGMI
-        ptdist.gather_frame(accum, bufs, frame, W, H, dst=0, collective=args.collective)
+        ptdist.gather_frame(accum, bufs, frame, W, H, dst=0, collective=collective)
 
-    def run_steps(first_iter, steps, every):
+    def run_steps(first_iter, steps, I, maxb, every, collective):
         """`steps` steps of I iterations from `first_iter`.  every == "batch": wavefront batches of `maxb` iterations (one or
         several steps each, or a part of one), the frame assembled at rank 0 after every batch; every == "1": I single-iteration
         calls per step, each followed by the collective."""
@@ -225,12 +337,12 @@ def main():
                 n = min(maxb, end - it)
                 pt.pathtrace_batch(None, 0, it, n)
                 if world > 1:
-                    collect()
+                    collect(collective)
                 it += n
             else:
                 pt.pathtrace(None, 0, it, readback=False)
                 if world > 1:
-                    collect()
+                    collect(collective)
                 it += 1
         return it
 
@@ -239,64 +351,109 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(first_iter, steps, every):
-        barrier()
-        t0 = time.perf_counter()
-        run_steps(first_iter, steps, every)
-        barrier()
-        dt = time.perf_counter() - t0
+    def max_over_ranks(dt):
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt
 
-    every = args.collective_every
-    # N ranks share the frame's rows, so a rank's launches cover 1/N of the paths: with the collective once per batch, a rank
-    # traces `fuse` consecutive steps as ONE wavefront batch (at most PT_MAX_BATCH iterations), which keeps its launches fat
-    # -- but not so few batches that the two in flight never overlap: at least 8 per timed run (measured on a rank of 8 and of
-    # 4 at the driver's 20 steps: batches of 64 beat 128 and 256 by 2-5 %)
-    # Weak scaling: a step is I = B x N iterations, traced as one wavefront batch (in pieces of PT_MAX_BATCH should it be larger).
-    if weak:
-        fuse = 1
-        maxb = min(I, pt.PT_MAX_BATCH) if every == "batch" else 1
-    else:
+    def sum_over_ranks(values):
+        if world > 1:
+            t = torch.tensor([float(v) for v in values], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            return [float(v) for v in t.tolist()]
+        return [float(v) for v in values]
+
+    def timed(first_iter, steps, I, maxb, every, collective):
+        """EXACTLY `steps` steps between barrier + torch.cuda.synchronize() on both sides; the slowest rank's time."""
+        barrier()
+        t0 = time.perf_counter()
+        nxt = run_steps(first_iter, steps, I, maxb, every, collective)
+        barrier()
+        return max_over_ranks(time.perf_counter() - t0), nxt
+
+    def plan(scaling, every):
+        """iterations of the whole frame per step, and the iterations a rank issues as one wavefront batch"""
+        if scaling == "weak":
+            # a step is I = B x N iterations, traced as one wavefront batch (in pieces of PT_MAX_BATCH should it be larger)
+            I = B * world
+            return I, (min(I, pt.PT_MAX_BATCH) if every == "batch" else 1)
+        # N ranks share the frame's rows, so a rank's launches cover 1/N of the paths: with the collective once per batch a rank
+        # traces `fuse` consecutive steps as ONE wavefront batch (at most PT_MAX_BATCH iterations), which keeps its launches fat
+        # -- but not so few batches that the two in flight never overlap: at least 8 per timed block
         fuse = max(1, min(world, pt.PT_MAX_BATCH // B, max(1, args.steps // 8))) if every == "batch" else 1
-        maxb = B * fuse if every == "batch" else 1
-    # ---- pass A: the headline number ----------------------------------------------------------
-    init(0, args.pipeline, maxb)
-    nxt = run_steps(1, args.warmup, every)
-    barrier()
-    pt.counters_reset()
-    dt = timed(nxt, args.steps, every)
-    cntA = pt.counters()
+        return B, (B * fuse if every == "batch" else 1)
+
+    def measure(scaling, every, collective, steps, repeats, warmup, flags=0, pipeline=None):
+        """one configuration: init, warm up, `repeats` timed blocks of `steps` steps; returns the blocks' walls (s) etc."""
+        I, maxb = plan(scaling, every)
+        accum.zero_()
+        init(flags, args.pipeline if pipeline is None else pipeline, maxb)
+        nxt = run_steps(1, warmup, I, maxb, every, collective)
+        barrier()
+        pt.counters_reset()
+        walls = []
+        for _ in range(repeats):
+            dt, nxt = timed(nxt, steps, I, maxb, every, collective)
+            walls.append(dt)
+        return {"I": I, "maxb": maxb, "walls": walls, "counters": pt.counters(), "next_iter": nxt}
+
+    def median(v):
+        s_ = sorted(v)
+        return s_[len(s_) // 2] if len(s_) % 2 else 0.5 * (s_[len(s_) // 2 - 1] + s_[len(s_) // 2])
+
+    every = args.collective_every
+    # ---- pass A: the headline number (`--scaling`, `--collective-every`, `--collective`), repeated blocks --------------
+    A = measure(args.scaling, every, args.collective, args.steps, args.repeats, args.warmup)
+    I, maxb = A["I"], A["maxb"]
+    dt = median(A["walls"])
+    cntA = A["counters"]
     if args.dump_frame and rank == 0:
         np.save(args.dump_frame, (frame if world > 1 else accum).cpu().numpy())
 
-    # ---- pass A': N > 1, the same workload with the collective after EVERY iteration (config C3 as written), bounded
-    per_iter = None
-    if world > 1 and every == "batch" and args.per_iteration_sample > 0:
-        accum.zero_()
-        init(0, args.pipeline, 1)
-        nxt1 = run_steps(1, 1, "1")
-        dt1 = timed(nxt1, args.per_iteration_sample, "1")
-        per_iter = {"value": round(P * D * I * args.per_iteration_sample / dt1 / 1e6, 2), "unit": "Mpaths/s",
-                    "steps": args.per_iteration_sample,
-                    "mode": "pt_iterate + one %s per iteration (BASELINE config C3 as written)" % args.collective}
+    # ---- N > 1: the collective on its own (its bytes and its share of a step), then the other readings of "N GPUs" -------
+    multi = None
+    if world > 1:
+        calls = 10
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            collect(args.collective)
+        barrier()
+        coll_ms = max_over_ranks(time.perf_counter() - t0) / calls * 1e3
+        block_bytes = accum.numel() * 4
+        coll_calls_per_step = (I + maxb - 1) // maxb if every == "batch" else I
+        multi = {"collective": args.collective, "collective_every": every,
+                 "collective_bytes_per_call": {"sent_by_each_rank": block_bytes if args.collective == "gather" else P * 12,
+                                               "received_by_rank_0": (world - 1) * (block_bytes if args.collective == "gather" else P * 12)},
+                 "collective_ms_per_call": round(coll_ms, 4), "collective_calls_per_step": coll_calls_per_step,
+                 "collective_share_of_step": round(coll_ms * coll_calls_per_step / (dt / args.steps * 1e3), 4)}
+
+        def reading(scaling, ev, collective, steps, warmup):
+            m = measure(scaling, ev, collective, steps, 1, warmup)
+            w = m["walls"][0]
+            return {"value": round(P * D * m["I"] * steps / w / 1e6, 2), "unit": "Mpaths/s", "steps": steps, "iterations_per_step": m["I"],
+                    "iterations_per_wavefront_batch": m["maxb"], "ms_per_step": round(w / steps * 1e3, 4),
+                    "mode": "%s scaling, one %s per %s" % (scaling, collective, "wavefront batch" if ev == "batch" else "iteration")}
+        if args.extra_passes:
+            other = "strong" if args.scaling == "weak" else "weak"
+            multi["value_" + other] = reading(other, every, args.collective, args.steps, min(args.warmup, 2))
+            if args.per_iteration_sample > 0:
+                # BASELINE config C3 to the letter: a fixed number of samples divided over the ranks, one pt_iterate and one
+                # reduce(sum) of zero-padded full frames per iteration
+                multi["value_c3_as_written"] = reading("strong", "1", "reduce", args.per_iteration_sample, 1)
 
     # ---- pass B: same steps with HIP events around every launch (roofline of the bounce kernel); one
     #      batch in flight, so that a launch's duration is the kernel's own and not its share of a GPU it
     #      co-occupies with the neighbouring batches' launches
-    accum.zero_()
-    init(pt.PT_FLAG_KERNEL_TIMING, 1, maxb)
-    nxt = run_steps(1, min(args.warmup, 2), every)
-    barrier()
-    pt.counters_reset()
-    dtB = timed(nxt, args.steps, every)
-    cnt = pt.counters()
+    Bp = measure(args.scaling, every, args.collective, args.steps, 1, min(args.warmup, 2), flags=pt.PT_FLAG_KERNEL_TIMING, pipeline=1)
+    dtB = Bp["walls"][0]
+    cnt = Bp["counters"]
     pt.pathtraceFree()
 
-    iters_timed = args.steps * I
+    iters_block = args.steps * I                             # iterations of one timed block
+    liveA = [int(cntA.live[d]) for d in range(D + 2)]
     live = [int(cnt.live[d]) for d in range(D + 2)]
     # paths that actually travel through the path pools: a survivor that certainly misses everything ends at its scatter and
     # is counted in live[d + 1] (it does enter that bounce and miss) without ever being written or read
@@ -311,10 +468,12 @@ def main():
     iters_per_launch = maxb      # (N > 1: the last launch of a run may carry fewer steps; the PMC figures are N = 1 only)
     avg_ms = cnt.bounce_kernel_ms / launches
     achieved = bounce_bytes / launches / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    # whole-frame path counts: summed over the ranks (every rank holds the counts of its own rows)
+    live_sum, moved_sum, liveA_sum = (sum_over_ranks([sum(live[1:D + 1]), sum(moved[1:D + 1]), sum(liveA[1:D + 1])]))
     # PMC counters of the bounce kernel from the committed rocprofv3 passes.  They are stored PER ITERATION of a launch's
     # batch together with the configuration they were collected on; used only for that very configuration (frame,
     # depth, iterations per launch), scaled by the iterations a launch of THIS run carries -- else null.
-    traffic, valu_insts, lds_conf, pmc_src = None, None, None, None
+    traffic, valu_insts, lds_conf, pmc_src, valu_util = None, None, None, None, None
     try:
         pmc = json.load(open(args.pmc_traffic_json))
         here = ["%s %dx%d" % (os.path.relpath(args.scene, ROOT), W, H), "%d bounces" % D]
@@ -322,13 +481,15 @@ def main():
             traffic = pmc["hbm_bytes_per_launch_iteration"] * iters_per_launch
             valu_insts = pmc["valu_wave_insts_per_launch_iteration"] * iters_per_launch
             lds_conf = pmc.get("lds_bank_conflict_cycles_per_launch")
+            valu_util = pmc.get("valu_utilisation_counter_derived")
             pmc_src = pmc.get("source")
     except Exception:
         pass
     rate = valu_issue_rate(args.valu_rate_json, 6)
 
     if rank == 0:
-        nominal = P * D * iters_timed
+        nominal = P * D * iters_block
+        walls = sorted(A["walls"])
         rf = {"bound": "hbm", "kernel": "k_bounce (fused [camera rays+]intersect+shade+compact, one launch per bounce and batch)",
               "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
               "frac": round(achieved / HBM_PEAK_GBS, 5),
@@ -339,12 +500,16 @@ def main():
               "bounce_kernel_share_of_step": round(cnt.bounce_kernel_ms / (dtB * 1e3), 4),
               "ms_per_step_with_events": round(dtB / args.steps * 1e3, 4),
               "pmc_source": pmc_src}
+        if world > 1:
+            rf["scope"] = "rank 0's shard (its launches, its rows' paths)"
         if valu_insts and rate:
             # the kernel is VALU-issue-bound, not HBM-bound: wave64 vector instructions per launch (PMC)
             # x MEASURED cycles per instruction per SIMD (profiles/valu_issue_rate.json) / (1024 SIMDs x 2.4 GHz)
             t_mix = valu_insts * rate["mix"] / (SIMDS * CLOCK_HZ) * 1e3
             t_fma = valu_insts * rate["fma"] / (SIMDS * CLOCK_HZ) * 1e3
             rf["valu"] = {"wave_instructions_per_launch": round(valu_insts),
+                          # from the counters alone: SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) of the profiled run
+                          "utilisation_counter_derived": round(valu_util, 4) if valu_util else None,
                           "cycles_per_instruction_per_simd_measured": {"kernel_like_mix": rate["mix"], "v_fma_f32": rate["fma"],
                                                                        "waves_per_simd": rate["waves_per_simd"]},
                           "issue_bound_ms_per_launch": {"kernel_like_mix": round(t_mix, 5), "v_fma_f32": round(t_fma, 5)},
@@ -357,32 +522,41 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            # the timed block (exactly `steps` steps between barrier + synchronise) repeated inside this run: median above
+            "repeats": len(walls),
+            "ms_per_step_min": round(walls[0] / args.steps * 1e3, 4), "ms_per_step_max": round(walls[-1] / args.steps * 1e3, 4),
+            "value_min": round(nominal / walls[-1] / 1e6, 2), "value_max": round(nominal / walls[0] / 1e6, 2),
+            "ms_per_step_blocks": [round(w / args.steps * 1e3, 4) for w in A["walls"]],
             "config": {"workload": "%s %dx%d, %d bounces, %d spp per step x %d steps%s" % (
                            os.path.relpath(args.scene, ROOT), W, H, D, I, args.steps,
                            "" if world == 1 else ", rows sharded y%%%d + RCCL %s of the row blocks per %s" % (
                                world, args.collective, "batch" if every == "batch" else "iteration")),
                        "iterations_per_step": I,
                        "paths_per_step_nominal": P * D * I,
-                       "ms_per_iteration": round(dt / iters_timed * 1e3, 5),
+                       "ms_per_iteration": round(dt / iters_block * 1e3, 5),
                        "iterations_per_wavefront_batch": maxb,
                        "batches_in_flight": args.pipeline if args.pipeline > 0 else 3,
                        "collective_every": None if world == 1 else every,
-                       "live_segments_per_iteration": round(sum(live[1:D + 1]) / max(iters_timed, 1), 1),
-                       "queued_segments_per_iteration": round(sum(moved[1:D + 1]) / max(iters_timed, 1), 1),
-                       "live_Msegments_per_s": round(sum(int(cntA.live[d]) for d in range(1, D + 1)) / dt / 1e6, 2)},
+                       "live_segments_per_iteration": round(live_sum / max(iters_block, 1), 1),
+                       # unterminated paths entering bounce d = 1 .. depth, per iteration (rank 0's rows when N > 1): the reference's
+                       # compaction analysis, README.md:284-293
+                       "live_per_bounce_per_iteration": [round(live[d] / max(iters_block, 1), 1) for d in range(1, D + 1)],
+                       "queued_segments_per_iteration": round(moved_sum / max(iters_block, 1), 1),
+                       "live_Msegments_per_s": round(liveA_sum / len(walls) / dt / 1e6, 2)},
             "roofline": rf,
         }
-        if per_iter:
-            out["config"]["per_iteration_collective"] = per_iter
+        if multi:
+            out["value_" + args.scaling] = {"value": out["value"], "unit": "Mpaths/s", "steps": args.steps, "iterations_per_step": I,
+                                            "iterations_per_wavefront_batch": maxb, "ms_per_step": out["ms_per_step"],
+                                            "mode": "%s scaling, one %s per %s" % (args.scaling, args.collective,
+                                                                                 "wavefront batch" if every == "batch" else "iteration")}
+            for k in ("value_weak", "value_strong", "value_c3_as_written"):
+                if k in multi:
+                    out[k] = multi.pop(k)
+            out["multi_gpu"] = multi
         if world == 1 and args.cpu_spp > 0:
-            out["cpu_baseline"] = cpu_baseline(args, scene)
+            out["cpu_baseline"] = cpu_baseline(args, scene, pt)
         print(json.dumps(out), flush=True)
-    if world > 1:
-        # orderly exit: nobody leaves (and tears its HIP context down) while another rank still works
-        torch.cuda.synchronize()
-        dist.barrier()
-        del accum, frame, bufs
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -218,53 +218,6 @@ int pt_scan_exclusive_i32(const int32_t *in_dev, int32_t *out_dev, int64_t n, vo
 int pt_compact_nonzero_i32(const int32_t *in_dev, int32_t *out_dev, int64_t n, int64_t *count_dev,
                            void *stream);
 
-/* ---- device primitives evaluated on the GPU over HOST arrays (parity tests of rows a6-a12, a19):
- * the same __device__ functions the render kernels call. ------------------------------------------ */
-int pt_test_utilhash(const uint32_t *in, uint32_t *out, int n);
-int pt_test_rng(const uint32_t *seeds, int nseeds, int ndraws, float *u01_out /* nseeds*ndraws */);
-/* rays: n x 6; each ray against ONE geom (geoms[geom_index[i]]); outputs keep their input values
- * on a miss like the reference's out-parameters (intersections.h:86-88,114-126). */
-int pt_test_intersect(const PtGeom *geoms, int ngeoms, const int32_t *geom_index, const float *rays,
-                      int n, float *t, float *p3, float *n3, int32_t *outside);
-/* sphereCertainMiss (world-space culling of spheres) soundness: `rays` pseudo-random rays against the spheres
- * of `geoms`; *violations = rays culled although the full test hits (must be 0), *culled = rays culled. */
-int pt_test_sphere_cull_sweep(const PtGeom *geoms, int ngeoms, uint64_t seed, int64_t rays, uint64_t *culled,
-                              uint64_t *violations);
-/* wallCertainMiss (world-space culling of large cubes against their inflated bounding boxes, which classes the queue by
- * the wall a path can still hit) soundness: as above, for the cubes of `geoms`. */
-int pt_test_wall_box_sweep(const PtGeom *geoms, int ngeoms, uint64_t seed, int64_t rays, uint64_t *culled,
-                           uint64_t *violations);
-/* Triangle meshes.  pt_test_mesh_intersect: `n` rays against ONE mesh geom on the GPU, through the hierarchy (flat = 0) or a
- * plain list of its triangles (flat = 1: the brute-force rule); outputs keep their input values on a miss; culled[i] = 1 when
- * the bounding-ball test (certainMiss) rejected the ray -- t[i] is NaN if the full test hits nevertheless (must not happen).
- * pt_test_mesh_bvh (host only, no GPU needed): the hierarchy pt_init would build -- the copy laid out for rays of direction
- * octant `octant` (bit a set: the direction's component a is negative), nearer child first -- 8 words per node (lo[3], skip,
- * hi[3], tri), links relative to the copy; *nnodes in = capacity, out = node count (2 ntris - 1). */
-int pt_test_mesh_intersect(const PtGeom *geom, const float *tris, int ntris, int flat, const float *rays, int n, float *t,
-                           float *p3, float *n3, int32_t *outside, int32_t *culled);
-int pt_test_mesh_bvh(const float *tris, int ntris, int octant, uint32_t *nodes8, int *nnodes);
-/* certainMiss soundness for a mesh geom: `rays` pseudo-random rays dense in grazes of its bounding ball (origins 1/64 .. 64
- * radii away); *violations = rays the bounding-ball test rejected although the walk hits (must be 0), *hits = rays that hit */
-int pt_test_mesh_cull_sweep(const PtGeom *geom, const float *tris, int ntris, uint64_t seed, int64_t rays, uint64_t *culled,
-                            uint64_t *violations, uint64_t *hits);
-/* slabQuotients (shared-reciprocal packed division of the box test) next to the compiler's correctly
- * rounded `/`: per-element outputs, and a device-side pseudo-random sweep that returns the number of
- * bit mismatches over `pairs` (o, d) pairs (must be 0). */
-int pt_test_slab_quotients(const float *o, const float *d, int n, float *t1, float *t2, float *ref1, float *ref2);
-int pt_test_slab_quotients_sweep(uint64_t seed, int64_t pairs, uint64_t *mismatches);
-/* sqrtUnscaled (the correctly rounded sqrt without its exponent-range handling, used by the hemisphere sampler)
- * next to the compiler's sqrt on every fp32 bit pattern of its range (+-0 and [2^-96, inf)), and inverseSqrtNearOne
- * (the re-normalisation of getPointOnRay) next to 1.0f / sqrtf on every bit pattern: mismatches[0] and [2] must be 0,
- * [1] = patterns inside sqrtUnscaled's range, [3] = patterns on inverseSqrtNearOne's short path (513). */
-int pt_test_unscaled_sqrt_sweep(uint64_t mismatches[4]);
-/* sets the renderer's device fault word by hand (2; 0 clears it in every slot), so that the reporting path can be tested */
-int pt_test_force_fault(int which);
-int pt_test_hemisphere(const float *normals3, const int32_t *iter_index_depth3, int n, float *out3);
-int pt_test_sincos(const float *x, int n, float *s, float *c);
-int pt_test_pow(const float *x, const float *e, int n, float *out);   /* build-defined x^e of the imperfect-specular sampler */
-int pt_test_reflect_refract(const float *I3, const float *N3, const float *eta, int n, float *refl3,
-                            float *refr3);
-
 #ifdef __cplusplus
 }
 #endif

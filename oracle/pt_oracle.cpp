@@ -699,6 +699,7 @@ struct OScene {
     std::string imageName;
     std::string dir;                   /* directory of the scene file: `mesh <file>` paths are relative to it */
     std::vector<OMesh> meshes;         /* geoms of type 2 */
+    bool failed = false;               /* a `mesh <file>` object whose file cannot be read: the load fails (like an unreadable scene file) */
 };
 
 struct ORender {
@@ -842,6 +843,8 @@ void load_geom(OScene &sc, std::ifstream &fp, const std::string &idtok) {
                     m.margin = mesh_margin(m.tris.data(), (int)(m.tris.size() / 9));
                     sc.meshes.push_back(m);
                     g.type = 2;
+                } else {
+                    sc.failed = true;
                 }
             }
         }
@@ -1119,6 +1122,10 @@ OScene *orc_scene_load(const char *path) {
             else if (t.size() >= 2 && is(t, "OBJECT")) load_geom(*sc, fp, t[1]);
             else if (is(t, "CAMERA")) load_camera(*sc, fp);
         }
+    }
+    if (sc->failed) {
+        delete sc;
+        return NULL;
     }
     return sc;
 }

@@ -36,7 +36,7 @@ def inst(name):
     m = re.search(r"k_bounce<([^>]*)>", name)
     if m:
         return "k_bounce<%s>" % m.group(1)
-    m = re.search(r"k_bounceILb([01])ELb([01])E(?:Lb([01])E)?", name)
+    m = re.search(r"k_bounceILb([01])ELb([01])E(?:Lb([01])E)?(?:Lb([01])E)?", name)
     if m:
         return "k_bounce<%s>" % ", ".join("true" if g == "1" else "false" for g in m.groups() if g is not None)
     return None
@@ -164,6 +164,12 @@ def main():
                 pj["valu_wave_insts_per_launch_iteration"] = kb["SQ_INSTS_VALU"] / ipl
                 pj["salu_insts_per_launch_iteration"] = kb.get("SQ_INSTS_SALU", 0.0) / ipl
                 pj["lds_bank_conflict_cycles_per_launch"] = kb.get("SQ_LDS_BANK_CONFLICT")
+                if kb.get("GRBM_GUI_ACTIVE"):
+                    # counter-derived vector-issue utilisation: wave64 vector instructions x the 2 cycles each occupies a SIMD
+                    # (MI355X_MICROARCH.md: "issues each VALU instruction over 2 cycles") / (1024 SIMDs x the launch's cycles;
+                    # GRBM_GUI_ACTIVE is summed over the 8 XCDs)
+                    pj["grbm_gui_active_per_launch"] = kb["GRBM_GUI_ACTIVE"]
+                    pj["valu_utilisation_counter_derived"] = kb["SQ_INSTS_VALU"] * 2.0 / (1024.0 * kb["GRBM_GUI_ACTIVE"] / 8.0)
         if args.set_default:
             json.dump(pj, open(os.path.join(HERE, "pmc_traffic.json"), "w"), indent=1)
         out["k_bounce"]["traffic"] = pj
@@ -179,6 +185,11 @@ def main():
             pd = ii["pmc_per_dispatch"]
             if "SQ_WAVE_CYCLES" in pd and "SQ_WAIT_ANY" in pd:
                 ii["wave_wait_fraction"] = pd["SQ_WAIT_ANY"] / pd["SQ_WAVE_CYCLES"]
+            if pd.get("GRBM_GUI_ACTIVE") and "SQ_INSTS_VALU" in pd:
+                ii["valu_utilisation_counter_derived"] = pd["SQ_INSTS_VALU"] * 2.0 / (1024.0 * pd["GRBM_GUI_ACTIVE"] / 8.0)
+            if "FETCH_SIZE" in pd and "WRITE_SIZE" in pd and ii.get("trace_avg_ns"):
+                ii["hbm_bytes_per_launch"] = pd["FETCH_SIZE"] * 2048.0 + pd["WRITE_SIZE"] * 1024.0
+                ii["hbm_fraction_of_8TBs"] = ii["hbm_bytes_per_launch"] / (ii["trace_avg_ns"] * 1e-9) / 8e12
     # the bench line of the profiled command (trace pass), for the record
     try:
         for line in open(os.path.join(src, "trace.log")):

@@ -45,15 +45,21 @@ PT_FLAG_ACCUM_SHARD_ROWS = 2
 PT_FLAG_DIRECT_LIGHTING = 4
 PT_FLAG_TRACE_AHEAD = 8
 
-# every symbol include/pt_amd.h declares
+# second link target of the same source: + the test-only entry points of include/pt_amd_test.h (tests/ and profiles/ only)
+TEST_LIB_PATH = os.path.join(HERE, "csrc", "libpt_amd_test.so")
+
+# every symbol include/pt_amd.h declares: the product's whole exported surface
 ABI_SYMBOLS = [
     "pt_init", "pt_iterate", "pt_iterate_batch", "pt_sync", "pt_readback", "pt_readback_rgba8", "pt_counters",
     "pt_counters_reset", "pt_free", "pt_last_error", "pt_device_count", "pt_debug_trace_paths",
-    "pt_scan_exclusive_i32", "pt_compact_nonzero_i32", "pt_test_utilhash", "pt_test_rng",
-    "pt_test_intersect", "pt_test_hemisphere", "pt_test_sincos", "pt_test_reflect_refract",
-    "pt_test_slab_quotients", "pt_test_slab_quotients_sweep", "pt_test_sphere_cull_sweep",
-    "pt_test_unscaled_sqrt_sweep", "pt_pin_host", "pt_unpin_host", "pt_test_force_fault", "pt_test_pow", "pt_test_wall_box_sweep",
-    "pt_set_meshes", "pt_test_mesh_intersect", "pt_test_mesh_bvh", "pt_test_mesh_cull_sweep",
+    "pt_scan_exclusive_i32", "pt_compact_nonzero_i32", "pt_pin_host", "pt_unpin_host", "pt_set_meshes",
+]
+# every symbol include/pt_amd_test.h declares: libpt_amd_test.so only -- the product library must NOT export them
+TEST_ABI_SYMBOLS = [
+    "pt_test_utilhash", "pt_test_rng", "pt_test_intersect", "pt_test_hemisphere", "pt_test_sincos", "pt_test_reflect_refract",
+    "pt_test_slab_quotients", "pt_test_slab_quotients_sweep", "pt_test_sphere_cull_sweep", "pt_test_unscaled_sqrt_sweep",
+    "pt_test_force_fault", "pt_test_pow", "pt_test_wall_box_sweep", "pt_test_mesh_intersect", "pt_test_mesh_bvh",
+    "pt_test_mesh_cull_sweep", "pt_test_camera_cull_sweep", "pt_test_camera_cull_tables",
 ]
 
 
@@ -78,39 +84,33 @@ class PtError(RuntimeError):
 
 
 _lib = None
+_test = None
 _host = None
+_atexit_registered = False
 
 
-def lib():
-    """The HIP extension.  Raises (never falls back) when it has not been built."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise PtError("HIP extension missing: %s (run __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
-        # torch (device memory / streams / RCCL plumbing) bundles its own libamdhip64.so; it has to be
-        # loaded FIRST so that this library binds to the same HIP runtime instance (same soname) and
-        # torch stream handles / device pointers are valid here.  Two runtimes in one process break both.
-        try:
-            import torch  # noqa: F401
-        except ImportError:
-            pass
-        L = C.CDLL(LIB_PATH)
-        vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
-        L.pt_init.argtypes = [vp, vp, i32, vp, i32, i32, C.POINTER(PtOptions)]
-        L.pt_iterate.argtypes = [i32, i32, vp]
-        L.pt_iterate_batch.argtypes = [i32, i32, i32, vp]
-        L.pt_sync.argtypes = []
-        L.pt_readback.argtypes = [vp]
-        L.pt_readback_rgba8.argtypes = [i32, vp]
-        L.pt_counters.argtypes = [C.POINTER(PtCounters)]
-        L.pt_counters_reset.argtypes = []
-        L.pt_free.argtypes = []
-        L.pt_free.restype = None
-        L.pt_last_error.restype = C.c_char_p
-        L.pt_device_count.argtypes = []
-        L.pt_debug_trace_paths.argtypes = [i32, i32, vp, vp, vp, vp, C.POINTER(C.c_int32)]
-        L.pt_scan_exclusive_i32.argtypes = [vp, vp, i64, vp]
-        L.pt_compact_nonzero_i32.argtypes = [vp, vp, i64, vp, vp]
+def _bind(L, with_tests):
+    vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
+    L.pt_init.argtypes = [vp, vp, i32, vp, i32, i32, C.POINTER(PtOptions)]
+    L.pt_iterate.argtypes = [i32, i32, vp]
+    L.pt_iterate_batch.argtypes = [i32, i32, i32, vp]
+    L.pt_sync.argtypes = []
+    L.pt_readback.argtypes = [vp]
+    L.pt_readback_rgba8.argtypes = [i32, vp]
+    L.pt_counters.argtypes = [C.POINTER(PtCounters)]
+    L.pt_counters_reset.argtypes = []
+    L.pt_free.argtypes = []
+    L.pt_free.restype = None
+    L.pt_last_error.restype = C.c_char_p
+    L.pt_device_count.argtypes = []
+    L.pt_debug_trace_paths.argtypes = [i32, i32, vp, vp, vp, vp, C.POINTER(C.c_int32)]
+    L.pt_scan_exclusive_i32.argtypes = [vp, vp, i64, vp]
+    L.pt_compact_nonzero_i32.argtypes = [vp, vp, i64, vp, vp]
+    L.pt_pin_host.argtypes = [vp, C.c_size_t]
+    L.pt_unpin_host.argtypes = []
+    L.pt_set_meshes.argtypes = [C.POINTER(PtMesh), i32]
+    if with_tests:
+        u64p = C.POINTER(C.c_uint64)
         L.pt_test_utilhash.argtypes = [vp, vp, i32]
         L.pt_test_rng.argtypes = [vp, i32, i32, vp]
         L.pt_test_intersect.argtypes = [vp, i32, vp, vp, i32, vp, vp, vp, vp]
@@ -118,25 +118,74 @@ def lib():
         L.pt_test_sincos.argtypes = [vp, i32, vp, vp]
         L.pt_test_reflect_refract.argtypes = [vp, vp, vp, i32, vp, vp]
         L.pt_test_slab_quotients.argtypes = [vp, vp, i32, vp, vp, vp, vp]
-        L.pt_test_slab_quotients_sweep.argtypes = [C.c_uint64, i64, C.POINTER(C.c_uint64)]
-        L.pt_test_sphere_cull_sweep.argtypes = [vp, i32, C.c_uint64, i64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
-        L.pt_test_unscaled_sqrt_sweep.argtypes = [C.POINTER(C.c_uint64)]
-        L.pt_pin_host.argtypes = [vp, C.c_size_t]
-        L.pt_unpin_host.argtypes = []
+        L.pt_test_slab_quotients_sweep.argtypes = [C.c_uint64, i64, u64p]
+        L.pt_test_sphere_cull_sweep.argtypes = [vp, i32, C.c_uint64, i64, u64p, u64p]
+        L.pt_test_unscaled_sqrt_sweep.argtypes = [u64p]
         L.pt_test_force_fault.argtypes = [i32]
         L.pt_test_pow.argtypes = [vp, vp, i32, vp]
-        L.pt_test_wall_box_sweep.argtypes = [vp, i32, C.c_uint64, i64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
-        L.pt_set_meshes.argtypes = [C.POINTER(PtMesh), i32]
+        L.pt_test_wall_box_sweep.argtypes = [vp, i32, C.c_uint64, i64, u64p, u64p]
         L.pt_test_mesh_intersect.argtypes = [vp, vp, i32, i32, vp, i32, vp, vp, vp, vp, vp]
         L.pt_test_mesh_bvh.argtypes = [vp, i32, i32, vp, C.POINTER(C.c_int)]
-        L.pt_test_mesh_cull_sweep.argtypes = [vp, vp, i32, C.c_uint64, i64] + [C.POINTER(C.c_uint64)] * 3
-        _lib = L
+        L.pt_test_mesh_cull_sweep.argtypes = [vp, vp, i32, C.c_uint64, i64] + [u64p] * 3
+        L.pt_test_camera_cull_sweep.argtypes = [vp, vp, i32, i32] + [u64p] * 3
+        L.pt_test_camera_cull_tables.argtypes = [vp, vp, i32, vp, vp, vp]
+    return L
+
+
+def _load(path, with_tests):
+    if not os.path.exists(path):
+        raise PtError("HIP extension missing: %s (run __graft_entry__.build()); there is no CPU fallback" % path)
+    # torch (device memory / streams / RCCL plumbing) bundles its own libamdhip64.so; it has to be
+    # loaded FIRST so that this library binds to the same HIP runtime instance (same soname) and
+    # torch stream handles / device pointers are valid here.  Two runtimes in one process break both.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    return _bind(C.CDLL(path), with_tests)
+
+
+def lib():
+    """The HIP extension (the product library).  Raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        _lib = _load(LIB_PATH, False)
     return _lib
 
 
-def _check(rc):
+def test_lib():
+    """libpt_amd_test.so: the same source linked with the test-only entry points of include/pt_amd_test.h.  It holds its own
+    renderer instance; the product path never loads it."""
+    global _test
+    if _test is None:
+        _test = _load(TEST_LIB_PATH, True)
+    return _test
+
+
+class renderer_from_test_library:
+    """Context manager for the one test that has to reach INTO a renderer (pt_test_force_fault): inside it the renderer API of
+    this module drives the instance that lives in libpt_amd_test.so."""
+
+    def __enter__(self):
+        global _lib
+        self._saved = lib()
+        _lib = test_lib()
+        return self
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib.pt_free()
+        _lib = self._saved
+        return False
+
+
+def _check(rc, L=None):
     if rc != 0:
-        raise PtError("pt_amd error %d: %s" % (rc, lib().pt_last_error().decode()))
+        raise PtError("pt_amd error %d: %s" % (rc, (L or lib()).pt_last_error().decode()))
+
+
+def _tcheck(rc):
+    _check(rc, test_lib())
 
 
 def _p(a):
@@ -245,6 +294,14 @@ def pathtraceInit(scene, shard_rank=0, shard_count=1, stream=0, accum_dev=0, dev
     cam = np.ascontiguousarray(scene.camera)
     depth = scene.traceDepth if traceDepth is None else traceDepth
     set_meshes(getattr(scene, "meshes", None) or {})
+    global _atexit_registered
+    if not _atexit_registered:
+        # an interpreter that exits with a live renderer (an exception between pathtrace and pathtraceFree): drain the streams
+        # and release everything while the interpreter, torch and the HIP runtime are still whole (the library registers its own
+        # exit handler as well, for hosts that are not Python)
+        import atexit
+        atexit.register(pathtraceFree)
+        _atexit_registered = True
     _check(lib().pt_init(_p(cam), _p(geoms), len(geoms), _p(mats), len(mats), depth, C.byref(opt)))
     _scene = scene
 
@@ -276,7 +333,8 @@ def pathtrace_batch(pbo, frame, first_iteration, count, readback=False):
 def pathtraceFree():
     """reference src/pathtrace.cu:87-92; legal before the first pathtraceInit (src/main.cpp:91-94)."""
     global _scene
-    lib().pt_free()
+    if _lib is not None:          # (nothing to free in a library that was never loaded)
+        _lib.pt_free()
     _scene = None
 
 
@@ -285,8 +343,8 @@ def sync():
 
 
 def force_fault(which):
-    """Diagnostics: set the renderer's device fault word by hand (2), or clear it (0)."""
-    _check(lib().pt_test_force_fault(which))
+    """Diagnostics (test library only, see renderer_from_test_library): set the renderer's device fault word by hand (2), or clear it (0)."""
+    _tcheck(test_lib().pt_test_force_fault(which))
 
 
 def readback(npixels):
@@ -348,14 +406,14 @@ def save_hdr(basename, image_sum, samples):
 def test_utilhash(x):
     x = np.ascontiguousarray(x, np.uint32)
     out = np.empty_like(x)
-    _check(lib().pt_test_utilhash(_p(x), _p(out), x.size))
+    _tcheck(test_lib().pt_test_utilhash(_p(x), _p(out), x.size))
     return out
 
 
 def test_rng(seeds, ndraws):
     seeds = np.ascontiguousarray(seeds, np.uint32)
     out = np.empty((seeds.size, ndraws), np.float32)
-    _check(lib().pt_test_rng(_p(seeds), seeds.size, ndraws, _p(out)))
+    _tcheck(test_lib().pt_test_rng(_p(seeds), seeds.size, ndraws, _p(out)))
     return out
 
 
@@ -368,7 +426,7 @@ def test_intersect(geoms, geom_index, rays, sentinel=-7.0):
     p = np.full((n, 3), sentinel, np.float32)
     nn = np.full((n, 3), sentinel, np.float32)
     o = np.ones(n, np.int32)
-    _check(lib().pt_test_intersect(_p(geoms), len(geoms), _p(gi), _p(rays), n, _p(t), _p(p), _p(nn), _p(o)))
+    _tcheck(test_lib().pt_test_intersect(_p(geoms), len(geoms), _p(gi), _p(rays), n, _p(t), _p(p), _p(nn), _p(o)))
     return t, p, nn, o
 
 
@@ -383,7 +441,7 @@ def test_mesh_intersect(geom, tris, rays, flat=False, sentinel=-7.0):
     nn = np.full((n, 3), sentinel, np.float32)
     o = np.ones(n, np.int32)
     culled = np.zeros(n, np.int32)
-    _check(lib().pt_test_mesh_intersect(_p(g), _p(tr), len(tr), 1 if flat else 0, _p(rays), n, _p(t), _p(p), _p(nn), _p(o), _p(culled)))
+    _tcheck(test_lib().pt_test_mesh_intersect(_p(g), _p(tr), len(tr), 1 if flat else 0, _p(rays), n, _p(t), _p(p), _p(nn), _p(o), _p(culled)))
     return t, p, nn, o, culled
 
 
@@ -392,7 +450,7 @@ def test_mesh_cull_sweep(geom, tris, seed, rays):
     g = np.ascontiguousarray(geom).reshape(-1)[:1]
     tr = np.ascontiguousarray(tris, np.float32).reshape(-1, 9)
     c, v, h = C.c_uint64(), C.c_uint64(), C.c_uint64()
-    _check(lib().pt_test_mesh_cull_sweep(_p(g), _p(tr), len(tr), seed, rays, C.byref(c), C.byref(v), C.byref(h)))
+    _tcheck(test_lib().pt_test_mesh_cull_sweep(_p(g), _p(tr), len(tr), seed, rays, C.byref(c), C.byref(v), C.byref(h)))
     return c.value, v.value, h.value
 
 
@@ -403,7 +461,7 @@ def mesh_bvh(tris, octant=0):
     node = np.dtype([("lo", "<f4", 3), ("skip", "<u4"), ("hi", "<f4", 3), ("tri", "<i4")])
     out = np.zeros(2 * len(tr), node)
     n = C.c_int(len(out))
-    _check(lib().pt_test_mesh_bvh(_p(tr), len(tr), octant, _p(out), C.byref(n)))
+    _tcheck(test_lib().pt_test_mesh_bvh(_p(tr), len(tr), octant, _p(out), C.byref(n)))
     return out[:n.value]
 
 
@@ -411,14 +469,14 @@ def test_hemisphere(normals, iter_index_depth):
     normals = np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
     iid = np.ascontiguousarray(iter_index_depth, np.int32).reshape(-1, 3)
     out = np.empty_like(normals)
-    _check(lib().pt_test_hemisphere(_p(normals), _p(iid), len(normals), _p(out)))
+    _tcheck(test_lib().pt_test_hemisphere(_p(normals), _p(iid), len(normals), _p(out)))
     return out
 
 
 def test_sincos(x):
     x = np.ascontiguousarray(x, np.float32)
     s, c = np.empty_like(x), np.empty_like(x)
-    _check(lib().pt_test_sincos(_p(x), x.size, _p(s), _p(c)))
+    _tcheck(test_lib().pt_test_sincos(_p(x), x.size, _p(s), _p(c)))
     return s, c
 
 
@@ -426,7 +484,7 @@ def test_pow(x, e):
     x = np.ascontiguousarray(x, np.float32)
     e = np.ascontiguousarray(e, np.float32)
     out = np.empty_like(x)
-    _check(lib().pt_test_pow(_p(x), _p(e), x.size, _p(out)))
+    _tcheck(test_lib().pt_test_pow(_p(x), _p(e), x.size, _p(out)))
     return out
 
 
@@ -435,7 +493,7 @@ def test_reflect_refract(I, N, eta):
     N = np.ascontiguousarray(N, np.float32).reshape(-1, 3)
     eta = np.ascontiguousarray(eta, np.float32)
     r1, r2 = np.empty_like(I), np.empty_like(I)
-    _check(lib().pt_test_reflect_refract(_p(I), _p(N), _p(eta), len(I), _p(r1), _p(r2)))
+    _tcheck(test_lib().pt_test_reflect_refract(_p(I), _p(N), _p(eta), len(I), _p(r1), _p(r2)))
     return r1, r2
 
 
@@ -443,34 +501,55 @@ def test_slab_quotients(o, d):
     o = np.ascontiguousarray(o, np.float32)
     d = np.ascontiguousarray(d, np.float32)
     out = [np.empty_like(o) for _ in range(4)]
-    _check(lib().pt_test_slab_quotients(_p(o), _p(d), o.size, *[_p(a) for a in out]))
+    _tcheck(test_lib().pt_test_slab_quotients(_p(o), _p(d), o.size, *[_p(a) for a in out]))
     return out
 
 
 def test_slab_quotients_sweep(seed, pairs):
     m = C.c_uint64(0)
-    _check(lib().pt_test_slab_quotients_sweep(seed, pairs, C.byref(m)))
+    _tcheck(test_lib().pt_test_slab_quotients_sweep(seed, pairs, C.byref(m)))
     return int(m.value)
 
 
 def test_unscaled_sqrt_sweep():
     m = (C.c_uint64 * 4)()
-    _check(lib().pt_test_unscaled_sqrt_sweep(m))
+    _tcheck(test_lib().pt_test_unscaled_sqrt_sweep(m))
     return [int(v) for v in m]
 
 
 def test_sphere_cull_sweep(geoms, seed, rays):
     geoms = np.ascontiguousarray(geoms)
     culled, bad = C.c_uint64(0), C.c_uint64(0)
-    _check(lib().pt_test_sphere_cull_sweep(_p(geoms), len(geoms), seed, rays, C.byref(culled), C.byref(bad)))
+    _tcheck(test_lib().pt_test_sphere_cull_sweep(_p(geoms), len(geoms), seed, rays, C.byref(culled), C.byref(bad)))
     return int(culled.value), int(bad.value)
 
 
 def test_wall_box_sweep(geoms, seed, rays):
     geoms = np.ascontiguousarray(geoms)
     culled, bad = C.c_uint64(0), C.c_uint64(0)
-    _check(lib().pt_test_wall_box_sweep(_p(geoms), len(geoms), seed, rays, C.byref(culled), C.byref(bad)))
+    _tcheck(test_lib().pt_test_wall_box_sweep(_p(geoms), len(geoms), seed, rays, C.byref(culled), C.byref(bad)))
     return int(culled.value), int(bad.value)
+
+
+def camera_cull_tables(camera, geoms):
+    """The camera-ray culling tables pt_init derives (host only).  Returns (rects (n, 4), scene rect (4,), spans (H, n, 2))."""
+    cam = np.ascontiguousarray(camera)
+    geoms = np.ascontiguousarray(geoms)
+    H = int(cam["resolution"][0][1])
+    rects = np.zeros((len(geoms), 4), np.int32)
+    scene = np.zeros(4, np.int32)
+    spans = np.zeros((H, len(geoms), 2), np.int32)
+    _tcheck(test_lib().pt_test_camera_cull_tables(_p(cam), _p(geoms), len(geoms), _p(rects), _p(scene), _p(spans)))
+    return rects, scene, spans
+
+
+def test_camera_cull_sweep(camera, geoms, samples=1):
+    """Device sweep of the camera-ray culling for one (camera, primitive set).  Returns (hits, culled pairs, violations)."""
+    cam = np.ascontiguousarray(camera)
+    geoms = np.ascontiguousarray(geoms)
+    h, c, v = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    _tcheck(test_lib().pt_test_camera_cull_sweep(_p(cam), _p(geoms), len(geoms), samples, C.byref(h), C.byref(c), C.byref(v)))
+    return int(h.value), int(c.value), int(v.value)
 
 
 def scan_exclusive_dev(in_ptr, out_ptr, n, stream=0):

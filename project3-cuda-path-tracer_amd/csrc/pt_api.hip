@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -25,11 +26,18 @@
 #include <string>
 #include <vector>
 
+#include <mutex>
+
 #include "../../include/pt_amd.h"
 #include "pt_compaction.h"
-#include "pt_test_kernels.h"
 #include "pt_trace.h"
 #include "pt_mesh.h"
+// The entry points of include/pt_amd_test.h (device primitives one by one, soundness sweeps, the fault-word hook) exist only in
+// the second link target of this source, libpt_amd_test.so (-DPT_TEST_API): the product library exports none of them.
+#ifdef PT_TEST_API
+#include "../../include/pt_amd_test.h"
+#include "pt_test_kernels.h"
+#endif
 
 using namespace ptd;
 using namespace ptk;
@@ -124,6 +132,10 @@ struct State {
     std::vector<hipEvent_t> evFree;   // resolved timing events, reused (creating two per launch cost 1 % of a timed step)
     double msBounce = 0;
     long long nBounce = 0;
+    // The sticky fault word once more, in page-locked HOST memory the kernels can write (a fault path stores it there too): pt_readback
+    // and pt_readback_rgba8, which synchronise anyway, then report a faulted render without a device-to-host copy of their own.
+    uint32_t *hostFault = nullptr;       // host address
+    uint32_t *hostFaultDev = nullptr;    // the same word as the kernels address it
 } S;
 
 // triangle soups registered by pt_set_meshes, consumed by the next pt_init (kept across pt_free: the reference's
@@ -342,12 +354,69 @@ void pack_material(const PtMaterial &m, MaterialDev &d) {
 // the primitive; its bounding rectangle is widened by 2 pixels.  Any corner not strictly in front of the eye, or a
 // singular M, disables the culling for this primitive (whole frame).
 // `hull` (optional): the eight projected corners (continuous pixel coordinates) when the rectangle is a real one, else empty
+// What the rectangle must contain is not the primitive but every pixel whose camera ray the REFERENCE's test can report as a hit,
+// and that test works in fp32 in object space: seen from R object units away (R large for a small, a distant or a flat
+// primitive -- the inverse transform magnifies the eye's coordinates by 1 / scale), the object-space origin carries an absolute error
+// ~eps R, the normalised object-space direction ~eps (row sums of the inverse transform x the transform's largest singular value), and the sphere's
+// radicand (ro . rd)^2 - (ro . ro - 0.25) ~eps R^2.  A ray that misses the exact primitive by less than that can come back as a hit
+// (the device sweep found them at once: a 100 : 1 ellipsoid seen from 20 000 object units through a 1.5-degree lens "hit" from
+// pixels 60 columns off its projection).  So the box whose corners are projected is the object-space box INFLATED by those errors, with
+// safety factors of 2 - 3 on first-order bounds (eps = 2^-24):
+//     A_i  = sum_j |inv_ij| |eye_j| + |inv_i3|        magnitude of the sums behind ro_i          (error of ro_i   <= 3 eps A_i)
+//     B_i  = sum_j |inv_ij|                           ... behind (inverseTransform d)_i, |d| <= 1 (error          <= 3 eps B_i)
+//     R    = |A| + 1                                  object-space distance over which a direction error acts
+//     D_i  = 8 eps A_i + R (8 eps B_i smax + 8 eps)   displacement of the computed line along axis i (smax >= the transform's largest
+//                                                     singular value: |inverseTransform d| >= |d| / smax)
+//     cube / mesh box: half extent + 2 D_i (+ 2e-5 R for a mesh: the relative slack of its slab comparisons), all x (1 + 1e-5)
+//     sphere:          the cube of half extent  sqrt(1/4 + 32 eps R^2) + 2 |D|  on every axis
+// For Cornell's walls that is a fraction of a pixel at 1280 x 720; for the ellipsoid above a hundred pixels; when the inflated box
+// reaches the eye, a corner is no longer in front of it and the primitive is not culled at all.
+void inflated_object_box(const PtGeom &g, const float *eye, const float *box, double lo[3], double hi[3]) {
+    const double eps = 5.9604644775390625e-08;                // 2^-24
+    double A[3], B[3], smax2 = 0;
+    for (int i = 0; i < 3; ++i) {
+        A[i] = std::fabs((double)g.inverseTransform[12 + i]);
+        B[i] = 0;
+        for (int j = 0; j < 3; ++j) {
+            const double m = std::fabs((double)g.inverseTransform[j * 4 + i]);
+            A[i] += m * std::fabs((double)eye[j]);
+            B[i] += m;
+            smax2 += (double)g.transform[j * 4 + i] * (double)g.transform[j * 4 + i];       // Frobenius norm >= largest singular value
+        }
+    }
+    const double smax = std::sqrt(smax2);
+    const double R = std::sqrt(A[0] * A[0] + A[1] * A[1] + A[2] * A[2]) + 1.0;
+    double D[3], Dn = 0;
+    for (int i = 0; i < 3; ++i) {
+        D[i] = 8 * eps * A[i] + R * (8 * eps * B[i] * smax + 8 * eps);
+        Dn += D[i] * D[i];
+    }
+    Dn = std::sqrt(Dn);
+    for (int i = 0; i < 3; ++i) {
+        double l = box ? box[i] : -0.5, h = box ? box[3 + i] : 0.5;
+        if (g.type == PT_SPHERE) {
+            const double r = std::sqrt(0.25 + 32 * eps * R * R) + 2 * Dn;
+            l = -r; h = r;
+        } else {
+            const double d = 2 * D[i] + (box ? 2e-5 * R : 0.0);
+            l -= d; h += d;
+        }
+        const double c = 0.5 * (l + h), e = 0.5 * (h - l) * (1 + 1e-5);
+        lo[i] = c - e;
+        hi[i] = c + e;
+    }
+}
+
 void project_geom(const PtGeom &g, const KParams &k, int rect[4], const float *box = nullptr, std::vector<std::pair<double, double>> *hull = nullptr) {
     if (hull) hull->clear();
     std::vector<std::pair<double, double>> pts;
     rect[0] = rect[1] = 0;
     rect[2] = k.W - 1;
     rect[3] = k.H - 1;
+    double blo[3], bhi[3];
+    inflated_object_box(g, k.pos, box, blo, bhi);
+    for (int a = 0; a < 3; ++a)
+        if (!std::isfinite(blo[a]) || !std::isfinite(bhi[a])) return;
     const double M[3][3] = {{k.view[0], -(double)k.pixLenX * k.right[0], -(double)k.pixLenY * k.up[0]},
                             {k.view[1], -(double)k.pixLenX * k.right[1], -(double)k.pixLenY * k.up[1]},
                             {k.view[2], -(double)k.pixLenX * k.right[2], -(double)k.pixLenY * k.up[2]}};
@@ -359,9 +428,8 @@ void project_geom(const PtGeom &g, const KParams &k, int rect[4], const float *b
     if (!(std::fabs(det) > 1e-12 * scale * scale * scale) || !std::isfinite(det)) return;
     double xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
     for (int corner = 0; corner < 8; ++corner) {
-        double o[3] = {(corner & 1) ? 0.5 : -0.5, (corner & 2) ? 0.5 : -0.5, (corner & 4) ? 0.5 : -0.5};
-        if (box)                                           // a mesh: the corners of its object-space box
-            for (int a = 0; a < 3; ++a) o[a] = box[((corner >> a) & 1) ? 3 + a : a];
+        double o[3];
+        for (int a = 0; a < 3; ++a) o[a] = ((corner >> a) & 1) ? bhi[a] : blo[a];       // (the inflated unit cube, or a mesh's inflated box)
         double q[3];
         for (int r = 0; r < 3; ++r)
             q[r] = (double)g.transform[0 + r] * o[0] + (double)g.transform[4 + r] * o[1] + (double)g.transform[8 + r] * o[2] +
@@ -415,6 +483,66 @@ bool hull_row_span(const std::vector<std::pair<double, double>> &pts, int y, dou
     return xmin <= xmax;
 }
 
+// Screen-space culling of camera rays, everything pt_init derives from the camera and the primitives' transforms:
+//   hg[i].rect   pixel rectangle of primitive i (project_geom),
+//   sceneRect    their union: camera rays of pixels outside miss everything (whole tiles are skipped there),
+//   rowOff/rowIdx per image row y the primitives whose rectangle covers it, each with the pixels of that row inside the convex
+//                hull of its projected corners (hull_row_span): entries {primitive, x0 | x1 << 16}, file order; empty when the
+//                frame is too large for the tables (the kernels then use the rectangles).
+// Soundness: a primitive lies inside its object-space box, the box inside the convex hull of its eight corners, and a camera ray
+// of pixel (x, y) passes the image plane at continuous coordinates in [x, x + 1] x [y, y + 1]; every hit of the reference's tests
+// (src/intersections.h:47-143) is a geometric hit of the primitive up to their ~1e-6 relative rounding, which the two pixels of
+// margin on every side exceed by orders of magnitude at any supported width (2 px of a 32768-px row is still 6e-5 of the
+// image plane).  Whatever cannot be bounded -- a corner not clearly in front of the eye, a singular camera basis -- disables
+// the culling for that primitive (whole frame).  `boxes[i]`: object-space bounds of a mesh (6 floats), nullptr otherwise.
+// `off`: no culling at all (PT_AMD_NO_CAMERA_CULL, tests only: the reference semantics the culled render must reproduce).
+struct CameraCull {
+    int sceneRect[4];
+    std::vector<int> rowOff, rowIdx;
+};
+void build_camera_cull(const PtGeom *geoms, int ngeoms, const KParams &k, bool off, const std::vector<const float *> &boxes,
+                       std::vector<GeomDev> &hg, CameraCull &cc) {
+    const int Wd = k.W, H = k.H;
+    cc.sceneRect[0] = cc.sceneRect[1] = 0x7fffffff;   // empty union: a scene without primitives is never entered
+    cc.sceneRect[2] = cc.sceneRect[3] = -1;
+    cc.rowOff.clear();
+    cc.rowIdx.clear();
+    std::vector<std::vector<std::pair<double, double>>> hulls(ngeoms ? ngeoms : 1);   // projected corners per primitive
+    for (int i = 0; i < ngeoms; ++i) {
+        project_geom(geoms[i], k, hg[i].rect, boxes[i], &hulls[i]);
+        if (off) {        // (thin lens: rays start anywhere on the lens, the pinhole projection bounds nothing)
+            hg[i].rect[0] = hg[i].rect[1] = 0;
+            hg[i].rect[2] = Wd - 1;
+            hg[i].rect[3] = H - 1;
+            hulls[i].clear();
+        }
+        cc.sceneRect[0] = std::min(cc.sceneRect[0], hg[i].rect[0]);
+        cc.sceneRect[1] = std::min(cc.sceneRect[1], hg[i].rect[1]);
+        cc.sceneRect[2] = std::max(cc.sceneRect[2], hg[i].rect[2]);
+        cc.sceneRect[3] = std::max(cc.sceneRect[3], hg[i].rect[3]);
+    }
+    if (off || !((long long)H * ngeoms < (1ll << 26) && Wd <= 32768)) return;
+    cc.rowOff.resize(H + 1);
+    for (int y = 0; y < H; ++y) {
+        cc.rowOff[y] = (int)(cc.rowIdx.size() / 2);
+        for (int i = 0; i < ngeoms; ++i) {
+            if (!(y >= hg[i].rect[1] && y <= hg[i].rect[3] && hg[i].rect[0] <= hg[i].rect[2])) continue;
+            int x0 = hg[i].rect[0], x1 = hg[i].rect[2];
+            if (!hulls[i].empty()) {
+                double xmin, xmax;
+                if (!hull_row_span(hulls[i], y, xmin, xmax)) continue;
+                x0 = std::max(x0, (int)std::max(std::floor(xmin) - 2.0, -1.0e9));
+                x1 = std::min(x1, (int)std::min(std::ceil(xmax) + 2.0, 1.0e9));
+                if (x0 > x1) continue;
+            }
+            cc.rowIdx.push_back(i);
+            cc.rowIdx.push_back(x0 | (x1 << 16));
+        }
+    }
+    cc.rowOff[H] = (int)(cc.rowIdx.size() / 2);
+    if (cc.rowIdx.empty()) { cc.rowIdx.push_back(0); cc.rowIdx.push_back(0); }
+}
+
 // host mirrors of the glm ops used for the camera basis (same op order as ptd::)
 struct H3 { float x, y, z; };
 H3 hcross(H3 x, H3 y) { return H3{x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y}; }
@@ -422,6 +550,26 @@ H3 hnormalize(H3 a) {
     float d = a.x * a.x + a.y * a.y + a.z * a.z;
     float s = 1.0f / std::sqrt(d);
     return H3{a.x * s, a.y * s, a.z * s};
+}
+
+// the camera constants of spec S2 (KParams: basis, pixel lengths, frame size), derived once on the host
+void camera_params(const PtCamera &cam, KParams &k) {
+    const int Wd = cam.resolution[0], H = cam.resolution[1];
+    const H3 view{cam.view.x, cam.view.y, cam.view.z}, up{cam.up.x, cam.up.y, cam.up.z};
+    const H3 right = hnormalize(hcross(view, up));
+    k.view[0] = view.x; k.view[1] = view.y; k.view[2] = view.z;
+    k.up[0] = up.x; k.up[1] = up.y; k.up[2] = up.z;
+    k.right[0] = right.x; k.right[1] = right.y; k.right[2] = right.z;
+    k.pos[0] = cam.position.x; k.pos[1] = cam.position.y; k.pos[2] = cam.position.z;
+    const float kPI = 3.1415926535897932384626422832795028841971f;   // src/utilities.h:12
+    const float ys = std::tan(cam.fov[1] * (kPI / 180));             // src/scene.cpp:133 convention
+    const float xs = (ys * Wd) / H;
+    k.pixLenX = (2.0f * xs) / (float)Wd;
+    k.pixLenY = (2.0f * ys) / (float)H;
+    k.halfW = (float)Wd * 0.5f;
+    k.halfH = (float)H * 0.5f;
+    k.W = Wd; k.H = H;
+    k.shardRank = 0; k.shardCount = 1;
 }
 
 int resolve_events(std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, double &ms, long long &n) {
@@ -475,6 +623,7 @@ int launch_bounce(Slot &sl, int iter, int batch, int depth, bool lastBounce, flo
     ba.rowOff = S.dRowOff; ba.rowIdx = S.dRowIdx;
     ba.walls = S.dwalls;
     ba.meshNodes = S.dMeshNodes; ba.meshTris = S.dMeshTris;
+    ba.hostFault = S.hostFaultDev;
     void *kargs[] = {&ba};
     const bool first = depth == 1;
     HIPCHECK(hipLaunchKernel(bounce_kernel(first, first && S.dof), dim3(first ? S.gridFirst : S.grid), dim3(kBlock), kargs, S.ldsBytes, sl.stream));
@@ -496,12 +645,21 @@ struct ScanWs {
     uint32_t *partial = nullptr;     // [kScanChunksMax + 1]
 };
 std::map<hipStream_t, ScanWs> g_scan;
+std::mutex g_scanMutex;              // the scan library may be called from several host threads (one stream each)
 
 int scan_ws(hipStream_t st, ScanWs **out) {
-    ScanWs &W = g_scan[st];
+    std::lock_guard<std::mutex> lock(g_scanMutex);
+    ScanWs &W = g_scan[st];          // (std::map: the reference stays valid while other streams are added)
     if (!W.partial) HIPCHECK(hipMalloc(&W.partial, (size_t)(kScanChunksMax + 1) * sizeof(uint32_t)));
     *out = &W;
     return PT_OK;
+}
+// releases every stream's workspace (pt_free, process exit); the caller has made sure that no scan is in flight
+void scan_release() {
+    std::lock_guard<std::mutex> lock(g_scanMutex);
+    for (auto &kv : g_scan)
+        if (kv.second.partial) (void)hipFree(kv.second.partial);
+    g_scan.clear();
 }
 // the array as chunks of whole tiles: at most kScanChunksMax of them
 void scan_chunks(long long n, long long *tilesPerChunk, int *chunks) {
@@ -526,6 +684,18 @@ int check_device_fault() {
         HIPCHECK(hipMemcpy(&err, &S.slot[i].ctrl->error, sizeof err, hipMemcpyDeviceToHost));
         if (err) return fail(PT_ERR_DEVICE, "device fault 0x%x:%s%s (results of this render are void; re-init)", err,
                              (err & kFaultPoolExhausted) ? " path pool exhausted" : "", (err & kFaultReserveTimeout) ? " chunk reservation timed out" : "");
+    }
+    return PT_OK;
+}
+
+// pt_readback / pt_readback_rgba8 have just synchronised the caller's stream: every launch whose radiance the image holds has
+// finished, and a fault any of them raised is in the host-visible copy of the fault word -- no device-to-host copy on the
+// good path.  A faulted render is then reported like pt_sync does (the image has been copied all the same; it is void).
+int readback_fault() {
+    if (S.hostFault && *(volatile uint32_t *)S.hostFault != 0u) {
+        int rc = check_device_fault();
+        if (rc) return rc;
+        return fail(PT_ERR_DEVICE, "device fault (results of this render are void; re-init)");
     }
     return PT_OK;
 }
@@ -606,6 +776,20 @@ int discard_ahead() {
     return PT_OK;
 }
 
+// Process exit with work in flight (an exception in the host between pt_iterate and pt_free, an interpreter that is torn down
+// with a live renderer): the streams are drained and everything is released BEFORE the HIP runtime's own exit handlers run --
+// this handler is registered after the library's first HIP call, and exit handlers run in reverse order of registration --
+// so that no launch of this process is still executing when its queues, its code object and its memory go away.
+extern "C" void pt_free(void);
+void exit_handler() { pt_free(); }
+void register_exit_handler() {
+    static bool done = false;
+    if (!done) {
+        done = true;
+        atexit(exit_handler);
+    }
+}
+
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
@@ -619,16 +803,23 @@ struct DevBuf {
 }  // namespace
 
 // =====================================================================================================
-// C ABI
+// C ABI (the library is built with -fvisibility=hidden: these entry points are all it exports)
 // =====================================================================================================
+#pragma GCC visibility push(default)
 extern "C" {
 
 const char *pt_last_error(void) { return g_err.c_str(); }
 int pt_device_count(void) { return count_devices(); }
 
 void pt_free(void) {
+    // the scan library's per-stream workspaces (allocated on first use, with or without a renderer)
+    if (!g_scan.empty()) {
+        (void)hipDeviceSynchronize();
+        scan_release();
+    }
     // pathtraceFree before the first Init (src/main.cpp:91-94) must be a no-op
-    if (!S.init && !S.image && !S.dgeoms && S.nslots == 0) return;
+    if (!S.init && !S.image && !S.dgeoms && S.nslots == 0 && !S.hostFault) return;
+    if (S.device >= 0 && S.nslots > 0) (void)hipSetDevice(S.device);     // (a host that switched devices in between)
     for (int i = 0; i < kMaxSlots; ++i)
         if (S.slot[i].stream) (void)hipStreamSynchronize(S.slot[i].stream);
     (void)hipStreamSynchronize(S.stream);
@@ -653,6 +844,7 @@ void pt_free(void) {
         if (sl.stream) (void)hipStreamDestroy(sl.stream);
     }
     if (S.pinnedHost) (void)hipHostUnregister(S.pinnedHost);
+    if (S.hostFault) (void)hipHostFree(S.hostFault);
     if (S.ownImage && S.image) (void)hipFree(S.image);
     if (S.dgeoms) (void)hipFree(S.dgeoms);
     if (S.dmats) (void)hipFree(S.dmats);
@@ -705,6 +897,7 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
         if (m.geom < 0 || m.geom >= ngeoms || geoms[m.geom].type != PT_MESH)
             return fail(PT_ERR_INVALID, "pt_init: triangles registered for geom %d, which is not a mesh of this scene (pt_set_meshes)", m.geom);
     if (count_devices() < 1) return fail(PT_ERR_NO_GPU, "pt_init: no HIP device (this library has no CPU fallback)");
+    register_exit_handler();
     pt_free();
 
     PtOptions o;
@@ -721,6 +914,10 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     S.flags = o.flags;
     S.cam = *cam;
 
+    HIPCHECK(hipHostMalloc((void **)&S.hostFault, sizeof(uint32_t), hipHostMallocMapped));
+    *S.hostFault = 0u;
+    HIPCHECK(hipHostGetDevicePointer((void **)&S.hostFaultDev, S.hostFault, 0));
+
     const int Wd = cam->resolution[0], H = cam->resolution[1];
     S.P = Wd * H;
     const int rows = H > o.shard_rank ? (H - o.shard_rank + o.shard_count - 1) / o.shard_count : 0;
@@ -728,20 +925,8 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
 
     KParams &k = S.prm;
     memset(&k, 0, sizeof k);
-    const H3 view{cam->view.x, cam->view.y, cam->view.z}, up{cam->up.x, cam->up.y, cam->up.z};
-    const H3 right = hnormalize(hcross(view, up));
-    k.view[0] = view.x; k.view[1] = view.y; k.view[2] = view.z;
-    k.up[0] = up.x; k.up[1] = up.y; k.up[2] = up.z;
-    k.right[0] = right.x; k.right[1] = right.y; k.right[2] = right.z;
-    k.pos[0] = cam->position.x; k.pos[1] = cam->position.y; k.pos[2] = cam->position.z;
-    const float kPI = 3.1415926535897932384626422832795028841971f;   // src/utilities.h:12
-    const float ys = std::tan(cam->fov[1] * (kPI / 180));            // src/scene.cpp:133 convention
-    const float xs = (ys * Wd) / H;
-    k.pixLenX = (2.0f * xs) / (float)Wd;
-    k.pixLenY = (2.0f * ys) / (float)H;
-    k.halfW = (float)Wd * 0.5f;
-    k.halfH = (float)H * 0.5f;
-    k.W = Wd; k.H = H;
+    camera_params(*cam, k);
+    const H3 view{cam->view.x, cam->view.y, cam->view.z};
     k.shardRank = o.shard_rank; k.shardCount = o.shard_count;
     k.nLocal = S.nLocal;
     magic_divisor((uint32_t)Wd, k.magicW, k.shiftW);
@@ -821,6 +1006,17 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     // Iterations are independent (RNG keyed on pixel/iteration/depth), so up to `nslots` of them are in flight
     // on their own streams; the small late-bounce launches of one overlap the big early launches of the next.
     S.nslots = o.pipeline_depth > 0 ? o.pipeline_depth : 3;
+    {   // the memory budget BEFORE the first large allocation: a batch that does not fit fails here, with nothing to undo
+        const size_t cpx = k.contribLocal ? (size_t)(S.nLocal > 0 ? S.nLocal : 1) : (size_t)S.P;
+        const size_t perSlot = 2 * (cap * kNumArrays * sizeof(float) + (size_t)kSeg * S.poolChunks * sizeof(unsigned long long)) + sizeof(Ctrl) +
+                               (size_t)S.maxBatch * cpx * 3 * sizeof(float) + (size_t)((S.maxBatch + 31) / 32) * cpx * sizeof(uint32_t);
+        const size_t need = perSlot * (size_t)S.nslots;
+        size_t freeB = 0, totalB = 0;
+        HIPCHECK(hipMemGetInfo(&freeB, &totalB));
+        if (need > freeB)
+            return fail(PT_ERR_HIP, "pt_init: %.2f GB of path pools and radiance buffers (max_batch %d x pipeline_depth %d) exceed the %.2f GB of free "
+                        "device memory: lower max_batch or pipeline_depth", need / 1e9, S.maxBatch, S.nslots, freeB / 1e9);
+    }
     for (int i = 0; i < S.nslots; ++i) {
         Slot &sl = S.slot[i];
         HIPCHECK(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
@@ -844,16 +1040,16 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
 
     std::vector<GeomDev> hg(ngeoms ? ngeoms : 1);
     std::vector<MaterialDev> hm(nmats ? nmats : 1);
-    k.sceneRect[0] = k.sceneRect[1] = 0x7fffffff;   // empty union: a scene without primitives is never entered
-    k.sceneRect[2] = k.sceneRect[3] = -1;
     // triangle meshes: one node / triangle array for the scene, a hierarchy per mesh (pt_mesh.h)
     std::vector<ptd::MeshNode> meshNodes;
     std::vector<ptd::MeshTri> meshTris;
     const bool flatMeshes = getenv("PT_AMD_MESH_FLAT") && atoi(getenv("PT_AMD_MESH_FLAT"));   // tests only: no hierarchy
-    std::vector<std::vector<std::pair<double, double>>> hulls(ngeoms ? ngeoms : 1);   // projected corners per primitive (camera-ray culling)
+    std::vector<std::array<float, 6>> meshBox(ngeoms ? ngeoms : 1);
+    std::vector<const float *> boxes(ngeoms ? ngeoms : 1, nullptr);
     for (int i = 0; i < ngeoms; ++i) {
-        float box[6];
+        float *box = meshBox[i].data();
         const bool isMesh = geoms[i].type == PT_MESH;
+        if (isMesh) boxes[i] = box;
         uint32_t root = ptd::kMeshEnd, stride = 0;
         if (isMesh) {
             const ptm::HostMesh *hm_ = mesh_of(i);
@@ -868,17 +1064,12 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
             if (k.nCubes >= 32767) return fail(PT_ERR_INVALID, "pt_init: more than 32767 cubes");
             hg[i].frameSlot = (short)k.nCubes++;
         }
-        project_geom(geoms[i], k, hg[i].rect, isMesh ? box : nullptr, &hulls[i]);
-        if (S.dof) {        // rays start anywhere on the lens: the pinhole projection bounds nothing
-            hg[i].rect[0] = hg[i].rect[1] = 0;
-            hg[i].rect[2] = Wd - 1;
-            hg[i].rect[3] = H - 1;
-        }
-        k.sceneRect[0] = std::min(k.sceneRect[0], hg[i].rect[0]);
-        k.sceneRect[1] = std::min(k.sceneRect[1], hg[i].rect[1]);
-        k.sceneRect[2] = std::max(k.sceneRect[2], hg[i].rect[2]);
-        k.sceneRect[3] = std::max(k.sceneRect[3], hg[i].rect[3]);
     }
+    // camera rays: pixel rectangles, their union and the per-row lists (thin lens: none -- rays start anywhere on the lens)
+    CameraCull cc;
+    const bool cullOff = S.dof || (getenv("PT_AMD_NO_CAMERA_CULL") && atoi(getenv("PT_AMD_NO_CAMERA_CULL")));   // (the variable: tests only)
+    build_camera_cull(geoms, ngeoms, k, cullOff, boxes, hg, cc);
+    for (int a = 0; a < 4; ++a) k.sceneRect[a] = cc.sceneRect[a];
     for (int i = 0; i < nmats; ++i) pack_material(mats[i], hm[i]);
     // Small primitives the queue is binned by (k_bounce): the spheres when there are at most kBinMax of them, then the
     // cubes whose bounding ball is small against the scene's (<= 0.3 of its radius), smallest first.  A choice that only
@@ -998,33 +1189,12 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
             }
         }
         k.classOff[kCls] = (int)idx.size();
-        // camera rays: per image row, the primitives whose pixel rectangle (project_geom) covers it, each with the pixels of
-        // that row inside the convex hull of its projected corners (hull_row_span; the rectangle's columns when there is no
-        // hull): entries {primitive, x0 | x1 << 16}, file order
-        if (!S.dof && (long long)H * ngeoms < (1ll << 26) && Wd <= 32768) {
-            std::vector<int> off(H + 1), ridx;
-            for (int y = 0; y < H; ++y) {
-                off[y] = (int)(ridx.size() / 2);
-                for (int i = 0; i < ngeoms; ++i) {
-                    if (!(y >= hg[i].rect[1] && y <= hg[i].rect[3] && hg[i].rect[0] <= hg[i].rect[2])) continue;
-                    int x0 = hg[i].rect[0], x1 = hg[i].rect[2];
-                    if (!hulls[i].empty()) {
-                        double xmin, xmax;
-                        if (!hull_row_span(hulls[i], y, xmin, xmax)) continue;
-                        x0 = std::max(x0, (int)std::max(std::floor(xmin) - 2.0, -1.0e9));
-                        x1 = std::min(x1, (int)std::min(std::ceil(xmax) + 2.0, 1.0e9));
-                        if (x0 > x1) continue;
-                    }
-                    ridx.push_back(i);
-                    ridx.push_back(x0 | (x1 << 16));
-                }
-            }
-            off[H] = (int)(ridx.size() / 2);
-            if (ridx.empty()) { ridx.push_back(0); ridx.push_back(0); }
-            HIPCHECK(hipMalloc(&S.dRowOff, off.size() * sizeof(int)));
-            HIPCHECK(hipMemcpy(S.dRowOff, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice));
-            HIPCHECK(hipMalloc(&S.dRowIdx, ridx.size() * sizeof(int)));
-            HIPCHECK(hipMemcpy(S.dRowIdx, ridx.data(), ridx.size() * sizeof(int), hipMemcpyHostToDevice));
+        // camera rays: the per-row primitive lists (build_camera_cull)
+        if (!cc.rowOff.empty()) {
+            HIPCHECK(hipMalloc(&S.dRowOff, cc.rowOff.size() * sizeof(int)));
+            HIPCHECK(hipMemcpy(S.dRowOff, cc.rowOff.data(), cc.rowOff.size() * sizeof(int), hipMemcpyHostToDevice));
+            HIPCHECK(hipMalloc(&S.dRowIdx, cc.rowIdx.size() * sizeof(int)));
+            HIPCHECK(hipMemcpy(S.dRowIdx, cc.rowIdx.data(), cc.rowIdx.size() * sizeof(int), hipMemcpyHostToDevice));
         }
         if (idx.empty()) idx.push_back(0);
         HIPCHECK(hipMalloc(&S.dClassIdx, idx.size() * sizeof(int)));
@@ -1160,14 +1330,14 @@ int pt_readback(float *rgb_sum_host) {
         for (int lr = 0; lr * S.prm.W < S.nLocal; ++lr)
             memcpy(rgb_sum_host + (size_t)(lr * S.prm.shardCount + S.prm.shardRank) * rowFloats, rows.data() + lr * rowFloats,
                    rowFloats * sizeof(float));
-        return PT_OK;
+        return readback_fault();
     }
     // a plain copy: at PCIe rate into a buffer the caller has page-locked with pt_pin_host, through the runtime's
     // pageable staging path otherwise.  The library never registers memory it does not own on its own initiative.
     const size_t bytes = (size_t)S.P * 3 * sizeof(float);
     HIPCHECK(hipMemcpyAsync(rgb_sum_host, S.image, bytes, hipMemcpyDeviceToHost, S.stream));
     HIPCHECK(hipStreamSynchronize(S.stream));
-    return PT_OK;
+    return readback_fault();
 }
 
 int pt_pin_host(void *host, size_t bytes) {
@@ -1194,16 +1364,6 @@ int pt_unpin_host(void) {
     return PT_OK;
 }
 
-int pt_test_force_fault(int which) {
-    if (count_devices() < 1) return fail(PT_ERR_NO_GPU, "no HIP device");
-    if (which != 0 && which != 2) return fail(PT_ERR_INVALID, "pt_test_force_fault: which must be 0 (clear) or 2 (the renderer's fault word)");
-    if (!S.init) return fail(PT_ERR_NOT_INIT, "pt_test_force_fault before pt_init");
-    HIPCHECK(hipDeviceSynchronize());
-    const uint32_t word = which == 2 ? 1u : 0u;
-    for (int i = 0; i < (which == 2 ? 1 : S.nslots); ++i) HIPCHECK(hipMemcpy(&S.slot[i].ctrl->error, &word, sizeof word, hipMemcpyHostToDevice));
-    return PT_OK;
-}
-
 int pt_readback_rgba8(int iter, uint8_t *rgba_host) {
     if (!S.init) return fail(PT_ERR_NOT_INIT, "pt_readback_rgba8 before pt_init");
     if (!rgba_host || iter < 1) return fail(PT_ERR_INVALID, "pt_readback_rgba8: bad argument");
@@ -1215,7 +1375,7 @@ int pt_readback_rgba8(int iter, uint8_t *rgba_host) {
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipMemcpyAsync(rgba_host, tmp.p, (size_t)S.P * 4, hipMemcpyDeviceToHost, S.stream));
     HIPCHECK(hipStreamSynchronize(S.stream));
-    return PT_OK;
+    return readback_fault();
 }
 
 int pt_counters(PtCounters *out) {
@@ -1367,6 +1527,7 @@ int pt_scan_exclusive_i32(const int32_t *in_dev, int32_t *out_dev, int64_t n, vo
     if (count_devices() < 1) return fail(PT_ERR_NO_GPU, "no HIP device");
     if (n > (1ll << 42)) return fail(PT_ERR_INVALID, "pt_scan_exclusive_i32: n too large");
     hipStream_t st = (hipStream_t)stream;
+    register_exit_handler();
     ScanWs *wp = nullptr;
     int rc = scan_ws(st, &wp);
     if (rc) return rc;
@@ -1389,6 +1550,7 @@ int pt_compact_nonzero_i32(const int32_t *in_dev, int32_t *out_dev, int64_t n, i
         HIPCHECK(hipMemsetAsync(count_dev, 0, sizeof(int64_t), st));
         return PT_OK;
     }
+    register_exit_handler();
     ScanWs *wp = nullptr;
     int rc = scan_ws(st, &wp);
     if (rc) return rc;
@@ -1402,7 +1564,19 @@ int pt_compact_nonzero_i32(const int32_t *in_dev, int32_t *out_dev, int64_t n, i
     return PT_OK;
 }
 
+#ifdef PT_TEST_API
 // ---- primitive tests over host arrays ------------------------------------------------------------------
+int pt_test_force_fault(int which) {
+    if (count_devices() < 1) return fail(PT_ERR_NO_GPU, "no HIP device");
+    if (which != 0 && which != 2) return fail(PT_ERR_INVALID, "pt_test_force_fault: which must be 0 (clear) or 2 (the renderer's fault word)");
+    if (!S.init) return fail(PT_ERR_NOT_INIT, "pt_test_force_fault before pt_init");
+    HIPCHECK(hipDeviceSynchronize());
+    const uint32_t word = which == 2 ? 1u : 0u;
+    for (int i = 0; i < (which == 2 ? 1 : S.nslots); ++i) HIPCHECK(hipMemcpy(&S.slot[i].ctrl->error, &word, sizeof word, hipMemcpyHostToDevice));
+    if (S.hostFault) *S.hostFault = word;
+    return PT_OK;
+}
+
 #define NEED_GPU() do { if (count_devices() < 1) return fail(PT_ERR_NO_GPU, "no HIP device"); } while (0)
 #define UP(buf, host, count) do { int rc_ = buf.alloc(count); if (rc_) return rc_; \
     HIPCHECK(hipMemcpy(buf.p, host, (size_t)(count) * sizeof(*buf.p), hipMemcpyHostToDevice)); } while (0)
@@ -1620,6 +1794,75 @@ int pt_test_wall_box_sweep(const PtGeom *geoms, int ngeoms, uint64_t seed, int64
     return PT_OK;
 }
 
+// host only: no GPU is touched
+int pt_test_camera_cull_tables(const PtCamera *cam, const PtGeom *geoms, int ngeoms, int32_t *rects4, int32_t *scene_rect4, int32_t *spans2) {
+    if (!cam || !geoms || ngeoms < 1 || !rects4 || !scene_rect4 || !spans2) return fail(PT_ERR_INVALID, "pt_test_camera_cull_tables: bad argument");
+    if (cam->resolution[0] < 1 || cam->resolution[1] < 1) return fail(PT_ERR_INVALID, "pt_test_camera_cull_tables: bad resolution");
+    KParams k;
+    memset(&k, 0, sizeof k);
+    camera_params(*cam, k);
+    k.ngeoms = ngeoms;
+    std::vector<GeomDev> hg(ngeoms);
+    for (int i = 0; i < ngeoms; ++i) pack_geom(geoms[i], hg[i], k.pos);
+    CameraCull cc;
+    build_camera_cull(geoms, ngeoms, k, false, std::vector<const float *>(ngeoms, nullptr), hg, cc);
+    for (int i = 0; i < ngeoms; ++i)
+        for (int a = 0; a < 4; ++a) rects4[4 * i + a] = hg[i].rect[a];
+    for (int a = 0; a < 4; ++a) scene_rect4[a] = cc.sceneRect[a];
+    for (int y = 0; y < k.H; ++y)
+        for (int i = 0; i < ngeoms; ++i) {
+            int x0 = 1, x1 = 0;                                // (empty: the row's list does not hold the primitive)
+            if (cc.rowOff.empty()) { x0 = hg[i].rect[0]; x1 = hg[i].rect[2]; }
+            else
+                for (int e = cc.rowOff[y]; e < cc.rowOff[y + 1]; ++e)
+                    if (cc.rowIdx[2 * e] == i) { x0 = cc.rowIdx[2 * e + 1] & 0xffff; x1 = cc.rowIdx[2 * e + 1] >> 16; }
+            spans2[2 * ((size_t)y * ngeoms + i)] = x0;
+            spans2[2 * ((size_t)y * ngeoms + i) + 1] = x1;
+        }
+    return PT_OK;
+}
+
+int pt_test_camera_cull_sweep(const PtCamera *cam, const PtGeom *geoms, int ngeoms, int samples, uint64_t *hits, uint64_t *culled,
+                              uint64_t *violations) {
+    NEED_GPU();
+    if (!cam || !geoms || ngeoms < 1 || samples < 1 || !hits || !culled || !violations) return fail(PT_ERR_INVALID, "pt_test_camera_cull_sweep: bad argument");
+    if (cam->resolution[0] < 1 || cam->resolution[1] < 1 || (long long)cam->resolution[0] * cam->resolution[1] > (1ll << 26))
+        return fail(PT_ERR_INVALID, "pt_test_camera_cull_sweep: bad resolution");
+    for (int i = 0; i < ngeoms; ++i)
+        if (geoms[i].type != PT_SPHERE && geoms[i].type != PT_CUBE) return fail(PT_ERR_INVALID, "pt_test_camera_cull_sweep: spheres and cubes only");
+    // exactly what pt_init derives: camera constants, packed primitives (object-space eye), rectangles, union, row lists
+    KParams k;
+    memset(&k, 0, sizeof k);
+    camera_params(*cam, k);
+    k.ngeoms = ngeoms;
+    magic_divisor((uint32_t)k.W, k.magicW, k.shiftW);
+    std::vector<GeomDev> hg(ngeoms);
+    for (int i = 0; i < ngeoms; ++i) pack_geom(geoms[i], hg[i], k.pos);
+    CameraCull cc;
+    build_camera_cull(geoms, ngeoms, k, false, std::vector<const float *>(ngeoms, nullptr), hg, cc);
+    for (int a = 0; a < 4; ++a) k.sceneRect[a] = cc.sceneRect[a];
+    DevBuf<GeomDev> dg;
+    DevBuf<int> doff, didx;
+    DevBuf<unsigned long long> cnt;
+    UP(dg, hg.data(), ngeoms);
+    if (!cc.rowOff.empty()) {
+        UP(doff, cc.rowOff.data(), cc.rowOff.size());
+        UP(didx, cc.rowIdx.data(), cc.rowIdx.size());
+    }
+    int rc = cnt.alloc(3);
+    if (rc) return rc;
+    HIPCHECK(hipMemset(cnt.p, 0, 24));
+    const int npix = k.W * k.H;
+    hipLaunchKernelGGL(k_sweep_camera_cull, GRID(npix), k, dg.p, doff.p, didx.p, samples, cnt.p, cnt.p + 1, cnt.p + 2);
+    HIPCHECK(hipDeviceSynchronize());
+    unsigned long long h[3] = {0, 0, 0};
+    HIPCHECK(hipMemcpy(h, cnt.p, 24, hipMemcpyDeviceToHost));
+    *hits = h[0];
+    *culled = h[1];
+    *violations = h[2];
+    return PT_OK;
+}
+
 int pt_test_slab_quotients(const float *o, const float *d, int n, float *t1, float *t2, float *ref1, float *ref2) {
     NEED_GPU();
     if (n <= 0) return PT_OK;
@@ -1754,4 +1997,7 @@ int pt_test_reflect_refract(const float *I3, const float *N3, const float *eta, 
     return PT_OK;
 }
 
+#endif  // PT_TEST_API
+
 }  // extern "C"
+#pragma GCC visibility pop

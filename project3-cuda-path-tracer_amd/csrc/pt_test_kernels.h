@@ -177,6 +177,42 @@ __global__ void k_sweep_wall_box(const GeomDev *geoms, const WallBox *walls, con
     if (nv) atomicAdd(violations, (unsigned long long)nv);
 }
 
+// Soundness sweep of the camera-ray culling (GeomDev::rect, KParams::sceneRect, the per-row lists with their hull spans): every
+// pixel of the frame sends `samples` camera rays (the render kernel's own cameraRayAt: iterations 1 .. samples of the pixel's
+// depth-0 stream) through the FULL test of EVERY primitive, exactly the instantiations the camera-ray bounce runs.  A hit from a
+// pixel the culling would have skipped -- outside the scene rectangle, outside the primitive's rectangle, or outside its span in
+// the row's list -- is a VIOLATION (must be 0); `culled` counts the (ray, primitive) pairs the culling skips, `hits` the hits.
+__global__ void k_sweep_camera_cull(KParams prm, const GeomDev *geoms, const int *rowOff, const int *rowIdx, int samples,
+                                    unsigned long long *hits, unsigned long long *culled, unsigned long long *violations) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= prm.W * prm.H) return;
+    const int y = j / prm.W, x = j - y * prm.W;
+    const bool inScene = x >= prm.sceneRect[0] && x <= prm.sceneRect[2] && y >= prm.sceneRect[1] && y <= prm.sceneRect[3];
+    unsigned int nh = 0, nc = 0, nv = 0;
+    for (int g = 0; g < prm.ngeoms; ++g) {
+        const GeomDev &G = geoms[g];
+        bool reach = inScene && x >= G.rect[0] && x <= G.rect[2] && y >= G.rect[1] && y <= G.rect[3];
+        if (reach && rowOff) {            // ... and listed for this row with a span that holds the pixel
+            bool listed = false;
+            for (int e = rowOff[y]; e < rowOff[y + 1]; ++e)
+                if (rowIdx[2 * e] == g) listed = x >= (rowIdx[2 * e + 1] & 0xffff) && x <= (rowIdx[2 * e + 1] >> 16);
+            reach = listed;
+        }
+        for (int sI = 1; sI <= samples; ++sI) {
+            F3 org, dir, P, N;
+            bool o;
+            cameraRayAt(prm, iterationHash(sI, 0), j, x, y, org, dir);
+            const float t = (G.flags & 1) ? boxIntersectionTest<true, true>(G, org, dir, P, N, o) : sphereIntersectionTest<true>(G, org, dir, P, N, o);
+            nh += t > 0.0f ? 1u : 0u;
+            nc += reach ? 0u : 1u;
+            nv += (!reach && t > 0.0f) ? 1u : 0u;
+        }
+    }
+    if (nh) atomicAdd(hits, (unsigned long long)nh);
+    if (nc) atomicAdd(culled, (unsigned long long)nc);
+    if (nv) atomicAdd(violations, (unsigned long long)nv);
+}
+
 // slabQuotients vs the compiler's correctly rounded division; counts mismatching lanes
 __global__ void k_test_slab_quotients(const float *o, const float *d, int n, float *t1, float *t2, float *r1, float *r2) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;

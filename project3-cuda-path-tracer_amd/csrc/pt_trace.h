@@ -137,8 +137,13 @@ __device__ __forceinline__ void stSlot(float *arr, uint32_t byteOff, float v) {
 // The loop is WAVE-UNIFORM with one poll per lane and trip: a lane never spins inside a trip, whatever the compiler
 // makes of the branches.
 // The run occupies  [base0, base0 + split)  and  [base1, base1 + total - split).
+// `hostFault`: the fault word's copy in page-locked host memory (State::hostFault), or nullptr.
+__device__ __forceinline__ void raiseFault(uint32_t *fault, uint32_t *hostFault, uint32_t bit) {
+    atomicOr(fault, bit);
+    if (hostFault) __hip_atomic_store(hostFault, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (any non-zero value: the host then reads `fault`)
+}
 __device__ __forceinline__ void reserveRun(uint32_t *pos, uint32_t *bump, unsigned long long *segList, uint32_t oseg,
-                                           uint32_t poolChunks, uint32_t shift, uint32_t gen, uint32_t total, uint32_t *fault,
+                                           uint32_t poolChunks, uint32_t shift, uint32_t gen, uint32_t total, uint32_t *fault, uint32_t *hostFault,
                                            uint32_t &cacheK, uint32_t &cacheC, uint32_t &base0, uint32_t &split, uint32_t &base1) {
     base0 = base1 = 0u;
     split = total;
@@ -151,7 +156,7 @@ __device__ __forceinline__ void reserveRun(uint32_t *pos, uint32_t *bump, unsign
         const uint32_t kNew = k1 + 1u;
         uint32_t x = (uint32_t)kSeg + 1u + atomicAdd(bump, 1u);
         if (x >= poolChunks) {
-            atomicOr(fault, kFaultPoolExhausted);
+            raiseFault(fault, hostFault, kFaultPoolExhausted);
             x = 0u;
         }
         if (kNew < poolChunks)
@@ -172,7 +177,7 @@ __device__ __forceinline__ void reserveRun(uint32_t *pos, uint32_t *bump, unsign
             if ((uint32_t)(e >> 32) == gen) { c1 = (uint32_t)e; need1 = false; }
         }
         if (polls > kReservePollLimit && (need0 || need1)) {
-            atomicOr(fault, kFaultReserveTimeout);
+            raiseFault(fault, hostFault, kFaultReserveTimeout);
             if (need0) c0 = 0u;
             if (need1) c1 = 0u;
             need0 = need1 = false;
@@ -332,6 +337,7 @@ struct BounceArgs {
     const int *rowOff;                  // camera rays (a tile is 256 pixels of one row): the primitives that can be reached from image row y are the entries
     const int *rowIdx;                  //   rowOff[y] .. rowOff[y + 1] of rowIdx, file order: pairs {primitive, x0 | x1 << 16} = the row's pixels
                                         //   inside the hull of the primitive's projected corners (pt_init); rowOff == nullptr: every primitive
+    uint32_t *hostFault;                // the sticky fault word's copy in page-locked host memory (raiseFault), or nullptr
 };
 typedef const PT_CAS BounceArgs *ArgsPtr;
 typedef const PT_CAS GeomDev *GeomPtr;
@@ -489,7 +495,13 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
     uint32_t wvSel = 0;                     // which half of s_wave the current tile counts in (0 or kWaves * kCls)
     uint32_t nEarly = 0;                    // survivors that certainly miss everything: ended at the scatter
     uint32_t sgIn = 0;                      // input segment of the tile being set up (tiles are visited in increasing order)
-    uint32_t firstK = 0;                    // FIRST: how many tiles this workgroup has processed
+    // FIRST: the k-th tile of a workgroup is rotated k column bands to the right inside its row (see below).  The grid is a multiple
+    // of the tiles per row (pt_init), so every tile of a workgroup has the same band c0 = blockIdx % tilesPerRow: ONE division, here.
+    uint32_t rot0 = 0, rot = 0;             // c0, and (c0 + k) % tilesPerRow of the tile about to be processed
+    if (FIRST) {
+        const uint32_t tpr = (uint32_t)launder(kargs)->prm.tilesPerRow;
+        if (tpr > 1) rot0 = rot = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x % tpr));
+    }
 
     // ---- later bounces: a tile's paths are requested ONE TILE AHEAD.  A workgroup's tiles form a chain of dependent
     // latencies -- load 44 B per path, trace, reserve the output runs (an atomic round trip between two barriers), store --
@@ -558,6 +570,10 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
         // that live, spilled, across the whole tile
         uint32_t tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
+        // the tile index is wave-uniform; said so explicitly, everything derived from it -- the tile's iteration, row and first
+        // column, the scene-rectangle test, the row's primitive list -- stays in scalar registers and on the scalar unit (left to
+        // itself the compiler carried T in a VGPR and expanded the divisions below into ~60 vector instructions per tile)
+        T = (uint32_t)__builtin_amdgcn_readfirstlane((int)T);
         probe(14);                                              // (a tile starts)
         uint32_t Tnext = T + gridDim.x;     // FIRST: simply the next one
         bool valid;
@@ -575,9 +591,8 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
             uint32_t pixTile = T;
             const uint32_t tilesPerRow = (uint32_t)prm.tilesPerRow;
             if (tilesPerRow > 1) {
-                const uint32_t c = T % tilesPerRow;
-                pixTile = T - c + (c + firstK) % tilesPerRow;
-                ++firstK;
+                pixTile = T - rot0 + rot;                       // (T % tilesPerRow == rot0 for every tile of this workgroup)
+                rot = rot + 1u == tilesPerRow ? 0u : rot + 1u;
             }
             // the tile's (wave-uniform) position: iteration of the batch, row of the shard, first column -- no per-lane divisions
             const uint32_t idx0 = pixTile * kBlock;
@@ -592,7 +607,9 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
             valid = px < prm.W;                                 // (lanes in the padding hold no pixel)
             // When the tile lies outside the scene rectangle altogether, all its camera rays are misses -- tally them and take
             // the next tile (no rays, no compaction, no barrier; the test is the same for the four waves of the workgroup).
-            if (y0 < prm.sceneRect[1] || y0 > prm.sceneRect[3] || x0 + (kBlock - 1) < prm.sceneRect[0] || x0 > prm.sceneRect[2]) {
+            // (the four bounds loaded together and compared without short-circuit: one scalar load, no chain of dependent ones)
+            const int sr0 = prm.sceneRect[0], sr1 = prm.sceneRect[1], sr2 = prm.sceneRect[2], sr3 = prm.sceneRect[3];
+            if ((y0 < sr1) | (y0 > sr3) | (x0 + (kBlock - 1) < sr0) | (x0 > sr2)) {
                 nMiss += valid ? 1u : 0u;
                 T = Tnext;
                 continue;
@@ -1053,7 +1070,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
                 const uint32_t oseg = tid * kSub + (blockIdx.x % kSub);
                 uint32_t r0, sp, r1;
                 reserveRun(&ctrl->pos[parity][dnext][oseg][0], &ctrl->bump[parity][dnext][0], A->out.list + (size_t)oseg * poolChunks, oseg,
-                           poolChunks, (uint32_t)A->prm.chunkShift, A->genOut, total, &ctrl->error, s_base[3 * kCls + tid],
+                           poolChunks, (uint32_t)A->prm.chunkShift, A->genOut, total, &ctrl->error, A->hostFault, s_base[3 * kCls + tid],
                            s_base[4 * kCls + tid], r0, sp, r1);
                 s_base[tid] = r0;
                 s_base[kCls + tid] = sp;

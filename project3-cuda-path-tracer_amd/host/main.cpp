@@ -17,6 +17,7 @@
 #include <cstring>
 #include <ctime>
 #include <sstream>
+#include <stdexcept>
 
 #include "image.h"
 #include "pathtrace.h"
@@ -120,7 +121,12 @@ int main(int argc, char **argv) {
         printf("Usage: %s SCENEFILE.txt [--res W H] [--iterations N] [--depth D] [--out BASENAME] [--hdr] [--batch B] [--lens R F] [--direct]\n", argv[0]);
         return 1;
     }
-    scene = new Scene(argv[1], true);
+    try {
+        scene = new Scene(argv[1], true);
+    } catch (const std::exception &e) {          // unreadable scene file, or a mesh object whose OBJ cannot be read
+        fprintf(stderr, "%s\n", e.what());
+        return 1;
+    }
     renderState = &scene->state;
     for (int i = 2; i < argc; ++i) {
         if (!strcmp(argv[i], "--res") && i + 2 < argc) { scene->setResolution(atoi(argv[i + 1]), atoi(argv[i + 2])); i += 2; }

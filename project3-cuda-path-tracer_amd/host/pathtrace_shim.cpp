@@ -37,10 +37,15 @@ void pathtraceInit(Scene *scene) {
     if (const char *e = getenv("PT_AMD_TRACE_AHEAD")) ahead = atoi(e);
     if (scene->state.iterations < (unsigned)(ahead > 0 ? ahead : 0)) ahead = (int)scene->state.iterations;
     if (ahead > PT_MAX_BATCH) ahead = PT_MAX_BATCH;
-    if (ahead > 1) {
-        opt.flags |= PT_FLAG_TRACE_AHEAD;
-        opt.max_batch = ahead;
-        opt.pipeline_depth = 2;         // one batch being consumed, one being traced (a third in flight only competes with the copy)
+    // A host written against the reference's pathtraceInit knows nothing of batches, so tracing ahead must never be the
+    // reason an Init fails: the batch is clamped to the library's limits for this frame (pixels x batch <= 2^29 paths,
+    // rows x padded width x batch < 2^30 tile slots: an 8192 x 8192 frame still traces 8 iterations ahead), and should the
+    // pools of the batch not fit the device's free memory -- pt_init then fails before it has allocated any -- it is halved
+    // until they do; the last resort is the plain protocol, one iteration per call, which fits frames up to 2^30 pixels.
+    {
+        const long long W = scene->state.camera.resolution.x, H = scene->state.camera.resolution.y;
+        const long long padded = (W + 255) / 256 * 256 * H;
+        while (ahead > 1 && (W * H * ahead > (1ll << 29) || padded * ahead >= (1ll << 30))) ahead /= 2;
     }
     // `mesh` objects (README.md:236): their triangles go in before the geoms that refer to them.  (Built against the
     // reference's own scene.h, whose loader knows no meshes, the shim registers none.)
@@ -55,11 +60,25 @@ void pathtraceInit(Scene *scene) {
     }
 #endif
     checkPtError(pt_set_meshes(meshes.empty() ? NULL : meshes.data(), (int)meshes.size()), "pathtraceInit");
-    checkPtError(pt_init(reinterpret_cast<const PtCamera *>(&scene->state.camera),
+    int status;
+    for (;;) {
+        opt.flags &= ~PT_FLAG_TRACE_AHEAD;
+        opt.max_batch = 0;
+        opt.pipeline_depth = 0;
+        if (ahead > 1) {
+            opt.flags |= PT_FLAG_TRACE_AHEAD;
+            opt.max_batch = ahead;
+            opt.pipeline_depth = 2;     // one batch being consumed, one being traced (a third in flight only competes with the copy)
+        }
+        status = pt_init(reinterpret_cast<const PtCamera *>(&scene->state.camera),
                          reinterpret_cast<const PtGeom *>(scene->geoms.data()), (int)scene->geoms.size(),
                          reinterpret_cast<const PtMaterial *>(scene->materials.data()), (int)scene->materials.size(),
-                         scene->state.traceDepth, &opt),
-                 "pathtraceInit");
+                         scene->state.traceDepth, &opt);
+        // (PT_ERR_INVALID / PT_ERR_HIP: a limit or an allocation that a smaller batch may satisfy; anything else is final)
+        if (status == PT_OK || ahead <= 1 || (status != PT_ERR_INVALID && status != PT_ERR_HIP)) break;
+        ahead /= 2;
+    }
+    checkPtError(status, "pathtraceInit");
     // state.image is owned by the Scene and lives from Init to Free: page-lock it for the per-iteration copy below
     // (an optimisation only; failure to register is not an error of the renderer)
     if (!scene->state.image.empty())

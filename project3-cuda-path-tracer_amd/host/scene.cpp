@@ -182,7 +182,10 @@ int Scene::loadGeom(std::string objectid) {
                     g.type = MESH;
                     meshes.push_back(m);
                 } else {
-                    std::cout << "ERROR: cannot read triangles from " << path << std::endl;
+                    // a mesh that cannot be read is a scene that cannot be rendered -- not a unit sphere with the mesh's
+                    // transform and material: fail the load like an unreadable scene file does
+                    std::cout << "ERROR: cannot read triangles from " << path << " - aborting!" << std::endl;
+                    throw std::runtime_error("cannot read triangles from " + path);
                 }
             }
         }

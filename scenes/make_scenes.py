@@ -45,12 +45,14 @@ CORNELL_OBJS = [
 GLASS = ("glass (Schlick Fresnel)", ".98 .98 .98", 0, ".98 .98 .98", 0, 1, 1.5, 0)
 
 
-def cornell(mats, name, title):
+def cornell(mats, name, title, closed=False):
     s = f"// {title}\n\n"
     for i, m in enumerate(mats):
         s += material(i, *m)
-    s += camera("800 800", 45, 5000, 8, name)
-    for i, o in enumerate(CORNELL_OBJS):
+    # closed: the eye moves inside the box (z = 4.5; the box spans z in [-5, 5]) and a front wall closes it behind the camera
+    s += camera("800 800", 45, 5000, 8, name, eye="0.0 5 4.5") if closed else camera("800 800", 45, 5000, 8, name)
+    objs = CORNELL_OBJS + ([("front wall (behind the camera)", "cube", 1, "0 5 5", "0 90 0", ".01 10 10")] if closed else [])
+    for i, o in enumerate(objs):
         s += obj(i, *o)
     return s
 
@@ -173,6 +175,9 @@ def main():
     w("cornell_mesh.txt", cornell_mesh())
     w("mesh_small.txt", mesh_small())
     w("cornell.txt", cornell(CORNELL_MATS, "cornell", "Cornell box, same values as the reference's scenes/cornell.txt"))
+    w("cornell_closed.txt", cornell(CORNELL_MATS, "cornell_closed",
+                                    "Cornell box CLOSED by a front wall, camera inside: no light can escape (the reference's analysis, README.md:284-293; "
+                                    "authored by this build)", closed=True))
     g = list(CORNELL_MATS)
     g[4] = GLASS
     w("cornell_glass.txt", cornell(g, "cornell_glass", "Cornell box with a glass sphere (BASELINE config C4; authored by this build)"))

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 def test_bench_json_contract(pt):
     if pt.device_count() < 1:
         pytest.fail("no HIP device: GPU tests must run on the MI355X box")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--cpu-spp", "1"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--cpu-spp", "1", "--repeats", "5"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -40,5 +40,13 @@ def test_bench_json_contract(pt):
     if rf["traffic"] is not None:
         assert 0.9 < rf["traffic_over_algorithmic"] < 1.25
         assert 0 < rf["valu"]["frac_of_issue_bound"]["v_fma_f32"] < 1
+    # the timed block of exactly `steps` steps is repeated inside the run: the median block's wall is the line's, the spread beside it
+    assert d["repeats"] == 5 and len(d["ms_per_step_blocks"]) == 5
+    assert d["ms_per_step"] == sorted(d["ms_per_step_blocks"])[2]
+    assert d["ms_per_step_min"] == min(d["ms_per_step_blocks"]) and d["ms_per_step_max"] == max(d["ms_per_step_blocks"])
+    assert d["value_min"] <= d["value"] <= d["value_max"]
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
+    assert cb["cpu_model"] and cb["host_cores"] >= 1 and cb["pinned_to_core"] is not None
+    # BASELINE config C1 (sphere.txt 400x400, 1 spp, depth 4) on the CPU, in full
+    assert cb["c1"]["value"] > 0 and cb["c1"]["runs"] == 15 and "400x400" in cb["c1"]["config"]

@@ -93,6 +93,7 @@ def _single_rank_frame(pt, iterations, batch):
 
 @pytest.mark.parametrize("every,extra,ranks,scaling", [("batch", [], 2, "weak"), ("1", ["--batch", "4"], 2, "weak"),
                                                        ("batch", ["--collective", "reduce", "--batch", "8"], 2, "strong"),
+                                                       ("1", ["--collective", "reduce", "--batch", "4"], 2, "strong"),   # config C3 as written
                                                        ("batch", ["--batch", "16"], 4, "strong"), ("batch", ["--batch", "96"], 3, "weak")])
 def test_bench_two_ranks_contract(pt, tmp_path, every, extra, ranks, scaling):
     # bench.py --gpus 2 (and 4) WITHOUT a torchrun environment: it starts its ranks itself (torch.distributed.run as a
@@ -105,9 +106,9 @@ def test_bench_two_ranks_contract(pt, tmp_path, every, extra, ranks, scaling):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     dump = str(tmp_path / "frame.npy")
-    steps, warmup = 3, 1
+    steps, warmup, repeats = 3, 1, 2
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", str(steps), "--warmup", str(warmup),
-                        "--collective-every", every, "--per-iteration-sample", "1", "--dump-frame", dump] + extra
+                        "--repeats", str(repeats), "--collective-every", every, "--per-iteration-sample", "1", "--dump-frame", dump] + extra
                        + ([] if scaling == "weak" else ["--scaling", "strong"]),                # (weak is the default)
                        capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -132,12 +133,43 @@ def test_bench_two_ranks_contract(pt, tmp_path, every, extra, ranks, scaling):
     else:
         wb = B * max(1, min(ranks, pt.PT_MAX_BATCH // B, steps // 8))
     assert d["config"]["iterations_per_wavefront_batch"] == wb
-    if every == "batch":
-        assert d["config"]["per_iteration_collective"]["value"] > 0   # config C3 as written, timed beside it
+    # the timed block is repeated inside the run: median / min / max, every block listed
+    assert d["repeats"] == repeats and len(d["ms_per_step_blocks"]) == repeats
+    assert d["ms_per_step_min"] <= d["ms_per_step"] <= d["ms_per_step_max"] and d["value_min"] <= d["value"] <= d["value_max"]
+    # ONE N > 1 run carries all three readings of "N GPUs", each over whole steps, and the collective's size and share
+    for k in ("value_weak", "value_strong", "value_c3_as_written"):
+        assert d[k]["value"] > 0 and d[k]["steps"] >= 1 and d[k]["unit"] == "Mpaths/s", k
+    assert d["value_" + scaling]["value"] == d["value"]             # `value` = the reading --scaling names
+    assert d["value_weak"]["iterations_per_step"] == B * ranks and d["value_strong"]["iterations_per_step"] == B
+    assert d["value_c3_as_written"]["iterations_per_step"] == B and d["value_c3_as_written"]["iterations_per_wavefront_batch"] == 1
+    assert "reduce per iteration" in d["value_c3_as_written"]["mode"]
+    mg = d["multi_gpu"]
+    block = -(-720 // ranks) * 1280 * 12                            # a rank's packed rows, padded to the largest shard
+    assert mg["collective_bytes_per_call"]["sent_by_each_rank"] == (1280 * 720 * 12 if "reduce" in extra else block)
+    assert mg["collective_ms_per_call"] > 0 and 0 < mg["collective_share_of_step"] < 1.5
+    assert d["roofline"]["scope"].startswith("rank 0")
     got = np.load(dump)
-    want = _single_rank_frame(pt, (steps + warmup) * I, min(I, 64))
+    want = _single_rank_frame(pt, (steps * repeats + warmup) * I, min(I, 64))
     assert want.max() > 0
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_rccl_needs_one_gpu_per_rank_and_says_so(pt):
+    # two ranks under the real backend on the box's single GPU: RCCL cannot serve ranks stacked on one device, so bench.py must
+    # refuse at once, with a clear message and a non-zero exit code that the self-launched parent relays
+    if pt.device_count() < 1:
+        pytest.fail("no HIP device: GPU tests must run on the MI355X box")
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("more than one GPU visible")
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "BENCH_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0
+    assert "2 ranks need 2 GPUs under RCCL" in (r.stderr + r.stdout)
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 
 def _rccl_single_rank(_index, port, out_path):

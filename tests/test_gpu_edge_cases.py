@@ -328,6 +328,13 @@ def test_undersized_pool_fails_loudly(gpu, oracle, monkeypatch):
     gpu.pathtrace(None, 0, 2, readback=False)             # still memory-safe, still flagged
     with pytest.raises(gpu.PtError, match="device fault"):
         gpu.sync()
+    # ... and by the calls a host of the reference protocol makes: the image copies report the faulted render too
+    with pytest.raises(gpu.PtError, match="device fault"):
+        gpu.readback(256 * 256)
+    with pytest.raises(gpu.PtError, match="device fault"):
+        gpu.readback_rgba8(2, 256 * 256)
+    with pytest.raises(gpu.PtError, match="device fault"):
+        gpu.pathtrace(None, 0, 3)                          # pathtrace() = pt_iterate + the copy into scene.image
     monkeypatch.delenv("PT_AMD_POOL_CHUNKS")
     _compare(gpu, oracle, sc, [1, 2])                     # a fresh pt_init with real pools renders correctly again
 
@@ -335,20 +342,27 @@ def test_undersized_pool_fails_loudly(gpu, oracle, monkeypatch):
 def test_forced_fault_words_are_reported(gpu):
     import torch
     # renderer: a fault word set by hand is reported by pt_sync and pt_counters and survives a counter reset
+    # (the hook that sets the word lives in the test library only -- the product exports no such thing -- so this one test
+    # drives the renderer instance of libpt_amd_test.so)
     sc = gpu.Scene(os.path.join(SCENES, "cornell.txt"))
     sc.set_resolution(32, 32)
     gpu.pathtraceFree()
-    gpu.pathtraceInit(sc)
-    gpu.sync()
-    gpu.force_fault(2)
-    with pytest.raises(gpu.PtError, match="device fault"):
+    assert not hasattr(gpu.lib(), "pt_test_force_fault")
+    with gpu.renderer_from_test_library():
+        gpu.pathtraceInit(sc)
         gpu.sync()
-    gpu.counters_reset()
-    with pytest.raises(gpu.PtError, match="device fault"):
+        gpu.force_fault(2)
+        with pytest.raises(gpu.PtError, match="device fault"):
+            gpu.sync()
+        gpu.counters_reset()
+        with pytest.raises(gpu.PtError, match="device fault"):
+            gpu.sync()
+        with pytest.raises(gpu.PtError, match="device fault"):
+            gpu.readback(32 * 32)
+        gpu.force_fault(0)                                    # (diagnostics: cleared, the renderer answers again)
         gpu.sync()
-    gpu.force_fault(0)                                    # (diagnostics: cleared, the renderer answers again)
-    gpu.sync()
-    gpu.pathtraceFree()
+        gpu.readback(32 * 32)
+        gpu.pathtraceFree()
     # the scan library has no fault word: no workgroup of it ever waits for another one.  Without a renderer pt_sync waits for it.
     x = torch.ones(5000, dtype=torch.int32, device="cuda")
     y = torch.empty_like(x)
@@ -428,3 +442,31 @@ def test_config_c4_frame_properties(gpu):
     gpu.pathtraceFree()
     assert np.array_equal(acc.view(np.uint32), full.view(np.uint32))
     assert np.isfinite(full).all() and full.min() >= 0 and full.max() > 0
+
+
+def test_closed_cornell_box_matches_the_oracle_and_lets_nothing_escape(gpu, oracle):
+    # the reference's analysis scene (README.md:284-293): Cornell closed by a front wall, camera inside.  No light can escape, so a
+    # path ends only on the light or at the depth limit: bit-identical to the oracle, zero misses, and every bounce's queue is the
+    # previous one minus the paths that reached the light
+    sc = gpu.Scene(os.path.join(SCENES, "cornell_closed.txt"))
+    W, H = 200, 120
+    sc.set_resolution(W, H)
+    ref = oracle.Renderer(sc.camera.view(oracle.CAMERA_DTYPE), sc.geoms.view(oracle.GEOM_DTYPE), sc.materials.view(oracle.MATERIAL_DTYPE), 8)
+    want = np.zeros(W * H * 3, np.float32)
+    live = np.zeros(16, np.int64)
+    hits = 0
+    for it in range(1, 5):
+        c = ref.iterate(it, want)
+        live += np.array(c.live[:16])
+        hits += int(c.lightHits)
+    gpu.pathtraceFree()
+    gpu.pathtraceInit(sc, traceDepth=8, max_batch=4, pipeline_depth=2)
+    gpu.pathtrace_batch(None, 0, 1, 4)
+    got = gpu.readback(W * H)
+    cnt = gpu.counters()
+    gpu.pathtraceFree()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)) and want.max() > 0
+    assert [int(cnt.live[d]) for d in range(1, 10)] == live[1:10].tolist()
+    assert int(cnt.misses) == 0 and int(cnt.light_hits) == hits
+    assert all(int(cnt.ended_early[d]) == 0 for d in range(10))          # nothing to end early in a closed box
+    assert live[8] > 0.5 * live[1]                                       # the closed box keeps most paths alive to the last bounce

@@ -14,6 +14,12 @@ import pytest
 from conftest import GOLD, ROOT, SCENES
 
 
+def _exported(path):
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
+    return sorted(l.split()[2] for l in out.splitlines() if len(l.split()) == 3 and l.split()[1] == "T")
+
+
 def test_abi_library_exports_every_declared_symbol(pt):
     hdr = open(os.path.join(ROOT, "include", "pt_amd.h")).read()
     declared = sorted(set(re.findall(r"\b(pt_[a-z0-9_]+)\s*\(", hdr)))
@@ -21,6 +27,15 @@ def test_abi_library_exports_every_declared_symbol(pt):
     L = C.CDLL(pt.LIB_PATH)
     for name in declared:
         assert hasattr(L, name), name
+    # ... and NOTHING else: no test hook, no probe, no fault injection in the product's exported functions
+    assert _exported(pt.LIB_PATH) == declared
+
+
+def test_test_library_adds_exactly_the_test_header(pt):
+    hdr = open(os.path.join(ROOT, "include", "pt_amd_test.h")).read()
+    declared = sorted(set(re.findall(r"\b(pt_test_[a-z0-9_]+)\s*\(", hdr)))
+    assert declared == sorted(pt.TEST_ABI_SYMBOLS)
+    assert _exported(pt.TEST_LIB_PATH) == sorted(pt.ABI_SYMBOLS + pt.TEST_ABI_SYMBOLS)
 
 
 def test_struct_sizes_match_reference_layout(pt):

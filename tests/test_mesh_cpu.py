@@ -5,6 +5,7 @@ rule in fp32, returns the oracle's brute-force result."""
 import os
 
 import numpy as np
+import pytest
 
 from conftest import SCENES
 
@@ -33,12 +34,20 @@ def test_obj_statements(pt, oracle, tmp_path):
         "MATERIAL 0\nRGB 1 1 1\nSPECEX 0\nSPECRGB 0 0 0\nREFL 0\nREFR 0\nREFRIOR 0\nEMITTANCE 1\n\n"
         "CAMERA\nRES 8 8\nFOVY 45\nITERATIONS 1\nDEPTH 2\nFILE x\nEYE 0 0 5\nVIEW 0 0 -1\nUP 0 1 0\n\n"
         "OBJECT 0\nmesh m.obj\nmaterial 0\nTRANS 0 0 0\nROTAT 0 0 0\nSCALE 1 1 1\n\n"
-        "OBJECT 1\nmesh missing.obj\nmaterial 0\nTRANS 0 0 0\nROTAT 0 0 0\nSCALE 1 1 1\n\n")
+        "OBJECT 1\nflubber\nmaterial 0\nTRANS 0 0 0\nROTAT 0 0 0\nSCALE 1 1 1\n\n")
     want = np.array([[0, 0, 0, 1, 0, 0, 1, 1, 0], [0, 0, 0, 1, 1, 0, 0, 1, 0], [0, 0, 1, 0, 0, 0, 1, 0, 0]], f32)
     for mod in (pt, oracle):
         sc = mod.Scene(str(tmp_path / "s.txt"))
         assert list(sc.meshes) == [0] and np.array_equal(sc.meshes[0], want)
-        assert list(sc.geoms["type"]) == [2, 0]       # an unreadable mesh file leaves the default type, like an unknown type line
+        assert list(sc.geoms["type"]) == [2, 0]       # an unknown type line leaves the default type (the reference's behaviour)
+    # a mesh object whose file is missing, unreadable or holds no triangle fails the LOAD (it used to render as a unit sphere
+    # with the mesh's transform and material)
+    (tmp_path / "empty.obj").write_text("# no faces\nv 0 0 0\nv 1 0 0\n")
+    for bad in ("missing.obj", "empty.obj"):
+        (tmp_path / "bad.txt").write_text((tmp_path / "s.txt").read_text().replace("flubber", "mesh " + bad))
+        for mod in (pt, oracle):
+            with pytest.raises(IOError):
+                mod.Scene(str(tmp_path / "bad.txt"))
 
 
 def _cube_mesh():
