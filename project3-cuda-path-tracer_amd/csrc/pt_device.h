@@ -405,12 +405,13 @@ __device__ __forceinline__ void slabQuotients(float o, float d, float &t1, float
 // the six correctly rounded divisions.  It only pays when whole waves take it, i.e. for coherent
 // rays (EARLY_MISS is set for the camera-ray bounce); results are identical either way.
 // CAM_ORIGIN: the ray starts at the camera, whose object-space position is precomputed (GeomDev::camObj).
+// `early` (wave-uniform, with EARLY_MISS): take the early miss at all -- callers that expect nearly every ray to hit skip its compares.
 template <bool EARLY_MISS, bool CAM_ORIGIN = false, typename GD>
-__device__ __forceinline__ float boxIntersectionTest(const GD &g, F3 ro, F3 rd, F3 &P, F3 &nsrc, bool &outside) {
+__device__ __forceinline__ float boxIntersectionTest(const GD &g, F3 ro, F3 rd, F3 &P, F3 &nsrc, bool &outside, bool early = true) {
     probe(0);
     const F3 qo = CAM_ORIGIN ? f3(g.camObj[0], g.camObj[1], g.camObj[2]) : mulMV(g.inv, ro, 1.0f);
     const F3 qdu = mulMV0(g.inv, g.invZ, rd);
-    if (EARLY_MISS) {
+    if (EARLY_MISS && early) {
         // (bitwise on purpose: twelve compares and eleven mask operations, no nest of divergent branches)
         const bool away = ((qo.x > 0.5f) & (qdu.x > 0.0f)) | ((qo.x < -0.5f) & (qdu.x < 0.0f)) |
                           ((qo.y > 0.5f) & (qdu.y > 0.0f)) | ((qo.y < -0.5f) & (qdu.y < 0.0f)) |

@@ -29,7 +29,8 @@ constexpr int kWallMax = 6;          // large cubes ("walls") whose world-space 
 constexpr int kMinChunkShift = 11;   // chunks hold at least 2048 paths: a multiple of the tile size, so a tile never straddles two
 // k_bounce<., MANY> (scenes with more than kBinMax spheres): LDS words of the fixed scratch, floats per staged sphere
 // record (inverseTransform rows, transform rows, GeomDev::invZ, 4 B of padding), spheres a lane can record per tile
-constexpr int kMiscWords = 2 * kWaves * kCls + 5 * kCls + kSeg + (kSeg + 2) + 2 * PT_MAX_BATCH + 2;
+constexpr int kNanWords = 12;        // nine NaNs (+ padding): the "face frame" of a cube hit without an exit slab (cubeFace: a ray of NaNs)
+constexpr int kMiscWords = 2 * kWaves * kCls + 5 * kCls + kSeg + (kSeg + 2) + 2 * PT_MAX_BATCH + 2 + kNanWords;
 static_assert(kMiscWords % 4 == 0, "the sphere records that follow are read as float4");
 constexpr int kSphRowFloats = 28;
 constexpr int kListMax = 8;
@@ -137,13 +138,8 @@ __device__ __forceinline__ void stSlot(float *arr, uint32_t byteOff, float v) {
 // The loop is WAVE-UNIFORM with one poll per lane and trip: a lane never spins inside a trip, whatever the compiler
 // makes of the branches.
 // The run occupies  [base0, base0 + split)  and  [base1, base1 + total - split).
-// `hostFault`: the fault word's copy in page-locked host memory (State::hostFault), or nullptr.
-__device__ __forceinline__ void raiseFault(uint32_t *fault, uint32_t *hostFault, uint32_t bit) {
-    atomicOr(fault, bit);
-    if (hostFault) __hip_atomic_store(hostFault, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (any non-zero value: the host then reads `fault`)
-}
 __device__ __forceinline__ void reserveRun(uint32_t *pos, uint32_t *bump, unsigned long long *segList, uint32_t oseg,
-                                           uint32_t poolChunks, uint32_t shift, uint32_t gen, uint32_t total, uint32_t *fault, uint32_t *hostFault,
+                                           uint32_t poolChunks, uint32_t shift, uint32_t gen, uint32_t total, uint32_t *fault,
                                            uint32_t &cacheK, uint32_t &cacheC, uint32_t &base0, uint32_t &split, uint32_t &base1) {
     base0 = base1 = 0u;
     split = total;
@@ -156,7 +152,7 @@ __device__ __forceinline__ void reserveRun(uint32_t *pos, uint32_t *bump, unsign
         const uint32_t kNew = k1 + 1u;
         uint32_t x = (uint32_t)kSeg + 1u + atomicAdd(bump, 1u);
         if (x >= poolChunks) {
-            raiseFault(fault, hostFault, kFaultPoolExhausted);
+            atomicOr(fault, kFaultPoolExhausted);
             x = 0u;
         }
         if (kNew < poolChunks)
@@ -177,7 +173,7 @@ __device__ __forceinline__ void reserveRun(uint32_t *pos, uint32_t *bump, unsign
             if ((uint32_t)(e >> 32) == gen) { c1 = (uint32_t)e; need1 = false; }
         }
         if (polls > kReservePollLimit && (need0 || need1)) {
-            raiseFault(fault, hostFault, kFaultReserveTimeout);
+            atomicOr(fault, kFaultReserveTimeout);
             if (need0) c0 = 0u;
             if (need1) c1 = 0u;
             need0 = need1 = false;
@@ -337,7 +333,7 @@ struct BounceArgs {
     const int *rowOff;                  // camera rays (a tile is 256 pixels of one row): the primitives that can be reached from image row y are the entries
     const int *rowIdx;                  //   rowOff[y] .. rowOff[y + 1] of rowIdx, file order: pairs {primitive, x0 | x1 << 16} = the row's pixels
                                         //   inside the hull of the primitive's projected corners (pt_init); rowOff == nullptr: every primitive
-    uint32_t *hostFault;                // the sticky fault word's copy in page-locked host memory (raiseFault), or nullptr
+    uint32_t *hostFault;                // the sticky fault word's copy in page-locked host memory (written by a batch's last launch), or nullptr
 };
 typedef const PT_CAS BounceArgs *ArgsPtr;
 typedef const PT_CAS GeomDev *GeomPtr;
@@ -399,6 +395,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
     uint32_t *const s_segcnt = s_base + 5 * kCls;          // [kSeg]   paths per input segment
     uint32_t *const s_segpre = s_segcnt + kSeg;            // [kSeg+2] tile prefix per input segment, [kSeg+1] = live paths
     uint32_t *const s_iterHash = s_segpre + kSeg + 2;      // [2][PT_MAX_BATCH] iterationHash(iter + b, depth) and (iter + b, 0)
+    const float *const s_nan = reinterpret_cast<const float *>(s_iterHash + 2 * PT_MAX_BATCH + 2);   // [kNanWords] NaNs: see cubeFace
 
     uint32_t nLive, numTiles;
     {
@@ -410,6 +407,14 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
             const int nwords = (A->prm.traceDepth + 2) * kSeg;
             for (int i = blockIdx.x * kBlock + threadIdx.x; i < nwords; i += gridDim.x * kBlock) other[i * kCtrPad] = 0u;
             if (blockIdx.x == 0 && threadIdx.x < kMaxDepthSlots) ctrl->bump[parity ^ 1][threadIdx.x][0] = 0u;
+            // ... and the batch's last launch (which compacts nothing, hence raises no fault itself) hands a fault word the earlier
+            // launches may have set to the host: its copy in page-locked memory is what pt_readback looks at after its synchronisation,
+            // without a device-to-host copy of its own.  Here, in the prologue, it costs the tile loop no register.
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                const uint32_t e = __hip_atomic_load(&ctrl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                uint32_t *const hostFault = A->hostFault;
+                if (e != 0u && hostFault != nullptr) __hip_atomic_store(hostFault, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
         // input queue: segment s holds s_cnt[s] paths = tiles [s_pre[s], s_pre[s+1]) of the global tile index
         if (FIRST) {
@@ -437,6 +442,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
         if (blockIdx.x >= numTiles) return;
         if (threadIdx.x < 2 * kWaves * kCls) s_wave[threadIdx.x] = 0u;
         if (threadIdx.x < kCls) s_base[3 * kCls + threadIdx.x] = 0xffffffffu;   // no chunk looked up yet
+        if (threadIdx.x < kNanWords) s_iterHash[2 * PT_MAX_BATCH + 2 + threadIdx.x] = 0x7fc00000u;
         for (int i = threadIdx.x; i < 2 * PT_MAX_BATCH; i += kBlock) {
             const int b = i % PT_MAX_BATCH;
             s_iterHash[i] = iterationHash(A->iter + b, i < PT_MAX_BATCH ? depth : 0);
@@ -497,10 +503,13 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
     uint32_t sgIn = 0;                      // input segment of the tile being set up (tiles are visited in increasing order)
     // FIRST: the k-th tile of a workgroup is rotated k column bands to the right inside its row (see below).  The grid is a multiple
     // of the tiles per row (pt_init), so every tile of a workgroup has the same band c0 = blockIdx % tilesPerRow: ONE division, here.
-    uint32_t rot0 = 0, rot = 0;             // c0, and (c0 + k) % tilesPerRow of the tile about to be processed
+    // The loop then carries the FIRST tile of the row (T - c0, which steps by the grid like T and stays below numTiles exactly as
+    // long as T does: both are multiples of the tiles per row apart from c0 < tilesPerRow) and the rotated band.
+    uint32_t rot = 0;                       // (c0 + k) % tilesPerRow of the tile about to be processed
+    uint32_t rowShift = 0;                  // c0
     if (FIRST) {
         const uint32_t tpr = (uint32_t)launder(kargs)->prm.tilesPerRow;
-        if (tpr > 1) rot0 = rot = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x % tpr));
+        if (tpr > 1) rowShift = rot = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x % tpr));
     }
 
     // ---- later bounces: a tile's paths are requested ONE TILE AHEAD.  A workgroup's tiles form a chain of dependent
@@ -557,7 +566,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
         }
     };
     // the first tile of this workgroup that needs work, and its paths
-    uint32_t T = blockIdx.x;
+    uint32_t T = blockIdx.x - rowShift;      // (FIRST with rotated bands: the first tile of the row; else the tile itself)
     TileMeta nextMeta = {false, 0u, 0u};
     PathRegs nextRegs = {f3(0, 0, 0), f3(0, 0, 1), f3(0, 0, 0), 0, 0};
     if (!FIRST) {
@@ -591,7 +600,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
             uint32_t pixTile = T;
             const uint32_t tilesPerRow = (uint32_t)prm.tilesPerRow;
             if (tilesPerRow > 1) {
-                pixTile = T - rot0 + rot;                       // (T % tilesPerRow == rot0 for every tile of this workgroup)
+                pixTile = T + rot;                              // (T: the first tile of this tile's row)
                 rot = rot + 1u == tilesPerRow ? 0u : rot + 1u;
             }
             // the tile's (wave-uniform) position: iteration of the batch, row of the shard, first column -- no per-lane divisions
@@ -627,6 +636,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
         uint32_t lightHitI = 0u, missedI = 0u;
         F3 org = f3(0, 0, 0), dir = f3(0, 0, 1), col = f3(0, 0, 0);
         int pix = 0, rem = 0;
+        uint32_t pixHash = 0u;                                  // FIRST: utilhash(pix), shared by the camera jitter's and the scatter's engines
         if (valid) {
             // Camera rays (FIRST): a primitive is reachable only from the pixels inside the projection of its bounding
             // cube (GeomDev::rect, 2-pixel margin >> any rounding of the reference's tests), and nothing is reachable
@@ -640,7 +650,8 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
                 inScene = px >= prm.sceneRect[0] && px <= prm.sceneRect[2] && py >= prm.sceneRect[1] && py <= prm.sceneRect[3];
                 if (inScene) {
                     // camera ray (spec S2), jitter from the depth-0 stream of (iteration, pixel)
-                    Rng rng = makeSeededRandomEngineHashed(s_iterHash[PT_MAX_BATCH + itb], pix);
+                    pixHash = utilhash((uint32_t)pix);              // (once: the scatter's engine below is keyed on the same pixel)
+                    Rng rng = seedEngine(s_iterHash[PT_MAX_BATCH + itb] ^ pixHash);
                     const float jx = u01(rng);
                     const float jy = u01(rng);
                     const float sx = ((float)px + jx) - prm.halfW;
@@ -719,6 +730,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
                     classIdx = (const PT_CAS int *)(A->classIdx);
                 }
                 const GeomPtr geoms = (GeomPtr)(A->ggeoms);
+                const bool earlyMiss = FIRST || A->prm.nWalls == 0 || (tileCls & 7u) >= 6u;     // (wave-uniform)
                 for (int gk = gk0; gk < gk1; ++gk) {
                     int g, span = 0;
                     if (FIRST && listed) {
@@ -768,7 +780,9 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
                             }
                         }
                     } else {
-                        t = boxIntersectionTest<true, FIRST && !DOF>(G, org, dir, p, n, o);
+                        // (the exact early miss pays where whole waves take it: not for camera rays inside a primitive's hull span -- 97 %
+                        // of their box tests reach the hit phase -- nor in a tile whose class names the ONE wall its paths can still hit)
+                        t = boxIntersectionTest<!FIRST, FIRST && !DOF>(G, org, dir, p, n, o, earlyMiss);
                     }
                     // (PACKED: a sphere tested in place above may hold the record with a higher index: file order decides a tie)
                     if (t > 0.0f && (hit < 0 || t < tbest || (PACKED && t == tbest && g < hit))) {
@@ -861,7 +875,10 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
                 bool faceOk = true;
                 const int face = isSphere ? 0 : cubeFace(nsrc, faceOk);
                 const bool outside = outsideI != 0;
-                const F3 N = isSphere ? hitNormalSphere(ghNm, nsrc, outside) : cubeFrameVector(ghFrame, face, 0, faceOk);
+                // a cube face's frame (normal + the sampler's two tangents, nine floats): ONE select on the address -- the face's
+                // row of the table, or the row of NaNs for a hit without an exit slab -- instead of nine on the values
+                const float *const fv = faceOk ? ghFrame + 9 * face : s_nan;
+                const F3 N = isSphere ? hitNormalSphere(ghNm, nsrc, outside) : f3(fv[0], fv[1], fv[2]);
                 const MaterialDev &M = smats[ghMaterial];
                 const F3 mcol = f3(M.color[0], M.color[1], M.color[2]);
                 if (M.emittance > 0.0f) {                        // S5: emitter ends the path
@@ -892,7 +909,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
                     }
                 } else if (!launder(kargs)->lastBounce) {        // S6 scatter (S7: skipped on the last bounce)
                     probe(10);
-                    Rng rng = makeSeededRandomEngineHashed(s_iterHash[itb], pix);
+                    Rng rng = seedEngine(s_iterHash[itb] ^ (FIRST ? pixHash : utilhash((uint32_t)pix)));   // = makeSeededRandomEngineHashed(., pix)
                     const F3 scol = f3(M.specColor[0], M.specColor[1], M.specColor[2]);
                     F3 ndir = dir, norg;
                     bool diffuse = false;                        // the hemisphere is sampled at one place, after the branches
@@ -980,8 +997,8 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
                         if (isSphere) {
                             hemisphereFrame(N, p1, p2);
                         } else {
-                            p1 = cubeFrameVector(ghFrame, face, 1, faceOk);
-                            p2 = cubeFrameVector(ghFrame, face, 2, faceOk);
+                            p1 = f3(fv[3], fv[4], fv[5]);
+                            p2 = f3(fv[6], fv[7], fv[8]);
                         }
                         ndir = hemisphereCombine(N, p1, p2, up, cOver, sOver);
                     }
@@ -1049,15 +1066,26 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
             // same-class mask of this lane from four bit ballots (the sign compares already are the ballots)
             const unsigned long long ba = __ballot(alive);
             // class bits 0-2: the wall the ray can still hit (scenes with walls) or the octant of its direction
-            const bool c0 = wallSel < 8u ? (wallSel & 1u) != 0u : dir.x < 0.0f;
-            const bool c1 = wallSel < 8u ? (wallSel & 2u) != 0u : dir.y < 0.0f;
-            const bool c2 = wallSel < 8u ? (wallSel & 4u) != 0u : dir.z < 0.0f;
-            const unsigned long long b0 = __ballot(c0), b1 = __ballot(c1), b2 = __ballot(c2);
-            const unsigned long long b3 = __ballot(smallCand);
-            const uint32_t cls = (c0 ? 1u : 0u) | (c1 ? 2u : 0u) | (c2 ? 4u : 0u) | (smallCand ? 8u : 0u);
-            const unsigned long long same = ba & (c0 ? b0 : ~b0) & (c1 ? b1 : ~b1) & (c2 ? b2 : ~b2) & (smallCand ? b3 : ~b3);
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(same >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)same, 0u));
-            if (alive && rank == 0u) wv[wave * kCls + cls] = (uint32_t)__popcll(same);   // the class's first lane
+            uint32_t cls;
+            if (launder(kargs)->prm.nWalls > 0) {
+                cls = wallSel & 7u;
+            } else {
+                cls = (dir.x < 0.0f ? 1u : 0u) | (dir.y < 0.0f ? 2u : 0u) | (dir.z < 0.0f ? 4u : 0u);
+            }
+            cls |= smallCand ? 8u : 0u;
+            // the lanes of this lane's class: per class bit k the ballot of the bit, taken as it is where the lane's own bit is set and
+            // complemented where it is clear (bit - 1 = 0 or ~0) -- 32-bit halves, three instructions per bit and half
+            uint32_t sameLo = (uint32_t)ba, sameHi = (uint32_t)(ba >> 32);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t bit = (cls >> k) & 1u;
+                const unsigned long long bk = __ballot(bit != 0u);
+                const uint32_t flip = bit - 1u;
+                sameLo &= (uint32_t)bk ^ flip;
+                sameHi &= (uint32_t)(bk >> 32) ^ flip;
+            }
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi(sameHi, __builtin_amdgcn_mbcnt_lo(sameLo, 0u));
+            if (alive && rank == 0u) wv[wave * kCls + cls] = (uint32_t)(__popc(sameLo) + __popc(sameHi));   // the class's first lane
             __syncthreads();
             if (tid < kCls) {
                 const ArgsPtr A = launder(kargs);
@@ -1070,7 +1098,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
                 const uint32_t oseg = tid * kSub + (blockIdx.x % kSub);
                 uint32_t r0, sp, r1;
                 reserveRun(&ctrl->pos[parity][dnext][oseg][0], &ctrl->bump[parity][dnext][0], A->out.list + (size_t)oseg * poolChunks, oseg,
-                           poolChunks, (uint32_t)A->prm.chunkShift, A->genOut, total, &ctrl->error, A->hostFault, s_base[3 * kCls + tid],
+                           poolChunks, (uint32_t)A->prm.chunkShift, A->genOut, total, &ctrl->error, s_base[3 * kCls + tid],
                            s_base[4 * kCls + tid], r0, sp, r1);
                 s_base[tid] = r0;
                 s_base[kCls + tid] = sp;
