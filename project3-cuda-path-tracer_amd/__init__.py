@@ -60,6 +60,7 @@ TEST_ABI_SYMBOLS = [
     "pt_test_slab_quotients", "pt_test_slab_quotients_sweep", "pt_test_sphere_cull_sweep", "pt_test_unscaled_sqrt_sweep",
     "pt_test_force_fault", "pt_test_pow", "pt_test_wall_box_sweep", "pt_test_mesh_intersect", "pt_test_mesh_bvh",
     "pt_test_mesh_cull_sweep", "pt_test_camera_cull_sweep", "pt_test_camera_cull_tables",
+    "pt_test_wall_plane_sweep",
 ]
 
 
@@ -129,6 +130,7 @@ def _bind(L, with_tests):
         L.pt_test_mesh_cull_sweep.argtypes = [vp, vp, i32, C.c_uint64, i64] + [u64p] * 3
         L.pt_test_camera_cull_sweep.argtypes = [vp, vp, i32, i32] + [u64p] * 3
         L.pt_test_camera_cull_tables.argtypes = [vp, vp, i32, vp, vp, vp]
+        L.pt_test_wall_plane_sweep.argtypes = [vp, i32, C.c_uint64, i64, C.POINTER(C.c_int32)] + [u64p] * 3
     return L
 
 
@@ -550,6 +552,15 @@ def test_camera_cull_sweep(camera, geoms, samples=1):
     h, c, v = C.c_uint64(), C.c_uint64(), C.c_uint64()
     _tcheck(test_lib().pt_test_camera_cull_sweep(_p(cam), _p(geoms), len(geoms), samples, C.byref(h), C.byref(c), C.byref(v)))
     return int(h.value), int(c.value), int(v.value)
+
+
+def test_wall_plane_sweep(geoms, seed, rays):
+    """Device sweep of the one-plane-per-wall certificates.  Returns (walls with a plane, certified, violations, single-wall rays)."""
+    geoms = np.ascontiguousarray(geoms)
+    n = C.c_int32(0)
+    c, v, s1 = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+    _tcheck(test_lib().pt_test_wall_plane_sweep(_p(geoms), len(geoms), seed, rays, C.byref(n), C.byref(c), C.byref(v), C.byref(s1)))
+    return int(n.value), int(c.value), int(v.value), int(s1.value)
 
 
 def scan_exclusive_dev(in_ptr, out_ptr, n, stream=0):

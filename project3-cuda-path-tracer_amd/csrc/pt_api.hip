@@ -320,6 +320,81 @@ double wall_box(const PtGeom &g, WallBox &w, double *omax = nullptr) {
     return S_;
 }
 
+// The walls of a scene -- its large cubes: not binned, finite, at most kWallMax of them, the largest first -- with what the survivors'
+// certificates need (k_bounce: which wall can a scattered ray still hit?): the inflated world boxes (wall_box), the bound on the ray
+// origins the margins hold for, and for the walls that have one the PLANE of their box that faces the scene's interior
+// (ptd::wallPlanesPossible): with C the centre of the box `outer` around all the walls' boxes, a face of a wall's box whose whole box
+// lies beyond C on that axis.  Six slots (axis x side) hold one wall each: a wall takes the free slot in which it lies farthest out
+// (in units of the scene's extent), the largest walls choose first; walls without a slot (a box across the middle of the scene, a
+// second wall on the same side) are numbered behind the others and keep the slab test.
+// Thresholds: the plane moved towards the interior by slack = 2e-6 (wallOMax + |diagonal of outer|), five times the rounding of the
+// ray's exit point.  A choice that only steers which tiles skip which tests; results never depend on it.
+// wallGeom[w] = the primitive that is wall w.
+void choose_walls(const PtGeom *geoms, int ngeoms, const std::vector<GeomDev> &hg, KParams &k, std::vector<WallBox> &hw, std::vector<int> &wallGeom) {
+    std::vector<std::pair<double, int>> cand;
+    for (int i = 0; i < ngeoms; ++i)
+        if (geoms[i].type == PT_CUBE && !hg[i].binned) cand.emplace_back(-(double)hg[i].boundR, i);
+    std::sort(cand.begin(), cand.end());
+    std::vector<WallBox> boxes;
+    std::vector<int> which;
+    double omaxAll = INFINITY;
+    for (size_t c = 0; c < cand.size() && (int)boxes.size() < kWallMax; ++c) {
+        WallBox wb;
+        double om = 0;
+        if (wall_box(geoms[cand[c].second], wb, &om) < 0) continue;
+        omaxAll = std::min(omaxAll, om);
+        boxes.push_back(wb);
+        which.push_back(cand[c].second);
+    }
+    const int n = (int)boxes.size();
+    k.nWalls = n;
+    k.wallOMax = n > 0 ? (float)omaxAll : 0.0f;      // the margin must hold for every wall
+    k.nSlotWalls = 0;
+    for (int sl = 0; sl < 6; ++sl) { k.slotTh[sl] = 0.0f; k.slotBit[sl] = 0u; }
+    for (int a = 0; a < 3; ++a) k.outerLo[a] = k.outerHi[a] = 0.0f;
+    wallGeom.clear();
+    if (n == 0) return;
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (const WallBox &b : boxes)
+        for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], (double)b.lo[a]); hi[a] = std::max(hi[a], (double)b.hi[a]); }
+    double diag = 0;
+    for (int a = 0; a < 3; ++a) diag += (hi[a] - lo[a]) * (hi[a] - lo[a]);
+    diag = std::sqrt(diag);
+    const double slack = 2e-6 * (omaxAll + diag);
+    // slot of every wall: 2 axis + (high side), or -1
+    std::vector<int> slot(n, -1);
+    std::vector<double> th(n, 0.0);
+    bool taken[6] = {false, false, false, false, false, false};
+    for (int w = 0; w < n && std::isfinite(slack); ++w) {            // (largest walls first)
+        double best = 0;
+        for (int a = 0; a < 3; ++a) {
+            const double C = 0.5 * (lo[a] + hi[a]), ext = std::max(hi[a] - lo[a], 1e-30);
+            const double gLow = (C - boxes[w].hi[a]) / ext, gHigh = (boxes[w].lo[a] - C) / ext;
+            if (gLow > best && !taken[2 * a] && std::isfinite((double)boxes[w].hi[a] + slack)) { best = gLow; slot[w] = 2 * a; th[w] = (double)boxes[w].hi[a] + slack; }
+            if (gHigh > best && !taken[2 * a + 1] && std::isfinite((double)boxes[w].lo[a] - slack)) { best = gHigh; slot[w] = 2 * a + 1; th[w] = (double)boxes[w].lo[a] - slack; }
+        }
+        if (slot[w] >= 0) taken[slot[w]] = true;
+    }
+    for (int pass = 0; pass < 2; ++pass)                              // walls with a slot first
+        for (int w = 0; w < n; ++w)
+            if ((slot[w] >= 0) == (pass == 0)) {
+                const int idx = (int)wallGeom.size();
+                hw[idx] = boxes[w];
+                if (slot[w] >= 0) {
+                    // rounded towards the interior: a threshold may only make the certificate rarer
+                    const float t = (float)th[w];
+                    k.slotTh[slot[w]] = (slot[w] & 1) ? ((double)t > th[w] ? std::nextafter(t, -INFINITY) : t) : ((double)t < th[w] ? std::nextafter(t, INFINITY) : t);
+                    k.slotBit[slot[w]] = 1u << idx;
+                    k.nSlotWalls = idx + 1;
+                }
+                wallGeom.push_back(which[w]);
+            }
+    for (int a = 0; a < 3; ++a) {       // rounded outwards
+        k.outerLo[a] = std::nextafter((float)lo[a], -INFINITY);
+        k.outerHi[a] = std::nextafter((float)hi[a], INFINITY);
+    }
+}
+
 // n / d for every n < 2^30 as (n * magic) >> shift: with s = ceil(log2 d), shift = 30 + s and magic = ceil(2^shift / d)
 // (< 2^31) the error e = magic * d - 2^shift is below d <= 2^s, so n * e < 2^(30 + s) = 2^shift and the quotient is exact
 // (Granlund-Montgomery); n * magic < 2^61 fits the 64-bit product.  (The camera-ray bounce divides path indices up to
@@ -1107,25 +1182,13 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     // A choice that only steers which tiles skip which tests; results never depend on it.
     std::vector<WallBox> hw(kWallMax);
     {
-        std::vector<std::pair<double, int>> cand;
-        for (int i = 0; i < ngeoms; ++i)
-            if (geoms[i].type == PT_CUBE && !hg[i].binned) cand.emplace_back(-(double)hg[i].boundR, i);
-        std::sort(cand.begin(), cand.end());
-        k.nWalls = 0;
-        double omaxAll = INFINITY;
-        for (size_t c = 0; c < cand.size() && k.nWalls < kWallMax; ++c) {
-            WallBox wb;
-            double om = 0;
-            const double b = wall_box(geoms[cand[c].second], wb, &om);
-            if (b < 0) continue;
-            omaxAll = std::min(omaxAll, om);
-            hw[k.nWalls] = wb;
-            hg[cand[c].second].flags |= (k.nWalls + 1) << 2;
-            hg[cand[c].second].cullFlags |= (k.nWalls + 1) << 2;
-            ++k.nWalls;
+        std::vector<int> wallGeom;
+        choose_walls(geoms, ngeoms, hg, k, hw, wallGeom);
+        for (int w = 0; w < k.nWalls; ++w) {
+            hg[wallGeom[w]].flags |= (w + 1) << 2;
+            hg[wallGeom[w]].cullFlags |= (w + 1) << 2;
         }
-        if (const char *e = getenv("PT_AMD_NO_WALLS")) { if (atoi(e)) { for (int i = 0; i < ngeoms; ++i) { hg[i].flags &= 3; hg[i].cullFlags &= 3; } k.nWalls = 0; } }   // experiments only
-        k.wallOMax = k.nWalls > 0 ? (float)omaxAll : 0.0f;     // the margin must hold for every wall
+        if (const char *e = getenv("PT_AMD_NO_WALLS")) { if (atoi(e)) { for (int i = 0; i < ngeoms; ++i) { hg[i].flags &= 3; hg[i].cullFlags &= 3; } k.nWalls = 0; k.wallOMax = 0.0f; k.nSlotWalls = 0; } }   // experiments only
         k.allClassified = k.nWalls > 0 ? 1 : 0;
         for (int i = 0; i < ngeoms; ++i)
             if (!hg[i].binned && (hg[i].flags & 28) == 0) k.allClassified = 0;
@@ -1860,6 +1923,49 @@ int pt_test_camera_cull_sweep(const PtCamera *cam, const PtGeom *geoms, int ngeo
     *hits = h[0];
     *culled = h[1];
     *violations = h[2];
+    return PT_OK;
+}
+
+int pt_test_wall_plane_sweep(const PtGeom *geoms, int ngeoms, uint64_t seed, int64_t rays, int32_t *nplane, uint64_t *certified,
+                             uint64_t *violations, uint64_t *single) {
+    NEED_GPU();
+    if (!geoms || ngeoms < 1 || !nplane || !certified || !violations || !single || rays < 0) return fail(PT_ERR_INVALID, "pt_test_wall_plane_sweep: bad argument");
+    // the walls exactly as pt_init chooses and numbers them (no primitive of the set is binned here)
+    std::vector<GeomDev> hg(ngeoms);
+    for (int i = 0; i < ngeoms; ++i) {
+        if (geoms[i].type != PT_CUBE) return fail(PT_ERR_INVALID, "pt_test_wall_plane_sweep: cubes only");
+        pack_geom(geoms[i], hg[i]);
+    }
+    KParams k;
+    memset(&k, 0, sizeof k);
+    std::vector<WallBox> hw(kWallMax);
+    std::vector<int> wallGeom;
+    choose_walls(geoms, ngeoms, hg, k, hw, wallGeom);
+    *nplane = k.nSlotWalls;
+    *certified = *violations = *single = 0;
+    if (k.nWalls < 1 || k.nSlotWalls < 1) return PT_OK;
+    std::vector<GeomDev> wg(k.nWalls);
+    for (int w = 0; w < k.nWalls; ++w) wg[w] = hg[wallGeom[w]];
+    DevBuf<GeomDev> dg;
+    DevBuf<WallBox> dw;
+    DevBuf<unsigned long long> cnt;
+    UP(dg, wg.data(), k.nWalls);
+    UP(dw, hw.data(), k.nWalls);
+    int rc = cnt.alloc(3);
+    if (rc) return rc;
+    HIPCHECK(hipMemset(cnt.p, 0, 24));
+    const int per_thread = 256, threads = 256;
+    long long blocks = (rays + (long long)per_thread * threads - 1) / ((long long)per_thread * threads);
+    if (blocks < 1) blocks = 1;
+    if (blocks > (1 << 20)) blocks = 1 << 20;
+    hipLaunchKernelGGL(k_sweep_wall_planes, dim3((unsigned)blocks), dim3(threads), 0, 0, k, dg.p, dw.p, (unsigned long long)seed, per_thread,
+                       cnt.p, cnt.p + 1, cnt.p + 2);
+    HIPCHECK(hipDeviceSynchronize());
+    unsigned long long h[3] = {0, 0, 0};
+    HIPCHECK(hipMemcpy(h, cnt.p, 24, hipMemcpyDeviceToHost));
+    *certified = h[0];
+    *violations = h[1];
+    *single = h[2];
     return PT_OK;
 }
 

@@ -529,6 +529,47 @@ __device__ __forceinline__ bool wallCertainMiss(const WB &w, F3 o, F3 inv) {
     return (tmin - tmax > 1e-5f * (__builtin_fabsf(tmin) + __builtin_fabsf(tmax))) | (tmax < 0.0f);
 }
 
+// Certain miss of walls by ONE plane each, for ~5 instructions per wall instead of ~27.  Every wall's inflated box lies inside the
+// box `outer` around all of them, a convex set: the part of the ray that can touch any wall is the SEGMENT from its origin to the
+// point where it leaves `outer`.  A segment whose two end points lie strictly on the outer side of one plane of a wall's box -- the
+// plane that faces the scene's interior, chosen on the host -- lies on that side as a whole: it misses the box.  Like
+// wallCertainMiss this is a sufficient condition for the reference's own miss with the inflation (4e-5 of the scene) as its
+// margin: the exit point carries a relative error below 4e-7 of (|origin| + the diagonal of `outer`), the thresholds are moved
+// towards the interior by five times that (pt_init), and origins beyond KParams::wallOMax get no certificate (caller).  A
+// scattered ray starts 1e-3 off the surface it leaves, beyond that wall's plane: the wall it leaves is certified with the others,
+// and what remains is, nearly always, exactly the one wall it will hit.
+// The planes sit in six SLOTS -- x low side, x high side, y low, y high, z low, z high; at most one wall each (KParams::slotTh,
+// slotBit: the wall's bit, 0 for an empty slot) -- so the test is straight-line code: one scalar load, no loop, no branch.
+// Returns the slot walls it does NOT certify (their bits); all of them when the ray does not leave `outer` at a positive finite
+// parameter (origin outside, NaN).
+// (tests/test_gpu_parity.py::test_wall_planes_never_reject_a_hit: 2^28 rays from the surfaces, the interior and the corners.)
+template <typename KP>
+__device__ __forceinline__ uint32_t wallPlanesPossible(const KP &prm, F3 o, F3 d, F3 inv) {
+    // the eighteen wave-uniform constants, fetched together and pinned to scalar registers by ONE empty asm (which also keeps a
+    // select of two of them from becoming a vector load from a selected address)
+    float lo0 = prm.outerLo[0], lo1 = prm.outerLo[1], lo2 = prm.outerLo[2], hi0 = prm.outerHi[0], hi1 = prm.outerHi[1], hi2 = prm.outerHi[2];
+    float th0 = prm.slotTh[0], th1 = prm.slotTh[1], th2 = prm.slotTh[2], th3 = prm.slotTh[3], th4 = prm.slotTh[4], th5 = prm.slotTh[5];
+    uint32_t b0 = prm.slotBit[0], b1 = prm.slotBit[1], b2 = prm.slotBit[2], b3 = prm.slotBit[3], b4 = prm.slotBit[4], b5 = prm.slotBit[5];
+    asm volatile("" : "+s"(lo0), "+s"(lo1), "+s"(lo2), "+s"(hi0), "+s"(hi1), "+s"(hi2), "+s"(th0), "+s"(th1), "+s"(th2), "+s"(th3), "+s"(th4),
+                 "+s"(th5), "+s"(b0), "+s"(b1), "+s"(b2), "+s"(b3), "+s"(b4), "+s"(b5));
+    // (the bound a component leaves through follows the sign of ITS reciprocal: a zero component gives +-inf, i.e. never)
+    const float bx = inv.x > 0.0f ? hi0 : lo0;
+    const float by = inv.y > 0.0f ? hi1 : lo1;
+    const float bz = inv.z > 0.0f ? hi2 : lo2;
+    const float tOut = __builtin_fminf(__builtin_fminf((bx - o.x) * inv.x, (by - o.y) * inv.y), (bz - o.z) * inv.z);
+    const F3 e = f3(__builtin_fmaf(d.x, tOut, o.x), __builtin_fmaf(d.y, tOut, o.y), __builtin_fmaf(d.z, tOut, o.z));
+    const bool leaves = (tOut > 0.0f) & (tOut < 3.0e38f);          // (NaN fails both)
+    uint32_t possible = 0u;
+    // slot: the wall lies on the low side of the axis -- certified when both end points are above its plane -- or on the high side
+    possible |= ((o.x > th0) & (e.x > th0) & leaves) ? 0u : b0;
+    possible |= ((o.x < th1) & (e.x < th1) & leaves) ? 0u : b1;
+    possible |= ((o.y > th2) & (e.y > th2) & leaves) ? 0u : b2;
+    possible |= ((o.y < th3) & (e.y < th3) & leaves) ? 0u : b3;
+    possible |= ((o.z > th4) & (e.z > th4) & leaves) ? 0u : b4;
+    possible |= ((o.z < th5) & (e.z < th5) & leaves) ? 0u : b5;
+    return possible;
+}
+
 // src/intersections.h:101-143 (pow(radius, 2) == 0.25f in the float overload nvcc selects).
 // `inv`, `invZ`, `xf`: rows 0-2 of inverseTransform (and its w = 0 products, GeomDev::invZ) / transform as mulMV expects them -- SGPR operands when the sphere is
 // wave-uniform (GeomDev through the scalar path), registers when every lane tests its own sphere (k_bounce<., MANY>).

@@ -213,6 +213,80 @@ __global__ void k_sweep_camera_cull(KParams prm, const GeomDev *geoms, const int
     if (nv) atomicAdd(violations, (unsigned long long)nv);
 }
 
+// wallPlanesPossible soundness sweep: pseudo-random rays against the walls of a scene as pt_init numbers them (`wallGeoms[w]` = the
+// cube that is wall w).  Origins as the render kernel meets them and worse: on a wall's inner face pushed 1e-3 (or 0 .. 4e-3) into
+// the room, in the corners where two and three walls meet, anywhere inside the box around the walls, outside it; directions random,
+// aimed at the shell of a wall's box (grazes), axis-parallel, with exact zeros.  A wall the planes certify as missed that the full
+// test hits is a VIOLATION.  `certified` counts (ray, wall) certificates, `single` the rays left with exactly one possible wall.
+__global__ void k_sweep_wall_planes(KParams prm, const GeomDev *wallGeoms, const WallBox *walls, unsigned long long seed, int per_thread,
+                                    unsigned long long *certified, unsigned long long *violations, unsigned long long *single) {
+    unsigned long long x = seed + (blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ull;
+    unsigned int nc = 0, nv = 0, ns = 0;
+    const int nPlane = prm.nSlotWalls;
+    const F3 olo = f3(prm.outerLo[0], prm.outerLo[1], prm.outerLo[2]), ohi = f3(prm.outerHi[0], prm.outerHi[1], prm.outerHi[2]);
+    const F3 oc = (olo + ohi) * 0.5f, oh = (ohi - olo) * 0.5f;
+    for (int k = 0; k < per_thread; ++k) {
+        float u[12];
+        for (int j = 0; j < 12; ++j) {
+            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+            u[j] = (float)(x >> 40) * (1.0f / 16777216.0f);
+        }
+        const int wi = (int)(u[0] * (float)prm.nWalls) % prm.nWalls;
+        const WallBox W = walls[wi];
+        const F3 wlo = f3(W.lo[0], W.lo[1], W.lo[2]), whi = f3(W.hi[0], W.hi[1], W.hi[2]);
+        const F3 wc = (wlo + whi) * 0.5f, wh = (whi - wlo) * 0.5f;
+        F3 org;
+        if (u[1] < 0.55f) {
+            // on wall wi's box, pulled towards the middle of the room by 0 .. 4e-3 (1e-3 in half of the cases: the scatter offset)
+            org = wc + f3((2 * u[2] - 1) * wh.x, (2 * u[3] - 1) * wh.y, (2 * u[4] - 1) * wh.z);
+            const float off = u[5] < 0.5f ? 1e-3f : u[5] * 8e-3f - 4e-3f;
+            // towards the room's centre along the wall's thinnest axis, from the face on that side
+            const int a = wh.x <= wh.y && wh.x <= wh.z ? 0 : (wh.y <= wh.z ? 1 : 2);
+            const float ca = a == 0 ? oc.x : (a == 1 ? oc.y : oc.z), wa = a == 0 ? wc.x : (a == 1 ? wc.y : wc.z), ha = a == 0 ? wh.x : (a == 1 ? wh.y : wh.z);
+            const float sgn = ca >= wa ? 1.0f : -1.0f;
+            const float pos = wa + sgn * (ha * 0.9999f + off);      // (0.9999: the real face lies inside the inflated box)
+            if (a == 0) org.x = pos; else if (a == 1) org.y = pos; else org.z = pos;
+            if (u[6] < 0.3f) {                                      // ... into a corner: clamp another coordinate to the room's border
+                const float m = u[6] < 0.15f ? 1.0f : -1.0f;
+                if (a != 0 && u[7] < 0.5f) org.x = oc.x + m * oh.x * (1.0f - 2e-3f * u[8]);
+                else if (a != 1) org.y = oc.y + m * oh.y * (1.0f - 2e-3f * u[8]);
+                else org.z = oc.z + m * oh.z * (1.0f - 2e-3f * u[8]);
+            }
+        } else if (u[1] < 0.85f) {
+            org = oc + f3((2 * u[2] - 1) * oh.x, (2 * u[3] - 1) * oh.y, (2 * u[4] - 1) * oh.z);
+        } else {
+            org = oc + f3((2 * u[2] - 1) * oh.x, (2 * u[3] - 1) * oh.y, (2 * u[4] - 1) * oh.z) * (1.0f + 3.0f * u[5]);
+        }
+        F3 dir;
+        if (u[9] < 0.5f) {
+            dir = normalize(f3(u[10] - 0.5f, u[11] - 0.5f, u[8] - 0.5f));
+        } else {                                                    // aimed at the shell of a wall's box: hits, grazes, near misses
+            const int wj = (int)(u[8] * (float)prm.nWalls) % prm.nWalls;
+            const WallBox V = walls[wj];
+            const F3 vc = f3(V.lo[0] + V.hi[0], V.lo[1] + V.hi[1], V.lo[2] + V.hi[2]) * 0.5f, vh = f3(V.hi[0] - V.lo[0], V.hi[1] - V.lo[1], V.hi[2] - V.lo[2]) * 0.5f;
+            const float shell = 0.95f + 0.1f * u[7];
+            dir = normalize(vc + f3((2 * u[10] - 1) * vh.x, (2 * u[11] - 1) * vh.y, (2 * u[6] - 1) * vh.z) * shell - org);
+        }
+        if (u[9] > 0.92f) dir = f3(u[9] < 0.95f ? 1.0f : 0.0f, (u[9] >= 0.95f && u[9] < 0.98f) ? -1.0f : 0.0f, u[9] >= 0.98f ? 1.0f : 0.0f);   // axis-parallel
+        else if (u[9] > 0.85f) dir = normalize(f3(dir.x, 0.0f, dir.z));                                      // an exact zero
+        const float l1 = (__builtin_fabsf(org.x) + __builtin_fabsf(org.y)) + __builtin_fabsf(org.z);
+        if (!(l1 <= prm.wallOMax)) continue;
+        const F3 inv = f3(__builtin_amdgcn_rcpf(dir.x), __builtin_amdgcn_rcpf(dir.y), __builtin_amdgcn_rcpf(dir.z));
+        const uint32_t possible = wallPlanesPossible(prm, org, dir, inv);
+        for (int w = 0; w < nPlane; ++w)
+            if (!((possible >> w) & 1u)) {
+                ++nc;
+                F3 P, N;
+                bool o;
+                if (boxIntersectionTest<false>(wallGeoms[w], org, dir, P, N, o) != -1.0f) ++nv;
+            }
+        ns += __popc(possible) == 1 ? 1u : 0u;
+    }
+    if (nc) atomicAdd(certified, (unsigned long long)nc);
+    if (nv) atomicAdd(violations, (unsigned long long)nv);
+    if (ns) atomicAdd(single, (unsigned long long)ns);
+}
+
 // slabQuotients vs the compiler's correctly rounded division; counts mismatching lanes
 __global__ void k_test_slab_quotients(const float *o, const float *d, int n, float *t1, float *t2, float *r1, float *r2) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -89,6 +89,13 @@ struct KParams {
     int   nWalls;
     int   allClassified;  // every primitive is a wall or binned: a survivor that certainly misses all of them is a miss, now
     float wallOMax;       // certificates are only issued for ray origins with |x| + |y| + |z| <= wallOMax
+    // Walls 0 .. nSlotWalls - 1 are certified by ONE plane each (ptd::wallPlanesPossible): six slots -- the plane is x = th with the wall
+    // on the low side, on the high side, then y, then z -- hold at most one wall each; the walls behind them (none in a box-shaped
+    // room) keep the slab certificate against their inflated box (ptd::wallCertainMiss).
+    int   nSlotWalls;
+    float slotTh[6];          // the slot's plane, moved towards the interior by the slack that covers the exit point's rounding
+    uint32_t slotBit[6];      // 1 << (the slot's wall), or 0: no wall in this slot
+    float outerLo[3], outerHi[3];   // box around all the walls' inflated boxes
     // ---- README extras, all off by default
     float lensRadius, focalDistance;   // thin lens (depth of field, README.md:100-101); radius 0 = pinhole
     float viewN[3];                    // normalize(view)
@@ -1026,8 +1033,9 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
                             if (l1 <= A->prm.wallOMax) {          // (NaN fails)
                                 const F3 inv = f3(__builtin_amdgcn_rcpf(ndir.x), __builtin_amdgcn_rcpf(ndir.y), __builtin_amdgcn_rcpf(ndir.z));
                                 const WallPtr walls = (WallPtr)(A->walls);
-                                uint32_t possible = 0u;
-                                for (int w = 0; w < nWalls; ++w) { probe(13);
+                                probe(13);
+                                uint32_t possible = wallPlanesPossible(A->prm, norg, ndir, inv);     // walls 0 .. nSlotWalls - 1
+                                for (int w = A->prm.nSlotWalls; w < nWalls; ++w) { probe(13);
                                     possible |= wallCertainMiss(*(launder(walls) + w), norg, inv) ? 0u : (1u << w); }
                                 const int cnt = __popc(possible);
                                 wallSel = cnt == 1 ? (uint32_t)(__ffs((int)possible) - 1) : (cnt == 0 ? 7u : 6u);

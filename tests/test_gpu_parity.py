@@ -175,6 +175,39 @@ def test_wall_boxes_never_reject_a_hit(gpu, oracle):
     assert culled > (1 << 28) // 16            # the certificate actually fires (most sweep rays are aimed at the cube)
 
 
+def test_wall_planes_never_reject_a_hit(gpu, oracle):
+    # round 3: most walls are certified by ONE plane of their inflated box and the point where the ray leaves the box around all the
+    # walls (ptd::wallPlanesPossible) instead of the slab test -- same statement (the exact ray misses the inflated box), a fifth of
+    # the instructions.  Swept over rooms as pt_init would number their walls: Cornell open and closed, a rotated and a tilted room,
+    # walls that overlap in the corners, a slab across the middle (which gets no plane), rooms far off the origin, a huge one
+    S = oracle.make_geom
+    cornell = [S(1, 0, (0, 0, 0), (0, 0, 0), (10, .01, 10)), S(1, 0, (0, 10, 0), (0, 0, 90), (.01, 10, 10)), S(1, 0, (0, 5, -5), (0, 90, 0), (.01, 10, 10)),
+               S(1, 0, (-5, 5, 0), (0, 0, 0), (.01, 10, 10)), S(1, 0, (5, 5, 0), (0, 0, 0), (.01, 10, 10))]
+    rooms = {
+        "cornell": cornell,
+        "cornell closed": cornell + [S(1, 0, (0, 5, 5), (0, 90, 0), (.01, 10, 10))],
+        "thick walls": [S(1, 0, (0, -1, 0), (0, 0, 0), (12, 2, 12)), S(1, 0, (0, 9, 0), (0, 0, 0), (12, 2, 12)), S(1, 0, (-6, 4, 0), (0, 0, 0), (2, 12, 12)),
+                        S(1, 0, (6, 4, 0), (0, 0, 0), (2, 12, 12)), S(1, 0, (0, 4, -6), (0, 0, 0), (12, 12, 2))],
+        "tilted": [S(1, 0, (0, 0, 0), (3, 0, -2), (10, .05, 10)), S(1, 0, (0, 8, 0), (-4, 10, 0), (10, .05, 10)), S(1, 0, (-5, 4, 0), (0, 5, 88), (8, .05, 10)),
+                   S(1, 0, (5, 4, 0), (7, 0, 93), (8, .05, 10)), S(1, 0, (0, 4, -5), (85, 3, 0), (10, .05, 8))],
+        "slab across": cornell + [S(1, 0, (0, 5, 0), (0, 0, 0), (10, .5, 3))],
+        "far away": [S(1, 0, (100, 50, -30), (0, 0, 0), (10, .01, 10)), S(1, 0, (100, 60, -30), (0, 0, 0), (10, .01, 10)),
+                     S(1, 0, (95, 55, -30), (0, 0, 90), (10, .01, 10)), S(1, 0, (105, 55, -30), (0, 0, 90), (10, .01, 10))],
+        "huge": [S(1, 0, (0, 0, 0), (0, 0, 0), (400, 1, 400)), S(1, 0, (0, 300, 0), (0, 0, 0), (400, 1, 400)), S(1, 0, (-200, 150, 0), (0, 0, 0), (1, 300, 400)),
+                 S(1, 0, (200, 150, 0), (0, 0, 0), (1, 300, 400))],
+    }
+    total = 0
+    for name, geoms in rooms.items():
+        g = np.concatenate(geoms).view(gpu.GEOM_DTYPE)
+        nplane, certified, bad, single = gpu.test_wall_plane_sweep(g, 977, 1 << 25)
+        print("%-15s walls with a plane %d of %d, certificates %d, rays with one possible wall %d, violations %d" % (name, nplane, len(g), certified, single, bad))
+        assert bad == 0, name
+        assert nplane == (len(g) - 1 if name == "slab across" else len(g)), name
+        assert certified > (1 << 25) and single > (1 << 25) // 8, name          # it certifies, and mostly down to one wall
+        total += certified
+    assert total > 1 << 28
+
+
 def test_reflect_refract_bit_exact(gpu):
     z = np.load(os.path.join(GOLD, "glm_ops.npz"))
     r1, r2 = gpu.test_reflect_refract(z["An"], z["Bn"], z["eta"])
