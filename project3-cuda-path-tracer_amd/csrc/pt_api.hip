@@ -693,6 +693,10 @@ int launch_bounce(Slot &sl, int iter, int batch, int depth, bool lastBounce, flo
     ba.iter = iter; ba.batch = batch; ba.depth = depth; ba.lastBounce = lastBounce ? 1 : 0; ba.parity = sl.parity;
     ba.genIn = genIn; ba.genOut = genOut;
     ba.in = in; ba.out = out;
+    ba.tile.inBase = in.base; ba.tile.inList = in.list; ba.tile.inCap = in.cap;
+    ba.tile.genIn = genIn; ba.tile.poolChunks = (uint32_t)S.prm.poolChunks; ba.tile.chunkShift = (uint32_t)S.prm.chunkShift;
+    ba.tile.skipNonCandidates = (lastBounce && S.prm.emittersBinned) ? 1u : 0u;
+    ba.tile.pad = 0u;
     ba.ctrl = sl.ctrl; ba.ggeoms = S.dgeoms; ba.gmats = S.dmats; ba.contrib = contrib; ba.hitMask = sl.hitMask;
     ba.sphCull = S.dSphCull; ba.classIdx = S.dClassIdx;
     ba.rowOff = S.dRowOff; ba.rowIdx = S.dRowIdx;
@@ -1176,6 +1180,15 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
             hg[cand[c].second].cullFlags |= 2;
         }
     }
+    for (int b = 0; b < kBinMax; ++b) {                      // (KParams::binCull: the binned primitives' culling groups, inline)
+        for (int q = 0; q < 8; ++q) k.binCull[b][q] = 0.0f;
+        k.binCull[b][3] = -INFINITY;                          // beyond nBinned: certified for everybody
+        if (b < k.nBinned) {
+            const GeomDev &G = hg[k.binGeom[b]];
+            k.binCull[b][0] = G.centre[0]; k.binCull[b][1] = G.centre[1]; k.binCull[b][2] = G.centre[2];
+            k.binCull[b][3] = G.cullR2; k.binCull[b][4] = G.cullK;
+        }
+    }
     // Walls: the large cubes -- not binned, finite -- at most kWallMax of them, the largest first.  Survivors are classed by
     // the one wall they can still hit (ptd::wallCertainMiss against the inflated world boxes computed here), so a tile of
     // the next bounce tests one wall instead of all of them, and a survivor that can hit nothing at all ends at once.
@@ -1553,9 +1566,11 @@ int pt_debug_trace_paths(int iter, int bounces, float *origin3, float *dir3, flo
     *count = (int32_t)n;
     if (n == 0) return PT_OK;
     const uint32_t chunkPaths = 1u << S.prm.chunkShift;
+    // the pool's three arrays (A: 16 B, B: 16 B, C: 12 B per path), chunk by chunk, into the eleven columns
     std::vector<float> cols[kNumArrays];
-    for (int k = 0; k < kNumArrays; ++k) {
-        cols[k].resize(n);
+    for (int k = 0; k < kNumArrays; ++k) cols[k].resize(n);
+    {
+        std::vector<float> bufA((size_t)chunkPaths * 4), bufB((size_t)chunkPaths * 4), bufC((size_t)chunkPaths * 3);
         size_t off = 0;
         for (int sg = 0; sg < kSeg; ++sg)
             for (uint32_t done = 0, j = 0; done < segn[sg]; done += chunkPaths, ++j) {
@@ -1564,7 +1579,15 @@ int pt_debug_trace_paths(int iter, int bounces, float *origin3, float *dir3, flo
                 const uint32_t c = j == 0 ? 1u + (uint32_t)sg : (uint32_t)e;
                 if (c == 0 || c >= (uint32_t)S.poolChunks || (j != 0 && (uint32_t)(e >> 32) != gen))
                     return fail(PT_ERR_DEVICE, "pt_debug_trace_paths: corrupt chunk list");
-                HIPCHECK(hipMemcpy(cols[k].data() + off, pb.a(k) + ((size_t)c << S.prm.chunkShift), (size_t)m * 4, hipMemcpyDeviceToHost));
+                const size_t first = (size_t)c << S.prm.chunkShift;
+                HIPCHECK(hipMemcpy(bufA.data(), pb.arrA(first), (size_t)m * 16, hipMemcpyDeviceToHost));
+                HIPCHECK(hipMemcpy(bufB.data(), pb.arrB(first), (size_t)m * 16, hipMemcpyDeviceToHost));
+                HIPCHECK(hipMemcpy(bufC.data(), pb.arrC(first), (size_t)m * 12, hipMemcpyDeviceToHost));
+                for (uint32_t i = 0; i < m; ++i) {
+                    const float *a = &bufA[4 * (size_t)i], *b = &bufB[4 * (size_t)i], *cc = &bufC[3 * (size_t)i];
+                    const float v[kNumArrays] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3], cc[0], cc[1], cc[2]};
+                    for (int k = 0; k < kNumArrays; ++k) cols[k][off + i] = v[k];
+                }
                 off += m;
             }
     }
@@ -2020,7 +2043,20 @@ int pt_test_unscaled_sqrt_sweep(uint64_t mismatches[4]) {
     return PT_OK;
 }
 
-#ifdef PT_PROBE
+#ifdef PT_PROBE_TIMELINE
+// instrumented build only (make timeline): reads and clears the per-phase cycle sums of pt_device.h
+extern "C" int pt_probe_timeline(uint64_t out[128]) {      // [0, 64) cycles (later bounces, then + 32 the camera-ray bounce), [64, 128) intervals
+    NEED_GPU();
+    unsigned long long h[128], z[64] = {0};
+    HIPCHECK(hipDeviceSynchronize());
+    HIPCHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(ptd::g_phaseT), 64 * sizeof(unsigned long long)));
+    HIPCHECK(hipMemcpyFromSymbol(h + 64, HIP_SYMBOL(ptd::g_phaseN), 64 * sizeof(unsigned long long)));
+    HIPCHECK(hipMemcpyToSymbol(HIP_SYMBOL(ptd::g_phaseT), z, sizeof z));
+    HIPCHECK(hipMemcpyToSymbol(HIP_SYMBOL(ptd::g_phaseN), z, sizeof z));
+    for (int i = 0; i < 128; ++i) out[i] = h[i];
+    return PT_OK;
+}
+#elif defined(PT_PROBE)
 // instrumented build only (make probe): the residency census of k_bounce -- out[k] = number of CUs on which at most k
 // workgroups of it were ever resident together (k = 0..15); cleared by the call
 extern "C" int pt_probe_census(uint32_t out[16]) {

@@ -15,7 +15,45 @@ namespace ptd {
 
 // Instrumentation for profiles/probe_phases.py (built with -DPT_PROBE only): wave-level executions and active lanes
 // of the phases of the two intersection tests.  g_probe[2k] += 1 per wave that enters phase k, g_probe[2k+1] += lanes.
-#ifdef PT_PROBE
+#ifdef PT_PROBE_TIMELINE
+// A timeline (MI355X_MICROARCH.md: in-kernel stamps, diagnostic build only, make timeline; nothing else is instrumented in it): the shader cycles that wave 0 of every workgroup spends
+// between two consecutive marks, summed per phase = the mark the interval starts at (g_phaseT[k], intervals counted in g_phaseN[k]).
+// The stamps cost ~10 % and go nowhere but these two arrays.
+// Marks 30 / 31 open a launch (later bounces / the camera-ray bounce, whose sums are kept apart: index + 32).
+__device__ unsigned long long g_phaseT[64], g_phaseN[64];
+// (sums are kept in LDS and flushed once, at mark 29 = the end of the kernel: global atomics at every mark would queue the wave's own
+// loads and stores behind them and inflate exactly the phases that touch memory)
+__device__ __forceinline__ void phaseStamp(int k) {
+    __shared__ unsigned long long s_phaseLast[3];            // [0] the last stamp, [1] the mark it was taken at, [2] 32 in the camera-ray launch
+    __shared__ unsigned long long s_phaseT[32];
+    __shared__ unsigned int s_phaseN[32];
+    if (threadIdx.x == 0) {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        if (k >= 30) {
+            s_phaseLast[2] = k == 31 ? 32ull : 0ull;
+            for (int q = 0; q < 32; ++q) { s_phaseT[q] = 0ull; s_phaseN[q] = 0u; }
+            k = 30;
+        } else {
+            const unsigned int idx = (unsigned int)(s_phaseLast[1] & 31ull);
+            s_phaseT[idx] += t - s_phaseLast[0];
+            s_phaseN[idx] += 1u;
+            if (k == 29)
+                for (int q = 0; q < 32; ++q)
+                    if (s_phaseN[q]) {
+                        atomicAdd(&g_phaseT[q + s_phaseLast[2]], s_phaseT[q]);
+                        atomicAdd(&g_phaseN[q + s_phaseLast[2]], (unsigned long long)s_phaseN[q]);
+                    }
+        }
+        s_phaseLast[0] = __builtin_amdgcn_s_memtime();
+        s_phaseLast[1] = (unsigned long long)k;
+    }
+}
+__device__ __forceinline__ void probe(int k) {
+    if (k >= 9) phaseStamp(k);        // (the tile-level marks only: the marks inside the intersection tests would dominate what they measure)
+}
+__device__ __forceinline__ void censusEnter() {}
+__device__ __forceinline__ void censusLeave() {}
+#elif defined(PT_PROBE)
 __device__ unsigned long long g_probe[32];
 // residency census (MI355X_MICROARCH.md: "verify with a census kernel"): workgroups of k_bounce resident on each CU right
 // now and the most there ever were, keyed by (XCC, SE, SH, CU) from the hardware id registers
@@ -37,7 +75,7 @@ __device__ __forceinline__ void censusLeave() {
     if (threadIdx.x == 0) atomicSub(&g_censusNow[censusKey()], 1u);
 }
 __device__ __forceinline__ void probe(int k) {
-    if (k >= 14) return;      // (14-20 are marks of the static listing only, PT_MARK: g_probe holds counters 0-13)
+    if (k >= 14) return;      // (14-23 are marks of the static listing and of the timeline: g_probe holds counters 0-13)
     const unsigned long long m = __ballot(1);
     if (__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) == 0) {
         atomicAdd(&g_probe[2 * k], 1ull);
@@ -751,14 +789,20 @@ __device__ __forceinline__ F3 hitNormal(const GeomDev &g, F3 nsrc, bool outside)
 // (12 floats), the material index, the type and the cube's six face frames.  Lanes of a wave index different geoms, so
 // the row stride is 76 words: consecutive rows start 12 banks apart and 8 different rows are conflict-free
 // (64-B rows collided two ways: SQ_LDS_BANK_CONFLICT 20 % of LDS cycles).
+// It opens with what EVERY hit needs -- the primitive's type and the hot fields of ITS material, copied in -- as two 16-byte reads
+// issued together: one LDS round trip where the chain hit -> record -> material index -> material table took two (round 3: a
+// wave's dependent waits on the scalar cache and on LDS, not its instruction count, turned out to bound the later bounces; the
+// fields of the rarer branches -- specular colour, index of refraction, Schlick's r0, the lobe exponent -- stay in the table).
 struct GeomHitDev {
-    float nm[12];
-    int   material;
     int   type;
+    float emittance, hasReflective, hasRefractive;
+    float color[3];
+    int   material;
+    float nm[12];
     float cubeFrame[54];
-    int   pad[8];
+    int   pad[2];
 };
-static_assert(sizeof(GeomHitDev) == 304, "GeomHitDev is 19 x 16 B");
+static_assert(sizeof(GeomHitDev) == 304 && offsetof(GeomHitDev, nm) == 32, "GeomHitDev is 19 x 16 B, its hot header 2 x 16 B");
 // Sphere-heavy scenes: 304 B for each of seventy primitives (21 KB, together with the lanes' sphere lists and matrices 33 KB of
 // LDS per workgroup) admitted only FOUR workgroups per CU where the registers allow seven (residency census,
 // profiles/census.py).  There the record is 68 B -- 17 words: an odd stride, so lanes that index different primitives do not

@@ -11,13 +11,16 @@
 namespace ptk {
 using namespace ptd;
 
-constexpr int kNumArrays = 11;       // SoA PathSegment: origin3, dir3, throughput3, pixelIndex, remainingBounces
+constexpr int kNumArrays = 11;       // PathSegment: origin3, dir3, throughput3, pixelIndex, remainingBounces = 11 dwords = 44 bytes per path
 constexpr int kMaxDepthSlots = PT_MAX_DEPTH + 2;
 
 // ---- device control block ------------------------------------------------------------------------
 constexpr int kOct = 8;              // direction octants: paths are binned by the signs of their new direction ...
 constexpr int kCls = 2 * kOct;       // ... and by "may hit a small primitive" (bit 3): 16 classes
-constexpr int kSub = 4;              // append-counter shards per class (workgroup blockIdx % kSub)
+#ifndef PT_KSUB
+#define PT_KSUB 4
+#endif
+constexpr int kSub = PT_KSUB;        // append-counter shards per class (workgroup blockIdx % kSub; PT_KSUB: shard-count experiments only)
 constexpr int kSeg = kCls * kSub;    // path buffers are split into kSeg segments with one append counter each
 constexpr int kBinMax = 4;           // at most this many small primitives take part in the binning
 constexpr int kEmitMax = 8;          // emissive primitives the direct-lighting bounce chooses from
@@ -83,6 +86,10 @@ struct KParams {
     int   emittersBinned; // every primitive with an emissive material is one of binGeom[]
     int   nBinned;      // 1..kBinMax small primitives (spheres, small cubes): survivors are binned by whether they can
     int   binGeom[kBinMax];   // hit one of them (certainMiss of each); 0: off, every path counts as a candidate
+    // ... and their culling data (GeomDev::centre, cullR2, cullK) once more, here: the scatter's two bounding-ball certificates then
+    // cost ONE scalar load from the argument block instead of a chain of three (index -> primitive -> its culling group) each.
+    // Rows beyond nBinned hold cullR2 = -inf: a ball nobody can miss being certified for.
+    float binCull[kBinMax][8];
     // ---- walls: the scene's large cubes (non-binned, at most kWallMax).  With walls the three low class bits of a survivor
     // are not its direction octant but WHICH wall it can still hit: 0..5 = that wall only (every other wall certified
     // missed by wallCertainMiss), 6 = several or uncertified, 7 = none
@@ -111,9 +118,12 @@ struct KParams {
     float emitRho2[kEmitMax];          // |scale|^2 / 4 of each: squared radius of its bounding ball
 };
 
-// SoA PathSegment pool: 11 arrays of `cap` = poolChunks << chunkShift 4-byte elements, array k at base + k*cap
-// (0-2 origin, 3-5 direction, 6-8 throughput, 9 pixelIndex, 10 remainingBounces | batch index << 8); chunk c owns
-// [c << chunkShift, (c + 1) << chunkShift) of every array.
+// SoA PathSegment pool: THREE arrays of `cap` = poolChunks << chunkShift elements -- A: float4 {origin, direction.x} at base,
+// B: float4 {direction.yz, throughput.xy} at base + 16 cap bytes, C: three dwords {throughput.z, pixelIndex, remainingBounces | batch
+// index << 8} at base + 32 cap bytes -- the same 44 bytes per path as eleven dword arrays (rounds 1-2), moved by 3 + 3 vector-memory
+// instructions per path and bounce instead of 11 + 11: round 3's in-kernel timeline showed a fifth of a later tile's time going into
+// ISSUING those instructions (64 lanes x 4 B each), not into waiting for their data.  A wave's access is 1 KiB (768 B) contiguous.
+// Chunk c owns [c << chunkShift, (c + 1) << chunkShift) of every array.
 // list[s * poolChunks + j] = {generation : 32 | chunk : 32} of the j-th chunk (j >= 1) of segment s of the queue the pool
 // holds; the generation is the serial number of the launch that filled the queue, so entries of earlier launches read as
 // "not there yet" without any clearing.  The 0-th chunk of segment s is always chunk 1 + s.
@@ -121,8 +131,12 @@ struct PathPool {
     float              *base;
     unsigned long long *list;
     uint32_t            cap;
-    __host__ __device__ __forceinline__ float *a(int k) const { return base + (size_t)k * cap; }
+    // byte address of element `slot` of array A / B / C
+    __host__ __device__ __forceinline__ char *arrA(size_t slot) const { return reinterpret_cast<char *>(base) + 16 * slot; }
+    __host__ __device__ __forceinline__ char *arrB(size_t slot) const { return reinterpret_cast<char *>(base) + 16 * (size_t)cap + 16 * slot; }
+    __host__ __device__ __forceinline__ char *arrC(size_t slot) const { return reinterpret_cast<char *>(base) + 32 * (size_t)cap + 12 * slot; }
 };
+struct PathC { float cz; int pix, packed; };       // array C's element (12 bytes: one global_load / store_dwordx3)
 
 // element `slot` of an array whose (wave-uniform) base pointer is `arr`: uniform 64-bit base + 32-bit byte offset, which
 // is the addressing form of global_load/store with an SGPR base (no 64-bit vector arithmetic per access)
@@ -322,7 +336,20 @@ typedef int int16v __attribute__((ext_vector_type(16)));
 __host__ __device__ constexpr size_t manyHitBytes(int ngeoms) { return ((size_t)ngeoms * sizeof(GeomHitSmall) + 15) / 16 * 16; }
 __host__ __device__ constexpr size_t manyFramePad(int ncubes) { return (16 - ((size_t)ncubes * 54 * sizeof(float)) % 16) % 16; }
 
+// What the set-up of a later bounce's tile reads from the argument block, side by side at its very start: ONE scalar load (the
+// fields used to be fetched where they were needed -- five scalar-cache round trips one after the other on the way to a tile's loads).
+struct TileArgs {
+    const float *inBase;                // PathPool `in`: base, chunk lists, capacity
+    const unsigned long long *inList;
+    uint32_t inCap;
+    uint32_t genIn;
+    uint32_t poolChunks, chunkShift;
+    uint32_t skipNonCandidates;         // lastBounce && emittersBinned: tiles whose class says "no binned primitive" have nothing to add
+    uint32_t pad;
+};
+static_assert(sizeof(TileArgs) == 40, "ten dwords");
 struct BounceArgs {
+    TileArgs tile;                      // (first: offset 0)
     KParams prm;
     int iter, batch, depth, lastBounce, parity;
     uint32_t genIn, genOut;             // serial numbers of the launches that filled / fill the input / output pool
@@ -381,6 +408,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
     (void)argsByValue;
     const ArgsPtr kargs = (ArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
     censusEnter();                       // (instrumented build only)
+    probe(FIRST ? 31 : 30);              // (prologue; timeline builds: the first stamp of the launch)
     // LDS: the material table and the per-geom hit records (normal matrix, material, type: indexed per lane by
     // the nearest hit), and the compaction scratch.  Geometry itself is wave-uniform in the nearest-hit loop, so it is fetched through the
     // scalar path (s_load into SGPRs, used directly as VALU operands): measured against an LDS-staged copy
@@ -428,16 +456,30 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
             nLive = (uint32_t)A->prm.nLocal * (uint32_t)A->batch;     // `batch` consecutive iterations share one wavefront
             numTiles = (uint32_t)A->prm.nLocalPad / kBlock * (uint32_t)A->batch;   // (tiles lie on padded rows)
         } else {
-            if (threadIdx.x < 64) {          // wave 0: exclusive scan of the kSeg tile counts
-                const uint32_t c = threadIdx.x < kSeg ? ctrl->pos[parity][depth][threadIdx.x][0] : 0u;
-                const uint32_t t = (c + kBlock - 1) / kBlock;
-                uint32_t inc = t, sum = c;
+            if (threadIdx.x < 64) {          // wave 0: exclusive scan of the kSeg tile counts, kSeg / 64 consecutive segments per lane
+                constexpr int kPerLane = (kSeg + 63) / 64;
+                uint32_t cs[kPerLane], ts[kPerLane];
+                uint32_t inc = 0u, sum = 0u;
+#pragma unroll
+                for (int q = 0; q < kPerLane; ++q) {
+                    const int sgi = (int)threadIdx.x * kPerLane + q;
+                    cs[q] = sgi < kSeg ? ctrl->pos[parity][depth][sgi][0] : 0u;
+                    ts[q] = (cs[q] + kBlock - 1) / kBlock;
+                    inc += ts[q];
+                    sum += cs[q];
+                }
 #pragma unroll
                 for (int o = 1; o < 64; o <<= 1) {
                     const uint32_t up = __shfl_up(inc, o, 64), us = __shfl_up(sum, o, 64);
                     if ((int)threadIdx.x >= o) { inc += up; sum += us; }
                 }
-                if (threadIdx.x < kSeg) { s_segcnt[threadIdx.x] = c; s_segpre[threadIdx.x + 1] = inc; }
+                uint32_t run = inc;                                // inclusive over this lane's segments; walk them backwards
+#pragma unroll
+                for (int q = kPerLane - 1; q >= 0; --q) {
+                    const int sgi = (int)threadIdx.x * kPerLane + q;
+                    if (sgi < kSeg) { s_segcnt[sgi] = cs[q]; s_segpre[sgi + 1] = run; }
+                    run -= ts[q];
+                }
                 if (threadIdx.x == 0) s_segpre[0] = 0;
                 if (threadIdx.x == 63) s_segpre[kSeg + 1] = sum;   // total live paths
             }
@@ -488,11 +530,16 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
         for (int i = threadIdx.x; !MANY && i < ngeoms * kHitWords; i += kBlock) {
             const int g = i / kHitWords, k = i - g * kHitWords;
             const GeomDev &G = ggeoms[g];
+            const MaterialDev &Mg = A->gmats[G.material];      // (the header carries the hot fields of the primitive's material)
             uint32_t v = 0;
-            if (k < 12) v = __float_as_uint(G.invT[k]);
-            else if (k == 12) v = (uint32_t)G.material;
-            else if (k == 13) v = (uint32_t)G.type;
-            else if (k < 14 + 54) v = __float_as_uint(G.cubeFrame[k - 14]);
+            if (k == 0) v = (uint32_t)G.type;
+            else if (k == 1) v = __float_as_uint(Mg.emittance);
+            else if (k == 2) v = __float_as_uint(Mg.hasReflective);
+            else if (k == 3) v = __float_as_uint(Mg.hasRefractive);
+            else if (k < 7) v = __float_as_uint(Mg.color[k - 4]);
+            else if (k == 7) v = (uint32_t)G.material;
+            else if (k < 20) v = __float_as_uint(G.invT[k - 8]);
+            else if (k < 20 + 54) v = __float_as_uint(G.cubeFrame[k - 20]);
             reinterpret_cast<uint32_t *>(s_geomHit)[i] = v;
         }
         if (MANY) {
@@ -530,51 +577,61 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
         uint32_t idx;                       // its slot in the input pool
         uint32_t cls;                       // wave-uniform: the tile's queue class: bit 3 = its paths may hit a binned primitive; bits 0-2 in a
                                             // scene with walls = the one wall they can still hit (6: any, 7: none), else the direction octant
+        const float *base;                  // the input pool's arrays (from setupTile's one scalar load to loadTile; dead afterwards)
+        uint32_t cap;
     };
     struct PathRegs { F3 org, dir, col; int pix, packed; };
     // tile T of the queue -> its segment, class and the lane's slot; false: the tile needs no work at all
     auto setupTile = [&](uint32_t T, uint32_t tid, TileMeta &m) -> bool {
-        const ArgsPtr A = launder(kargs);
+        // everything the set-up needs from the argument block: one scalar load, in flight while the segment is looked up in LDS
+        const PT_CAS TileArgs &ta = launder(kargs)->tile;
+        const uint32_t shift = ta.chunkShift, poolChunks = ta.poolChunks, genIn = ta.genIn, skipNonCand = ta.skipNonCandidates;
+        const PT_CAS unsigned long long *const inList = (const PT_CAS unsigned long long *)ta.inList;
+        m.base = ta.inBase;
+        m.cap = ta.inCap;
         // global tile -> (segment, local tile)
         while (T >= s_segpre[sgIn + 1]) ++sgIn;
+        probe(26);                                              // (segment found)
         sgIn = (uint32_t)__builtin_amdgcn_readfirstlane((int)sgIn);
-        const uint32_t local = (T - s_segpre[sgIn]) * kBlock + tid;
+        const uint32_t segFirst = s_segpre[sgIn];
+        const uint32_t local = (T - segFirst) * kBlock + tid;
         m.valid = local < s_segcnt[sgIn];
         m.cls = sgIn / kSub;
         // The last bounce only asks whether a path ends on an emitter (S7: no scatter).  When every emitter of the scene
         // is a binned small primitive, the paths of a non-candidate tile certainly miss all of them: nothing to add.
-        if (A->lastBounce && A->prm.emittersBinned && (m.cls & 8u) == 0u) return false;
-        // the tile's chunk (a chunk is a multiple of the tile size): j-th chunk of the segment, wave-uniform lookup
-        // (entries were written by the previous launch; the 0-th chunk of a segment is static)
-        const uint32_t shift = (uint32_t)A->prm.chunkShift, poolChunks = (uint32_t)A->prm.poolChunks;
-        const uint32_t q0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)((T - s_segpre[sgIn]) * kBlock));
+        if (skipNonCand != 0u && (m.cls & 8u) == 0u) return false;
+        // the tile's chunk (a chunk is a multiple of the tile size): j-th chunk of the segment, wave-uniform lookup through the
+        // scalar cache (entries were written by the previous launch; the 0-th chunk of a segment is static)
+        const uint32_t q0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)((T - segFirst) * kBlock));
         const uint32_t j = q0 >> shift;
         uint32_t chunk = 1u + sgIn;
         if (j != 0u) {
-            const unsigned long long e = j < poolChunks ? A->in.list[(size_t)sgIn * poolChunks + j] : 0ull;
-            chunk = (uint32_t)(e >> 32) == A->genIn ? (uint32_t)e : 0u;
+            const unsigned long long e = j < poolChunks ? inList[(size_t)sgIn * poolChunks + j] : 0ull;
+            chunk = (uint32_t)(e >> 32) == genIn ? (uint32_t)e : 0u;
             chunk = chunk < poolChunks ? chunk : 0u;
         }
         m.idx = (chunk << shift) + (local - (j << shift));
+        probe(27);                                              // (chunk looked up: the loads can go)
         return true;
     };
     auto loadTile = [&](const TileMeta &m, PathRegs &r) {
         if (m.valid) {
-            // one running (scalar) pointer through the 11 arrays (stride = cap) + the lane's 32-bit byte offset
-            const ArgsPtr A = launder(kargs);
-            const float *src = A->in.base;
-            const size_t cap = (size_t)A->in.cap;
-            const uint32_t off = m.idx * 4u;
-            r.org.x = ldSlot(src, off); src += cap; r.org.y = ldSlot(src, off); src += cap; r.org.z = ldSlot(src, off); src += cap;
-            r.dir.x = ldSlot(src, off); src += cap; r.dir.y = ldSlot(src, off); src += cap; r.dir.z = ldSlot(src, off); src += cap;
-            r.col.x = ldSlot(src, off); src += cap; r.col.y = ldSlot(src, off); src += cap; r.col.z = ldSlot(src, off); src += cap;
-            r.pix = __float_as_int(ldSlot(src, off)); src += cap;
-            r.packed = __float_as_int(ldSlot(src, off));            // remainingBounces | batch index << 8
+            // three loads: 16 + 16 + 12 bytes (uniform base of the array + the lane's element)
+            const char *const src = reinterpret_cast<const char *>(m.base);
+            const size_t cap = (size_t)m.cap;
+            const float4 a = *reinterpret_cast<const float4 *>(src + 16 * (size_t)m.idx);
+            const float4 b = *reinterpret_cast<const float4 *>(src + 16 * cap + 16 * (size_t)m.idx);
+            const PathC c = *reinterpret_cast<const PathC *>(src + 32 * cap + 12 * (size_t)m.idx);
+            r.org = f3(a.x, a.y, a.z);
+            r.dir = f3(a.w, b.x, b.y);
+            r.col = f3(b.z, b.w, c.cz);
+            r.pix = c.pix;
+            r.packed = c.packed;                                // remainingBounces | batch index << 8
         }
     };
     // the first tile of this workgroup that needs work, and its paths
     uint32_t T = blockIdx.x - rowShift;      // (FIRST with rotated bands: the first tile of the row; else the tile itself)
-    TileMeta nextMeta = {false, 0u, 0u};
+    TileMeta nextMeta = {false, 0u, 0u, nullptr, 0u};
     PathRegs nextRegs = {f3(0, 0, 0), f3(0, 0, 1), f3(0, 0, 0), 0, 0};
     if (!FIRST) {
         while (T < numTiles && !setupTile(T, threadIdx.x, nextMeta)) T += gridDim.x;
@@ -869,14 +926,23 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
                 // per-lane primitive: LDS lookup of its hit record (sphere-heavy scenes: the compact record + the frame table)
                 int ghType, ghMaterial;
                 const float *ghNm, *ghFrame;
+                float mEmit, mRefl, mRefr;                       // the material's hot fields
+                F3 mcol;
                 if (MANY) {
                     const ArgsPtr A = launder(kargs);
                     const GeomHitSmall &h = S_GEOMHIT_SMALL(A->prm.nmats)[hit];
                     ghType = h.type; ghMaterial = h.material; ghNm = h.nm;
                     ghFrame = S_FRAMES(A->prm.nmats, A->prm.ngeoms) + h.frame * 54;
+                    const MaterialDev &Mm = smats[ghMaterial];
+                    mEmit = Mm.emittance; mRefl = Mm.hasReflective; mRefr = Mm.hasRefractive;
+                    mcol = f3(Mm.color[0], Mm.color[1], Mm.color[2]);
                 } else {
+                    // the record's header: two 16-byte reads, in flight together
                     const GeomHitDev &h = S_GEOMHIT(launder(kargs)->prm.nmats)[hit];
-                    ghType = h.type; ghMaterial = h.material; ghNm = h.nm; ghFrame = h.cubeFrame;
+                    const float4 h0 = reinterpret_cast<const float4 *>(&h)[0], h1 = reinterpret_cast<const float4 *>(&h)[1];
+                    ghType = __float_as_int(h0.x); mEmit = h0.y; mRefl = h0.z; mRefr = h0.w;
+                    mcol = f3(h1.x, h1.y, h1.z); ghMaterial = __float_as_int(h1.w);
+                    ghNm = h.nm; ghFrame = h.cubeFrame;
                 }
                 const bool isSphere = ghType == 0;
                 bool faceOk = true;
@@ -886,9 +952,8 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
                 // row of the table, or the row of NaNs for a hit without an exit slab -- instead of nine on the values
                 const float *const fv = faceOk ? ghFrame + 9 * face : s_nan;
                 const F3 N = isSphere ? hitNormalSphere(ghNm, nsrc, outside) : f3(fv[0], fv[1], fv[2]);
-                const MaterialDev &M = smats[ghMaterial];
-                const F3 mcol = f3(M.color[0], M.color[1], M.color[2]);
-                if (M.emittance > 0.0f) {                        // S5: emitter ends the path
+                const MaterialDev &M = smats[ghMaterial];       // (the fields of the rarer branches)
+                if (mEmit > 0.0f) {                              // S5: emitter ends the path
                     lightHitI = 1u;
                     const ArgsPtr A = launder(kargs);
                     float *const contrib = A->contrib;
@@ -896,7 +961,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
                         // Deferred accumulation: iterations overlap on several streams, so the radiance
                         // is parked in this iteration's own buffer (one path per pixel: race-free, no
                         // read) and k_commit adds it to the accumulator in iteration order.
-                        const F3 c = (col * mcol) * M.emittance;
+                        const F3 c = (col * mcol) * mEmit;
                         // (index of the pixel in the radiance buffers: the frame's, or, for a row shard, the shard's own)
                         size_t frame = (size_t)A->prm.W * A->prm.H;
                         uint32_t cpix = (uint32_t)pix;
@@ -920,7 +985,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
                     const F3 scol = f3(M.specColor[0], M.specColor[1], M.specColor[2]);
                     F3 ndir = dir, norg;
                     bool diffuse = false;                        // the hemisphere is sampled at one place, after the branches
-                    if (M.hasRefractive > 0.0f) {
+                    if (mRefr > 0.0f) {
                         const float eta = outside ? M.invIor : M.ior;
                         const float c = dot(N, dir);
                         const float k = 1.0f - eta * eta * (1.0f - c * c);
@@ -944,7 +1009,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
                             norg = P - N * 0.001f;
                             col = col * mcol;
                         }
-                    } else if (M.hasReflective > 0.0f) {
+                    } else if (mRefl > 0.0f) {
                         const float u = u01(rng);
                         if (u < 0.5f) {
                             ndir = reflect(dir, N);
@@ -1016,11 +1081,19 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
                         const ArgsPtr A = launder(kargs);
                         const int nBinned = A->prm.nBinned;
                         if (nBinned > 0) {
-                            const GeomPtr geoms = (GeomPtr)(A->ggeoms);
                             const float ndd = dot(ndir, ndir);
                             uint32_t cand = 0u;
-                            for (int sI = 0; sI < nBinned; ++sI) { probe(12);
-                                cand |= certainMiss(*(launder(geoms) + A->prm.binGeom[sI]), norg, ndir, ndd) ? 0u : 1u; }
+                            for (int sI = 0; sI < nBinned; sI += 2) { probe(12);          // two at a time: one 64-byte scalar load
+                                int16v v;
+                                asm volatile("s_load_dwordx16 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(launder(kargs)), "s"((int)(offsetof(BounceArgs, prm) + offsetof(KParams, binCull)) + sI * 32) : "memory");
+#pragma unroll
+                                for (int h = 0; h < 2; ++h) {
+                                    CullGroup cg;
+                                    cg.centre[0] = __int_as_float(v[8 * h]); cg.centre[1] = __int_as_float(v[8 * h + 1]); cg.centre[2] = __int_as_float(v[8 * h + 2]);
+                                    cg.cullR2 = __int_as_float(v[8 * h + 3]); cg.cullK = __int_as_float(v[8 * h + 4]);
+                                    cand |= certainMiss(cg, norg, ndir, ndd) ? 0u : 1u;
+                                }
+                            }
                             smallCandI = cand;
                         }
                     }
@@ -1052,6 +1125,43 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
                 }
             }
         }
+#if defined(PT_EXP) && (PT_EXP & 0x7c)
+        // experiments: what is a tile's time sensitive to?  100 more instructions of one class per wave and tile (the result feeds a
+        // store that never executes, so nothing is optimised away and no result changes)
+        {
+            float xa = org.x, xb = dir.y;
+            uint32_t sa = (uint32_t)__builtin_amdgcn_readfirstlane(pix), sb = sa ^ 0x55u;
+#pragma unroll 1
+            for (int q = 0; q < 25; ++q) {
+#if PT_EXP & 4        // vector, VGPR operands only
+                asm volatile("v_fma_f32 %0, %0, %1, %1\n\tv_fma_f32 %1, %1, %0, %0\n\tv_fma_f32 %0, %0, %1, %1\n\tv_fma_f32 %1, %1, %0, %0" : "+v"(xa), "+v"(xb));
+#endif
+#if PT_EXP & 8        // vector with one SGPR operand
+                asm volatile("v_mul_f32 %0, %2, %0\n\tv_mul_f32 %1, %2, %1\n\tv_mul_f32 %0, %2, %0\n\tv_mul_f32 %1, %2, %1" : "+v"(xa), "+v"(xb) : "s"(sa));
+#endif
+#if PT_EXP & 16       // scalar ALU
+                asm volatile("s_add_u32 %0, %0, %1\n\ts_xor_b32 %1, %1, %0\n\ts_add_u32 %0, %0, %1\n\ts_xor_b32 %1, %1, %0" : "+s"(sa), "+s"(sb));
+#endif
+#if PT_EXP & 64       // compare into an SGPR pair + select on it
+                asm volatile("v_cmp_lt_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc\n\tv_cmp_gt_f32 vcc, %0, %1\n\tv_cndmask_b32 %1, %1, %0, vcc" : "+v"(xa), "+v"(xb) : : "vcc");
+#endif
+            }
+#if PT_EXP & 32       // 20 dependent scalar loads (a latency chain through the scalar cache)
+            {
+                const PT_CAS uint32_t *pp = (const PT_CAS uint32_t *)launder(kargs);
+                uint32_t acc = 0;
+#pragma unroll 1
+                for (int q = 0; q < 20; ++q) {
+                    uint32_t v;
+                    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(pp + ((acc & 3u))) : "memory");
+                    acc = (acc + v) & 0xffu;
+                }
+                sa += acc;
+            }
+#endif
+            if (__float_as_uint(xa) + __float_as_uint(xb) + sa + sb == 0x12345677u && pix == -12345) nMiss += 7u;
+        }
+#endif
         probe(17);                                              // (next tile's loads)
         nLight += lightHitI;
         nMiss += missedI;
@@ -1094,7 +1204,9 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
             }
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi(sameHi, __builtin_amdgcn_mbcnt_lo(sameLo, 0u));
             if (alive && rank == 0u) wv[wave * kCls + cls] = (uint32_t)(__popc(sameLo) + __popc(sameHi));   // the class's first lane
+            probe(21);                                          // (first barrier)
             __syncthreads();
+            probe(22);                                          // (reservation)
             if (tid < kCls) {
                 const ArgsPtr A = launder(kargs);
                 Ctrl *const ctrl = A->ctrl;
@@ -1112,6 +1224,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
                 s_base[kCls + tid] = sp;
                 s_base[2 * kCls + tid] = r1;
             }
+            probe(23);                                          // (second barrier)
             __syncthreads();
 #if defined(PT_EXP) && (PT_EXP & 2)      // experiment: one more workgroup barrier per tile
             asm volatile("" ::: "memory");
@@ -1129,14 +1242,13 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
                 }
                 const uint32_t r = waveOff + rank, sp = s_base[kCls + cls];
                 const uint32_t slot = r < sp ? s_base[cls] + r : s_base[2 * kCls + cls] + (r - sp);
-                float *dst = A->out.base;
+                char *const dst = reinterpret_cast<char *>(A->out.base);
                 const size_t ocap = (size_t)A->out.cap;
-                const uint32_t off = slot * 4u;
-                stSlot(dst, off, org.x); dst += ocap; stSlot(dst, off, org.y); dst += ocap; stSlot(dst, off, org.z); dst += ocap;
-                stSlot(dst, off, dir.x); dst += ocap; stSlot(dst, off, dir.y); dst += ocap; stSlot(dst, off, dir.z); dst += ocap;
-                stSlot(dst, off, col.x); dst += ocap; stSlot(dst, off, col.y); dst += ocap; stSlot(dst, off, col.z); dst += ocap;
-                stSlot(dst, off, __int_as_float(pix)); dst += ocap;
-                stSlot(dst, off, __int_as_float((rem - 1) | (itb << 8)));
+                *reinterpret_cast<float4 *>(dst + 16 * (size_t)slot) = make_float4(org.x, org.y, org.z, dir.x);
+                *reinterpret_cast<float4 *>(dst + 16 * ocap + 16 * (size_t)slot) = make_float4(dir.y, dir.z, col.x, col.y);
+                PathC c;
+                c.cz = col.z; c.pix = pix; c.packed = (rem - 1) | (itb << 8);
+                *reinterpret_cast<PathC *>(dst + 32 * ocap + 12 * (size_t)slot) = c;
             }
             // No third barrier: the counts are double-buffered.  The other half was last read in the previous tile, and every
             // wave finished those reads before it arrived at THIS tile's first barrier, so each wave may now clear its own
@@ -1150,6 +1262,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
         T = Tnext;
     }
     censusLeave();
+    probe(29);                           // (timeline builds: the launch's sums go out)
     // tallies: lanes -> wave (shuffles) -> workgroup (LDS) -> ONE atomic per workgroup and tally on counters sharded 8 ways
     // (every workgroup of a launch ends with these: unsharded, or one per wave, they serialise at the memory side)
     const uint32_t waveLight = waveSum(nLight), waveEarly = waveSum(nEarly), waveMiss = waveSum(nMiss) + waveEarly;
