@@ -18,7 +18,7 @@ constexpr int kMaxDepthSlots = PT_MAX_DEPTH + 2;
 constexpr int kOct = 8;              // direction octants: paths are binned by the signs of their new direction ...
 constexpr int kCls = 2 * kOct;       // ... and by "may hit a small primitive" (bit 3): 16 classes
 #ifndef PT_KSUB
-#define PT_KSUB 4
+#define PT_KSUB 8
 #endif
 constexpr int kSub = PT_KSUB;        // append-counter shards per class (workgroup blockIdx % kSub; PT_KSUB: shard-count experiments only)
 constexpr int kSeg = kCls * kSub;    // path buffers are split into kSeg segments with one append counter each
@@ -492,9 +492,13 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
         if (threadIdx.x < 2 * kWaves * kCls) s_wave[threadIdx.x] = 0u;
         if (threadIdx.x < kCls) s_base[3 * kCls + threadIdx.x] = 0xffffffffu;   // no chunk looked up yet
         if (threadIdx.x < kNanWords) s_iterHash[2 * PT_MAX_BATCH + 2 + threadIdx.x] = 0x7fc00000u;
-        for (int i = threadIdx.x; i < 2 * PT_MAX_BATCH; i += kBlock) {
-            const int b = i % PT_MAX_BATCH;
-            s_iterHash[i] = iterationHash(A->iter + b, i < PT_MAX_BATCH ? depth : 0);
+        // (only the batch's own iterations: a batch of 32 needs 64 of the 512 entries -- every workgroup of every launch fills this table)
+        {
+            const int nb = A->batch;
+            for (int i = threadIdx.x; i < 2 * nb; i += kBlock) {
+                const int b = i < nb ? i : i - nb;
+                s_iterHash[i < nb ? b : PT_MAX_BATCH + b] = iterationHash(A->iter + b, i < nb ? depth : 0);
+            }
         }
 
         // stage the materials in LDS once per (persistent) workgroup, 16 B per lane per step

@@ -317,7 +317,7 @@ def test_undersized_pool_fails_loudly(gpu, oracle, monkeypatch):
     # PT_AMD_POOL_CHUNKS (tests only) shrinks the pools below what the render needs: the kernels must stay in bounds,
     # and the fault must surface as PT_ERR_DEVICE -- at pt_sync, at pt_counters, and stay sticky until the next pt_init
     sc = _one_class_scene(gpu, oracle, (256, 256), 6)
-    monkeypatch.setenv("PT_AMD_POOL_CHUNKS", "70")        # 64 static chunks + 5: 256 x 256 paths need 32 more
+    monkeypatch.setenv("PT_AMD_POOL_CHUNKS", "134")       # 128 static chunks (16 classes x 8 shards) + 5: 256 x 256 paths in ONE class need ~24 more
     gpu.pathtraceFree()
     gpu.pathtraceInit(sc, pipeline_depth=1)
     gpu.pathtrace(None, 0, 1, readback=False)
