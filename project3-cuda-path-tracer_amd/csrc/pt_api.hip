@@ -696,7 +696,10 @@ int launch_bounce(Slot &sl, int iter, int batch, int depth, bool lastBounce, flo
     ba.tile.inBase = in.base; ba.tile.inList = in.list; ba.tile.inCap = in.cap;
     ba.tile.genIn = genIn; ba.tile.poolChunks = (uint32_t)S.prm.poolChunks; ba.tile.chunkShift = (uint32_t)S.prm.chunkShift;
     ba.tile.skipNonCandidates = (lastBounce && S.prm.emittersBinned) ? 1u : 0u;
-    ba.tile.pad = 0u;
+    ba.tile.hot = (lastBounce ? kHotLast : 0u) | (S.prm.allClassified ? kHotAllClassified : 0u) | (contrib ? kHotContrib : 0u) |
+                  ((S.prm.directDepth != 0 && depth == S.prm.directDepth && S.prm.nEmit > 0) ? kHotToLight : 0u) |
+                  (S.prm.contribLocal ? kHotContribLocal : 0u) | ((uint32_t)S.prm.nWalls << 8) | ((uint32_t)S.prm.nSlotWalls << 11) |
+                  ((uint32_t)S.prm.nBinned << 14) | ((uint32_t)S.prm.nmats << 20);
     ba.ctrl = sl.ctrl; ba.ggeoms = S.dgeoms; ba.gmats = S.dmats; ba.contrib = contrib; ba.hitMask = sl.hitMask;
     ba.sphCull = S.dSphCull; ba.classIdx = S.dClassIdx;
     ba.rowOff = S.dRowOff; ba.rowIdx = S.dRowIdx;
@@ -1281,6 +1284,7 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
                                (size_t)ngeoms * kSphRowFloats * sizeof(float) + (size_t)kListMax * kBlock * sizeof(uint16_t)
                          : sizeof(GeomHitDev) * ngeoms);
     if (S.ldsBytes > 160 * 1024) return fail(PT_ERR_INVALID, "pt_init: scene does not fit the 160 KiB LDS (%zu B)", S.ldsBytes);
+    if (nmats >= 4096) return fail(PT_ERR_INVALID, "pt_init: more than 4095 materials");      // (TileArgs::hot holds nmats in 12 bits)
     const void *kFirst = bounce_kernel(true, S.dof);
     const void *kNext = bounce_kernel(false, false);
     if (S.ldsBytes > 64 * 1024) {

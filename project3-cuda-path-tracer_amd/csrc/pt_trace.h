@@ -345,8 +345,18 @@ struct TileArgs {
     uint32_t genIn;
     uint32_t poolChunks, chunkShift;
     uint32_t skipNonCandidates;         // lastBounce && emittersBinned: tiles whose class says "no binned primitive" have nothing to add
-    uint32_t pad;
+    // The launch's small wave-uniform facts in ONE word, fetched once per workgroup and kept in a scalar register: each of them used to
+    // be its own scalar load in the phase that asks for it, and round 3's experiments price a dependent scalar-cache round trip at
+    // half a percent of a tile's time (profiles/r03_sensitivity_experiments.txt).
+    //   bit 0 lastBounce, 1 allClassified, 2 radiance is parked (contrib != null), 3 this bounce aims at a light (direct lighting),
+    //   4 contribLocal; bits 8-10 nWalls, 11-13 nSlotWalls, 14-16 nBinned, 20-31 nmats
+    uint32_t hot;
 };
+constexpr uint32_t kHotLast = 1u, kHotAllClassified = 2u, kHotContrib = 4u, kHotToLight = 8u, kHotContribLocal = 16u;
+__host__ __device__ constexpr uint32_t hotWalls(uint32_t h) { return (h >> 8) & 7u; }
+__host__ __device__ constexpr uint32_t hotSlotWalls(uint32_t h) { return (h >> 11) & 7u; }
+__host__ __device__ constexpr uint32_t hotBinned(uint32_t h) { return (h >> 14) & 7u; }
+__host__ __device__ constexpr uint32_t hotMats(uint32_t h) { return h >> 20; }
 static_assert(sizeof(TileArgs) == 40, "ten dwords");
 struct BounceArgs {
     TileArgs tile;                      // (first: offset 0)
@@ -555,6 +565,16 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
     }
     __syncthreads();
 
+    // (see TileArgs::hot; opaque to the optimiser so that it stays ONE register instead of being re-derived from re-loaded fields)
+    uint32_t hotWord = launder(kargs)->tile.hot;
+    asm volatile("" : "+s"(hotWord));
+    // (every use goes through an empty asm of its own: what is derived from the word -- a mask, a count, an LDS offset -- is then
+    // derived where it is used, not hoisted out of the tile loop into registers that live, and spill, across the whole tile)
+    auto hotNow = [&]() -> uint32_t {
+        uint32_t h = hotWord;
+        asm volatile("" : "+s"(h));
+        return h;
+    };
     uint32_t nLight = 0, nMiss = 0;         // per-lane tallies (VGPRs are the less scarce kind here), reduced and flushed once at the end
     uint32_t wvSel = 0;                     // which half of s_wave the current tile counts in (0 or kWaves * kCls)
     uint32_t nEarly = 0;                    // survivors that certainly miss everything: ended at the scatter
@@ -798,7 +818,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
                     classIdx = (const PT_CAS int *)(A->classIdx);
                 }
                 const GeomPtr geoms = (GeomPtr)(A->ggeoms);
-                const bool earlyMiss = FIRST || A->prm.nWalls == 0 || (tileCls & 7u) >= 6u;     // (wave-uniform)
+                const bool earlyMiss = FIRST || hotWalls(hotNow()) == 0u || (tileCls & 7u) >= 6u;    // (wave-uniform)
                 for (int gk = gk0; gk < gk1; ++gk) {
                     int g, span = 0;
                     if (FIRST && listed) {
@@ -942,7 +962,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
                     mcol = f3(Mm.color[0], Mm.color[1], Mm.color[2]);
                 } else {
                     // the record's header: two 16-byte reads, in flight together
-                    const GeomHitDev &h = S_GEOMHIT(launder(kargs)->prm.nmats)[hit];
+                    const GeomHitDev &h = S_GEOMHIT(hotMats(hotNow()))[hit];
                     const float4 h0 = reinterpret_cast<const float4 *>(&h)[0], h1 = reinterpret_cast<const float4 *>(&h)[1];
                     ghType = __float_as_int(h0.x); mEmit = h0.y; mRefl = h0.z; mRefr = h0.w;
                     mcol = f3(h1.x, h1.y, h1.z); ghMaterial = __float_as_int(h1.w);
@@ -961,7 +981,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
                     lightHitI = 1u;
                     const ArgsPtr A = launder(kargs);
                     float *const contrib = A->contrib;
-                    if (contrib) {
+                    if (hotNow() & kHotContrib) {
                         // Deferred accumulation: iterations overlap on several streams, so the radiance
                         // is parked in this iteration's own buffer (one path per pixel: race-free, no
                         // read) and k_commit adds it to the accumulator in iteration order.
@@ -969,7 +989,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
                         // (index of the pixel in the radiance buffers: the frame's, or, for a row shard, the shard's own)
                         size_t frame = (size_t)A->prm.W * A->prm.H;
                         uint32_t cpix = (uint32_t)pix;
-                        if (A->prm.contribLocal) {
+                        if (hotNow() & kHotContribLocal) {
                             const uint32_t y = fastDiv((uint32_t)pix, A->prm.magicW, A->prm.shiftW);
                             const uint32_t lr = fastDiv(y, A->prm.magicS, A->prm.shiftS);
                             cpix = (uint32_t)pix - (y - lr) * (uint32_t)A->prm.W;      // x + lr * W
@@ -983,7 +1003,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
                         (void)__hip_atomic_fetch_or(A->hitMask + (size_t)(itb >> 5) * frame + (size_t)cpix, 1u << (itb & 31), __ATOMIC_RELAXED,
                                                     __HIP_MEMORY_SCOPE_AGENT);
                     }
-                } else if (!launder(kargs)->lastBounce) {        // S6 scatter (S7: skipped on the last bounce)
+                } else if (!(hotNow() & kHotLast)) {                  // S6 scatter (S7: skipped on the last bounce)
                     probe(10);
                     Rng rng = seedEngine(s_iterHash[itb] ^ (FIRST ? pixHash : utilhash((uint32_t)pix)));   // = makeSeededRandomEngineHashed(., pix)
                     const F3 scol = f3(M.specColor[0], M.specColor[1], M.specColor[2]);
@@ -1033,7 +1053,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
                         // chosen point of the (transformed) unit cube of a uniformly chosen emissive primitive, weighted by the
                         // cosine at the surface; the launch after this one collects what it hits
                         const ArgsPtr A = launder(kargs);
-                        toLight = A->prm.directDepth != 0 && A->depth == A->prm.directDepth && A->prm.nEmit > 0;
+                        toLight = (hotNow() & kHotToLight) != 0u;
                         if (toLight) {
                             const int ne = A->prm.nEmit;
                             int pick = (int)(u01(rng) * (float)ne);
@@ -1082,8 +1102,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
                     dir = ndir;
                     aliveI = 1u;
                     {                                            // class bit 3: can the new ray hit a small primitive at all?
-                        const ArgsPtr A = launder(kargs);
-                        const int nBinned = A->prm.nBinned;
+                        const int nBinned = (int)hotBinned(hotNow());
                         if (nBinned > 0) {
                             const float ndd = dot(ndir, ndir);
                             uint32_t cand = 0u;
@@ -1103,7 +1122,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
                     }
                     {                                            // class bits 0-2 with walls: which of them can the new ray still hit?
                         const ArgsPtr A = launder(kargs);
-                        const int nWalls = A->prm.nWalls;
+                        const int nWalls = (int)hotWalls(hotNow());
                         if (nWalls > 0) {
                             wallSel = 6u;
                             const float l1 = (__builtin_fabsf(norg.x) + __builtin_fabsf(norg.y)) + __builtin_fabsf(norg.z);
@@ -1112,14 +1131,14 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
                                 const WallPtr walls = (WallPtr)(A->walls);
                                 probe(13);
                                 uint32_t possible = wallPlanesPossible(A->prm, norg, ndir, inv);     // walls 0 .. nSlotWalls - 1
-                                for (int w = A->prm.nSlotWalls; w < nWalls; ++w) { probe(13);
+                                for (int w = (int)hotSlotWalls(hotNow()); w < nWalls; ++w) { probe(13);
                                     possible |= wallCertainMiss(*(launder(walls) + w), norg, inv) ? 0u : (1u << w); }
                                 const int cnt = __popc(possible);
                                 wallSel = cnt == 1 ? (uint32_t)(__ffs((int)possible) - 1) : (cnt == 0 ? 7u : 6u);
                                 // nothing left to hit: the reference's nearest-hit loop would come back empty at the next bounce.
                                 // The path ends here and is tallied as what it is, a path that entered that bounce and missed.
                                 // (Not under pt_debug_trace_paths, which shows the queue as the oracle lists it.)
-                                if (cnt == 0 && smallCandI == 0u && A->prm.allClassified && A->contrib) {
+                                if (cnt == 0 && smallCandI == 0u && (hotNow() & (kHotAllClassified | kHotContrib)) == (kHotAllClassified | kHotContrib)) {
                                     aliveI = 0u;
                                     ++nEarly;
                                 }
@@ -1176,7 +1195,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
         probe(18);                                              // (compaction)
         const bool alive = aliveI != 0u, smallCand = smallCandI != 0u;
 
-        if (!launder(kargs)->lastBounce) {                       // S8: compaction into `out`, binned by class
+        if (!(hotNow() & kHotLast)) {                                 // S8: compaction into `out`, binned by class
             // The compaction is the tile's latency chain (barrier, reservation round trip, barrier, stores): its waves issue
             // ahead of the ones that are tracing, so the chain is not stretched by instruction arbitration.  Measured
             // (profiles/r02_priority_experiments.txt): a launch on its own 5-6 % shorter, the pipelined rate +0.5 % (Cornell)
@@ -1189,7 +1208,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
             const unsigned long long ba = __ballot(alive);
             // class bits 0-2: the wall the ray can still hit (scenes with walls) or the octant of its direction
             uint32_t cls;
-            if (launder(kargs)->prm.nWalls > 0) {
+            if (hotWalls(hotNow()) > 0u) {
                 cls = wallSel & 7u;
             } else {
                 cls = (dir.x < 0.0f ? 1u : 0u) | (dir.y < 0.0f ? 2u : 0u) | (dir.z < 0.0f ? 4u : 0u);
