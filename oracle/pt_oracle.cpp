@@ -714,6 +714,12 @@ struct ORender {
     float lensRadius, focalDistance;   /* thin lens (README.md:100-101); radius 0 = pinhole */
     V3 viewN;                          /* normalize(view) */
     int directLighting;                /* README.md:107-108: a final ray to a random point of an emissive object */
+    /* STUDY VARIANTS (orc_render_set_variant; never used by a parity test): where the reference is silent the pipeline is build-defined
+     * (spec S6), and the one external anchor -- the staff render img/REFERENCE_cornell.5000samp.png -- differs from it by a systematic
+     * 2 % on the back wall.  These switches render the candidate explanations in the oracle (DESIGN.md section 2 tabulates them). */
+    float scatterOffset = 0.001f;      /* new origin = hit +- offset * normal */
+    int mirrorMode = 0;                /* REFL > 0 materials: 0 = 50/50 mirror / diffuse, energy conserving (the build's choice); 1 = 50/50 with
+                                          the 1 / p weights (either branch x 2); 2 = a pure mirror */
     std::vector<int> emitters;         /* geoms with an emissive material, file order */
     std::vector<OMesh> meshes;         /* triangle data of the geoms of type 2 */
     std::vector<int> meshOf;           /* geom -> index into meshes, -1 */
@@ -986,18 +992,18 @@ Fate bounce(const ORender &R, int iter, int index, int depth, Ray &ray, V3 &colo
         }
         if (doReflect) {
             ndir = reflect3(ray.direction, n);
-            norg = add(p, muls(n, 0.001f));
+            norg = add(p, muls(n, R.scatterOffset));
             color = mul(color, scol);
         } else {
             ndir = refract3(ray.direction, n, eta);
-            norg = sub(p, muls(n, 0.001f));
+            norg = sub(p, muls(n, R.scatterOffset));
             color = mul(color, mcol);
         }
     } else if (m.hasReflective > 0.0f) {
         /* energy-conserving 50/50 mirror/diffuse mixture (spec S6) */
         float u = rng_u01(rng);
-        norg = add(p, muls(n, 0.001f));
-        if (u < 0.5f) {
+        norg = add(p, muls(n, R.scatterOffset));
+        if (u < 0.5f || R.mirrorMode == 2) {
             ndir = reflect3(ray.direction, n);
             if (m.specExponent > 0.0f)      /* SPECEX > 0: imperfect specular (README.md:171-185); 0 = the perfect mirror */
                 ndir = random_direction_in_specular_lobe(ndir, n, 1.0f / (m.specExponent + 1.0f), rng);
@@ -1008,8 +1014,9 @@ Fate bounce(const ORender &R, int iter, int index, int depth, Ray &ray, V3 &colo
             ndir = random_direction_in_hemisphere(n, rng);
             color = mul(color, mcol);
         }
+        if (R.mirrorMode == 1) color = muls(color, 2.0f);      /* (study variant: the 1 / p weight of the branch taken) */
     } else {
-        norg = add(p, muls(n, 0.001f));
+        norg = add(p, muls(n, R.scatterOffset));
         if (direct && !R.emitters.empty()) {
             scatter_to_light(R, n, norg, mcol, rng, ndir, color);
         } else {
@@ -1219,6 +1226,11 @@ void orc_render_set_extras(ORender *R, float lensRadius, float focalDistance, in
     R->lensRadius = lensRadius;
     R->focalDistance = focalDistance;
     R->directLighting = directLighting;
+}
+/* study variants (see ORender): offset of the scattered ray's origin, treatment of REFL > 0 materials */
+void orc_render_set_variant(ORender *R, float scatterOffset, int mirrorMode) {
+    R->scatterOffset = scatterOffset;
+    R->mirrorMode = mirrorMode;
 }
 float orc_pow(float x, float e) { return pow_poly(x, e); }
 void orc_render_free(ORender *R) { delete R; }

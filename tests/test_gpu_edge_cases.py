@@ -259,6 +259,33 @@ def test_headless_driver_renders_the_reference_protocol(gpu, oracle, tmp_path):
     assert open(base + "_b.png", "rb").read() == open(base + ".png", "rb").read()
 
 
+def test_headless_driver_renders_a_frame_beyond_2_24_pixels(gpu, oracle, tmp_path):
+    # A host written against the reference's pathtraceInit knows nothing of batches: the shim's trace-ahead (32 iterations per
+    # wavefront batch by default) must never be the reason an Init fails.  8192 x 2064 = 16.9 M pixels: 32 x that many paths exceed
+    # the library's 2^29 per batch, so the shim clamps the batch (to 16) -- round 2's shim exited in pathtraceInit here.
+    import subprocess
+    from test_host import _decode_png
+    from conftest import ROOT
+    W, H, its, depth = 8192, 2064, 3, 2
+    assert W * H > 1 << 24
+    exe = os.path.join(ROOT, "project3-cuda-path-tracer_amd", "host", "pt_render")
+    base = str(tmp_path / "big")
+    r = subprocess.run([exe, os.path.join(SCENES, "cornell.txt"), "--res", str(W), str(H), "--iterations", str(its), "--depth", str(depth),
+                        "--out", base], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = _decode_png(base + ".png")
+    assert got.shape == (H, W, 3)
+    # every 64th row against the oracle (rows y with y % 64 == 7), X mirrored like the file
+    sc = oracle.Scene(os.path.join(SCENES, "cornell.txt"))
+    sc.set_resolution(W, H)
+    ref = oracle.Renderer(sc.camera, sc.geoms, sc.materials, depth)
+    img = np.zeros(W * H * 3, np.float32)
+    for it in range(1, its + 1):
+        ref.iterate(it, img, 7, 64)
+    want = (np.clip(img.reshape(H, W, 3) / np.float32(its), 0, 1) * np.float32(255)).astype(np.uint8)[:, ::-1]
+    assert want[7::64].max() > 0 and np.array_equal(got[7::64], want[7::64])
+
+
 @pytest.mark.parametrize("eye,view,up,fovy", [
     ((0, 5, 4.9), (0, 0, -1), (0, 1, 0), 45.0),          # inside the room: every wall's bounding cube surrounds the eye
     ((0, 5, 30), (0.02, -0.01, -1), (0, 1, 0), 12.0),    # far away, narrow: the room covers a small pixel rectangle
