@@ -28,6 +28,13 @@ int pt_test_intersect(const PtGeom *geoms, int ngeoms, const int32_t *geom_index
  * of `geoms`; *violations = rays culled although the full test hits (must be 0), *culled = rays culled. */
 int pt_test_sphere_cull_sweep(const PtGeom *geoms, int ngeoms, uint64_t seed, int64_t rays, uint64_t *culled,
                               uint64_t *violations);
+/* sphereHalfLineExcess (pt_device.h: the certificate of the sphere-heavy sweep of the later bounces -- the squared distance of a sphere's
+ * centre from the HALF-line, direction normalised approximately) swept like certainMiss: `rays` rays in three families (aimed near the
+ * ball from 1/64 .. 64 units; leaving the sphere's own surface as a scatter does; from within 2 % of the bounding ball's surface),
+ * directions unit and not.  *culled = certified misses, *behind = those with the centre behind the origin, *violations = certified
+ * although src/intersections.h:101-143 returns a hit (must be 0). */
+int pt_test_sphere_halfline_sweep(const PtGeom *geoms, int ngeoms, uint64_t seed, int64_t rays, uint64_t *culled, uint64_t *behind,
+                                  uint64_t *violations);
 /* wallCertainMiss (world-space culling of large cubes against their inflated bounding boxes, which classes the queue by
  * the wall a path can still hit) soundness: as above, for the cubes of `geoms`. */
 int pt_test_wall_box_sweep(const PtGeom *geoms, int ngeoms, uint64_t seed, int64_t rays, uint64_t *culled,

@@ -60,7 +60,7 @@ TEST_ABI_SYMBOLS = [
     "pt_test_slab_quotients", "pt_test_slab_quotients_sweep", "pt_test_sphere_cull_sweep", "pt_test_unscaled_sqrt_sweep",
     "pt_test_force_fault", "pt_test_pow", "pt_test_wall_box_sweep", "pt_test_mesh_intersect", "pt_test_mesh_bvh",
     "pt_test_mesh_cull_sweep", "pt_test_camera_cull_sweep", "pt_test_camera_cull_tables",
-    "pt_test_wall_plane_sweep",
+    "pt_test_wall_plane_sweep", "pt_test_sphere_halfline_sweep",
 ]
 
 
@@ -121,6 +121,7 @@ def _bind(L, with_tests):
         L.pt_test_slab_quotients.argtypes = [vp, vp, i32, vp, vp, vp, vp]
         L.pt_test_slab_quotients_sweep.argtypes = [C.c_uint64, i64, u64p]
         L.pt_test_sphere_cull_sweep.argtypes = [vp, i32, C.c_uint64, i64, u64p, u64p]
+        L.pt_test_sphere_halfline_sweep.argtypes = [vp, i32, C.c_uint64, i64, u64p, u64p, u64p]
         L.pt_test_unscaled_sqrt_sweep.argtypes = [u64p]
         L.pt_test_force_fault.argtypes = [i32]
         L.pt_test_pow.argtypes = [vp, vp, i32, vp]
@@ -524,6 +525,14 @@ def test_sphere_cull_sweep(geoms, seed, rays):
     culled, bad = C.c_uint64(0), C.c_uint64(0)
     _tcheck(test_lib().pt_test_sphere_cull_sweep(_p(geoms), len(geoms), seed, rays, C.byref(culled), C.byref(bad)))
     return int(culled.value), int(bad.value)
+
+
+def test_sphere_halfline_sweep(geoms, seed, rays):
+    """-> (certified misses, of them with the centre behind the origin, violations)"""
+    geoms = np.ascontiguousarray(geoms)
+    culled, behind, bad = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+    _tcheck(test_lib().pt_test_sphere_halfline_sweep(_p(geoms), len(geoms), seed, rays, C.byref(culled), C.byref(behind), C.byref(bad)))
+    return int(culled.value), int(behind.value), int(bad.value)
 
 
 def test_wall_box_sweep(geoms, seed, rays):

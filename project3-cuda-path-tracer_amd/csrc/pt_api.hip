@@ -1238,16 +1238,11 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
                 memset(&e, 0, sizeof e);
                 for (int a = 0; a < 3; ++a) e.centre[a] = hg[i].centre[a];
                 e.cullR2 = hg[i].cullR2;
-                e.cullK = hg[i].cullK;
+                e.cullK = hg[i].cullK + kUnitDirSlack;      // (the sweep's direction is normalised approximately: sphereHalfLineExcess)
                 e.geom = i;
                 sc.push_back(e);
             }
-        if (sc.size() % 2) {
-            SphereCull e;
-            memset(&e, 0, sizeof e);
-            e.geom = -1;
-            sc.push_back(e);
-        }
+        if (sc.size() % 2) sc.push_back(sc.back());      // (two per scalar load; testing a sphere twice changes nothing)
         k.nSphCull = (int)sc.size();
         HIPCHECK(hipMalloc(&S.dSphCull, sc.size() * sizeof(SphereCull)));
         HIPCHECK(hipMemcpy(S.dSphCull, sc.data(), sc.size() * sizeof(SphereCull), hipMemcpyHostToDevice));
@@ -1281,7 +1276,8 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     }
     S.ldsBytes = sizeof(MaterialDev) * nmats + kMiscWords * sizeof(uint32_t) +
                  (S.many ? manyHitBytes(ngeoms) + (size_t)k.nCubes * 54 * sizeof(float) + manyFramePad(k.nCubes) +
-                               (size_t)ngeoms * kSphRowFloats * sizeof(float) + (size_t)kListMax * kBlock * sizeof(uint16_t)
+                               (size_t)ngeoms * kSphRowFloats * sizeof(float) +
+                                   std::max((size_t)kListMax * kBlock, ((size_t)k.nSphCull + 7) / 8 * 8) * sizeof(uint16_t)
                          : sizeof(GeomHitDev) * ngeoms);
     if (S.ldsBytes > 160 * 1024) return fail(PT_ERR_INVALID, "pt_init: scene does not fit the 160 KiB LDS (%zu B)", S.ldsBytes);
     if (nmats >= 4096) return fail(PT_ERR_INVALID, "pt_init: more than 4095 materials");      // (TileArgs::hot holds nmats in 12 bits)
@@ -1843,6 +1839,36 @@ int pt_test_sphere_cull_sweep(const PtGeom *geoms, int ngeoms, uint64_t seed, in
     HIPCHECK(hipMemcpy(h, cnt.p, 16, hipMemcpyDeviceToHost));
     *culled = h[0];
     *violations = h[1];
+    return PT_OK;
+}
+
+int pt_test_sphere_halfline_sweep(const PtGeom *geoms, int ngeoms, uint64_t seed, int64_t rays, uint64_t *culled, uint64_t *behind,
+                                  uint64_t *violations) {
+    NEED_GPU();
+    if (!geoms || ngeoms < 1 || !culled || !behind || !violations || rays < 0) return fail(PT_ERR_INVALID, "pt_test_sphere_halfline_sweep: bad argument");
+    std::vector<GeomDev> hg(ngeoms);
+    for (int i = 0; i < ngeoms; ++i) {
+        if (geoms[i].type != PT_SPHERE) return fail(PT_ERR_INVALID, "pt_test_sphere_halfline_sweep: spheres only");
+        pack_geom(geoms[i], hg[i]);
+    }
+    DevBuf<GeomDev> dg;
+    DevBuf<unsigned long long> cnt;
+    UP(dg, hg.data(), ngeoms);
+    int rc = cnt.alloc(3);
+    if (rc) return rc;
+    HIPCHECK(hipMemset(cnt.p, 0, 24));
+    const int per_thread = 256, threads = 256;
+    long long blocks = (rays + (long long)per_thread * threads - 1) / ((long long)per_thread * threads);
+    if (blocks < 1) blocks = 1;
+    if (blocks > (1 << 20)) blocks = 1 << 20;
+    hipLaunchKernelGGL(k_sweep_sphere_halfline, dim3((unsigned)blocks), dim3(threads), 0, 0, dg.p, ngeoms, (unsigned long long)seed,
+                       per_thread, cnt.p, cnt.p + 1, cnt.p + 2);
+    HIPCHECK(hipDeviceSynchronize());
+    unsigned long long h[3] = {0, 0, 0};
+    HIPCHECK(hipMemcpy(h, cnt.p, 24, hipMemcpyDeviceToHost));
+    *culled = h[0];
+    *behind = h[1];
+    *violations = h[2];
     return PT_OK;
 }
 

@@ -135,6 +135,60 @@ __global__ void k_sweep_sphere_cull(const GeomDev *geoms, int ngeoms, unsigned l
     if (nv) atomicAdd(violations, (unsigned long long)nv);
 }
 
+// sphereHalfLineExcess soundness sweep (the certificate of k_bounce's packed sphere sweep, with the kernel's own approximate
+// normalisation of the direction): three families of rays per sphere -- (a) k_sweep_sphere_cull's (origins 1/64 .. 64 units away, aimed
+// within ~1.3 bounding radii of the centre; one in ten reversed), (b) origins ON the sphere's surface moved 1e-3 along the normal, as a
+// scatter leaves them, any direction (the sphere just left lies behind half of them, by next to nothing), (c) origins within 2 % of the
+// bounding ball's surface, inside and outside, any direction, directions not unit (|dir| in 0.999 .. 1.001 and 0.25 .. 4).
+// Counts certified misses, those certified with the centre BEHIND the origin, and VIOLATIONS (certified although the full test hits).
+__global__ void k_sweep_sphere_halfline(const GeomDev *geoms, int ngeoms, unsigned long long seed, int per_thread,
+                                        unsigned long long *culled, unsigned long long *behind, unsigned long long *violations) {
+    unsigned long long x = seed + (blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ull;
+    unsigned int nc = 0, nb = 0, nv = 0;
+    for (int k = 0; k < per_thread; ++k) {
+        float u[10];
+        for (int j = 0; j < 10; ++j) {
+            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+            u[j] = (float)(x >> 40) * (1.0f / 16777216.0f);
+        }
+        const GeomDev G = geoms[(blockIdx.x + k) % ngeoms];
+        const F3 c = f3(G.centre[0], G.centre[1], G.centre[2]);
+        const float R = __builtin_sqrtf(G.cullR2);
+        const F3 od = normalize(f3(u[1] - 0.5f, u[2] - 0.5f, u[3] - 0.5f));
+        const int family = k % 3;
+        F3 org, dir;
+        if (family == 0) {
+            org = c + od * __builtin_exp2f(u[0] * 12.0f - 6.0f);
+            dir = normalize(c + f3(u[4] - 0.5f, u[5] - 0.5f, u[6] - 0.5f) * (2.6f * R) - org);
+            if (u[7] < 0.1f) dir = -dir;
+        } else if (family == 1) {
+            // a point of the sphere itself: the image of a unit-diameter object-space point, then 1e-3 along +-the world normal
+            const F3 pobj = od * 0.5f;
+            const F3 P = mulMV(G.xf, pobj, 1.0f);
+            const F3 N = normalize(mulMV(G.invT, pobj, 0.0f));
+            org = P + N * (u[0] < 0.5f ? 0.001f : -0.001f);
+            dir = normalize(f3(u[4] - 0.5f, u[5] - 0.5f, u[6] - 0.5f));
+        } else {
+            org = c + od * (R * (0.98f + 0.04f * u[0]));
+            dir = normalize(f3(u[4] - 0.5f, u[5] - 0.5f, u[6] - 0.5f));
+        }
+        dir = dir * (u[8] < 0.5f ? 1.0f : (u[8] < 0.75f ? 0.999f + 0.002f * u[9] : __builtin_exp2f(4.0f * u[9] - 2.0f)));
+        const float dd = dot(dir, dir);
+        const F3 dhat = unitDirection(dir, dd);
+        if (sphereHalfLineExcess(c, G.cullK + kUnitDirSlack, org, dhat) > G.cullR2) {
+            ++nc;
+            if (dot(org - c, dhat) > 0.0f) ++nb;
+            F3 P, N;
+            bool o;
+            const float t = sphereIntersectionTest(G, org, dir, P, N, o);
+            if (t != -1.0f) ++nv;
+        }
+    }
+    if (nc) atomicAdd(culled, (unsigned long long)nc);
+    if (nb) atomicAdd(behind, (unsigned long long)nb);
+    if (nv) atomicAdd(violations, (unsigned long long)nv);
+}
+
 // wallCertainMiss soundness sweep: pseudo-random rays against every cube of `geoms` and its inflated world box `walls`
 // (origins inside the |x| + |y| + |z| bound the render kernel certifies under, from touching the cube to far away; aimed at
 // points on and around the cube so that grazes, edge-on plates and corner passes are dense; directions with exact zeros

@@ -110,7 +110,7 @@ struct KParams {
                                        // (= the scene's trace depth; traceDepth is then one more: the bounce that collects); 0 = off
     int   nEmit;                       // emissive primitives the direct-lighting bounce samples, at most kEmitMax (file order)
     int   nCubes;                      // cubes of the scene (sphere-heavy scenes: rows of the LDS frame table)
-    int   nSphCull;                    // sphere-heavy scenes: entries of BounceArgs::sphCull (even: padded with geom = -1)
+    int   nSphCull;                    // sphere-heavy scenes: entries of BounceArgs::sphCull (even: padded with a copy of the last one)
     int   classOff[kCls + 1];          // later bounces: the primitives a tile of class c has to look at are classIdx[classOff[c] ..
                                        // classOff[c + 1]) (BounceArgs::classIdx): not the binned ones unless the class says so, of the walls only
                                        // the class's own, in sphere-heavy scenes no sphere (those come from sphCull)
@@ -561,6 +561,10 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
                 const int g = i / 27, k = i - g * 27;
                 s_sph[g * kSphRowFloats + k] = k < 12 ? ggeoms[g].inv[k] : (k < 24 ? ggeoms[g].xf[k - 12] : ggeoms[g].invZ[k - 24]);
             }
+            if (!FIRST) {      // later bounces: entry k of the packed culling data -> its primitive (where the camera rays keep the lanes' lists)
+                uint16_t *const sphGeom = reinterpret_cast<uint16_t *>(s_sph + (size_t)ngeoms * kSphRowFloats);
+                for (int i = threadIdx.x; i < A->prm.nSphCull; i += kBlock) sphGeom[i] = (uint16_t)A->sphCull[i].geom;
+            }
         }
     }
     __syncthreads();
@@ -903,43 +907,66 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
             };
             if (MANY && !PACKED) candidatePass();
             if (PACKED) {
-                // Rounds: a lane records up to kListMax spheres per round; one that meets more resumes, in the next round, at
-                // the first sphere it could not record (rare: rays through a dense cluster).  Two spheres per 64-byte scalar load.
+                // The sweep keeps no list: the outcome of a sphere's bounding-ball test (sphereHalfLineExcess, pt_device.h) is SHIFTED into a per-lane bit mask (compare,
+                // then add-with-carry m = m + m + vcc: two instructions, no branch, no exec-mask change, no LDS), 64 spheres per
+                // round; the candidate passes then take each lane's set bits from the top.  (Rounds 1-3 recorded up to eight
+                // candidates per lane in LDS lists: ~8 vector instructions, two exec-mask regions and two branches per sphere on top
+                // of the 15 of the test.)  Two spheres per 64-byte scalar load.
                 const ArgsPtr A = launder(kargs);
-                const int nS = A->prm.nSphCull;
+                const int nS = A->prm.nSphCull;                       // (even: the host pads with a copy of the last sphere)
                 const PT_CAS SphereCull *sc = (const PT_CAS SphereCull *)(A->sphCull);
-                int resume = 0;
-                auto sweep = [&](auto firstRound) {
-                    constexpr bool kFirstRound = decltype(firstRound)::value;
-                    nCand = 0;
-                    int over = -1;
-                    for (int k = 0; k < nS; k += 2) {
-                        int16v v;
-                        asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(sc + k) : "memory");
+                const uint16_t *const sphGeom = s_list;               // [nS]: the primitive behind entry k (prologue)
+                const F3 dhat = unitDirection(dir, dd);
+                for (int base = 0; base < nS; base += 64) {           // (wave-uniform)
+                    uint32_t mHi = 0u, mLo = 0u;                      // entry base + j: bit 31 - j of mHi (j < 32) / of mLo
+                    if (inScene) {
+                        auto sweep32 = [&](int k0, uint32_t &m) {
+                            const int n = min(32, nS - k0);           // (even)
+                            if (n <= 0) return;
+                            for (int k = 0; k < n; k += 2) {
+                                int16v v;
+                                asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(sc + k0 + k) : "memory");
 #pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            CullGroup cg;
-                            cg.centre[0] = __int_as_float(v[8 * h]); cg.centre[1] = __int_as_float(v[8 * h + 1]); cg.centre[2] = __int_as_float(v[8 * h + 2]);
-                            cg.cullR2 = __int_as_float(v[8 * h + 3]); cg.cullK = __int_as_float(v[8 * h + 4]);
-                            const int g = v[8 * h + 5];
-                            if (g < 0) continue;                     // padding
-                            probe(3);
-                            if ((kFirstRound || k + h >= resume) && !certainMiss(cg, org, dir, dd)) {
-                                if (nCand < kListMax) {
-                                    s_list[nCand * kBlock + tid] = (uint16_t)g;
-                                    ++nCand;
-                                } else if (over < 0) {
-                                    over = k + h;
+                                for (int h = 0; h < 2; ++h) {
+                                    probe(3);
+                                    const float x = sphereHalfLineExcess(f3(__int_as_float(v[8 * h]), __int_as_float(v[8 * h + 1]), __int_as_float(v[8 * h + 2])),
+                                                                         __int_as_float(v[8 * h + 4]), org, dhat);
+                                    // candidate = !(cullR2 < x) (NaN: candidate), shifted in from below
+                                    asm("v_cmp_nlt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "s"(__int_as_float(v[8 * h + 3])), "v"(x) : "vcc");
                                 }
+                            }
+                            m <<= (32 - n);                           // (wave-uniform shift: entry k0 + j at bit 31 - j whatever n)
+                        };
+                        sweep32(base, mHi);
+                        sweep32(base + 32, mLo);
+                    }
+                    // pass k tests every lane's k-th candidate with that lane's own matrices from LDS
+                    while (__ballot((mHi | mLo) != 0u) != 0ull) {     // wave-uniform trip count
+                        if ((mHi | mLo) != 0u) {
+                            const bool hi = mHi != 0u;
+                            const uint32_t mm = hi ? mHi : mLo;
+                            const int j = __builtin_clz(mm);
+                            const uint32_t rest = mm & ~(0x80000000u >> j);
+                            mHi = hi ? rest : mHi;
+                            mLo = hi ? mLo : rest;
+                            const int g = sphGeom[base + (hi ? 0 : 32) + j];
+                            const float4 *row = reinterpret_cast<const float4 *>(s_sph + g * kSphRowFloats);
+                            float m[28];
+#pragma unroll
+                            for (int q = 0; q < 7; ++q) {
+                                const float4 v = row[q];
+                                m[4 * q] = v.x; m[4 * q + 1] = v.y; m[4 * q + 2] = v.z; m[4 * q + 3] = v.w;
+                            }
+                            F3 p, n;
+                            bool o = false;
+                            probe(4);
+                            const float t = sphereIntersectionTestM<false>(m, m + 24, m + 12, m, org, dir, p, n, o);
+                            // nearest by (distance, file order): a sphere may precede the primitive that holds the record so far
+                            if (t > 0.0f && (hit < 0 || t < tbest || (t == tbest && g < hit))) {
+                                tbest = t; hit = g; P = p; nsrc = n; outsideI = o ? 1 : 0;
                             }
                         }
                     }
-                    candidatePass();
-                    resume = over < 0 ? 0x7fffffff : over;          // (a lane that recorded everything takes no further part)
-                    return __ballot(over >= 0) != 0ull;
-                };
-                if (inScene && sweep(std::true_type{})) {
-                    while (sweep(std::false_type{})) {}
                 }
             }
             probe(16);                                          // (shading)

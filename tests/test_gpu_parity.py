@@ -130,6 +130,26 @@ def test_sphere_culling_never_rejects_a_hit(gpu, oracle):
     assert culled > (1 << 28) // 10           # the shortcut actually fires (most sweep rays are aimed at the sphere)
 
 
+def test_sphere_halfline_certificate_never_rejects_a_hit(gpu, oracle):
+    # sphereHalfLineExcess -- what the sphere-heavy sweep of the later bounces certifies a miss with: the centre's distance from the
+    # HALF-line, the direction normalised approximately -- is a sufficient condition for the reference's miss, `radicand < 0` or
+    # `t1 < 0 && t2 < 0` (src/intersections.h:114, 121-123).  2^28 rays: aimed near the ball from 1/64 .. 64 units, leaving the
+    # sphere's own surface the way a scatter does (+-1e-3 along the normal), starting within 2 % of the bounding ball's surface;
+    # directions unit, nearly unit and far from unit.
+    geoms = np.concatenate([
+        oracle.make_geom(0, 0, (-1, 4, -1), (0, 0, 0), (3, 3, 3)),            # Cornell sphere
+        oracle.make_geom(0, 0, (1, 2, 3), (30, 45, 60), (1, 2, 3)),           # ellipsoid
+        oracle.make_geom(0, 0, (0, 0, 0), (0, 0, 0), (0.6, 0.6, 0.6)),        # C5-sized
+        oracle.make_geom(0, 0, (2.5, 6, -2), (10, 20, 30), (0.05, 0.05, 0.05)),
+        oracle.make_geom(0, 0, (-3, 1, 2), (75, -20, 130), (8, 0.5, 3)),      # 16:1 anisotropy
+        oracle.make_geom(0, 0, (100, -50, 25), (0, 0, 0), (40, 40, 40)),
+        oracle.make_geom(0, 0, (4.1, 8.7, -3.3), (0, 0, 0), (1.1, 1.1, 1.1)),
+    ]).view(gpu.GEOM_DTYPE)
+    culled, behind, bad = gpu.test_sphere_halfline_sweep(geoms, 2026, 1 << 28)
+    assert bad == 0
+    assert culled > (1 << 28) // 5 and behind > (1 << 28) // 16      # both branches of the certificate fire, by the tens of millions
+
+
 def test_cube_culling_never_rejects_a_hit(gpu, oracle):
     # the same bounding-ball test decides which queue tiles skip the scene's small cubes (k_bounce bins survivors by
     # it): it must imply the reference's own miss for cubes of every shape -- the Cornell light and walls, thin plates
