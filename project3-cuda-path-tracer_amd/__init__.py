@@ -127,7 +127,7 @@ def _bind(L, with_tests):
         L.pt_test_pow.argtypes = [vp, vp, i32, vp]
         L.pt_test_wall_box_sweep.argtypes = [vp, i32, C.c_uint64, i64, u64p, u64p]
         L.pt_test_mesh_intersect.argtypes = [vp, vp, i32, i32, vp, i32, vp, vp, vp, vp, vp]
-        L.pt_test_mesh_bvh.argtypes = [vp, i32, i32, vp, C.POINTER(C.c_int)]
+        L.pt_test_mesh_bvh.argtypes = [vp, i32, i32, vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.pt_test_mesh_cull_sweep.argtypes = [vp, vp, i32, C.c_uint64, i64] + [u64p] * 3
         L.pt_test_camera_cull_sweep.argtypes = [vp, vp, i32, i32] + [u64p] * 3
         L.pt_test_camera_cull_tables.argtypes = [vp, vp, i32, vp, vp, vp]
@@ -457,15 +457,26 @@ def test_mesh_cull_sweep(geom, tris, seed, rays):
     return c.value, v.value, h.value
 
 
+MESH_LEAF = 0x80000000
+# the two kinds of 64-byte record of a mesh (pt_device.h: MeshRec)
+MESH_TRI_DTYPE = np.dtype([("v0", "<f4", 3), ("e1", "<f4", 3), ("e2", "<f4", 3), ("lo", "<f4", 3), ("hi", "<f4", 3), ("pad", "<u4")])
+MESH_NODE_DTYPE = np.dtype([("planes", "<f2", 6), ("ref", "<u4"), ("far_planes", "<f2", 6), ("far_ref", "<u4")])
+
+
 def mesh_bvh(tris, octant=0):
     """The hierarchy pt_init builds for a mesh (host only), in the layout for rays of direction octant `octant` (bit a set:
-    component a negative): structured array of nodes (lo, skip, hi, tri)."""
+    component a negative) -> (triangle records [ntris], inner nodes [max(ntris - 1, 1)], stack levels a lane needs).  A node holds
+    the boxes and refs of its near (planes, ref) and far (far_planes, far_ref) child, a box as six half-precision planes: the
+    three a ray of the octant enters through (lo where its direction is positive, hi where negative), then the three it leaves
+    through; lo rounded down, hi up.  A ref with MESH_LEAF set is triangle (ref & ~MESH_LEAF) / 2, any other is inner node
+    ref - 2 ntris (refs count units of 32 bytes: a triangle takes two)."""
     tr = np.ascontiguousarray(tris, np.float32).reshape(-1, 9)
-    node = np.dtype([("lo", "<f4", 3), ("skip", "<u4"), ("hi", "<f4", 3), ("tri", "<i4")])
-    out = np.zeros(2 * len(tr), node)
-    n = C.c_int(len(out))
-    _tcheck(test_lib().pt_test_mesh_bvh(_p(tr), len(tr), octant, _p(out), C.byref(n)))
-    return out[:n.value]
+    out = np.zeros((3 * len(tr) + 1, 8), np.uint32)
+    n, need = C.c_int(len(out)), C.c_int(0)
+    _tcheck(test_lib().pt_test_mesh_bvh(_p(tr), len(tr), octant, _p(out), C.byref(n), C.byref(need)))
+    assert n.value == 2 * len(tr) + max(len(tr) - 1, 1)
+    return (out[:2 * len(tr)].reshape(-1).view(MESH_TRI_DTYPE).reshape(-1), out[2 * len(tr):n.value].reshape(-1).view(MESH_NODE_DTYPE).reshape(-1),
+            need.value)
 
 
 def test_hemisphere(normals, iter_index_depth):

@@ -105,8 +105,7 @@ struct State {
     SphereCull *dSphCull = nullptr; // sphere-heavy scenes: packed culling data of the spheres, and ...
     int *dRowOff = nullptr, *dRowIdx = nullptr;   // camera-ray bounce: per image row, the primitives whose pixel rectangle covers it
     int *dClassIdx = nullptr;       // later bounces: per queue class, the primitives to look at (KParams::classOff)
-    float4 *dMeshNodes = nullptr;   // ptd::MeshNode[] / MeshTri[] of every mesh of the scene (k_bounce<., ., ., true>)
-    float4 *dMeshTris = nullptr;
+    float4 *dMeshRecs = nullptr;    // ptd::MeshUnit[]: triangles and inner nodes of every mesh of the scene (k_bounce<., ., ., true>)
     bool mesh = false;      // the scene holds triangle meshes: the k_bounce<., false, ., true> variants
     int numTilesMax = 0;    // upper bound of tiles in one bounce queue (incl. one partial tile per segment)
     int poolChunks = 0;     // chunks per path pool (incl. the trash chunk 0); a pool holds poolChunks * kChunk paths per array
@@ -704,7 +703,7 @@ int launch_bounce(Slot &sl, int iter, int batch, int depth, bool lastBounce, flo
     ba.sphCull = S.dSphCull; ba.classIdx = S.dClassIdx;
     ba.rowOff = S.dRowOff; ba.rowIdx = S.dRowIdx;
     ba.walls = S.dwalls;
-    ba.meshNodes = S.dMeshNodes; ba.meshTris = S.dMeshTris;
+    ba.meshRecs = S.dMeshRecs;
     ba.hostFault = S.hostFaultDev;
     void *kargs[] = {&ba};
     const bool first = depth == 1;
@@ -935,8 +934,7 @@ void pt_free(void) {
     if (S.dClassIdx) (void)hipFree(S.dClassIdx);
     if (S.dRowOff) (void)hipFree(S.dRowOff);
     if (S.dRowIdx) (void)hipFree(S.dRowIdx);
-    if (S.dMeshNodes) (void)hipFree(S.dMeshNodes);
-    if (S.dMeshTris) (void)hipFree(S.dMeshTris);
+    if (S.dMeshRecs) (void)hipFree(S.dMeshRecs);
     S = State();
 }
 
@@ -1122,9 +1120,9 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
 
     std::vector<GeomDev> hg(ngeoms ? ngeoms : 1);
     std::vector<MaterialDev> hm(nmats ? nmats : 1);
-    // triangle meshes: one node / triangle array for the scene, a hierarchy per mesh (pt_mesh.h)
-    std::vector<ptd::MeshNode> meshNodes;
-    std::vector<ptd::MeshTri> meshTris;
+    // triangle meshes: one record array for the scene, a hierarchy per mesh (pt_mesh.h)
+    std::vector<ptd::MeshUnit> meshRecs;
+    int meshStackNeed = 0;
     const bool flatMeshes = getenv("PT_AMD_MESH_FLAT") && atoi(getenv("PT_AMD_MESH_FLAT"));   // tests only: no hierarchy
     std::vector<std::array<float, 6>> meshBox(ngeoms ? ngeoms : 1);
     std::vector<const float *> boxes(ngeoms ? ngeoms : 1, nullptr);
@@ -1135,9 +1133,11 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
         uint32_t root = ptd::kMeshEnd, stride = 0;
         if (isMesh) {
             const ptm::HostMesh *hm_ = mesh_of(i);
-            root = (uint32_t)meshNodes.size();
-            stride = ptm::appendMesh(hm_->tris.data(), (int)(hm_->tris.size() / 9), flatMeshes, meshNodes, meshTris, box);
-            if (meshNodes.size() >= (1ull << 31)) return fail(PT_ERR_INVALID, "pt_init: too many triangles");
+            const ptm::MeshLayout lay = ptm::appendMesh(hm_->tris.data(), (int)(hm_->tris.size() / 9), flatMeshes, meshRecs, box);
+            root = lay.root;
+            stride = lay.stride;
+            meshStackNeed = std::max(meshStackNeed, lay.stackNeed);
+            if (meshRecs.size() >= (1ull << 31)) return fail(PT_ERR_INVALID, "pt_init: too many triangles");
         }
         pack_geom(geoms[i], hg[i], k.pos, isMesh ? box : nullptr);
         hg[i].meshRoot = root;
@@ -1218,12 +1218,10 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     HIPCHECK(hipMemcpy(S.dmats, hm.data(), hm.size() * sizeof(MaterialDev), hipMemcpyHostToDevice));
     HIPCHECK(hipMalloc(&S.dwalls, hw.size() * sizeof(WallBox)));
     HIPCHECK(hipMemcpy(S.dwalls, hw.data(), hw.size() * sizeof(WallBox), hipMemcpyHostToDevice));
-    S.mesh = !meshNodes.empty();
+    S.mesh = !meshRecs.empty();
     if (S.mesh) {
-        HIPCHECK(hipMalloc(&S.dMeshNodes, meshNodes.size() * sizeof(ptd::MeshNode)));
-        HIPCHECK(hipMalloc(&S.dMeshTris, meshTris.size() * sizeof(ptd::MeshTri)));
-        HIPCHECK(hipMemcpy(S.dMeshNodes, meshNodes.data(), meshNodes.size() * sizeof(ptd::MeshNode), hipMemcpyHostToDevice));
-        HIPCHECK(hipMemcpy(S.dMeshTris, meshTris.data(), meshTris.size() * sizeof(ptd::MeshTri), hipMemcpyHostToDevice));
+        HIPCHECK(hipMalloc(&S.dMeshRecs, meshRecs.size() * sizeof(ptd::MeshUnit)));
+        HIPCHECK(hipMemcpy(S.dMeshRecs, meshRecs.data(), meshRecs.size() * sizeof(ptd::MeshUnit), hipMemcpyHostToDevice));
     }
 
     int nspheres = 0;
@@ -1279,6 +1277,11 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
                                (size_t)ngeoms * kSphRowFloats * sizeof(float) +
                                    std::max((size_t)kListMax * kBlock, ((size_t)k.nSphCull + 7) / 8 * 8) * sizeof(uint16_t)
                          : sizeof(GeomHitDev) * ngeoms);
+    if (S.mesh) {        // the lanes' stacks of far children (ptd::meshIntersectionTest): kBlock words per level, behind everything else
+        S.ldsBytes = (S.ldsBytes + 15) / 16 * 16;
+        k.meshStackOff = (int)S.ldsBytes;
+        S.ldsBytes += (size_t)std::max(meshStackNeed, 1) * kBlock * sizeof(uint32_t);
+    }
     if (S.ldsBytes > 160 * 1024) return fail(PT_ERR_INVALID, "pt_init: scene does not fit the 160 KiB LDS (%zu B)", S.ldsBytes);
     if (nmats >= 4096) return fail(PT_ERR_INVALID, "pt_init: more than 4095 materials");      // (TileArgs::hot holds nmats in 12 bits)
     const void *kFirst = bounce_kernel(true, S.dof);
@@ -1726,29 +1729,28 @@ int pt_test_mesh_intersect(const PtGeom *geom, const float *tris, int ntris, int
     NEED_GPU();
     if (!geom || !tris || ntris < 1 || geom->type != PT_MESH) return fail(PT_ERR_INVALID, "pt_test_mesh_intersect: bad argument");
     if (n <= 0) return PT_OK;
-    std::vector<ptd::MeshNode> nodes;
-    std::vector<ptd::MeshTri> mt;
+    std::vector<ptd::MeshUnit> recs;
     float box[6];
-    const uint32_t stride = ptm::appendMesh(tris, ntris, flat != 0, nodes, mt, box);
+    const ptm::MeshLayout lay = ptm::appendMesh(tris, ntris, flat != 0, recs, box);
     GeomDev hg;
     pack_geom(*geom, hg, nullptr, box);
-    hg.meshRoot = 0;
-    hg.meshStride = stride;
+    hg.meshRoot = lay.root;
+    hg.meshStride = lay.stride;
     DevBuf<GeomDev> dg;
-    DevBuf<ptd::MeshNode> dn_;
-    DevBuf<ptd::MeshTri> dtr;
+    DevBuf<ptd::MeshUnit> drec;
     DevBuf<int> dout, dcull;
     DevBuf<float> dr, dt, dp, dn;
     UP(dg, &hg, 1);
-    UP(dn_, nodes.data(), nodes.size());
-    UP(dtr, mt.data(), mt.size());
+    UP(drec, recs.data(), recs.size());
     UP(dr, rays, (size_t)n * 6);
     UP(dp, p3, (size_t)n * 3);
     UP(dn, n3, (size_t)n * 3);
     UP(dout, outside, n);
     int rc = dt.alloc(n); if (rc) return rc;
     rc = dcull.alloc(n); if (rc) return rc;
-    hipLaunchKernelGGL(k_test_mesh, GRID(n), dg.p, reinterpret_cast<const float4 *>(dn_.p), reinterpret_cast<const float4 *>(dtr.p),
+    const size_t stackBytes = (size_t)std::max(lay.stackNeed, 1) * 256 * sizeof(uint32_t);
+    if (stackBytes > 64 * 1024) return fail(PT_ERR_INVALID, "pt_test_mesh_intersect: the hierarchy needs %d stack levels", lay.stackNeed);
+    hipLaunchKernelGGL(k_test_mesh, dim3((unsigned)((n + 255) / 256)), dim3(256), stackBytes, 0, dg.p, reinterpret_cast<const float4 *>(drec.p),
                        dr.p, n, dt.p, dp.p, dn.p, dout.p, dcull.p);
     HIPCHECK(hipDeviceSynchronize());
     DOWN(t, dt, n);
@@ -1764,22 +1766,19 @@ int pt_test_mesh_cull_sweep(const PtGeom *geom, const float *tris, int ntris, ui
     NEED_GPU();
     if (!geom || !tris || ntris < 1 || geom->type != PT_MESH || !culled || !violations || !hits || rays < 0)
         return fail(PT_ERR_INVALID, "pt_test_mesh_cull_sweep: bad argument");
-    std::vector<ptd::MeshNode> nodes;
-    std::vector<ptd::MeshTri> mt;
+    std::vector<ptd::MeshUnit> recs;
     float box[6];
-    const uint32_t stride = ptm::appendMesh(tris, ntris, false, nodes, mt, box);
+    const ptm::MeshLayout lay = ptm::appendMesh(tris, ntris, false, recs, box);
     GeomDev hg;
     pack_geom(*geom, hg, nullptr, box);
-    hg.meshRoot = 0;
-    hg.meshStride = stride;
+    hg.meshRoot = lay.root;
+    hg.meshStride = lay.stride;
     if (!std::isfinite(hg.cullR2)) return fail(PT_ERR_INVALID, "pt_test_mesh_cull_sweep: this mesh is never culled");
     DevBuf<GeomDev> dg;
-    DevBuf<ptd::MeshNode> dn_;
-    DevBuf<ptd::MeshTri> dtr;
+    DevBuf<ptd::MeshUnit> drec;
     DevBuf<unsigned long long> cnt;
     UP(dg, &hg, 1);
-    UP(dn_, nodes.data(), nodes.size());
-    UP(dtr, mt.data(), mt.size());
+    UP(drec, recs.data(), recs.size());
     int rc = cnt.alloc(3);
     if (rc) return rc;
     HIPCHECK(hipMemset(cnt.p, 0, 24));
@@ -1787,8 +1786,10 @@ int pt_test_mesh_cull_sweep(const PtGeom *geom, const float *tris, int ntris, ui
     long long blocks = (rays + (long long)per_thread * threads - 1) / ((long long)per_thread * threads);
     if (blocks < 1) blocks = 1;
     if (blocks > (1 << 20)) blocks = 1 << 20;
-    hipLaunchKernelGGL(k_sweep_mesh_cull, dim3((unsigned)blocks), dim3(threads), 0, 0, dg.p, reinterpret_cast<const float4 *>(dn_.p),
-                       reinterpret_cast<const float4 *>(dtr.p), (unsigned long long)seed, per_thread, cnt.p, cnt.p + 1, cnt.p + 2);
+    const size_t stackBytes = (size_t)std::max(lay.stackNeed, 1) * 256 * sizeof(uint32_t);
+    if (stackBytes > 64 * 1024) return fail(PT_ERR_INVALID, "pt_test_mesh_cull_sweep: the hierarchy needs %d stack levels", lay.stackNeed);
+    hipLaunchKernelGGL(k_sweep_mesh_cull, dim3((unsigned)blocks), dim3(threads), stackBytes, 0, dg.p, reinterpret_cast<const float4 *>(drec.p),
+                       (unsigned long long)seed, per_thread, cnt.p, cnt.p + 1, cnt.p + 2);
     HIPCHECK(hipDeviceSynchronize());
     unsigned long long h[3] = {0, 0, 0};
     HIPCHECK(hipMemcpy(h, cnt.p, 24, hipMemcpyDeviceToHost));
@@ -1799,20 +1800,25 @@ int pt_test_mesh_cull_sweep(const PtGeom *geom, const float *tris, int ntris, ui
 }
 
 // host only: no GPU is touched
-int pt_test_mesh_bvh(const float *tris, int ntris, int octant, uint32_t *nodes8, int *nnodes) {
-    if (!tris || ntris < 1 || !nodes8 || !nnodes || octant < 0 || octant > 7) return fail(PT_ERR_INVALID, "pt_test_mesh_bvh: bad argument");
-    std::vector<ptd::MeshNode> nodes;
-    std::vector<ptd::MeshTri> mt;
+int pt_test_mesh_bvh(const float *tris, int ntris, int octant, uint32_t *units8, int *nrecs, int *stack_need) {
+    if (!tris || ntris < 1 || !units8 || !nrecs || !stack_need || octant < 0 || octant > 7) return fail(PT_ERR_INVALID, "pt_test_mesh_bvh: bad argument");
+    std::vector<ptd::MeshUnit> recs;
     float box[6];
-    const uint32_t stride = ptm::appendMesh(tris, ntris, false, nodes, mt, box);
-    if ((int)stride > *nnodes) return fail(PT_ERR_INVALID, "pt_test_mesh_bvh: %u nodes do not fit %d", stride, *nnodes);
-    // the copy of this octant, its links rebased to the copy's first node
-    for (uint32_t i = 0; i < stride; ++i) {
-        ptd::MeshNode n = nodes[(size_t)octant * stride + i];
-        if (n.skip != ptd::kMeshEnd) n.skip -= (uint32_t)octant * stride;
-        memcpy(nodes8 + 8 * (size_t)i, &n, sizeof n);
+    const ptm::MeshLayout lay = ptm::appendMesh(tris, ntris, false, recs, box);
+    const uint32_t total = 2u * (uint32_t)ntris + lay.stride;        // units: the triangles (two each), then this octant's inner nodes
+    if ((int)total > *nrecs) return fail(PT_ERR_INVALID, "pt_test_mesh_bvh: %u units do not fit %d", total, *nrecs);
+    // refs rebased: triangle i -> kMeshLeaf | 2 i, inner node j of the copy -> 2 ntris + j
+    const uint32_t innerBase = 2u * (uint32_t)ntris + (uint32_t)octant * lay.stride;
+    auto rebase = [&](uint32_t r) { return (r & ptd::kMeshLeaf) ? r : r - innerBase + 2u * (uint32_t)ntris; };
+    memcpy(units8, recs.data(), (size_t)ntris * 2 * sizeof(ptd::MeshUnit));
+    for (uint32_t j = 0; j < lay.stride; ++j) {
+        ptd::MeshUnit n = recs[(size_t)innerBase + j];
+        n.w[3] = rebase(n.w[3]);
+        n.w[7] = rebase(n.w[7]);
+        memcpy(units8 + 8 * (2 * (size_t)ntris + j), &n, sizeof n);
     }
-    *nnodes = (int)stride;
+    *nrecs = (int)total;
+    *stack_need = lay.stackNeed;
     return PT_OK;
 }
 

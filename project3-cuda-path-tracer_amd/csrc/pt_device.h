@@ -678,25 +678,37 @@ __device__ __forceinline__ float sphereIntersectionTest(const GD &g, F3 ro_w, F3
 // test of the triangle's own bounding box (inflated by a per-mesh margin), and its hit counts only at or beyond that box's
 // entry parameter; nearest = smallest object-space t, ties to the lower triangle index.  Every part of that rule is local
 // to (ray, triangle), and fp32 subtraction, multiplication by a common factor and comparison are monotone: a ray that
-// passes a box's test passes the test of every box that contains it.  So the threaded bounding-volume hierarchy below
+// passes a box's test passes the test of every box that contains it.  So the bounding-volume hierarchy below
 // (node boxes = exact unions of their triangles' boxes) visits every triangle the brute-force rule accepts, and a node
 // whose entry parameter lies beyond the best hit so far cannot hold a better one: bit-identical results in any order.
 //
-// Nodes in depth-first order, 32 B each: an inner node is followed by its first child; `skip` is the next node when the
-// subtree is left (kMeshEnd after the mesh's last); a leaf (tri >= 0) is one triangle and its box.  No stack, no LDS.
-// The hierarchy is stored once per sign octant of the ray direction, nearer child first (pt_mesh.h): a ray walks its
-// octant's copy front to back.
-struct MeshNode {
-    float    lo[3];
-    uint32_t skip;
-    float    hi[3];
-    int32_t  tri;        // -1: inner node; else index into the triangle array
+// ONE array per scene, addressed in units of 32 bytes by a 31-bit index (`ref`, bit 31 = the record is a triangle), two kinds of record:
+//   inner node (one unit):   the boxes of BOTH its children and their refs -- a visit decides about two subtrees.  The boxes are
+//                            stored as the planes a ray enters / leaves through (below) in HALF precision, rounded outwards: an inner
+//                            box only has to CONTAIN what lies below it (a ray that passes a box passes every box around it), and a
+//                            visit is what the walk pays for: the texture addresser is busy 16 cycles per 16-byte-per-lane load,
+//                            however few lanes take part, and it is what bounds a mesh scene (profiles/r03_mesh_walk_experiments.txt:
+//                            TA_BUSY 80 % of a launch);
+//   triangle (two units):    v0, e1, e2 and the triangle's own inflated box in full precision (the box the semantics test).
+// Rounds 1-2 walked 32-byte full-precision nodes in depth-first order with skip links, no stack: every child of a visited node, hit
+// or missed, was a visit of its own (2 I + 1 for a ray that passes I inner nodes), and a leaf two fetches (its node, then its triangle).
+// Here the far child of a node whose children both pass waits on a short per-lane stack in LDS (slots kBlock words apart: lanes never
+// share a bank; its depth is the scene's, computed by pt_init), and a ray asks for 2 I + 4 T loads instead of 4 I + 2 + 5 T.
+// Inner nodes are stored once per sign octant of the ray direction, nearer child first (pt_mesh.h): a ray walks its octant's copy
+// front to back, so the first hits prune most of what lies behind them; the triangles, in file order, once.
+struct MeshUnit {
+    uint32_t w[8];
 };
-struct MeshTri {         // v0, e1 = v1 - v0, e2 = v2 - v0 (the subtractions glm does first, evaluated once on the host)
-    float v0[3], e1[3], e2[3], pad[3];
-};
-static_assert(sizeof(MeshNode) == 32 && sizeof(MeshTri) == 48, "two / three float4 loads");
-constexpr uint32_t kMeshEnd = 0xffffffffu;
+// inner node: w[0..2] the near child's planes as six halves -- entry x, y, z, exit x, y, z --, w[3] its ref, w[4..6] / w[7] the far child's.
+//             The copy of an octant knows the sign of every direction component, hence which of a box's two planes per axis a ray of
+//             that octant meets first (lo where the component is positive, hi where it is negative): min(fma(lo, inv, rc),
+//             fma(hi, inv, rc)) IS the entry plane's parameter (fma is monotone in its first operand) -- the hierarchy stores the
+//             planes in that order and the six min / max per box of the slab test are gone.  lo is rounded down, hi up.
+// triangle:   floats 0..2 v0, 3..5 e1 = v1 - v0, 6..8 e2 = v2 - v0 (the subtractions glm does first, evaluated once on the host),
+//             9..11 box lo, 12..14 box hi
+static_assert(sizeof(MeshUnit) == 32, "two float4 loads");
+constexpr uint32_t kMeshEnd = 0xffffffffu;                 // GeomDev::meshRoot of a primitive that is not a mesh
+constexpr uint32_t kMeshLeaf = 0x80000000u;
 constexpr float kMeshEps = 1.1920928955078125e-07f;        // std::numeric_limits<float>::epsilon(), intersect.inl:50
 constexpr float kMeshUp = 1.00001f, kMeshDn = 0.99999f;    // relative slack of the slab comparison
 
@@ -724,51 +736,98 @@ __device__ __forceinline__ bool meshTriangle(F3 o, F3 d, F3 v0, F3 e1, F3 e2, fl
     return t >= 0.0f;
 }
 
-// One ray against one mesh.  `nodes` / `tris`: the scene's node and triangle arrays (per-lane loads: every lane walks its
-// own way through the hierarchy), `root`: the mesh's first node.  Outputs as the sphere test's (P world point, nsrc the
+// the slab test of one box, the semantics' own (fma form, see below): entry parameter scaled down, pass = not certainly missed
+// and not certainly behind the best hit so far
+__device__ __forceinline__ bool meshBoxPass(F3 lo, F3 hi, F3 inv, F3 rc, bool haveBest, float tbest, float &tmin) {
+    const float ax = __builtin_fmaf(lo.x, inv.x, rc.x), bx = __builtin_fmaf(hi.x, inv.x, rc.x);
+    const float ay = __builtin_fmaf(lo.y, inv.y, rc.y), by = __builtin_fmaf(hi.y, inv.y, rc.y);
+    const float az = __builtin_fmaf(lo.z, inv.z, rc.z), bz = __builtin_fmaf(hi.z, inv.z, rc.z);
+    const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
+    const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
+    tmin = tn * kMeshDn;
+    // (a box whose entry parameter lies beyond the best hit cannot improve on it: accepted hits have t >= tmin)
+    return (tf * kMeshUp >= tmin) & (tf >= 0.0f) & (!haveBest | !(tmin > tbest));
+}
+
+// ... and of a child's box inside an inner node of the ray's octant copy: entry / exit planes as stored (see MeshUnit), three words of
+// two halves each.  The parameters meshBoxPass would compute from the rounded (lo, hi); an operand that is NaN (inf - inf: coordinates
+// beyond 1e8) drops out of max3 / min3, i.e. leaves the test more permissive, which an inner node may always be.
+__device__ __forceinline__ float halfLo(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xffffu)); }
+__device__ __forceinline__ float halfHi(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16)); }
+__device__ __forceinline__ bool meshPlanesPass(uint32_t w0, uint32_t w1, uint32_t w2, F3 inv, F3 rc, bool haveBest, float tbest) {
+    const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(halfLo(w0), inv.x, rc.x), __builtin_fmaf(halfHi(w0), inv.y, rc.y)),
+                                     __builtin_fmaf(halfLo(w1), inv.z, rc.z));
+    const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaf(halfHi(w1), inv.x, rc.x), __builtin_fmaf(halfLo(w2), inv.y, rc.y)),
+                                     __builtin_fmaf(halfHi(w2), inv.z, rc.z));
+    const float tmin = tn * kMeshDn;
+    return (tf * kMeshUp >= tmin) & (tf >= 0.0f) & (!haveBest | !(tmin > tbest));
+}
+
+// One ray against one mesh.  `recs`: the scene's record array (per-lane loads: every lane walks its own way through the
+// hierarchy), `root`: the ref of the mesh's root node in the copy of octant 0, `stride`: inner nodes per copy.  `stack`: this lane's
+// first stack slot (LDS), the next ones STRIDE words apart.  Outputs as the sphere test's (P world point, nsrc the
 // object-space vector the normal is made of -- here the unit face normal -- and `outside` = front side).
 // (NaN operands: every triangle test fails whatever the slab tests say -- a, or s, is NaN -- like in the oracle's loop.)
-template <bool CAM_ORIGIN = false, typename GD>
-__device__ __forceinline__ float meshIntersectionTest(const GD &g, const float4 *nodes, const float4 *tris, uint32_t root,
-                                                      uint32_t stride, F3 ro_w, F3 rd_w, F3 &P, F3 &nsrc, bool &outside) {
+template <bool CAM_ORIGIN = false, int STRIDE = 256, typename GD>
+__device__ __forceinline__ float meshIntersectionTest(const GD &g, const float4 *recs, uint32_t root, uint32_t stride, uint32_t *stack,
+                                                      F3 ro_w, F3 rd_w, F3 &P, F3 &nsrc, bool &outside) {
     const F3 ro = CAM_ORIGIN ? f3(g.camObj[0], g.camObj[1], g.camObj[2]) : mulMV(g.inv, ro_w, 1.0f);
     const F3 rd = normalize(mulMV0(g.inv, g.invZ, rd_w));
     const F3 inv = f3(guardedReciprocal(rd.x), guardedReciprocal(rd.y), guardedReciprocal(rd.z));
     // the parameter of a box plane x = lo is ONE fused multiply-add, fma(lo, inv, rc) with rc = -(ro * inv): a single rounding of
-    // lo * inv - fl(ro * inv), monotone in lo like the subtract-then-multiply form, at a third fewer instructions per node
+    // lo * inv - fl(ro * inv), monotone in lo like the subtract-then-multiply form, at a third fewer instructions per box
     const F3 rc = f3(-(ro.x * inv.x), -(ro.y * inv.y), -(ro.z * inv.z));
-    int best = -1;
+    int best = -1;                                          // unit index of the best triangle so far (file order within a mesh)
     float tbest = 0.0f;
     uint32_t bestFront = 0u;
-    const uint32_t octant = (rd.x < 0.0f ? 1u : 0u) | (rd.y < 0.0f ? 2u : 0u) | (rd.z < 0.0f ? 4u : 0u);
-    uint32_t node = root + octant * stride;
-    while (node != kMeshEnd) {
-        const float4 n0 = nodes[2 * (size_t)node], n1 = nodes[2 * (size_t)node + 1];
-        const float ax = __builtin_fmaf(n0.x, inv.x, rc.x), bx = __builtin_fmaf(n1.x, inv.x, rc.x);
-        const float ay = __builtin_fmaf(n0.y, inv.y, rc.y), by = __builtin_fmaf(n1.y, inv.y, rc.y);
-        const float az = __builtin_fmaf(n0.z, inv.z, rc.z), bz = __builtin_fmaf(n1.z, inv.z, rc.z);
-        const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
-        const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
-        const float tmin = tn * kMeshDn;
-        const int tri = __float_as_int(n1.w);
-        // (a node whose entry parameter lies beyond the best hit cannot improve on it: accepted hits have t >= tmin)
-        const bool pass = (tf * kMeshUp >= tmin) & (tf >= 0.0f) & ((best < 0) | !(tmin > tbest));
-        if (pass && tri >= 0) {
-            const float4 a = tris[3 * (size_t)tri], b = tris[3 * (size_t)tri + 1], c = tris[3 * (size_t)tri + 2];
-            float t;
-            bool front;
-            if (meshTriangle(ro, rd, f3(a.x, a.y, a.z), f3(a.w, b.x, b.y), f3(b.z, b.w, c.x), t, front)) {
-                if ((t >= tmin) & ((best < 0) | (t < tbest) | ((t == tbest) & (tri < best)))) {
-                    best = tri;
-                    tbest = t;
-                    bestFront = front ? 1u : 0u;
+    // (the octant is read off the SIGN BITS of the reciprocals, the operands of the plane parameters: a component of -0 counts as negative)
+    const uint32_t octant = (__float_as_uint(inv.x) >> 31) | ((__float_as_uint(inv.y) >> 31) << 1) | ((__float_as_uint(inv.z) >> 31) << 2);
+    uint32_t ref = root + octant * stride;
+    uint32_t *sp = stack;
+    constexpr uint32_t kDone = 0xffffffffu;                 // (reads as a triangle's ref: the loop over inner nodes stops on it)
+    auto pop = [&]() -> uint32_t {
+        if (sp == stack) return kDone;
+        sp -= STRIDE;
+        return *sp;
+    };
+    // Inner nodes until the lane holds a triangle (or nothing), THEN the triangle: the lanes of a wave leave the inner loop together, so
+    // the triangle code -- twice an inner step's instructions -- runs once for all the triangles they found instead of at every step
+    // at which some lane happens to hold one (one loop over both kinds of record ran both halves at four steps out of five).
+    for (;;) {
+        while (!(ref & kMeshLeaf)) {
+            const float4 *r = recs + 2 * (size_t)ref;
+            const float4 q0 = r[0], q1 = r[1];
+            const bool passN = meshPlanesPass(__float_as_uint(q0.x), __float_as_uint(q0.y), __float_as_uint(q0.z), inv, rc, best >= 0, tbest);
+            const bool passF = meshPlanesPass(__float_as_uint(q1.x), __float_as_uint(q1.y), __float_as_uint(q1.z), inv, rc, best >= 0, tbest);
+            const uint32_t refN = __float_as_uint(q0.w), refF = __float_as_uint(q1.w);
+            if (passN & passF) {
+                *sp = refF;
+                sp += STRIDE;
+            }
+            ref = passN ? refN : (passF ? refF : pop());
+        }
+        if (ref == kDone) break;
+        {
+            const float4 *r = recs + 2 * (size_t)(ref & ~kMeshLeaf);
+            const float4 q0 = r[0], q1 = r[1], q2 = r[2], q3 = r[3];
+            float tmin;
+            if (meshBoxPass(f3(q2.y, q2.z, q2.w), f3(q3.x, q3.y, q3.z), inv, rc, best >= 0, tbest, tmin)) {
+                float t;
+                bool front;
+                if (meshTriangle(ro, rd, f3(q0.x, q0.y, q0.z), f3(q0.w, q1.x, q1.y), f3(q1.z, q1.w, q2.x), t, front)) {
+                    const int tri = (int)(ref & ~kMeshLeaf);
+                    if ((t >= tmin) & ((best < 0) | (t < tbest) | ((t == tbest) & (tri < best)))) {
+                        best = tri;
+                        tbest = t;
+                        bestFront = front ? 1u : 0u;
+                    }
                 }
             }
         }
-        node = (pass && tri < 0) ? node + 1u : __float_as_uint(n0.w);
+        ref = pop();
     }
     if (best < 0) return -1.0f;
-    const float4 a = tris[3 * (size_t)best], b = tris[3 * (size_t)best + 1], c = tris[3 * (size_t)best + 2];
+    const float4 a = recs[2 * (size_t)best], b = recs[2 * (size_t)best + 1], c = recs[2 * (size_t)best + 2];
     const F3 nobj = normalize(cross(f3(a.w, b.x, b.y), f3(b.z, b.w, c.x)));
     const F3 obj = getPointOnRay(ro, rd, tbest);
     P = mulMV(g.xf, obj, 1.0f);

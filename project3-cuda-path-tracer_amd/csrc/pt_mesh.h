@@ -11,9 +11,18 @@
 
 namespace ptm {
 
-using ptd::MeshNode;
-using ptd::MeshTri;
+using ptd::MeshUnit;
 using ptd::kMeshEnd;
+using ptd::kMeshLeaf;
+
+// what a GeomDev needs to know about its mesh, and what pt_init needs for the LDS budget
+struct MeshLayout {
+    uint32_t root;      // ref of the root node in the copy of octant 0
+    uint32_t stride;    // inner nodes per octant copy: max(ntris - 1, 1)
+    int stackNeed;      // far children that can wait at once on a lane's stack (ptd::meshIntersectionTest)
+};
+// a hierarchy that would need more stack than this is rebuilt by median splits alone (need <= ceil(log2 ntris))
+constexpr int kMeshStackSoftMax = 24;
 
 // triangle soup registered by pt_set_meshes for the next pt_init
 struct HostMesh {
@@ -36,52 +45,121 @@ inline float meshMargin(const float *tris, int ntris) {
 inline float min2(float a, float b) { return a < b ? a : b; }
 inline float max2(float a, float b) { return a < b ? b : a; }
 
-// Appends one mesh to the scene's node and triangle arrays.  Leaves are single triangles whose box is the triangle's
-// bounding box inflated by the margin -- the very box the semantics tests -- and an inner node's box is the exact union
-// of its children's (min / max of floats: no rounding), so box inclusion holds exactly, which is all the traversal's
-// equivalence with the brute-force rule needs.  Median split of the centroids along their widest axis.
+// fp32 -> fp16 bits, rounded DOWN (towards -inf) or UP: what a box plane may do when the box only has to contain its content.
+// (values beyond the half range go to the largest finite half or to the infinity on the permitted side; NaN does not occur)
+inline uint16_t halfBitsDirected(float x, bool up) {
+    if (x == 0.0f) return 0;
+    const bool neg = x < 0.0f;
+    const double a = std::fabs((double)x);
+    // magnitude rounds away from zero when the value moves in its own direction (up for positives, down for negatives)
+    const bool away = up != neg;
+    uint32_t bits;
+    if (std::isinf(a)) bits = 0x7c00u;
+    else if (a >= 65504.0) bits = a > 65504.0 && away ? 0x7c00u : 0x7bffu;
+    else {
+        int e;
+        (void)std::frexp(a, &e);                       // a = m 2^e, m in [0.5, 1)
+        int exp = e - 1;                               // a = 1.f 2^exp
+        double q;                                      // spacing of halves at this magnitude
+        if (exp < -14) { exp = -15; q = std::ldexp(1.0, -24); }      // subnormal halves
+        else q = std::ldexp(1.0, exp - 10);
+        const double n = a / q;                        // exact: a is a float, q a power of two
+        double k = away ? std::ceil(n) : std::floor(n);
+        if (exp == -15) bits = (uint32_t)k;            // 0 .. 1024 (1024 = the smallest normal)
+        else {
+            // k in [1024, 2048]; 2048 carries into the next exponent
+            bits = ((uint32_t)(exp + 15) << 10) + ((uint32_t)k - 1024u);
+        }
+        if (bits > 0x7c00u) bits = 0x7c00u;
+    }
+    return (uint16_t)(bits | (neg ? 0x8000u : 0u));
+}
+
+// Appends one mesh to the scene's record array: its triangles in file order (a triangle's record index is its rank in the tie rule),
+// then its inner nodes.  A triangle's box is its bounding box inflated by the margin -- the very box the semantics test -- and an
+// inner node carries the boxes of its two children, each the exact union of what lies below (min / max of floats: no rounding), so
+// box inclusion holds exactly, which is all the traversal's equivalence with the brute-force rule needs.  Split by a binned
+// surface-area heuristic with a median fallback (below).
 //
-// The tree is laid out EIGHT times, once per sign octant of the ray direction, each in depth-first order with skip links
-// and with the child on the ray's near side of the split first: a ray walks the copy of its octant (root + octant *
-// stride) front to back, so the first hits prune most of what lies behind them, and the walk itself stays a loop over
-// consecutive nodes without a stack.  (The order of the visits never changes the result, only how much is pruned.)
-// Returns the stride = nodes per copy (2 ntris - 1).  `flat`: no hierarchy, ONE list of leaves in index order and
-// stride 0 (tests: the brute-force rule on the device).  bbox receives the union of all leaf boxes (lo[3], hi[3]).
-inline uint32_t appendMesh(const float *tris, int ntris, bool flat, std::vector<MeshNode> &nodes, std::vector<MeshTri> &out,
-                           float bbox[6]) {
+// The inner nodes are laid out EIGHT times, once per sign octant of the ray direction, each in depth-first order with the child on
+// the ray's near side of the split FIRST in its parent's record: a ray walks the copy of its octant (root + octant * stride) front
+// to back, so the first hits prune most of what lies behind them.  (The order of the visits never changes the result, only how much
+// is pruned.)  `flat`: no hierarchy -- a chain of nodes whose near child is triangle i and whose far child, in a box that holds
+// everything, is the rest of the chain: the brute-force rule on the device, for the tests.  bbox receives the union of all
+// triangle boxes (lo[3], hi[3]).
+inline MeshLayout appendMesh(const float *tris, int ntris, bool flat, std::vector<MeshUnit> &recs, float bbox[6]) {
     const float m = meshMargin(tris, ntris);
-    const int triBase = (int)out.size();
+    if (recs.size() % 2) recs.push_back(MeshUnit());          // (a triangle's two units share a 64-byte line)
+    const uint32_t triBase = (uint32_t)recs.size();
     struct Leaf { float lo[3], hi[3], c[3]; int idx; };
     std::vector<Leaf> leaves((size_t)ntris);
     for (int a = 0; a < 3; ++a) { bbox[a] = INFINITY; bbox[3 + a] = -INFINITY; }
     for (int i = 0; i < ntris; ++i) {
         const float *t = tris + 9 * (size_t)i;
-        MeshTri mt;
-        memset(&mt, 0, sizeof mt);
+        float mt[16];
+        memset(mt, 0, sizeof mt);
         Leaf &L = leaves[(size_t)i];
         L.idx = i;
         for (int a = 0; a < 3; ++a) {
-            mt.v0[a] = t[a];
-            mt.e1[a] = t[3 + a] - t[a];
-            mt.e2[a] = t[6 + a] - t[a];
+            mt[a] = t[a];
+            mt[3 + a] = t[3 + a] - t[a];
+            mt[6 + a] = t[6 + a] - t[a];
             L.lo[a] = min2(min2(t[a], t[3 + a]), t[6 + a]) - m;
             L.hi[a] = max2(max2(t[a], t[3 + a]), t[6 + a]) + m;
+            mt[9 + a] = L.lo[a];
+            mt[12 + a] = L.hi[a];
             L.c[a] = 0.5f * (L.lo[a] + L.hi[a]);
             bbox[a] = min2(bbox[a], L.lo[a]);
             bbox[3 + a] = max2(bbox[3 + a], L.hi[a]);
         }
-        out.push_back(mt);
+        MeshUnit u[2];
+        memcpy(u, mt, sizeof mt);
+        recs.push_back(u[0]);
+        recs.push_back(u[1]);
     }
-    if (flat) {
-        const uint32_t nodeBase = (uint32_t)nodes.size();
-        for (int i = 0; i < ntris; ++i) {
-            MeshNode n;
-            for (int a = 0; a < 3; ++a) { n.lo[a] = leaves[(size_t)i].lo[a]; n.hi[a] = leaves[(size_t)i].hi[a]; }
-            n.tri = triBase + i;
-            n.skip = i + 1 < ntris ? nodeBase + (uint32_t)i + 1u : kMeshEnd;
-            nodes.push_back(n);
+    MeshLayout lay;
+    lay.stackNeed = 0;
+    // an inner node's record for octant `oct`: child h's box as entry / exit planes (entry = lo where the rays of the octant run
+    // towards +axis, hi where they run towards -axis), refs in f[3] and f[7]
+    auto innerRec = [](int oct, const float *lo0, const float *hi0, uint32_t ref0, const float *lo1, const float *hi1, uint32_t ref1) {
+        MeshUnit n;
+        const float *lo[2] = {lo0, lo1}, *hi[2] = {hi0, hi1};
+        const uint32_t ref[2] = {ref0, ref1};
+        for (int h = 0; h < 2; ++h) {
+            uint16_t pl[6];                      // entry x, y, z, exit x, y, z; lo rounded down, hi up
+            for (int a = 0; a < 3; ++a) {
+                const bool neg = ((oct >> a) & 1) != 0;
+                const uint16_t l = halfBitsDirected(lo[h][a], false), u = halfBitsDirected(hi[h][a], true);
+                pl[a] = neg ? u : l;
+                pl[3 + a] = neg ? l : u;
+            }
+            for (int k = 0; k < 3; ++k) n.w[4 * h + k] = (uint32_t)pl[2 * k] | ((uint32_t)pl[2 * k + 1] << 16);
+            n.w[4 * h + 3] = ref[h];
         }
-        return 0u;
+        return n;
+    };
+    // a box no ray passes (entry planes at +inf of the ray's parameter, exit planes at -inf) / every ray passes
+    const float kNone[2][3] = {{INFINITY, INFINITY, INFINITY}, {-INFINITY, -INFINITY, -INFINITY}};
+    const float kAll[2][3] = {{-INFINITY, -INFINITY, -INFINITY}, {INFINITY, INFINITY, INFINITY}};
+    const uint32_t innerBase = (uint32_t)recs.size();
+    if (ntris == 1 || flat) {
+        // one triangle: a root whose near child is the triangle and whose far child is nothing.  flat: a chain -- near child =
+        // triangle i, far child = the rest of the chain in a box that holds everything (the last node: triangle ntris - 1)
+        const uint32_t stride = (uint32_t)std::max(ntris - 1, 1);
+        for (int oct = 0; oct < 8; ++oct) {
+            const uint32_t base = innerBase + (uint32_t)oct * stride;
+            for (uint32_t i = 0; i < stride; ++i) {
+                const Leaf &L = leaves[(size_t)i];
+                const uint32_t ref0 = kMeshLeaf | (triBase + 2u * i);
+                if (ntris == 1) recs.push_back(innerRec(oct, L.lo, L.hi, ref0, kNone[0], kNone[1], ref0));
+                else if (i + 2 == (uint32_t)ntris) recs.push_back(innerRec(oct, L.lo, L.hi, ref0, leaves[(size_t)i + 1].lo, leaves[(size_t)i + 1].hi, kMeshLeaf | (triBase + 2u * (i + 1u))));
+                else recs.push_back(innerRec(oct, L.lo, L.hi, ref0, kAll[0], kAll[1], base + i + 1u));
+            }
+        }
+        lay.root = innerBase;
+        lay.stride = stride;
+        lay.stackNeed = ntris == 1 ? 0 : 1;
+        return lay;
     }
     // the tree: node k has a box and either a triangle or two children (lower / upper half along `axis`)
     struct TreeNode { float lo[3], hi[3]; int tri, left, right, axis, size; };
@@ -90,6 +168,7 @@ inline uint32_t appendMesh(const float *tris, int ntris, bool flat, std::vector<
     struct Builder {
         std::vector<Leaf> &lv;
         std::vector<TreeNode> &tree;
+        bool medianOnly;
         int build(int lo, int hi) {                       // recursion depth: ceil(log2 ntris) + 1
             const int me = (int)tree.size();
             tree.push_back(TreeNode());
@@ -118,7 +197,7 @@ inline uint32_t appendMesh(const float *tris, int ntris, bool flat, std::vector<
                 const int b = (int)(((double)L.c[a] - (double)cmin[a]) / w * kBins);
                 return b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
             };
-            if (count > 4) {
+            if (count > 4 && !medianOnly) {
                 double bestCost = INFINITY;
                 int bestBin = 0;
                 for (int a = 0; a < 3; ++a) {
@@ -190,31 +269,70 @@ inline uint32_t appendMesh(const float *tris, int ntris, bool flat, std::vector<
             n.size = 1 + tree[(size_t)l].size + tree[(size_t)r].size;
             return me;
         }
-    } builder{leaves, tree};
+    } builder{leaves, tree, false};
     builder.build(0, ntris);
-    const uint32_t stride = (uint32_t)tree.size();
-    for (int oct = 0; oct < 8; ++oct) {
-        const uint32_t base = (uint32_t)nodes.size(), end = base + stride;
-        // depth-first emission with an explicit stack of (tree node); a node's skip link = its position + its subtree size
-        std::vector<int> stack(1, 0);
-        while (!stack.empty()) {
-            const TreeNode &t = tree[(size_t)stack.back()];
-            stack.pop_back();
-            MeshNode n;
-            for (int a = 0; a < 3; ++a) { n.lo[a] = t.lo[a]; n.hi[a] = t.hi[a]; }
-            n.tri = t.tri >= 0 ? triBase + t.tri : -1;
-            const uint32_t next = (uint32_t)nodes.size() + (uint32_t)t.size;
-            n.skip = next < end ? next : kMeshEnd;
-            nodes.push_back(n);
-            if (t.tri < 0) {
-                const bool upperFirst = ((oct >> t.axis) & 1) != 0;       // the ray runs towards -axis: the upper half is nearer
-                const int first = upperFirst ? t.right : t.left, second = upperFirst ? t.left : t.right;
-                stack.push_back(second);
-                stack.push_back(first);
+    // what a lane's stack must hold: the far child waits while the near one is walked (the near child depends on the octant)
+    auto stackNeed = [&](int oct) {
+        struct Rec {
+            const std::vector<TreeNode> &tree;
+            int oct;
+            int need(int k) const {
+                const TreeNode &t = tree[(size_t)k];
+                if (t.tri >= 0) return 0;
+                const bool upperFirst = ((oct >> t.axis) & 1) != 0;
+                const int nearC = upperFirst ? t.right : t.left, farC = upperFirst ? t.left : t.right;
+                return std::max(1 + need(nearC), need(farC));
             }
-        }
+        } r{tree, oct};
+        return r.need(0);
+    };
+    auto needAll = [&]() {
+        int n = 0;
+        for (int oct = 0; oct < 8; ++oct) n = std::max(n, stackNeed(oct));
+        return n;
+    };
+    lay.stackNeed = needAll();
+    if (lay.stackNeed > kMeshStackSoftMax) {                 // (lopsided splits all the way down: median splits bound the depth by log2)
+        tree.clear();
+        std::sort(leaves.begin(), leaves.end(), [](const Leaf &x, const Leaf &y) { return x.idx < y.idx; });
+        builder.medianOnly = true;
+        builder.build(0, ntris);
+        lay.stackNeed = needAll();
     }
-    return stride;
+    const uint32_t stride = (uint32_t)ntris - 1u;            // inner nodes of a binary tree with ntris leaves
+    for (int oct = 0; oct < 8; ++oct) {
+        const uint32_t base = innerBase + (uint32_t)oct * stride;
+        // depth-first emission of the inner nodes; a child's ref is known once its position is: inner children are numbered as
+        // they are met (near child = the next record, far child = after the near child's inner nodes)
+        struct Emit {
+            const std::vector<TreeNode> &tree;
+            std::vector<MeshUnit> &recs;
+            uint32_t triBase;
+            int oct;
+            decltype(innerRec) &innerRec;
+            static int inner(const std::vector<TreeNode> &tree, int k) { return tree[(size_t)k].tri >= 0 ? 0 : (tree[(size_t)k].size - 1) / 2; }
+            void emit(int k) {
+                const TreeNode &t = tree[(size_t)k];
+                const bool upperFirst = ((oct >> t.axis) & 1) != 0;   // the ray runs towards -axis: the upper half is nearer
+                const int c[2] = {upperFirst ? t.right : t.left, upperFirst ? t.left : t.right};
+                const uint32_t me = (uint32_t)recs.size();
+                recs.push_back(MeshUnit());
+                uint32_t ref[2];
+                ref[0] = tree[(size_t)c[0]].tri >= 0 ? (kMeshLeaf | (triBase + 2u * (uint32_t)tree[(size_t)c[0]].tri)) : me + 1u;
+                ref[1] = tree[(size_t)c[1]].tri >= 0 ? (kMeshLeaf | (triBase + 2u * (uint32_t)tree[(size_t)c[1]].tri))
+                                                      : me + 1u + (uint32_t)inner(tree, c[0]);
+                const MeshUnit n = innerRec(oct, tree[(size_t)c[0]].lo, tree[(size_t)c[0]].hi, ref[0], tree[(size_t)c[1]].lo, tree[(size_t)c[1]].hi, ref[1]);
+                recs[(size_t)me] = n;
+                if (tree[(size_t)c[0]].tri < 0) emit(c[0]);
+                if (tree[(size_t)c[1]].tri < 0) emit(c[1]);
+            }
+        } e{tree, recs, triBase, oct, innerRec};
+        e.emit(0);
+        (void)base;
+    }
+    lay.root = innerBase;
+    lay.stride = stride;
+    return lay;
 }
 
 }  // namespace ptm

@@ -46,8 +46,10 @@ __global__ void k_test_intersect(const GeomDev *geoms, const int *gidx, const fl
     outside[i] = o ? 1 : 0;
 }
 // rays against one triangle mesh: the render kernels' test, plus the verdict of the bounding-ball test
-__global__ void k_test_mesh(const GeomDev *geom, const float4 *nodes, const float4 *tris, const float *rays, int n, float *t,
+// (blocks of 256 threads; dynamic LDS = the lanes' traversal stacks, [levels][256] words)
+__global__ void k_test_mesh(const GeomDev *geom, const float4 *recs, const float *rays, int n, float *t,
                             float *p3, float *n3, int *outside, int *culled) {
+    extern __shared__ uint32_t s_meshStack[];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const GeomDev G = *geom;
@@ -58,7 +60,7 @@ __global__ void k_test_mesh(const GeomDev *geom, const float4 *nodes, const floa
     bool o = outside[i] != 0;
     F3 nsrc = f3(0, 0, 0);
     const bool cull = certainMiss(G, ro, rd, dot(rd, rd));
-    const float tt = meshIntersectionTest(G, nodes, tris, G.meshRoot, G.meshStride, ro, rd, P, nsrc, o);
+    const float tt = meshIntersectionTest<false, 256>(G, recs, G.meshRoot, G.meshStride, s_meshStack + threadIdx.x, ro, rd, P, nsrc, o);
     culled[i] = cull ? 1 : 0;
     t[i] = cull && tt != -1.0f ? __builtin_nanf("") : tt;
     if (tt != -1.0f) N = hitNormal(G, nsrc, o);
@@ -68,8 +70,9 @@ __global__ void k_test_mesh(const GeomDev *geom, const float4 *nodes, const floa
 }
 // certainMiss soundness sweep for ONE mesh geom: rays as in k_sweep_sphere_cull (origins 1/64 .. 64 units from the bounding
 // ball's centre, aimed within ~1.3 radii of it: hits, grazes, near misses); a culled ray that the full walk hits is a violation
-__global__ void k_sweep_mesh_cull(const GeomDev *geom, const float4 *nodes, const float4 *tris, unsigned long long seed, int per_thread,
+__global__ void k_sweep_mesh_cull(const GeomDev *geom, const float4 *recs, unsigned long long seed, int per_thread,
                                   unsigned long long *culled, unsigned long long *violations, unsigned long long *hits) {
+    extern __shared__ uint32_t s_meshStack[];
     unsigned long long x = seed + (blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ull;
     unsigned int nc = 0, nv = 0, nh = 0;
     const GeomDev G = *geom;
@@ -91,7 +94,7 @@ __global__ void k_sweep_mesh_cull(const GeomDev *geom, const float4 *nodes, cons
         F3 P, N;
         bool o;
         // (every ray takes the walk: the hit count shows that the sweep does probe the mesh)
-        const float t = meshIntersectionTest(G, nodes, tris, G.meshRoot, G.meshStride, org, dir, P, N, o);
+        const float t = meshIntersectionTest<false, 256>(G, recs, G.meshRoot, G.meshStride, s_meshStack + threadIdx.x, org, dir, P, N, o);
         nc += cull ? 1u : 0u;
         nh += t != -1.0f ? 1u : 0u;
         nv += cull && t != -1.0f ? 1u : 0u;

@@ -111,6 +111,7 @@ struct KParams {
     int   nEmit;                       // emissive primitives the direct-lighting bounce samples, at most kEmitMax (file order)
     int   nCubes;                      // cubes of the scene (sphere-heavy scenes: rows of the LDS frame table)
     int   nSphCull;                    // sphere-heavy scenes: entries of BounceArgs::sphCull (even: padded with a copy of the last one)
+    int   meshStackOff;                // scenes with meshes: byte offset of the lanes' traversal stacks in the dynamic LDS ([levels][kBlock] words)
     int   classOff[kCls + 1];          // later bounces: the primitives a tile of class c has to look at are classIdx[classOff[c] ..
                                        // classOff[c + 1]) (BounceArgs::classIdx): not the binned ones unless the class says so, of the walls only
                                        // the class's own, in sphere-heavy scenes no sphere (those come from sphCull)
@@ -369,8 +370,7 @@ struct BounceArgs {
     const MaterialDev *gmats;
     float *contrib;
     const WallBox *walls;               // [prm.nWalls] inflated world-space boxes of the walls
-    const float4 *meshNodes;            // MeshNode[] of every mesh of the scene (k_bounce<., ., ., true>), or nullptr
-    const float4 *meshTris;             // MeshTri[]
+    const float4 *meshRecs;             // ptd::MeshRec[] of every mesh of the scene (k_bounce<., ., ., true>), or nullptr
     uint32_t *hitMask;                  // [ceil(max_batch / 32)][W * H]: bit b of word w set = contrib[32 w + b][pix] was written
     const SphereCull *sphCull;          // sphere-heavy scenes (k_bounce<false, true, ...>): the spheres' culling data, packed
     const int *classIdx;                // later bounces: per queue class, the indices of the primitives to look at, file order (KParams::classOff)
@@ -859,7 +859,8 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
                         // a triangle mesh: its bounding ball first, then every lane walks the mesh's hierarchy on its own
                         if (!certainMiss(cg, org, dir, dd)) {
                             const ArgsPtr A2 = launder(kargs);
-                            t = meshIntersectionTest<FIRST && !DOF>(G, A2->meshNodes, A2->meshTris, G.meshRoot, G.meshStride, org, dir, p, n, o);
+                            uint32_t *const stack = reinterpret_cast<uint32_t *>(smem + A2->prm.meshStackOff) + tid;
+                            t = meshIntersectionTest<FIRST && !DOF, kBlock>(G, A2->meshRecs, G.meshRoot, G.meshStride, stack, org, dir, p, n, o);
                         }
                     } else if (!PACKED && (flags & 1) == 0) {          // (PACKED: no sphere comes this way)
                         probe(3);

@@ -108,68 +108,122 @@ def test_icosphere_mesh_approximates_the_sphere(oracle):
 def test_hierarchy_invariants(pt):
     sc = pt.Scene(os.path.join(SCENES, "cornell_mesh.txt"))
     cases = [(t, o) for t in sc.meshes.values() for o in (0, 5)] + [(_cube_mesh(), o) for o in range(8)] + [(_cube_mesh()[:1], 3)]
+    LEAF = pt.MESH_LEAF
     for tris, octant in cases:
         nt = len(tris)
-        nodes = pt.mesh_bvh(tris, octant)
-        assert len(nodes) == 2 * nt - 1
-        END = 0xFFFFFFFF
+        recs, nodes, need = pt.mesh_bvh(tris, octant)
+        assert len(recs) == nt and len(nodes) == max(nt - 1, 1)
         margin = f32(1e-5) * np.abs(tris).max()
-        leaves = nodes[nodes["tri"] >= 0]
-        assert sorted(leaves["tri"].tolist()) == list(range(nt))                       # every triangle exactly once
         v = tris.reshape(nt, 3, 3)
-        for nd in leaves:                                                              # a leaf's box IS the triangle's box
-            t = v[nd["tri"]]
-            assert np.array_equal(nd["lo"], t.min(0) - margin) and np.array_equal(nd["hi"], t.max(0) + margin)
-        # depth-first layout: the subtree of node i is [i, end_i); children are i + 1 and skip(i + 1)
-        end = lambda i: len(nodes) if nodes["skip"][i] == END else int(nodes["skip"][i])
-        depth = 0
-        stack = [(0, 1)]
-        while stack:
-            i, dpt = stack.pop()
-            depth = max(depth, dpt)
-            assert i < end(i) <= len(nodes)
-            if nodes["tri"][i] >= 0:
-                assert end(i) == i + 1
-                continue
-            l, r = i + 1, end(i + 1)
-            assert r < end(i) and end(r) == end(i)
-            for a in range(3):                                                         # exact union of the children
-                assert nodes["lo"][i][a] == min(nodes["lo"][l][a], nodes["lo"][r][a])
-                assert nodes["hi"][i][a] == max(nodes["hi"][l][a], nodes["hi"][r][a])
+        neg = np.array([(octant >> a) & 1 for a in range(3)], bool)
+        for i, r in enumerate(recs):                          # triangle i, file order: v0, the two edges, and the triangle's own box
+            assert np.array_equal(r["v0"], v[i][0]) and np.array_equal(r["e1"], v[i][1] - v[i][0]) and np.array_equal(r["e2"], v[i][2] - v[i][0])
+            assert np.array_equal(r["lo"], v[i].min(0) - margin) and np.array_equal(r["hi"], v[i].max(0) + margin)
+        def planes_of(lo, hi):
+            # the six halves of a box for this octant: entry planes, exit planes; lo rounded down, hi up (never inwards, and by
+            # less than one half-precision step)
+            lo16 = lo.astype(np.float16)
+            lo16 = np.where(lo16.astype(f32) > lo, np.nextafter(lo16, np.float16(-np.inf)), lo16)
+            hi16 = hi.astype(np.float16)
+            hi16 = np.where(hi16.astype(f32) < hi, np.nextafter(hi16, np.float16(np.inf)), hi16)
+            return np.concatenate([np.where(neg, hi16, lo16), np.where(neg, lo16, hi16)])
+
+        if nt == 1:
+            # a root whose near child is the triangle and whose far child is a box no ray passes (entered at +inf, left at -inf)
+            nd = nodes[0]
+            assert need == 0 and int(nd["ref"]) == LEAF
+            assert np.array_equal(nd["planes"], planes_of(recs[0]["lo"], recs[0]["hi"]))
+            fp = nd["far_planes"].astype(f32)
+            assert np.all(np.isinf(fp)) and np.all((fp[:3] > 0) != neg) and np.all((fp[3:] < 0) != neg)
+            continue
+        # walk from the root (inner node 0): every triangle exactly once, every inner node exactly once; a child's box in its
+        # parent is the exact union of what lies below it, rounded outwards to half precision and stored as the planes a ray of
+        # the octant enters / leaves through; near child first
+        seen_tri, seen_node = [], []
+
+        def box_of(ref):
+            ref = int(ref)
+            if ref & LEAF:
+                t = (ref & ~LEAF) // 2
+                assert (ref & ~LEAF) % 2 == 0
+                seen_tri.append(t)
+                return recs[t]["lo"], recs[t]["hi"], 0, 0
+            k = ref - 2 * nt
+            assert 0 <= k < len(nodes)
+            seen_node.append(k)
+            nd = nodes[k]
+            nlo, nhi, nd_, nn = box_of(nd["ref"])
+            flo, fhi, fd_, fn = box_of(nd["far_ref"])
+            assert np.array_equal(nd["planes"], planes_of(nlo, nhi)) and np.array_equal(nd["far_planes"], planes_of(flo, fhi))
             # the first child is the nearer one for this octant along some axis: its centre does not lie behind the second's
-            cl = nodes["lo"][l] + nodes["hi"][l]
-            cr = nodes["lo"][r] + nodes["hi"][r]
+            cl, cr = nlo + nhi, flo + fhi
             assert any((cl[a] >= cr[a]) if (octant >> a) & 1 else (cl[a] <= cr[a]) for a in range(3))
-            stack += [(l, dpt + 1), (r, dpt + 1)]
+            # depth-first layout: the near child's inner nodes follow their parent directly, the far child's come after them
+            if not int(nd["ref"]) & LEAF:
+                assert int(nd["ref"]) - 2 * nt == k + 1
+            return np.minimum(nlo, flo), np.maximum(nhi, fhi), 1 + max(nd_, fd_), max(1 + nn, fn)
+
+        _, _, depth, need_here = box_of(2 * nt)
+        assert sorted(seen_tri) == list(range(nt)) and sorted(seen_node) == list(range(nt - 1))
         assert depth <= 3 * int(np.ceil(np.log2(max(nt, 1)))) + 2                      # no side of a split below an eighth: logarithmic
+        # the far children that can wait at once on a lane's stack: this copy's need is within what pt_init reserves for all eight
+        assert need_here <= need <= depth and need <= 24
 
 
-def _walk(nodes, tris, oracle, ro, rd):
+def _walk(recs, nodes, tris, oracle, ro, rd, need):
     """The kernel's traversal (ptd::meshIntersectionTest) in numpy fp32 on object-space rays; triangle test by the oracle."""
-    END = 0xFFFFFFFF
+    LEAF = 0x80000000
+    nt = len(recs)
     up, dn = f32(1.00001), f32(0.99999)
     g = np.where(np.abs(rd) < f32(1e-30), np.copysign(f32(1e-30), rd), rd).astype(f32)
     inv = (f32(1.0) / g).astype(f32)
     c = (-(ro * inv)).astype(f32)
     fma = lambda x: (x.astype(np.float64) * inv.astype(np.float64) + c.astype(np.float64)).astype(f32)   # exact in fp64, rounded once
-    best, tbest, node, visited = -1, f32(0), 0, 0
-    while node != END:
-        nd = nodes[node]
-        a = fma(nd["lo"])
-        b = fma(nd["hi"])
+    best, tbest, visited, deepest = -1, f32(0), 0, 0
+
+    def box_pass(lo, hi):
+        a, b = fma(lo), fma(hi)
         tn = np.max(np.minimum(a, b))
         tf = np.min(np.maximum(a, b))
         tmin = f32(tn * dn)
-        tri = int(nd["tri"])
-        ok = f32(tf * up) >= tmin and tf >= 0 and (best < 0 or not tmin > tbest)
+        return bool(f32(tf * up) >= tmin and tf >= 0 and (best < 0 or not tmin > tbest)), tmin
+
+    def planes_pass(pl):
+        pl = pl.astype(f32)
+        tn, tf = np.max(fma(pl[:3])), np.min(fma(pl[3:]))
+        tmin = f32(tn * dn)
+        return bool(f32(tf * up) >= tmin and tf >= 0 and (best < 0 or not tmin > tbest))
+
+    ref = 2 * nt
+    stack = []
+    while True:
         visited += 1
-        if ok and tri >= 0:
-            v = tris[tri]
-            hit, tuv, front = oracle.mesh_triangle(ro, rd, v[0:3], v[3:6], v[6:9])
-            t = f32(tuv[0])
-            if hit and t >= tmin and (best < 0 or t < tbest or (t == tbest and tri < best)):
-                best, tbest = tri, t
-        node = node + 1 if (ok and tri < 0) else int(nd["skip"])
+        pop = True
+        if ref & LEAF:
+            tri = (ref & ~LEAF) // 2
+            r = recs[tri]
+            ok, tmin = box_pass(r["lo"], r["hi"])
+            if ok:
+                v = tris[tri]
+                hit, tuv, front = oracle.mesh_triangle(ro, rd, v[0:3], v[3:6], v[6:9])
+                t = f32(tuv[0])
+                if hit and t >= tmin and (best < 0 or t < tbest or (t == tbest and tri < best)):
+                    best, tbest = tri, t
+        else:
+            nd = nodes[int(ref) - 2 * nt]
+            pn = planes_pass(nd["planes"])
+            pf = planes_pass(nd["far_planes"])
+            if pn and pf:
+                stack.append(int(nd["far_ref"]))
+                deepest = max(deepest, len(stack))
+            if pn or pf:
+                ref = int(nd["ref"]) if pn else int(nd["far_ref"])
+                pop = False
+        if pop:
+            if not stack:
+                break
+            ref = stack.pop()
+    assert deepest <= need
     return best, tbest, visited
 
 
@@ -186,15 +240,17 @@ def test_hierarchy_walk_equals_the_brute_force_rule(pt, oracle):
             tgt = tris[rng.integers(len(tris))].reshape(3, 3).mean(0) + rng.normal(size=3) * 0.02
             d = (tgt - o) if i % 5 else rng.normal(size=3)
             d = (d / np.linalg.norm(d)).astype(f32)
+            if i % 7 == 3:                        # axis-parallel components, +0 and -0: the copy is chosen by the SIGN BIT of the reciprocal
+                d[i % 3] = f32(0.0) if i % 2 else f32(-0.0)
+                d = (d / np.linalg.norm(d)).astype(f32)
             # (the oracle normalises once more in object space; feed it the direction it will actually use)
             rd = oracle.normalize(d)
             wt, wp, wn, wo, wtri = oracle.mesh_intersect(ident, tris, np.concatenate([o, d]))
-            octant = int(rd[0] < 0) | int(rd[1] < 0) << 1 | int(rd[2] < 0) << 2
-            best, tbest, vis = _walk(copies[octant], tris, oracle, o, rd)
-            if i % 16 == 0:                       # ... and whatever copy a ray walks, the result is the same
-                assert _walk(copies[7 - octant], tris, oracle, o, rd)[:2] == (best, tbest)
+            octant = int(np.signbit(rd[0])) | int(np.signbit(rd[1])) << 1 | int(np.signbit(rd[2])) << 2
+            best, tbest, vis = _walk(copies[octant][0], copies[octant][1], tris, oracle, o, rd, copies[octant][2])
             assert best == wtri, (g, i, best, wtri)
             hits += best >= 0
             visited += vis
         assert hits > 250
-        assert visited / 400 < 0.1 * len(copies[0])      # ... and it is a hierarchy: a fraction of the nodes per ray
+        assert visited / 400 < 0.05 * (2 * len(tris) - 1)      # ... and it is a hierarchy: a fraction of the records per ray
+        print('mesh', g, 'records fetched per ray', visited / 400)
