@@ -57,16 +57,17 @@ int pt_test_camera_cull_tables(const PtCamera *cam, const PtGeom *geoms, int nge
 /* Triangle meshes.  pt_test_mesh_intersect: `n` rays against ONE mesh geom on the GPU, through the hierarchy (flat = 0) or a
  * plain list of its triangles (flat = 1: the brute-force rule); outputs keep their input values on a miss; culled[i] = 1 when
  * the bounding-ball test (certainMiss) rejected the ray -- t[i] is NaN if the full test hits nevertheless (must not happen).
- * pt_test_mesh_bvh (host only, no GPU needed): the records pt_init would build, in units of 8 words (pt_device.h: MeshUnit) --
- * the triangles in file order, two units each (v0, e1, e2, box lo, box hi as floats), then the inner nodes of the copy laid out
- * for rays of direction octant `octant` (bit a set: the direction's component a is negative), one unit each, nearer child first:
- * six half-precision planes in three words (entry x, y, z, exit x, y, z; entry = lo where the direction is positive, hi where
- * negative; lo rounded down, hi up), the child's ref, then the same for the far child; refs in units relative to this array,
- * bit 31 = a triangle; *nrecs in = capacity in units, out = unit count (2 ntris + max(ntris - 1, 1));
- * *stack_need = far children that can wait at once on a lane's stack, over all eight copies. */
+ * pt_test_mesh_bvh (host only, no GPU needed): the records pt_init would build, in units of 4 words (pt_device.h: MeshUnit) --
+ * the triangles in file order, three units each (v0, v1, v2, the mesh's box margin as floats, two words unused), one unit of
+ * padding when that is an odd number of units, then the inner nodes of the copy laid out for rays of direction octant `octant`
+ * (bit a set: the direction's component a is negative), two units each, nearer child first: six half-precision planes in three
+ * words (entry x, y, z, exit x, y, z; entry = lo where the direction is positive, hi where negative; lo rounded down, hi up)
+ * and the child's ref, then the same for the far child; refs in units relative to this array, bit 31 = a triangle;
+ * *nrecs in = capacity in units, out = unit count; *stack_need = far children that can wait at once on a lane's stack, over
+ * all eight copies. */
 int pt_test_mesh_intersect(const PtGeom *geom, const float *tris, int ntris, int flat, const float *rays, int n, float *t,
                            float *p3, float *n3, int32_t *outside, int32_t *culled);
-int pt_test_mesh_bvh(const float *tris, int ntris, int octant, uint32_t *units8, int *nrecs, int *stack_need);
+int pt_test_mesh_bvh(const float *tris, int ntris, int octant, uint32_t *units4, int *nrecs, int *stack_need);
 /* certainMiss soundness for a mesh geom: `rays` pseudo-random rays dense in grazes of its bounding ball (origins 1/64 .. 64
  * radii away); *violations = rays the bounding-ball test rejected although the walk hits (must be 0), *hits = rays that hit */
 int pt_test_mesh_cull_sweep(const PtGeom *geom, const float *tris, int ntris, uint64_t seed, int64_t rays, uint64_t *culled,

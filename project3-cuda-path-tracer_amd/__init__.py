@@ -459,24 +459,27 @@ def test_mesh_cull_sweep(geom, tris, seed, rays):
 
 MESH_LEAF = 0x80000000
 # the two kinds of 64-byte record of a mesh (pt_device.h: MeshRec)
-MESH_TRI_DTYPE = np.dtype([("v0", "<f4", 3), ("e1", "<f4", 3), ("e2", "<f4", 3), ("lo", "<f4", 3), ("hi", "<f4", 3), ("pad", "<u4")])
+MESH_TRI_DTYPE = np.dtype([("v0", "<f4", 3), ("v1", "<f4", 3), ("v2", "<f4", 3), ("margin", "<f4"), ("pad", "<u4", 2)])
 MESH_NODE_DTYPE = np.dtype([("planes", "<f2", 6), ("ref", "<u4"), ("far_planes", "<f2", 6), ("far_ref", "<u4")])
+MESH_TRI_UNITS, MESH_NODE_UNITS = 3, 2
 
 
 def mesh_bvh(tris, octant=0):
     """The hierarchy pt_init builds for a mesh (host only), in the layout for rays of direction octant `octant` (bit a set:
-    component a negative) -> (triangle records [ntris], inner nodes [max(ntris - 1, 1)], stack levels a lane needs).  A node holds
-    the boxes and refs of its near (planes, ref) and far (far_planes, far_ref) child, a box as six half-precision planes: the
-    three a ray of the octant enters through (lo where its direction is positive, hi where negative), then the three it leaves
-    through; lo rounded down, hi up.  A ref with MESH_LEAF set is triangle (ref & ~MESH_LEAF) / 2, any other is inner node
-    ref - 2 ntris (refs count units of 32 bytes: a triangle takes two)."""
+    component a negative) -> (triangle records [ntris], inner nodes [max(ntris - 1, 1)], first unit of the inner nodes, stack
+    levels a lane needs).  A node holds the boxes and refs of its near (planes, ref) and far (far_planes, far_ref) child, a box
+    as six half-precision planes: the three a ray of the octant enters through (lo where its direction is positive, hi where
+    negative), then the three it leaves through; lo rounded down, hi up.  Refs count units of 16 bytes: with MESH_LEAF set it is
+    triangle (ref & ~MESH_LEAF) / 3, any other is inner node (ref - first unit) / 2."""
     tr = np.ascontiguousarray(tris, np.float32).reshape(-1, 9)
-    out = np.zeros((3 * len(tr) + 1, 8), np.uint32)
+    nt = len(tr)
+    out = np.zeros((5 * nt + 4, 4), np.uint32)
     n, need = C.c_int(len(out)), C.c_int(0)
-    _tcheck(test_lib().pt_test_mesh_bvh(_p(tr), len(tr), octant, _p(out), C.byref(n), C.byref(need)))
-    assert n.value == 2 * len(tr) + max(len(tr) - 1, 1)
-    return (out[:2 * len(tr)].reshape(-1).view(MESH_TRI_DTYPE).reshape(-1), out[2 * len(tr):n.value].reshape(-1).view(MESH_NODE_DTYPE).reshape(-1),
-            need.value)
+    _tcheck(test_lib().pt_test_mesh_bvh(_p(tr), nt, octant, _p(out), C.byref(n), C.byref(need)))
+    first = 3 * nt + (3 * nt) % 2
+    assert n.value == first + 2 * max(nt - 1, 1)
+    return (out[:3 * nt].reshape(-1).view(MESH_TRI_DTYPE).reshape(-1), out[first:n.value].reshape(-1).view(MESH_NODE_DTYPE).reshape(-1),
+            first, need.value)
 
 
 def test_hemisphere(normals, iter_index_depth):

@@ -1800,22 +1800,23 @@ int pt_test_mesh_cull_sweep(const PtGeom *geom, const float *tris, int ntris, ui
 }
 
 // host only: no GPU is touched
-int pt_test_mesh_bvh(const float *tris, int ntris, int octant, uint32_t *units8, int *nrecs, int *stack_need) {
-    if (!tris || ntris < 1 || !units8 || !nrecs || !stack_need || octant < 0 || octant > 7) return fail(PT_ERR_INVALID, "pt_test_mesh_bvh: bad argument");
+int pt_test_mesh_bvh(const float *tris, int ntris, int octant, uint32_t *units4, int *nrecs, int *stack_need) {
+    if (!tris || ntris < 1 || !units4 || !nrecs || !stack_need || octant < 0 || octant > 7) return fail(PT_ERR_INVALID, "pt_test_mesh_bvh: bad argument");
     std::vector<ptd::MeshUnit> recs;
     float box[6];
     const ptm::MeshLayout lay = ptm::appendMesh(tris, ntris, false, recs, box);
-    const uint32_t total = 2u * (uint32_t)ntris + lay.stride;        // units: the triangles (two each), then this octant's inner nodes
+    // units of 16 bytes: the triangles (three each), [one unit of padding when their count is odd,] this octant's inner nodes (two each)
+    const uint32_t triUnits = (uint32_t)ptd::kMeshTriUnits * (uint32_t)ntris, pad = triUnits % 2u;
+    const uint32_t total = triUnits + pad + lay.stride;
     if ((int)total > *nrecs) return fail(PT_ERR_INVALID, "pt_test_mesh_bvh: %u units do not fit %d", total, *nrecs);
-    // refs rebased: triangle i -> kMeshLeaf | 2 i, inner node j of the copy -> 2 ntris + j
-    const uint32_t innerBase = 2u * (uint32_t)ntris + (uint32_t)octant * lay.stride;
-    auto rebase = [&](uint32_t r) { return (r & ptd::kMeshLeaf) ? r : r - innerBase + 2u * (uint32_t)ntris; };
-    memcpy(units8, recs.data(), (size_t)ntris * 2 * sizeof(ptd::MeshUnit));
+    // refs rebased to this array: triangle i -> kMeshLeaf | 3 i, inner node j of the copy -> triUnits + pad + 2 j
+    const uint32_t innerBase = triUnits + pad + (uint32_t)octant * lay.stride;
+    auto rebase = [&](uint32_t r) { return (r & ptd::kMeshLeaf) ? r : r - innerBase + triUnits + pad; };
+    memcpy(units4, recs.data(), (size_t)(triUnits + pad) * sizeof(ptd::MeshUnit));
     for (uint32_t j = 0; j < lay.stride; ++j) {
         ptd::MeshUnit n = recs[(size_t)innerBase + j];
         n.w[3] = rebase(n.w[3]);
-        n.w[7] = rebase(n.w[7]);
-        memcpy(units8 + 8 * (2 * (size_t)ntris + j), &n, sizeof n);
+        memcpy(units4 + 4 * ((size_t)triUnits + pad + j), &n, sizeof n);
     }
     *nrecs = (int)total;
     *stack_need = lay.stackNeed;

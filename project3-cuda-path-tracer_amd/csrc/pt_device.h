@@ -682,31 +682,35 @@ __device__ __forceinline__ float sphereIntersectionTest(const GD &g, F3 ro_w, F3
 // (node boxes = exact unions of their triangles' boxes) visits every triangle the brute-force rule accepts, and a node
 // whose entry parameter lies beyond the best hit so far cannot hold a better one: bit-identical results in any order.
 //
-// ONE array per scene, addressed in units of 32 bytes by a 31-bit index (`ref`, bit 31 = the record is a triangle), two kinds of record:
-//   inner node (one unit):   the boxes of BOTH its children and their refs -- a visit decides about two subtrees.  The boxes are
+// ONE array per scene, addressed in units of 16 bytes by a 31-bit index (`ref`, bit 31 = the record is a triangle), two kinds of record:
+//   inner node (two units):  the boxes of BOTH its children and their refs -- a visit decides about two subtrees.  The boxes are
 //                            stored as the planes a ray enters / leaves through (below) in HALF precision, rounded outwards: an inner
 //                            box only has to CONTAIN what lies below it (a ray that passes a box passes every box around it), and a
 //                            visit is what the walk pays for: the texture addresser is busy 16 cycles per 16-byte-per-lane load,
 //                            however few lanes take part, and it is what bounds a mesh scene (profiles/r03_mesh_walk_experiments.txt:
 //                            TA_BUSY 80 % of a launch);
-//   triangle (two units):    v0, e1, e2 and the triangle's own inflated box in full precision (the box the semantics test).
+//   triangle (three units):  its vertices and the mesh's box margin, 40 bytes of the 48 fetched (16 + 16 + 8): the edges e1 = v1 - v0,
+//                            e2 = v2 - v0 and the triangle's own inflated box -- the box the semantics test, min / max of the
+//                            vertices -+ the margin -- are the same fp32 operations wherever they are evaluated, so they are
+//                            evaluated here, for 18 instructions, instead of being fetched, for 24 more bytes per lane.
 // Rounds 1-2 walked 32-byte full-precision nodes in depth-first order with skip links, no stack: every child of a visited node, hit
 // or missed, was a visit of its own (2 I + 1 for a ray that passes I inner nodes), and a leaf two fetches (its node, then its triangle).
 // Here the far child of a node whose children both pass waits on a short per-lane stack in LDS (slots kBlock words apart: lanes never
-// share a bank; its depth is the scene's, computed by pt_init), and a ray asks for 2 I + 4 T loads instead of 4 I + 2 + 5 T.
+// share a bank; its depth is the scene's, computed by pt_init), and a ray keeps the texture addresser busy for 32 I + 40 T cycles
+// instead of 64 I + 32 + 80 T.
 // Inner nodes are stored once per sign octant of the ray direction, nearer child first (pt_mesh.h): a ray walks its octant's copy
 // front to back, so the first hits prune most of what lies behind them; the triangles, in file order, once.
 struct MeshUnit {
-    uint32_t w[8];
+    uint32_t w[4];
 };
 // inner node: w[0..2] the near child's planes as six halves -- entry x, y, z, exit x, y, z --, w[3] its ref, w[4..6] / w[7] the far child's.
 //             The copy of an octant knows the sign of every direction component, hence which of a box's two planes per axis a ray of
 //             that octant meets first (lo where the component is positive, hi where it is negative): min(fma(lo, inv, rc),
 //             fma(hi, inv, rc)) IS the entry plane's parameter (fma is monotone in its first operand) -- the hierarchy stores the
 //             planes in that order and the six min / max per box of the slab test are gone.  lo is rounded down, hi up.
-// triangle:   floats 0..2 v0, 3..5 e1 = v1 - v0, 6..8 e2 = v2 - v0 (the subtractions glm does first, evaluated once on the host),
-//             9..11 box lo, 12..14 box hi
-static_assert(sizeof(MeshUnit) == 32, "two float4 loads");
+// triangle:   floats 0..2 v0, 3..5 v1, 6..8 v2, 9 the mesh's margin (pt_mesh.h: meshMargin)
+static_assert(sizeof(MeshUnit) == 16, "one float4 load");
+constexpr int kMeshNodeUnits = 2, kMeshTriUnits = 3;
 constexpr uint32_t kMeshEnd = 0xffffffffu;                 // GeomDev::meshRoot of a primitive that is not a mesh
 constexpr uint32_t kMeshLeaf = 0x80000000u;
 constexpr float kMeshEps = 1.1920928955078125e-07f;        // std::numeric_limits<float>::epsilon(), intersect.inl:50
@@ -795,7 +799,7 @@ __device__ __forceinline__ float meshIntersectionTest(const GD &g, const float4 
     // at which some lane happens to hold one (one loop over both kinds of record ran both halves at four steps out of five).
     for (;;) {
         while (!(ref & kMeshLeaf)) {
-            const float4 *r = recs + 2 * (size_t)ref;
+            const float4 *r = recs + (size_t)ref;
             const float4 q0 = r[0], q1 = r[1];
             const bool passN = meshPlanesPass(__float_as_uint(q0.x), __float_as_uint(q0.y), __float_as_uint(q0.z), inv, rc, best >= 0, tbest);
             const bool passF = meshPlanesPass(__float_as_uint(q1.x), __float_as_uint(q1.y), __float_as_uint(q1.z), inv, rc, best >= 0, tbest);
@@ -808,13 +812,21 @@ __device__ __forceinline__ float meshIntersectionTest(const GD &g, const float4 
         }
         if (ref == kDone) break;
         {
-            const float4 *r = recs + 2 * (size_t)(ref & ~kMeshLeaf);
-            const float4 q0 = r[0], q1 = r[1], q2 = r[2], q3 = r[3];
+            const float4 *r = recs + (size_t)(ref & ~kMeshLeaf);
+            const float4 q0 = r[0], q1 = r[1];
+            const float2 q2 = *reinterpret_cast<const float2 *>(r + 2);
+            const F3 v0 = f3(q0.x, q0.y, q0.z), v1 = f3(q0.w, q1.x, q1.y), v2 = f3(q1.z, q1.w, q2.x);
+            const float m = q2.y;
+            // the triangle's box as pt_mesh.h states it: min / max of the vertices, moved outwards by the mesh's margin
+            const F3 lo = f3(__builtin_fminf(__builtin_fminf(v0.x, v1.x), v2.x) - m, __builtin_fminf(__builtin_fminf(v0.y, v1.y), v2.y) - m,
+                             __builtin_fminf(__builtin_fminf(v0.z, v1.z), v2.z) - m);
+            const F3 hi = f3(__builtin_fmaxf(__builtin_fmaxf(v0.x, v1.x), v2.x) + m, __builtin_fmaxf(__builtin_fmaxf(v0.y, v1.y), v2.y) + m,
+                             __builtin_fmaxf(__builtin_fmaxf(v0.z, v1.z), v2.z) + m);
             float tmin;
-            if (meshBoxPass(f3(q2.y, q2.z, q2.w), f3(q3.x, q3.y, q3.z), inv, rc, best >= 0, tbest, tmin)) {
+            if (meshBoxPass(lo, hi, inv, rc, best >= 0, tbest, tmin)) {
                 float t;
                 bool front;
-                if (meshTriangle(ro, rd, f3(q0.x, q0.y, q0.z), f3(q0.w, q1.x, q1.y), f3(q1.z, q1.w, q2.x), t, front)) {
+                if (meshTriangle(ro, rd, v0, v1 - v0, v2 - v0, t, front)) {
                     const int tri = (int)(ref & ~kMeshLeaf);
                     if ((t >= tmin) & ((best < 0) | (t < tbest) | ((t == tbest) & (tri < best)))) {
                         best = tri;
@@ -827,8 +839,10 @@ __device__ __forceinline__ float meshIntersectionTest(const GD &g, const float4 
         ref = pop();
     }
     if (best < 0) return -1.0f;
-    const float4 a = recs[2 * (size_t)best], b = recs[2 * (size_t)best + 1], c = recs[2 * (size_t)best + 2];
-    const F3 nobj = normalize(cross(f3(a.w, b.x, b.y), f3(b.z, b.w, c.x)));
+    const float4 a = recs[(size_t)best], b = recs[(size_t)best + 1];
+    const float v2z = *reinterpret_cast<const float *>(recs + (size_t)best + 2);
+    const F3 w0 = f3(a.x, a.y, a.z);
+    const F3 nobj = normalize(cross(f3(a.w, b.x, b.y) - w0, f3(b.z, b.w, v2z) - w0));
     const F3 obj = getPointOnRay(ro, rd, tbest);
     P = mulMV(g.xf, obj, 1.0f);
     nsrc = nobj;         // normal = +-normalize(invTranspose * (nobj, 0)): hitNormal(), evaluated for the nearest hit only

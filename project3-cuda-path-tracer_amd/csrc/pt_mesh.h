@@ -14,11 +14,13 @@ namespace ptm {
 using ptd::MeshUnit;
 using ptd::kMeshEnd;
 using ptd::kMeshLeaf;
+using ptd::kMeshNodeUnits;
+using ptd::kMeshTriUnits;
 
 // what a GeomDev needs to know about its mesh, and what pt_init needs for the LDS budget
 struct MeshLayout {
     uint32_t root;      // ref of the root node in the copy of octant 0
-    uint32_t stride;    // inner nodes per octant copy: max(ntris - 1, 1)
+    uint32_t stride;    // units per octant copy: 2 max(ntris - 1, 1)
     int stackNeed;      // far children that can wait at once on a lane's stack (ptd::meshIntersectionTest)
 };
 // a hierarchy that would need more stack than this is rebuilt by median splits alone (need <= ceil(log2 ntris))
@@ -89,40 +91,41 @@ inline uint16_t halfBitsDirected(float x, bool up) {
 // triangle boxes (lo[3], hi[3]).
 inline MeshLayout appendMesh(const float *tris, int ntris, bool flat, std::vector<MeshUnit> &recs, float bbox[6]) {
     const float m = meshMargin(tris, ntris);
-    if (recs.size() % 2) recs.push_back(MeshUnit());          // (a triangle's two units share a 64-byte line)
+    while (recs.size() % 4) recs.push_back(MeshUnit());       // (64-byte alignment of a mesh's first record)
     const uint32_t triBase = (uint32_t)recs.size();
     struct Leaf { float lo[3], hi[3], c[3]; int idx; };
     std::vector<Leaf> leaves((size_t)ntris);
     for (int a = 0; a < 3; ++a) { bbox[a] = INFINITY; bbox[3 + a] = -INFINITY; }
     for (int i = 0; i < ntris; ++i) {
         const float *t = tris + 9 * (size_t)i;
-        float mt[16];
+        float mt[12];
         memset(mt, 0, sizeof mt);
         Leaf &L = leaves[(size_t)i];
         L.idx = i;
         for (int a = 0; a < 3; ++a) {
             mt[a] = t[a];
-            mt[3 + a] = t[3 + a] - t[a];
-            mt[6 + a] = t[6 + a] - t[a];
+            mt[3 + a] = t[3 + a];
+            mt[6 + a] = t[6 + a];
             L.lo[a] = min2(min2(t[a], t[3 + a]), t[6 + a]) - m;
             L.hi[a] = max2(max2(t[a], t[3 + a]), t[6 + a]) + m;
-            mt[9 + a] = L.lo[a];
-            mt[12 + a] = L.hi[a];
             L.c[a] = 0.5f * (L.lo[a] + L.hi[a]);
             bbox[a] = min2(bbox[a], L.lo[a]);
             bbox[3 + a] = max2(bbox[3 + a], L.hi[a]);
         }
-        MeshUnit u[2];
+        mt[9] = m;
+        MeshUnit u[3];
         memcpy(u, mt, sizeof mt);
         recs.push_back(u[0]);
         recs.push_back(u[1]);
+        recs.push_back(u[2]);
     }
     MeshLayout lay;
     lay.stackNeed = 0;
     // an inner node's record for octant `oct`: child h's box as entry / exit planes (entry = lo where the rays of the octant run
     // towards +axis, hi where they run towards -axis), refs in f[3] and f[7]
+    struct Node { MeshUnit u[2]; };
     auto innerRec = [](int oct, const float *lo0, const float *hi0, uint32_t ref0, const float *lo1, const float *hi1, uint32_t ref1) {
-        MeshUnit n;
+        Node n;
         const float *lo[2] = {lo0, lo1}, *hi[2] = {hi0, hi1};
         const uint32_t ref[2] = {ref0, ref1};
         for (int h = 0; h < 2; ++h) {
@@ -133,27 +136,29 @@ inline MeshLayout appendMesh(const float *tris, int ntris, bool flat, std::vecto
                 pl[a] = neg ? u : l;
                 pl[3 + a] = neg ? l : u;
             }
-            for (int k = 0; k < 3; ++k) n.w[4 * h + k] = (uint32_t)pl[2 * k] | ((uint32_t)pl[2 * k + 1] << 16);
-            n.w[4 * h + 3] = ref[h];
+            for (int k = 0; k < 3; ++k) n.u[h].w[k] = (uint32_t)pl[2 * k] | ((uint32_t)pl[2 * k + 1] << 16);
+            n.u[h].w[3] = ref[h];
         }
         return n;
     };
+    auto pushNode = [&recs](const Node &n) { recs.push_back(n.u[0]); recs.push_back(n.u[1]); };
     // a box no ray passes (entry planes at +inf of the ray's parameter, exit planes at -inf) / every ray passes
     const float kNone[2][3] = {{INFINITY, INFINITY, INFINITY}, {-INFINITY, -INFINITY, -INFINITY}};
     const float kAll[2][3] = {{-INFINITY, -INFINITY, -INFINITY}, {INFINITY, INFINITY, INFINITY}};
+    if (recs.size() % 2) recs.push_back(MeshUnit());          // (an inner node's two units share a 32-byte sector)
     const uint32_t innerBase = (uint32_t)recs.size();
     if (ntris == 1 || flat) {
         // one triangle: a root whose near child is the triangle and whose far child is nothing.  flat: a chain -- near child =
         // triangle i, far child = the rest of the chain in a box that holds everything (the last node: triangle ntris - 1)
-        const uint32_t stride = (uint32_t)std::max(ntris - 1, 1);
+        const uint32_t stride = (uint32_t)std::max(ntris - 1, 1) * kMeshNodeUnits;
         for (int oct = 0; oct < 8; ++oct) {
             const uint32_t base = innerBase + (uint32_t)oct * stride;
-            for (uint32_t i = 0; i < stride; ++i) {
+            for (uint32_t i = 0; i * kMeshNodeUnits < stride; ++i) {
                 const Leaf &L = leaves[(size_t)i];
-                const uint32_t ref0 = kMeshLeaf | (triBase + 2u * i);
-                if (ntris == 1) recs.push_back(innerRec(oct, L.lo, L.hi, ref0, kNone[0], kNone[1], ref0));
-                else if (i + 2 == (uint32_t)ntris) recs.push_back(innerRec(oct, L.lo, L.hi, ref0, leaves[(size_t)i + 1].lo, leaves[(size_t)i + 1].hi, kMeshLeaf | (triBase + 2u * (i + 1u))));
-                else recs.push_back(innerRec(oct, L.lo, L.hi, ref0, kAll[0], kAll[1], base + i + 1u));
+                const uint32_t ref0 = kMeshLeaf | (triBase + kMeshTriUnits * i);
+                if (ntris == 1) pushNode(innerRec(oct, L.lo, L.hi, ref0, kNone[0], kNone[1], ref0));
+                else if (i + 2 == (uint32_t)ntris) pushNode(innerRec(oct, L.lo, L.hi, ref0, leaves[(size_t)i + 1].lo, leaves[(size_t)i + 1].hi, kMeshLeaf | (triBase + kMeshTriUnits * (i + 1u))));
+                else pushNode(innerRec(oct, L.lo, L.hi, ref0, kAll[0], kAll[1], base + kMeshNodeUnits * (i + 1u)));
             }
         }
         lay.root = innerBase;
@@ -299,9 +304,8 @@ inline MeshLayout appendMesh(const float *tris, int ntris, bool flat, std::vecto
         builder.build(0, ntris);
         lay.stackNeed = needAll();
     }
-    const uint32_t stride = (uint32_t)ntris - 1u;            // inner nodes of a binary tree with ntris leaves
+    const uint32_t stride = ((uint32_t)ntris - 1u) * kMeshNodeUnits;     // (a binary tree with ntris leaves has ntris - 1 inner nodes)
     for (int oct = 0; oct < 8; ++oct) {
-        const uint32_t base = innerBase + (uint32_t)oct * stride;
         // depth-first emission of the inner nodes; a child's ref is known once its position is: inner children are numbered as
         // they are met (near child = the next record, far child = after the near child's inner nodes)
         struct Emit {
@@ -317,18 +321,19 @@ inline MeshLayout appendMesh(const float *tris, int ntris, bool flat, std::vecto
                 const int c[2] = {upperFirst ? t.right : t.left, upperFirst ? t.left : t.right};
                 const uint32_t me = (uint32_t)recs.size();
                 recs.push_back(MeshUnit());
+                recs.push_back(MeshUnit());
                 uint32_t ref[2];
-                ref[0] = tree[(size_t)c[0]].tri >= 0 ? (kMeshLeaf | (triBase + 2u * (uint32_t)tree[(size_t)c[0]].tri)) : me + 1u;
-                ref[1] = tree[(size_t)c[1]].tri >= 0 ? (kMeshLeaf | (triBase + 2u * (uint32_t)tree[(size_t)c[1]].tri))
-                                                      : me + 1u + (uint32_t)inner(tree, c[0]);
-                const MeshUnit n = innerRec(oct, tree[(size_t)c[0]].lo, tree[(size_t)c[0]].hi, ref[0], tree[(size_t)c[1]].lo, tree[(size_t)c[1]].hi, ref[1]);
-                recs[(size_t)me] = n;
+                ref[0] = tree[(size_t)c[0]].tri >= 0 ? (kMeshLeaf | (triBase + kMeshTriUnits * (uint32_t)tree[(size_t)c[0]].tri)) : me + kMeshNodeUnits;
+                ref[1] = tree[(size_t)c[1]].tri >= 0 ? (kMeshLeaf | (triBase + kMeshTriUnits * (uint32_t)tree[(size_t)c[1]].tri))
+                                                      : me + kMeshNodeUnits * (1u + (uint32_t)inner(tree, c[0]));
+                const auto n = innerRec(oct, tree[(size_t)c[0]].lo, tree[(size_t)c[0]].hi, ref[0], tree[(size_t)c[1]].lo, tree[(size_t)c[1]].hi, ref[1]);
+                recs[(size_t)me] = n.u[0];
+                recs[(size_t)me + 1] = n.u[1];
                 if (tree[(size_t)c[0]].tri < 0) emit(c[0]);
                 if (tree[(size_t)c[1]].tri < 0) emit(c[1]);
             }
         } e{tree, recs, triBase, oct, innerRec};
         e.emit(0);
-        (void)base;
     }
     lay.root = innerBase;
     lay.stride = stride;

@@ -111,14 +111,16 @@ def test_hierarchy_invariants(pt):
     LEAF = pt.MESH_LEAF
     for tris, octant in cases:
         nt = len(tris)
-        recs, nodes, need = pt.mesh_bvh(tris, octant)
+        recs, nodes, first, need = pt.mesh_bvh(tris, octant)
         assert len(recs) == nt and len(nodes) == max(nt - 1, 1)
         margin = f32(1e-5) * np.abs(tris).max()
         v = tris.reshape(nt, 3, 3)
         neg = np.array([(octant >> a) & 1 for a in range(3)], bool)
-        for i, r in enumerate(recs):                          # triangle i, file order: v0, the two edges, and the triangle's own box
-            assert np.array_equal(r["v0"], v[i][0]) and np.array_equal(r["e1"], v[i][1] - v[i][0]) and np.array_equal(r["e2"], v[i][2] - v[i][0])
-            assert np.array_equal(r["lo"], v[i].min(0) - margin) and np.array_equal(r["hi"], v[i].max(0) + margin)
+        for i, r in enumerate(recs):                          # triangle i, file order: its vertices and the mesh's margin
+            assert np.array_equal(r["v0"], v[i][0]) and np.array_equal(r["v1"], v[i][1]) and np.array_equal(r["v2"], v[i][2])
+            assert r["margin"] == margin
+        box_lo = lambda t: v[t].min(0) - margin                # a triangle's own box, as the kernel derives it
+        box_hi = lambda t: v[t].max(0) + margin
         def planes_of(lo, hi):
             # the six halves of a box for this octant: entry planes, exit planes; lo rounded down, hi up (never inwards, and by
             # less than one half-precision step)
@@ -132,7 +134,7 @@ def test_hierarchy_invariants(pt):
             # a root whose near child is the triangle and whose far child is a box no ray passes (entered at +inf, left at -inf)
             nd = nodes[0]
             assert need == 0 and int(nd["ref"]) == LEAF
-            assert np.array_equal(nd["planes"], planes_of(recs[0]["lo"], recs[0]["hi"]))
+            assert np.array_equal(nd["planes"], planes_of(box_lo(0), box_hi(0)))
             fp = nd["far_planes"].astype(f32)
             assert np.all(np.isinf(fp)) and np.all((fp[:3] > 0) != neg) and np.all((fp[3:] < 0) != neg)
             continue
@@ -144,11 +146,12 @@ def test_hierarchy_invariants(pt):
         def box_of(ref):
             ref = int(ref)
             if ref & LEAF:
-                t = (ref & ~LEAF) // 2
-                assert (ref & ~LEAF) % 2 == 0
+                t = (ref & ~LEAF) // 3
+                assert (ref & ~LEAF) % 3 == 0
                 seen_tri.append(t)
-                return recs[t]["lo"], recs[t]["hi"], 0, 0
-            k = ref - 2 * nt
+                return box_lo(t), box_hi(t), 0, 0
+            assert (ref - first) % 2 == 0
+            k = (ref - first) // 2
             assert 0 <= k < len(nodes)
             seen_node.append(k)
             nd = nodes[k]
@@ -160,17 +163,17 @@ def test_hierarchy_invariants(pt):
             assert any((cl[a] >= cr[a]) if (octant >> a) & 1 else (cl[a] <= cr[a]) for a in range(3))
             # depth-first layout: the near child's inner nodes follow their parent directly, the far child's come after them
             if not int(nd["ref"]) & LEAF:
-                assert int(nd["ref"]) - 2 * nt == k + 1
+                assert (int(nd["ref"]) - first) // 2 == k + 1
             return np.minimum(nlo, flo), np.maximum(nhi, fhi), 1 + max(nd_, fd_), max(1 + nn, fn)
 
-        _, _, depth, need_here = box_of(2 * nt)
+        _, _, depth, need_here = box_of(first)
         assert sorted(seen_tri) == list(range(nt)) and sorted(seen_node) == list(range(nt - 1))
         assert depth <= 3 * int(np.ceil(np.log2(max(nt, 1)))) + 2                      # no side of a split below an eighth: logarithmic
         # the far children that can wait at once on a lane's stack: this copy's need is within what pt_init reserves for all eight
         assert need_here <= need <= depth and need <= 24
 
 
-def _walk(recs, nodes, tris, oracle, ro, rd, need):
+def _walk(recs, nodes, first, tris, oracle, ro, rd, need):
     """The kernel's traversal (ptd::meshIntersectionTest) in numpy fp32 on object-space rays; triangle test by the oracle."""
     LEAF = 0x80000000
     nt = len(recs)
@@ -194,15 +197,16 @@ def _walk(recs, nodes, tris, oracle, ro, rd, need):
         tmin = f32(tn * dn)
         return bool(f32(tf * up) >= tmin and tf >= 0 and (best < 0 or not tmin > tbest))
 
-    ref = 2 * nt
+    ref = first
     stack = []
+    margin = recs[0]["margin"]
     while True:
         visited += 1
         pop = True
         if ref & LEAF:
-            tri = (ref & ~LEAF) // 2
-            r = recs[tri]
-            ok, tmin = box_pass(r["lo"], r["hi"])
+            tri = (ref & ~LEAF) // 3
+            vv = np.stack([recs[tri]["v0"], recs[tri]["v1"], recs[tri]["v2"]])
+            ok, tmin = box_pass(vv.min(0) - margin, vv.max(0) + margin)
             if ok:
                 v = tris[tri]
                 hit, tuv, front = oracle.mesh_triangle(ro, rd, v[0:3], v[3:6], v[6:9])
@@ -210,7 +214,7 @@ def _walk(recs, nodes, tris, oracle, ro, rd, need):
                 if hit and t >= tmin and (best < 0 or t < tbest or (t == tbest and tri < best)):
                     best, tbest = tri, t
         else:
-            nd = nodes[int(ref) - 2 * nt]
+            nd = nodes[(int(ref) - first) // 2]
             pn = planes_pass(nd["planes"])
             pf = planes_pass(nd["far_planes"])
             if pn and pf:
@@ -247,7 +251,7 @@ def test_hierarchy_walk_equals_the_brute_force_rule(pt, oracle):
             rd = oracle.normalize(d)
             wt, wp, wn, wo, wtri = oracle.mesh_intersect(ident, tris, np.concatenate([o, d]))
             octant = int(np.signbit(rd[0])) | int(np.signbit(rd[1])) << 1 | int(np.signbit(rd[2])) << 2
-            best, tbest, vis = _walk(copies[octant][0], copies[octant][1], tris, oracle, o, rd, copies[octant][2])
+            best, tbest, vis = _walk(*copies[octant][:3], tris, oracle, o, rd, copies[octant][3])
             assert best == wtri, (g, i, best, wtri)
             hits += best >= 0
             visited += vis
