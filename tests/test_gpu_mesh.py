@@ -99,6 +99,38 @@ def test_mesh_test_against_the_oracle_per_ray(gpu, oracle, flat):
     assert hits > 1500 and culled_total > 300
 
 
+def test_mesh_half_precision_planes_at_the_extremes(gpu, oracle):
+    # The inner nodes keep their children's boxes as half-precision planes rounded outwards (pt_mesh.h: halfBitsDirected).  Object
+    # coordinates beyond the half range (planes at the largest finite half or at infinity), in the subnormal halves, straddling
+    # zero, and the smallest hierarchies (one triangle: a root with one child; two; three) -- per ray against the oracle's loop
+    # over every triangle, bit for bit, with the hierarchy and with the plain list.
+    sc = gpu.Scene(os.path.join(SCENES, "mesh_small.txt"))
+    rng = np.random.default_rng(20261004)
+    base = sc.meshes[4]                                                   # the 128-triangle torus
+    cases = []
+    for k, (obj_scale, label) in enumerate(((1.0e5, "beyond the half range"), (3.0e-7, "subnormal halves"), (70000.0, "around 65504"))):
+        tris = (base * np.float32(obj_scale)).astype(np.float32)
+        inv = 1.0 / obj_scale
+        cases.append((oracle.make_geom(2, 0, (1.0, 2.0, -0.5), (20 * k, 35, -10), (2 * inv, 3 * inv, 2.5 * inv)), tris))
+    cases.append((oracle.make_geom(2, 0, (0, 0, 0), (0, 0, 0), (1, 1, 1)), base - np.float32(0.25)))      # boxes straddling zero
+    for nt in (1, 2, 3, 5):
+        cases.append((oracle.make_geom(2, 0, (0.5, 0, 0), (10, 20, 30), (2, 2, 2)), base[:nt].copy()))
+    hits = 0
+    for geom, tris in cases:
+        rays = mesh_rays(rng, geom, tris, 768)
+        for flat in (False, True):
+            t, p, n, o, culled = gpu.test_mesh_intersect(geom, tris, rays, flat=flat)
+            assert not np.isnan(t[culled != 0]).any()
+            for i in range(len(rays)):
+                wt, wp, wn, wo, _ = oracle.mesh_intersect(geom.view(oracle.GEOM_DTYPE), tris, rays[i])
+                assert np.float32(t[i]).view(np.uint32) == np.float32(wt).view(np.uint32), (len(tris), flat, i, rays[i], t[i], wt)
+                assert np.array_equal(p[i].view(np.uint32), wp.view(np.uint32)) and o[i] == wo
+                if wt != -1.0:
+                    assert np.array_equal(n[i].view(np.uint32), wn.view(np.uint32))
+            hits += int((t > 0).sum())
+    assert hits > 1500
+
+
 def test_bounding_ball_never_rejects_a_mesh_hit(gpu, oracle):
     """2^24 rays per case, dense in grazes of the bounding ball, origins 1/64 .. 64 radii away: the world-space test that
     lets tiles skip a mesh (and classes the queue) never rejects a ray the full walk hits."""

@@ -173,6 +173,33 @@ def test_hierarchy_invariants(pt):
         assert need_here <= need <= depth and need <= 24
 
 
+def test_half_precision_planes_round_outwards_everywhere(pt):
+    # halfBitsDirected (pt_mesh.h) on boxes from 1e-9 to 1e6, both signs: a node's planes contain the exact box, by less than
+    # one step of half precision; beyond the half range they are the largest finite half or infinity, on the permitted side
+    rng = np.random.default_rng(5)
+    for scale in (1e-9, 3e-7, 6e-5, 1e-3, 1.0, 300.0, 65504.0, 7e4, 1e6):
+        tris = (rng.uniform(-1, 1, (6, 9)) * scale).astype(f32)
+        recs, nodes, first, need = pt.mesh_bvh(tris, 0)
+        margin = f32(1e-5) * np.abs(tris).max()
+        v = tris.reshape(-1, 3, 3)
+        for nd in nodes:
+            for ref, planes in ((int(nd["ref"]), nd["planes"]), (int(nd["far_ref"]), nd["far_planes"])):
+                if not ref & pt.MESH_LEAF:
+                    continue
+                t = (ref & ~pt.MESH_LEAF) // 3
+                lo, hi = v[t].min(0) - margin, v[t].max(0) + margin
+                pl = planes.astype(np.float64)
+                assert np.all(pl[:3] <= lo) and np.all(pl[3:] >= hi)                      # (octant 0: entry = lo, exit = hi)
+                lo16, hi16 = planes[:3], planes[3:]
+                fin = np.isfinite(lo16.astype(np.float64))
+                assert np.all(np.nextafter(lo16, np.float16(np.inf)).astype(np.float64)[fin] > lo[fin])   # the nearest half below
+                fin = np.isfinite(hi16.astype(np.float64))
+                assert np.all(np.nextafter(hi16, np.float16(-np.inf)).astype(np.float64)[fin] < hi[fin])
+                exact = np.concatenate([lo, hi]).astype(np.float64)
+                big = np.abs(exact) > 65504.0                                             # beyond the half range
+                assert np.all((np.abs(pl[big]) == 65504.0) | np.isinf(pl[big]))
+
+
 def _walk(recs, nodes, first, tris, oracle, ro, rd, need):
     """The kernel's traversal (ptd::meshIntersectionTest) in numpy fp32 on object-space rays; triangle test by the oracle."""
     LEAF = 0x80000000
