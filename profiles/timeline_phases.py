@@ -13,7 +13,7 @@ L = pt.lib()
 L.pt_probe_timeline.argtypes = [C.POINTER(C.c_uint64)]
 names = {14: "tile start: set-up / camera ray", 15: "nearest-hit loop", 16: "after the loop -> a hit's record", 9: "shading: hit record, normal, material",
          10: "scatter: engine, branch by material", 11: "hemisphere sample", 12: "bounding-ball certificates", 13: "wall certificates, class", 17: "next tile: segment look-up (LDS)",
-         26: "next tile: chunk look-up (scalar cache)", 27: "next tile: 11 loads issued",
+         26: "next tile: chunk look-up (scalar cache)", 27: "next tile: 3 loads issued",
          18: "compaction: ballots, ranks", 21: "wait at the first barrier", 22: "reservation (atomic round trip) / waves 1-3 idle", 23: "wait at the second barrier",
          19: "stores", 20: "tile end -> next tile start", 30: "prologue (staging, scan of the segment counts)"}
 order = [30, 14, 15, 16, 9, 10, 11, 12, 13, 17, 26, 27, 18, 21, 22, 23, 19, 20]
