@@ -120,6 +120,34 @@ def cpu_model():
     return "unknown"
 
 
+def box_calibration(pt, torch):
+    """What THIS box does on a fixed memory-bound job, beside the line's own numbers: the library's exclusive scan of 2^26 int32
+    (8 algorithmic bytes per element; 0.19 ms = 2.8 TB/s on the boxes of rounds 2-3).  Boxes of the pool differ -- the same two
+    builds measured 167 G and 228 G paths/s on two boxes within minutes (profiles/r03_sensitivity_experiments.txt) -- and a
+    reader of one line cannot tell a slow box from a slow build without it."""
+    n = 1 << 26
+    try:
+        x = torch.ones(n, dtype=torch.int32, device="cuda")
+        y = torch.empty_like(x)
+        st = torch.cuda.current_stream().cuda_stream
+        for _ in range(3):
+            pt.scan_exclusive_dev(x.data_ptr(), y.data_ptr(), n, st)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 20
+        e0.record()
+        for _ in range(reps):
+            pt.scan_exclusive_dev(x.data_ptr(), y.data_ptr(), n, st)
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        ok = int(y[-1].item()) == n - 1
+        del x, y
+        return {"job": "pt_scan_exclusive_i32 of 2^26 elements, 20 calls", "ms_per_call": round(ms, 4),
+                "algorithmic_GBps": round(8.0 * n / (ms * 1e-3) / 1e9, 1), "result_checked": ok}
+    except Exception as e:            # (a calibration must never cost the line)
+        return {"job": "pt_scan_exclusive_i32 of 2^26 elements", "error": repr(e)}
+
+
 def cpu_baseline(args, scene, pt):
     """Single-thread CPU oracle (oracle/, kind 'port') on a bounded sample of the same workload, pinned to ONE core; plus BASELINE
     config C1 (scenes/sphere.txt 400x400, 1 spp, depth 4) in full."""
@@ -554,6 +582,7 @@ def run(args, ctx):
                 if k in multi:
                     out[k] = multi.pop(k)
             out["multi_gpu"] = multi
+        out["box_calibration"] = box_calibration(pt, torch)
         if world == 1 and args.cpu_spp > 0:
             out["cpu_baseline"] = cpu_baseline(args, scene, pt)
         print(json.dumps(out), flush=True)

@@ -45,6 +45,8 @@ def test_bench_json_contract(pt):
     assert d["ms_per_step"] == sorted(d["ms_per_step_blocks"])[2]
     assert d["ms_per_step_min"] == min(d["ms_per_step_blocks"]) and d["ms_per_step_max"] == max(d["ms_per_step_blocks"])
     assert d["value_min"] <= d["value"] <= d["value_max"]
+    # the line says what the box it ran on does on a fixed job (boxes of the pool differ by up to 1.8x)
+    assert d["box_calibration"]["result_checked"] is True and d["box_calibration"]["algorithmic_GBps"] > 500
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
     assert cb["cpu_model"] and cb["host_cores"] >= 1 and cb["pinned_to_core"] is not None
