@@ -100,6 +100,7 @@ struct State {
     int maxBatch = 1;       // iterations that may share one wavefront (pt_iterate_batch)
     Slot slot[kMaxSlots];
     GeomDev *dgeoms = nullptr;
+    float4 *dGeomHit = nullptr;     // GeomHitDev[ngeoms], as the kernels stage it in LDS (scenes that are not sphere-heavy)
     MaterialDev *dmats = nullptr;
     WallBox *dwalls = nullptr;
     SphereCull *dSphCull = nullptr; // sphere-heavy scenes: packed culling data of the spheres, and ...
@@ -699,7 +700,7 @@ int launch_bounce(Slot &sl, int iter, int batch, int depth, bool lastBounce, flo
                   ((S.prm.directDepth != 0 && depth == S.prm.directDepth && S.prm.nEmit > 0) ? kHotToLight : 0u) |
                   (S.prm.contribLocal ? kHotContribLocal : 0u) | ((uint32_t)S.prm.nWalls << 8) | ((uint32_t)S.prm.nSlotWalls << 11) |
                   ((uint32_t)S.prm.nBinned << 14) | ((uint32_t)S.prm.nmats << 20);
-    ba.ctrl = sl.ctrl; ba.ggeoms = S.dgeoms; ba.gmats = S.dmats; ba.contrib = contrib; ba.hitMask = sl.hitMask;
+    ba.ctrl = sl.ctrl; ba.ggeoms = S.dgeoms; ba.gmats = S.dmats; ba.ghit = S.dGeomHit; ba.contrib = contrib; ba.hitMask = sl.hitMask;
     ba.sphCull = S.dSphCull; ba.classIdx = S.dClassIdx;
     ba.rowOff = S.dRowOff; ba.rowIdx = S.dRowIdx;
     ba.walls = S.dwalls;
@@ -928,6 +929,7 @@ void pt_free(void) {
     if (S.hostFault) (void)hipHostFree(S.hostFault);
     if (S.ownImage && S.image) (void)hipFree(S.image);
     if (S.dgeoms) (void)hipFree(S.dgeoms);
+    if (S.dGeomHit) (void)hipFree(S.dGeomHit);
     if (S.dmats) (void)hipFree(S.dmats);
     if (S.dwalls) (void)hipFree(S.dwalls);
     if (S.dSphCull) (void)hipFree(S.dSphCull);
@@ -1216,6 +1218,25 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     HIPCHECK(hipMalloc(&S.dmats, hm.size() * sizeof(MaterialDev)));
     HIPCHECK(hipMemcpy(S.dgeoms, hg.data(), hg.size() * sizeof(GeomDev), hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(S.dmats, hm.data(), hm.size() * sizeof(MaterialDev), hipMemcpyHostToDevice));
+    {   // the per-primitive hit records, ready-made: a workgroup's prologue copies them to LDS in one round trip instead of following
+        // primitive -> material index -> material on the device (every workgroup of every launch did)
+        std::vector<GeomHitDev> hh(hg.size());
+        for (size_t i = 0; i < hg.size(); ++i) {
+            GeomHitDev &h = hh[i];
+            memset(&h, 0, sizeof h);
+            const GeomDev &G = hg[i];
+            const int mi = (int)i < ngeoms && G.material >= 0 && G.material < nmats ? G.material : 0;
+            const MaterialDev &M = hm[(size_t)mi];
+            h.type = G.type;
+            h.emittance = M.emittance; h.hasReflective = M.hasReflective; h.hasRefractive = M.hasRefractive;
+            for (int a = 0; a < 3; ++a) h.color[a] = M.color[a];
+            h.material = G.material;
+            memcpy(h.nm, G.invT, sizeof h.nm);
+            memcpy(h.cubeFrame, G.cubeFrame, sizeof h.cubeFrame);
+        }
+        HIPCHECK(hipMalloc(&S.dGeomHit, hh.size() * sizeof(GeomHitDev)));
+        HIPCHECK(hipMemcpy(S.dGeomHit, hh.data(), hh.size() * sizeof(GeomHitDev), hipMemcpyHostToDevice));
+    }
     HIPCHECK(hipMalloc(&S.dwalls, hw.size() * sizeof(WallBox)));
     HIPCHECK(hipMemcpy(S.dwalls, hw.data(), hw.size() * sizeof(WallBox), hipMemcpyHostToDevice));
     S.mesh = !meshRecs.empty();

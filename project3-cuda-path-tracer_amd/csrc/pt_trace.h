@@ -368,6 +368,7 @@ struct BounceArgs {
     Ctrl *ctrl;
     const GeomDev *ggeoms;
     const MaterialDev *gmats;
+    const float4 *ghit;                 // GeomHitDev[ngeoms] (19 x 16 B each), staged in LDS by the prologue
     float *contrib;
     const WallBox *walls;               // [prm.nWalls] inflated world-space boxes of the walls
     const float4 *meshRecs;             // ptd::MeshRec[] of every mesh of the scene (k_bounce<., ., ., true>), or nullptr
@@ -447,6 +448,17 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
         const ArgsPtr A = launder(kargs);
         Ctrl *const ctrl = A->ctrl;
         const int depth = A->depth, parity = A->parity;
+        // The prologue's global reads ALL go out here, before anything waits: the first 256 x 16 bytes of the materials and of the
+        // ready-made hit records (Cornell: 20 + 152) stay in registers across the scan of the segment counts, whose own loads follow.
+        // (Round 3's timeline: 29 k cycles of prologue per workgroup and launch -- kernel arguments, counts, barrier, materials,
+        // primitive, ITS material, barrier: five dependent round trips, a third of a last bounce's 33 us.)
+        const int m16 = A->prm.nmats * (int)(sizeof(MaterialDev) / 16);
+        const int h16 = MANY ? 0 : A->prm.ngeoms * (int)(sizeof(GeomHitDev) / 16);
+        const float4 *const msrc = reinterpret_cast<const float4 *>(A->gmats);
+        const float4 *const hsrc = A->ghit;
+        float4 stageM = make_float4(0, 0, 0, 0), stageH = make_float4(0, 0, 0, 0);
+        if ((int)threadIdx.x < m16) stageM = msrc[threadIdx.x];
+        if ((int)threadIdx.x < h16) stageH = hsrc[threadIdx.x];
         if (A->lastBounce) {   // re-arm the slot's next batch: nobody touches the other parity's counters now
             uint32_t *other = &ctrl->pos[parity ^ 1][0][0][0];
             const int nwords = (A->prm.traceDepth + 2) * kSeg;
@@ -516,10 +528,9 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
         const int ngeoms = A->prm.ngeoms;
         GeomHitDev *const s_geomHit = S_GEOMHIT(A->prm.nmats);
         float *const s_sph = S_SPH(A->prm.nmats, ngeoms, A->prm.nCubes);   // MANY: [ngeoms][kSphRowFloats]
-        const float4 *msrc = reinterpret_cast<const float4 *>(A->gmats);
         float4 *mdst = reinterpret_cast<float4 *>(smats);
-        const int m16 = A->prm.nmats * (int)(sizeof(MaterialDev) / 16);
-        for (int i = threadIdx.x; i < m16; i += kBlock) mdst[i] = msrc[i];
+        if ((int)threadIdx.x < m16) mdst[threadIdx.x] = stageM;
+        for (int i = threadIdx.x + kBlock; i < m16; i += kBlock) mdst[i] = msrc[i];
         if (MANY) {
             constexpr int kSmallWords = (int)(sizeof(GeomHitSmall) / 4);
             uint32_t *const dst = reinterpret_cast<uint32_t *>(S_GEOMHIT_SMALL(A->prm.nmats));
@@ -540,21 +551,10 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
                 if (G.type == 1) fr[(int)G.frameSlot * 54 + k] = G.cubeFrame[k];
             }
         }
-        constexpr int kHitWords = (int)(sizeof(GeomHitDev) / 4);
-        for (int i = threadIdx.x; !MANY && i < ngeoms * kHitWords; i += kBlock) {
-            const int g = i / kHitWords, k = i - g * kHitWords;
-            const GeomDev &G = ggeoms[g];
-            const MaterialDev &Mg = A->gmats[G.material];      // (the header carries the hot fields of the primitive's material)
-            uint32_t v = 0;
-            if (k == 0) v = (uint32_t)G.type;
-            else if (k == 1) v = __float_as_uint(Mg.emittance);
-            else if (k == 2) v = __float_as_uint(Mg.hasReflective);
-            else if (k == 3) v = __float_as_uint(Mg.hasRefractive);
-            else if (k < 7) v = __float_as_uint(Mg.color[k - 4]);
-            else if (k == 7) v = (uint32_t)G.material;
-            else if (k < 20) v = __float_as_uint(G.invT[k - 8]);
-            else if (k < 20 + 54) v = __float_as_uint(G.cubeFrame[k - 20]);
-            reinterpret_cast<uint32_t *>(s_geomHit)[i] = v;
+        if (!MANY) {
+            float4 *const hdst = reinterpret_cast<float4 *>(s_geomHit);
+            if ((int)threadIdx.x < h16) hdst[threadIdx.x] = stageH;
+            for (int i = threadIdx.x + kBlock; i < h16; i += kBlock) hdst[i] = hsrc[i];
         }
         if (MANY) {
             for (int i = threadIdx.x; i < ngeoms * 27; i += kBlock) {
