@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -297,7 +298,10 @@ inline MeshLayout appendMesh(const float *tris, int ntris, bool flat, std::vecto
         return n;
     };
     lay.stackNeed = needAll();
-    if (lay.stackNeed > kMeshStackSoftMax) {                 // (lopsided splits all the way down: median splits bound the depth by log2)
+    // (tests only: PT_AMD_MESH_STACK_MAX lowers the threshold so that ordinary meshes take the rebuild)
+    const char *envMax = getenv("PT_AMD_MESH_STACK_MAX");
+    const int softMax = envMax && atoi(envMax) > 0 ? atoi(envMax) : kMeshStackSoftMax;
+    if (lay.stackNeed > softMax) {                           // (lopsided splits all the way down: median splits bound the depth by log2)
         tree.clear();
         std::sort(leaves.begin(), leaves.end(), [](const Leaf &x, const Leaf &y) { return x.idx < y.idx; });
         builder.medianOnly = true;

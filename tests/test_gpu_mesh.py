@@ -181,6 +181,15 @@ def test_mesh_scene_render_against_the_oracle(gpu, oracle):
     _render_both(gpu, oracle, sc, 6, [1, 2, 3], (96, 96), dump_bounces=(1, 2, 4))
 
 
+def test_mesh_scene_render_with_the_median_rebuild(gpu, oracle, monkeypatch):
+    # pt_init rebuilds a hierarchy that would need more stack levels than its threshold by median splits alone (pt_mesh.h); the
+    # tests' switch lowers the threshold so that the small scene's meshes take that path: the same frame, bit for bit
+    sc = gpu.Scene(os.path.join(SCENES, "mesh_small.txt"))
+    monkeypatch.setenv("PT_AMD_MESH_STACK_MAX", "3")
+    _render_both(gpu, oracle, sc, 6, [1, 2, 3], (96, 96), dump_bounces=(1, 3))
+    monkeypatch.delenv("PT_AMD_MESH_STACK_MAX")
+
+
 def test_mesh_scene_row_shards(gpu, oracle):
     sc = gpu.Scene(os.path.join(SCENES, "mesh_small.txt"))
     total = np.zeros(96 * 96 * 3, np.float32)

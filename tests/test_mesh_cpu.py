@@ -173,6 +173,33 @@ def test_hierarchy_invariants(pt):
         assert need_here <= need <= depth and need <= 24
 
 
+def test_median_rebuild_bounds_the_stack(pt, oracle, monkeypatch):
+    # a hierarchy that would need more stack levels than the threshold (24; lowered here through the tests' switch) is rebuilt by
+    # median splits alone: need <= ceil(log2 ntris), the same invariants, the same winners as the loop over every triangle
+    sc = pt.Scene(os.path.join(SCENES, "cornell_mesh.txt"))
+    tris = sc.meshes[7]
+    _, _, _, need_sah = pt.mesh_bvh(tris, 0)
+    monkeypatch.setenv("PT_AMD_MESH_STACK_MAX", str(need_sah - 1))
+    copies = [pt.mesh_bvh(tris, o) for o in range(8)]
+    monkeypatch.delenv("PT_AMD_MESH_STACK_MAX")
+    need = copies[0][3]
+    assert need <= int(np.ceil(np.log2(len(tris)))) and need < need_sah + 1
+    ident = oracle.make_geom(2, 0, (0, 0, 0), (0, 0, 0), (1, 1, 1))
+    rng = np.random.default_rng(11)
+    hits = 0
+    for i in range(200):
+        o = (rng.normal(size=3) * 2.0).astype(f32)
+        tgt = tris[rng.integers(len(tris))].reshape(3, 3).mean(0) + rng.normal(size=3) * 0.02
+        d = ((tgt - o) / np.linalg.norm(tgt - o)).astype(f32)
+        rd = oracle.normalize(d)
+        wt, wp, wn, wo, wtri = oracle.mesh_intersect(ident, tris, np.concatenate([o, d]))
+        octant = int(np.signbit(rd[0])) | int(np.signbit(rd[1])) << 1 | int(np.signbit(rd[2])) << 2
+        best, tbest, vis = _walk(*copies[octant][:3], tris, oracle, o, rd, copies[octant][3])
+        assert best == wtri
+        hits += best >= 0
+    assert hits > 150
+
+
 def test_half_precision_planes_round_outwards_everywhere(pt):
     # halfBitsDirected (pt_mesh.h) on boxes from 1e-9 to 1e6, both signs: a node's planes contain the exact box, by less than
     # one step of half precision; beyond the half range they are the largest finite half or infinity, on the permitted side
