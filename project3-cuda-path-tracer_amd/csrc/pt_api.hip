@@ -1154,6 +1154,38 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     const bool cullOff = S.dof || (getenv("PT_AMD_NO_CAMERA_CULL") && atoi(getenv("PT_AMD_NO_CAMERA_CULL")));   // (the variable: tests only)
     build_camera_cull(geoms, ngeoms, k, cullOff, boxes, hg, cc);
     for (int a = 0; a < 4; ++a) k.sceneRect[a] = cc.sceneRect[a];
+    {   // The camera-ray tiles' index space covers only the column bands (of kBlock pixels) and the rows of this shard that meet the
+        // scene rectangle: at 16:9 two of Cornell's five bands lie outside it, and a workgroup spent a tenth of the launch
+        // stepping over their tiles one by one.  The pixels never visited are misses whatever their jitter: tallied at once.
+        const int perRow = k.Wp / kBlock;
+        int c0 = 0, c1 = perRow - 1, r0 = 0, r1 = rows - 1;
+        if (cc.sceneRect[0] > cc.sceneRect[2] || cc.sceneRect[1] > cc.sceneRect[3]) {      // nothing can be hit
+            c1 = -1; r1 = -1;
+        } else {
+            c0 = std::max(cc.sceneRect[0], 0) / kBlock;
+            c1 = std::min(std::min(cc.sceneRect[2], Wd - 1) / kBlock, perRow - 1);
+            // rows y = lr * shard_count + shard_rank inside [sceneRect[1], sceneRect[3]]
+            const int y0 = std::max(cc.sceneRect[1], 0), y1 = std::min(cc.sceneRect[3], H - 1);
+            r0 = y0 <= o.shard_rank ? 0 : (y0 - o.shard_rank + o.shard_count - 1) / o.shard_count;
+            r1 = y1 < o.shard_rank ? -1 : std::min((y1 - o.shard_rank) / o.shard_count, rows - 1);
+        }
+        const int nCols = std::max(c1 - c0 + 1, 0), nRows = std::max(r1 - r0 + 1, 0);
+        const long long visited = nCols > 0 && nRows > 0 ? (long long)nRows * (std::min(Wd, (c1 + 1) * kBlock) - c0 * kBlock) : 0;
+        k.firstY0 = (nRows > 0 ? r0 : 0) * o.shard_count + o.shard_rank;      // (the first column: the band of sceneRect[0], k_bounce)
+        k.firstSkipped = (int)((long long)S.nLocal - visited);
+        k.Wp = std::max(nCols, 1) * kBlock;                       // (>= one band: the divisions below stay defined)
+        k.nLocalPad = nCols > 0 ? nRows * k.Wp : 0;
+        magic_divisor((uint32_t)k.Wp, k.magicWp, k.shiftWp);
+        magic_divisor((uint32_t)std::max(k.nLocalPad, 1), k.magicN, k.shiftN);
+        for (uint32_t d : {(uint32_t)k.Wp, (uint32_t)std::max(k.nLocalPad, 1)}) {
+            uint32_t m, sh;
+            magic_divisor(d, m, sh);
+            for (uint64_t q = 0; q * d < (1ull << 30); q = q < 64 ? q + 1 : q * 2 + 1)
+                for (uint64_t n : {q * d, q * d + d - 1, (uint64_t)((1ull << 30) - 1) - q})
+                    if (n < (1ull << 30) && (uint32_t)((n * m) >> sh) != (uint32_t)(n / d))
+                        return fail(PT_ERR_INVALID, "pt_init: magic division self-check failed for d=%u n=%llu", d, (unsigned long long)n);
+        }
+    }
     for (int i = 0; i < nmats; ++i) pack_material(mats[i], hm[i]);
     // Small primitives the queue is binned by (k_bounce): the spheres when there are at most kBinMax of them, then the
     // cubes whose bounding ball is small against the scene's (<= 0.3 of its radius), smallest first.  A choice that only

@@ -79,8 +79,10 @@ struct KParams {
     // Camera-ray tiles are laid over rows PADDED to a multiple of the tile size (Wp = ceil(W / 256) * 256; lanes beyond W idle), so a
     // tile is always 256 pixels of ONE row whatever the frame's width: its pixels follow from its wave-uniform position, it is
     // skipped as a whole outside the scene rectangle, and it walks its row's own list of primitives (rowOff / rowIdx).
-    int   Wp;           // padded row width
-    int   nLocalPad;    // rows of this shard x Wp: the tile index space of one iteration; magicN / shiftN divide by it
+    int   Wp;           // width of the camera-ray tiles' index space: the column bands (of kBlock pixels) that meet the scene rectangle
+    int   nLocalPad;    // this shard's rows that meet the scene rectangle x Wp: the tile index space of one iteration; magicN / shiftN divide by it
+    int   firstY0;              // image row of that index space's first row (its first column: the band of sceneRect[0])
+    int   firstSkipped;         // this shard's pixels outside it: camera rays that miss whatever their jitter (tallied once per iteration)
     uint32_t magicWp, shiftWp;   // n / Wp
     int   tilesPerRow;  // Wp / 256 when the camera-ray grid is a multiple of it (see k_bounce), else 0
     int   emittersBinned; // every primitive with an emissive material is one of binGeom[]
@@ -510,7 +512,8 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
             nLive = s_segpre[kSeg + 1];
         }
         if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctrl->sum_live[depth], (unsigned long long)nLive);
-        if (blockIdx.x >= numTiles) return;
+        // (camera rays: the pixels outside the tiles' index space are misses; workgroup 0 tallies them, tiles or no tiles)
+        if (blockIdx.x >= numTiles && !(FIRST && blockIdx.x == 0)) return;
         if (threadIdx.x < 2 * kWaves * kCls) s_wave[threadIdx.x] = 0u;
         if (threadIdx.x < kCls) s_base[3 * kCls + threadIdx.x] = 0xffffffffu;   // no chunk looked up yet
         if (threadIdx.x < kNanWords) s_iterHash[2 * PT_MAX_BATCH + 2 + threadIdx.x] = 0x7fc00000u;
@@ -700,8 +703,11 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
             const uint32_t itb0 = fastDiv(idx0, prm.magicN, prm.shiftN);
             const uint32_t j0 = idx0 - itb0 * (uint32_t)prm.nLocalPad;
             const int lr0 = (int)fastDiv(j0, prm.magicWp, prm.shiftWp);
-            const int x0 = (int)j0 - lr0 * prm.Wp;
-            const int y0 = lr0 * prm.shardCount + prm.shardRank;
+            // (the index space starts at the column band and the row that meet the scene rectangle first: the band from the
+            // rectangle's own bound, which the test below loads anyway, the row folded into the shard's offset by the host)
+            const int sr0 = prm.sceneRect[0], sr1 = prm.sceneRect[1], sr2 = prm.sceneRect[2], sr3 = prm.sceneRect[3];
+            const int x0 = ((int)j0 - lr0 * prm.Wp) + ((sr0 > 0 ? sr0 : 0) & ~(kBlock - 1));
+            const int y0 = lr0 * prm.shardCount + prm.firstY0;
             px = x0 + (int)tid;
             py = y0;
             itb = (int)itb0;
@@ -709,7 +715,6 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
             // When the tile lies outside the scene rectangle altogether, all its camera rays are misses -- tally them and take
             // the next tile (no rays, no compaction, no barrier; the test is the same for the four waves of the workgroup).
             // (the four bounds loaded together and compared without short-circuit: one scalar load, no chain of dependent ones)
-            const int sr0 = prm.sceneRect[0], sr1 = prm.sceneRect[1], sr2 = prm.sceneRect[2], sr3 = prm.sceneRect[3];
             if ((y0 < sr1) | (y0 > sr3) | (x0 + (kBlock - 1) < sr0) | (x0 > sr2)) {
                 nMiss += valid ? 1u : 0u;
                 T = Tnext;
@@ -1330,9 +1335,12 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
         const ArgsPtr A = launder(kargs);
         Ctrl *const ctrl = A->ctrl;
         const int shard = blockIdx.x % kOct;
-        const uint32_t wgLight = s_wave[0], wgMiss = s_wave[1], wgEarly = s_wave[2];
+        const uint32_t wgLight = s_wave[0], wgEarly = s_wave[2];
+        unsigned long long wgMiss = s_wave[1];
+        // (the camera rays of the pixels outside the tiles' index space, KParams::firstSkipped: misses whatever their jitter)
+        if (FIRST && blockIdx.x == 0) wgMiss += (unsigned long long)A->prm.firstSkipped * (unsigned long long)A->batch;
         if (wgLight) atomicAdd(&ctrl->light_hits[shard][0], (unsigned long long)wgLight);
-        if (wgMiss) atomicAdd(&ctrl->misses[shard][0], (unsigned long long)wgMiss);
+        if (wgMiss) atomicAdd(&ctrl->misses[shard][0], wgMiss);
         if (wgEarly) atomicAdd(&ctrl->early[A->depth + 1][shard][0], (unsigned long long)wgEarly);
     }
 }
