@@ -480,6 +480,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
             nLive = (uint32_t)A->prm.nLocal * (uint32_t)A->batch;     // `batch` consecutive iterations share one wavefront
             numTiles = (uint32_t)A->prm.nLocalPad / kBlock * (uint32_t)A->batch;   // (tiles lie on padded rows)
         } else {
+            const bool skipNonCand = A->tile.skipNonCandidates != 0u;
             if (threadIdx.x < 64) {          // wave 0: exclusive scan of the kSeg tile counts, kSeg / 64 consecutive segments per lane
                 constexpr int kPerLane = (kSeg + 63) / 64;
                 uint32_t cs[kPerLane], ts[kPerLane];
@@ -489,6 +490,9 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
                     const int sgi = (int)threadIdx.x * kPerLane + q;
                     cs[q] = sgi < kSeg ? ctrl->pos[parity][depth][sgi][0] : 0u;
                     ts[q] = (cs[q] + kBlock - 1) / kBlock;
+                    // (the last bounce of a scene whose emitters are all binned: the tiles of the classes that cannot reach one have
+                    // nothing to add -- they get no tile index at all instead of being stepped over one by one)
+                    if (skipNonCand && ((uint32_t)(sgi / kSub) & 8u) == 0u) ts[q] = 0u;
                     inc += ts[q];
                     sum += cs[q];
                 }
