@@ -452,7 +452,8 @@ def run(args, ctx):
         coll_ms = max_over_ranks(time.perf_counter() - t0) / calls * 1e3
         block_bytes = accum.numel() * 4
         coll_calls_per_step = (I + maxb - 1) // maxb if every == "batch" else I
-        multi = {"collective": args.collective, "collective_every": every,
+        multi = {"backend": backend if backend != "nccl" else "nccl (RCCL)", "ranks_per_device": max(1, (world + max(ngpu, 1) - 1) // max(ngpu, 1)),
+                 "collective": args.collective, "collective_every": every,
                  "collective_bytes_per_call": {"sent_by_each_rank": block_bytes if args.collective == "gather" else P * 12,
                                                "received_by_rank_0": (world - 1) * (block_bytes if args.collective == "gather" else P * 12)},
                  "collective_ms_per_call": round(coll_ms, 4), "collective_calls_per_step": coll_calls_per_step,

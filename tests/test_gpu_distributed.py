@@ -149,6 +149,7 @@ def test_bench_two_ranks_contract(pt, tmp_path, every, extra, ranks, scaling):
     # (the collective is timed on its own, outside the steps: with gloo ranks sharing one GPU and the host's cores its share of a step
     # is whatever the box's load makes it -- 0.3 .. 1.6 seen; the field must be there and sane, its size is not the test's business)
     assert mg["collective_ms_per_call"] > 0 and 0 < mg["collective_share_of_step"] < 100
+    assert mg["backend"] == "gloo" and mg["ranks_per_device"] == ranks          # (a rehearsal says so in its line)
     assert d["roofline"]["scope"].startswith("rank 0")
     got = np.load(dump)
     want = _single_rank_frame(pt, (steps * repeats + warmup) * I, min(I, 64))
