@@ -1,6 +1,7 @@
-"""Static count of the vector instructions that issue at half rate when they FOLLOW one of their own kind (profiles/valu_issue_rate.json:
-an SGPR / VCC / EXEC operand or result -- the scalar-path geometry, v_cmp, v_cndmask --, integer multiplies, the division helpers),
-per phase of k_bounce, from the marked listing:
+"""Static count of the vector instructions that issue at half rate when the SIMD's previous issue was one of their own kind
+(profiles/valu_issue_rate.json: an SGPR / VCC / EXEC operand or result -- the scalar-path geometry, v_cmp, v_cndmask --, integer multiplies, the
+division helpers), per phase of k_bounce, from the marked listing.  The penalty is the SIMD's (it shows with eight waves resident), so with waves
+out of step it is the class's SHARE that prices it (share^2 of the issues pay); the adjacency in program order is printed as well:
 
     make -C project3-cuda-path-tracer_amd/csrc marks && python profiles/class_adjacency.py [/tmp/pt_marks/pt_api-hip-amdgcn-amd-amdhsa-gfx950.s]
 
