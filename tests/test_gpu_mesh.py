@@ -11,6 +11,7 @@ import pytest
 from conftest import SCENES
 
 pytestmark = pytest.mark.gpu
+_SW = int(os.environ.get("PT_SWEEP_SCALE", "1"))      # (see tests/test_gpu_parity.py)
 
 
 @pytest.fixture(scope="module")
@@ -140,7 +141,7 @@ def test_bounding_ball_never_rejects_a_mesh_hit(gpu, oracle):
     cases.append((oracle.make_geom(2, 0, (0, 0, 0), (0, 0, 0), (1, 1, 1)), sc.meshes[6] + np.float32(20.0)))   # far off its origin
     cases.append((oracle.make_geom(2, 0, (-4, 1, 2), (0, 45, 0), (40, 1.0, 40)), sc.meshes[6]))          # a 40:1 pancake
     for k, (geom, tris) in enumerate(cases):
-        culled, violations, hits = gpu.test_mesh_cull_sweep(geom, tris, 565 + k, 1 << 24)
+        culled, violations, hits = gpu.test_mesh_cull_sweep(geom, tris, 565 + k + 100 * (_SW - 1), (1 << 24) * _SW)
         assert violations == 0, (k, violations)
         assert hits > (1 << 24) // 50, (k, hits)
         assert culled > (1 << 24) // (20 if k != 4 else 2000), (k, culled)      # (the pancake's margin term leaves little to cull)

@@ -8,6 +8,9 @@ import os
 import numpy as np
 import pytest
 
+# PT_SWEEP_SCALE=<n>: the certificates' sweeps with n times the rays and other seeds (a longer one-off run: profiles/r03_sweeps.txt)
+_SW = int(os.environ.get("PT_SWEEP_SCALE", "1"))
+
 from conftest import GOLD, SCENES
 
 pytestmark = pytest.mark.gpu
@@ -125,7 +128,7 @@ def test_sphere_culling_never_rejects_a_hit(gpu, oracle):
         oracle.make_geom(0, 0, (-3, 1, 2), (75, -20, 130), (8, 0.5, 3)),      # 16:1 anisotropy
         oracle.make_geom(0, 0, (100, -50, 25), (0, 0, 0), (40, 40, 40)),
     ]).view(gpu.GEOM_DTYPE)
-    culled, bad = gpu.test_sphere_cull_sweep(geoms, 2024, 1 << 28)
+    culled, bad = gpu.test_sphere_cull_sweep(geoms, 2024 + _SW - 1, (1 << 28) * _SW)
     assert bad == 0
     assert culled > (1 << 28) // 10           # the shortcut actually fires (most sweep rays are aimed at the sphere)
 
@@ -145,7 +148,7 @@ def test_sphere_halfline_certificate_never_rejects_a_hit(gpu, oracle):
         oracle.make_geom(0, 0, (100, -50, 25), (0, 0, 0), (40, 40, 40)),
         oracle.make_geom(0, 0, (4.1, 8.7, -3.3), (0, 0, 0), (1.1, 1.1, 1.1)),
     ]).view(gpu.GEOM_DTYPE)
-    culled, behind, bad = gpu.test_sphere_halfline_sweep(geoms, 2026, 1 << 28)
+    culled, behind, bad = gpu.test_sphere_halfline_sweep(geoms, 2026 + _SW - 1, (1 << 28) * _SW)
     assert bad == 0
     assert culled > (1 << 28) // 5 and behind > (1 << 28) // 16      # both branches of the certificate fire, by the tens of millions
 
@@ -166,7 +169,7 @@ def test_cube_culling_never_rejects_a_hit(gpu, oracle):
         oracle.make_geom(1, 0, (-2, 3, 1), (20, 70, -35), (5, 0.1, 5)),       # 50:1 plate, near the anisotropy limit of the test
         oracle.make_geom(1, 0, (4, -1, 2), (-60, 15, 80), (0.12, 6, 0.12)),   # 50:1 rod
     ]).view(gpu.GEOM_DTYPE)
-    culled, bad = gpu.test_sphere_cull_sweep(geoms, 77, 1 << 28)
+    culled, bad = gpu.test_sphere_cull_sweep(geoms, 77 + _SW - 1, (1 << 28) * _SW)
     assert bad == 0
     assert culled > (1 << 28) // 16            # (the elongated shapes carry wide margins and are rarely culled)
 
@@ -190,7 +193,7 @@ def test_wall_boxes_never_reject_a_hit(gpu, oracle):
         oracle.make_geom(1, 0, (-2, 3, 1), (20, 70, -35), (5, 0.1, 5)),
         oracle.make_geom(1, 0, (0, -1, 0), (0, 0, 0), (30, 1, 30)),           # a ground slab
     ]).view(gpu.GEOM_DTYPE)
-    culled, bad = gpu.test_wall_box_sweep(geoms, 4242, 1 << 28)
+    culled, bad = gpu.test_wall_box_sweep(geoms, 4242 + _SW - 1, (1 << 28) * _SW)
     assert bad == 0
     assert culled > (1 << 28) // 16            # the certificate actually fires (most sweep rays are aimed at the cube)
 
@@ -219,7 +222,7 @@ def test_wall_planes_never_reject_a_hit(gpu, oracle):
     total = 0
     for name, geoms in rooms.items():
         g = np.concatenate(geoms).view(gpu.GEOM_DTYPE)
-        nplane, certified, bad, single = gpu.test_wall_plane_sweep(g, 977, 1 << 25)
+        nplane, certified, bad, single = gpu.test_wall_plane_sweep(g, 977 + _SW - 1, (1 << 25) * _SW)
         print("%-15s walls with a plane %d of %d, certificates %d, rays with one possible wall %d, violations %d" % (name, nplane, len(g), certified, single, bad))
         assert bad == 0, name
         assert nplane == (len(g) - 1 if name == "slab across" else len(g)), name
