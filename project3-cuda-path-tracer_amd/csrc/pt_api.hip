@@ -1524,11 +1524,11 @@ int pt_counters(PtCounters *out) {
         HIPCHECK(hipMemcpy(&h, S.slot[i].ctrl, sizeof h, hipMemcpyDeviceToHost));
         for (int d = 0; d < kMaxDepthSlots; ++d) {
             int64_t early = 0;
-            for (int sg = 0; sg < kOct; ++sg) early += (int64_t)h.early[d][sg][0];
+            for (int sg = 0; sg < kTallyShards; ++sg) early += (int64_t)h.early[d][sg][0];
             out->live[d] += (int64_t)h.sum_live[d] + early;   // they did enter bounce d
             out->ended_early[d] += early;                      // ... without being moved through memory
         }
-        for (int sg = 0; sg < kOct; ++sg) {
+        for (int sg = 0; sg < kTallyShards; ++sg) {
             out->light_hits += (int64_t)h.light_hits[sg][0];
             out->misses += (int64_t)h.misses[sg][0];
         }

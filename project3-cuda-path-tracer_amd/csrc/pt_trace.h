@@ -22,6 +22,7 @@ constexpr int kCls = 2 * kOct;       // ... and by "may hit a small primitive" (
 #endif
 constexpr int kSub = PT_KSUB;        // append-counter shards per class (workgroup blockIdx % kSub; PT_KSUB: shard-count experiments only)
 constexpr int kSeg = kCls * kSub;    // path buffers are split into kSeg segments with one append counter each
+static_assert(kSeg % 64 == 0, "setupTile compares kSeg / 64 prefix entries per lane");
 constexpr int kBinMax = 4;           // at most this many small primitives take part in the binning
 constexpr int kEmitMax = 8;          // emissive primitives the direct-lighting bounce chooses from
 constexpr int kWallMax = 6;          // large cubes ("walls") whose world-space boxes class the survivors (wallCertainMiss)
@@ -33,11 +34,17 @@ constexpr int kMinChunkShift = 11;   // chunks hold at least 2048 paths: a multi
 // k_bounce<., MANY> (scenes with more than kBinMax spheres): LDS words of the fixed scratch, floats per staged sphere
 // record (inverseTransform rows, transform rows, GeomDev::invZ, 4 B of padding), spheres a lane can record per tile
 constexpr int kNanWords = 12;        // nine NaNs (+ padding): the "face frame" of a cube hit without an exit slab (cubeFace: a ray of NaNs)
-constexpr int kMiscWords = 2 * kWaves * kCls + 5 * kCls + kSeg + (kSeg + 2) + 2 * PT_MAX_BATCH + 2 + kNanWords;
+constexpr int kTicketWords = 4;      // the workgroup's next ticket (+ padding)
+constexpr int kMiscWords = 2 * kWaves * kCls + 5 * kCls + kSeg + (kSeg + 2) + 2 * PT_MAX_BATCH + 2 + kNanWords + kTicketWords;
 static_assert(kMiscWords % 4 == 0, "the sphere records that follow are read as float4");
 constexpr int kSphRowFloats = 28;
 constexpr int kListMax = 8;
 constexpr int kCtrPad = 32;          // one counter per 128-byte line: same-line atomics serialise at the memory side
+// Every workgroup of a launch ends with one atomic per tally, and atomics on one address serialise at ~12 ns each (round 2 measured a
+// 0.1 ms tail with 8192 of them on one word): 64 shards leave 32 per word for a 2048-workgroup launch (rounds 2-3: 8 shards, 256 per
+// word = the last 3 us of every launch).
+constexpr int kTallyShards = 64;
+constexpr int kTicketShards = 64;    // tile tickets (k_bounce): 32 workgroups of a 2048-workgroup launch share a counter
 
 struct Ctrl {
     // pos[p][d][s][0] = paths appended to segment s of the queue ENTERING bounce d of a batch with parity p (a run of
@@ -46,14 +53,18 @@ struct Ctrl {
     // needs neither a memset nor a separate re-arm launch.
     uint32_t pos[2][kMaxDepthSlots][kSeg][kCtrPad];
     uint32_t bump[2][kMaxDepthSlots][kCtrPad];
+    // ticket[p][d][0] = tiles handed out beyond the two static ones per workgroup by the launch of bounce d (k_bounce: "tickets")
+    // (sharded: ticket t of shard s = blockIdx % kTicketShards stands for tile 2 grid + t kTicketShards + s -- one word for a whole
+    // launch's tiles serialised its 20 000 atomics at ~12 ns each, twice the launch's own length)
+    uint32_t ticket[2][kMaxDepthSlots][kTicketShards][kCtrPad];
     // never zeroed by an iteration
     uint32_t error;                    // sticky device fault: kFault* bits (pool exhausted, chunk-list poll timeout)
     uint32_t pad[kCtrPad - 1];
     unsigned long long sum_live[kMaxDepthSlots];
     // paths that ended at the scatter of bounce d - 1 (they enter bounce d and miss, but are never enqueued), sharded like
     // the tallies below: every workgroup adds to them when it ends, and 2048 atomics on ONE address take ~100 us
-    unsigned long long early[kMaxDepthSlots][kOct][kCtrPad / 2];
-    unsigned long long light_hits[kOct][kCtrPad / 2], misses[kOct][kCtrPad / 2];
+    unsigned long long early[kMaxDepthSlots][kTallyShards][kCtrPad / 2];
+    unsigned long long light_hits[kTallyShards][kCtrPad / 2], misses[kTallyShards][kCtrPad / 2];
 };
 constexpr uint32_t kFaultPoolExhausted = 1u, kFaultReserveTimeout = 2u;
 constexpr int kReservePollLimit = 1 << 14;    // polls (each a memory round trip) for a chunk-list entry; a real wait is a few
@@ -444,6 +455,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
     uint32_t *const s_segpre = s_segcnt + kSeg;            // [kSeg+2] tile prefix per input segment, [kSeg+1] = live paths
     uint32_t *const s_iterHash = s_segpre + kSeg + 2;      // [2][PT_MAX_BATCH] iterationHash(iter + b, depth) and (iter + b, 0)
     const float *const s_nan = reinterpret_cast<const float *>(s_iterHash + 2 * PT_MAX_BATCH + 2);   // [kNanWords] NaNs: see cubeFace
+    uint32_t *const s_ticket = s_iterHash + 2 * PT_MAX_BATCH + 2 + kNanWords;   // [1] the tile after the next one (tickets, below)
 
     uint32_t nLive, numTiles;
     {
@@ -466,6 +478,8 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
             const int nwords = (A->prm.traceDepth + 2) * kSeg;
             for (int i = blockIdx.x * kBlock + threadIdx.x; i < nwords; i += gridDim.x * kBlock) other[i * kCtrPad] = 0u;
             if (blockIdx.x == 0 && threadIdx.x < kMaxDepthSlots) ctrl->bump[parity ^ 1][threadIdx.x][0] = 0u;
+            if (blockIdx.x == 1 % gridDim.x)
+                for (int i = threadIdx.x; i < kMaxDepthSlots * kTicketShards; i += kBlock) (&ctrl->ticket[parity ^ 1][0][0][0])[i * kCtrPad] = 0u;
             // ... and the batch's last launch (which compacts nothing, hence raises no fault itself) hands a fault word the earlier
             // launches may have set to the host: its copy in page-locked memory is what pt_readback looks at after its synchronisation,
             // without a device-to-host copy of its own.  Here, in the prologue, it costs the tile loop no register.
@@ -574,7 +588,8 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
             }
         }
     }
-    __syncthreads();
+    // (the barrier that publishes the staged tables stands further down, behind the first tile's loads: they only need the
+    // segment prefix, which the barrier above published, and fly while the workgroup meets here)
 
     // (see TileArgs::hot; opaque to the optimiser so that it stays ONE register instead of being re-derived from re-loaded fields)
     uint32_t hotWord = launder(kargs)->tile.hot;
@@ -624,8 +639,17 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
         const PT_CAS unsigned long long *const inList = (const PT_CAS unsigned long long *)ta.inList;
         m.base = ta.inBase;
         m.cap = ta.inCap;
-        // global tile -> (segment, local tile)
-        while (T >= s_segpre[sgIn + 1]) ++sgIn;
+        // global tile -> (segment, local tile): the segment is the number of prefix entries s_segpre[1 .. kSeg] that do not exceed T.
+        // Every lane compares its kSeg / 64 entries and the ballots are counted -- ONE LDS round trip.  (Rounds 1-3 walked the prefix
+        // from the previous tile's segment, a chain of dependent LDS reads: ~10 per tile, and up to kSeg of them in front of a
+        // workgroup's very first loads -- round 3's timeline has 1067 cycles per tile in it, and the tail of the prologue.)
+        {
+            const uint32_t ln = tid & 63u;
+            uint32_t cnt = 0u;
+#pragma unroll
+            for (int q = 0; q < kSeg / 64; ++q) cnt += (uint32_t)__popcll(__ballot(s_segpre[1 + 64 * q + ln] <= T));
+            sgIn = cnt;
+        }
         probe(26);                                              // (segment found)
         sgIn = (uint32_t)__builtin_amdgcn_readfirstlane((int)sgIn);
         const uint32_t segFirst = s_segpre[sgIn];
@@ -672,6 +696,19 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
         while (T < numTiles && !setupTile(T, threadIdx.x, nextMeta)) T += gridDim.x;
         if (T < numTiles) loadTile(nextMeta, nextRegs);
     }
+    __syncthreads();                         // (materials, hit records, iteration hashes, the cleared scratch: staged by the prologue)
+    // ---- TICKETS (later bounces that compact): a workgroup's first two tiles are static (blockIdx, blockIdx + grid), every further one
+    // is 2 grid + a ticket from the launch's counter.  Tiles differ in cost by a factor of three (one wall's box test against every
+    // primitive of a candidate tile), and a launch is only 7-26 tiles per workgroup long: with a fixed stride the slowest workgroup's
+    // surplus was the tail of every launch.  The ticket for the tile after the next one is drawn by lane 16 of wave 0 next to the
+    // reservation's atomics (same round trip, between the same two barriers) and handed to the other waves through LDS, so the next
+    // tile -- whose loads are requested before the compaction -- is always known: no new latency in the chain.  A shard's tickets are
+    // drawn in increasing order, so a workgroup whose next tile lies beyond the queue's end holds no valid later one.
+#ifndef PT_TICKETS
+#define PT_TICKETS 1
+#endif
+    const bool ticketed = PT_TICKETS && !FIRST && (hotWord & kHotLast) == 0u;
+    uint32_t Tn1 = FIRST ? 0u : T + gridDim.x;   // the tile after T (camera rays: always T + grid, not carried)
     while (T < numTiles) {
         // the lane id, opaque to the optimiser: the lane masks derived from it (tid < 16, wave > k, ...) are then
         // recomputed where a tile needs them -- one v_cmp each -- instead of being hoisted out of the loop into SGPR pairs
@@ -683,7 +720,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
         // itself the compiler carried T in a VGPR and expanded the divisions below into ~60 vector instructions per tile)
         T = (uint32_t)__builtin_amdgcn_readfirstlane((int)T);
         probe(14);                                              // (a tile starts)
-        uint32_t Tnext = T + gridDim.x;     // FIRST: simply the next one
+        uint32_t Tnext = FIRST ? T + gridDim.x : Tn1;   // (last bounce: T + grid as well)
         bool valid;
         uint32_t tileCls = 0u;              // wave-uniform: the tile's queue class (later bounces)
         PathRegs cur = nextRegs;
@@ -736,7 +773,10 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
         uint32_t wallSel = 8u;                                  // class bits 0-2 of a survivor in a scene with walls (8: no walls: the octant)
         uint32_t lightHitI = 0u, missedI = 0u;
         F3 org = f3(0, 0, 0), dir = f3(0, 0, 1), col = f3(0, 0, 0);
-        int pix = 0, rem = 0;
+        int pix = 0;
+        int packedCur = 0;                                      // later bounces: remainingBounces | batch index << 8, as loaded (ONE register
+                                                                // across the tile; the iteration is shifted out where it is needed)
+        auto iterOf = [&]() -> int { return FIRST ? itb : (packedCur >> 8); };
         uint32_t pixHash = 0u;                                  // FIRST: utilhash(pix), shared by the camera jitter's and the scatter's engines
         if (valid) {
             // Camera rays (FIRST): a primitive is reachable only from the pixels inside the projection of its bounding
@@ -778,12 +818,17 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
                     }
                 }
                 col = f3(1.0f, 1.0f, 1.0f);
-                rem = prm.traceDepth;
             } else {
                 org = cur.org; dir = cur.dir; col = cur.col;        // requested one tile ahead (loadTile)
-                pix = cur.pix;
-                rem = cur.packed & 0xff;                            // remainingBounces | batch index << 8
-                itb = cur.packed >> 8;
+                // The pixel index and the packed word outlive the next tile's loads (the stores need them), so they cannot stay in the
+                // register tuple array C's element is loaded into: their copies out of it are made HERE, where the data has long
+                // arrived.  (Left to itself the register allocator copied the NEXT tile's pixel index right behind its load -- v_mov
+                // behind s_waitcnt vmcnt(2) -- and every wave sat out a memory round trip BEFORE the compaction's barriers instead of
+                // under them: the "3 loads issued: 7 %" of round 3's timeline.)
+                int cpix = cur.pix, cpacked = cur.packed;
+                asm volatile("" : "+v"(cpix), "+v"(cpacked));
+                pix = cpix;
+                packedCur = cpacked;
             }
 
             if (FIRST) { if (inScene) probe(8); } else probe(7);                                   // tiles (waves with at least one valid path) and valid paths
@@ -988,7 +1033,8 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
                 int ghType, ghMaterial;
                 const float *ghNm, *ghFrame;
                 float mEmit, mRefl, mRefr;                       // the material's hot fields
-                F3 mcol;
+                F3 mcolMany = f3(0, 0, 0);
+                const float4 *hrec1 = nullptr;                   // small scenes: the record's second 16 bytes {material colour, material index}
                 if (MANY) {
                     const ArgsPtr A = launder(kargs);
                     const GeomHitSmall &h = S_GEOMHIT_SMALL(A->prm.nmats)[hit];
@@ -996,13 +1042,16 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
                     ghFrame = S_FRAMES(A->prm.nmats, A->prm.ngeoms) + h.frame * 54;
                     const MaterialDev &Mm = smats[ghMaterial];
                     mEmit = Mm.emittance; mRefl = Mm.hasReflective; mRefr = Mm.hasRefractive;
-                    mcol = f3(Mm.color[0], Mm.color[1], Mm.color[2]);
+                    mcolMany = f3(Mm.color[0], Mm.color[1], Mm.color[2]);
                 } else {
-                    // the record's header: two 16-byte reads, in flight together
+                    // the record's header: type and the material's three switches now; its colour and index are read where they are
+                    // used (fetched here with the rest they sat in four registers across the normal's evaluation -- one too many: the
+                    // allocator parked them in scratch -- while a second LDS read costs one instruction and hides behind the engine's hash)
                     const GeomHitDev &h = S_GEOMHIT(hotMats(hotNow()))[hit];
-                    const float4 h0 = reinterpret_cast<const float4 *>(&h)[0], h1 = reinterpret_cast<const float4 *>(&h)[1];
+                    const float4 h0 = reinterpret_cast<const float4 *>(&h)[0];
+                    hrec1 = reinterpret_cast<const float4 *>(&h) + 1;
                     ghType = __float_as_int(h0.x); mEmit = h0.y; mRefl = h0.z; mRefr = h0.w;
-                    mcol = f3(h1.x, h1.y, h1.z); ghMaterial = __float_as_int(h1.w);
+                    ghMaterial = 0;
                     ghNm = h.nm; ghFrame = h.cubeFrame;
                 }
                 const bool isSphere = ghType == 0;
@@ -1013,6 +1062,14 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
                 // row of the table, or the row of NaNs for a hit without an exit slab -- instead of nine on the values
                 const float *const fv = faceOk ? ghFrame + 9 * face : s_nan;
                 const F3 N = isSphere ? hitNormalSphere(ghNm, nsrc, outside) : f3(fv[0], fv[1], fv[2]);
+                F3 mcol = mcolMany;
+                if (!MANY) {
+                    uint32_t off = (uint32_t)(reinterpret_cast<const unsigned char *>(hrec1) - smem);
+                    asm volatile("" : "+v"(off));                // (read HERE, not hoisted to the header's read; the LDS offset, so that the
+                                                                 // read stays a ds_read)
+                    const float4 h1 = *reinterpret_cast<const float4 *>(smem + off);
+                    mcol = f3(h1.x, h1.y, h1.z); ghMaterial = __float_as_int(h1.w);
+                }
                 const MaterialDev &M = smats[ghMaterial];       // (the fields of the rarer branches)
                 if (mEmit > 0.0f) {                              // S5: emitter ends the path
                     lightHitI = 1u;
@@ -1032,17 +1089,18 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
                             cpix = (uint32_t)pix - (y - lr) * (uint32_t)A->prm.W;      // x + lr * W
                             frame = (size_t)A->prm.nLocal;
                         }
-                        float *dst = contrib + 3 * ((size_t)itb * frame + (size_t)cpix);
+                        const int itq = iterOf();
+                        float *dst = contrib + 3 * ((size_t)itq * frame + (size_t)cpix);
                         dst[0] = c.x; dst[1] = c.y; dst[2] = c.z;
                         // ... and the pixel's mask says which iterations of the batch left something: k_commit then reads
                         // 4 B per pixel and word instead of 12 B per pixel and iteration (one path per pixel and iteration: the
                         // bits of a word come from different launches or lanes, hence the atomic; nobody waits for it)
-                        (void)__hip_atomic_fetch_or(A->hitMask + (size_t)(itb >> 5) * frame + (size_t)cpix, 1u << (itb & 31), __ATOMIC_RELAXED,
+                        (void)__hip_atomic_fetch_or(A->hitMask + (size_t)(itq >> 5) * frame + (size_t)cpix, 1u << (itq & 31), __ATOMIC_RELAXED,
                                                     __HIP_MEMORY_SCOPE_AGENT);
                     }
                 } else if (!(hotNow() & kHotLast)) {                  // S6 scatter (S7: skipped on the last bounce)
                     probe(10);
-                    Rng rng = seedEngine(s_iterHash[itb] ^ (FIRST ? pixHash : utilhash((uint32_t)pix)));   // = makeSeededRandomEngineHashed(., pix)
+                    Rng rng = seedEngine(s_iterHash[iterOf()] ^ (FIRST ? pixHash : utilhash((uint32_t)pix)));   // = makeSeededRandomEngineHashed(., pix)
                     const F3 scol = f3(M.specColor[0], M.specColor[1], M.specColor[2]);
                     F3 ndir = dir, norg;
                     bool diffuse = false;                        // the hemisphere is sampled at one place, after the branches
@@ -1267,6 +1325,11 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
             probe(21);                                          // (first barrier)
             __syncthreads();
             probe(22);                                          // (reservation)
+            uint32_t tk = 0u;
+            if (ticketed && tid == (uint32_t)kCls) {            // (lane 16 of wave 0: in flight together with the reservation's atomics)
+                const ArgsPtr A = launder(kargs);
+                tk = atomicAdd(&A->ctrl->ticket[A->parity][A->depth][blockIdx.x % kTicketShards][0], 1u);
+            }
             if (tid < kCls) {
                 const ArgsPtr A = launder(kargs);
                 Ctrl *const ctrl = A->ctrl;
@@ -1284,8 +1347,10 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
                 s_base[kCls + tid] = sp;
                 s_base[2 * kCls + tid] = r1;
             }
+            if (ticketed && tid == (uint32_t)kCls) s_ticket[0] = 2u * gridDim.x + tk * (uint32_t)kTicketShards + blockIdx.x % kTicketShards;
             probe(23);                                          // (second barrier)
             __syncthreads();
+            if (!FIRST) Tn1 = ticketed ? s_ticket[0] : Tnext + gridDim.x;
 #if defined(PT_EXP) && (PT_EXP & 2)      // experiment: one more workgroup barrier per tile
             asm volatile("" ::: "memory");
             __syncthreads();
@@ -1307,7 +1372,8 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
                 *reinterpret_cast<float4 *>(dst + 16 * (size_t)slot) = make_float4(org.x, org.y, org.z, dir.x);
                 *reinterpret_cast<float4 *>(dst + 16 * ocap + 16 * (size_t)slot) = make_float4(dir.y, dir.z, col.x, col.y);
                 PathC c;
-                c.cz = col.z; c.pix = pix; c.packed = (rem - 1) | (itb << 8);
+                // (remainingBounces - 1 | batch index << 8: the low byte is at least 1 here)
+                c.cz = col.z; c.pix = pix; c.packed = FIRST ? ((launder(kargs)->prm.traceDepth - 1) | (itb << 8)) : packedCur - 1;
                 *reinterpret_cast<PathC *>(dst + 32 * ocap + 12 * (size_t)slot) = c;
             }
             // No third barrier: the counts are double-buffered.  The other half was last read in the previous tile, and every
@@ -1317,13 +1383,15 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
             wvSel ^= (uint32_t)(kWaves * kCls);
             if (lane < kCls) s_wave[wvSel + wave * kCls + lane] = 0u;
             __builtin_amdgcn_s_setprio(0);
+        } else if (!FIRST) {
+            Tn1 = Tnext + gridDim.x;
         }
         probe(20);                                              // (tile done)
         T = Tnext;
     }
     censusLeave();
     probe(29);                           // (timeline builds: the launch's sums go out)
-    // tallies: lanes -> wave (shuffles) -> workgroup (LDS) -> ONE atomic per workgroup and tally on counters sharded 8 ways
+    // tallies: lanes -> wave (shuffles) -> workgroup (LDS) -> ONE atomic per workgroup and tally on counters sharded kTallyShards ways
     // (every workgroup of a launch ends with these: unsharded, or one per wave, they serialise at the memory side)
     const uint32_t waveLight = waveSum(nLight), waveEarly = waveSum(nEarly), waveMiss = waveSum(nMiss) + waveEarly;
     __syncthreads();                                   // (every wave is done with the scratch of its last tile)
@@ -1338,7 +1406,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
     if (threadIdx.x == 0) {
         const ArgsPtr A = launder(kargs);
         Ctrl *const ctrl = A->ctrl;
-        const int shard = blockIdx.x % kOct;
+        const int shard = blockIdx.x % kTallyShards;
         const uint32_t wgLight = s_wave[0], wgEarly = s_wave[2];
         unsigned long long wgMiss = s_wave[1];
         // (the camera rays of the pixels outside the tiles' index space, KParams::firstSkipped: misses whatever their jitter)
