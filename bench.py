@@ -4,14 +4,16 @@
 Metric (BASELINE.json): Mpaths/s, paths = pixels x bounces x spp (NOMINAL segments), Cornell box at
 1280x720, 8 bounces.
 
-One STEP = one pass of the hot path over one batch of input = `--batch` (32) consecutive iterations (spp) of the
-whole frame: camera rays, 8 fused intersect+shade+compact bounces, ordered accumulation, issued as ONE wavefront
-batch (pt_iterate_batch: the 32 iterations' paths share the 8 launches; results are identical to one call per
-iteration), with 2 batches in flight on internal streams.  So `--steps 20` times 640 iterations.  Scene, accumulator
-and path state are resident in HBM before the timed region.
+One STEP = one pass of the hot path over one batch of input = `--batch` (64) consecutive iterations (spp) of the
+whole frame -- BASELINE config C2 in full: 1280x720, 64 spp, 8 bounces -- camera rays, 8 fused intersect+shade+compact
+bounces, ordered accumulation, issued as ONE wavefront batch (pt_iterate_batch: the 64 iterations' paths share the 8
+launches; results are identical to one call per iteration), with 2 batches in flight on internal streams.  So
+`--steps 20` times 1280 iterations.  Scene, accumulator and path state are resident in HBM before the timed region.
+(Rounds 1-3 stepped in batches of 32; a launch carries a fixed ~15 us of ramp-up and tail, which 64 iterations
+amortise over twice the paths: `--batch 32` reproduces the old step.)
 
 The timed block -- EXACTLY `--steps` steps between barrier + device synchronisation on both sides -- is repeated
-`--repeats` (15) times inside one run (a single block is ~27 ms; fifteen are ~0.4 s of GPU time): `ms_per_step` and
+`--repeats` (15) times inside one run (a single block is ~40 ms; fifteen are ~0.6 s of GPU time): `ms_per_step` and
 `value` are the MEDIAN block's (ms_per_step x steps = that block's wall), `ms_per_step_min` / `_max` and `value_min` /
 `_max` give the spread over the blocks, `ms_per_step_blocks` lists them all.
 
@@ -36,6 +38,11 @@ each over whole steps: `value_weak`, `value_strong` (collective per wavefront ba
 one pt_iterate + one reduce(sum) of zero-padded full frames per ITERATION: BASELINE config C3 to the letter), plus
 `collective_bytes_per_call` and the collective's share of a step; `value` = the one `--scaling` names (default weak:
 per-GPU work fixed as N grows, which is what "scaling": "weak" in the line says).
+`value_c3_as_written` is a FAST path (round 4) and is also measured at N = 1: the iterations come out of batches traced
+ahead (PT_FLAG_TRACE_AHEAD: one small commit launch per call), the renderer accumulates into the zero-padded full frame
+itself, and the reduce of a double-buffered snapshot runs on a stream of its own, overlapped with the next iteration's
+commit (distributed.PerIterationReducer); at N = 1 the reduce goes through a one-rank RCCL group, so the protocol's
+per-iteration cost is a hardware number even without a second GPU.  It is timed over the same `--steps` steps as `value`.
 
 Prints ONE JSON line on rank 0, with `roofline` (dominant kernel = the fused bounce kernel, HIP-event timed on the
 streams it runs on, against the 8 TB/s HBM peak) and `cpu_baseline` (the single-thread CPU oracle on a bounded
@@ -75,7 +82,8 @@ def parse(argv=None):
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--cpu-spp", type=int, default=40, help="spp of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--pipeline", type=int, default=2, help="batches in flight (PtOptions.pipeline_depth; 0 = library default 3)")
-    ap.add_argument("--batch", type=int, default=32, help="iterations per step = iterations traced as one wavefront batch")
+    ap.add_argument("--batch", type=int, default=64,
+                    help="iterations per step = iterations traced as one wavefront batch (64 = the spp of BASELINE config C2)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1.  weak (default): a step is --batch x N iterations of the whole frame, so a rank's share of a step -- "
                          "its 1/N of the rows of N times the iterations -- is as many paths as the single GPU's step (more GPUs = "
@@ -85,9 +93,10 @@ def parse(argv=None):
                     help="N > 1: assemble the frame at rank 0 after every wavefront batch, or after every iteration")
     ap.add_argument("--collective", default="gather", choices=["gather", "reduce"],
                     help="N > 1: gather of the packed row blocks (default) or reduce(sum) of zero-padded full frames")
-    ap.add_argument("--per-iteration-sample", type=int, default=2,
-                    help="N > 1: whole steps timed in the per-iteration mode of BASELINE config C3 (strong scaling, one pt_iterate + one "
-                         "reduce per iteration); 0 = skip")
+    ap.add_argument("--per-iteration-sample", type=int, default=None,
+                    help="whole steps timed in the per-iteration mode of BASELINE config C3 (strong scaling, one pt_iterate + one "
+                         "reduce per iteration, N = 1 included); default = --steps; 0 = skip")
+    ap.add_argument("--dump-c3-frame", default=None, help="rank 0 writes the frame the per-iteration mode's last reduce delivered to this .npy file")
     ap.add_argument("--extra-passes", type=int, default=1, help="N > 1: 0 = only the pass `--scaling` names (no value_weak / value_strong pair)")
     ap.add_argument("--pmc-traffic-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"),
                     help="PMC counters per bounce-kernel launch from the rocprofv3 --pmc passes (profiles/README.md)")
@@ -118,6 +127,72 @@ def cpu_model():
     except OSError:
         pass
     return "unknown"
+
+
+class BoxTelemetry:
+    """Shader / memory clock, package power against its cap and temperatures of THIS process's GPU, sampled from the amdgpu hwmon
+    files (sysfs: plain reads from a host thread, no GPU call, no child process) every 20 ms while the timed blocks run -- so that a
+    line from a slow box says WHY it is slow (a power cap, a hot card, a clock that never leaves its floor) without a second run.
+    Boxes of the pool differ by up to 1.8 x on the same build (profiles/r03_sensitivity_experiments.txt)."""
+    FILES = {"sclk_mhz": ("freq1_input", 1e-6), "mclk_mhz": ("freq2_input", 1e-6), "power_w": ("power1_input", 1e-6),
+             "temp_junction_c": ("temp2_input", 1e-3), "temp_mem_c": ("temp3_input", 1e-3)}
+
+    def __init__(self, torch, device_index):
+        import glob
+        import threading
+        self.hwmon, self.samples, self.err = None, {k: [] for k in self.FILES}, None
+        self._stop = threading.Event()
+        self._on = threading.Event()
+        try:
+            p = torch.cuda.get_device_properties(device_index)
+            want = "%04x:%02x:%02x." % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+            for d in glob.glob("/sys/class/drm/card*/device"):
+                if os.path.basename(os.path.realpath(d)).startswith(want):
+                    h = glob.glob(d + "/hwmon/hwmon*")
+                    if h:
+                        self.hwmon, self.pci = h[0], os.path.basename(os.path.realpath(d))
+            if self.hwmon is None:
+                self.err = "no amdgpu hwmon directory for PCI device %s*" % want
+        except Exception as e:
+            self.err = repr(e)
+        self._thread = threading.Thread(target=self._run, daemon=True)
+        if self.hwmon:
+            self._thread.start()
+
+    def _read(self, name):
+        try:
+            return float(open(os.path.join(self.hwmon, name)).read())
+        except (OSError, ValueError):
+            return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            if self._on.is_set():
+                for k, (f, scale) in self.FILES.items():
+                    v = self._read(f)
+                    if v is not None:
+                        self.samples[k].append(v * scale)
+            self._stop.wait(0.02)
+
+    def start(self):
+        self._on.set()
+
+    def pause(self):
+        self._on.clear()
+
+    def report(self):
+        self._stop.set()
+        if not self.hwmon:
+            return {"error": self.err}
+        out = {"source": "amdgpu hwmon (sysfs) of PCI device %s, sampled every 20 ms during the timed blocks" % self.pci,
+               "samples": len(self.samples["sclk_mhz"])}
+        for k, v in self.samples.items():
+            if v:
+                s_ = sorted(v)
+                out[k] = {"min": round(s_[0], 1), "median": round(s_[len(s_) // 2], 1), "max": round(s_[-1], 1)}
+        cap = self._read("power1_cap")
+        out["power_cap_w"] = round(cap * 1e-6, 1) if cap else None
+        return out
 
 
 def box_calibration(pt, torch):
@@ -232,11 +307,19 @@ def valu_issue_rate(path, waves_per_simd):
     return {"mix": mix[0], "fma": fma[0], "waves_per_simd": mix[1]}
 
 
+def _on_sigterm(signum, frame):
+    # torchrun ends the surviving ranks of a failed job with SIGTERM, which Python does not turn into an exception by itself: raise
+    # one, so that main()'s `finally: cleanup()` drains the streams and frees the renderer before the process goes away
+    raise SystemExit(128 + signum)
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world == 1 and args.gpus > 1:
         self_launch(args)                                   # never returns
+    import signal
+    signal.signal(signal.SIGTERM, _on_sigterm)
     # Every exit path of a rank drains and frees the renderer BEFORE the process goes away (an exception between pt_iterate
     # and pathtraceFree used to leave launches in flight at context teardown), and a failed rank exits non-zero.
     ctx = {}
@@ -276,9 +359,15 @@ def cleanup(ctx, ok):
     dist = ctx.get("dist")
     if dist is not None and dist.is_initialized():
         try:
-            if ok:
-                dist.barrier()
-            for k in ("accum", "frame", "bufs"):
+            if ok and dist.get_world_size() > 1:
+                # leave together, but never wait for ever: the group was formed with a timeout (distributed.init_process_group), which
+                # RCCL's watchdog enforces on this barrier too; gloo takes it explicitly
+                import datetime
+                if ctx.get("backend") == "gloo":
+                    dist.monitored_barrier(timeout=datetime.timedelta(seconds=120))
+                else:
+                    dist.barrier()
+            for k in ("accum", "frame", "bufs", "reducer", "accum_full"):
                 ctx.pop(k, None)
             dist.destroy_process_group()
         except Exception:
@@ -312,14 +401,16 @@ def run(args, ctx):
     ngpu = torch.cuda.device_count()
     if world > 1 and backend == "nccl" and ngpu < world:
         # (local_rank % device_count would silently stack ranks on one device, which RCCL cannot serve)
-        sys.exit("bench.py: %d ranks need %d GPUs under RCCL (backend nccl), this node shows %d; BENCH_BACKEND=gloo rehearses "
-                 "several ranks on one GPU" % (world, world, ngpu))
+        print("bench.py: %d ranks need %d GPUs under RCCL (backend nccl), this node shows %d; BENCH_BACKEND=gloo rehearses "
+              "several ranks on one GPU" % (world, world, ngpu), file=sys.stderr, flush=True)
+        sys.exit(2)
     device_index = local_rank % ngpu
     torch.cuda.set_device(device_index)
     import __graft_entry__ as ge
     pt = ge.load_package()
     ctx["pt"] = pt
     ptdist = ge.load_submodule("distributed")
+    ctx["backend"] = backend
     if world > 1:
         ptdist.init_process_group(backend)
         ctx["dist"] = dist
@@ -344,20 +435,24 @@ def run(args, ctx):
     ctx.update(accum=accum, frame=frame, bufs=bufs)
     stream = torch.cuda.current_stream()
 
-    def init(flags, pipeline, max_batch):
+    def init(flags, pipeline, max_batch, full_frame=None):
+        """`full_frame`: accumulate into this zero-padded FULL frame (own rows in place, zeros elsewhere) instead of the packed row
+        block -- the per-iteration mode of config C3, whose reduce then needs no scatter"""
         pt.pathtraceFree()
         pt.pathtraceInit(scene, shard_rank=rank, shard_count=world, stream=stream.cuda_stream,
-                         accum_dev=accum.data_ptr(), device=device_index, flags=flags | shard_flag,
+                         accum_dev=(accum if full_frame is None else full_frame).data_ptr(), device=device_index,
+                         flags=flags | (shard_flag if full_frame is None else 0),
                          traceDepth=D, pipeline_depth=pipeline, max_batch=max_batch)
 
     def collect(collective):
         # the single collective of the data path: the row blocks travel to rank 0 over xGMI
         ptdist.gather_frame(accum, bufs, frame, W, H, dst=0, collective=collective)
 
-    def run_steps(first_iter, steps, I, maxb, every, collective):
+    def run_steps(first_iter, steps, I, maxb, every, collective, reducer=None):
         """`steps` steps of I iterations from `first_iter`.  every == "batch": wavefront batches of `maxb` iterations (one or
         several steps each, or a part of one), the frame assembled at rank 0 after every batch; every == "1": I single-iteration
-        calls per step, each followed by the collective."""
+        calls per step (each commits one iteration of a batch of `maxb` traced ahead), each followed by the collective -- the
+        gather / reduce on the caller's stream, or, with a `reducer`, config C3's overlapped reduce of full frames."""
         it = first_iter
         end = first_iter + steps * I
         while it < end:
@@ -369,7 +464,9 @@ def run(args, ctx):
                 it += n
             else:
                 pt.pathtrace(None, 0, it, readback=False)
-                if world > 1:
+                if reducer is not None:
+                    reducer.collect()
+                elif world > 1:
                     collect(collective)
                 it += 1
         return it
@@ -393,39 +490,52 @@ def run(args, ctx):
             return [float(v) for v in t.tolist()]
         return [float(v) for v in values]
 
-    def timed(first_iter, steps, I, maxb, every, collective):
+    def timed(first_iter, steps, I, maxb, every, collective, reducer=None):
         """EXACTLY `steps` steps between barrier + torch.cuda.synchronize() on both sides; the slowest rank's time."""
         barrier()
         t0 = time.perf_counter()
-        nxt = run_steps(first_iter, steps, I, maxb, every, collective)
+        nxt = run_steps(first_iter, steps, I, maxb, every, collective, reducer)
         barrier()
         return max_over_ranks(time.perf_counter() - t0), nxt
 
     def plan(scaling, every):
         """iterations of the whole frame per step, and the iterations a rank issues as one wavefront batch"""
+        # (per-iteration modes: the single-iteration calls draw on batches of B iterations traced ahead, PT_FLAG_TRACE_AHEAD)
         if scaling == "weak":
             # a step is I = B x N iterations, traced as one wavefront batch (in pieces of PT_MAX_BATCH should it be larger)
             I = B * world
-            return I, (min(I, pt.PT_MAX_BATCH) if every == "batch" else 1)
+            return I, (min(I, pt.PT_MAX_BATCH) if every == "batch" else B)
         # N ranks share the frame's rows, so a rank's launches cover 1/N of the paths: with the collective once per batch a rank
         # traces `fuse` consecutive steps as ONE wavefront batch (at most PT_MAX_BATCH iterations), which keeps its launches fat
         # -- but not so few batches that the two in flight never overlap: at least 8 per timed block
         fuse = max(1, min(world, pt.PT_MAX_BATCH // B, max(1, args.steps // 8))) if every == "batch" else 1
-        return B, (B * fuse if every == "batch" else 1)
+        return B, (B * fuse if every == "batch" else B)
 
-    def measure(scaling, every, collective, steps, repeats, warmup, flags=0, pipeline=None):
-        """one configuration: init, warm up, `repeats` timed blocks of `steps` steps; returns the blocks' walls (s) etc."""
+    def measure(scaling, every, collective, steps, repeats, warmup, flags=0, pipeline=None, c3=False):
+        """one configuration: init, warm up, `repeats` timed blocks of `steps` steps; returns the blocks' walls (s) etc.
+        `c3`: BASELINE config C3 as written -- accumulation into the zero-padded full frame, one overlapped reduce per iteration"""
         I, maxb = plan(scaling, every)
-        accum.zero_()
-        init(flags, args.pipeline if pipeline is None else pipeline, maxb)
-        nxt = run_steps(1, warmup, I, maxb, every, collective)
+        reducer = None
+        if every == "1":
+            flags |= pt.PT_FLAG_TRACE_AHEAD
+        if c3:
+            if ctx.get("accum_full") is None:
+                ctx["accum_full"] = torch.zeros(P * 3, dtype=torch.float32, device="cuda")
+            ctx["accum_full"].zero_()
+            init(flags, args.pipeline if pipeline is None else pipeline, maxb, full_frame=ctx["accum_full"])
+            reducer = ptdist.PerIterationReducer(ctx["accum_full"], dst=0, always_collective=True)
+            ctx["reducer"] = reducer
+        else:
+            accum.zero_()
+            init(flags, args.pipeline if pipeline is None else pipeline, maxb)
+        nxt = run_steps(1, warmup, I, maxb, every, collective, reducer)
         barrier()
         pt.counters_reset()
         walls = []
         for _ in range(repeats):
-            dt, nxt = timed(nxt, steps, I, maxb, every, collective)
+            dt, nxt = timed(nxt, steps, I, maxb, every, collective, reducer)
             walls.append(dt)
-        return {"I": I, "maxb": maxb, "walls": walls, "counters": pt.counters(), "next_iter": nxt}
+        return {"I": I, "maxb": maxb, "walls": walls, "counters": pt.counters(), "next_iter": nxt, "reducer": reducer}
 
     def median(v):
         s_ = sorted(v)
@@ -433,12 +543,32 @@ def run(args, ctx):
 
     every = args.collective_every
     # ---- pass A: the headline number (`--scaling`, `--collective-every`, `--collective`), repeated blocks --------------
+    telemetry = BoxTelemetry(torch, device_index) if rank == 0 else None
+    if telemetry:
+        telemetry.start()
+    if os.environ.get("BENCH_MARK_FILE") and rank == 0:    # (tests: "the timed blocks are about to start")
+        open(os.environ["BENCH_MARK_FILE"], "w").close()
     A = measure(args.scaling, every, args.collective, args.steps, args.repeats, args.warmup)
+    if telemetry:
+        telemetry.pause()
     I, maxb = A["I"], A["maxb"]
     dt = median(A["walls"])
     cntA = A["counters"]
     if args.dump_frame and rank == 0:
         np.save(args.dump_frame, (frame if world > 1 else accum).cpu().numpy())
+
+    def reading(scaling, ev, collective, steps, warmup, c3=False):
+        m = measure(scaling, ev, collective, steps, 1, warmup, c3=c3)
+        w = m["walls"][0]
+        r = {"value": round(P * D * m["I"] * steps / w / 1e6, 2), "unit": "Mpaths/s", "steps": steps, "iterations_per_step": m["I"],
+             "iterations_per_wavefront_batch": m["maxb"], "ms_per_step": round(w / steps * 1e3, 4),
+             "mode": "%s scaling, one %s per %s" % (scaling, collective, "wavefront batch" if ev == "batch" else "iteration")}
+        if ev == "1":
+            r["ms_per_iteration"] = round(w / (steps * m["I"]) * 1e3, 5)
+            r["calls"] = "one pt_iterate per iteration, committing one iteration of a wavefront batch traced ahead (PT_FLAG_TRACE_AHEAD)"
+        if c3:
+            r["mode"] += " of zero-padded full frames, snapshot double-buffered, the reduce on its own stream"
+        return r
 
     # ---- N > 1: the collective on its own (its bytes and its share of a step), then the other readings of "N GPUs" -------
     multi = None
@@ -459,19 +589,32 @@ def run(args, ctx):
                  "collective_ms_per_call": round(coll_ms, 4), "collective_calls_per_step": coll_calls_per_step,
                  "collective_share_of_step": round(coll_ms * coll_calls_per_step / (dt / args.steps * 1e3), 4)}
 
-        def reading(scaling, ev, collective, steps, warmup):
-            m = measure(scaling, ev, collective, steps, 1, warmup)
-            w = m["walls"][0]
-            return {"value": round(P * D * m["I"] * steps / w / 1e6, 2), "unit": "Mpaths/s", "steps": steps, "iterations_per_step": m["I"],
-                    "iterations_per_wavefront_batch": m["maxb"], "ms_per_step": round(w / steps * 1e3, 4),
-                    "mode": "%s scaling, one %s per %s" % (scaling, collective, "wavefront batch" if ev == "batch" else "iteration")}
         if args.extra_passes:
             other = "strong" if args.scaling == "weak" else "weak"
             multi["value_" + other] = reading(other, every, args.collective, args.steps, min(args.warmup, 2))
-            if args.per_iteration_sample > 0:
-                # BASELINE config C3 to the letter: a fixed number of samples divided over the ranks, one pt_iterate and one
-                # reduce(sum) of zero-padded full frames per iteration
-                multi["value_c3_as_written"] = reading("strong", "1", "reduce", args.per_iteration_sample, 1)
+
+    # ---- BASELINE config C3 to the letter, N >= 1: a fixed number of samples divided over the ranks, one pt_iterate and one
+    #      reduce(sum) of zero-padded full frames per ITERATION (the reference's per-iteration full-frame transfer,
+    #      src/pathtrace.cu:170-171), as the overlapped fast path of distributed.PerIterationReducer.  N = 1: through a one-rank
+    #      RCCL group, so that the protocol's per-iteration cost is a hardware number without a second GPU.
+    c3 = None
+    c3_steps = args.steps if args.per_iteration_sample is None else args.per_iteration_sample
+    if c3_steps > 0 and (world > 1 or args.extra_passes):
+        try:
+            if world == 1 and not dist.is_initialized():
+                ptdist.init_process_group(backend, single_rank=True)
+                ctx["dist"] = dist
+            c3 = reading("strong", "1", "reduce", c3_steps, 1, c3=True)
+            red = ctx.get("reducer")
+            c3["collective_bytes_per_call"] = red.bytes_per_call() if red is not None else None
+            c3["collective_backend"] = (backend if backend != "nccl" else "nccl (RCCL)") + (", one-rank group" if world == 1 else "")
+            if args.dump_c3_frame and rank == 0 and red is not None:
+                np.save(args.dump_c3_frame, red.frame().cpu().numpy())
+        except Exception as e:                               # (the extra reading must never cost the line)
+            if world > 1:
+                raise
+            c3 = {"error": repr(e)}
+        ctx.pop("reducer", None)
 
     # ---- pass B: same steps with HIP events around every launch (roofline of the bounce kernel); one
     #      batch in flight, so that a launch's duration is the kernel's own and not its share of a GPU it
@@ -526,6 +669,9 @@ def run(args, ctx):
               "algorithmic_bytes_per_launch": round(bounce_bytes / launches, 1),
               "traffic_over_algorithmic": round(traffic / (bounce_bytes / launches), 3) if traffic else None,
               "avg_launch_ms": round(avg_ms, 5), "launches": launches, "iterations_per_launch": iters_per_launch,
+              # the PIPELINED effective rate (labelled as such; `frac` above is the per-launch one): the same algorithmic bytes per step
+              # over the headline pass's ms_per_step, i.e. with the batches in flight overlapping each other's ramp-up and tail
+              "frac_pipelined": round(bounce_bytes / args.steps / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 5),
               "bounce_kernel_share_of_step": round(cnt.bounce_kernel_ms / (dtB * 1e3), 4),
               "ms_per_step_with_events": round(dtB / args.steps * 1e3, 4),
               "pmc_source": pmc_src}
@@ -558,8 +704,8 @@ def run(args, ctx):
             "ms_per_step_blocks": [round(w / args.steps * 1e3, 4) for w in A["walls"]],
             "config": {"workload": "%s %dx%d, %d bounces, %d spp per step x %d steps%s" % (
                            os.path.relpath(args.scene, ROOT), W, H, D, I, args.steps,
-                           "" if world == 1 else ", rows sharded y%%%d + RCCL %s of the row blocks per %s" % (
-                               world, args.collective, "batch" if every == "batch" else "iteration")),
+                           "" if world == 1 else ", rows sharded y%%%d + %s %s of the row blocks per %s" % (
+                               world, "RCCL" if backend == "nccl" else backend, args.collective, "batch" if every == "batch" else "iteration")),
                        "iterations_per_step": I,
                        "paths_per_step_nominal": P * D * I,
                        "ms_per_iteration": round(dt / iters_block * 1e3, 5),
@@ -579,11 +725,14 @@ def run(args, ctx):
                                             "iterations_per_wavefront_batch": maxb, "ms_per_step": out["ms_per_step"],
                                             "mode": "%s scaling, one %s per %s" % (args.scaling, args.collective,
                                                                                  "wavefront batch" if every == "batch" else "iteration")}
-            for k in ("value_weak", "value_strong", "value_c3_as_written"):
+            for k in ("value_weak", "value_strong"):
                 if k in multi:
                     out[k] = multi.pop(k)
             out["multi_gpu"] = multi
+        if c3 is not None:
+            out["value_c3_as_written"] = c3
         out["box_calibration"] = box_calibration(pt, torch)
+        out["box_calibration"]["telemetry_during_timed_blocks"] = telemetry.report() if telemetry else None
         if world == 1 and args.cpu_spp > 0:
             out["cpu_baseline"] = cpu_baseline(args, scene, pt)
         print(json.dumps(out), flush=True)

@@ -729,19 +729,29 @@ struct ScanWs {
 std::map<hipStream_t, ScanWs> g_scan;
 std::mutex g_scanMutex;              // the scan library may be called from several host threads (one stream each)
 
+// The caller HOLDS g_scanMutex from here until its launches that use the workspace are enqueued: pt_free, which releases the
+// workspaces, takes the same lock first and then waits for the device -- so a workspace is never freed between its look-up and the
+// kernels that use it (round 3 handed the pointer out of the lock: a second host thread could enqueue on freed memory).
 int scan_ws(hipStream_t st, ScanWs **out) {
-    std::lock_guard<std::mutex> lock(g_scanMutex);
     ScanWs &W = g_scan[st];          // (std::map: the reference stays valid while other streams are added)
     if (!W.partial) HIPCHECK(hipMalloc(&W.partial, (size_t)(kScanChunksMax + 1) * sizeof(uint32_t)));
     *out = &W;
     return PT_OK;
 }
-// releases every stream's workspace (pt_free, process exit); the caller has made sure that no scan is in flight
+// releases every stream's workspace: the PUBLIC pt_free and the process's exit only -- not the pt_free inside pt_init (the
+// reference's Free -> Init restart), which other host threads' scans must survive.  Under the lock: no scan call is between its
+// look-up and its launches; then everything enqueued is waited for, then freed.
 void scan_release() {
     std::lock_guard<std::mutex> lock(g_scanMutex);
+    if (g_scan.empty()) return;
+    (void)hipDeviceSynchronize();
     for (auto &kv : g_scan)
         if (kv.second.partial) (void)hipFree(kv.second.partial);
     g_scan.clear();
+}
+bool scan_in_use() {
+    std::lock_guard<std::mutex> lock(g_scanMutex);
+    return !g_scan.empty();
 }
 // the array as chunks of whole tiles: at most kScanChunksMax of them
 void scan_chunks(long long n, long long *tilesPerChunk, int *chunks) {
@@ -863,6 +873,7 @@ int discard_ahead() {
 // this handler is registered after the library's first HIP call, and exit handlers run in reverse order of registration --
 // so that no launch of this process is still executing when its queues, its code object and its memory go away.
 extern "C" void pt_free(void);
+void free_renderer();
 void exit_handler() { pt_free(); }
 void register_exit_handler() {
     static bool done = false;
@@ -895,10 +906,15 @@ int pt_device_count(void) { return count_devices(); }
 
 void pt_free(void) {
     // the scan library's per-stream workspaces (allocated on first use, with or without a renderer)
-    if (!g_scan.empty()) {
-        (void)hipDeviceSynchronize();
-        scan_release();
-    }
+    scan_release();
+    free_renderer();
+}
+
+}  // extern "C"
+#pragma GCC visibility pop
+namespace {
+// everything pt_init allocated (pt_free, and pt_init's own restart)
+void free_renderer() {
     // pathtraceFree before the first Init (src/main.cpp:91-94) must be a no-op
     if (!S.init && !S.image && !S.dgeoms && S.nslots == 0 && !S.hostFault) return;
     if (S.device >= 0 && S.nslots > 0) (void)hipSetDevice(S.device);     // (a host that switched devices in between)
@@ -939,6 +955,9 @@ void pt_free(void) {
     if (S.dMeshRecs) (void)hipFree(S.dMeshRecs);
     S = State();
 }
+}  // namespace
+#pragma GCC visibility push(default)
+extern "C" {
 
 int pt_set_meshes(const PtMesh *meshes, int nmeshes) {
     if (nmeshes < 0 || (nmeshes && !meshes)) return fail(PT_ERR_INVALID, "pt_set_meshes: null argument");
@@ -980,7 +999,7 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
             return fail(PT_ERR_INVALID, "pt_init: triangles registered for geom %d, which is not a mesh of this scene (pt_set_meshes)", m.geom);
     if (count_devices() < 1) return fail(PT_ERR_NO_GPU, "pt_init: no HIP device (this library has no CPU fallback)");
     register_exit_handler();
-    pt_free();
+    free_renderer();
 
     PtOptions o;
     memset(&o, 0, sizeof o);
@@ -1442,7 +1461,7 @@ int pt_iterate(int frame, int iter, void *rgba8_dev) { return pt_iterate_batch(f
 
 int pt_sync(void) {
     if (!S.init) {
-        if (g_scan.empty()) return fail(PT_ERR_NOT_INIT, "pt_sync before pt_init");
+        if (!scan_in_use()) return fail(PT_ERR_NOT_INIT, "pt_sync before pt_init");
         HIPCHECK(hipDeviceSynchronize());          // the scan library alone
         return PT_OK;
     }
@@ -1670,6 +1689,7 @@ int pt_scan_exclusive_i32(const int32_t *in_dev, int32_t *out_dev, int64_t n, vo
     if (n > (1ll << 42)) return fail(PT_ERR_INVALID, "pt_scan_exclusive_i32: n too large");
     hipStream_t st = (hipStream_t)stream;
     register_exit_handler();
+    std::lock_guard<std::mutex> lock(g_scanMutex);   // (look-up AND launches: see scan_ws)
     ScanWs *wp = nullptr;
     int rc = scan_ws(st, &wp);
     if (rc) return rc;
@@ -1693,6 +1713,7 @@ int pt_compact_nonzero_i32(const int32_t *in_dev, int32_t *out_dev, int64_t n, i
         return PT_OK;
     }
     register_exit_handler();
+    std::lock_guard<std::mutex> lock(g_scanMutex);   // (look-up AND launches: see scan_ws)
     ScanWs *wp = nullptr;
     int rc = scan_ws(st, &wp);
     if (rc) return rc;

@@ -30,13 +30,27 @@ def padded_block_floats(width, height, world):
     return ((height + world - 1) // world) * width * 3
 
 
-def init_process_group(backend=None):
-    """Rendezvous from the torchrun environment (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT)."""
+def init_process_group(backend=None, timeout_s=180, single_rank=False):
+    """Rendezvous from the torchrun environment (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT).  Every collective of the
+    group -- the exit barrier included -- gives up after `timeout_s` seconds instead of waiting for a rank that died.
+    `single_rank`: form a ONE-rank group on 127.0.0.1 when there is no torchrun environment (bench.py at N = 1 sends its
+    per-iteration reduce through RCCL's call path: a hardware number for the protocol's fixed cost without a second GPU)."""
+    import datetime
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world == 1:
+    if world == 1 and not single_rank:
         return 0, 1
+    if world == 1:
+        import socket
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(port))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     # HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC, the only kind this driver supports) is read when the HSA runtime
@@ -47,7 +61,7 @@ def init_process_group(backend=None):
     kw = {}
     if backend == "nccl":
         kw["device_id"] = torch.device("cuda", torch.cuda.current_device())
-    dist.init_process_group(backend=backend, **kw)
+    dist.init_process_group(backend=backend, timeout=datetime.timedelta(seconds=timeout_s), **kw)
     return dist.get_rank(), dist.get_world_size()
 
 
@@ -113,3 +127,67 @@ def gather_frame(block, bufs, frame, width, height, dst=0, collective="gather", 
     if rank == dst:
         frame.copy_(full)
     return frame
+
+
+class PerIterationReducer:
+    """BASELINE config C3 AS WRITTEN: after EVERY iteration one reduce(sum) of zero-padded full frames to rank `dst` -- the
+    reference's own per-iteration full-frame transfer (src/pathtrace.cu:170-171, src/main.cpp:97-106) with RCCL in the place of
+    its cudaMemcpy -- as a pipeline instead of a stop-and-go loop:
+
+      * the renderer accumulates into a FULL frame, its own rows in place and zeros everywhere else (a row shard WITHOUT
+        PT_FLAG_ACCUM_SHARD_ROWS: k_commit indexes by the global pixel), so the accumulator itself is the zero-padded frame:
+        no per-call torch.zeros, no strided scatter;
+      * `collect()` takes a SNAPSHOT of it on the caller's stream (one contiguous device-to-device copy, ordered behind the
+        iteration's commit) into one of two buffers and issues the reduce of that buffer asynchronously: the backend runs it on a
+        stream of its own, ordered behind the snapshot (torch's ProcessGroupNCCL synchronises its stream with the caller's at the
+        call), so iteration i's reduce runs while iteration i + 1 is committed and while the batches traced ahead keep tracing;
+      * a buffer is reused two calls later, behind the completion of the reduce that read it (`Work.wait()`: a stream-level
+        wait under RCCL, nothing the host blocks on).
+    Three calls into torch per iteration.
+
+    At rank `dst` the buffer of the latest call holds the summed frame once its reduce has finished (`frame()`).  Rows are
+    disjoint, every other rank adds +0.0 to them: bit-identical to a single-GPU render.
+    CPU tensors (the gloo tests) take the same calls.  `always_collective`: issue the reduce in a one-rank group too (N = 1:
+    the RCCL call path on one GPU)."""
+
+    def __init__(self, accum_full, dst=0, always_collective=False):
+        import torch
+        import torch.distributed as dist
+        self.accum = accum_full
+        self.dst = dst
+        self.collective = dist.is_initialized() and (dist.get_world_size() > 1 or always_collective)
+        self.snap = [torch.empty_like(accum_full) for _ in range(2)]
+        self.work = [None, None]
+        self.k = 0
+        self.last = None
+        self.calls = 0
+        self._reduce = dist.reduce
+        self._sum = dist.ReduceOp.SUM
+
+    def collect(self):
+        k = self.k
+        self.k = k ^ 1
+        w = self.work[k]
+        if w is not None:
+            w.wait()                                        # the reduce that last read this buffer
+        buf = self.snap[k]
+        buf.copy_(self.accum, non_blocking=True)
+        if self.collective:
+            self.work[k] = self._reduce(buf, dst=self.dst, op=self._sum, async_op=True)
+        self.last = k
+        self.calls += 1
+
+    def finish(self):
+        """every reduce issued so far has completed, as far as the caller's stream is concerned"""
+        for k in (0, 1):
+            if self.work[k] is not None:
+                self.work[k].wait()
+                self.work[k] = None
+
+    def frame(self):
+        """rank `dst`: the frame of the latest collect() (summed over the ranks); other ranks: their own snapshot"""
+        self.finish()
+        return self.snap[self.last] if self.last is not None else None
+
+    def bytes_per_call(self):
+        return self.accum.numel() * self.accum.element_size()

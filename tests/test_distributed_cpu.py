@@ -101,6 +101,57 @@ def test_reduce_collective_assembles_the_same_frame(tmp_path):
     assert np.load(out)[0] == 1
 
 
+def _worker_per_iteration(rank, world, port, res, iters, out_path):
+    """config C3 as written: every rank accumulates ITS rows into a full frame (zeros elsewhere) and the frame is reduced after
+    EVERY iteration through PerIterationReducer -- the oracle stands in for the kernels, the collective is the product's."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch
+    import __graft_entry__ as ge
+    import oracle as orc
+    ptdist = ge.load_submodule("distributed")
+    ptdist.init_process_group("gloo", timeout_s=120)
+    W, H = res
+    sc = orc.Scene(os.path.join(SCENES, "cornell.txt"))
+    sc.set_resolution(W, H)
+    ren = orc.Renderer(sc.camera, sc.geoms, sc.materials, 8)
+    sparse = np.zeros(W * H * 3, np.float32)                     # full frame, own rows only: the accumulator itself
+    accum = torch.from_numpy(sparse)                             # (shares the memory: what the renderer's commit writes)
+    red = ptdist.PerIterationReducer(accum, dst=0)
+    assert red.bytes_per_call() == W * H * 12
+    full = np.zeros(W * H * 3, np.float32)
+    ok = True
+    for it in iters:
+        ren.iterate(it, sparse, rank, world)
+        red.collect()
+        if rank == 0:
+            ren.iterate(it, full)
+            ok = ok and np.array_equal(red.frame().numpy().view(np.uint32), full.view(np.uint32))
+    ok = ok and red.calls == len(iters)
+    # the accumulator itself is never touched by the collective: still this rank's rows only
+    rows = sparse.reshape(H, W, 3)
+    other = np.ones(H, bool)
+    other[list(ptdist.shard_rows(H, rank, world))] = False
+    assert not np.any(rows[other])
+    if rank == 0:
+        np.save(out_path, np.array([1 if ok else 0]))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,res", [(2, (48, 37)), (3, (40, 30))])
+def test_per_iteration_reduce_of_full_frames_is_bit_exact(tmp_path, world, res):
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "ok.npy")
+    mp.spawn(_worker_per_iteration, args=(world, port, res, [1, 2, 3, 4], out), nprocs=world, join=True)
+    assert np.load(out)[0] == 1
+
+
 def test_shard_rows_partition():
     sys.path.insert(0, ROOT)
     import __graft_entry__ as ge

@@ -11,10 +11,12 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def test_bench_json_contract(pt):
+def test_bench_json_contract(pt, tmp_path):
     if pt.device_count() < 1:
         pytest.fail("no HIP device: GPU tests must run on the MI355X box")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--cpu-spp", "1", "--repeats", "5"],
+    dump, dump_c3 = str(tmp_path / "frame.npy"), str(tmp_path / "frame_c3.npy")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--cpu-spp", "1", "--repeats", "5",
+                        "--dump-frame", dump, "--dump-c3-frame", dump_c3],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -27,16 +29,19 @@ def test_bench_json_contract(pt):
     assert d["metric"] == "Mpaths/sec (paths = pixels x bounces x spp) at 1280x720, 8 bounces"
     assert d["unit"] == "Mpaths/s" and d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None
     assert "workload" in d["config"] and "model" not in d["config"]
-    # one step = one wavefront batch of 32 iterations of the whole frame
-    assert d["config"]["iterations_per_step"] == 32 and d["config"]["paths_per_step_nominal"] == 1280 * 720 * 8 * 32
-    assert abs(d["value"] - 1280 * 720 * 8 * 32 / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 0.01
+    # one step = one wavefront batch of 64 iterations of the whole frame = BASELINE config C2 (64 spp) in full
+    assert d["config"]["iterations_per_step"] == 64 and d["config"]["paths_per_step_nominal"] == 1280 * 720 * 8 * 64
+    assert abs(d["value"] - 1280 * 720 * 8 * 64 / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 0.01
     assert d["value"] > 1000.0                                   # north star: >= 1.0 Gpaths/s
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4 and 0 < rf["frac"] < 1
     # every timed launch carries a full batch, so the committed PMC figures describe the launches that were timed:
     # measured HBM traffic within 25 % of the algorithmic bytes, and the kernel cannot beat its own VALU issue bound
-    assert rf["iterations_per_launch"] == 32 and rf["launches"] == 3 * 8
+    assert rf["iterations_per_launch"] == 64 and rf["launches"] == 3 * 8
+    # the pipelined effective rate stands beside the per-launch fraction, labelled: same bytes over the headline pass's ms_per_step
+    assert 0 < rf["frac_pipelined"] < 1
+    assert abs(rf["frac_pipelined"] - rf["algorithmic_bytes_per_launch"] * 8 / (d["ms_per_step"] * 1e-3) / 8e12) < 0.02 * rf["frac_pipelined"]
     if rf["traffic"] is not None:
         assert 0.9 < rf["traffic_over_algorithmic"] < 1.25
         assert 0 < rf["valu"]["frac_of_issue_bound"]["v_fma_f32"] < 1
@@ -47,6 +52,33 @@ def test_bench_json_contract(pt):
     assert d["value_min"] <= d["value"] <= d["value_max"]
     # the line says what the box it ran on does on a fixed job (boxes of the pool differ by up to 1.8x)
     assert d["box_calibration"]["result_checked"] is True and d["box_calibration"]["algorithmic_GBps"] > 500
+    # ... and what its clocks, power and temperature were WHILE the timed blocks ran (a slow line is attributable without a second run)
+    tm = d["box_calibration"]["telemetry_during_timed_blocks"]
+    assert "error" not in tm, tm
+    assert tm["samples"] >= 1 and tm["power_cap_w"] > 0      # (5 blocks of 3 steps are ~30 ms; a hwmon read takes milliseconds)
+    for k in ("sclk_mhz", "mclk_mhz", "power_w", "temp_junction_c"):
+        assert tm[k]["min"] <= tm[k]["median"] <= tm[k]["max"] and tm[k]["max"] > 0, k
+    assert 100 <= tm["sclk_mhz"]["max"] <= 3000 and tm["power_w"]["max"] <= 1.1 * tm["power_cap_w"]
+    # BASELINE config C3 AS WRITTEN -- one pt_iterate + one reduce(sum) of zero-padded full frames per iteration -- measured at N = 1
+    # as well, through a one-rank RCCL group, over the same number of steps, as the overlapped fast path
+    c3 = d["value_c3_as_written"]
+    assert "error" not in c3, c3
+    assert c3["steps"] == 3 and c3["iterations_per_step"] == 64 and c3["value"] > 1000.0
+    assert "reduce per iteration" in c3["mode"] and "RCCL" in c3["collective_backend"] and "one-rank" in c3["collective_backend"]
+    assert c3["collective_bytes_per_call"] == 1280 * 720 * 12
+    assert abs(c3["ms_per_iteration"] - c3["ms_per_step"] / 64) < 1e-3 and c3["ms_per_iteration"] < 0.2
+    # its frame (what the LAST reduce delivered: warm-up step + 3 steps = 256 iterations) against the batched render of the same iterations
+    import numpy as np
+    got = np.load(dump_c3)
+    sc = pt.Scene(os.path.join(ROOT, "scenes", "cornell.txt"))
+    sc.set_resolution(1280, 720)
+    pt.pathtraceFree()
+    pt.pathtraceInit(sc, traceDepth=8, pipeline_depth=2, max_batch=64)
+    for it in range(1, 257, 64):
+        pt.pathtrace_batch(None, 0, it, 64)
+    want = pt.readback(1280 * 720)
+    pt.pathtraceFree()
+    assert want.max() > 0 and np.array_equal(got.view(np.uint32), want.view(np.uint32))
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
     assert cb["cpu_model"] and cb["host_cores"] >= 1 and cb["pinned_to_core"] is not None

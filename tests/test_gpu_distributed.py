@@ -105,17 +105,18 @@ def test_bench_two_ranks_contract(pt, tmp_path, every, extra, ranks, scaling):
     env = dict(os.environ, BENCH_BACKEND="gloo")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    dump = str(tmp_path / "frame.npy")
+    dump, dump_c3 = str(tmp_path / "frame.npy"), str(tmp_path / "frame_c3.npy")
     steps, warmup, repeats = 3, 1, 2
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", str(steps), "--warmup", str(warmup),
-                        "--repeats", str(repeats), "--collective-every", every, "--per-iteration-sample", "1", "--dump-frame", dump] + extra
+                        "--repeats", str(repeats), "--collective-every", every, "--per-iteration-sample", "1", "--dump-frame", dump,
+                        "--dump-c3-frame", dump_c3] + extra
                        + ([] if scaling == "weak" else ["--scaling", "strong"]),                # (weak is the default)
                        capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                          # rank 0 only
     d = json.loads(lines[0])
-    B = int(extra[extra.index("--batch") + 1]) if "--batch" in extra else 32
+    B = int(extra[extra.index("--batch") + 1]) if "--batch" in extra else 64
     # weak scaling: a step is B x N iterations of the whole frame (a rank's share = the single GPU's step); strong: B iterations
     I = B * ranks if scaling == "weak" else B
     assert d["n_gpus"] == ranks and d["steps"] == steps and d["warmup"] == warmup and d["scaling"] == scaling
@@ -127,7 +128,7 @@ def test_bench_two_ranks_contract(pt, tmp_path, every, extra, ranks, scaling):
     # strong, collective per batch: a rank fuses min(N, PT_MAX_BATCH // B, steps // 8) steps (at least one) into one wavefront batch;
     # weak: a step is one wavefront batch, in pieces of PT_MAX_BATCH iterations should it be larger (3 x 96 = 288 -> 256 + 32)
     if every != "batch":
-        wb = 1
+        wb = B                                                      # (single-iteration calls draw on batches of B traced ahead)
     elif scaling == "weak":
         wb = min(I, pt.PT_MAX_BATCH)
     else:
@@ -141,8 +142,13 @@ def test_bench_two_ranks_contract(pt, tmp_path, every, extra, ranks, scaling):
         assert d[k]["value"] > 0 and d[k]["steps"] >= 1 and d[k]["unit"] == "Mpaths/s", k
     assert d["value_" + scaling]["value"] == d["value"]             # `value` = the reading --scaling names
     assert d["value_weak"]["iterations_per_step"] == B * ranks and d["value_strong"]["iterations_per_step"] == B
-    assert d["value_c3_as_written"]["iterations_per_step"] == B and d["value_c3_as_written"]["iterations_per_wavefront_batch"] == 1
-    assert "reduce per iteration" in d["value_c3_as_written"]["mode"]
+    c3 = d["value_c3_as_written"]
+    assert c3["iterations_per_step"] == B and c3["iterations_per_wavefront_batch"] == B and c3["steps"] == 1
+    assert "reduce per iteration" in c3["mode"] and c3["collective_bytes_per_call"] == 1280 * 720 * 12 and c3["ms_per_iteration"] > 0
+    # ... and the frame its LAST reduce delivered at rank 0 (1 warm-up step + 1 step of B iterations) equals the single-rank render
+    c3_got = np.load(dump_c3)
+    c3_want = _single_rank_frame(pt, 2 * B, min(B, 64))
+    assert c3_want.max() > 0 and np.array_equal(c3_got.view(np.uint32), c3_want.view(np.uint32))
     mg = d["multi_gpu"]
     block = -(-720 // ranks) * 1280 * 12                            # a rank's packed rows, padded to the largest shard
     assert mg["collective_bytes_per_call"]["sent_by_each_rank"] == (1280 * 720 * 12 if "reduce" in extra else block)
