@@ -51,6 +51,11 @@ int pt_test_wall_plane_sweep(const PtGeom *geoms, int ngeoms, uint64_t seed, int
  * would have skipped (must be 0), *culled = (ray, primitive) pairs the culling skips, *hits = hits.  Spheres and cubes. */
 int pt_test_camera_cull_sweep(const PtCamera *cam, const PtGeom *geoms, int ngeoms, int samples, uint64_t *hits, uint64_t *culled,
                               uint64_t *violations);
+/* ... and the MARGIN of the tables' object-space inflation (pt_api.hip: inflated_object_box): for every hit of the same sweep, the
+ * fraction of the inflation the hit needs -- 0 for a geometric hit, up to 1 for a hit the fp32 test's rounding created, above 1 for a
+ * hit outside the inflated box -- evaluated in double precision on the exact object-space half-line.  *worst_fraction = the largest
+ * (its reciprocal is the safety margin), *needed = hits with a fraction above 0.  Primitives whose culling is off are skipped. */
+int pt_test_camera_cull_margin(const PtCamera *cam, const PtGeom *geoms, int ngeoms, int samples, double *worst_fraction, uint64_t *needed);
 /* The same tables for inspection (host only, no GPU needed): rects4[4 i ..] = primitive i's pixel rectangle, scene_rect4 = their
  * union, spans2[2 (y ngeoms + i) ..] = the pixels x0 .. x1 of row y from which primitive i is reachable (x0 > x1: none). */
 int pt_test_camera_cull_tables(const PtCamera *cam, const PtGeom *geoms, int ngeoms, int32_t *rects4, int32_t *scene_rect4, int32_t *spans2);

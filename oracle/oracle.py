@@ -292,12 +292,16 @@ class Renderer:
     def set_extras(self, lens_radius=0.0, focal_distance=0.0, direct_lighting=False):
         lib().orc_render_set_extras(self.h, C.c_float(lens_radius), C.c_float(focal_distance), 1 if direct_lighting else 0)
 
-    def set_variant(self, scatter_offset=0.001, mirror_mode=0):
+    def set_variant(self, scatter_offset=0.001, mirror_mode=0, emit_color_mode=0):
         """STUDY variants of the build-defined scatter (never used by a parity test): offset of the new origin along the normal;
-        REFL > 0 materials as 50/50 energy conserving (0, the build's choice), 50/50 with 1 / p weights (1) or a pure mirror (2)."""
+        REFL > 0 materials as 50/50 energy conserving (0, the build's choice), 50/50 with 1 / p weights (1), a pure mirror (2) or split
+        by the intensities of the two colours with 1 / p weights (3, src/interactions.h:56-59); emit_color_mode 1 = an emitter hit
+        contributes throughput x emittance without the emitter's own colour (`color *= m.color` AFTER the emitter test)."""
         L = lib()
         L.orc_render_set_variant.argtypes = [C.c_void_p, C.c_float, C.c_int]
         L.orc_render_set_variant(self.h, C.c_float(scatter_offset), mirror_mode)
+        L.orc_render_set_emit_variant.argtypes = [C.c_void_p, C.c_int]
+        L.orc_render_set_emit_variant(self.h, emit_color_mode)
 
     def iterate(self, it, image, rank=0, count=1):
         c = Counters()

@@ -719,7 +719,10 @@ struct ORender {
      * 2 % on the back wall.  These switches render the candidate explanations in the oracle (DESIGN.md section 2 tabulates them). */
     float scatterOffset = 0.001f;      /* new origin = hit +- offset * normal */
     int mirrorMode = 0;                /* REFL > 0 materials: 0 = 50/50 mirror / diffuse, energy conserving (the build's choice); 1 = 50/50 with
-                                          the 1 / p weights (either branch x 2); 2 = a pure mirror */
+                                          the 1 / p weights (either branch x 2); 2 = a pure mirror; 3 = the split "based on the intensity of
+                                          each material color", either branch divided by its probability (src/interactions.h:56-59) */
+    int emitColorMode = 0;             /* 0 = an emitter hit contributes throughput x m.color x emittance (the build's choice: `color *= m.color`
+                                          BEFORE the emitter test); 1 = throughput x emittance (m.color applied only to paths that go on) */
     std::vector<int> emitters;         /* geoms with an emissive material, file order */
     std::vector<OMesh> meshes;         /* triangle data of the geoms of type 2 */
     std::vector<int> meshOf;           /* geom -> index into meshes, -1 */
@@ -965,7 +968,7 @@ Fate bounce(const ORender &R, int iter, int index, int depth, Ray &ray, V3 &colo
     const OMaterial &m = R.mats[R.geoms[g].materialid];
     V3 mcol = from(m.color);
     if (m.emittance > 0.0f) {
-        contrib = muls(mul(color, mcol), m.emittance);
+        contrib = R.emitColorMode == 1 ? muls(color, m.emittance) : muls(mul(color, mcol), m.emittance);
         return LIGHT;
     }
     uint32_t rng = rng_seed(make_seed(iter, index, depth));
@@ -1003,7 +1006,11 @@ Fate bounce(const ORender &R, int iter, int index, int depth, Ray &ray, V3 &colo
         /* energy-conserving 50/50 mirror/diffuse mixture (spec S6) */
         float u = rng_u01(rng);
         norg = add(p, muls(n, R.scatterOffset));
-        if (u < 0.5f || R.mirrorMode == 2) {
+        /* (study variant 3: p(mirror) = I(specular colour) / (I(specular colour) + I(diffuse colour)), I = r + g + b) */
+        float is = (scol.x + scol.y) + scol.z, id = (mcol.x + mcol.y) + mcol.z;
+        float pSpec = R.mirrorMode == 3 && is + id > 0.0f ? is / (is + id) : 0.5f;
+        bool mirror = u < pSpec || R.mirrorMode == 2;
+        if (mirror) {
             ndir = reflect3(ray.direction, n);
             if (m.specExponent > 0.0f)      /* SPECEX > 0: imperfect specular (README.md:171-185); 0 = the perfect mirror */
                 ndir = random_direction_in_specular_lobe(ndir, n, 1.0f / (m.specExponent + 1.0f), rng);
@@ -1015,6 +1022,7 @@ Fate bounce(const ORender &R, int iter, int index, int depth, Ray &ray, V3 &colo
             color = mul(color, mcol);
         }
         if (R.mirrorMode == 1) color = muls(color, 2.0f);      /* (study variant: the 1 / p weight of the branch taken) */
+        if (R.mirrorMode == 3) color = muls(color, 1.0f / (mirror ? pSpec : 1.0f - pSpec));
     } else {
         norg = add(p, muls(n, R.scatterOffset));
         if (direct && !R.emitters.empty()) {
@@ -1232,6 +1240,7 @@ void orc_render_set_variant(ORender *R, float scatterOffset, int mirrorMode) {
     R->scatterOffset = scatterOffset;
     R->mirrorMode = mirrorMode;
 }
+void orc_render_set_emit_variant(ORender *R, int emitColorMode) { R->emitColorMode = emitColorMode; }
 float orc_pow(float x, float e) { return pow_poly(x, e); }
 void orc_render_free(ORender *R) { delete R; }
 

@@ -24,7 +24,12 @@ VARIANTS = [("build: offset 1e-3, 50/50 energy conserving, depth 8", dict()),
             ("50/50 with 1/p weights", dict(mirror_mode=1)),
             ("pure mirror", dict(mirror_mode=2)),
             ("depth 9 (one more bounce)", dict(depth=9)),
-            ("depth 7 (one bounce fewer)", dict(depth=7))]
+            ("depth 7 (one bounce fewer)", dict(depth=7)),
+            # round 4: the two remaining readings of src/interactions.h:44-68
+            ("split by colour intensity, 1/p weights (:56-59)", dict(mirror_mode=3)),
+            ("m.color applied AFTER the emitter test", dict(emit_color_mode=1))]
+if os.environ.get("VARIANTS_ONLY"):          # e.g. VARIANTS_ONLY=0,6,7: a subset of the table, by index
+    VARIANTS = [VARIANTS[int(i)] for i in os.environ["VARIANTS_ONLY"].split(",")]
 
 
 def work(args):

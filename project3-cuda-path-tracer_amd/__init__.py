@@ -60,7 +60,7 @@ TEST_ABI_SYMBOLS = [
     "pt_test_slab_quotients", "pt_test_slab_quotients_sweep", "pt_test_sphere_cull_sweep", "pt_test_unscaled_sqrt_sweep",
     "pt_test_force_fault", "pt_test_pow", "pt_test_wall_box_sweep", "pt_test_mesh_intersect", "pt_test_mesh_bvh",
     "pt_test_mesh_cull_sweep", "pt_test_camera_cull_sweep", "pt_test_camera_cull_tables",
-    "pt_test_wall_plane_sweep", "pt_test_sphere_halfline_sweep",
+    "pt_test_wall_plane_sweep", "pt_test_sphere_halfline_sweep", "pt_test_camera_cull_margin",
 ]
 
 
@@ -131,6 +131,7 @@ def _bind(L, with_tests):
         L.pt_test_mesh_cull_sweep.argtypes = [vp, vp, i32, C.c_uint64, i64] + [u64p] * 3
         L.pt_test_camera_cull_sweep.argtypes = [vp, vp, i32, i32] + [u64p] * 3
         L.pt_test_camera_cull_tables.argtypes = [vp, vp, i32, vp, vp, vp]
+        L.pt_test_camera_cull_margin.argtypes = [vp, vp, i32, i32, C.POINTER(C.c_double), u64p]
         L.pt_test_wall_plane_sweep.argtypes = [vp, i32, C.c_uint64, i64, C.POINTER(C.c_int32)] + [u64p] * 3
     return L
 
@@ -575,6 +576,16 @@ def test_camera_cull_sweep(camera, geoms, samples=1):
     h, c, v = C.c_uint64(), C.c_uint64(), C.c_uint64()
     _tcheck(test_lib().pt_test_camera_cull_sweep(_p(cam), _p(geoms), len(geoms), samples, C.byref(h), C.byref(c), C.byref(v)))
     return int(h.value), int(c.value), int(v.value)
+
+
+def test_camera_cull_margin(camera, geoms, samples=1):
+    """Device measurement of the culling tables' inflation margin for one (camera, primitive set).  Returns (largest fraction of the
+    inflation a hit of the reference's test needed, hits that needed any)."""
+    cam = np.ascontiguousarray(camera)
+    geoms = np.ascontiguousarray(geoms)
+    w, n = C.c_double(), C.c_uint64()
+    _tcheck(test_lib().pt_test_camera_cull_margin(_p(cam), _p(geoms), len(geoms), samples, C.byref(w), C.byref(n)))
+    return float(w.value), int(n.value)
 
 
 def test_wall_plane_sweep(geoms, seed, rays):

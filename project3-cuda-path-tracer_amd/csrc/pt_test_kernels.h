@@ -270,6 +270,83 @@ __global__ void k_sweep_camera_cull(KParams prm, const GeomDev *geoms, const int
     if (nv) atomicAdd(violations, (unsigned long long)nv);
 }
 
+// How much of the culling tables' object-space inflation (pt_api.hip: inflated_object_box) do the reference's hits actually NEED?  For
+// every camera ray the full test reports as a hit, the ray as the test received it (fp32 origin and direction) is taken through the
+// primitive's inverse transform in DOUBLE precision -- the exact line the fp32 test approximates -- and the smallest fraction s of the
+// inflation is found at which that half-line meets the primitive grown by s x the inflation: s = 0 for a hit that is a geometric
+// hit, 0 < s <= 1 for one the rounding of the fp32 test created (the hits the inflation exists for), s > 1 would be a hit outside the
+// inflated box.  `infl`: per primitive {dx, dy, dz, active} for a cube (growth of the half extents) and {r_inflated, -, -, active}
+// for a sphere; primitives whose culling is switched off (a corner not in front of the eye) are skipped.  Outputs: the largest s
+// (bit pattern of a non-negative double: ordered like an unsigned integer) and the number of hits with s > 0.
+__device__ __forceinline__ bool halfLineMeetsBoxD(const double ro[3], const double rd[3], const double h[3]) {
+    double t0 = 0.0, t1 = 1e300;
+    for (int a = 0; a < 3; ++a) {
+        if (rd[a] == 0.0) {
+            if (ro[a] < -h[a] || ro[a] > h[a]) return false;
+            continue;
+        }
+        double ta = (-h[a] - ro[a]) / rd[a], tb = (h[a] - ro[a]) / rd[a];
+        if (ta > tb) { const double q = ta; ta = tb; tb = q; }
+        t0 = ta > t0 ? ta : t0;
+        t1 = tb < t1 ? tb : t1;
+    }
+    return t0 <= t1;
+}
+__global__ void k_sweep_camera_cull_margin(KParams prm, const GeomDev *geoms, const double *infl, int samples, unsigned long long *worstBits,
+                                           unsigned long long *needed) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= prm.W * prm.H) return;
+    const int y = j / prm.W, x = j - y * prm.W;
+    double worst = 0.0;
+    unsigned int nn = 0;
+    for (int g = 0; g < prm.ngeoms; ++g) {
+        if (infl[4 * g + 3] == 0.0) continue;
+        const GeomDev &G = geoms[g];
+        for (int sI = 1; sI <= samples; ++sI) {
+            F3 org, dir, P, N;
+            bool o;
+            cameraRayAt(prm, iterationHash(sI, 0), j, x, y, org, dir);
+            const float t = (G.flags & 1) ? boxIntersectionTest<true, true>(G, org, dir, P, N, o) : sphereIntersectionTest<true>(G, org, dir, P, N, o);
+            if (!(t > 0.0f)) continue;
+            const double ow[3] = {org.x, org.y, org.z}, dw[3] = {dir.x, dir.y, dir.z};
+            double ro[3], rd[3];
+            for (int r = 0; r < 3; ++r) {
+                ro[r] = (double)G.inv[r] * ow[0] + (double)G.inv[3 + r] * ow[1] + (double)G.inv[6 + r] * ow[2] + (double)G.inv[9 + r];
+                rd[r] = (double)G.inv[r] * dw[0] + (double)G.inv[3 + r] * dw[1] + (double)G.inv[6 + r] * dw[2];
+            }
+            double s = 0.0;
+            if (G.flags & 1) {
+                double h[3] = {0.5, 0.5, 0.5};
+                if (!halfLineMeetsBoxD(ro, rd, h)) {
+                    double lo = 0.0, hi = 1.0;
+                    for (int a = 0; a < 3; ++a) h[a] = 0.5 + infl[4 * g + a];
+                    if (!halfLineMeetsBoxD(ro, rd, h)) {
+                        s = 2.0;                              // (outside the inflated box: reported as 2)
+                    } else {
+                        for (int it = 0; it < 30; ++it) {
+                            const double mid = 0.5 * (lo + hi);
+                            for (int a = 0; a < 3; ++a) h[a] = 0.5 + mid * infl[4 * g + a];
+                            if (halfLineMeetsBoxD(ro, rd, h)) hi = mid; else lo = mid;
+                        }
+                        s = hi;
+                    }
+                }
+            } else {
+                const double a = rd[0] * rd[0] + rd[1] * rd[1] + rd[2] * rd[2], b = ro[0] * rd[0] + ro[1] * rd[1] + ro[2] * rd[2];
+                double ts = a > 0.0 ? -b / a : 0.0;
+                ts = ts > 0.0 ? ts : 0.0;
+                const double qx = ro[0] + ts * rd[0], qy = ro[1] + ts * rd[1], qz = ro[2] + ts * rd[2];
+                const double dist = sqrt(qx * qx + qy * qy + qz * qz);
+                if (dist > 0.5) s = (dist - 0.5) / (infl[4 * g] - 0.5);
+            }
+            if (s > 0.0) ++nn;
+            worst = s > worst ? s : worst;
+        }
+    }
+    if (nn) atomicAdd(needed, (unsigned long long)nn);
+    if (worst > 0.0) atomicMax(worstBits, (unsigned long long)__double_as_longlong(worst));
+}
+
 // wallPlanesPossible soundness sweep: pseudo-random rays against the walls of a scene as pt_init numbers them (`wallGeoms[w]` = the
 // cube that is wall w).  Origins as the render kernel meets them and worse: on a wall's inner face pushed 1e-3 (or 0 .. 4e-3) into
 // the room, in the corners where two and three walls meet, anywhere inside the box around the walls, outside it; directions random,

@@ -427,7 +427,7 @@ static_assert(sizeof(CullGroup) == 32 && offsetof(GeomDev, cullFlags) - offsetof
 // DOF (with FIRST only): camera rays start on a thin lens (README.md:100-101), so they share no origin (no precomputed
 // object-space camera position) and the pixel rectangles, which project the primitives through a pinhole, are not used.
 template <bool FIRST, bool MANY, bool DOF = false, bool MESH = false>
-__global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void k_bounce(BounceArgs argsByValue) {
+__global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF ? 5 : (MANY ? 7 : 8))) void k_bounce(BounceArgs argsByValue) {
     static_assert(FIRST || !DOF, "the lens only concerns the camera-ray bounce");
     (void)argsByValue;
     const ArgsPtr kargs = (ArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -707,8 +707,9 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
 #ifndef PT_TICKETS
 #define PT_TICKETS 1
 #endif
-    const bool ticketed = PT_TICKETS && !FIRST && (hotWord & kHotLast) == 0u;
-    uint32_t Tn1 = FIRST ? 0u : T + gridDim.x;   // the tile after T (camera rays: always T + grid, not carried)
+    constexpr bool kTickets = PT_TICKETS && !FIRST;
+    const bool ticketed = kTickets && (hotWord & kHotLast) == 0u;
+    uint32_t Tn1 = kTickets ? T + gridDim.x : 0u;   // the tile after T (carried only where tickets can be drawn; else always T + grid)
     while (T < numTiles) {
         // the lane id, opaque to the optimiser: the lane masks derived from it (tid < 16, wave > k, ...) are then
         // recomputed where a tile needs them -- one v_cmp each -- instead of being hoisted out of the loop into SGPR pairs
@@ -720,7 +721,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
         // itself the compiler carried T in a VGPR and expanded the divisions below into ~60 vector instructions per tile)
         T = (uint32_t)__builtin_amdgcn_readfirstlane((int)T);
         probe(14);                                              // (a tile starts)
-        uint32_t Tnext = FIRST ? T + gridDim.x : Tn1;   // (last bounce: T + grid as well)
+        uint32_t Tnext = kTickets ? Tn1 : T + gridDim.x;   // (last bounce: T + grid as well)
         bool valid;
         uint32_t tileCls = 0u;              // wave-uniform: the tile's queue class (later bounces)
         PathRegs cur = nextRegs;
@@ -826,7 +827,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
                 // behind s_waitcnt vmcnt(2) -- and every wave sat out a memory round trip BEFORE the compaction's barriers instead of
                 // under them: the "3 loads issued: 7 %" of round 3's timeline.)
                 int cpix = cur.pix, cpacked = cur.packed;
-                asm volatile("" : "+v"(cpix), "+v"(cpacked));
+                if (!MANY) asm volatile("" : "+v"(cpix), "+v"(cpacked));   // (sphere-heavy variants: no register to spare for the copies)
                 pix = cpix;
                 packedCur = cpacked;
             }
@@ -1350,7 +1351,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
             if (ticketed && tid == (uint32_t)kCls) s_ticket[0] = 2u * gridDim.x + tk * (uint32_t)kTicketShards + blockIdx.x % kTicketShards;
             probe(23);                                          // (second barrier)
             __syncthreads();
-            if (!FIRST) Tn1 = ticketed ? s_ticket[0] : Tnext + gridDim.x;
+            if (kTickets) Tn1 = ticketed ? s_ticket[0] : Tnext + gridDim.x;
 #if defined(PT_EXP) && (PT_EXP & 2)      // experiment: one more workgroup barrier per tile
             asm volatile("" ::: "memory");
             __syncthreads();
@@ -1383,7 +1384,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : (DOF ? 5 : (MANY ? 7 : 8))) void
             wvSel ^= (uint32_t)(kWaves * kCls);
             if (lane < kCls) s_wave[wvSel + wave * kCls + lane] = 0u;
             __builtin_amdgcn_s_setprio(0);
-        } else if (!FIRST) {
+        } else if (kTickets) {
             Tn1 = Tnext + gridDim.x;
         }
         probe(20);                                              // (tile done)
