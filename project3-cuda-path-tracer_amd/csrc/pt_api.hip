@@ -1322,6 +1322,14 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
                 e.geom = i;
                 sc.push_back(e);
             }
+        // the K |oc|^2 term of the certificate folded into the sweep's direction (ptd::sphereHalfLineExcessScaled): one factor for the
+        // scene, from its largest K, and every threshold multiplied by its square -- both rounded upwards (the conservative side)
+        double kmax = 0.0;
+        for (const SphereCull &e : sc) kmax = std::max(kmax, (double)e.cullK);
+        const float sdir = std::nextafter((float)std::sqrt(1.0 / (1.0 - kmax)), INFINITY);
+        k.sphDirScale = sdir;
+        for (SphereCull &e : sc)
+            if (std::isfinite(e.cullR2)) e.cullR2 = std::nextafter((float)((double)e.cullR2 * (double)sdir * (double)sdir), INFINITY);
         if (sc.size() % 2) sc.push_back(sc.back());      // (two per scalar load; testing a sphere twice changes nothing)
         k.nSphCull = (int)sc.size();
         HIPCHECK(hipMalloc(&S.dSphCull, sc.size() * sizeof(SphereCull)));

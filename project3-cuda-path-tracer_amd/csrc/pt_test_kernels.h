@@ -177,8 +177,12 @@ __global__ void k_sweep_sphere_halfline(const GeomDev *geoms, int ngeoms, unsign
         }
         dir = dir * (u[8] < 0.5f ? 1.0f : (u[8] < 0.75f ? 0.999f + 0.002f * u[9] : __builtin_exp2f(4.0f * u[9] - 2.0f)));
         const float dd = dot(dir, dir);
-        const F3 dhat = unitDirection(dir, dd);
-        if (sphereHalfLineExcess(c, G.cullK + kUnitDirSlack, org, dhat) > G.cullR2) {
+        // the kernel's own form (round 4): the K |oc|^2 term folded into the direction, factor and threshold rounded upwards as pt_init does
+        const float K = G.cullK + kUnitDirSlack;
+        const float sdir = __uint_as_float(__float_as_uint(__builtin_sqrtf(1.0f / (1.0f - K)) * 1.0000002f) + 1u);     // (positive: one ulp up)
+        const float R2s = __uint_as_float(__float_as_uint(G.cullR2 * sdir * sdir * 1.0000002f) + 1u);
+        const F3 dhat = unitDirectionScaled(dir, dd, sdir);
+        if (sphereHalfLineExcessScaled(c, org, dhat) > R2s) {
             ++nc;
             if (dot(org - c, dhat) > 0.0f) ++nb;
             F3 P, N;

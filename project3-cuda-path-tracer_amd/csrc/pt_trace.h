@@ -124,6 +124,7 @@ struct KParams {
     int   nEmit;                       // emissive primitives the direct-lighting bounce samples, at most kEmitMax (file order)
     int   nCubes;                      // cubes of the scene (sphere-heavy scenes: rows of the LDS frame table)
     int   nSphCull;                    // sphere-heavy scenes: entries of BounceArgs::sphCull (even: padded with a copy of the last one)
+    float sphDirScale;                 // ... and the factor s >= 1 / sqrt(1 - K) on the sweep's unit direction (ptd::sphereHalfLineExcessScaled)
     int   meshStackOff;                // scenes with meshes: byte offset of the lanes' traversal stacks in the dynamic LDS ([levels][kBlock] words)
     int   classOff[kCls + 1];          // later bounces: the primitives a tile of class c has to look at are classIdx[classOff[c] ..
                                        // classOff[c + 1]) (BounceArgs::classIdx): not the binned ones unless the class says so, of the walls only
@@ -338,7 +339,7 @@ __device__ __forceinline__ uint32_t waveSum(uint32_t v) {
 // critical path of the loop over seventy of them).
 struct SphereCull {
     float centre[3];
-    float cullR2, cullK;
+    float cullR2, cullK;   // cullR2: the threshold of the SCALED certificate, rho^2 smax^2 (1 + 1e-3) s^2, rounded up (sphDirScale); cullK: as GeomDev's + slack
     int   geom;          // index of the sphere among the scene's primitives; -1: padding
     int   pad[2];
 };
@@ -972,7 +973,7 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
                 const int nS = A->prm.nSphCull;                       // (even: the host pads with a copy of the last sphere)
                 const PT_CAS SphereCull *sc = (const PT_CAS SphereCull *)(A->sphCull);
                 const uint16_t *const sphGeom = s_list;               // [nS]: the primitive behind entry k (prologue)
-                const F3 dhat = unitDirection(dir, dd);
+                const F3 dhat = unitDirectionScaled(dir, dd, A->prm.sphDirScale);
                 for (int base = 0; base < nS; base += 64) {           // (wave-uniform)
                     uint32_t mHi = 0u, mLo = 0u;                      // entry base + j: bit 31 - j of mHi (j < 32) / of mLo
                     if (inScene) {
@@ -985,8 +986,7 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
 #pragma unroll
                                 for (int h = 0; h < 2; ++h) {
                                     probe(3);
-                                    const float x = sphereHalfLineExcess(f3(__int_as_float(v[8 * h]), __int_as_float(v[8 * h + 1]), __int_as_float(v[8 * h + 2])),
-                                                                         __int_as_float(v[8 * h + 4]), org, dhat);
+                                    const float x = sphereHalfLineExcessScaled(f3(__int_as_float(v[8 * h]), __int_as_float(v[8 * h + 1]), __int_as_float(v[8 * h + 2])), org, dhat);
                                     // candidate = !(cullR2 < x) (NaN: candidate), shifted in from below
                                     asm("v_cmp_nlt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "s"(__int_as_float(v[8 * h + 3])), "v"(x) : "vcc");
                                 }
