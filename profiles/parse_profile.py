@@ -133,11 +133,29 @@ def main():
         cal["raygen_write_counted_bytes"] = sum(wr) / len(wr)
         cal["raygen_known_write_bytes"] = known
         cal["write_factor"] = known / (sum(wr) / len(wr))
+    # Round 4: the path pools are read with 16- and 12-byte-per-lane loads since round 3, a pattern the factor above
+    # was never calibrated on.  bench.py's box calibration runs the library's exclusive scan of 2^26 int32 in the SAME process: its
+    # k_scan_reduce launches read exactly 4 n bytes with 16-byte-per-lane loads (int4, pt_compaction.h) and write next to nothing, its
+    # k_scan_apply launches read 4 n and write 4 n -- launches of known traffic in the same --pmc pass.
+    n_scan = 4.0 * (1 << 26)
+    rd = [float(r["Counter_Value"]) * 1024.0 for r in load_pmc(os.path.join(src, "pmc_fetch"))
+          if "k_scan_reduce" in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE"]
+    wr16 = [float(r["Counter_Value"]) * 1024.0 for r in load_pmc(os.path.join(src, "pmc_write"))
+            if "k_scan_apply" in r["Kernel_Name"] and r["Counter_Name"] == "WRITE_SIZE"]
+    if rd:
+        cal["scan_reduce_fetch_counted_bytes"] = sum(rd) / len(rd)
+        cal["scan_reduce_known_read_bytes"] = n_scan
+        cal["read_factor_16B_per_lane_loads"] = n_scan / (sum(rd) / len(rd))
+        cal["scan_reduce_launches"] = len(rd)
+    if wr16:
+        cal["scan_apply_write_counted_bytes"] = sum(wr16) / len(wr16)
+        cal["scan_apply_known_write_bytes"] = n_scan
+        cal["write_factor_16B_per_lane_stores"] = n_scan / (sum(wr16) / len(wr16))
     out["calibration"] = cal
 
     kb = out.get("k_bounce", {}).get("pmc_per_dispatch", {})
     if "FETCH_SIZE" in kb and "WRITE_SIZE" in kb:
-        rf = cal.get("read_factor", 2.0)
+        rf = cal.get("read_factor_16B_per_lane_loads", cal.get("read_factor", 2.0))
         # snap to the two documented regimes (exact, or the 2x under-count of coalesced streams)
         rf_used = 2.0 if rf > 1.5 else 1.0
         traffic = kb["FETCH_SIZE"] * 1024.0 * rf_used + kb["WRITE_SIZE"] * 1024.0
@@ -188,7 +206,7 @@ def main():
             if pd.get("GRBM_GUI_ACTIVE") and "SQ_INSTS_VALU" in pd:
                 ii["valu_utilisation_counter_derived"] = pd["SQ_INSTS_VALU"] * 2.0 / (1024.0 * pd["GRBM_GUI_ACTIVE"] / 8.0)
             if "FETCH_SIZE" in pd and "WRITE_SIZE" in pd and ii.get("trace_avg_ns"):
-                ii["hbm_bytes_per_launch"] = pd["FETCH_SIZE"] * 2048.0 + pd["WRITE_SIZE"] * 1024.0
+                ii["hbm_bytes_per_launch"] = pd["FETCH_SIZE"] * 1024.0 * out.get("k_bounce", {}).get("read_factor_used", 2.0) + pd["WRITE_SIZE"] * 1024.0
                 ii["hbm_fraction_of_8TBs"] = ii["hbm_bytes_per_launch"] / (ii["trace_avg_ns"] * 1e-9) / 8e12
     # the bench line of the profiled command (trace pass), for the record
     try:

@@ -114,6 +114,7 @@ struct State {
     int gridFirst = 0;      // ... and of k_bounce<true> (its own register budget, hence its own residency)
     bool many = false;      // more than kBinMax spheres: the k_bounce<., true> variants (per-lane sphere lists)
     bool dof = false;       // thin-lens camera: the k_bounce<true, ., true> variants for the camera-ray bounce
+    bool plain = false;     // no refractive material, no specular exponent on a reflective one, no direct lighting: k_bounce<..., PLAIN>
     size_t ldsBytes = 0;
     long long iterations = 0;
     long long seq = 0;      // batches enqueued since pt_init: slot = seq % nslots
@@ -673,9 +674,11 @@ int resolve_events(std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, double &ms
 
 // The instantiation of k_bounce a launch takes: FIRST (camera rays), MANY (per-lane sphere lists: scenes with more than
 // kBinMax spheres), DOF (thin lens: the camera-ray launch only), MESH (scenes with triangle meshes).
-template <bool F, bool M, bool D, bool ME>
-const void *kb() { return reinterpret_cast<const void *>(k_bounce<F, M, D, ME>); }
+template <bool F, bool M, bool D, bool ME, bool PL = false>
+const void *kb() { return reinterpret_cast<const void *>(k_bounce<F, M, D, ME, PL>); }
 const void *bounce_kernel(bool first, bool dof) {
+    // (plain scenes -- diffuse / emissive / perfect-mirror materials, no README extra: the instantiations without the rarer branches)
+    if (S.plain && !S.mesh && !S.many && !dof) return first ? kb<true, false, false, false, true>() : kb<false, false, false, false, true>();
     if (S.mesh && S.many) return first ? (dof ? kb<true, true, true, true>() : kb<true, true, false, true>()) : kb<false, true, false, true>();
     if (S.mesh) return first ? (dof ? kb<true, false, true, true>() : kb<true, false, false, true>()) : kb<false, false, false, true>();
     if (first && dof) return S.many ? kb<true, true, true, false>() : kb<true, false, true, false>();
@@ -1077,6 +1080,10 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
         k.viewN[0] = vn.x; k.viewN[1] = vn.y; k.viewN[2] = vn.z;
     }
     S.dof = o.lens_radius > 0.0f;
+    // plain: nothing in the scene takes the scatter's rarer branches (PT_AMD_NO_PLAIN: experiments / tests only)
+    S.plain = !direct && !(getenv("PT_AMD_NO_PLAIN") && atoi(getenv("PT_AMD_NO_PLAIN")));
+    for (int i = 0; i < nmats; ++i)
+        if (mats[i].hasRefractive > 0.0f || (mats[i].hasReflective > 0.0f && mats[i].specularExponent > 0.0f)) S.plain = false;
 
     if (o.accum_dev) {
         S.image = o.accum_dev;

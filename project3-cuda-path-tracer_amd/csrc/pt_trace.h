@@ -427,7 +427,10 @@ static_assert(sizeof(CullGroup) == 32 && offsetof(GeomDev, cullFlags) - offsetof
 
 // DOF (with FIRST only): camera rays start on a thin lens (README.md:100-101), so they share no origin (no precomputed
 // object-space camera position) and the pixel rectangles, which project the primitives through a pinhole, are not used.
-template <bool FIRST, bool MANY, bool DOF = false, bool MESH = false>
+// PLAIN: the scene's materials are diffuse, emissive or 50/50 perfect mirrors only and no README extra is on -- no refraction, no
+// specular lobe, no direct lighting: their code (a third of the scatter's static instructions: Schlick + refract, the lobe's pow, the
+// emitter pick) is not even compiled in.  Same results (the branches are never taken in such a scene); pt_init picks the instantiation.
+template <bool FIRST, bool MANY, bool DOF = false, bool MESH = false, bool PLAIN = false>
 __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF ? 5 : (MANY ? 7 : 8))) void k_bounce(BounceArgs argsByValue) {
     static_assert(FIRST || !DOF, "the lens only concerns the camera-ray bounce");
     (void)argsByValue;
@@ -1105,7 +1108,7 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
                     const F3 scol = f3(M.specColor[0], M.specColor[1], M.specColor[2]);
                     F3 ndir = dir, norg;
                     bool diffuse = false;                        // the hemisphere is sampled at one place, after the branches
-                    if (mRefr > 0.0f) {
+                    if (!PLAIN && mRefr > 0.0f) {
                         const float eta = outside ? M.invIor : M.ior;
                         const float c = dot(N, dir);
                         const float k = 1.0f - eta * eta * (1.0f - c * c);
@@ -1133,7 +1136,7 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
                         const float u = u01(rng);
                         if (u < 0.5f) {
                             ndir = reflect(dir, N);
-                            if (M.invSpecExp1 > 0.0f) ndir = specularLobeDirection(ndir, N, M.invSpecExp1, rng);   // SPECEX > 0
+                            if (!PLAIN && M.invSpecExp1 > 0.0f) ndir = specularLobeDirection(ndir, N, M.invSpecExp1, rng);   // SPECEX > 0
                             col = col * scol;
                         } else {
                             diffuse = true;
@@ -1149,7 +1152,7 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
                         // chosen point of the (transformed) unit cube of a uniformly chosen emissive primitive, weighted by the
                         // cosine at the surface; the launch after this one collects what it hits
                         const ArgsPtr A = launder(kargs);
-                        toLight = (hotNow() & kHotToLight) != 0u;
+                        toLight = !PLAIN && (hotNow() & kHotToLight) != 0u;
                         if (toLight) {
                             const int ne = A->prm.nEmit;
                             int pick = (int)(u01(rng) * (float)ne);
