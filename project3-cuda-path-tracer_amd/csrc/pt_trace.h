@@ -998,6 +998,15 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
                         };
                         sweep32(base, mHi);
                         sweep32(base + 32, mLo);
+#if defined(PT_EXP) && (PT_EXP & 128)    // experiment: what does the sweep cost?  (run it twice; the masks are the same)
+                        {
+                            uint32_t xHi = 0u, xLo = 0u;
+                            asm volatile("" : "+v"(org.x));
+                            sweep32(base, xHi);
+                            sweep32(base + 32, xLo);
+                            mHi |= xHi; mLo |= xLo;
+                        }
+#endif
                     }
                     // pass k tests every lane's k-th candidate with that lane's own matrices from LDS
                     while (__ballot((mHi | mLo) != 0u) != 0ull) {     // wave-uniform trip count
