@@ -152,6 +152,15 @@ typedef struct PtMesh {
     int32_t geom;           /* index into pt_init's geoms */
     int32_t ntris;
     const float *tris;      /* ntris x 9 floats, finite */
+    /* README.md:112-116 leftovers (round 4), both optional:
+     *   normals    ntris x 9 floats: the vertex normals n0, n1, n2 of every triangle, object space (an OBJ's `vn`).  The shading normal
+     *              of a hit is then the barycentric blend n0 (1 - u - v) + n1 u + n2 v with the hit's own (u, v), turned to the side the
+     *              counter-clockwise face normal points to and normalised (a blend of length zero keeps the face normal); everything
+     *              else -- which side is "outside", the hit point, the invTranspose map to world space -- as for flat shading.
+     *   materials  ntris scene materials, one per face (an OBJ's `usemtl <k>`); -1 = the object's own.  pt_init fails with
+     *              PT_ERR_INVALID on an id >= nmats. */
+    const float *normals;   /* or NULL: flat shading */
+    const int32_t *materials;   /* or NULL: every face takes the object's material */
 } PtMesh;
 int pt_set_meshes(const PtMesh *meshes, int nmeshes);
 

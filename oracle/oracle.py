@@ -91,6 +91,13 @@ def lib():
         L.orc_scene_mesh_tris.argtypes = [C.c_void_p, C.c_int]
         L.orc_scene_mesh_tris.restype = C.c_void_p
         L.orc_render_set_mesh.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.orc_render_set_mesh_attributes.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        for name in ("orc_scene_mesh_normals", "orc_scene_mesh_materials"):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_int]
+            getattr(L, name).restype = C.c_void_p
+        L.orc_mesh_intersect_attr.restype = C.c_float
+        L.orc_mesh_intersect_attr.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.orc_mesh_intersect.restype = C.c_float
         L.orc_mesh_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -213,15 +220,20 @@ def intersect(geom, ray6, sphere=None):
     return np.float32(t), p, n, int(o.value)
 
 
-def mesh_intersect(geom, tris, ray6):
-    """One ray against one mesh geom (tris: n x 9 floats, object space), brute force over every triangle.
-    Returns (t, p, n, outside, triangle); p, n, outside keep their sentinels on a miss, triangle = -1."""
+def mesh_intersect(geom, tris, ray6, normals=None):
+    """One ray against one mesh geom (tris: n x 9 floats, object space), brute force over every triangle.  `normals`: n x 9 vertex
+    normals (smooth shading) or None (flat).  Returns (t, p, n, outside, triangle); p, n, outside keep their sentinels on a miss,
+    triangle = -1."""
     g = np.ascontiguousarray(geom).reshape(-1)[:1]
     tr = np.ascontiguousarray(tris, np.float32).reshape(-1, 9)
     p = np.full(3, -7.0, np.float32)
     n = np.full(3, -7.0, np.float32)
     o, k = C.c_int(1), C.c_int(-1)
-    t = lib().orc_mesh_intersect(_p(g), _p(tr), len(tr), _p(f32(*ray6)), _p(p), _p(n), C.byref(o), C.byref(k))
+    if normals is None:
+        t = lib().orc_mesh_intersect(_p(g), _p(tr), len(tr), _p(f32(*ray6)), _p(p), _p(n), C.byref(o), C.byref(k))
+    else:
+        nn = np.ascontiguousarray(normals, np.float32).reshape(len(tr), 9)
+        t = lib().orc_mesh_intersect_attr(_p(g), _p(tr), len(tr), _p(nn), _p(f32(*ray6)), _p(p), _p(n), C.byref(o), C.byref(k))
     return np.float32(t), p, n, int(o.value), int(k.value)
 
 
@@ -261,10 +273,17 @@ class Scene:
         self.depth = L.orc_scene_depth(h)
         self.image_name = L.orc_scene_image_name(h).decode()
         self.meshes = {}            # geom index -> (ntris, 9) float32, object space
+        self.mesh_normals = {}      # geom index -> (ntris, 9) float32 vertex normals (`vn`); absent: flat shading
+        self.mesh_materials = {}    # geom index -> (ntris,) int32 scene material per face (`usemtl <k>`, -1 = the object's); absent: none
         for i in range(L.orc_scene_num_meshes(h)):
             nt = L.orc_scene_mesh_ntris(h, i)
-            self.meshes[L.orc_scene_mesh_geom(h, i)] = np.frombuffer(
-                C.string_at(L.orc_scene_mesh_tris(h, i), 36 * nt), np.float32).reshape(nt, 9).copy()
+            g = L.orc_scene_mesh_geom(h, i)
+            self.meshes[g] = np.frombuffer(C.string_at(L.orc_scene_mesh_tris(h, i), 36 * nt), np.float32).reshape(nt, 9).copy()
+            nptr, mptr = L.orc_scene_mesh_normals(h, i), L.orc_scene_mesh_materials(h, i)
+            if nptr:
+                self.mesh_normals[g] = np.frombuffer(C.string_at(nptr, 36 * nt), np.float32).reshape(nt, 9).copy()
+            if mptr:
+                self.mesh_materials[g] = np.frombuffer(C.string_at(mptr, 4 * nt), np.int32).copy()
         L.orc_scene_free(h)
 
     def set_resolution(self, w, h):
@@ -272,7 +291,7 @@ class Scene:
 
 
 class Renderer:
-    def __init__(self, camera, geoms, materials, depth, meshes=None):
+    def __init__(self, camera, geoms, materials, depth, meshes=None, mesh_normals=None, mesh_materials=None):
         self.camera = np.ascontiguousarray(camera).copy()
         self.geoms = np.ascontiguousarray(geoms)
         self.materials = np.ascontiguousarray(materials)
@@ -283,6 +302,12 @@ class Renderer:
         for g, tris in (meshes or {}).items():
             tr = np.ascontiguousarray(tris, np.float32).reshape(-1, 9)
             lib().orc_render_set_mesh(self.h, int(g), _p(tr), len(tr))
+            nn = (mesh_normals or {}).get(g)
+            mm = (mesh_materials or {}).get(g)
+            if nn is not None or mm is not None:
+                nn = None if nn is None else np.ascontiguousarray(nn, np.float32).reshape(len(tr), 9)
+                mm = None if mm is None else np.ascontiguousarray(mm, np.int32).reshape(len(tr))
+                lib().orc_render_set_mesh_attributes(self.h, int(g), None if nn is None else _p(nn), None if mm is None else _p(mm))
 
     def __del__(self):
         if getattr(self, "h", None):

@@ -500,6 +500,9 @@ struct OMesh {
     int geom;
     std::vector<float> tris;    /* 9 floats per triangle: v0, v1, v2 */
     float margin;
+    /* README.md:112-116 leftovers, build-defined (include/pt_amd.h states the semantics): */
+    std::vector<float> normals; /* 9 floats per triangle: the vertex normals n0, n1, n2 (object space) -- or EMPTY: flat shading */
+    std::vector<int> mats;      /* one per triangle: the scene material of that face, -1 = the object's own -- or EMPTY */
 };
 
 float mesh_margin(const float *tris, int ntris) {
@@ -561,7 +564,7 @@ bool mesh_triangle(V3 o, V3 d, V3 v0, V3 e1, V3 e2, float &t, bool &front, float
 }
 
 float mesh_intersection_test(const OGeom &g, const OMesh &mesh, const Ray &r, V3 &intersectionPoint, V3 &normal,
-                             bool &outside, int *triOut = NULL) {
+                             bool &outside, int *triOut = NULL, int *matOut = NULL) {
     M4 inv = m4_from(g.inverseTransform);
     M4 xf = m4_from(g.transform);
     M4 invT = m4_from(g.invTranspose);
@@ -594,10 +597,25 @@ float mesh_intersection_test(const OGeom &g, const OMesh &mesh, const Ray &r, V3
     }
     if (triOut) *triOut = best;
     if (best < 0) return -1;
+    if (matOut) *matOut = mesh.mats.empty() ? -1 : mesh.mats[(size_t)best];
     const float *tv = &mesh.tris[9 * (size_t)best];
     V3 v0 = v3(tv[0], tv[1], tv[2]);
     V3 e1 = sub(v3(tv[3], tv[4], tv[5]), v0), e2 = sub(v3(tv[6], tv[7], tv[8]), v0);
-    V3 nobj = normalize3(cross3(e1, e2));
+    V3 nface = cross3(e1, e2);
+    V3 nobj = normalize3(nface);
+    if (!mesh.normals.empty()) {
+        /* vertex normals (`vn`): the object-space normal is the barycentric blend n0 (1 - u - v) + n1 u + n2 v of the triangle's three,
+         * (u, v) from the very triangle test that found the hit (evaluated once more for the winner: same operands, same bits); turned
+         * to the side the counter-clockwise face normal points to; a blend of length zero (or NaN) keeps the face normal */
+        float t2, uv[2] = {0.0f, 0.0f};
+        bool f2;
+        (void)mesh_triangle(rt.origin, rt.direction, v0, e1, e2, t2, f2, uv);
+        const float *nn = &mesh.normals[9 * (size_t)best];
+        float w = (1.0f - uv[0]) - uv[1];
+        V3 ns = add(add(muls(v3(nn[0], nn[1], nn[2]), w), muls(v3(nn[3], nn[4], nn[5]), uv[0])), muls(v3(nn[6], nn[7], nn[8]), uv[1]));
+        if (dot3(ns, nface) < 0.0f) ns = neg(ns);
+        if (dot3(ns, ns) > 0.0f) nobj = normalize3(ns);
+    }
     V3 obj = get_point_on_ray(rt, tbest);
     intersectionPoint = multiplyMV(xf, v4(obj.x, obj.y, obj.z, 1.f));
     normal = normalize3(multiplyMV(invT, v4(nobj.x, nobj.y, nobj.z, 0.f)));
@@ -608,21 +626,35 @@ float mesh_intersection_test(const OGeom &g, const OMesh &mesh, const Ray &r, V3
 
 /* Wavefront OBJ: `v x y z` and `f a b c ...` (a = i, i/j, i//k or i/j/k; 1-based, negative = relative to the vertices read
  * so far); polygons are fanned from their first vertex; everything else is ignored.  false when the file cannot be read. */
-bool load_obj(const std::string &path, std::vector<float> &tris) {
+bool load_obj(const std::string &path, std::vector<float> &tris, std::vector<float> *normalsOut = NULL, std::vector<int> *matsOut = NULL) {
     std::ifstream fp(path.c_str());
     if (!fp.is_open()) return false;
-    std::vector<float> verts;
+    std::vector<float> verts, vnorm;
+    std::vector<float> normals;         /* 9 per triangle; allNormals says whether every corner of every face named one */
+    std::vector<int> mats;
+    bool allNormals = true, anyMat = false;
+    int curMat = -1;
     std::string line;
     while (std::getline(fp, line)) {
         std::istringstream ss(line);
         std::string key;
         if (!(ss >> key)) continue;
-        if (key == "v") {
+        if (key == "v" || key == "vn") {
             double x = 0, y = 0, z = 0;
             ss >> x >> y >> z;
-            verts.push_back((float)x); verts.push_back((float)y); verts.push_back((float)z);
+            std::vector<float> &dst = key == "v" ? verts : vnorm;
+            dst.push_back((float)x); dst.push_back((float)y); dst.push_back((float)z);
+        } else if (key == "usemtl") {
+            /* `usemtl <k>`: the faces that follow take scene material k (an integer; anything else: back to the object's material) */
+            std::string tok;
+            curMat = -1;
+            if (ss >> tok) {
+                char *end = NULL;
+                long k = strtol(tok.c_str(), &end, 10);
+                if (end && *end == 0 && k >= 0 && k < 1000000) curMat = (int)k;
+            }
         } else if (key == "f") {
-            std::vector<int> idx;
+            std::vector<int> idx, nidx;
             std::string tok;
             while (ss >> tok) {
                 int i = atoi(tok.c_str());      /* stops at the first '/' */
@@ -630,14 +662,34 @@ bool load_obj(const std::string &path, std::vector<float> &tris) {
                 int k = i > 0 ? i - 1 : nv + i;
                 if (i == 0 || k < 0 || k >= nv) { idx.clear(); break; }
                 idx.push_back(k);
+                /* the normal index: the field behind the second '/' (i//k or i/j/k) */
+                int nk = -1;
+                size_t s1 = tok.find('/');
+                size_t s2 = s1 == std::string::npos ? std::string::npos : tok.find('/', s1 + 1);
+                if (s2 != std::string::npos && s2 + 1 < tok.size()) {
+                    int j = atoi(tok.c_str() + s2 + 1);
+                    int nn = (int)(vnorm.size() / 3);
+                    int q = j > 0 ? j - 1 : nn + j;
+                    if (j != 0 && q >= 0 && q < nn) nk = q;
+                }
+                nidx.push_back(nk);
             }
             for (size_t k = 2; k < idx.size(); ++k) {
                 const int tri[3] = {idx[0], idx[k - 1], idx[k]};
+                const int ntri[3] = {nidx[0], nidx[k - 1], nidx[k]};
                 for (int c = 0; c < 3; ++c)
-                    for (int a = 0; a < 3; ++a) tris.push_back(verts[3 * (size_t)tri[c] + a]);
+                    for (int a = 0; a < 3; ++a) {
+                        tris.push_back(verts[3 * (size_t)tri[c] + a]);
+                        normals.push_back(ntri[c] >= 0 ? vnorm[3 * (size_t)ntri[c] + a] : 0.0f);
+                    }
+                if (ntri[0] < 0 || ntri[1] < 0 || ntri[2] < 0) allNormals = false;
+                mats.push_back(curMat);
+                if (curMat >= 0) anyMat = true;
             }
         }
     }
+    if (normalsOut) { if (allNormals && !tris.empty()) *normalsOut = normals; else normalsOut->clear(); }
+    if (matsOut) { if (anyMat) *matsOut = mats; else matsOut->clear(); }
     return true;
 }
 
@@ -848,7 +900,7 @@ void load_geom(OScene &sc, std::ifstream &fp, const std::string &idtok) {
                 OMesh m;
                 m.geom = id;
                 std::string path = t[1][0] == '/' ? t[1] : sc.dir + t[1];
-                if (load_obj(path, m.tris) && !m.tris.empty()) {
+                if (load_obj(path, m.tris, &m.normals, &m.mats) && !m.tris.empty()) {
                     m.margin = mesh_margin(m.tris.data(), (int)(m.tris.size() / 9));
                     sc.meshes.push_back(m);
                     g.type = 2;
@@ -879,16 +931,18 @@ void load_geom(OScene &sc, std::ifstream &fp, const std::string &idtok) {
 }
 
 /* Nearest hit over all geoms in file order (spec S3).  Returns geom index or -1. */
-int nearest_hit(const ORender &R, const Ray &ray, V3 &p, V3 &n, bool &outside) {
+int nearest_hit(const ORender &R, const Ray &ray, V3 &p, V3 &n, bool &outside, int *faceMat = NULL) {
     float t_min = 0;
     int hit = -1;
+    if (faceMat) *faceMat = -1;
     for (int i = 0; i < (int)R.geoms.size(); ++i) {
         V3 tp = v3(0, 0, 0), tn = v3(0, 0, 0);
         bool to = false;
         float t;
+        int fm = -1;
         if (R.geoms[i].type == 2) {
             /* a mesh geom without triangle data is never hit */
-            t = i < (int)R.meshOf.size() && R.meshOf[i] >= 0 ? mesh_intersection_test(R.geoms[i], R.meshes[R.meshOf[i]], ray, tp, tn, to) : -1.0f;
+            t = i < (int)R.meshOf.size() && R.meshOf[i] >= 0 ? mesh_intersection_test(R.geoms[i], R.meshes[R.meshOf[i]], ray, tp, tn, to, NULL, &fm) : -1.0f;
         } else {
             t = R.geoms[i].type == 0 ? sphere_intersection_test(R.geoms[i], ray, tp, tn, to)
                                      : box_intersection_test(R.geoms[i], ray, tp, tn, to);
@@ -899,6 +953,7 @@ int nearest_hit(const ORender &R, const Ray &ray, V3 &p, V3 &n, bool &outside) {
             p = tp;
             n = tn;
             outside = to;
+            if (faceMat) *faceMat = fm;
         }
     }
     return hit;
@@ -963,9 +1018,11 @@ static void scatter_to_light(const ORender &R, V3 n, V3 norg, V3 mcol, uint32_t 
 Fate bounce(const ORender &R, int iter, int index, int depth, Ray &ray, V3 &color, V3 &contrib, bool direct = false) {
     V3 p = v3(0, 0, 0), n = v3(0, 0, 0);
     bool outside = false;
-    int g = nearest_hit(R, ray, p, n, outside);
+    int faceMat = -1;
+    int g = nearest_hit(R, ray, p, n, outside, &faceMat);
     if (g < 0) return MISS;
-    const OMaterial &m = R.mats[R.geoms[g].materialid];
+    /* (a mesh face with a material of its own, `usemtl`; ids beyond the scene's materials fall back to the object's) */
+    const OMaterial &m = R.mats[faceMat >= 0 && faceMat < (int)R.mats.size() ? faceMat : R.geoms[g].materialid];
     V3 mcol = from(m.color);
     if (m.emittance > 0.0f) {
         contrib = R.emitColorMode == 1 ? muls(color, m.emittance) : muls(mul(color, mcol), m.emittance);
@@ -1157,6 +1214,8 @@ int orc_scene_num_meshes(const OScene *s) { return (int)s->meshes.size(); }
 int orc_scene_mesh_geom(const OScene *s, int i) { return s->meshes[i].geom; }
 int orc_scene_mesh_ntris(const OScene *s, int i) { return (int)(s->meshes[i].tris.size() / 9); }
 const float *orc_scene_mesh_tris(const OScene *s, int i) { return s->meshes[i].tris.data(); }
+const float *orc_scene_mesh_normals(const OScene *s, int i) { return s->meshes[i].normals.empty() ? NULL : s->meshes[i].normals.data(); }
+const int *orc_scene_mesh_materials(const OScene *s, int i) { return s->meshes[i].mats.empty() ? NULL : s->meshes[i].mats.data(); }
 void orc_camera_set_resolution(OCamera *cam, int w, int h) {
     cam->resX = w;
     cam->resY = h;
@@ -1200,6 +1259,14 @@ void orc_render_set_mesh(ORender *R, int geom, const float *tris, int ntris) {
     R->meshOf[geom] = (int)R->meshes.size();
     R->meshes.push_back(m);
 }
+/* vertex normals (ntris x 9, or NULL: flat) and face materials (ntris, or NULL: the object's) of a mesh set before */
+void orc_render_set_mesh_attributes(ORender *R, int geom, const float *normals, const int *mats) {
+    if (geom < 0 || geom >= (int)R->meshOf.size() || R->meshOf[geom] < 0) return;
+    OMesh &m = R->meshes[(size_t)R->meshOf[geom]];
+    const size_t nt = m.tris.size() / 9;
+    if (normals) m.normals.assign(normals, normals + 9 * nt); else m.normals.clear();
+    if (mats) m.mats.assign(mats, mats + nt); else m.mats.clear();
+}
 float orc_mesh_margin(const float *tris, int ntris) { return mesh_margin(tris, ntris); }
 /* the two-sided triangle test alone: returns hit; tuv = (t, u, v) as far as they were evaluated (glm's baryPosition is (u, v, t)) */
 int orc_mesh_triangle(const float o[3], const float d[3], const float v0[3], const float v1[3], const float v2[3], float tuv[3],
@@ -1212,6 +1279,24 @@ int orc_mesh_triangle(const float o[3], const float d[3], const float v0[3], con
     tuv[0] = t;
     *front = f ? 1 : 0;
     return hit ? 1 : 0;
+}
+float orc_mesh_intersect_attr(const OGeom *g, const float *tris, int ntris, const float *normals, const float ray[6], float p[3], float n[3],
+                              int *outside, int *tri) {
+    OMesh m;
+    m.geom = 0;
+    m.tris.assign(tris, tris + 9 * (size_t)ntris);
+    m.margin = mesh_margin(tris, ntris);
+    if (normals) m.normals.assign(normals, normals + 9 * (size_t)ntris);
+    Ray r;
+    r.origin = v3(ray[0], ray[1], ray[2]);
+    r.direction = v3(ray[3], ray[4], ray[5]);
+    V3 tp = v3(p[0], p[1], p[2]), tn = v3(n[0], n[1], n[2]);
+    bool to = *outside != 0;
+    float t = mesh_intersection_test(*g, m, r, tp, tn, to, tri);
+    p[0] = tp.x; p[1] = tp.y; p[2] = tp.z;
+    n[0] = tn.x; n[1] = tn.y; n[2] = tn.z;
+    *outside = to ? 1 : 0;
+    return t;
 }
 float orc_mesh_intersect(const OGeom *g, const float *tris, int ntris, const float ray[6], float p[3], float n[3], int *outside,
                          int *tri) {

@@ -100,6 +100,8 @@ int     orc_scene_num_meshes(const OScene *);
 int     orc_scene_mesh_geom(const OScene *, int i);
 int     orc_scene_mesh_ntris(const OScene *, int i);
 const float *orc_scene_mesh_tris(const OScene *, int i);
+const float *orc_scene_mesh_normals(const OScene *, int i);      /* ntris x 9 vertex normals (`vn`), or NULL: flat shading */
+const int   *orc_scene_mesh_materials(const OScene *, int i);    /* ntris scene materials (`usemtl <k>`; -1 = the object's), or NULL */
 /* RES override: recomputes fov.x exactly as scene.cpp:133-136 does */
 void    orc_camera_set_resolution(OCamera *cam, int w, int h);
 
@@ -114,6 +116,9 @@ void     orc_render_free(ORender *);
 void     orc_render_set_extras(ORender *, float lensRadius, float focalDistance, int directLighting);
 /* triangles of a geom of type 2 (a mesh geom without triangles is never hit) */
 void     orc_render_set_mesh(ORender *, int geom, const float *tris, int ntris);
+void     orc_render_set_mesh_attributes(ORender *, int geom, const float *normals /* ntris x 9 or NULL */, const int *mats /* ntris or NULL */);
+float    orc_mesh_intersect_attr(const OGeom *g, const float *tris, int ntris, const float *normals, const float ray[6], float p[3],
+                                 float n[3], int *outside, int *tri);
 /* one ray against one mesh: brute force over every triangle (the semantics; see pt_oracle.cpp).  *tri = winning triangle or -1;
  * outputs keep their input values on a miss */
 float    orc_mesh_intersect(const OGeom *g, const float *tris, int ntris, const float ray[6], float p[3], float n[3],

@@ -71,7 +71,7 @@ class PtOptions(C.Structure):
 
 
 class PtMesh(C.Structure):
-    _fields_ = [("geom", C.c_int32), ("ntris", C.c_int32), ("tris", C.c_void_p)]
+    _fields_ = [("geom", C.c_int32), ("ntris", C.c_int32), ("tris", C.c_void_p), ("normals", C.c_void_p), ("materials", C.c_void_p)]
 
 
 class PtCounters(C.Structure):
@@ -227,6 +227,9 @@ def host_lib():
             getattr(H, n).argtypes = [vp, C.c_int]
         H.pth_scene_mesh_tris.argtypes = [vp, C.c_int]
         H.pth_scene_mesh_tris.restype = vp
+        for n in ("pth_scene_mesh_normals", "pth_scene_mesh_materials"):
+            getattr(H, n).argtypes = [vp, C.c_int]
+            getattr(H, n).restype = vp
         for n in ("pth_save_png", "pth_save_hdr"):
             getattr(H, n).argtypes = [C.c_char_p, vp, C.c_int, C.c_int, C.c_float]
             getattr(H, n).restype = C.c_int
@@ -258,10 +261,17 @@ class Scene:
         self.imageName = H.pth_scene_image_name(h).decode()
         # `mesh <file.obj>` objects (README.md:236): geom index -> (ntris, 9) float32 triangles in object space
         self.meshes = {}
+        self.mesh_normals = {}      # geom index -> (ntris, 9) vertex normals (`vn`); absent: flat shading
+        self.mesh_materials = {}    # geom index -> (ntris,) int32 scene material per face (`usemtl <k>`, -1 = the object's); absent: none
         for i in range(H.pth_scene_num_meshes(h)):
             nt = H.pth_scene_mesh_ntris(h, i)
-            self.meshes[H.pth_scene_mesh_geom(h, i)] = np.frombuffer(
-                C.string_at(H.pth_scene_mesh_tris(h, i), 36 * nt), np.float32).reshape(nt, 9).copy()
+            g = H.pth_scene_mesh_geom(h, i)
+            self.meshes[g] = np.frombuffer(C.string_at(H.pth_scene_mesh_tris(h, i), 36 * nt), np.float32).reshape(nt, 9).copy()
+            nptr, mptr = H.pth_scene_mesh_normals(h, i), H.pth_scene_mesh_materials(h, i)
+            if nptr:
+                self.mesh_normals[g] = np.frombuffer(C.string_at(nptr, 36 * nt), np.float32).reshape(nt, 9).copy()
+            if mptr:
+                self.mesh_materials[g] = np.frombuffer(C.string_at(mptr, 4 * nt), np.int32).copy()
         w, hh = (int(v) for v in self.camera["resolution"][0])
         self.image = np.zeros((hh, w, 3), np.float32)   # RenderState::image (src/sceneStructs.h:53)
 
@@ -297,7 +307,7 @@ def pathtraceInit(scene, shard_rank=0, shard_count=1, stream=0, accum_dev=0, dev
     mats = np.ascontiguousarray(scene.materials)
     cam = np.ascontiguousarray(scene.camera)
     depth = scene.traceDepth if traceDepth is None else traceDepth
-    set_meshes(getattr(scene, "meshes", None) or {})
+    set_meshes(getattr(scene, "meshes", None) or {}, getattr(scene, "mesh_normals", None), getattr(scene, "mesh_materials", None))
     global _atexit_registered
     if not _atexit_registered:
         # an interpreter that exits with a live renderer (an exception between pathtrace and pathtraceFree): drain the streams
@@ -310,12 +320,19 @@ def pathtraceInit(scene, shard_rank=0, shard_count=1, stream=0, accum_dev=0, dev
     _scene = scene
 
 
-def set_meshes(meshes):
-    """pt_set_meshes: {geom index: (ntris, 9) triangles in object space} for the next pathtraceInit (an empty dict clears)."""
+def set_meshes(meshes, normals=None, materials=None):
+    """pt_set_meshes: {geom index: (ntris, 9) triangles in object space} for the next pathtraceInit (an empty dict clears); optionally
+    {geom index: (ntris, 9) vertex normals} and {geom index: (ntris,) int32 face materials}."""
     keep = [(int(g), np.ascontiguousarray(t, np.float32).reshape(-1, 9)) for g, t in sorted(meshes.items())]
+    extra = []                                       # (keeps the attribute arrays alive across the call)
     arr = (PtMesh * max(len(keep), 1))()
     for i, (g, t) in enumerate(keep):
-        arr[i] = PtMesh(g, len(t), t.ctypes.data)
+        nn = (normals or {}).get(g)
+        mm = (materials or {}).get(g)
+        nn = None if nn is None else np.ascontiguousarray(nn, np.float32).reshape(len(t), 9)
+        mm = None if mm is None else np.ascontiguousarray(mm, np.int32).reshape(len(t))
+        extra += [nn, mm]
+        arr[i] = PtMesh(g, len(t), t.ctypes.data, None if nn is None else nn.ctypes.data, None if mm is None else mm.ctypes.data)
     _check(lib().pt_set_meshes(arr, len(keep)))
 
 

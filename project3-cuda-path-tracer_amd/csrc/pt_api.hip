@@ -980,12 +980,17 @@ int pt_set_meshes(const PtMesh *meshes, int nmeshes) {
             if (meshes[j].geom == meshes[i].geom) return fail(PT_ERR_INVALID, "pt_set_meshes: geom %d given twice", meshes[i].geom);
         for (size_t q = 0; q < 9 * (size_t)meshes[i].ntris; ++q)
             if (!std::isfinite(meshes[i].tris[q])) return fail(PT_ERR_INVALID, "pt_set_meshes: mesh %d holds a non-finite coordinate", i);
+        if (meshes[i].normals)
+            for (size_t q = 0; q < 9 * (size_t)meshes[i].ntris; ++q)
+                if (!std::isfinite(meshes[i].normals[q])) return fail(PT_ERR_INVALID, "pt_set_meshes: mesh %d holds a non-finite normal", i);
     }
     g_meshes.clear();
     for (int i = 0; i < nmeshes; ++i) {
         ptm::HostMesh m;
         m.geom = meshes[i].geom;
         m.tris.assign(meshes[i].tris, meshes[i].tris + 9 * (size_t)meshes[i].ntris);
+        if (meshes[i].normals) m.normals.assign(meshes[i].normals, meshes[i].normals + 9 * (size_t)meshes[i].ntris);
+        if (meshes[i].materials) m.mats.assign(meshes[i].materials, meshes[i].materials + (size_t)meshes[i].ntris);
         g_meshes.push_back(std::move(m));
     }
     return PT_OK;
@@ -1171,7 +1176,10 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
         uint32_t root = ptd::kMeshEnd, stride = 0;
         if (isMesh) {
             const ptm::HostMesh *hm_ = mesh_of(i);
-            const ptm::MeshLayout lay = ptm::appendMesh(hm_->tris.data(), (int)(hm_->tris.size() / 9), flatMeshes, meshRecs, box);
+            for (int fm : hm_->mats)
+                if (fm >= nmats) return fail(PT_ERR_INVALID, "pt_init: a face of mesh geom %d names material %d of %d", i, fm, nmats);
+            const ptm::MeshLayout lay = ptm::appendMesh(hm_->tris.data(), (int)(hm_->tris.size() / 9), flatMeshes, meshRecs, box,
+                                                        hm_->normals.empty() ? nullptr : hm_->normals.data(), hm_->mats.empty() ? nullptr : hm_->mats.data());
             root = lay.root;
             stride = lay.stride;
             meshStackNeed = std::max(meshStackNeed, lay.stackNeed);
@@ -1280,8 +1288,13 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
             if (!hg[i].binned && (hg[i].flags & 28) == 0) k.allClassified = 0;
     }
     k.emittersBinned = k.nBinned > 0 ? 1 : 0;
-    for (int i = 0; i < ngeoms; ++i)
-        if (mats[geoms[i].materialid].emittance > 0.0f && !hg[i].binned) k.emittersBinned = 0;
+    for (int i = 0; i < ngeoms; ++i) {
+        bool emits = mats[geoms[i].materialid].emittance > 0.0f;
+        if (geoms[i].type == PT_MESH)                   // (a mesh emits when any of its faces' own materials does)
+            if (const ptm::HostMesh *hm_ = mesh_of(i))
+                for (int fm : hm_->mats) emits = emits || (fm >= 0 && mats[fm].emittance > 0.0f);
+        if (emits && !hg[i].binned) k.emittersBinned = 0;
+    }
     HIPCHECK(hipMalloc(&S.dgeoms, hg.size() * sizeof(GeomDev)));
     HIPCHECK(hipMalloc(&S.dmats, hm.size() * sizeof(MaterialDev)));
     HIPCHECK(hipMemcpy(S.dgeoms, hg.data(), hg.size() * sizeof(GeomDev), hipMemcpyHostToDevice));

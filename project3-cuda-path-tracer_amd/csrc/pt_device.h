@@ -722,7 +722,9 @@ struct MeshUnit {
 //             that octant meets first (lo where the component is positive, hi where it is negative): min(fma(lo, inv, rc),
 //             fma(hi, inv, rc)) IS the entry plane's parameter (fma is monotone in its first operand) -- the hierarchy stores the
 //             planes in that order and the six min / max per box of the slab test are gone.  lo is rounded down, hi up.
-// triangle:   floats 0..2 v0, 3..5 v1, 6..8 v2, 9 the mesh's margin (pt_mesh.h: meshMargin)
+// triangle:   floats 0..2 v0, 3..5 v1, 6..8 v2, 9 the mesh's margin (pt_mesh.h: meshMargin); word 10 = 1 + the face's own material (0: the
+//             object's), word 11 = ref of the triangle's vertex normals -- three units: n0, n1, n2 -- or 0: flat shading (PtMesh::normals /
+//             materials; read for the winning triangle of a walk only)
 static_assert(sizeof(MeshUnit) == 16, "one float4 load");
 constexpr int kMeshNodeUnits = 2, kMeshTriUnits = 3;
 constexpr uint32_t kMeshEnd = 0xffffffffu;                 // GeomDev::meshRoot of a primitive that is not a mesh
@@ -786,9 +788,10 @@ __device__ __forceinline__ bool meshPlanesPass(uint32_t w0, uint32_t w1, uint32_
 // first stack slot (LDS), the next ones STRIDE words apart.  Outputs as the sphere test's (P world point, nsrc the
 // object-space vector the normal is made of -- here the unit face normal -- and `outside` = front side).
 // (NaN operands: every triangle test fails whatever the slab tests say -- a, or s, is NaN -- like in the oracle's loop.)
+// `faceMat`: 1 + the scene material of the triangle that was hit when it has one of its own (`usemtl`), else 0.
 template <bool CAM_ORIGIN = false, int STRIDE = 256, typename GD>
 __device__ __forceinline__ float meshIntersectionTest(const GD &g, const float4 *recs, uint32_t root, uint32_t stride, uint32_t *stack,
-                                                      F3 ro_w, F3 rd_w, F3 &P, F3 &nsrc, bool &outside) {
+                                                      F3 ro_w, F3 rd_w, F3 &P, F3 &nsrc, bool &outside, int &faceMat) {
     const F3 ro = CAM_ORIGIN ? f3(g.camObj[0], g.camObj[1], g.camObj[2]) : mulMV(g.inv, ro_w, 1.0f);
     const F3 rd = normalize(mulMV0(g.inv, g.invZ, rd_w));
     const F3 inv = f3(guardedReciprocal(rd.x), guardedReciprocal(rd.y), guardedReciprocal(rd.z));
@@ -853,15 +856,40 @@ __device__ __forceinline__ float meshIntersectionTest(const GD &g, const float4 
         ref = pop();
     }
     if (best < 0) return -1.0f;
-    const float4 a = recs[(size_t)best], b = recs[(size_t)best + 1];
-    const float v2z = *reinterpret_cast<const float *>(recs + (size_t)best + 2);
+    const float4 a = recs[(size_t)best], b = recs[(size_t)best + 1], c = recs[(size_t)best + 2];
     const F3 w0 = f3(a.x, a.y, a.z);
-    const F3 nobj = normalize(cross(f3(a.w, b.x, b.y) - w0, f3(b.z, b.w, v2z) - w0));
+    const F3 e1 = f3(a.w, b.x, b.y) - w0, e2 = f3(b.z, b.w, c.x) - w0;
+    const F3 nface = cross(e1, e2);
+    F3 nobj = normalize(nface);
+    faceMat = (int)__float_as_uint(c.z);
+    const uint32_t nref = __float_as_uint(c.w);
+    if (nref != 0u) {
+        // vertex normals: the blend n0 (1 - u - v) + n1 u + n2 v with the hit's own (u, v) -- the triangle test's, evaluated once more
+        // for the winner (same operands, same bits) --, turned to the face normal's side; a blend of length zero keeps the face normal
+        const F3 p = cross(rd, e2);
+        const float f = 1.0f / dot(e1, p);
+        const F3 sv = ro - w0;
+        const float u = f * dot(sv, p);
+        const F3 q = cross(sv, e1);
+        const float v = f * dot(rd, q);
+        const float4 n0 = recs[(size_t)nref], n1 = recs[(size_t)nref + 1], n2 = recs[(size_t)nref + 2];
+        const float w = (1.0f - u) - v;
+        F3 ns = (f3(n0.x, n0.y, n0.z) * w + f3(n0.w, n1.x, n1.y) * u) + f3(n1.z, n1.w, n2.x) * v;
+        if (dot(ns, nface) < 0.0f) ns = -ns;
+        if (dot(ns, ns) > 0.0f) nobj = normalize(ns);
+    }
     const F3 obj = getPointOnRay(ro, rd, tbest);
     P = mulMV(g.xf, obj, 1.0f);
     nsrc = nobj;         // normal = +-normalize(invTranspose * (nobj, 0)): hitNormal(), evaluated for the nearest hit only
     outside = bestFront != 0u;
     return length(ro_w - P);
+}
+
+template <bool CAM_ORIGIN = false, int STRIDE = 256, typename GD>
+__device__ __forceinline__ float meshIntersectionTest(const GD &g, const float4 *recs, uint32_t root, uint32_t stride, uint32_t *stack,
+                                                      F3 ro_w, F3 rd_w, F3 &P, F3 &nsrc, bool &outside) {
+    int faceMat = 0;
+    return meshIntersectionTest<CAM_ORIGIN, STRIDE>(g, recs, root, stride, stack, ro_w, rd_w, P, nsrc, outside, faceMat);
 }
 
 // The surface normal of a hit, from what the two tests leave in `nsrc` (src/intersections.h:85 and :137-140).

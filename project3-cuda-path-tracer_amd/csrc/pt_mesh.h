@@ -31,6 +31,8 @@ constexpr int kMeshStackSoftMax = 24;
 struct HostMesh {
     int geom;
     std::vector<float> tris;    // 9 floats per triangle: v0, v1, v2 (object space)
+    std::vector<float> normals; // 9 floats per triangle: vertex normals (PtMesh::normals), or empty: flat shading
+    std::vector<int> mats;      // one per triangle: the face's scene material (PtMesh::materials; -1 = the object's), or empty
 };
 
 // The per-mesh margin every triangle box is inflated by: 1e-5 of the largest |coordinate| (fp32, as the oracle's mesh_margin).
@@ -90,10 +92,15 @@ inline uint16_t halfBitsDirected(float x, bool up) {
 // is pruned.)  `flat`: no hierarchy -- a chain of nodes whose near child is triangle i and whose far child, in a box that holds
 // everything, is the rest of the chain: the brute-force rule on the device, for the tests.  bbox receives the union of all
 // triangle boxes (lo[3], hi[3]).
-inline MeshLayout appendMesh(const float *tris, int ntris, bool flat, std::vector<MeshUnit> &recs, float bbox[6]) {
+// `normals` (9 floats per triangle, or nullptr) / `mats` (one int per triangle, or nullptr): the triangle records' two spare words --
+// word 10 = 1 + the face's material (0: the object's), word 11 = the ref of the triangle's three normal units (0: flat shading), which
+// follow the mesh's triangle records: only the WINNING triangle of a walk ever reads them.
+inline MeshLayout appendMesh(const float *tris, int ntris, bool flat, std::vector<MeshUnit> &recs, float bbox[6], const float *normals = nullptr,
+                             const int *mats = nullptr) {
     const float m = meshMargin(tris, ntris);
     while (recs.size() % 4) recs.push_back(MeshUnit());       // (64-byte alignment of a mesh's first record)
     const uint32_t triBase = (uint32_t)recs.size();
+    const uint32_t normBase = triBase + (uint32_t)kMeshTriUnits * (uint32_t)ntris;       // (behind the triangle records)
     struct Leaf { float lo[3], hi[3], c[3]; int idx; };
     std::vector<Leaf> leaves((size_t)ntris);
     for (int a = 0; a < 3; ++a) { bbox[a] = INFINITY; bbox[3 + a] = -INFINITY; }
@@ -116,10 +123,23 @@ inline MeshLayout appendMesh(const float *tris, int ntris, bool flat, std::vecto
         mt[9] = m;
         MeshUnit u[3];
         memcpy(u, mt, sizeof mt);
+        u[2].w[2] = mats && mats[i] >= 0 ? (uint32_t)mats[i] + 1u : 0u;
+        u[2].w[3] = normals ? normBase + 3u * (uint32_t)i : 0u;
         recs.push_back(u[0]);
         recs.push_back(u[1]);
         recs.push_back(u[2]);
     }
+    if (normals)
+        for (int i = 0; i < ntris; ++i) {
+            float nt[12];
+            memset(nt, 0, sizeof nt);
+            memcpy(nt, normals + 9 * (size_t)i, 9 * sizeof(float));
+            MeshUnit u[3];
+            memcpy(u, nt, sizeof nt);
+            recs.push_back(u[0]);
+            recs.push_back(u[1]);
+            recs.push_back(u[2]);
+        }
     MeshLayout lay;
     lay.stackNeed = 0;
     // an inner node's record for octant `oct`: child h's box as entry / exit planes (entry = lo where the rays of the octant run

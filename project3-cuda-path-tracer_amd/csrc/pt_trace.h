@@ -898,6 +898,7 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
                     const int flags = cg.cullFlags;
                     F3 p, n;
                     bool o = false;
+                    int fm = 0;                                      // MESH: 1 + the material of the face that was hit, if it has its own
                     float t = -1.0f;
                     // camera rays: only the lanes whose pixel lies in the primitive's rectangle take the test.  A predicate and a
                     // wave-uniform skip, not a per-lane `continue`: the loop over the primitives stays a scalar loop
@@ -919,7 +920,7 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
                         if (!certainMiss(cg, org, dir, dd)) {
                             const ArgsPtr A2 = launder(kargs);
                             uint32_t *const stack = reinterpret_cast<uint32_t *>(smem + A2->prm.meshStackOff) + tid;
-                            t = meshIntersectionTest<FIRST && !DOF, kBlock>(G, A2->meshRecs, G.meshRoot, G.meshStride, stack, org, dir, p, n, o);
+                            t = meshIntersectionTest<FIRST && !DOF, kBlock>(G, A2->meshRecs, G.meshRoot, G.meshStride, stack, org, dir, p, n, o, fm);
                         }
                     } else if (!PACKED && (flags & 1) == 0) {          // (PACKED: no sphere comes this way)
                         probe(3);
@@ -938,7 +939,8 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
                     }
                     // (PACKED: a sphere tested in place above may hold the record with a higher index: file order decides a tie)
                     if (t > 0.0f && (hit < 0 || t < tbest || (PACKED && t == tbest && g < hit))) {
-                        tbest = t; hit = g; P = p; nsrc = n; outsideI = o ? 1 : 0;
+                        // (bit 0: the hit is on the outside; MESH: the bits above it carry the face's own material, 1 + its index)
+                        tbest = t; hit = g; P = p; nsrc = n; outsideI = (o ? 1 : 0) | (MESH ? fm << 1 : 0);
                     }
                 }
             }
@@ -1043,6 +1045,7 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
             } else {
                 probe(9);
                 // per-lane primitive: LDS lookup of its hit record (sphere-heavy scenes: the compact record + the frame table)
+                const int faceMat = MESH ? (outsideI >> 1) : 0;    // a mesh face with a material of its own (`usemtl`): 1 + its index
                 int ghType, ghMaterial;
                 const float *ghNm, *ghFrame;
                 float mEmit, mRefl, mRefr;                       // the material's hot fields
@@ -1053,6 +1056,7 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
                     const GeomHitSmall &h = S_GEOMHIT_SMALL(A->prm.nmats)[hit];
                     ghType = h.type; ghMaterial = h.material; ghNm = h.nm;
                     ghFrame = S_FRAMES(A->prm.nmats, A->prm.ngeoms) + h.frame * 54;
+                    if (MESH && faceMat != 0) ghMaterial = faceMat - 1;
                     const MaterialDev &Mm = smats[ghMaterial];
                     mEmit = Mm.emittance; mRefl = Mm.hasReflective; mRefr = Mm.hasRefractive;
                     mcolMany = f3(Mm.color[0], Mm.color[1], Mm.color[2]);
@@ -1065,12 +1069,16 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
                     hrec1 = reinterpret_cast<const float4 *>(&h) + 1;
                     ghType = __float_as_int(h0.x); mEmit = h0.y; mRefl = h0.z; mRefr = h0.w;
                     ghMaterial = 0;
+                    if (MESH && faceMat != 0) {                      // (the face's material instead of the record's copy of the object's)
+                        const MaterialDev &Mf = smats[faceMat - 1];
+                        mEmit = Mf.emittance; mRefl = Mf.hasReflective; mRefr = Mf.hasRefractive;
+                    }
                     ghNm = h.nm; ghFrame = h.cubeFrame;
                 }
                 const bool isSphere = ghType == 0;
                 bool faceOk = true;
                 const int face = isSphere ? 0 : cubeFace(nsrc, faceOk);
-                const bool outside = outsideI != 0;
+                const bool outside = (outsideI & 1) != 0;
                 // a cube face's frame (normal + the sampler's two tangents, nine floats): ONE select on the address -- the face's
                 // row of the table, or the row of NaNs for a hit without an exit slab -- instead of nine on the values
                 const float *const fv = faceOk ? ghFrame + 9 * face : s_nan;
@@ -1082,6 +1090,11 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
                                                                  // read stays a ds_read)
                     const float4 h1 = *reinterpret_cast<const float4 *>(smem + off);
                     mcol = f3(h1.x, h1.y, h1.z); ghMaterial = __float_as_int(h1.w);
+                    if (MESH && faceMat != 0) {
+                        ghMaterial = faceMat - 1;
+                        const MaterialDev &Mf = smats[ghMaterial];
+                        mcol = f3(Mf.color[0], Mf.color[1], Mf.color[2]);
+                    }
                 }
                 const MaterialDev &M = smats[ghMaterial];       // (the fields of the rarer branches)
                 if (mEmit > 0.0f) {                              // S5: emitter ends the path

@@ -28,6 +28,15 @@ int pth_scene_num_meshes(void *s) { return (int)static_cast<Scene *>(s)->meshes.
 int pth_scene_mesh_geom(void *s, int i) { return static_cast<Scene *>(s)->meshes[i].geom; }
 int pth_scene_mesh_ntris(void *s, int i) { return (int)(static_cast<Scene *>(s)->meshes[i].tris.size() / 9); }
 const float *pth_scene_mesh_tris(void *s, int i) { return static_cast<Scene *>(s)->meshes[i].tris.data(); }
+// vertex normals (ntris x 9) / face materials (ntris) of mesh i, or NULL when the OBJ gave none
+const float *pth_scene_mesh_normals(void *s, int i) {
+    const Mesh &m = static_cast<Scene *>(s)->meshes[i];
+    return m.normals.empty() ? NULL : m.normals.data();
+}
+const int *pth_scene_mesh_materials(void *s, int i) {
+    const Mesh &m = static_cast<Scene *>(s)->meshes[i];
+    return m.mats.empty() ? NULL : m.mats.data();
+}
 void pth_scene_set_resolution(void *s, int w, int h) { static_cast<Scene *>(s)->setResolution(w, h); }
 
 // saveImage (reference src/main.cpp:49-70) on a W*H*3 running sum: /samples, X mirror, PNG

@@ -98,6 +98,8 @@ static void renderBatched() {
         m.geom = scene->meshes[i].geom;
         m.ntris = (int)(scene->meshes[i].tris.size() / 9);
         m.tris = scene->meshes[i].tris.data();
+        m.normals = scene->meshes[i].normals.empty() ? NULL : scene->meshes[i].normals.data();      // `vn`: smooth shading
+        m.materials = scene->meshes[i].mats.empty() ? NULL : scene->meshes[i].mats.data();          // `usemtl <k>`: a material per face
         meshes.push_back(m);
     }
     check(pt_set_meshes(meshes.empty() ? NULL : meshes.data(), (int)meshes.size()), "pt_set_meshes");

@@ -25,23 +25,38 @@ float num(const Tokens &t, size_t i) { return i < t.size() ? (float)atof(t[i].c_
 lin::vec3 triple(const Tokens &t) { return lin::vec3(num(t, 1), num(t, 2), num(t, 3)); }
 
 // Wavefront OBJ -> triangle soup.  `v x y z` and `f a b c ...` with a = i, i/j, i//k or i/j/k (1-based; negative = relative
-// to the vertices read so far); polygons are fanned from their first vertex; every other statement is ignored.
-bool loadObj(const std::string &path, std::vector<float> &tris) {
+// to the vertices read so far); polygons are fanned from their first vertex.  `vn x y z` + the third field of a face corner give
+// vertex normals: kept only when EVERY corner of EVERY face names one (else the mesh is shaded flat).  `usemtl <k>` (k an integer
+// = a MATERIAL of the scene file) gives the faces that follow a material of their own; any other name returns to the object's.
+// Every other statement is ignored.
+bool loadObj(const std::string &path, std::vector<float> &tris, std::vector<float> &normalsOut, std::vector<int> &matsOut) {
     std::ifstream fp(path.c_str());
     if (!fp.is_open()) return false;
-    std::vector<float> verts;
+    std::vector<float> verts, vnorm, normals;
+    std::vector<int> mats;
+    bool allNormals = true, anyMat = false;
+    int curMat = -1;
     std::string line;
     while (std::getline(fp, line)) {
         std::istringstream ss(line);
         std::string keyword;
         if (!(ss >> keyword)) continue;
-        if (keyword == "v") {
+        if (keyword == "v" || keyword == "vn") {
             double c[3] = {0, 0, 0};
             ss >> c[0] >> c[1] >> c[2];
-            for (int a = 0; a < 3; ++a) verts.push_back((float)c[a]);
+            std::vector<float> &dst = keyword == "v" ? verts : vnorm;
+            for (int a = 0; a < 3; ++a) dst.push_back((float)c[a]);
+        } else if (keyword == "usemtl") {
+            std::string tok;
+            curMat = -1;
+            if (ss >> tok) {
+                char *end = nullptr;
+                const long k = strtol(tok.c_str(), &end, 10);
+                if (end && *end == 0 && k >= 0 && k < 1000000) curMat = (int)k;
+            }
         } else if (keyword == "f") {
-            const int nv = (int)(verts.size() / 3);
-            std::vector<int> corner;
+            const int nv = (int)(verts.size() / 3), nn = (int)(vnorm.size() / 3);
+            std::vector<int> corner, ncorner;
             std::string ref;
             bool ok = true;
             while (ss >> ref) {
@@ -49,14 +64,32 @@ bool loadObj(const std::string &path, std::vector<float> &tris) {
                 const int k = i > 0 ? i - 1 : nv + i;
                 if (i == 0 || k < 0 || k >= nv) { ok = false; break; }
                 corner.push_back(k);
+                int nk = -1;                                   // the normal: the field behind the second '/'
+                const size_t s1 = ref.find('/');
+                const size_t s2 = s1 == std::string::npos ? std::string::npos : ref.find('/', s1 + 1);
+                if (s2 != std::string::npos && s2 + 1 < ref.size()) {
+                    const int j = atoi(ref.c_str() + s2 + 1);
+                    const int q = j > 0 ? j - 1 : nn + j;
+                    if (j != 0 && q >= 0 && q < nn) nk = q;
+                }
+                ncorner.push_back(nk);
             }
             for (size_t k = 2; ok && k < corner.size(); ++k) {
                 const int tri[3] = {corner[0], corner[k - 1], corner[k]};
+                const int ntri[3] = {ncorner[0], ncorner[k - 1], ncorner[k]};
                 for (int c = 0; c < 3; ++c)
-                    for (int a = 0; a < 3; ++a) tris.push_back(verts[3 * (size_t)tri[c] + a]);
+                    for (int a = 0; a < 3; ++a) {
+                        tris.push_back(verts[3 * (size_t)tri[c] + a]);
+                        normals.push_back(ntri[c] >= 0 ? vnorm[3 * (size_t)ntri[c] + a] : 0.0f);
+                    }
+                if (ntri[0] < 0 || ntri[1] < 0 || ntri[2] < 0) allNormals = false;
+                mats.push_back(curMat);
+                if (curMat >= 0) anyMat = true;
             }
         }
     }
+    if (allNormals && !tris.empty()) normalsOut = normals; else normalsOut.clear();
+    if (anyMat) matsOut = mats; else matsOut.clear();
     return true;
 }
 
@@ -177,7 +210,7 @@ int Scene::loadGeom(std::string objectid) {
                 Mesh m;
                 m.geom = (int)geoms.size();
                 const std::string path = t[1][0] == '/' ? t[1] : dir + t[1];
-                if (loadObj(path, m.tris) && !m.tris.empty()) {
+                if (loadObj(path, m.tris, m.normals, m.mats) && !m.tris.empty()) {
                     if (verbose) std::cout << "Creating new mesh (" << m.tris.size() / 9 << " triangles)..." << std::endl;
                     g.type = MESH;
                     meshes.push_back(m);

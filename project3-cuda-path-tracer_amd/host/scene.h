@@ -14,6 +14,8 @@
 struct Mesh {
     int geom;                   // index into Scene::geoms (a Geom of type MESH)
     std::vector<float> tris;    // 9 floats per triangle: v0, v1, v2
+    std::vector<float> normals; // 9 floats per triangle: the vertex normals n0, n1, n2 (`vn`, smooth shading) -- or EMPTY: flat shading
+    std::vector<int> mats;      // one per triangle: the scene material of that face (`usemtl <k>`), -1 = the object's own -- or EMPTY
 };
 
 class Scene {

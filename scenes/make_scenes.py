@@ -130,14 +130,26 @@ def torus(nu, nv, R=0.35, r=0.15):
     return v, f
 
 
-def write_obj(name, title, v, f):
+def write_obj(name, title, v, f, vn=None, usemtl=None):
+    """vn: one normal per vertex (faces then read `i//i`); usemtl: {first face index: scene material} -- `usemtl <k>` statements"""
     os.makedirs(os.path.join(HERE, "models"), exist_ok=True)
     with open(os.path.join(HERE, "models", name), "w") as fp:
         fp.write(f"# {title} (generated by scenes/make_scenes.py)\n")
         for p in v:
             fp.write("v %.6f %.6f %.6f\n" % p)
-        for face in f:
-            fp.write("f " + " ".join(str(i + 1) for i in face) + "\n")
+        for p in vn or []:
+            fp.write("vn %.6f %.6f %.6f\n" % p)
+        for k, face in enumerate(f):
+            if usemtl and k in usemtl:
+                fp.write("usemtl %s\n" % usemtl[k])
+            fp.write("f " + " ".join(("%d//%d" % (i + 1, i + 1)) if vn else str(i + 1) for i in face) + "\n")
+
+
+def unit_cube():
+    """[-0.5, 0.5]^3 as six outward counter-clockwise quads: -x, +x, -y, +y, -z, +z"""
+    v = [(x, y, z) for x in (-0.5, 0.5) for y in (-0.5, 0.5) for z in (-0.5, 0.5)]          # index = 4 x + 2 y + z
+    f = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
+    return v, f
 
 
 def cornell_mesh():
@@ -166,8 +178,30 @@ def mesh_small():
     return s
 
 
+def mesh_attributes():
+    """vertex normals and per-face materials (README.md:112-116: `vn`, `usemtl`): a smooth-shaded icosphere, a flat one beside it, and a
+    cube mesh whose six faces take six materials (one of them emissive, one a mirror mix)"""
+    s = "// mesh attributes: an icosphere with vertex normals (smooth), the same icosphere without (flat), a cube with a material per face\n\n"
+    for i, m in enumerate(CORNELL_MATS + [GLASS]):
+        s += material(i, *m)
+    s += camera("96 96", 45, 16, 6, "mesh_attributes")
+    s += obj(0, "ceiling light", "cube", 0, "0 10 0", "0 0 0", "6 .3 6")
+    s += obj(1, "floor", "cube", 1, "0 0 0", "0 0 0", "10 .01 10")
+    s += obj(2, "back wall", "cube", 2, "0 5 -5", "0 90 0", ".01 10 10")
+    s += obj(3, "icosphere with vertex normals (mirror mix)", "mesh models/icosphere1_vn.obj", 4, "-2.5 3 0", "10 20 30", "4 3 4")
+    s += obj(4, "the same icosphere, flat", "mesh models/icosphere1.obj", 1, "2.5 6.5 -1", "10 20 30", "3 3 3")
+    s += obj(5, "cube mesh, a material per face", "mesh models/cube_materials.obj", 1, "2.2 2.5 1", "20 35 10", "3 3 3")
+    return s
+
+
 def main():
     w = lambda n, s: open(os.path.join(HERE, n), "w").write(s)
+    v1, f1 = icosphere(1)
+    write_obj("icosphere1_vn.obj", "icosphere, 1 subdivision: 80 triangles, diameter 1, with vertex normals (the radial directions)", v1, f1,
+              vn=[tuple(c / 0.5 for c in p) for p in v1])
+    write_obj("cube_materials.obj", "unit cube, six quads, a scene material per face (usemtl <k>; the last face keeps the object's)",
+              *unit_cube(), usemtl={0: 2, 1: 3, 2: 4, 3: 0, 4: 5, 5: "object"})
+    w("mesh_attributes.txt", mesh_attributes())
     write_obj("icosphere3.obj", "icosphere, 3 subdivisions: 1280 triangles, diameter 1", *icosphere(3))
     write_obj("icosphere1.obj", "icosphere, 1 subdivision: 80 triangles, diameter 1", *icosphere(1))
     write_obj("torus.obj", "torus, 48 x 24 quads = 2304 triangles", *torus(48, 24))

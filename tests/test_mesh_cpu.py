@@ -50,6 +50,89 @@ def test_obj_statements(pt, oracle, tmp_path):
                 mod.Scene(str(tmp_path / "bad.txt"))
 
 
+def test_loaders_agree_on_mesh_attributes(pt, oracle, tmp_path):
+    # `vn` + the third field of a face corner = vertex normals (kept only when every corner of every face names one), `usemtl <k>` = a
+    # scene material per face: the product's host loader and the oracle's read the same arrays
+    name = os.path.join(SCENES, "mesh_attributes.txt")
+    a, b = pt.Scene(name), oracle.Scene(name)
+    assert a.geoms.tobytes() == b.geoms.tobytes() and sorted(a.meshes) == sorted(b.meshes) == [3, 4, 5]
+    assert sorted(a.mesh_normals) == sorted(b.mesh_normals) == [3] and sorted(a.mesh_materials) == sorted(b.mesh_materials) == [5]
+    assert a.mesh_normals[3].shape == (80, 9) and a.mesh_normals[3].tobytes() == b.mesh_normals[3].tobytes()
+    # (the model's normals are its vertices' radial directions: vertices on a sphere of diameter 1)
+    assert np.allclose(a.mesh_normals[3], 2 * a.meshes[3], atol=2e-6)
+    want = np.repeat(np.array([2, 3, 4, 0, 5, -1], np.int32), 2)               # six quads = twelve triangles, `usemtl object` = the object's
+    assert np.array_equal(a.mesh_materials[5], want) and np.array_equal(b.mesh_materials[5], want)
+    # a face corner without a normal makes the whole mesh flat; a name that is no integer returns to the object's material
+    (tmp_path / "m.obj").write_text("v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvn 0 0 1\nusemtl 1\nf 1//1 2//1 3//1\nusemtl shiny\nf 1//1 3//1 4\n")
+    (tmp_path / "s.txt").write_text(
+        "MATERIAL 0\nRGB 1 1 1\nSPECEX 0\nSPECRGB 0 0 0\nREFL 0\nREFR 0\nREFRIOR 0\nEMITTANCE 1\n\n"
+        "MATERIAL 1\nRGB 1 0 0\nSPECEX 0\nSPECRGB 0 0 0\nREFL 0\nREFR 0\nREFRIOR 0\nEMITTANCE 0\n\n"
+        "CAMERA\nRES 8 8\nFOVY 45\nITERATIONS 1\nDEPTH 2\nFILE x\nEYE 0 0 5\nVIEW 0 0 -1\nUP 0 1 0\n\n"
+        "OBJECT 0\nmesh m.obj\nmaterial 0\nTRANS 0 0 0\nROTAT 0 0 0\nSCALE 1 1 1\n\n")
+    for mod in (pt, oracle):
+        sc = mod.Scene(str(tmp_path / "s.txt"))
+        assert sc.mesh_normals == {} and np.array_equal(sc.mesh_materials[0], np.array([1, -1], np.int32))
+
+
+def test_vertex_normals_of_an_icosphere_are_the_spheres_normals(oracle):
+    # The model's vertex normals are the radial directions of its vertices, which lie on the sphere of diameter 1: the barycentric
+    # blend of the normals at a hit is then parallel to the same blend of the vertices -- the hit point itself.  So the shading
+    # normal of the smooth icosphere must be the normal the SPHERE primitive's formula gives at that object-space point,
+    # normalize(invTranspose * (p_obj, 0)) (src/intersections.h:137-140), whatever the (anisotropic) transform -- and the flat
+    # icosphere's normal must not (it is constant per face).
+    sc = oracle.Scene(os.path.join(SCENES, "mesh_attributes.txt"))
+    tris, normals = sc.meshes[3], sc.mesh_normals[3]
+    rng = np.random.default_rng(5)
+    worst_smooth, worst_flat, hits = 0.0, 0.0, 0
+    for scale in ((4, 3, 4), (1, 1, 1), (0.5, 2.0, 1.0)):
+        geom = oracle.make_geom(2, 0, (-1.5, 3, 0), (10, 20, 30), scale)
+        M = geom["transform"][0].astype(np.float64).reshape(4, 4).T          # (column-major in the struct)
+        invT = np.linalg.inv(M[:3, :3]).T
+        for _ in range(400):
+            o = np.array([-1.5, 3, 0]) + rng.normal(size=3) * 6
+            target = np.array([-1.5, 3, 0]) + rng.normal(size=3) * 0.8
+            d = (target - o) / np.linalg.norm(target - o)
+            ray = tuple(o.astype(f32)) + tuple(d.astype(f32))
+            t, p, n, outside, tri = oracle.mesh_intersect(geom, tris, ray, normals=normals)
+            tf, pf, nf, of, trif = oracle.mesh_intersect(geom, tris, ray)
+            assert np.float32(t).view(np.uint32) == np.float32(tf).view(np.uint32) and tri == trif       # the normals change the shading only
+            if t <= 0:
+                continue
+            assert np.array_equal(p.view(np.uint32), pf.view(np.uint32)) and outside == of
+            pobj = np.linalg.inv(M) @ np.append(p.astype(np.float64), 1.0)
+            want = invT @ pobj[:3]
+            want /= np.linalg.norm(want)
+            if not outside:
+                want = -want
+            worst_smooth = max(worst_smooth, float(np.abs(n - want).max()))
+            worst_flat = max(worst_flat, float(np.abs(nf - want).max()))
+            hits += 1
+    assert hits > 300
+    assert worst_smooth < 2e-3, worst_smooth          # (the hit point is offset by 1e-4 along the ray: 2e-4 of the radius at most)
+    assert worst_flat > 0.05                           # an 80-triangle icosphere's face normals are up to ~15 degrees off
+
+
+def test_face_materials_in_the_oracle(oracle):
+    # `usemtl`: a face takes the scene material it names.  (i) naming the object's own material for every face changes nothing, bit for
+    # bit; (ii) the cube mesh of mesh_attributes.txt has an emissive face (material 0): paths end there as on a light
+    sc = oracle.Scene(os.path.join(SCENES, "mesh_attributes.txt"))
+    sc.set_resolution(48, 48)
+
+    def render(mats):
+        ref = oracle.Renderer(sc.camera, sc.geoms, sc.materials, 5, meshes=sc.meshes, mesh_normals=sc.mesh_normals, mesh_materials=mats)
+        img = np.zeros(48 * 48 * 3, f32)
+        lights = 0
+        for it in (1, 2, 3):
+            lights += ref.iterate(it, img).lightHits
+        return img, lights
+    base, lights_base = render({})
+    own = {5: np.full(12, int(sc.geoms["materialid"][5]), np.int32)}
+    same, lights_same = render(own)
+    assert np.array_equal(base.view(np.uint32), same.view(np.uint32)) and lights_base == lights_same
+    with_faces, lights_faces = render(sc.mesh_materials)
+    assert lights_faces > lights_base + 50 and not np.array_equal(base, with_faces)
+
+
 def _cube_mesh():
     c = np.array([[x, y, z] for x in (-.5, .5) for y in (-.5, .5) for z in (-.5, .5)], f32)
     quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]      # outward counter-clockwise
