@@ -7,7 +7,7 @@ Metric (BASELINE.json): Mpaths/s, paths = pixels x bounces x spp (NOMINAL segmen
 One STEP = one pass of the hot path over one batch of input = `--batch` (64) consecutive iterations (spp) of the
 whole frame -- BASELINE config C2 in full: 1280x720, 64 spp, 8 bounces -- camera rays, 8 fused intersect+shade+compact
 bounces, ordered accumulation, issued as ONE wavefront batch (pt_iterate_batch: the 64 iterations' paths share the 8
-launches; results are identical to one call per iteration), with 2 batches in flight on internal streams.  So
+launches; results are identical to one call per iteration), with 3 batches in flight on internal streams.  So
 `--steps 20` times 1280 iterations.  Scene, accumulator and path state are resident in HBM before the timed region.
 (Rounds 1-3 stepped in batches of 32; a launch carries a fixed ~15 us of ramp-up and tail, which 64 iterations
 amortise over twice the paths: `--batch 32` reproduces the old step.)
@@ -81,7 +81,9 @@ def parse(argv=None):
     ap.add_argument("--res", type=int, nargs=2, default=[1280, 720])
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--cpu-spp", type=int, default=40, help="spp of the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--pipeline", type=int, default=2, help="batches in flight (PtOptions.pipeline_depth; 0 = library default 3)")
+    ap.add_argument("--pipeline", type=int, default=3,
+                    help="batches in flight (PtOptions.pipeline_depth; 0 = library default 3).  Round 4: 3 -- with steps of 64 iterations a third "
+                         "batch in flight is worth +1.5 .. 4 % (profiles/exp_r4i.sh, exp_r4k.sh); the per-iteration reading of config C3 keeps 2")
     ap.add_argument("--batch", type=int, default=64,
                     help="iterations per step = iterations traced as one wavefront batch (64 = the spp of BASELINE config C2)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -557,8 +559,8 @@ def run(args, ctx):
     if args.dump_frame and rank == 0:
         np.save(args.dump_frame, (frame if world > 1 else accum).cpu().numpy())
 
-    def reading(scaling, ev, collective, steps, warmup, c3=False):
-        m = measure(scaling, ev, collective, steps, 1, warmup, c3=c3)
+    def reading(scaling, ev, collective, steps, warmup, c3=False, pipeline=None):
+        m = measure(scaling, ev, collective, steps, 1, warmup, c3=c3, pipeline=pipeline)
         w = m["walls"][0]
         r = {"value": round(P * D * m["I"] * steps / w / 1e6, 2), "unit": "Mpaths/s", "steps": steps, "iterations_per_step": m["I"],
              "iterations_per_wavefront_batch": m["maxb"], "ms_per_step": round(w / steps * 1e3, 4),
@@ -604,7 +606,7 @@ def run(args, ctx):
             if world == 1 and not dist.is_initialized():
                 ptdist.init_process_group(backend, single_rank=True)
                 ctx["dist"] = dist
-            c3 = reading("strong", "1", "reduce", c3_steps, 1, c3=True)
+            c3 = reading("strong", "1", "reduce", c3_steps, 1, c3=True, pipeline=min(args.pipeline, 2) if args.pipeline > 0 else 2)
             red = ctx.get("reducer")
             c3["collective_bytes_per_call"] = red.bytes_per_call() if red is not None else None
             c3["collective_backend"] = (backend if backend != "nccl" else "nccl (RCCL)") + (", one-rank group" if world == 1 else "")

@@ -437,11 +437,11 @@ void pack_material(const PtMaterial &m, MaterialDev &d) {
 // radicand (ro . rd)^2 - (ro . ro - 0.25) ~eps R^2.  A ray that misses the exact primitive by less than that can come back as a hit
 // (the device sweep found them at once: a 100 : 1 ellipsoid seen from 20 000 object units through a 1.5-degree lens "hit" from
 // pixels 60 columns off its projection).  So the box whose corners are projected is the object-space box INFLATED by those errors, with
-// factors of ~40 on first-order bounds (eps = 2^-24):
+// factors on first-order bounds (eps = 2^-24; k = 8 for a cube, 128 for a sphere or a mesh's box):
 //     A_i  = sum_j |inv_ij| |eye_j| + |inv_i3|        magnitude of the sums behind ro_i          (error of ro_i   <= 3 eps A_i)
 //     B_i  = sum_j |inv_ij|                           ... behind (inverseTransform d)_i, |d| <= 1 (error          <= 3 eps B_i)
 //     R    = |A| + 1                                  object-space distance over which a direction error acts
-//     D_i  = 128 eps A_i + R (128 eps B_i smax + 128 eps) displacement of the computed line along axis i (smax >= the transform's largest
+//     D_i  = k eps A_i + R (k eps B_i smax + k eps)    displacement of the computed line along axis i (smax >= the transform's largest
 //                                                     singular value: |inverseTransform d| >= |d| / smax)
 //     cube / mesh box: half extent + 2 D_i (+ 2e-5 R for a mesh: the relative slack of its slab comparisons), all x (1 + 1e-5)
 //     sphere:          the cube of half extent  sqrt(1/4 + 512 eps R^2) + 2 |D|  on every axis
@@ -449,12 +449,14 @@ void pack_material(const PtMaterial &m, MaterialDev &d) {
 // space, by which the EXACT half-line of a camera ray may miss the primitive while the reference's fp32 test still reports a hit.
 // pt_test_camera_cull_margin measures it per hit -- the exact half-line in double precision against the primitive grown by a
 // fraction s of the inflation -- over the 10 500 (camera, primitive set) pairs of the soundness sweep
-// (tests/test_gpu_camera_cull.py::test_inflation_margin_of_the_culling_tables).  Round 3's factors (8 eps, 32 eps R^2: "safety
-// factors 2 - 3") turned out to leave the worst hit of those cases at s ~ 0.85 of the inflation -- a margin of 1.2 x where every other
-// shortcut has 40 - 500 x (0.445 over the first 3000 cases; 0.212 over all of them with the terms x 4, measured on the way).  Round 4
-// multiplies the error terms by SIXTEEN: worst observed fraction 0.105 = a margin of 9.5 x in distance (the case is a sphere seen
-// from ~10^4 object units, where the inflation is the radicand's term sqrt(512 eps) R: in that term's factor the margin is the
-// square, ~90 x); the test asserts <= 0.125.  The cost is nil where it matters (Cornell's rectangles move by a fraction of a pixel).
+// (tests/test_gpu_camera_cull.py::test_inflation_margin_of_the_culling_tables, per primitive type).  Round 3's factors (8 eps, 32 eps R^2:
+// "safety factors 2 - 3") turned out to leave the worst SPHERE hit of those cases at s ~ 0.85 of the inflation -- a margin of 1.2 x where
+// every other shortcut has 40 - 500 x (0.445 over the first 3000 cases; 0.212 over all of them with the terms x 4, measured on the way).
+// Round 4 multiplies the sphere's error terms by SIXTEEN: worst observed fraction 0.105 = a margin of 9.5 x in distance (the case is a
+// sphere seen from ~10^4 object units, where the inflation is the radicand's term sqrt(512 eps) R: in that term's factor the margin is
+// the square, ~90 x).  CUBES keep round 3's factors: of ~10^9 cube hits in the sweep 18 needed any inflation at all, the worst 0.003 of
+// it -- a margin of 300 x -- and the x 16 terms, tried first for every type, made Cornell's thin walls (inverse scale 100 on one axis)
+// 0.33 units thick in the tables, ten pixels per side: 7 % of the headline throughput for nothing (profiles/exp_r4l.sh).
 // For Cornell's walls that is a fraction of a pixel at 1280 x 720; for the ellipsoid above a hundred pixels; when the inflated box
 // reaches the eye, a corner is no longer in front of it and the primitive is not culled at all.
 void inflated_object_box(const PtGeom &g, const float *eye, const float *box, double lo[3], double hi[3]) {
@@ -472,9 +474,11 @@ void inflated_object_box(const PtGeom &g, const float *eye, const float *box, do
     }
     const double smax = std::sqrt(smax2);
     const double R = std::sqrt(A[0] * A[0] + A[1] * A[1] + A[2] * A[2]) + 1.0;
+    // (the factor on the first-order terms: 8 for a cube -- measured margin 300 x, below --, 128 for a sphere and for a mesh's box)
+    const double kf = (g.type == PT_CUBE && !box) ? 8.0 : 128.0;
     double D[3], Dn = 0;
     for (int i = 0; i < 3; ++i) {
-        D[i] = 128 * eps * A[i] + R * (128 * eps * B[i] * smax + 128 * eps);
+        D[i] = kf * eps * A[i] + R * (kf * eps * B[i] * smax + kf * eps);
         Dn += D[i] * D[i];
     }
     Dn = std::sqrt(Dn);
