@@ -615,7 +615,16 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
     // long as T does: both are multiples of the tiles per row apart from c0 < tilesPerRow) and the rotated band.
     uint32_t rot = 0;                       // (c0 + k) % tilesPerRow of the tile about to be processed
     uint32_t rowShift = 0;                  // c0
-    if (FIRST) {
+#ifndef PT_TICKETS
+#define PT_TICKETS 1
+#endif
+#ifndef PT_TICKETS_FIRST
+#define PT_TICKETS_FIRST 1
+#endif
+    // (a camera-ray launch that draws tickets -- see TICKETS below -- takes its tiles in ticket order: no rotation to set up)
+    constexpr bool kTickets = PT_TICKETS && (!FIRST || PT_TICKETS_FIRST);
+    const bool ticketed = kTickets && (hotWord & kHotLast) == 0u;
+    if (FIRST && !ticketed) {
         const uint32_t tpr = (uint32_t)launder(kargs)->prm.tilesPerRow;
         if (tpr > 1) rowShift = rot = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x % tpr));
     }
@@ -708,11 +717,6 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
     // reservation's atomics (same round trip, between the same two barriers) and handed to the other waves through LDS, so the next
     // tile -- whose loads are requested before the compaction -- is always known: no new latency in the chain.  A shard's tickets are
     // drawn in increasing order, so a workgroup whose next tile lies beyond the queue's end holds no valid later one.
-#ifndef PT_TICKETS
-#define PT_TICKETS 1
-#endif
-    constexpr bool kTickets = PT_TICKETS && !FIRST;
-    const bool ticketed = kTickets && (hotWord & kHotLast) == 0u;
     uint32_t Tn1 = kTickets ? T + gridDim.x : 0u;   // the tile after T (carried only where tickets can be drawn; else always T + grid)
     while (T < numTiles) {
         // the lane id, opaque to the optimiser: the lane masks derived from it (tid < 16, wave > k, ...) are then
@@ -740,7 +744,7 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
             // row: a bijection on the row's tiles (they share k), which walks every workgroup through all bands.
             uint32_t pixTile = T;
             const uint32_t tilesPerRow = (uint32_t)prm.tilesPerRow;
-            if (tilesPerRow > 1) {
+            if (tilesPerRow > 1 && !ticketed) {
                 pixTile = T + rot;                              // (T: the first tile of this tile's row)
                 rot = rot + 1u == tilesPerRow ? 0u : rot + 1u;
             }
