@@ -734,7 +734,18 @@ def run(args, ctx):
         if c3 is not None:
             out["value_c3_as_written"] = c3
         out["box_calibration"] = box_calibration(pt, torch)
-        out["box_calibration"]["telemetry_during_timed_blocks"] = telemetry.report() if telemetry else None
+        tm = telemetry.report() if telemetry else None
+        out["box_calibration"]["telemetry_during_timed_blocks"] = tm
+        # the vector-issue bound once more at the shader clock the card actually ran at (the figures above price it at the 2.4 GHz maximum;
+        # under this load the card settles some 10 % below it, at ~1.2 of its 1.4 kW cap)
+        try:
+            sclk = tm["sclk_mhz"]["median"] * 1e6
+            v = rf.get("valu")
+            if v and sclk > 0:
+                v["frac_of_issue_bound_at_measured_sclk"] = {k: round(x * CLOCK_HZ / sclk, 4) for k, x in v["frac_of_issue_bound"].items()}
+                v["measured_sclk_mhz"] = tm["sclk_mhz"]["median"]
+        except (TypeError, KeyError):
+            pass
         if world == 1 and args.cpu_spp > 0:
             out["cpu_baseline"] = cpu_baseline(args, scene, pt)
         print(json.dumps(out), flush=True)
