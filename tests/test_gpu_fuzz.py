@@ -76,8 +76,23 @@ def _random_scene(gpu, oracle, seed, tris_by_name):
     cam["position"], cam["view"], cam["up"] = eye, (rng.uniform(-0.15, 0.15), rng.uniform(-0.15, 0.05), -1), (0, 1, 0)
     cam["fov"] = (0.0, rng.uniform(25, 50))
     oracle.lib().orc_camera_set_resolution(cam.ctypes.data, res[0], res[1])
+    # mesh attributes (round 4), from a generator of their own so that the scenes themselves stay the ones of rounds 2-3: vertex normals --
+    # the face normal bent by up to ~40 degrees per vertex, some of them through the surface (the blend is turned to the face's side) -- for
+    # two meshes in five, a material per face (any of the scene's six, or -1 = the object's) for two in five
+    arng = np.random.default_rng(seed + 977)
+    mesh_normals, mesh_materials = {}, {}
+    for g in sorted(meshes):
+        t = meshes[g].reshape(-1, 3, 3).astype(np.float64)
+        if arng.random() < 0.4:
+            fn = np.cross(t[:, 1] - t[:, 0], t[:, 2] - t[:, 0])
+            fn /= np.maximum(np.linalg.norm(fn, axis=1, keepdims=True), 1e-30)
+            vn = fn[:, None, :] + arng.uniform(-0.8, 0.8, t.shape)
+            mesh_normals[g] = (vn / np.maximum(np.linalg.norm(vn, axis=2, keepdims=True), 1e-30)).reshape(-1, 9).astype(np.float32)
+        if arng.random() < 0.4:
+            mesh_materials[g] = arng.integers(-1, 6, len(t)).astype(np.int32)
     sc = types.SimpleNamespace(geoms=np.concatenate(geoms).view(gpu.GEOM_DTYPE), materials=mats.view(gpu.MATERIAL_DTYPE),
                                camera=cam.view(gpu.CAMERA_DTYPE), traceDepth=int(rng.integers(2, 9)), meshes=meshes,
+                               mesh_normals=mesh_normals, mesh_materials=mesh_materials,
                                image=np.zeros((res[1], res[0], 3), np.float32))
     extras = {}
     if rng.random() < 0.25:
@@ -95,7 +110,7 @@ def test_random_scene(gpu, oracle, seed):
     sc, (W, H), extras, rng = _random_scene(gpu, oracle, 5650 + seed, tris)
     depth = sc.traceDepth
     ref = oracle.Renderer(sc.camera.view(oracle.CAMERA_DTYPE), sc.geoms.view(oracle.GEOM_DTYPE), sc.materials.view(oracle.MATERIAL_DTYPE),
-                          depth, meshes=sc.meshes)
+                          depth, meshes=sc.meshes, mesh_normals=sc.mesh_normals, mesh_materials=sc.mesh_materials)
     ref.set_extras(**extras)
     world = int(rng.choice([1, 1, 2, 3]))
     rank = int(rng.integers(0, world))
