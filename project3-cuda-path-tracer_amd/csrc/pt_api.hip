@@ -121,7 +121,8 @@ struct State {
     // PT_FLAG_TRACE_AHEAD: batches traced ahead of the pt_iterate calls that will ask for their iterations, oldest first.
     // A parked batch occupies its slot (radiance buffers, iteration masks) until its last iteration is committed or it
     // is discarded; the parked slots are the `ahead.size()` slots before seq % nslots in the rotation.
-    struct Parked { int slot, first, count, next; };   // iterations first .. first + count - 1, the next one to commit = first + next
+    struct Parked { int slot, first, count, next; bool waited; };   // iterations first .. first + count - 1, the next one to commit = first + next;
+                                                                    // waited: the caller's stream already waits for the batch's launches
     std::deque<Parked> ahead;
     uint32_t launchSerial = 0;   // bounce launches since pt_init
     // host buffer of pt_readback, page-locked on first use so the per-iteration D2H copy of the reference protocol
@@ -866,7 +867,7 @@ int trace_ahead(int first) {
     const int slot = (int)(S.seq % S.nslots);
     int rc = trace_batch(S.slot[slot], first, count);
     if (rc) return rc;
-    S.ahead.push_back({slot, first, count, 0});
+    S.ahead.push_back({slot, first, count, 0, false});
     S.seq += 1;
     return PT_OK;
 }
@@ -1460,7 +1461,10 @@ int pt_iterate_batch(int frame, int first_iter, int count, void *rgba8_dev) {
         }
         State::Parked &p = S.ahead.front();
         Slot &sl = S.slot[p.slot];
-        HIPCHECK(hipStreamWaitEvent(S.stream, sl.evDone, 0));
+        if (!p.waited) {      // (once per batch: the commits that follow on the caller's stream are ordered behind this one)
+            HIPCHECK(hipStreamWaitEvent(S.stream, sl.evDone, 0));
+            p.waited = true;
+        }
         rc = commit_range(sl, p.count, p.next, p.next + 1, false);
         if (rc) return rc;
         int after = p.first + p.count;               // first iteration behind the parked batches
