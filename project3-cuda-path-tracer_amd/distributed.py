@@ -30,9 +30,10 @@ def padded_block_floats(width, height, world):
     return ((height + world - 1) // world) * width * 3
 
 
-def init_process_group(backend=None, timeout_s=180, single_rank=False):
+def init_process_group(backend=None, timeout_s=600, single_rank=False):
     """Rendezvous from the torchrun environment (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT).  Every collective of the
-    group -- the exit barrier included -- gives up after `timeout_s` seconds instead of waiting for a rank that died.
+    group -- the exit barrier included -- gives up after `timeout_s` seconds instead of waiting for a rank that died (the same bound
+    holds for the rendezvous itself: ranks of a fresh box can be a minute or two apart in their first `import torch`).
     `single_rank`: form a ONE-rank group on 127.0.0.1 when there is no torchrun environment (bench.py at N = 1 sends its
     per-iteration reduce through RCCL's call path: a hardware number for the protocol's fixed cost without a second GPU)."""
     import datetime
