@@ -1266,6 +1266,20 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
             hg[cand[c].second].cullFlags |= 2;
         }
     }
+    // Mesh scenes bin by two candidate bits (pt_trace.h: kClsMax): the costliest binned mesh (most triangles) alone in group 1 when there is
+    // another binned primitive beside it, everything else in group 0 -- a tile of the next bounce then walks that mesh only when its paths
+    // can hit it, with all its lanes, instead of every cand tile walking every mesh with some.
+    int binGroup[kBinMax] = {0, 0, 0, 0};
+    if (!meshRecs.empty() && k.nBinned > 1) {
+        int bestB = -1;
+        size_t bestTris = 0;
+        for (int b = 0; b < k.nBinned; ++b)
+            if (geoms[k.binGeom[b]].type == PT_MESH) {
+                const size_t nt = mesh_of(k.binGeom[b])->tris.size() / 9;
+                if (nt > bestTris) { bestTris = nt; bestB = b; }
+            }
+        if (bestB >= 0) binGroup[bestB] = 1;
+    }
     for (int b = 0; b < kBinMax; ++b) {                      // (KParams::binCull: the binned primitives' culling groups, inline)
         for (int q = 0; q < 8; ++q) k.binCull[b][q] = 0.0f;
         k.binCull[b][3] = -INFINITY;                          // beyond nBinned: certified for everybody
@@ -1273,6 +1287,9 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
             const GeomDev &G = hg[k.binGeom[b]];
             k.binCull[b][0] = G.centre[0]; k.binCull[b][1] = G.centre[1]; k.binCull[b][2] = G.centre[2];
             k.binCull[b][3] = G.cullR2; k.binCull[b][4] = G.cullK;
+            // word 5: the primitive's candidate bit in a survivor's class (k_bounce<..., MESH>): 1 = group 0, 2 = group 1
+            const uint32_t bit = 1u << binGroup[b];
+            memcpy(&k.binCull[b][5], &bit, sizeof bit);
         }
     }
     // Walls: the large cubes -- not binned, finite -- at most kWallMax of them, the largest first.  Survivors are classed by
@@ -1363,19 +1380,26 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     {   // Later bounces: which primitives a tile of queue class c looks at.  Class bit 3 = its paths may hit a binned primitive;
         // bits 0-2 in a scene with walls = the one wall they can still hit (6: any, 7: none), else the direction octant.
         std::vector<int> idx;
-        for (int c = 0; c < kCls; ++c) {
+        const int ncls = meshRecs.empty() ? kCls : kClsMax;                   // (mesh scenes: two candidate bits, 32 classes)
+        for (int c = 0; c < kClsMax; ++c) {
             k.classOff[c] = (int)idx.size();
-            const bool small = (c & 8) != 0;
+            if (c >= ncls) continue;
+            const int small = c >> 3;                                          // candidate bits: which groups of binned primitives
             const int wall = k.nWalls > 0 ? (c & 7) : 6;
             for (int i = 0; i < ngeoms; ++i) {
                 if (S.many && geoms[i].type == PT_SPHERE) continue;            // swept from their packed culling data
-                if (hg[i].binned && !small) continue;
+                if (hg[i].binned) {
+                    int grp = 0;
+                    for (int b = 0; b < k.nBinned; ++b)
+                        if (k.binGeom[b] == i) grp = binGroup[b];
+                    if (!((small >> grp) & 1)) continue;
+                }
                 const int w = (hg[i].flags >> 2) & 7;                          // 1 + index among the walls, 0: not one
                 if (w != 0 && wall != 6 && w != wall + 1) continue;
                 idx.push_back(i);
             }
         }
-        k.classOff[kCls] = (int)idx.size();
+        k.classOff[kClsMax] = (int)idx.size();
         // camera rays: the per-row primitive lists (build_camera_cull)
         if (!cc.rowOff.empty()) {
             HIPCHECK(hipMalloc(&S.dRowOff, cc.rowOff.size() * sizeof(int)));
@@ -1387,7 +1411,7 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
         HIPCHECK(hipMalloc(&S.dClassIdx, idx.size() * sizeof(int)));
         HIPCHECK(hipMemcpy(S.dClassIdx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
     }
-    S.ldsBytes = sizeof(MaterialDev) * nmats + kMiscWords * sizeof(uint32_t) +
+    S.ldsBytes = sizeof(MaterialDev) * nmats + (size_t)miscWords(S.mesh ? kClsMax : kCls) * sizeof(uint32_t) +
                  (S.many ? manyHitBytes(ngeoms) + (size_t)k.nCubes * 54 * sizeof(float) + manyFramePad(k.nCubes) +
                                (size_t)ngeoms * kSphRowFloats * sizeof(float) +
                                    std::max((size_t)kListMax * kBlock, ((size_t)k.nSphCull + 7) / 8 * 8) * sizeof(uint16_t)
@@ -1410,7 +1434,7 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
         int rc = persistent_grid(first ? kFirst : kNext, S.ldsBytes, &grid);
         if (rc) return rc;
         if (grid > S.numTilesMax) grid = S.numTilesMax;
-        grid = (grid / kSub) * kSub;      // T % kSub == blockIdx % kSub for every tile T of a workgroup
+        grid = (grid / kSub) * kSub;      // T % kSub == blockIdx % kSub for every tile T of a workgroup (kSub: a multiple of the mesh scenes' 4 too)
         if (grid < kSub) grid = kSub;
     }
     // Camera-ray bounce: tile T covers pixels 256 T ... of the row-major frame and a workgroup owns the tiles b, b + grid,

@@ -22,6 +22,10 @@ constexpr int kCls = 2 * kOct;       // ... and by "may hit a small primitive" (
 #endif
 constexpr int kSub = PT_KSUB;        // append-counter shards per class (workgroup blockIdx % kSub; PT_KSUB: shard-count experiments only)
 constexpr int kSeg = kCls * kSub;    // path buffers are split into kSeg segments with one append counter each
+// Scenes with triangle meshes bin by TWO candidate bits instead of one (class bits 3 and 4: "may hit a binned primitive of group 0 /
+// of group 1" -- pt_init puts the costliest mesh alone into group 1): 32 classes of kSeg / 32 shards each in the same kSeg segments.
+// A tile then walks only the mesh its paths can hit instead of every mesh one after the other with part of its lanes (round 4).
+constexpr int kClsMax = 2 * kCls;
 static_assert(kSeg % 64 == 0, "setupTile compares kSeg / 64 prefix entries per lane");
 constexpr int kBinMax = 4;           // at most this many small primitives take part in the binning
 constexpr int kEmitMax = 8;          // emissive primitives the direct-lighting bounce chooses from
@@ -35,8 +39,9 @@ constexpr int kMinChunkShift = 11;   // chunks hold at least 2048 paths: a multi
 // record (inverseTransform rows, transform rows, GeomDev::invZ, 4 B of padding), spheres a lane can record per tile
 constexpr int kNanWords = 12;        // nine NaNs (+ padding): the "face frame" of a cube hit without an exit slab (cubeFace: a ray of NaNs)
 constexpr int kTicketWords = 4;      // the workgroup's next ticket (+ padding)
-constexpr int kMiscWords = 2 * kWaves * kCls + 5 * kCls + kSeg + (kSeg + 2) + 2 * PT_MAX_BATCH + 2 + kNanWords + kTicketWords;
-static_assert(kMiscWords % 4 == 0, "the sphere records that follow are read as float4");
+// LDS words of the fixed scratch of an instantiation with `cls` queue classes (16, or the mesh scenes' 32)
+constexpr int miscWords(int cls) { return 2 * kWaves * cls + 5 * cls + kSeg + (kSeg + 2) + 2 * PT_MAX_BATCH + 2 + kNanWords + kTicketWords; }
+static_assert(miscWords(kCls) % 4 == 0 && miscWords(kClsMax) % 4 == 0, "the sphere records that follow are read as float4");
 constexpr int kSphRowFloats = 28;
 constexpr int kListMax = 8;
 constexpr int kCtrPad = 32;          // one counter per 128-byte line: same-line atomics serialise at the memory side
@@ -126,7 +131,7 @@ struct KParams {
     int   nSphCull;                    // sphere-heavy scenes: entries of BounceArgs::sphCull (even: padded with a copy of the last one)
     float sphDirScale;                 // ... and the factor s >= 1 / sqrt(1 - K) on the sweep's unit direction (ptd::sphereHalfLineExcessScaled)
     int   meshStackOff;                // scenes with meshes: byte offset of the lanes' traversal stacks in the dynamic LDS ([levels][kBlock] words)
-    int   classOff[kCls + 1];          // later bounces: the primitives a tile of class c has to look at are classIdx[classOff[c] ..
+    int   classOff[kClsMax + 1];          // later bounces: the primitives a tile of class c has to look at are classIdx[classOff[c] ..
                                        // classOff[c + 1]) (BounceArgs::classIdx): not the binned ones unless the class says so, of the walls only
                                        // the class's own, in sphere-heavy scenes no sphere (those come from sphCull)
     int   emitGeom[kEmitMax];
@@ -445,6 +450,7 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
     // Layout: the fixed-size scratch first (constant offsets), then the tables whose sizes depend on the scene.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *const s_misc = reinterpret_cast<uint32_t *>(smem);
+    constexpr int kMiscWords = miscWords(MESH ? kClsMax : kCls);
     MaterialDev *const smats = reinterpret_cast<MaterialDev *>(smem + kMiscWords * sizeof(uint32_t));
 #define S_GEOMHIT(nmats_) (reinterpret_cast<GeomHitDev *>(smem + kMiscWords * sizeof(uint32_t) + sizeof(MaterialDev) * (nmats_)))
 // sphere-heavy scenes (MANY): compact hit records, then the cubes' face frames, then the per-primitive matrices and the lanes' lists
@@ -452,10 +458,12 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
 #define S_FRAMES(nmats_, ngeoms_) (reinterpret_cast<float *>(smem + kMiscWords * sizeof(uint32_t) + sizeof(MaterialDev) * (nmats_) + manyHitBytes(ngeoms_)))
 #define S_SPH(nmats_, ngeoms_, ncubes_) (reinterpret_cast<float *>(smem + kMiscWords * sizeof(uint32_t) + sizeof(MaterialDev) * (nmats_) + \
                                          (MANY ? manyHitBytes(ngeoms_) + (size_t)(ncubes_) * 54 * sizeof(float) + manyFramePad(ncubes_) : sizeof(GeomHitDev) * (ngeoms_))))
-    uint32_t *const s_wave = s_misc;                       // [kWaves][kCls] survivors per wave and class (zero between tiles)
-    uint32_t *const s_base = s_wave + 2 * kWaves * kCls;       // [5][kCls] this tile's output run per class: first slot, paths before the
+    // queue classes of this instantiation and append-counter shards per class (see kClsMax)
+    constexpr int CLS = MESH ? kClsMax : kCls, SUB = kSeg / CLS, CLSBITS = MESH ? 5 : 4;
+    uint32_t *const s_wave = s_misc;                       // [2][kWaves][CLS] survivors per wave and class (zero between tiles)
+    uint32_t *const s_base = s_wave + 2 * kWaves * CLS;        // [5][CLS] this tile's output run per class: first slot, paths before the
                                                            //           chunk boundary, first slot behind it; the class's last chunk lookup (reserveRun)
-    uint32_t *const s_segcnt = s_base + 5 * kCls;          // [kSeg]   paths per input segment
+    uint32_t *const s_segcnt = s_base + 5 * CLS;           // [kSeg]   paths per input segment
     uint32_t *const s_segpre = s_segcnt + kSeg;            // [kSeg+2] tile prefix per input segment, [kSeg+1] = live paths
     uint32_t *const s_iterHash = s_segpre + kSeg + 2;      // [2][PT_MAX_BATCH] iterationHash(iter + b, depth) and (iter + b, 0)
     const float *const s_nan = reinterpret_cast<const float *>(s_iterHash + 2 * PT_MAX_BATCH + 2);   // [kNanWords] NaNs: see cubeFace
@@ -510,7 +518,7 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
                     ts[q] = (cs[q] + kBlock - 1) / kBlock;
                     // (the last bounce of a scene whose emitters are all binned: the tiles of the classes that cannot reach one have
                     // nothing to add -- they get no tile index at all instead of being stepped over one by one)
-                    if (skipNonCand && ((uint32_t)(sgi / kSub) & 8u) == 0u) ts[q] = 0u;
+                    if (skipNonCand && ((uint32_t)(sgi / SUB) >> 3) == 0u) ts[q] = 0u;
                     inc += ts[q];
                     sum += cs[q];
                 }
@@ -536,8 +544,8 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
         if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctrl->sum_live[depth], (unsigned long long)nLive);
         // (camera rays: the pixels outside the tiles' index space are misses; workgroup 0 tallies them, tiles or no tiles)
         if (blockIdx.x >= numTiles && !(FIRST && blockIdx.x == 0)) return;
-        if (threadIdx.x < 2 * kWaves * kCls) s_wave[threadIdx.x] = 0u;
-        if (threadIdx.x < kCls) s_base[3 * kCls + threadIdx.x] = 0xffffffffu;   // no chunk looked up yet
+        if (threadIdx.x < 2 * kWaves * CLS) s_wave[threadIdx.x] = 0u;
+        if (threadIdx.x < CLS) s_base[3 * CLS + threadIdx.x] = 0xffffffffu;   // no chunk looked up yet
         if (threadIdx.x < kNanWords) s_iterHash[2 * PT_MAX_BATCH + 2 + threadIdx.x] = 0x7fc00000u;
         // (only the batch's own iterations: a batch of 32 needs 64 of the 512 entries -- every workgroup of every launch fills this table)
         {
@@ -668,10 +676,10 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
         const uint32_t segFirst = s_segpre[sgIn];
         const uint32_t local = (T - segFirst) * kBlock + tid;
         m.valid = local < s_segcnt[sgIn];
-        m.cls = sgIn / kSub;
+        m.cls = sgIn / SUB;
         // The last bounce only asks whether a path ends on an emitter (S7: no scatter).  When every emitter of the scene
         // is a binned small primitive, the paths of a non-candidate tile certainly miss all of them: nothing to add.
-        if (skipNonCand != 0u && (m.cls & 8u) == 0u) return false;
+        if (skipNonCand != 0u && (m.cls >> 3) == 0u) return false;
         // the tile's chunk (a chunk is a multiple of the tile size): j-th chunk of the segment, wave-uniform lookup through the
         // scalar cache (entries were written by the previous launch; the 0-th chunk of a segment is static)
         const uint32_t q0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)((T - segFirst) * kBlock));
@@ -1239,7 +1247,8 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
                                     CullGroup cg;
                                     cg.centre[0] = __int_as_float(v[8 * h]); cg.centre[1] = __int_as_float(v[8 * h + 1]); cg.centre[2] = __int_as_float(v[8 * h + 2]);
                                     cg.cullR2 = __int_as_float(v[8 * h + 3]); cg.cullK = __int_as_float(v[8 * h + 4]);
-                                    cand |= certainMiss(cg, norg, ndir, ndd) ? 0u : 1u;
+                                    // (the primitive's candidate bit: 1, or 2 for the mesh scenes' group 1 -- word 5 of its row)
+                                    cand |= certainMiss(cg, norg, ndir, ndd) ? 0u : (MESH ? (uint32_t)v[8 * h + 5] : 1u);
                                 }
                             }
                             smallCandI = cand;
@@ -1318,7 +1327,7 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
             if (Tnext < numTiles) loadTile(nextMeta, nextRegs);
         }
         probe(18);                                              // (compaction)
-        const bool alive = aliveI != 0u, smallCand = smallCandI != 0u;
+        const bool alive = aliveI != 0u;
 
         if (!(hotNow() & kHotLast)) {                                 // S8: compaction into `out`, binned by class
             // The compaction is the tile's latency chain (barrier, reservation round trip, barrier, stores): its waves issue
@@ -1338,12 +1347,12 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
             } else {
                 cls = (dir.x < 0.0f ? 1u : 0u) | (dir.y < 0.0f ? 2u : 0u) | (dir.z < 0.0f ? 4u : 0u);
             }
-            cls |= smallCand ? 8u : 0u;
+            cls |= smallCandI << 3;                             // (bit 3; mesh scenes: bits 3 and 4)
             // the lanes of this lane's class: per class bit k the ballot of the bit, taken as it is where the lane's own bit is set and
             // complemented where it is clear (bit - 1 = 0 or ~0) -- 32-bit halves, three instructions per bit and half
             uint32_t sameLo = (uint32_t)ba, sameHi = (uint32_t)(ba >> 32);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < CLSBITS; ++k) {
                 const uint32_t bit = (cls >> k) & 1u;
                 const unsigned long long bk = __ballot(bit != 0u);
                 const uint32_t flip = bit - 1u;
@@ -1351,33 +1360,33 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
                 sameHi &= (uint32_t)(bk >> 32) ^ flip;
             }
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi(sameHi, __builtin_amdgcn_mbcnt_lo(sameLo, 0u));
-            if (alive && rank == 0u) wv[wave * kCls + cls] = (uint32_t)(__popc(sameLo) + __popc(sameHi));   // the class's first lane
+            if (alive && rank == 0u) wv[wave * CLS + cls] = (uint32_t)(__popc(sameLo) + __popc(sameHi));   // the class's first lane
             probe(21);                                          // (first barrier)
             __syncthreads();
             probe(22);                                          // (reservation)
             uint32_t tk = 0u;
-            if (ticketed && tid == (uint32_t)kCls) {            // (lane 16 of wave 0: in flight together with the reservation's atomics)
+            if (ticketed && tid == (uint32_t)CLS) {             // (the lane behind the reserving ones, wave 0: in flight together with the reservation's atomics)
                 const ArgsPtr A = launder(kargs);
                 tk = atomicAdd(&A->ctrl->ticket[A->parity][A->depth][blockIdx.x % kTicketShards][0], 1u);
             }
-            if (tid < kCls) {
+            if (tid < CLS) {
                 const ArgsPtr A = launder(kargs);
                 Ctrl *const ctrl = A->ctrl;
                 const uint32_t poolChunks = (uint32_t)A->prm.poolChunks;
                 const int parity = A->parity, dnext = A->depth + 1;
                 uint32_t total = 0;
 #pragma unroll
-                for (int w = 0; w < kWaves; ++w) total += wv[w * kCls + tid];
-                const uint32_t oseg = tid * kSub + (blockIdx.x % kSub);
+                for (int w = 0; w < kWaves; ++w) total += wv[w * CLS + tid];
+                const uint32_t oseg = tid * SUB + (blockIdx.x % SUB);
                 uint32_t r0, sp, r1;
                 reserveRun(&ctrl->pos[parity][dnext][oseg][0], &ctrl->bump[parity][dnext][0], A->out.list + (size_t)oseg * poolChunks, oseg,
-                           poolChunks, (uint32_t)A->prm.chunkShift, A->genOut, total, &ctrl->error, s_base[3 * kCls + tid],
-                           s_base[4 * kCls + tid], r0, sp, r1);
+                           poolChunks, (uint32_t)A->prm.chunkShift, A->genOut, total, &ctrl->error, s_base[3 * CLS + tid],
+                           s_base[4 * CLS + tid], r0, sp, r1);
                 s_base[tid] = r0;
-                s_base[kCls + tid] = sp;
-                s_base[2 * kCls + tid] = r1;
+                s_base[CLS + tid] = sp;
+                s_base[2 * CLS + tid] = r1;
             }
-            if (ticketed && tid == (uint32_t)kCls) s_ticket[0] = 2u * gridDim.x + tk * (uint32_t)kTicketShards + blockIdx.x % kTicketShards;
+            if (ticketed && tid == (uint32_t)CLS) s_ticket[0] = 2u * gridDim.x + tk * (uint32_t)kTicketShards + blockIdx.x % kTicketShards;
             probe(23);                                          // (second barrier)
             __syncthreads();
             if (kTickets) Tn1 = ticketed ? s_ticket[0] : Tnext + gridDim.x;
@@ -1392,11 +1401,11 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
                 uint32_t waveOff = 0u;
 #pragma unroll
                 for (int w = 0; w < kWaves - 1; ++w) {
-                    const uint32_t wq = wv[w * kCls + cls];
+                    const uint32_t wq = wv[w * CLS + cls];
                     waveOff += wave > w ? wq : 0u;
                 }
-                const uint32_t r = waveOff + rank, sp = s_base[kCls + cls];
-                const uint32_t slot = r < sp ? s_base[cls] + r : s_base[2 * kCls + cls] + (r - sp);
+                const uint32_t r = waveOff + rank, sp = s_base[CLS + cls];
+                const uint32_t slot = r < sp ? s_base[cls] + r : s_base[2 * CLS + cls] + (r - sp);
                 char *const dst = reinterpret_cast<char *>(A->out.base);
                 const size_t ocap = (size_t)A->out.cap;
                 *reinterpret_cast<float4 *>(dst + 16 * (size_t)slot) = make_float4(org.x, org.y, org.z, dir.x);
@@ -1410,8 +1419,8 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
             // wave finished those reads before it arrived at THIS tile's first barrier, so each wave may now clear its own
             // row of it for the next tile (its own next writes follow in program order; the other waves' next reads of that
             // row come after the next tile's first barrier).  s_base is rewritten only after the next tile's first barrier.
-            wvSel ^= (uint32_t)(kWaves * kCls);
-            if (lane < kCls) s_wave[wvSel + wave * kCls + lane] = 0u;
+            wvSel ^= (uint32_t)(kWaves * CLS);
+            if (lane < CLS) s_wave[wvSel + wave * CLS + lane] = 0u;
             __builtin_amdgcn_s_setprio(0);
         } else if (kTickets) {
             Tn1 = Tnext + gridDim.x;
