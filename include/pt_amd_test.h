@@ -35,6 +35,14 @@ int pt_test_sphere_cull_sweep(const PtGeom *geoms, int ngeoms, uint64_t seed, in
  * although src/intersections.h:101-143 returns a hit (must be 0). */
 int pt_test_sphere_halfline_sweep(const PtGeom *geoms, int ngeoms, uint64_t seed, int64_t rays, uint64_t *culled, uint64_t *behind,
                                   uint64_t *violations);
+/* The sphere CLUSTERS' box certificates (sphere-heavy scenes without meshes: a survivor's class bits 3 / 4 say which of the two clusters of
+ * spheres its ray can hit; pt_api.hip: build_sphere_clusters builds them for `geoms` -- a whole scene, spheres and cubes -- exactly as
+ * pt_init does) soundness: `rays` rays in four families (scatters off the spheres; from the scene's extent towards a cluster's box and
+ * its shell; from close to a box; axis- and plane-parallel directions).  certified2[g] = certificates issued for cluster g, *violations
+ * = spheres of a cluster certified as missed that src/intersections.h:101-143 hits (must be 0).  info18 (may be null): the bound on
+ * the origins, the size of cluster 0 in the table, the two boxes {lo, hi, -, -}. */
+int pt_test_sphere_cluster_sweep(const PtGeom *geoms, int ngeoms, uint64_t seed, int64_t rays, uint64_t *certified2, uint64_t *violations,
+                                 float *info18);
 /* wallCertainMiss (world-space culling of large cubes against their inflated bounding boxes, which classes the queue by
  * the wall a path can still hit) soundness: as above, for the cubes of `geoms`. */
 int pt_test_wall_box_sweep(const PtGeom *geoms, int ngeoms, uint64_t seed, int64_t rays, uint64_t *culled,

@@ -11,25 +11,26 @@ pt = ge.load_package()
 pt.LIB_PATH = os.path.join(ROOT, "project3-cuda-path-tracer_amd", "csrc", "libpt_amd_timeline.so")   # before the first call
 L = pt.lib()
 L.pt_probe_timeline.argtypes = [C.POINTER(C.c_uint64)]
-names = {14: "tile start: set-up / camera ray", 15: "nearest-hit loop", 16: "after the loop -> a hit's record", 9: "shading: hit record, normal, material",
+names = {14: "tile start: set-up / camera ray", 15: "nearest-hit loop", 24: "sphere-heavy: sweep of the packed spheres", 25: "sphere-heavy: the candidates' passes", 16: "after the loop -> a hit's record", 9: "shading: hit record, normal, material",
          10: "scatter: engine, branch by material", 11: "hemisphere sample", 12: "bounding-ball certificates", 13: "wall certificates, class", 17: "next tile: segment look-up (LDS)",
          26: "next tile: chunk look-up (scalar cache)", 27: "next tile: 3 loads issued",
          18: "compaction: ballots, ranks", 21: "wait at the first barrier", 22: "reservation (atomic round trip) / waves 1-3 idle", 23: "wait at the second barrier",
          19: "stores", 20: "tile end -> next tile start", 30: "prologue (staging, scan of the segment counts)"}
-order = [30, 14, 15, 16, 9, 10, 11, 12, 13, 17, 26, 27, 18, 21, 22, 23, 19, 20]
+order = [30, 14, 15, 24, 25, 16, 9, 10, 11, 12, 13, 17, 26, 27, 18, 21, 22, 23, 19, 20]
 scene = sys.argv[1] if len(sys.argv) > 1 else "cornell.txt"
 res = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1280, 720)
+batch = int(sys.argv[4]) if len(sys.argv) > 4 else 32
 for depth, pipeline in ((8, 2),):
     sc = pt.Scene(os.path.join(ROOT, "scenes", scene))
     sc.set_resolution(*res)
     pt.pathtraceFree()
-    pt.pathtraceInit(sc, traceDepth=depth, max_batch=32, pipeline_depth=pipeline)
+    pt.pathtraceInit(sc, traceDepth=depth, max_batch=batch, pipeline_depth=pipeline)
     out = (C.c_uint64 * 128)()
-    pt.pathtrace_batch(None, 0, 1, 32)
+    pt.pathtrace_batch(None, 0, 1, batch)
     pt.sync()
     L.pt_probe_timeline(out)                                  # (warm-up discarded)
-    for it in range(33, 33 + 8 * 32, 32):
-        pt.pathtrace_batch(None, 0, it, 32)
+    for it in range(1 + batch, 1 + batch + 8 * batch, batch):
+        pt.pathtrace_batch(None, 0, it, batch)
     pt.sync()
     L.pt_probe_timeline(out)
     v = [int(x) for x in out]

@@ -60,7 +60,7 @@ TEST_ABI_SYMBOLS = [
     "pt_test_slab_quotients", "pt_test_slab_quotients_sweep", "pt_test_sphere_cull_sweep", "pt_test_unscaled_sqrt_sweep",
     "pt_test_force_fault", "pt_test_pow", "pt_test_wall_box_sweep", "pt_test_mesh_intersect", "pt_test_mesh_bvh",
     "pt_test_mesh_cull_sweep", "pt_test_camera_cull_sweep", "pt_test_camera_cull_tables",
-    "pt_test_wall_plane_sweep", "pt_test_sphere_halfline_sweep", "pt_test_camera_cull_margin",
+    "pt_test_wall_plane_sweep", "pt_test_sphere_halfline_sweep", "pt_test_sphere_cluster_sweep", "pt_test_camera_cull_margin",
 ]
 
 
@@ -122,6 +122,7 @@ def _bind(L, with_tests):
         L.pt_test_slab_quotients_sweep.argtypes = [C.c_uint64, i64, u64p]
         L.pt_test_sphere_cull_sweep.argtypes = [vp, i32, C.c_uint64, i64, u64p, u64p]
         L.pt_test_sphere_halfline_sweep.argtypes = [vp, i32, C.c_uint64, i64, u64p, u64p, u64p]
+        L.pt_test_sphere_cluster_sweep.argtypes = [vp, i32, C.c_uint64, i64, u64p, u64p, vp]
         L.pt_test_unscaled_sqrt_sweep.argtypes = [u64p]
         L.pt_test_force_fault.argtypes = [i32]
         L.pt_test_pow.argtypes = [vp, vp, i32, vp]
@@ -565,6 +566,17 @@ def test_sphere_halfline_sweep(geoms, seed, rays):
     culled, behind, bad = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
     _tcheck(test_lib().pt_test_sphere_halfline_sweep(_p(geoms), len(geoms), seed, rays, C.byref(culled), C.byref(behind), C.byref(bad)))
     return int(culled.value), int(behind.value), int(bad.value)
+
+
+def test_sphere_cluster_sweep(geoms, seed, rays):
+    """geoms: a whole scene (spheres and cubes) -> (certificates issued per cluster [2], violations, {omax, n0, boxes[2][6]})"""
+    geoms = np.ascontiguousarray(geoms)
+    cert = (C.c_uint64 * 2)()
+    bad = C.c_uint64(0)
+    info = np.zeros(18, np.float32)
+    _tcheck(test_lib().pt_test_sphere_cluster_sweep(_p(geoms), len(geoms), seed, rays, cert, C.byref(bad), info.ctypes.data))
+    boxes = info[2:].reshape(2, 8)[:, :6].copy()
+    return [int(cert[0]), int(cert[1])], int(bad.value), {"omax": float(info[0]), "n0": int(info[1]), "boxes": boxes}
 
 
 def test_wall_box_sweep(geoms, seed, rays):

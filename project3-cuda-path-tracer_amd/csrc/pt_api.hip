@@ -115,7 +115,7 @@ struct State {
     bool many = false;      // more than kBinMax spheres: the k_bounce<., true> variants (per-lane sphere lists)
     bool dof = false;       // thin-lens camera: the k_bounce<true, ., true> variants for the camera-ray bounce
     bool plain = false;     // no refractive material, no specular exponent on a reflective one, no direct lighting: k_bounce<..., PLAIN>
-    size_t ldsBytes = 0;
+    size_t ldsBytes = 0, ldsBytesNext = 0;   // dynamic LDS of the camera-ray launch / of the later ones
     long long iterations = 0;
     long long seq = 0;      // batches enqueued since pt_init: slot = seq % nslots
     // PT_FLAG_TRACE_AHEAD: batches traced ahead of the pt_iterate calls that will ask for their iterations, oldest first.
@@ -320,6 +320,105 @@ double wall_box(const PtGeom &g, WallBox &w, double *omax = nullptr) {
         if (!std::isfinite(w.lo[r]) || !std::isfinite(w.hi[r])) return -1.0;
     }
     return S_;
+}
+
+// Sphere-heavy scenes: the spheres in TWO SPATIAL CLUSTERS.  `sc` (every sphere's packed culling data, thresholds already scaled) is split at
+// the median centre along one axis and reordered, cluster 0 first (n0 entries, even: padded with a copy of its last one).  A survivor's class bits
+// 3 / 4 say which clusters its ray can hit (k_bounce: a slab certificate, ptd::wallCertainMiss, against each cluster's box), and a tile of the
+// next bounce sweeps only those.  The binned primitives (group 0) share bit 3: axis and order of the halves are the ones with the smallest sum of
+// (surface area of what a bit stands for) x (spheres behind it).  A choice that only steers which tiles skip which tests; results never depend on it.
+// What the certificate rests on: box g holds, for every sphere of cluster g, the ball of radius sqrt(cullR2 + K ocMax^2) (1 + 1e-6) around its
+// centre -- the sphere's own half-line certificate (ptd::sphereHalfLineExcess: distance^2 of the centre from the half-line > cullR2 + K |oc|^2, with
+// |oc| <= ocMax = omax + |centre| for every origin a certificate is issued for, |x| + |y| + |z| <= omax) holds for every half-line that misses
+// that ball -- and is inflated like a wall's box (wall_box: delta = 4e-5 S against ~2e-7 (|o| + S) of rounding in the slab test, |o| <= 5 S).
+// Returns false (and leaves everything as it was) when no clusters can be built: fewer than two spheres, or one that is never culled.
+// (tests/test_gpu_parity.py::test_sphere_cluster_boxes_never_reject_a_hit: pt_test_sphere_cluster_sweep, 2^28 rays, 0 violations.)
+bool build_sphere_clusters(const PtGeom *geoms, int ngeoms, const std::vector<GeomDev> &hg, const std::vector<int> &binned, std::vector<SphereCull> &sc,
+                           int &n0, float &omaxOut, float box[2][8]) {
+    // a sphere's half-line ball for the origins certificates are issued for: radius^2 = cullR2 + K ocMax^2 (scaled thresholds: the larger)
+    auto build = [&](const std::vector<SphereCull> &v, double omax, double lo[3], double hi[3]) {
+        for (int a = 0; a < 3; ++a) { lo[a] = INFINITY; hi[a] = -INFINITY; }
+        for (const SphereCull &e : v) {
+            const double cn = std::sqrt((double)e.centre[0] * e.centre[0] + (double)e.centre[1] * e.centre[1] + (double)e.centre[2] * e.centre[2]);
+            const double ocMax = omax + cn;
+            const double r = std::sqrt((double)e.cullR2 + (double)e.cullK * ocMax * ocMax) * (1.0 + 1e-6);
+            for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], (double)e.centre[a] - r); hi[a] = std::max(hi[a], (double)e.centre[a] + r); }
+        }
+    };
+    auto area = [](const double lo[3], const double hi[3]) {
+        const double x = hi[0] - lo[0], y = hi[1] - lo[1], z = hi[2] - lo[2];
+        return x * y + y * z + z * x;
+    };
+    bool finite = true;
+    for (const SphereCull &e : sc) finite = finite && std::isfinite(e.cullR2) && std::isfinite(e.cullK);
+    if (!finite || sc.size() < 2) return false;
+    double bestCost = INFINITY;
+    std::vector<SphereCull> best0, best1;
+    for (int axis = 0; axis < 3; ++axis)
+        for (int swap = 0; swap < 2; ++swap) {
+            std::vector<SphereCull> v = sc;
+            std::stable_sort(v.begin(), v.end(), [&](const SphereCull &a, const SphereCull &b) { return a.centre[axis] < b.centre[axis]; });
+            const size_t h = v.size() / 2;
+            std::vector<SphereCull> c0(v.begin(), v.begin() + h), c1(v.begin() + h, v.end());
+            if (swap) std::swap(c0, c1);
+            double lo0[3], hi0[3], lo1[3], hi1[3];
+            build(c0, 0.0, lo0, hi0);
+            build(c1, 0.0, lo1, hi1);
+            for (int i : binned) {                                // bit 3 also stands for the binned primitives
+                const GeomDev &G = hg[i];
+                for (int a = 0; a < 3; ++a) { lo0[a] = std::min(lo0[a], (double)G.centre[a] - G.boundR); hi0[a] = std::max(hi0[a], (double)G.centre[a] + G.boundR); }
+            }
+            const double cost = area(lo0, hi0) * (double)c0.size() + area(lo1, hi1) * (double)c1.size();
+            if (cost < bestCost) { bestCost = cost; best0 = c0; best1 = c1; }
+        }
+    // (a scattered ray starts on a primitive: the scene's own extent, |x| + |y| + |z| over its bounding box, with a quarter to spare,
+    // bounds the origins worth a certificate -- and K |oc|^2 grows with the bound)
+    double omax = 0.0, S_[2], big_[2];
+    {
+        double slo[3] = {INFINITY, INFINITY, INFINITY}, shi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int i = 0; i < ngeoms; ++i) {
+            WallBox wb;
+            if (geoms[i].type == PT_CUBE && wall_box(geoms[i], wb) >= 0)
+                for (int a = 0; a < 3; ++a) { slo[a] = std::min(slo[a], (double)wb.lo[a]); shi[a] = std::max(shi[a], (double)wb.hi[a]); }
+            else if (std::isfinite(hg[i].boundR))
+                for (int a = 0; a < 3; ++a) { slo[a] = std::min(slo[a], (double)hg[i].centre[a] - hg[i].boundR); shi[a] = std::max(shi[a], (double)hg[i].centre[a] + hg[i].boundR); }
+        }
+        for (int a = 0; a < 3; ++a) omax += std::max(std::fabs(slo[a]), std::fabs(shi[a]));
+        omax *= 1.25;
+        if (!std::isfinite(omax)) omax = 0.0;
+    }
+    float bx[2][8];
+    for (int g = 0; g < 2; ++g) for (int q = 0; q < 8; ++q) bx[g][q] = 0.0f;
+    for (int pass = 0; pass < 2; ++pass)          // pass 0: the boxes' sizes with |oc| = |c|, for the bound; pass 1: the boxes for the bound that gave
+        for (int g = 0; g < 2; ++g) {
+            double lo[3], hi[3];
+            build(g ? best1 : best0, pass ? omax : 0.0, lo, hi);
+            double diag = 0, big = 0;
+            for (int a = 0; a < 3; ++a) {
+                diag += (hi[a] - lo[a]) * (hi[a] - lo[a]);
+                big = std::max(big, std::max(std::fabs(lo[a]), std::fabs(hi[a])));
+            }
+            S_[g] = std::max(std::sqrt(diag), big); big_[g] = big;
+            if (!pass) omax = std::min(omax, 5.0 * S_[g] - big);
+            else {
+                const double delta = 4e-5 * S_[g];
+                for (int a = 0; a < 3; ++a) {
+                    bx[g][a] = std::nextafter((float)(lo[a] - delta), -INFINITY);
+                    bx[g][3 + a] = std::nextafter((float)(hi[a] + delta), INFINITY);
+                    finite = finite && std::isfinite(bx[g][a]) && std::isfinite(bx[g][3 + a]);
+                }
+                // (the boxes only grew since pass 0 -- and a box built for a larger bound than the final one is the conservative side)
+                omax = std::min(omax, 5.0 * S_[g] - big_[g]);
+            }
+        }
+    if (!finite || !(omax > 0.0) || !std::isfinite(omax)) return false;
+    if (best0.size() % 2) best0.push_back(best0.back());      // (two per scalar load; testing a sphere twice changes nothing)
+    sc = best0;
+    sc.insert(sc.end(), best1.begin(), best1.end());
+    n0 = (int)best0.size();
+    omaxOut = std::nextafter((float)omax, 0.0f);
+    memcpy(box, bx, sizeof bx);
+    return true;
 }
 
 // The walls of a scene -- its large cubes: not binned, finite, at most kWallMax of them, the largest first -- with what the survivors'
@@ -726,7 +825,7 @@ int launch_bounce(Slot &sl, int iter, int batch, int depth, bool lastBounce, flo
     ba.hostFault = S.hostFaultDev;
     void *kargs[] = {&ba};
     const bool first = depth == 1;
-    HIPCHECK(hipLaunchKernel(bounce_kernel(first, first && S.dof), dim3(first ? S.gridFirst : S.grid), dim3(kBlock), kargs, S.ldsBytes, sl.stream));
+    HIPCHECK(hipLaunchKernel(bounce_kernel(first, first && S.dof), dim3(first ? S.gridFirst : S.grid), dim3(kBlock), kargs, first ? S.ldsBytes : S.ldsBytesNext, sl.stream));
     if (e0) {
         HIPCHECK(hipEventRecord(e1, sl.stream));
         S.evBounce.emplace_back(e0, e1);
@@ -1372,6 +1471,21 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
         k.sphDirScale = sdir;
         for (SphereCull &e : sc)
             if (std::isfinite(e.cullR2)) e.cullR2 = std::nextafter((float)((double)e.cullR2 * (double)sdir * (double)sdir), INFINITY);
+        // two spatial CLUSTERS (scenes without meshes, whose second candidate bit is free): build_sphere_clusters
+        k.sphN0 = 0; k.sphOMax = 0.0f;
+        for (int g = 0; g < 2; ++g) for (int q = 0; q < 8; ++q) k.sphBox[g][q] = 0.0f;
+        if (meshRecs.empty()) {
+            std::vector<int> binned(k.binGeom, k.binGeom + k.nBinned);
+            build_sphere_clusters(geoms, ngeoms, hg, binned, sc, k.sphN0, k.sphOMax, k.sphBox);
+        }
+        if (k.sphOMax <= 0.0f) { k.sphN0 = 0; k.sphOMax = -1.0f; }      // no clusters: no certificate is issued, every tile sweeps the whole table
+        else if (k.nWalls > 0) {
+            // with the spheres behind candidate bits too, a survivor whose certificates leave no wall, no binned primitive and no cluster has
+            // nothing left to hit (KParams::allClassified) -- when there is no primitive of another kind
+            k.allClassified = 1;
+            for (int i = 0; i < ngeoms; ++i)
+                if (!hg[i].binned && (hg[i].flags & 28) == 0 && geoms[i].type != PT_SPHERE) k.allClassified = 0;
+        }
         if (sc.size() % 2) sc.push_back(sc.back());      // (two per scalar load; testing a sphere twice changes nothing)
         k.nSphCull = (int)sc.size();
         HIPCHECK(hipMalloc(&S.dSphCull, sc.size() * sizeof(SphereCull)));
@@ -1380,7 +1494,7 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     {   // Later bounces: which primitives a tile of queue class c looks at.  Class bit 3 = its paths may hit a binned primitive;
         // bits 0-2 in a scene with walls = the one wall they can still hit (6: any, 7: none), else the direction octant.
         std::vector<int> idx;
-        const int ncls = meshRecs.empty() ? kCls : kClsMax;                   // (mesh scenes: two candidate bits, 32 classes)
+        const int ncls = (S.mesh || S.many) ? kClsMax : kCls;                 // (mesh and sphere-heavy scenes: two candidate bits, 32 classes)
         for (int c = 0; c < kClsMax; ++c) {
             k.classOff[c] = (int)idx.size();
             if (c >= ncls) continue;
@@ -1411,16 +1525,21 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
         HIPCHECK(hipMalloc(&S.dClassIdx, idx.size() * sizeof(int)));
         HIPCHECK(hipMemcpy(S.dClassIdx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
     }
-    S.ldsBytes = sizeof(MaterialDev) * nmats + (size_t)miscWords(S.mesh ? kClsMax : kCls) * sizeof(uint32_t) +
-                 (S.many ? manyHitBytes(ngeoms) + (size_t)k.nCubes * 54 * sizeof(float) + manyFramePad(k.nCubes) +
-                               (size_t)ngeoms * kSphRowFloats * sizeof(float) +
-                                   std::max((size_t)kListMax * kBlock, ((size_t)k.nSphCull + 7) / 8 * 8) * sizeof(uint16_t)
-                         : sizeof(GeomHitDev) * ngeoms);
+    const size_t ldsFixed = sizeof(MaterialDev) * nmats + (size_t)miscWords((S.mesh || S.many) ? kClsMax : kCls) * sizeof(uint32_t) +
+                            (S.many ? manyHitBytes(ngeoms) + (size_t)k.nCubes * 54 * sizeof(float) + manyFramePad(k.nCubes) +
+                                          (size_t)ngeoms * kSphRowFloats * sizeof(float)
+                                    : sizeof(GeomHitDev) * ngeoms);
+    // (sphere-heavy scenes: the camera-ray launch keeps the lanes' candidate lists behind the tables, the later ones only the sweep's
+    // entry -> primitive map -- 4 KB less, which is what their seventh workgroup per CU needs)
+    const size_t sphMapBytes = ((size_t)k.nSphCull + 7) / 8 * 8 * sizeof(uint16_t);
+    S.ldsBytes = ldsFixed + (S.many ? std::max((size_t)kListMax * kBlock * sizeof(uint16_t), sphMapBytes) : 0);
+    S.ldsBytesNext = (S.many && !S.mesh) ? ldsFixed + sphMapBytes : 0;
     if (S.mesh) {        // the lanes' stacks of far children (ptd::meshIntersectionTest): kBlock words per level, behind everything else
         S.ldsBytes = (S.ldsBytes + 15) / 16 * 16;
         k.meshStackOff = (int)S.ldsBytes;
         S.ldsBytes += (size_t)std::max(meshStackNeed, 1) * kBlock * sizeof(uint32_t);
     }
+    if (S.ldsBytesNext == 0) S.ldsBytesNext = S.ldsBytes;
     if (S.ldsBytes > 160 * 1024) return fail(PT_ERR_INVALID, "pt_init: scene does not fit the 160 KiB LDS (%zu B)", S.ldsBytes);
     if (nmats >= 4096) return fail(PT_ERR_INVALID, "pt_init: more than 4095 materials");      // (TileArgs::hot holds nmats in 12 bits)
     const void *kFirst = bounce_kernel(true, S.dof);
@@ -1431,7 +1550,7 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     }
     for (int first = 0; first < 2; ++first) {
         int &grid = first ? S.gridFirst : S.grid;
-        int rc = persistent_grid(first ? kFirst : kNext, S.ldsBytes, &grid);
+        int rc = persistent_grid(first ? kFirst : kNext, first ? S.ldsBytes : S.ldsBytesNext, &grid);
         if (rc) return rc;
         if (grid > S.numTilesMax) grid = S.numTilesMax;
         grid = (grid / kSub) * kSub;      // T % kSub == blockIdx % kSub for every tile T of a workgroup (kSub: a multiple of the mesh scenes' 4 too)
@@ -1457,6 +1576,10 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
             }
         }
     }
+    if (getenv("PT_AMD_VERBOSE") && atoi(getenv("PT_AMD_VERBOSE")))       // experiments: what pt_init decided
+        fprintf(stderr, "pt_init: lds %zu / %zu B, grid %d / %d, mesh %d many %d plain %d, binned %d walls %d allClassified %d, sphCull %d (cluster 0: %d) omax %g\n",
+                S.ldsBytes, S.ldsBytesNext, S.gridFirst, S.grid, (int)S.mesh, (int)S.many, (int)S.plain, k.nBinned, k.nWalls, k.allClassified, k.nSphCull,
+                k.sphN0, (double)k.sphOMax);
     HIPCHECK(hipDeviceSynchronize());
     S.init = true;
     g_err.clear();
@@ -2020,6 +2143,73 @@ int pt_test_sphere_halfline_sweep(const PtGeom *geoms, int ngeoms, uint64_t seed
     *culled = h[0];
     *behind = h[1];
     *violations = h[2];
+    return PT_OK;
+}
+
+int pt_test_sphere_cluster_sweep(const PtGeom *geoms, int ngeoms, uint64_t seed, int64_t rays, uint64_t *certified2, uint64_t *violations, float *info18) {
+    NEED_GPU();
+    if (!geoms || ngeoms < 2 || !certified2 || !violations || rays < 0) return fail(PT_ERR_INVALID, "pt_test_sphere_cluster_sweep: bad argument");
+    // the clusters exactly as pt_init builds them for this scene (no primitive binned: binning only moves the choice of the split)
+    std::vector<GeomDev> hg(ngeoms);
+    std::vector<SphereCull> sc;
+    for (int i = 0; i < ngeoms; ++i) {
+        pack_geom(geoms[i], hg[i]);
+        if (geoms[i].type == PT_MESH) return fail(PT_ERR_INVALID, "pt_test_sphere_cluster_sweep: spheres and cubes only");
+        if (geoms[i].type != PT_SPHERE) continue;
+        SphereCull e;
+        memset(&e, 0, sizeof e);
+        for (int a = 0; a < 3; ++a) e.centre[a] = hg[i].centre[a];
+        e.cullR2 = hg[i].cullR2;
+        e.cullK = hg[i].cullK + kUnitDirSlack;
+        e.geom = i;
+        sc.push_back(e);
+    }
+    double kmax = 0.0;
+    for (const SphereCull &e : sc) kmax = std::max(kmax, (double)e.cullK);
+    const float sdir = std::nextafter((float)std::sqrt(1.0 / (1.0 - kmax)), INFINITY);
+    for (SphereCull &e : sc)
+        if (std::isfinite(e.cullR2)) e.cullR2 = std::nextafter((float)((double)e.cullR2 * (double)sdir * (double)sdir), INFINITY);
+    int n0 = 0;
+    float omax = 0.0f, box[2][8];
+    if (!build_sphere_clusters(geoms, ngeoms, hg, std::vector<int>(), sc, n0, omax, box))
+        return fail(PT_ERR_INVALID, "pt_test_sphere_cluster_sweep: no clusters for this scene");
+    std::vector<GeomDev> hs;
+    for (const SphereCull &e : sc) hs.push_back(hg[e.geom]);
+    WallBox hb[2];
+    memset(hb, 0, sizeof hb);
+    for (int g = 0; g < 2; ++g)
+        for (int a = 0; a < 3; ++a) { hb[g].lo[a] = box[g][a]; hb[g].hi[a] = box[g][3 + a]; }
+    F3 slo = F3{INFINITY, INFINITY, INFINITY}, shi = F3{-INFINITY, -INFINITY, -INFINITY};
+    for (int i = 0; i < ngeoms; ++i) {
+        const float r = hg[i].boundR;
+        if (!std::isfinite(r)) continue;
+        slo = F3{std::min(slo.x, hg[i].centre[0] - r), std::min(slo.y, hg[i].centre[1] - r), std::min(slo.z, hg[i].centre[2] - r)};
+        shi = F3{std::max(shi.x, hg[i].centre[0] + r), std::max(shi.y, hg[i].centre[1] + r), std::max(shi.z, hg[i].centre[2] + r)};
+    }
+    if (info18) {
+        info18[0] = omax; info18[1] = (float)n0;
+        for (int g = 0; g < 2; ++g) for (int q = 0; q < 8; ++q) info18[2 + 8 * g + q] = box[g][q];
+    }
+    DevBuf<GeomDev> ds;
+    DevBuf<WallBox> db;
+    DevBuf<unsigned long long> cnt;
+    UP(ds, hs.data(), (int)hs.size());
+    UP(db, hb, 2);
+    int rc = cnt.alloc(3);
+    if (rc) return rc;
+    HIPCHECK(hipMemset(cnt.p, 0, 24));
+    const int per_thread = 64, threads = 256;
+    long long blocks = (rays + (long long)per_thread * threads - 1) / ((long long)per_thread * threads);
+    if (blocks < 1) blocks = 1;
+    if (blocks > (1 << 22)) blocks = 1 << 22;
+    hipLaunchKernelGGL(k_sweep_sphere_clusters, dim3((unsigned)blocks), dim3(threads), 0, 0, ds.p, (int)hs.size(), n0, db.p, omax, slo, shi,
+                       (unsigned long long)seed, per_thread, cnt.p, cnt.p + 2);
+    HIPCHECK(hipDeviceSynchronize());
+    unsigned long long hc[3] = {0, 0, 0};
+    HIPCHECK(hipMemcpy(hc, cnt.p, 24, hipMemcpyDeviceToHost));
+    certified2[0] = hc[0];
+    certified2[1] = hc[1];
+    *violations = hc[2];
     return PT_OK;
 }
 

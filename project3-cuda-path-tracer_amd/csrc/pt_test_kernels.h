@@ -238,6 +238,81 @@ __global__ void k_sweep_wall_box(const GeomDev *geoms, const WallBox *walls, con
     if (nv) atomicAdd(violations, (unsigned long long)nv);
 }
 
+// Soundness sweep of the sphere CLUSTERS' box certificates (k_bounce: CLUSTER; pt_api.hip: build_sphere_clusters): `spheres` in table
+// order, the first n0 of them cluster 0; box[g] = cluster g's inflated world box; certificates are issued for origins with
+// |x| + |y| + |z| <= omax.  Rays in four families -- leaving a sphere's own surface as a scatter does (+-1e-3 along the normal); from a point
+// of the scene's extent (the walls, the interior) towards a cluster's box, its shell 0.9 .. 1.2 of the half extents included, where the
+// inflation is what decides; from close to a box outwards and along it; axis-parallel directions with exact zeros mixed in.  A box
+// certified as missed sends the ray through the FULL test of every sphere of that cluster: a hit is a VIOLATION (must be 0).
+__global__ void k_sweep_sphere_clusters(const GeomDev *spheres, int nspheres, int n0, const WallBox *box, float omax, F3 sceneLo, F3 sceneHi,
+                                        unsigned long long seed, int per_thread, unsigned long long *certified, unsigned long long *violations) {
+    unsigned long long x = seed + (blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ull;
+    unsigned int nc0 = 0, nc1 = 0, nv = 0;
+    for (int k = 0; k < per_thread; ++k) {
+        float u[12];
+        for (int j = 0; j < 12; ++j) {
+            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+            u[j] = (float)(x >> 40) * (1.0f / 16777216.0f);
+        }
+        const int gsel = u[10] < 0.5f ? 0 : 1;
+        const WallBox W = box[gsel];
+        const F3 lo = f3(W.lo[0], W.lo[1], W.lo[2]), hi = f3(W.hi[0], W.hi[1], W.hi[2]);
+        const F3 c = (lo + hi) * 0.5f, h = (hi - lo) * 0.5f;
+        const float shell = u[9] < 0.5f ? 0.9f + 0.3f * u[8] : u[8];
+        const F3 tgt = c + f3((2 * u[0] - 1) * h.x, (2 * u[1] - 1) * h.y, (2 * u[2] - 1) * h.z) * shell;
+        const int family = k & 3;
+        F3 org, dir;
+        if (family == 0) {              // a scatter off a sphere (any of them), any direction
+            const GeomDev &G = spheres[(int)(u[3] * (float)nspheres) % nspheres];
+            const F3 pobj = normalize(f3(u[4] - 0.5f, u[5] - 0.5f, u[6] - 0.5f)) * 0.5f;
+            const F3 P = mulMV(G.xf, pobj, 1.0f);
+            const F3 N = normalize(mulMV(G.invT, pobj, 0.0f));
+            org = P + N * (u[7] < 0.5f ? 0.001f : -0.001f);
+            dir = u[11] < 0.5f ? normalize(f3(u[0] - 0.5f, u[1] - 0.5f, u[2] - 0.5f)) : normalize(tgt - org);
+        } else if (family == 1) {       // from the scene's extent (a wall, the interior) towards the box and its shell
+            org = f3(sceneLo.x + u[4] * (sceneHi.x - sceneLo.x), sceneLo.y + u[5] * (sceneHi.y - sceneLo.y), sceneLo.z + u[6] * (sceneHi.z - sceneLo.z));
+            if (u[7] < 0.5f) {          // ... on one of the extent's six faces
+                const int face = (int)(u[7] * 12.0f);
+                if (face == 0) org.x = sceneLo.x; else if (face == 1) org.x = sceneHi.x; else if (face == 2) org.y = sceneLo.y;
+                else if (face == 3) org.y = sceneHi.y; else if (face == 4) org.z = sceneLo.z; else org.z = sceneHi.z;
+            }
+            dir = normalize(tgt - org);
+        } else if (family == 2) {       // from close to the box (2^-8 .. 2^2 of its size away from the target), towards it or away
+            const float dist = __builtin_exp2f(u[3] * 10.0f - 8.0f) * (h.x + h.y + h.z);
+            const F3 od = normalize(f3(u[4] - 0.5f, u[5] - 0.5f, u[6] - 0.5f));
+            org = tgt + od * dist;
+            dir = normalize(tgt - org);
+            if (u[7] > 0.8f) dir = -dir;
+        } else {                        // axis-parallel and plane-parallel directions (exact zeros), past the box's faces
+            const float dist = __builtin_exp2f(u[3] * 10.0f - 8.0f) * (h.x + h.y + h.z);
+            const int ax = (int)(u[7] * 3.0f) % 3;
+            F3 od = f3(ax == 0 ? 1.0f : 0.0f, ax == 1 ? 1.0f : 0.0f, ax == 2 ? 1.0f : 0.0f);
+            if (u[11] < 0.5f) od = normalize(f3(ax == 0 ? 0.0f : u[4] - 0.5f, ax == 1 ? 0.0f : u[5] - 0.5f, ax == 2 ? 0.0f : u[6] - 0.5f));
+            org = tgt + od * dist;
+            dir = -od;
+            if (u[8] > 0.8f) dir = od;
+        }
+        // (directions of a scatter are unit to a few ulp; lengths far from 1 as well: the certificate must not depend on it)
+        dir = dir * (u[9] < 0.7f ? 1.0f : __builtin_exp2f(4.0f * u[8] - 2.0f));
+        const float l1 = (__builtin_fabsf(org.x) + __builtin_fabsf(org.y)) + __builtin_fabsf(org.z);
+        if (!(l1 <= omax)) continue;
+        const F3 inv = f3(__builtin_amdgcn_rcpf(dir.x), __builtin_amdgcn_rcpf(dir.y), __builtin_amdgcn_rcpf(dir.z));
+        for (int g = 0; g < 2; ++g) {
+            if (!wallCertainMiss(box[g], org, inv)) continue;
+            if (g) ++nc1; else ++nc0;
+            const int s0 = g ? n0 : 0, s1 = g ? nspheres : n0;
+            for (int si = s0; si < s1; ++si) {
+                F3 P, N;
+                bool o;
+                if (sphereIntersectionTest(spheres[si], org, dir, P, N, o) != -1.0f) ++nv;
+            }
+        }
+    }
+    if (nc0) atomicAdd(certified, (unsigned long long)nc0);
+    if (nc1) atomicAdd(certified + 1, (unsigned long long)nc1);
+    if (nv) atomicAdd(violations, (unsigned long long)nv);
+}
+
 // Soundness sweep of the camera-ray culling (GeomDev::rect, KParams::sceneRect, the per-row lists with their hull spans): every
 // pixel of the frame sends `samples` camera rays (the render kernel's own cameraRayAt: iterations 1 .. samples of the pixel's
 // depth-0 stream) through the FULL test of EVERY primitive, exactly the instantiations the camera-ray bounce runs.  A hit from a

@@ -130,6 +130,10 @@ struct KParams {
     int   nCubes;                      // cubes of the scene (sphere-heavy scenes: rows of the LDS frame table)
     int   nSphCull;                    // sphere-heavy scenes: entries of BounceArgs::sphCull (even: padded with a copy of the last one)
     float sphDirScale;                 // ... and the factor s >= 1 / sqrt(1 - K) on the sweep's unit direction (ptd::sphereHalfLineExcessScaled)
+    int   sphN0;                       // ... the first sphN0 entries (even) are the spheres of CLUSTER 0, the rest those of cluster 1: a survivor's class
+                                       // bits 3 / 4 say which clusters its ray can hit at all, and a tile sweeps only those (k_bounce: CLUSTER)
+    float sphOMax;                     // ... largest |x| + |y| + |z| of a ray origin the clusters' box certificates are issued for
+    float sphBox[2][8];                // ... the clusters' inflated world boxes {lo, hi, -, -} (ptd::wallCertainMiss); neither cluster is empty (pt_init)
     int   meshStackOff;                // scenes with meshes: byte offset of the lanes' traversal stacks in the dynamic LDS ([levels][kBlock] words)
     int   classOff[kClsMax + 1];          // later bounces: the primitives a tile of class c has to look at are classIdx[classOff[c] ..
                                        // classOff[c + 1]) (BounceArgs::classIdx): not the binned ones unless the class says so, of the walls only
@@ -450,7 +454,10 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
     // Layout: the fixed-size scratch first (constant offsets), then the tables whose sizes depend on the scene.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *const s_misc = reinterpret_cast<uint32_t *>(smem);
-    constexpr int kMiscWords = miscWords(MESH ? kClsMax : kCls);
+    // sphere-heavy scenes without meshes: the spheres in two spatial clusters, a survivor's candidate bits name the clusters it can hit
+    constexpr bool CLUSTER = MANY && !MESH;
+    constexpr bool WIDE = MESH || CLUSTER;                 // two candidate bits: 32 queue classes
+    constexpr int kMiscWords = miscWords(WIDE ? kClsMax : kCls);
     MaterialDev *const smats = reinterpret_cast<MaterialDev *>(smem + kMiscWords * sizeof(uint32_t));
 #define S_GEOMHIT(nmats_) (reinterpret_cast<GeomHitDev *>(smem + kMiscWords * sizeof(uint32_t) + sizeof(MaterialDev) * (nmats_)))
 // sphere-heavy scenes (MANY): compact hit records, then the cubes' face frames, then the per-primitive matrices and the lanes' lists
@@ -459,7 +466,10 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
 #define S_SPH(nmats_, ngeoms_, ncubes_) (reinterpret_cast<float *>(smem + kMiscWords * sizeof(uint32_t) + sizeof(MaterialDev) * (nmats_) + \
                                          (MANY ? manyHitBytes(ngeoms_) + (size_t)(ncubes_) * 54 * sizeof(float) + manyFramePad(ncubes_) : sizeof(GeomHitDev) * (ngeoms_))))
     // queue classes of this instantiation and append-counter shards per class (see kClsMax)
-    constexpr int CLS = MESH ? kClsMax : kCls, SUB = kSeg / CLS, CLSBITS = MESH ? 5 : 4;
+    constexpr int CLS = WIDE ? kClsMax : kCls, SUB = kSeg / CLS, CLSBITS = WIDE ? 5 : 4;
+    // the class bits behind which a binned primitive -- an emitter, where a tile is skipped for not reaching one -- can stand: the candidate
+    // bits; CLUSTER: bit 3 alone (the binned primitives are all of group 0, bit 4 stands for spheres of cluster 1 only)
+    constexpr uint32_t kEmitBits = CLUSTER ? 8u : (WIDE ? 24u : 8u);
     uint32_t *const s_wave = s_misc;                       // [2][kWaves][CLS] survivors per wave and class (zero between tiles)
     uint32_t *const s_base = s_wave + 2 * kWaves * CLS;        // [5][CLS] this tile's output run per class: first slot, paths before the
                                                            //           chunk boundary, first slot behind it; the class's last chunk lookup (reserveRun)
@@ -518,7 +528,7 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
                     ts[q] = (cs[q] + kBlock - 1) / kBlock;
                     // (the last bounce of a scene whose emitters are all binned: the tiles of the classes that cannot reach one have
                     // nothing to add -- they get no tile index at all instead of being stepped over one by one)
-                    if (skipNonCand && ((uint32_t)(sgi / SUB) >> 3) == 0u) ts[q] = 0u;
+                    if (skipNonCand && ((uint32_t)(sgi / SUB) & kEmitBits) == 0u) ts[q] = 0u;
                     inc += ts[q];
                     sum += cs[q];
                 }
@@ -679,7 +689,7 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
         m.cls = sgIn / SUB;
         // The last bounce only asks whether a path ends on an emitter (S7: no scatter).  When every emitter of the scene
         // is a binned small primitive, the paths of a non-candidate tile certainly miss all of them: nothing to add.
-        if (skipNonCand != 0u && (m.cls >> 3) == 0u) return false;
+        if (skipNonCand != 0u && (m.cls & kEmitBits) == 0u) return false;
         // the tile's chunk (a chunk is a multiple of the tile size): j-th chunk of the segment, wave-uniform lookup through the
         // scalar cache (entries were written by the previous launch; the 0-th chunk of a segment is static)
         const uint32_t q0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)((T - segFirst) * kBlock));
@@ -986,12 +996,16 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
                 // round; the candidate passes then take each lane's set bits from the top.  (Rounds 1-3 recorded up to eight
                 // candidates per lane in LDS lists: ~8 vector instructions, two exec-mask regions and two branches per sphere on top
                 // of the 15 of the test.)  Two spheres per 64-byte scalar load.
+                probe(24);                                          // (the sweep of the packed spheres)
                 const ArgsPtr A = launder(kargs);
-                const int nS = A->prm.nSphCull;                       // (even: the host pads with a copy of the last sphere)
+                // (even: the host pads with a copy of the last sphere.)  CLUSTER: entries [0, sphN0) are cluster 0, the tile's class bit 3,
+                // [sphN0, nSphCull) cluster 1, bit 4 -- a tile sweeps the clusters its paths can hit (wave-uniform bounds)
+                const int nS = CLUSTER ? ((tileCls & 16u) ? A->prm.nSphCull : A->prm.sphN0) : A->prm.nSphCull;
+                const int kS0 = CLUSTER ? ((tileCls & 8u) ? 0 : A->prm.sphN0) : 0;
                 const PT_CAS SphereCull *sc = (const PT_CAS SphereCull *)(A->sphCull);
                 const uint16_t *const sphGeom = s_list;               // [nS]: the primitive behind entry k (prologue)
                 const F3 dhat = unitDirectionScaled(dir, dd, A->prm.sphDirScale);
-                for (int base = 0; base < nS; base += 64) {           // (wave-uniform)
+                for (int base = kS0; base < nS; base += 64) {         // (wave-uniform)
                     uint32_t mHi = 0u, mLo = 0u;                      // entry base + j: bit 31 - j of mHi (j < 32) / of mLo
                     if (inScene) {
                         auto sweep32 = [&](int k0, uint32_t &m) {
@@ -1022,6 +1036,7 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
                         }
 #endif
                     }
+                    probe(25);                                      // (the candidates' passes)
                     // pass k tests every lane's k-th candidate with that lane's own matrices from LDS
                     while (__ballot((mHi | mLo) != 0u) != 0ull) {     // wave-uniform trip count
                         if ((mHi | mLo) != 0u) {
@@ -1248,7 +1263,7 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
                                     cg.centre[0] = __int_as_float(v[8 * h]); cg.centre[1] = __int_as_float(v[8 * h + 1]); cg.centre[2] = __int_as_float(v[8 * h + 2]);
                                     cg.cullR2 = __int_as_float(v[8 * h + 3]); cg.cullK = __int_as_float(v[8 * h + 4]);
                                     // (the primitive's candidate bit: 1, or 2 for the mesh scenes' group 1 -- word 5 of its row)
-                                    cand |= certainMiss(cg, norg, ndir, ndd) ? 0u : (MESH ? (uint32_t)v[8 * h + 5] : 1u);
+                                    cand |= certainMiss(cg, norg, ndir, ndd) ? 0u : (WIDE ? (uint32_t)v[8 * h + 5] : 1u);
                                 }
                             }
                             smallCandI = cand;
@@ -1257,25 +1272,48 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
                     {                                            // class bits 0-2 with walls: which of them can the new ray still hit?
                         const ArgsPtr A = launder(kargs);
                         const int nWalls = (int)hotWalls(hotNow());
-                        if (nWalls > 0) {
+                        // CLUSTER: the sphere clusters too -- a slab certificate against each cluster's inflated box (the box holds every sphere's
+                        // half-line ball, sqrt(cullR2 + K |oc|^2) around its centre for the origins certificates are issued for: a half-line
+                        // that misses the box passes every sphere's own certificate with room to spare)
+                        uint32_t cb = CLUSTER ? 3u : 0u;
+                        if (nWalls > 0 || CLUSTER) {
                             wallSel = 6u;
                             const float l1 = (__builtin_fabsf(norg.x) + __builtin_fabsf(norg.y)) + __builtin_fabsf(norg.z);
-                            if (l1 <= A->prm.wallOMax) {          // (NaN fails)
+                            const bool wallsOk = nWalls > 0 && l1 <= A->prm.wallOMax;          // (NaN fails)
+                            const bool sphOk = CLUSTER && l1 <= A->prm.sphOMax;
+                            if (wallsOk || sphOk) {
                                 const F3 inv = f3(__builtin_amdgcn_rcpf(ndir.x), __builtin_amdgcn_rcpf(ndir.y), __builtin_amdgcn_rcpf(ndir.z));
-                                const WallPtr walls = (WallPtr)(A->walls);
-                                probe(13);
-                                uint32_t possible = wallPlanesPossible(A->prm, norg, ndir, inv);     // walls 0 .. nSlotWalls - 1
-                                for (int w = (int)hotSlotWalls(hotNow()); w < nWalls; ++w) { probe(13);
-                                    possible |= wallCertainMiss(*(launder(walls) + w), norg, inv) ? 0u : (1u << w); }
-                                const int cnt = __popc(possible);
-                                wallSel = cnt == 1 ? (uint32_t)(__ffs((int)possible) - 1) : (cnt == 0 ? 7u : 6u);
-                                // nothing left to hit: the reference's nearest-hit loop would come back empty at the next bounce.
-                                // The path ends here and is tallied as what it is, a path that entered that bounce and missed.
-                                // (Not under pt_debug_trace_paths, which shows the queue as the oracle lists it.)
-                                if (cnt == 0 && smallCandI == 0u && (hotNow() & (kHotAllClassified | kHotContrib)) == (kHotAllClassified | kHotContrib)) {
-                                    aliveI = 0u;
-                                    ++nEarly;
+                                if (sphOk) {
+                                    int16v v;
+                                    asm volatile("s_load_dwordx16 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(launder(kargs)), "s"((int)(offsetof(BounceArgs, prm) + offsetof(KParams, sphBox))) : "memory");
+                                    cb = 0u;
+#pragma unroll
+                                    for (int h = 0; h < 2; ++h) {
+                                        WallBox wb;
+                                        wb.lo[0] = __int_as_float(v[8 * h]); wb.lo[1] = __int_as_float(v[8 * h + 1]); wb.lo[2] = __int_as_float(v[8 * h + 2]);
+                                        wb.hi[0] = __int_as_float(v[8 * h + 3]); wb.hi[1] = __int_as_float(v[8 * h + 4]); wb.hi[2] = __int_as_float(v[8 * h + 5]);
+                                        cb |= wallCertainMiss(wb, norg, inv) ? 0u : (1u << h);
+                                    }
                                 }
+                                if (CLUSTER) smallCandI = (hotBinned(hotNow()) > 0u ? smallCandI : 0u) | cb;
+                                if (wallsOk) {
+                                    const WallPtr walls = (WallPtr)(A->walls);
+                                    probe(13);
+                                    uint32_t possible = wallPlanesPossible(A->prm, norg, ndir, inv);     // walls 0 .. nSlotWalls - 1
+                                    for (int w = (int)hotSlotWalls(hotNow()); w < nWalls; ++w) { probe(13);
+                                        possible |= wallCertainMiss(*(launder(walls) + w), norg, inv) ? 0u : (1u << w); }
+                                    const int cnt = __popc(possible);
+                                    wallSel = cnt == 1 ? (uint32_t)(__ffs((int)possible) - 1) : (cnt == 0 ? 7u : 6u);
+                                    // nothing left to hit: the reference's nearest-hit loop would come back empty at the next bounce.
+                                    // The path ends here and is tallied as what it is, a path that entered that bounce and missed.
+                                    // (Not under pt_debug_trace_paths, which shows the queue as the oracle lists it.)
+                                    if (cnt == 0 && smallCandI == 0u && (hotNow() & (kHotAllClassified | kHotContrib)) == (kHotAllClassified | kHotContrib)) {
+                                        aliveI = 0u;
+                                        ++nEarly;
+                                    }
+                                }
+                            } else if (CLUSTER) {
+                                smallCandI = (hotBinned(hotNow()) > 0u ? smallCandI : 0u) | cb;
                             }
                         }
                     }

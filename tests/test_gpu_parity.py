@@ -153,6 +153,36 @@ def test_sphere_halfline_certificate_never_rejects_a_hit(gpu, oracle):
     assert culled > (1 << 28) // 5 and behind > (1 << 28) // 16      # both branches of the certificate fire, by the tens of millions
 
 
+def test_sphere_cluster_boxes_never_reject_a_hit(gpu, oracle):
+    # Sphere-heavy scenes without meshes bin the survivors by which of TWO spatial clusters of spheres their ray can hit (class bits 3 / 4,
+    # a slab certificate against each cluster's inflated box: pt_api.hip build_sphere_clusters, k_bounce CLUSTER); a tile then sweeps only
+    # the clusters its class names.  A box certified as missed must imply the reference's miss (src/intersections.h:101-143) for EVERY
+    # sphere behind it.  2^28 rays per scene: scatters off the spheres, rays from the scene's extent at the boxes and their shells, from
+    # close to the boxes, axis- and plane-parallel ones.  Scenes: config C5's own; ellipsoids, tiny and large spheres, rotated, far off the
+    # origin and between walls that are not axis-parallel.
+    sc = oracle.Scene(os.path.join(SCENES, "spheres64.txt"))
+    rng = np.random.default_rng(41)
+    odd = [oracle.make_geom(1, 1, (0, 0, 0), (0, 0, 0), (30, 0.02, 30)), oracle.make_geom(1, 1, (0, 12, 0), (0, 0, 30), (30, 0.02, 30)),
+           oracle.make_geom(1, 1, (-9, 6, 0), (0, 0, 90), (14, 0.02, 30))]
+    for i in range(23):
+        c = rng.uniform(-6, 6, 3) + np.array([3.0, 6.0, -2.0])
+        scale = np.exp(rng.uniform(np.log(0.05), np.log(3.0), 3)) if i % 3 else np.full(3, np.exp(rng.uniform(np.log(0.05), np.log(4.0))))
+        odd.append(oracle.make_geom(0, 1, tuple(c), tuple(rng.uniform(-180, 180, 3)), tuple(scale)))
+    far = [oracle.make_geom(1, 1, (100, -50, 25), (0, 0, 0), (60, 0.1, 60))]
+    for i in range(9):
+        far.append(oracle.make_geom(0, 1, tuple(np.array([100.0, -40.0, 25.0]) + rng.uniform(-20, 20, 3)), (0, 0, 0), (6 + i,) * 3))
+    total = 0
+    for name, geoms in (("spheres64", sc.geoms), ("odd", np.concatenate(odd)), ("far", np.concatenate(far))):
+        cert, bad, info = gpu.test_sphere_cluster_sweep(geoms.view(gpu.GEOM_DTYPE), 4242 + _SW - 1, (1 << 28) * _SW)
+        assert bad == 0, (name, bad, info)
+        # both clusters' certificates fire: by the tens of millions in C5's scene, by the millions where anisotropic spheres (K |oc|^2 is
+        # large for them) make the boxes wide
+        assert min(cert) > ((1 << 28) // 16 if name == "spheres64" else (1 << 20)), (name, cert, info)
+        assert info["omax"] > 0 and info["n0"] >= 2 and info["n0"] % 2 == 0
+        total += sum(cert)
+    assert total > 0
+
+
 def test_cube_culling_never_rejects_a_hit(gpu, oracle):
     # the same bounding-ball test decides which queue tiles skip the scene's small cubes (k_bounce bins survivors by
     # it): it must imply the reference's own miss for cubes of every shape -- the Cornell light and walls, thin plates
