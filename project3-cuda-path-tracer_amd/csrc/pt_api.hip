@@ -790,7 +790,7 @@ const void *bounce_kernel(bool first, bool dof) {
     return S.many ? kb<false, true, false, false>() : kb<false, false, false, false>();
 }
 
-int launch_bounce(Slot &sl, int iter, int batch, int depth, bool lastBounce, float *contrib) {
+int launch_bounce(Slot &sl, int iter, int batch, int depth, bool lastBounce, float *contrib, bool nextIsLast = false) {
     const PathPool in = pool(sl, (depth - 1) & 1);
     const PathPool out = pool(sl, depth & 1);
     // chunk-list entries carry the serial number of the launch that wrote them (never 0)
@@ -817,6 +817,11 @@ int launch_bounce(Slot &sl, int iter, int batch, int depth, bool lastBounce, flo
                   ((S.prm.directDepth != 0 && depth == S.prm.directDepth && S.prm.nEmit > 0) ? kHotToLight : 0u) |
                   (S.prm.contribLocal ? kHotContribLocal : 0u) | ((uint32_t)S.prm.nWalls << 8) | ((uint32_t)S.prm.nSlotWalls << 11) |
                   ((uint32_t)S.prm.nBinned << 14) | ((uint32_t)S.prm.nmats << 20);
+    // sphere clusters: the queue that ENTERS the last bounce carries other candidate bits (k_bounce: kHotWritesLastBits) -- that launch only asks
+    // whether a path ends on an emitter, and with every emitter binned it visits the tiles of the binned primitives' candidates alone
+    const bool lastBits = S.many && !S.mesh && S.prm.sphOMax > 0.0f && S.prm.emittersBinned;
+    if (lastBits && nextIsLast) ba.tile.hot |= kHotWritesLastBits;
+    if (lastBits && lastBounce && depth > 1) ba.tile.hot |= kHotReadsLastBits;
     ba.ctrl = sl.ctrl; ba.ggeoms = S.dgeoms; ba.gmats = S.dmats; ba.ghit = S.dGeomHit; ba.contrib = contrib; ba.hitMask = sl.hitMask;
     ba.sphCull = S.dSphCull; ba.classIdx = S.dClassIdx;
     ba.rowOff = S.dRowOff; ba.rowIdx = S.dRowIdx;
@@ -937,7 +942,7 @@ int trace_batch(Slot &sl, int first_iter, int count) {
     HIPCHECK(hipStreamWaitEvent(sl.stream, sl.evCommitted, 0));
     const int D = S.prm.traceDepth;
     for (int d = 1; d <= D; ++d) {
-        int rc = launch_bounce(sl, first_iter, count, d, d == D, sl.contrib);
+        int rc = launch_bounce(sl, first_iter, count, d, d == D, sl.contrib, d + 1 == D);
         if (rc) {
             // a launch failed with part of the batch enqueued: counters, parity and radiance buffers are half-updated, so the
             // renderer refuses further work until it is re-initialised (pt_free still releases everything)

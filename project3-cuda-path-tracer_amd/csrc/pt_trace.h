@@ -43,7 +43,9 @@ constexpr int kTicketWords = 4;      // the workgroup's next ticket (+ padding)
 constexpr int miscWords(int cls) { return 2 * kWaves * cls + 5 * cls + kSeg + (kSeg + 2) + 2 * PT_MAX_BATCH + 2 + kNanWords + kTicketWords; }
 static_assert(miscWords(kCls) % 4 == 0 && miscWords(kClsMax) % 4 == 0, "the sphere records that follow are read as float4");
 constexpr int kSphRowFloats = 28;
-constexpr int kListMax = 8;
+constexpr int kListMax = 6;          // (8 until the 32 queue classes of round 4 took 832 B more: with C5's scene the camera-ray launch then needed 23 200 B of
+                                     // LDS, one 512-byte granule more than seven workgroups per CU leave each other -- 2.39 -> 2.86 ms; a camera ray rarely
+                                     // meets more than three bounding balls, and a lane whose list is full tests in place)
 constexpr int kCtrPad = 32;          // one counter per 128-byte line: same-line atomics serialise at the memory side
 // Every workgroup of a launch ends with one atomic per tally, and atomics on one address serialise at ~12 ns each (round 2 measured a
 // 0.1 ms tail with 8192 of them on one word): 64 shards leave 32 per word for a 2048-workgroup launch (rounds 2-3: 8 shards, 256 per
@@ -373,10 +375,16 @@ struct TileArgs {
     // be its own scalar load in the phase that asks for it, and round 3's experiments price a dependent scalar-cache round trip at
     // half a percent of a tile's time (profiles/r03_sensitivity_experiments.txt).
     //   bit 0 lastBounce, 1 allClassified, 2 radiance is parked (contrib != null), 3 this bounce aims at a light (direct lighting),
-    //   4 contribLocal; bits 8-10 nWalls, 11-13 nSlotWalls, 14-16 nBinned, 20-31 nmats
+    //   4 contribLocal, 5 / 6 the output / input queue carries the last bounce's candidate bits; bits 8-10 nWalls, 11-13 nSlotWalls, 14-16 nBinned, 20-31 nmats
     uint32_t hot;
 };
 constexpr uint32_t kHotLast = 1u, kHotAllClassified = 2u, kHotContrib = 4u, kHotToLight = 8u, kHotContribLocal = 16u;
+// Sphere clusters (k_bounce: CLUSTER), scenes whose emitters are all binned: the last bounce only asks whether a path ends on an emitter and
+// visits the tiles whose class has bit 3 -- which, between the other bounces, stands for "a binned primitive OR a sphere of cluster 0", five
+// times as many paths as the binned primitives' candidates alone.  So the queue that enters the last bounce is classed differently: bit 3 =
+// a binned primitive's candidate, bit 4 = a candidate of EITHER cluster (a tile with it sweeps all the spheres: they may stand in front of
+// the emitter).  kHotWritesLastBits: the launch that fills that queue; kHotReadsLastBits: the launch that reads it.
+constexpr uint32_t kHotWritesLastBits = 32u, kHotReadsLastBits = 64u;
 __host__ __device__ constexpr uint32_t hotWalls(uint32_t h) { return (h >> 8) & 7u; }
 __host__ __device__ constexpr uint32_t hotSlotWalls(uint32_t h) { return (h >> 11) & 7u; }
 __host__ __device__ constexpr uint32_t hotBinned(uint32_t h) { return (h >> 14) & 7u; }
@@ -1000,8 +1008,16 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
                 const ArgsPtr A = launder(kargs);
                 // (even: the host pads with a copy of the last sphere.)  CLUSTER: entries [0, sphN0) are cluster 0, the tile's class bit 3,
                 // [sphN0, nSphCull) cluster 1, bit 4 -- a tile sweeps the clusters its paths can hit (wave-uniform bounds)
-                const int nS = CLUSTER ? ((tileCls & 16u) ? A->prm.nSphCull : A->prm.sphN0) : A->prm.nSphCull;
-                const int kS0 = CLUSTER ? ((tileCls & 8u) ? 0 : A->prm.sphN0) : 0;
+                // (the queue that enters the last bounce: bit 4 = either cluster, bit 3 = the binned primitives alone -- kHotReadsLastBits)
+                int nS = A->prm.nSphCull, kS0 = 0;
+                if (CLUSTER) {
+                    if (hotNow() & kHotReadsLastBits) {
+                        nS = (tileCls & 16u) ? nS : 0;
+                    } else {
+                        nS = (tileCls & 16u) ? nS : A->prm.sphN0;
+                        kS0 = (tileCls & 8u) ? 0 : A->prm.sphN0;
+                    }
+                }
                 const PT_CAS SphereCull *sc = (const PT_CAS SphereCull *)(A->sphCull);
                 const uint16_t *const sphGeom = s_list;               // [nS]: the primitive behind entry k (prologue)
                 const F3 dhat = unitDirectionScaled(dir, dd, A->prm.sphDirScale);
@@ -1295,7 +1311,7 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
                                         cb |= wallCertainMiss(wb, norg, inv) ? 0u : (1u << h);
                                     }
                                 }
-                                if (CLUSTER) smallCandI = (hotBinned(hotNow()) > 0u ? smallCandI : 0u) | cb;
+                                if (CLUSTER) smallCandI = (hotBinned(hotNow()) > 0u ? smallCandI : 0u) | ((hotNow() & kHotWritesLastBits) ? (cb != 0u ? 2u : 0u) : cb);
                                 if (wallsOk) {
                                     const WallPtr walls = (WallPtr)(A->walls);
                                     probe(13);
@@ -1313,7 +1329,7 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
                                     }
                                 }
                             } else if (CLUSTER) {
-                                smallCandI = (hotBinned(hotNow()) > 0u ? smallCandI : 0u) | cb;
+                                smallCandI = (hotBinned(hotNow()) > 0u ? smallCandI : 0u) | ((hotNow() & kHotWritesLastBits) ? 2u : cb);
                             }
                         }
                     }
