@@ -102,12 +102,55 @@ def _random_scene(gpu, oracle, seed, tris_by_name):
     return sc, res, extras, rng
 
 
-# PT_FUZZ_SEEDS=<n>: a longer one-off run (profiles/r02_fuzz.txt holds the last one)
-@pytest.mark.parametrize("seed", range(int(os.environ.get("PT_FUZZ_SEEDS", "40"))))
-def test_random_scene(gpu, oracle, seed):
-    small = gpu.Scene(os.path.join(SCENES, "mesh_small.txt"))
-    tris = {"icosphere": small.meshes[3], "torus": small.meshes[4]}
-    sc, (W, H), extras, rng = _random_scene(gpu, oracle, 5650 + seed, tris)
+def _sphere_field(gpu, oracle, seed):
+    """Sphere-heavy scenes without meshes (k_bounce's CLUSTER variants: the survivors binned by which of two clusters of spheres their ray
+    can hit): 5 .. 40 spheres of similar size in a box-shaped region, in a room or in the open; the emitter a ceiling light (binned: the
+    last bounce then visits its candidates alone), an emissive sphere among the others (not binned), or both."""
+    rng = np.random.default_rng(seed)
+    kinds = ["light", "diffuse", "diffuse", "mirror", "glass", "diffuse"]
+    mats = np.concatenate([_material(oracle, rng, k) for k in kinds])
+    geoms = []
+    S = rng.uniform(8, 14)
+    room = rng.random() < 0.7
+    if room:
+        walls = [((0, 0, 0), (S, 0.01, S)), ((0, S, 0), (S, 0.01, S)), ((0, S / 2, -S / 2), (S, S, 0.01)),
+                 ((-S / 2, S / 2, 0), (0.01, S, S)), ((S / 2, S / 2, 0), (0.01, S, S))]
+        for t, sc_ in walls:
+            if rng.random() < 0.1:
+                continue
+            geoms.append(oracle.make_geom(1, int(rng.integers(1, 6)), t, (0, 0, 0), sc_))
+    emitter = rng.choice(["light", "sphere", "both"])
+    if emitter != "sphere":
+        geoms.append(oracle.make_geom(1, 0, (0, S - 0.2, 0), (0, 0, 0), (S / 3, 0.3, S / 3)))
+    n = int(rng.choice([5, 6, 9, 16, 27, 40]))
+    ext = rng.uniform(0.3, 0.45, 3) * S * np.where(rng.random(3) < 0.3, 0.4, 1.0)          # (sometimes a slab or a column of spheres)
+    base = rng.uniform(0.15, 0.5) * S / n ** (1 / 3)
+    for k in range(n):
+        t = np.array([0, S / 2, 0]) + rng.uniform(-1, 1, 3) * ext
+        d = base * rng.uniform(0.6, 1.4)
+        scale = (d, d, d) if rng.random() < 0.8 else tuple(d * rng.uniform(0.7, 1.3, 3))
+        mat = 0 if (emitter != "light" and k == 0) else int(rng.integers(1, 6))
+        geoms.append(oracle.make_geom(0, mat, tuple(t), tuple(rng.uniform(-180, 180, 3)), scale))
+    if rng.random() < 0.3:                                    # coincident duplicates: file order decides
+        geoms.append(geoms[-1].copy())
+    order = rng.permutation(len(geoms)) if rng.random() < 0.5 else np.arange(len(geoms))        # spheres between the walls in file order too
+    geoms = [geoms[i] for i in order]
+    res = (int(rng.choice([64, 256])), int(rng.choice([36, 50])))
+    cam = np.zeros(1, oracle.CAMERA_DTYPE)
+    cam["resolution"] = res
+    cam["position"], cam["view"], cam["up"] = (rng.uniform(-1, 1), S / 2 + rng.uniform(-1, 1), S * 1.05), (rng.uniform(-0.1, 0.1), rng.uniform(-0.1, 0.05), -1), (0, 1, 0)
+    cam["fov"] = (0.0, rng.uniform(30, 45))
+    oracle.lib().orc_camera_set_resolution(cam.ctypes.data, res[0], res[1])
+    sc = types.SimpleNamespace(geoms=np.concatenate(geoms).view(gpu.GEOM_DTYPE), materials=mats.view(gpu.MATERIAL_DTYPE),
+                               camera=cam.view(gpu.CAMERA_DTYPE), traceDepth=int(rng.integers(2, 9)), meshes={}, mesh_normals={}, mesh_materials={},
+                               image=np.zeros((res[1], res[0], 3), np.float32))
+    extras = {}
+    if rng.random() < 0.2:
+        extras.update(direct_lighting=True)
+    return sc, res, extras, rng
+
+
+def _check(gpu, oracle, sc, W, H, extras, rng, seed):
     depth = sc.traceDepth
     ref = oracle.Renderer(sc.camera.view(oracle.CAMERA_DTYPE), sc.geoms.view(oracle.GEOM_DTYPE), sc.materials.view(oracle.MATERIAL_DTYPE),
                           depth, meshes=sc.meshes, mesh_normals=sc.mesh_normals, mesh_materials=sc.mesh_materials)
@@ -144,3 +187,18 @@ def test_random_scene(gpu, oracle, seed):
     assert np.array_equal(o.view(np.uint32), wo.view(np.uint32)) and np.array_equal(d.view(np.uint32), wd.view(np.uint32)), seed
     assert np.array_equal(c.view(np.uint32), wc.view(np.uint32)), seed
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), seed
+
+
+# PT_FUZZ_SEEDS=<n>: a longer one-off run (profiles/r02_fuzz.txt holds the last one)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PT_FUZZ_SEEDS", "40"))))
+def test_random_scene(gpu, oracle, seed):
+    small = gpu.Scene(os.path.join(SCENES, "mesh_small.txt"))
+    tris = {"icosphere": small.meshes[3], "torus": small.meshes[4]}
+    sc, (W, H), extras, rng = _random_scene(gpu, oracle, 5650 + seed, tris)
+    _check(gpu, oracle, sc, W, H, extras, rng, seed)
+
+
+@pytest.mark.parametrize("seed", range(max(16, int(os.environ.get("PT_FUZZ_SEEDS", "40")) // 4)))
+def test_random_sphere_field(gpu, oracle, seed):
+    sc, (W, H), extras, rng = _sphere_field(gpu, oracle, 8800 + seed)
+    _check(gpu, oracle, sc, W, H, extras, rng, seed)
