@@ -448,7 +448,7 @@ static_assert(sizeof(CullGroup) == 32 && offsetof(GeomDev, cullFlags) - offsetof
 // specular lobe, no direct lighting: their code (a third of the scatter's static instructions: Schlick + refract, the lobe's pow, the
 // emitter pick) is not even compiled in.  Same results (the branches are never taken in such a scene); pt_init picks the instantiation.
 template <bool FIRST, bool MANY, bool DOF = false, bool MESH = false, bool PLAIN = false>
-__global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF ? 5 : (MANY ? 7 : 8))) void k_bounce(BounceArgs argsByValue) {
+__global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF ? 5 : (MANY ? (FIRST ? 7 : 6) : 8))) void k_bounce(BounceArgs argsByValue) {
     static_assert(FIRST || !DOF, "the lens only concerns the camera-ray bounce");
     (void)argsByValue;
     const ArgsPtr kargs = (ArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
