@@ -43,6 +43,10 @@ int pt_test_sphere_halfline_sweep(const PtGeom *geoms, int ngeoms, uint64_t seed
  * the origins, the size of cluster 0 in the table, the two boxes {lo, hi, -, -}. */
 int pt_test_sphere_cluster_sweep(const PtGeom *geoms, int ngeoms, uint64_t seed, int64_t rays, uint64_t *certified2, uint64_t *violations,
                                  float *info18);
+/* ... and the clusters themselves for inspection (host only, no GPU needed): info18 as above; table[k] = the primitive behind entry k of the
+ * sweep's table (cluster 0 = entries 0 .. info18[1] - 1, padded to an even count with a copy of its last sphere; then cluster 1 -- whose end pt_init
+ * pads likewise), *ntable entries (<= table_cap). */
+int pt_test_sphere_clusters(const PtGeom *geoms, int ngeoms, float *info18, int32_t *table, int32_t table_cap, int32_t *ntable);
 /* wallCertainMiss (world-space culling of large cubes against their inflated bounding boxes, which classes the queue by
  * the wall a path can still hit) soundness: as above, for the cubes of `geoms`. */
 int pt_test_wall_box_sweep(const PtGeom *geoms, int ngeoms, uint64_t seed, int64_t rays, uint64_t *culled,

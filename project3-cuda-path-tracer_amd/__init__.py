@@ -60,7 +60,7 @@ TEST_ABI_SYMBOLS = [
     "pt_test_slab_quotients", "pt_test_slab_quotients_sweep", "pt_test_sphere_cull_sweep", "pt_test_unscaled_sqrt_sweep",
     "pt_test_force_fault", "pt_test_pow", "pt_test_wall_box_sweep", "pt_test_mesh_intersect", "pt_test_mesh_bvh",
     "pt_test_mesh_cull_sweep", "pt_test_camera_cull_sweep", "pt_test_camera_cull_tables",
-    "pt_test_wall_plane_sweep", "pt_test_sphere_halfline_sweep", "pt_test_sphere_cluster_sweep", "pt_test_camera_cull_margin",
+    "pt_test_wall_plane_sweep", "pt_test_sphere_halfline_sweep", "pt_test_sphere_cluster_sweep", "pt_test_sphere_clusters", "pt_test_camera_cull_margin",
 ]
 
 
@@ -123,6 +123,7 @@ def _bind(L, with_tests):
         L.pt_test_sphere_cull_sweep.argtypes = [vp, i32, C.c_uint64, i64, u64p, u64p]
         L.pt_test_sphere_halfline_sweep.argtypes = [vp, i32, C.c_uint64, i64, u64p, u64p, u64p]
         L.pt_test_sphere_cluster_sweep.argtypes = [vp, i32, C.c_uint64, i64, u64p, u64p, vp]
+        L.pt_test_sphere_clusters.argtypes = [vp, i32, vp, vp, i32, vp]
         L.pt_test_unscaled_sqrt_sweep.argtypes = [u64p]
         L.pt_test_force_fault.argtypes = [i32]
         L.pt_test_pow.argtypes = [vp, vp, i32, vp]
@@ -577,6 +578,17 @@ def test_sphere_cluster_sweep(geoms, seed, rays):
     _tcheck(test_lib().pt_test_sphere_cluster_sweep(_p(geoms), len(geoms), seed, rays, cert, C.byref(bad), info.ctypes.data))
     boxes = info[2:].reshape(2, 8)[:, :6].copy()
     return [int(cert[0]), int(cert[1])], int(bad.value), {"omax": float(info[0]), "n0": int(info[1]), "boxes": boxes}
+
+
+def sphere_clusters(geoms):
+    """The two clusters of spheres pt_init builds for a sphere-heavy scene without meshes (host only).
+    -> {omax, n0, boxes (2, 6): lo, hi}, table (primitive index per entry of the sweep's table: cluster 0 first, n0 entries)"""
+    geoms = np.ascontiguousarray(geoms)
+    info = np.zeros(18, np.float32)
+    table = np.zeros(len(geoms) + 2, np.int32)
+    n = C.c_int32(0)
+    _tcheck(test_lib().pt_test_sphere_clusters(_p(geoms), len(geoms), info.ctypes.data, table.ctypes.data, len(table), C.byref(n)))
+    return {"omax": float(info[0]), "n0": int(info[1]), "boxes": info[2:].reshape(2, 8)[:, :6].copy()}, table[:n.value].copy()
 
 
 def test_wall_box_sweep(geoms, seed, rays):

@@ -2151,15 +2151,12 @@ int pt_test_sphere_halfline_sweep(const PtGeom *geoms, int ngeoms, uint64_t seed
     return PT_OK;
 }
 
-int pt_test_sphere_cluster_sweep(const PtGeom *geoms, int ngeoms, uint64_t seed, int64_t rays, uint64_t *certified2, uint64_t *violations, float *info18) {
-    NEED_GPU();
-    if (!geoms || ngeoms < 2 || !certified2 || !violations || rays < 0) return fail(PT_ERR_INVALID, "pt_test_sphere_cluster_sweep: bad argument");
-    // the clusters exactly as pt_init builds them for this scene (no primitive binned: binning only moves the choice of the split)
-    std::vector<GeomDev> hg(ngeoms);
-    std::vector<SphereCull> sc;
+// the sweep's table: every sphere of `geoms` with its culling data as pt_init packs it (thresholds scaled for the folded K |oc|^2 term)
+static void pack_sphere_cull(const PtGeom *geoms, int ngeoms, std::vector<GeomDev> &hg, std::vector<SphereCull> &sc) {
+    hg.resize(ngeoms);
+    sc.clear();
     for (int i = 0; i < ngeoms; ++i) {
         pack_geom(geoms[i], hg[i]);
-        if (geoms[i].type == PT_MESH) return fail(PT_ERR_INVALID, "pt_test_sphere_cluster_sweep: spheres and cubes only");
         if (geoms[i].type != PT_SPHERE) continue;
         SphereCull e;
         memset(&e, 0, sizeof e);
@@ -2174,6 +2171,36 @@ int pt_test_sphere_cluster_sweep(const PtGeom *geoms, int ngeoms, uint64_t seed,
     const float sdir = std::nextafter((float)std::sqrt(1.0 / (1.0 - kmax)), INFINITY);
     for (SphereCull &e : sc)
         if (std::isfinite(e.cullR2)) e.cullR2 = std::nextafter((float)((double)e.cullR2 * (double)sdir * (double)sdir), INFINITY);
+}
+
+int pt_test_sphere_clusters(const PtGeom *geoms, int ngeoms, float *info18, int32_t *table, int32_t table_cap, int32_t *ntable) {
+    if (!geoms || ngeoms < 2 || !info18 || !table || !ntable) return fail(PT_ERR_INVALID, "pt_test_sphere_clusters: bad argument");
+    for (int i = 0; i < ngeoms; ++i)
+        if (geoms[i].type == PT_MESH) return fail(PT_ERR_INVALID, "pt_test_sphere_clusters: spheres and cubes only");
+    std::vector<GeomDev> hg;
+    std::vector<SphereCull> sc;
+    pack_sphere_cull(geoms, ngeoms, hg, sc);
+    int n0 = 0;
+    float omax = 0.0f, box[2][8];
+    if (!build_sphere_clusters(geoms, ngeoms, hg, std::vector<int>(), sc, n0, omax, box))
+        return fail(PT_ERR_INVALID, "pt_test_sphere_clusters: no clusters for this scene");
+    if ((int)sc.size() > table_cap) return fail(PT_ERR_INVALID, "pt_test_sphere_clusters: table_cap too small (%d entries)", (int)sc.size());
+    info18[0] = omax; info18[1] = (float)n0;
+    for (int g = 0; g < 2; ++g) for (int q = 0; q < 8; ++q) info18[2 + 8 * g + q] = box[g][q];
+    for (size_t i = 0; i < sc.size(); ++i) table[i] = sc[i].geom;
+    *ntable = (int)sc.size();
+    return PT_OK;
+}
+
+int pt_test_sphere_cluster_sweep(const PtGeom *geoms, int ngeoms, uint64_t seed, int64_t rays, uint64_t *certified2, uint64_t *violations, float *info18) {
+    NEED_GPU();
+    if (!geoms || ngeoms < 2 || !certified2 || !violations || rays < 0) return fail(PT_ERR_INVALID, "pt_test_sphere_cluster_sweep: bad argument");
+    // the clusters exactly as pt_init builds them for this scene (no primitive binned: binning only moves the choice of the split)
+    for (int i = 0; i < ngeoms; ++i)
+        if (geoms[i].type == PT_MESH) return fail(PT_ERR_INVALID, "pt_test_sphere_cluster_sweep: spheres and cubes only");
+    std::vector<GeomDev> hg;
+    std::vector<SphereCull> sc;
+    pack_sphere_cull(geoms, ngeoms, hg, sc);
     int n0 = 0;
     float omax = 0.0f, box[2][8];
     if (!build_sphere_clusters(geoms, ngeoms, hg, std::vector<int>(), sc, n0, omax, box))
