@@ -1275,6 +1275,9 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
                                 asm volatile("s_load_dwordx16 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(launder(kargs)), "s"((int)(offsetof(BounceArgs, prm) + offsetof(KParams, binCull)) + sI * 32) : "memory");
 #pragma unroll
                                 for (int h = 0; h < 2; ++h) {
+                                    // (sphere-heavy scenes bin one primitive, the light: the row behind it stands for nobody -- a scalar
+                                    // branch instead of fourteen vector instructions per scatter)
+                                    if (MANY && h == 1 && sI + 1 >= nBinned) break;
                                     CullGroup cg;
                                     cg.centre[0] = __int_as_float(v[8 * h]); cg.centre[1] = __int_as_float(v[8 * h + 1]); cg.centre[2] = __int_as_float(v[8 * h + 2]);
                                     cg.cullR2 = __int_as_float(v[8 * h + 3]); cg.cullK = __int_as_float(v[8 * h + 4]);
