@@ -1536,9 +1536,11 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
                                     : sizeof(GeomHitDev) * ngeoms);
     // (sphere-heavy scenes: the camera-ray launch keeps the lanes' candidate lists behind the tables, the later ones only the sweep's
     // entry -> primitive map -- 4 KB less, which is what their seventh workgroup per CU needs)
-    const size_t sphMapBytes = ((size_t)k.nSphCull + 7) / 8 * 8 * sizeof(uint16_t);
-    S.ldsBytes = ldsFixed + (S.many ? std::max((size_t)kListMax * kBlock * sizeof(uint16_t), sphMapBytes) : 0);
-    S.ldsBytesNext = (S.many && !S.mesh) ? ldsFixed + sphMapBytes : 0;
+    // (... and, behind the map, the pooled pass's pair descriptors: [kWaves][64] words)
+    const size_t sphMapBytes = ((size_t)k.nSphCull + 7) / 8 * 8 * sizeof(uint16_t), pairBytes = (size_t)kBlock * sizeof(uint32_t);
+    k.pairOff = (int)(ldsFixed + sphMapBytes);
+    S.ldsBytes = ldsFixed + (S.many ? std::max((size_t)kListMax * kBlock * sizeof(uint16_t), sphMapBytes + pairBytes) : 0);
+    S.ldsBytesNext = (S.many && !S.mesh) ? ldsFixed + sphMapBytes + pairBytes : 0;
     if (S.mesh) {        // the lanes' stacks of far children (ptd::meshIntersectionTest): kBlock words per level, behind everything else
         S.ldsBytes = (S.ldsBytes + 15) / 16 * 16;
         k.meshStackOff = (int)S.ldsBytes;

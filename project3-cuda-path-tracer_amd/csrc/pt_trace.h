@@ -20,6 +20,9 @@ constexpr int kCls = 2 * kOct;       // ... and by "may hit a small primitive" (
 #ifndef PT_KSUB
 #define PT_KSUB 8
 #endif
+#ifndef PT_POOL
+#define PT_POOL 1                    // sphere-heavy scenes, later bounces: a wave's candidates tested in ONE pooled pass (k_bounce); 0: experiments only
+#endif
 constexpr int kSub = PT_KSUB;        // append-counter shards per class (workgroup blockIdx % kSub; PT_KSUB: shard-count experiments only)
 constexpr int kSeg = kCls * kSub;    // path buffers are split into kSeg segments with one append counter each
 // Scenes with triangle meshes bin by TWO candidate bits instead of one (class bits 3 and 4: "may hit a binned primitive of group 0 /
@@ -136,6 +139,7 @@ struct KParams {
                                        // bits 3 / 4 say which clusters its ray can hit at all, and a tile sweeps only those (k_bounce: CLUSTER)
     float sphOMax;                     // ... largest |x| + |y| + |z| of a ray origin the clusters' box certificates are issued for
     float sphBox[2][8];                // ... the clusters' inflated world boxes {lo, hi, -, -} (ptd::wallCertainMiss); neither cluster is empty (pt_init)
+    int   pairOff;                     // sphere-heavy scenes, later bounces: byte offset of the pooled pass's pair descriptors in the dynamic LDS ([kWaves][64] words)
     int   meshStackOff;                // scenes with meshes: byte offset of the lanes' traversal stacks in the dynamic LDS ([levels][kBlock] words)
     int   classOff[kClsMax + 1];          // later bounces: the primitives a tile of class c has to look at are classIdx[classOff[c] ..
                                        // classOff[c + 1]) (BounceArgs::classIdx): not the binned ones unless the class says so, of the walls only
@@ -1053,6 +1057,92 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
 #endif
                     }
                     probe(25);                                      // (the candidates' passes)
+#if PT_POOL
+                    // POOLED pass.  A pass of the loop below runs for the lanes that still hold a candidate -- a quarter of a wave in C5
+                    // (profiles/probe_phases.py: 13.9 lanes per pass, 1.6 passes per tile) -- and a wave takes as many passes as its
+                    // busiest lane has candidates.  When some lane has two or more and the wave's candidates are no more than its running lanes, ALL of
+                    // them are tested in ONE pass instead: every (ray, sphere) pair is handed to a lane of its own -- the pairs numbered
+                    // level by level (a ballot per level: the lanes with at least l candidates), the descriptor {owner lane, entry} through
+                    // LDS, the owner's ray through ds_bpermute -- and each owner collects its pairs' outcomes the same way, nearest first,
+                    // file order on a tie, exactly as the passes would have.  Same arithmetic on another lane: bit-identical.
+                    {
+                        const uint32_t cnt = (uint32_t)(__popc(mHi) + __popc(mLo));
+                        if (__ballot(cnt >= 2u) != 0ull) {              // (wave-uniform)
+                            const ArgsPtr A2 = launder(kargs);
+                            uint32_t *const s_pair = reinterpret_cast<uint32_t *>(smem + A2->prm.pairOff) + (tid & ~63u);   // [kWaves][64]
+                            const uint32_t ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+                            uint32_t total = 0u, hi = mHi, lo = mLo;
+                            for (uint32_t l = 1u;; ++l) {               // (wave-uniform trip count: the busiest lane's candidates)
+                                const unsigned long long b = __ballot(cnt >= l);
+                                if (b == 0ull) break;
+                                if (cnt >= l) {
+                                    const bool useHi = hi != 0u;
+                                    const uint32_t mm = useHi ? hi : lo;
+                                    const int j = __builtin_clz(mm);
+                                    const uint32_t rest = mm & ~(0x80000000u >> j);
+                                    hi = useHi ? rest : hi;
+                                    lo = useHi ? lo : rest;
+                                    const uint32_t slot = total + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+                                    if (slot < 64u) s_pair[slot] = ln | ((uint32_t)((useHi ? 0 : 32) + j) << 8);
+                                }
+                                total += (uint32_t)__popcll(b);
+                            }
+                            // (a pair's lane must be one that runs: a tile's valid lanes are a prefix of it, so of every wave)
+                            if (total <= (uint32_t)__popcll(__ballot(true))) {   // (wave-uniform)
+                                const uint32_t desc = ln < total ? s_pair[ln] : ln;
+                                const int src = (int)((desc & 63u) << 2);
+                                const F3 oorg = f3(__int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(org.x))),
+                                                   __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(org.y))),
+                                                   __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(org.z))));
+                                const F3 odir = f3(__int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(dir.x))),
+                                                   __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(dir.y))),
+                                                   __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(dir.z))));
+                                float te = -1.0f;
+                                int ge = 0, oe = 0;
+                                F3 pe = f3(0, 0, 0), ne = f3(0, 0, 0);
+                                if (ln < total) {
+                                    ge = sphGeom[base + (int)(desc >> 8)];
+                                    const float4 *row = reinterpret_cast<const float4 *>(s_sph + ge * kSphRowFloats);
+                                    float m[28];
+#pragma unroll
+                                    for (int q = 0; q < 7; ++q) {
+                                        const float4 v = row[q];
+                                        m[4 * q] = v.x; m[4 * q + 1] = v.y; m[4 * q + 2] = v.z; m[4 * q + 3] = v.w;
+                                    }
+                                    bool o = false;
+                                    probe(4);
+                                    te = sphereIntersectionTestM<false>(m, m + 24, m + 12, m, oorg, odir, pe, ne, o);
+                                    oe = o ? 1 : 0;
+                                }
+                                // every owner collects its pairs: the same numbering, level by level
+                                float tb = -1.0f;
+                                int gb = 0;
+                                uint32_t sb = ln, off = 0u;
+                                for (uint32_t l = 1u;; ++l) {
+                                    const unsigned long long b = __ballot(cnt >= l);
+                                    if (b == 0ull) break;
+                                    const uint32_t slot = cnt >= l ? off + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u)) : ln;
+                                    const float tt = __int_as_float(__builtin_amdgcn_ds_bpermute((int)(slot << 2), __float_as_int(te)));
+                                    const int gg = __builtin_amdgcn_ds_bpermute((int)(slot << 2), ge);
+                                    if (cnt >= l && tt > 0.0f && (!(tb > 0.0f) || tt < tb || (tt == tb && gg < gb))) { tb = tt; gb = gg; sb = slot; }
+                                    off += (uint32_t)__popcll(b);
+                                }
+                                const int ws = (int)(sb << 2);
+                                const F3 pw = f3(__int_as_float(__builtin_amdgcn_ds_bpermute(ws, __float_as_int(pe.x))),
+                                                 __int_as_float(__builtin_amdgcn_ds_bpermute(ws, __float_as_int(pe.y))),
+                                                 __int_as_float(__builtin_amdgcn_ds_bpermute(ws, __float_as_int(pe.z))));
+                                const F3 nw = f3(__int_as_float(__builtin_amdgcn_ds_bpermute(ws, __float_as_int(ne.x))),
+                                                 __int_as_float(__builtin_amdgcn_ds_bpermute(ws, __float_as_int(ne.y))),
+                                                 __int_as_float(__builtin_amdgcn_ds_bpermute(ws, __float_as_int(ne.z))));
+                                const int ow = __builtin_amdgcn_ds_bpermute(ws, oe);
+                                if (tb > 0.0f && (hit < 0 || tb < tbest || (tb == tbest && gb < hit))) {
+                                    tbest = tb; hit = gb; P = pw; nsrc = nw; outsideI = ow;
+                                }
+                                mHi = 0u; mLo = 0u;
+                            }
+                        }
+                    }
+#endif
                     // pass k tests every lane's k-th candidate with that lane's own matrices from LDS
                     while (__ballot((mHi | mLo) != 0u) != 0ull) {     // wave-uniform trip count
                         if ((mHi | mLo) != 0u) {
