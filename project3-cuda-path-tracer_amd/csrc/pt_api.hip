@@ -1211,8 +1211,8 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     // Path pools: a bounce's queue is kSeg = kCls x kSub segments, each a list of chunks handed out on demand, one ahead of
     // their use (ptk::reserveRun).  At most nLocal * maxBatch paths are alive; every segment may end in a partly filled
     // chunk and holds one chunk installed ahead: ceil(paths / chunk) + 2 kSeg chunks always suffice, whatever the
-    // distribution over the classes (+ the trash chunk 0).  Chunk size: ~1/1024 of the paths (a power of two, at least
-    // 2048), so that the slack stays around 10 % while a chunk outlasts the appends of one memory round trip.
+    // distribution over the classes (+ the trash chunk 0).  Chunk size: a power of two, at least 2048 (rounds 1-3: ~1/1024 of the
+    // paths, so that the slack stayed around 10 % while a chunk outlasts the appends of one memory round trip).
     S.maxBatch = o.max_batch > 0 ? o.max_batch : 1;
     if (S.maxBatch == 1) S.flags &= ~PT_FLAG_TRACE_AHEAD;   // nothing to trace ahead with: every call traces its own iteration
     // slots are 32-bit element indices with 32-bit byte offsets: paths per pool must stay below 2^30
@@ -1221,8 +1221,11 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     if ((long long)k.nLocalPad * S.maxBatch >= (1ll << 30))     // (the camera-ray tiles' index space: rows padded to the tile size)
         return fail(PT_ERR_INVALID, "pt_init: max_batch x rows x padded width too large (limit 2^30)");
     S.numTilesMax = (int)((maxPaths + kBlock - 1) / kBlock) + kSeg;
+    // (round 4: ~1/256 of the paths, at most 2^18, where it was 1/1024 and 2^17 -- a run that opens a new chunk pays a dependent
+    // look-up of the chunk list INSIDE the reservation's window, and four times fewer of them are +2 % on C2, +4 % on the closed box
+    // (profiles/r04_chunk_size_sweep.txt); the slack of 2 kSeg chunks then doubles a mid-sized pool, which 288 GB shrug off)
     k.chunkShift = kMinChunkShift;
-    while (k.chunkShift < 17 && (maxPaths >> k.chunkShift) > 1024) ++k.chunkShift;
+    while (k.chunkShift < 18 && (maxPaths >> k.chunkShift) > 256) ++k.chunkShift;
     if (const char *e = getenv("PT_AMD_CHUNK_SHIFT")) {      // experiments only
         const int v = atoi(e);
         if (v >= kMinChunkShift && v <= 20) k.chunkShift = v;
