@@ -1498,6 +1498,32 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
         k.nSphCull = (int)sc.size();
         HIPCHECK(hipMalloc(&S.dSphCull, sc.size() * sizeof(SphereCull)));
         HIPCHECK(hipMemcpy(S.dSphCull, sc.data(), sc.size() * sizeof(SphereCull), hipMemcpyHostToDevice));
+        // The tables a sphere-heavy workgroup stages in LDS -- the compact hit records, the cubes' face frames, the spheres' matrix rows,
+        // the sweep's entry -> primitive map -- as ONE image in the kernel's own layout (k_bounce: S_GEOMHIT_SMALL .. behind S_SPH), so that
+        // the prologue is a straight copy of 16-byte words: gathering them field by field from the primitives took ~30 dependent
+        // round trips, 28 us at the head of every launch of C5 (profiles/timeline_phases.py: 62 k cycles against Cornell's 10 k).
+        {
+            const size_t hitB = manyHitBytes(ngeoms), frameB = (size_t)k.nCubes * 54 * sizeof(float) + manyFramePad(k.nCubes);
+            const size_t rowB = (size_t)ngeoms * kSphRowFloats * sizeof(float), mapB = ((size_t)k.nSphCull + 7) / 8 * 8 * sizeof(uint16_t);
+            std::vector<unsigned char> blob(hitB + frameB + rowB + mapB, 0);
+            GeomHitSmall *hs = reinterpret_cast<GeomHitSmall *>(blob.data());
+            float *fr = reinterpret_cast<float *>(blob.data() + hitB);
+            float *rows = reinterpret_cast<float *>(blob.data() + hitB + frameB);
+            uint16_t *map = reinterpret_cast<uint16_t *>(blob.data() + hitB + frameB + rowB);
+            for (int g = 0; g < ngeoms; ++g) {
+                const GeomDev &G = hg[g];
+                memcpy(hs[g].nm, G.invT, sizeof hs[g].nm);
+                hs[g].material = G.material; hs[g].type = G.type; hs[g].frame = G.type == 1 ? (int)G.frameSlot : 0;
+                if (G.type == 1) memcpy(fr + (size_t)G.frameSlot * 54, G.cubeFrame, 54 * sizeof(float));
+                float *r = rows + (size_t)g * kSphRowFloats;
+                memcpy(r, G.inv, 12 * sizeof(float)); memcpy(r + 12, G.xf, 12 * sizeof(float)); memcpy(r + 24, G.invZ, 3 * sizeof(float));
+            }
+            for (int i = 0; i < k.nSphCull; ++i) map[i] = (uint16_t)sc[i].geom;
+            if (S.dGeomHit) (void)hipFree(S.dGeomHit);
+            S.dGeomHit = nullptr;
+            HIPCHECK(hipMalloc(&S.dGeomHit, blob.size()));
+            HIPCHECK(hipMemcpy(S.dGeomHit, blob.data(), blob.size(), hipMemcpyHostToDevice));
+        }
     }
     {   // Later bounces: which primitives a tile of queue class c looks at.  Class bit 3 = its paths may hit a binned primitive;
         // bits 0-2 in a scene with walls = the one wall they can still hit (6: any, 7: none), else the direction octant.

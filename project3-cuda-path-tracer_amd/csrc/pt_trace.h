@@ -579,47 +579,36 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
         }
 
         // stage the materials in LDS once per (persistent) workgroup, 16 B per lane per step
-        const GeomDev *ggeoms = A->ggeoms;
         const int ngeoms = A->prm.ngeoms;
         GeomHitDev *const s_geomHit = S_GEOMHIT(A->prm.nmats);
-        float *const s_sph = S_SPH(A->prm.nmats, ngeoms, A->prm.nCubes);   // MANY: [ngeoms][kSphRowFloats]
         float4 *mdst = reinterpret_cast<float4 *>(smats);
         if ((int)threadIdx.x < m16) mdst[threadIdx.x] = stageM;
         for (int i = threadIdx.x + kBlock; i < m16; i += kBlock) mdst[i] = msrc[i];
         if (MANY) {
-            constexpr int kSmallWords = (int)(sizeof(GeomHitSmall) / 4);
-            uint32_t *const dst = reinterpret_cast<uint32_t *>(S_GEOMHIT_SMALL(A->prm.nmats));
-            for (int i = threadIdx.x; i < ngeoms * kSmallWords; i += kBlock) {
-                const int g = i / kSmallWords, k = i - g * kSmallWords;
-                const GeomDev &G = ggeoms[g];
-                uint32_t v = 0;
-                if (k < 12) v = __float_as_uint(G.invT[k]);
-                else if (k == 12) v = (uint32_t)G.material;
-                else if (k == 13) v = (uint32_t)G.type;
-                else if (k == 14) v = (uint32_t)(G.type == 1 ? (int)G.frameSlot : 0);
-                dst[i] = v;
-            }
-            float *const fr = S_FRAMES(A->prm.nmats, ngeoms);
-            for (int i = threadIdx.x; i < ngeoms * 54; i += kBlock) {       // (cubes only: a few of the primitives)
-                const int g = i / 54, k = i - g * 54;
-                const GeomDev &G = ggeoms[g];
-                if (G.type == 1) fr[(int)G.frameSlot * 54 + k] = G.cubeFrame[k];
+            // the tables of a sphere-heavy scene -- hit records, face frames, matrix rows, (later bounces) the sweep's entry -> primitive
+            // map -- arrive as ONE host-built image in this very layout (pt_init): a straight copy, four 16-byte loads per lane in flight
+            const int n16 = (int)((manyHitBytes(ngeoms) + (size_t)A->prm.nCubes * 54 * sizeof(float) + manyFramePad(A->prm.nCubes) +
+                                   (size_t)ngeoms * kSphRowFloats * sizeof(float) +
+                                   (FIRST ? 0 : ((size_t)A->prm.nSphCull + 7) / 8 * 8 * sizeof(uint16_t))) / 16);
+            float4 *const dst = reinterpret_cast<float4 *>(S_GEOMHIT_SMALL(A->prm.nmats));
+            for (int i0 = 0; i0 < n16; i0 += 4 * kBlock) {
+                float4 v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = i0 + q * kBlock + (int)threadIdx.x;
+                    v[q] = i < n16 ? hsrc[i] : make_float4(0, 0, 0, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = i0 + q * kBlock + (int)threadIdx.x;
+                    if (i < n16) dst[i] = v[q];
+                }
             }
         }
         if (!MANY) {
             float4 *const hdst = reinterpret_cast<float4 *>(s_geomHit);
             if ((int)threadIdx.x < h16) hdst[threadIdx.x] = stageH;
             for (int i = threadIdx.x + kBlock; i < h16; i += kBlock) hdst[i] = hsrc[i];
-        }
-        if (MANY) {
-            for (int i = threadIdx.x; i < ngeoms * 27; i += kBlock) {
-                const int g = i / 27, k = i - g * 27;
-                s_sph[g * kSphRowFloats + k] = k < 12 ? ggeoms[g].inv[k] : (k < 24 ? ggeoms[g].xf[k - 12] : ggeoms[g].invZ[k - 24]);
-            }
-            if (!FIRST) {      // later bounces: entry k of the packed culling data -> its primitive (where the camera rays keep the lanes' lists)
-                uint16_t *const sphGeom = reinterpret_cast<uint16_t *>(s_sph + (size_t)ngeoms * kSphRowFloats);
-                for (int i = threadIdx.x; i < A->prm.nSphCull; i += kBlock) sphGeom[i] = (uint16_t)A->sphCull[i].geom;
-            }
         }
     }
     // (the barrier that publishes the staged tables stands further down, behind the first tile's loads: they only need the
