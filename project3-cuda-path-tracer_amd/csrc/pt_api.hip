@@ -930,6 +930,7 @@ int persistent_grid(const void *kernel, size_t lds, int *grid) {
     if (const char *e = getenv("PT_AMD_BLOCKS_PER_CU")) cap = atoi(e);   // experiments only
     if (perCU > cap) perCU = cap;
     *grid = prop.multiProcessorCount * perCU;
+    if (const char *e = getenv("PT_AMD_MAX_GRID")) *grid = std::max(1, std::min(*grid, atoi(e)));   // tests: a small or partitioned device's grid
     return PT_OK;
 }
 
@@ -2468,6 +2469,48 @@ int pt_test_wall_plane_sweep(const PtGeom *geoms, int ngeoms, uint64_t seed, int
     return PT_OK;
 }
 
+int pt_test_box_fast_sweep(const PtGeom *geoms, int ngeoms, uint64_t seed, int64_t rays, uint64_t counts[4], uint64_t div_mismatches[2]) {
+    NEED_GPU();
+    if (!geoms || ngeoms < 1 || !counts || !div_mismatches || rays < 0) return fail(PT_ERR_INVALID, "pt_test_box_fast_sweep: bad argument");
+    std::vector<GeomDev> hg(ngeoms);
+    for (int i = 0; i < ngeoms; ++i) {
+        if (geoms[i].type != PT_CUBE) return fail(PT_ERR_INVALID, "pt_test_box_fast_sweep: cubes only");
+        pack_geom(geoms[i], hg[i]);
+    }
+    DevBuf<GeomDev> dg;
+    DevBuf<unsigned long long> cnt;
+    UP(dg, hg.data(), ngeoms);
+    int rc = cnt.alloc(8);
+    if (rc) return rc;
+    HIPCHECK(hipMemset(cnt.p, 0, 64));
+    DevBuf<float> dump;
+    const bool verbose = getenv("PT_AMD_VERBOSE") && atoi(getenv("PT_AMD_VERBOSE"));
+    if (verbose && (rc = dump.alloc(8 * 24))) return rc;
+    const int per_thread = 256, threads = 256;
+    long long blocks = (rays + (long long)per_thread * threads - 1) / ((long long)per_thread * threads);
+    if (blocks < 1) blocks = 1;
+    if (blocks > (1 << 20)) blocks = 1 << 20;
+    hipLaunchKernelGGL(k_sweep_box_fast, dim3((unsigned)blocks), dim3(threads), 0, 0, dg.p, ngeoms, (unsigned long long)seed, per_thread, cnt.p,
+                       verbose ? dump.p : nullptr);
+    hipLaunchKernelGGL(k_sweep_div_unscaled, dim3(1 << 12), dim3(256), 0, 0, (unsigned long long)seed, 1024, cnt.p + 4);   // 2^20 threads
+    HIPCHECK(hipDeviceSynchronize());
+    unsigned long long h[8];
+    HIPCHECK(hipMemcpy(h, cnt.p, 64, hipMemcpyDeviceToHost));
+    if (verbose && h[6]) {                                // (experiments: the first mismatching rays)
+        float r[8 * 24];
+        HIPCHECK(hipMemcpy(r, dump.p, sizeof r, hipMemcpyDeviceToHost));
+        for (int i = 0; i < (int)std::min<unsigned long long>(h[6], 8); ++i) {
+            const float *q = r + 24 * i;
+            fprintf(stderr, "box sweep mismatch: geom %d org %.9g %.9g %.9g dir %.9g %.9g %.9g | t fast %.9g exact %.9g early %.9g outside %g %g | P %.9g %.9g %.9g / %.9g %.9g %.9g | n %a %a %a / %a %a %a\n",
+                    (int)q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8], q[9], q[10], q[11], q[12], q[13], q[14], q[15], q[16], q[17], q[18], q[19], q[20], q[21], q[22], q[23]);
+        }
+    }
+    for (int i = 0; i < 4; ++i) counts[i] = h[i];
+    div_mismatches[0] = h[4];
+    div_mismatches[1] = h[5];
+    return PT_OK;
+}
+
 int pt_test_slab_quotients(const float *o, const float *d, int n, float *t1, float *t2, float *ref1, float *ref2) {
     NEED_GPU();
     if (n <= 0) return PT_OK;
@@ -2547,13 +2590,13 @@ extern "C" int pt_probe_census(uint32_t out[16]) {
     return PT_OK;
 }
 // instrumented build only (make probe): reads and clears the phase counters of pt_device.h
-extern "C" int pt_probe_read(uint64_t out[32]) {
+extern "C" int pt_probe_read(uint64_t out[64]) {
     NEED_GPU();
-    unsigned long long h[32], z[32] = {0};
+    unsigned long long h[64], z[64] = {0};
     HIPCHECK(hipDeviceSynchronize());
     HIPCHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(ptd::g_probe), sizeof h));
     HIPCHECK(hipMemcpyToSymbol(HIP_SYMBOL(ptd::g_probe), z, sizeof z));
-    for (int i = 0; i < 32; ++i) out[i] = h[i];
+    for (int i = 0; i < 64; ++i) out[i] = h[i];
     return PT_OK;
 }
 #endif

@@ -51,10 +51,11 @@ __device__ __forceinline__ void phaseStamp(int k) {
 __device__ __forceinline__ void probe(int k) {
     if (k >= 9) phaseStamp(k);        // (the tile-level marks only: the marks inside the intersection tests would dominate what they measure)
 }
+__device__ __forceinline__ void probeCount(int, bool) {}
 __device__ __forceinline__ void censusEnter() {}
 __device__ __forceinline__ void censusLeave() {}
 #elif defined(PT_PROBE)
-__device__ unsigned long long g_probe[32];
+__device__ unsigned long long g_probe[64];
 // residency census (MI355X_MICROARCH.md: "verify with a census kernel"): workgroups of k_bounce resident on each CU right
 // now and the most there ever were, keyed by (XCC, SE, SH, CU) from the hardware id registers
 __device__ unsigned int g_censusNow[4096], g_censusMax[4096];
@@ -82,13 +83,23 @@ __device__ __forceinline__ void probe(int k) {
         atomicAdd(&g_probe[2 * k + 1], (unsigned long long)__popcll(m));
     }
 }
+// (counters 16 .. 31 of the same array: events of the lanes for which `cond` holds, e.g. the box test's fast path giving up, by cause)
+__device__ __forceinline__ void probeCount(int k, bool cond) {
+    const unsigned long long m = __ballot(cond);
+    if (m != 0ull && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == (unsigned)__builtin_ctzll(__ballot(1))) {
+        atomicAdd(&g_probe[2 * k], 1ull);
+        atomicAdd(&g_probe[2 * k + 1], (unsigned long long)__popcll(m));
+    }
+}
 #elif defined(PT_MARK)
 // static phase marks in the ISA listing (make marks; profiles/phase_instructions.py counts the instructions between them)
 #define probe(k) asm volatile("; PTMARK " #k)
+__device__ __forceinline__ void probeCount(int, bool) {}
 __device__ __forceinline__ void censusEnter() {}
 __device__ __forceinline__ void censusLeave() {}
 #else
 __device__ __forceinline__ void probe(int) {}
+__device__ __forceinline__ void probeCount(int, bool) {}
 __device__ __forceinline__ void censusEnter() {}
 __device__ __forceinline__ void censusLeave() {}
 #endif
@@ -431,37 +442,17 @@ __device__ __forceinline__ void slabQuotients(float o, float d, float &t1, float
     }
 }
 
-// src/intersections.h:47-89
+// ---- the slab phase of the box test (src/intersections.h:51-77), twice ---------------------------------
+// Both forms leave: hit = `tmax >= tmin && tmax > 0`, and on a hit tmin = the parameter the reference goes on with (tmax when the origin
+// is inside), outs = `outside`, face = the slab normal tmin_n = +-e_axis as axis * 2 + (sign > 0) -- or -1: no slab ever updated it (a
+// ray of NaNs "hits" with the zero vector for a normal, which the reference then normalises: every derived vector is NaN).
 //
-// Early miss (exact, not a heuristic): if on some axis the object-space origin lies beyond a face
-// (o > .5 or o < -.5) and the ray moves further away (d has the sign of o), then in the reference's
-// slab loop both quotients t1, t2 of that axis are <= -0 (a non-zero numerator over a divisor of the
-// opposite sign; +-0 and inf divisors included, NaN impossible), so tb <= -0 updates tmax to a value
-// <= 0 and the final `tmax > 0` fails whatever the other axes do: the test returns -1.  The sign of
-// every component of normalize(v) equals the sign of v's component (the scale 1/sqrt(dot) is >= 0 or
-// NaN, and NaN fails the comparisons below), so the decision is taken BEFORE the normalisation and
-// the six correctly rounded divisions.  It only pays when whole waves take it, i.e. for coherent
-// rays (EARLY_MISS is set for the camera-ray bounce); results are identical either way.
-// CAM_ORIGIN: the ray starts at the camera, whose object-space position is precomputed (GeomDev::camObj).
-// `early` (wave-uniform, with EARLY_MISS): take the early miss at all -- callers that expect nearly every ray to hit skip its compares.
-template <bool EARLY_MISS, bool CAM_ORIGIN = false, typename GD>
-__device__ __forceinline__ float boxIntersectionTest(const GD &g, F3 ro, F3 rd, F3 &P, F3 &nsrc, bool &outside, bool early = true) {
-    probe(0);
-    const F3 qo = CAM_ORIGIN ? f3(g.camObj[0], g.camObj[1], g.camObj[2]) : mulMV(g.inv, ro, 1.0f);
-    const F3 qdu = mulMV0(g.inv, g.invZ, rd);
-    if (EARLY_MISS && early) {
-        // (bitwise on purpose: twelve compares and eleven mask operations, no nest of divergent branches)
-        const bool away = ((qo.x > 0.5f) & (qdu.x > 0.0f)) | ((qo.x < -0.5f) & (qdu.x < 0.0f)) |
-                          ((qo.y > 0.5f) & (qdu.y > 0.0f)) | ((qo.y < -0.5f) & (qdu.y < 0.0f)) |
-                          ((qo.z > 0.5f) & (qdu.z > 0.0f)) | ((qo.z < -0.5f) & (qdu.z < 0.0f));
-        if (away) return -1.0f;
-    }
-    probe(1);
-    const F3 qd = normalize(qdu);
+// boxSlabsExact: the reference's loop as it stands -- normalize, six correctly rounded quotients, the sequential min / max updates.
+__device__ __forceinline__ void boxSlabsExact(F3 qo, F3 qdu, F3 &qd, bool &hit, bool &outs, float &tminOut, int &face) {
+    qd = normalize(qdu);
     float tmin = -1e38f, tmax = 1e38f;
-    // the slab normal n (zero except n[xyz] = +-1) is tracked as axis + value instead of a vector
-    int tmin_axis = -1, tmax_axis = -1;
-    float tmin_nv = 0.0f, tmax_nv = 0.0f;
+    // the slab normal n (zero except n[xyz] = +-1) is tracked as its face index instead of a vector
+    int tmin_face = -1, tmax_face = -1;
     const float qoa[3] = {qo.x, qo.y, qo.z};
     const float qda[3] = {qd.x, qd.y, qd.z};
     // the three axes' quotient pairs by the guarded sequence, and ONE practically never taken region that redoes the
@@ -484,31 +475,144 @@ __device__ __forceinline__ float boxIntersectionTest(const GD &g, F3 ro, F3 rd, 
         const float t1 = t1a[xyz], t2 = t2a[xyz];
         const float ta = t1 < t2 ? t1 : t2;  // glm::min, func_common.inl:409-414
         const float tb = t1 > t2 ? t1 : t2;  // glm::max, func_common.inl:430-435
-        const float nv = t2 < t1 ? +1.0f : -1.0f;
+        const int nf = 2 * xyz + (t2 < t1 ? 1 : 0);      // n[xyz] = t2 < t1 ? +1 : -1
         if (ta > 0 && ta > tmin) {
             tmin = ta;
-            tmin_axis = xyz;
-            tmin_nv = nv;
+            tmin_face = nf;
         }
         if (tb < tmax) {
             tmax = tb;
-            tmax_axis = xyz;
-            tmax_nv = nv;
+            tmax_face = nf;
         }
     }
-    if (tmax >= tmin && tmax > 0) {
+    hit = tmax >= tmin && tmax > 0;
+    outs = true;
+    if (tmin <= 0) {
+        tmin = tmax;
+        tmin_face = tmax_face;
+        outs = false;
+    }
+    tminOut = tmin;
+    face = tmin_face;
+}
+
+// a / d for operands inside the range where the compiler's correctly rounded division neither scales nor fixes anything up (see
+// slabQuotientsFast: the very instructions of that expansion, minus v_div_scale / v_div_fixup); `r0` = v_rcp_f32(d)
+__device__ __forceinline__ float divUnscaled(float a, float d, float r0) {
+    const float r = __builtin_fmaf(__builtin_fmaf(-d, r0, 1.0f), r0, r0);
+    float q = a * r;
+    q = __builtin_fmaf(__builtin_fmaf(-d, q, a), r, q);
+    q = __builtin_fmaf(__builtin_fmaf(-d, q, a), r, q);
+    return q;
+}
+
+// boxSlabsFastDecide + boxSlabsFastFinish (round 5): the same outputs, bit for bit, for half of the instructions -- or `false`: no
+// statement, run boxSlabsExact.
+// The reference's loop needs SIX correctly rounded quotients (~11 instructions each) to take ONE of them as its result; the other
+// five only take part in comparisons.  Here the comparisons are decided on approximate quotients a * v_rcp_f32(d) wherever their
+// outcome is beyond doubt -- the operands differ by more than 2^-19 relative, against an error below 2^-21.5 (v_rcp_f32: one ulp;
+// the product and the reference's own quotient: half an ulp each) -- and only the winner is divided exactly.  Any doubt (operands
+// within the margin of each other: a ray through an edge of the cube) and any operand outside the guarded range (NaN, inf, a
+// direction component below 2^-40 of its length, an object-space origin beyond 2^20, a direction transform outside [2^-40, 2^40])
+// returns `false`.
+// Under the guards (|o| <= 2^20, 2^-40 <= |d| <= ~1, all finite):
+//   a1 = RN(-.5 - o) < a2 = RN(.5 - o) strictly (they differ by 1, an ulp is at most 2^-3), hence t1 = RN(a1 / d) and t2 = RN(a2 / d)
+//   differ as well (relative distance >= 2^-21.2) and are ordered by the sign of d:  d > 0: ta = t1, tb = t2, n = -1;  d < 0: ta = t2,
+//   tb = t1, n = +1.  So ta = RN(an / d), tb = RN(af / d) with the NEAR numerator an = -h - o, the FAR one af = h - o, h =
+//   copysign(.5, d), and n = -sign(d) for both.
+//   The loop leaves tmin = the largest positive ta (-1e38 when none is), tmax = the smallest tb, each with the FIRST axis that
+//   attains it; signs of quotients are exact in either arithmetic (no underflow: |a| is 0 or >= 2^-25), so "some ta > 0" and
+//   "tmax > 0" (= every tb > 0) are decided exactly; `tmax >= tmin` by the margin; the axis is the unique one whose approximate
+//   quotient stands clear of the other two by the margin -- else `false`.
+// Its normalize is the reference's, correctly rounded sqrt and division, without their range handling (sqrtUnscaled, divUnscaled):
+// the squared length is inside [2^-80, 2^80) or the function returns `false`.
+// Two parts, so that the axis and the exact quotient are evaluated for the hits only.  `axis` (Decide -> Finish): the axis K whose
+// quotient is the result -- the entry axis, or the exit axis of a ray that starts inside.
+// tests/test_gpu_parity.py::test_box_fast_path_equals_the_exact_one sweeps 2^28 rays dense in edges, corners and grazes; in a render
+// of cornell.txt one wave in 1400 meets a lane that falls back (profiles/probe_phases.py).
+__device__ __forceinline__ bool boxSlabsFastDecide(F3 qo, F3 qdu, F3 &qd, bool &hit, bool &outs, int &axis) {
+    const float x = dot(qdu, qdu);
+    bool ok = (__float_as_uint(x) - 0x17800000u) < 0x50000000u;            // 2^-80 <= x < 2^80 (NaN, inf, 0, negative: no)
+    const float s = sqrtUnscaled(x);
+    const float inv = divUnscaled(1.0f, s, __builtin_amdgcn_rcpf(s));      // = 1.0f / s: glm's inversesqrt
+    qd = qdu * inv;
+    ok &= (__builtin_fabsf(qo.x) + __builtin_fabsf(qo.y)) + __builtin_fabsf(qo.z) <= 0x1p+20f;     // (NaN fails)
+    ok &= __builtin_fminf(__builtin_fminf(__builtin_fabsf(qd.x), __builtin_fabsf(qd.y)), __builtin_fabsf(qd.z)) >= 0x1p-40f;   // (finite: x is)
+    const F3 h = f3(__builtin_copysignf(0.5f, qd.x), __builtin_copysignf(0.5f, qd.y), __builtin_copysignf(0.5f, qd.z));
+    const F3 an = (-h) - qo, af = h - qo;                                 // (-.5 - o, not -(.5 + o): the zero of o = -.5 is +0)
+    const F3 r0 = f3(__builtin_amdgcn_rcpf(qd.x), __builtin_amdgcn_rcpf(qd.y), __builtin_amdgcn_rcpf(qd.z));
+    const F3 Ta = an * r0, Tb = af * r0;
+    const float m = __builtin_fmaxf(__builtin_fmaxf(Ta.x, Ta.y), Ta.z), md = __builtin_amdgcn_fmed3f(Ta.x, Ta.y, Ta.z);
+    const float M = __builtin_fminf(__builtin_fminf(Tb.x, Tb.y), Tb.z), Md = __builtin_amdgcn_fmed3f(Tb.x, Tb.y, Tb.z);
+    outs = m > 0.0f;                                                      // some ta > 0 (exact)
+    const bool exitPos = M > 0.0f;                                         // tmax > 0 (exact)
+    const float diff = M - m, tol = 0x1p-19f * (__builtin_fabsf(M) + __builtin_fabsf(m));
+    const bool sureHit = exitPos & (!outs | (diff > tol)), sureMiss = !exitPos | (outs & (-diff > tol));
+    constexpr float kBelowOne = 1.0f - 0x1p-19f;
+    const bool unique = (outs & (md < m * kBelowOne)) | (!outs & (Md * kBelowOne > M));   // (hits only: M > 0 there)
+    probeCount(16, true);                                                 // (instrumented build: why the fast path gives up)
+    probeCount(17, !ok);
+    probeCount(18, !(sureHit | sureMiss));
+    probeCount(19, sureHit & !unique);
+    ok &= sureMiss | (sureHit & unique);
+    probeCount(20, !ok);
+    hit = sureHit;
+    const float key0 = outs ? Ta.x : Tb.x, key1 = outs ? Ta.y : Tb.y, ref = outs ? m : M;
+    axis = key0 == ref ? 0 : (key1 == ref ? 1 : 2);
+    return ok;
+}
+// the one exact quotient of a hit
+__device__ __forceinline__ void boxSlabsFastFinish(F3 qo, F3 qd, bool outs, int axis, float &tminOut, int &face) {
+    const bool e0 = axis == 0, e1 = axis == 1;
+    const float oK = e0 ? qo.x : (e1 ? qo.y : qo.z), dK = e0 ? qd.x : (e1 ? qd.y : qd.z);
+    const float hK = __builtin_copysignf(0.5f, dK);
+    const float aK = (outs ? -hK : hK) - oK;
+    tminOut = divUnscaled(aK, dK, __builtin_amdgcn_rcpf(dK));
+    face = 2 * axis + (int)(__float_as_uint(dK) >> 31);                  // n = -sign(d): + (face bit 1) for d < 0
+}
+
+// src/intersections.h:47-89
+//
+// Early miss (exact, not a heuristic): if on some axis the object-space origin lies beyond a face
+// (o > .5 or o < -.5) and the ray moves further away (d has the sign of o), then in the reference's
+// slab loop both quotients t1, t2 of that axis are <= -0 (a non-zero numerator over a divisor of the
+// opposite sign; +-0 and inf divisors included, NaN impossible), so tb <= -0 updates tmax to a value
+// <= 0 and the final `tmax > 0` fails whatever the other axes do: the test returns -1.  The sign of
+// every component of normalize(v) equals the sign of v's component (the scale 1/sqrt(dot) is >= 0 or
+// NaN, and NaN fails the comparisons below), so the decision is taken BEFORE the normalisation and
+// the six correctly rounded divisions.  It only pays when whole waves take it, i.e. for coherent
+// rays (EARLY_MISS is set for the camera-ray bounce); results are identical either way.
+// CAM_ORIGIN: the ray starts at the camera, whose object-space position is precomputed (GeomDev::camObj).
+// `early` (wave-uniform, with EARLY_MISS): take the early miss at all -- callers that expect nearly every ray to hit skip its compares.
+// EXACT_ONLY: the slab phase by the reference's loop alone (the parity sweep's other side; experiments)
+#ifndef PT_BOX_FAST
+#define PT_BOX_FAST 1
+#endif
+template <bool EARLY_MISS, bool CAM_ORIGIN = false, bool EXACT_ONLY = !PT_BOX_FAST, typename GD>
+__device__ __forceinline__ float boxIntersectionTest(const GD &g, F3 ro, F3 rd, F3 &P, F3 &nsrc, bool &outside, bool early = true) {
+    probe(0);
+    const F3 qo = CAM_ORIGIN ? f3(g.camObj[0], g.camObj[1], g.camObj[2]) : mulMV(g.inv, ro, 1.0f);
+    const F3 qdu = mulMV0(g.inv, g.invZ, rd);
+    if (EARLY_MISS && early) {
+        // (bitwise on purpose: twelve compares and eleven mask operations, no nest of divergent branches)
+        const bool away = ((qo.x > 0.5f) & (qdu.x > 0.0f)) | ((qo.x < -0.5f) & (qdu.x < 0.0f)) |
+                          ((qo.y > 0.5f) & (qdu.y > 0.0f)) | ((qo.y < -0.5f) & (qdu.y < 0.0f)) |
+                          ((qo.z > 0.5f) & (qdu.z > 0.0f)) | ((qo.z < -0.5f) & (qdu.z < 0.0f));
+        if (away) return -1.0f;
+    }
+    probe(1);
+    F3 qd;
+    float tmin;
+    int face, axis;
+    bool hit, outs;
+    if (EXACT_ONLY || !boxSlabsFastDecide(qo, qdu, qd, hit, outs, axis)) boxSlabsExact(qo, qdu, qd, hit, outs, tmin, face);
+    else if (hit) boxSlabsFastFinish(qo, qd, outs, axis, tmin, face);
+    if (hit) {
         probe(2);
-        outside = true;
-        if (tmin <= 0) {
-            tmin = tmax;
-            tmin_axis = tmax_axis;
-            tmin_nv = tmax_nv;
-            outside = false;
-        }
-        const F3 tmin_n = f3(tmin_axis == 0 ? tmin_nv : 0.0f, tmin_axis == 1 ? tmin_nv : 0.0f,
-                             tmin_axis == 2 ? tmin_nv : 0.0f);
+        outside = outs;
         P = mulMV(g.xf, getPointOnRay(qo, qd, tmin), 1.0f);
-        nsrc = tmin_n;   // normal = normalize(transform * (tmin_n, 0)): hitNormal(), evaluated for the nearest hit only
+        // the slab normal's face index, as bits, in nsrc.x: normal = normalize(transform * (tmin_n, 0)) is looked up by it for the nearest hit only (cubeFace)
+        nsrc = f3(__int_as_float(face), 0.0f, 0.0f);
         return length(ro - P);
     }
     return -1.0f;
@@ -903,13 +1007,12 @@ __device__ __forceinline__ F3 hitNormalSphere(const float *invT, F3 nsrc, bool o
     const F3 n = normalize(mulMV(invT, nsrc, 0.0f));
     return outside ? n : -n;
 }
-// face index of a cube hit (axis * 2 + (sign > 0)); ok = false for a hit without an exit slab -- a ray of NaNs -- which
-// leaves nsrc = 0: the reference then normalises the zero vector, i.e. every derived vector is NaN
+// face index of a cube hit (axis * 2 + (sign > 0)), which boxIntersectionTest leaves as bits in nsrc.x; ok = false (face -1) for a hit
+// without an exit slab -- a ray of NaNs -- whose slab normal is the zero vector: the reference then normalises it, i.e. every derived vector is NaN
 __device__ __forceinline__ int cubeFace(F3 nsrc, bool &ok) {
-    const int axis = nsrc.x != 0.0f ? 0 : (nsrc.y != 0.0f ? 1 : 2);
-    const float v = nsrc.x + nsrc.y + nsrc.z;                     // the one non-zero component, +-1
-    ok = v != 0.0f;
-    return 2 * axis + (v > 0.0f ? 1 : 0);
+    const int face = __float_as_int(nsrc.x);
+    ok = face >= 0;
+    return face;
 }
 // entry `which` (0 normal, 1 and 2 the sampler's tangents) of a face of the table (selects: adding 0 would turn -0 into +0)
 __device__ __forceinline__ F3 cubeFrameVector(const float *cubeFrame, int face, int which, bool ok) {

@@ -500,6 +500,114 @@ __global__ void k_sweep_wall_planes(KParams prm, const GeomDev *wallGeoms, const
     if (ns) atomicAdd(single, (unsigned long long)ns);
 }
 
+// boxIntersectionTest with the fast slab phase (boxSlabsFast, falling back on the reference's loop) next to the test with the
+// reference's loop alone, on rays dense in what the fast path has to be careful about: edges and corners of the cube (the slabs'
+// parameters within the margin of each other), grazes, origins on, just off and inside the surface, directions with tiny, zero,
+// infinite and NaN components, axis-parallel ones.  cnt[0] = rays, [1] = rays the fast path decided, [2] = hits among those,
+// [3] = bit mismatches (t, and on a hit P, nsrc, outside; NaN == NaN) -- must be 0.
+__global__ void k_sweep_box_fast(const GeomDev *geoms, int ngeoms, unsigned long long seed, int per_thread, unsigned long long *cnt, float *dump) {
+    unsigned long long x = seed + (blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ull;
+    unsigned int nr = 0, nf = 0, nh = 0, bad = 0;
+    for (int k = 0; k < per_thread; ++k) {
+        float u[16];
+        for (int j = 0; j < 16; ++j) {
+            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+            u[j] = (float)(x >> 40) * (1.0f / 16777216.0f);
+        }
+        const GeomDev &G = geoms[(int)(u[0] * (float)ngeoms) % ngeoms];
+        // a point of the cube in object space: anywhere in it, on a face, on an edge, at a corner (coordinates snapped to +-.5)
+        auto snap = [](float v, float w) { return w < 0.5f ? v - 0.5f : (w < 0.75f ? -0.5f : 0.5f); };
+        const F3 onCube = f3(snap(u[1], u[4]), snap(u[2], u[5]), snap(u[3], u[6] * 0.75f));
+        // the origin: around the cube (up to 3 of its sizes away), a multiple of it (far), on / just off its surface, inside
+        F3 oobj;
+        const int ok = (int)(u[7] * 8.0f);
+        if (ok < 3) oobj = f3(6 * u[8] - 3, 6 * u[9] - 3, 6 * u[10] - 3);
+        else if (ok == 3) oobj = f3(600 * u[8] - 300, 600 * u[9] - 300, 600 * u[10] - 300);
+        else if (ok == 4) oobj = f3(u[8] - 0.5f, u[9] - 0.5f, u[10] - 0.5f);
+        else {
+            const F3 q = f3(snap(u[8], u[11]), snap(u[9], 0.2f), snap(u[10], 0.2f));
+            const float off = ok == 5 ? 0.0f : (ok == 6 ? 1e-3f : 1e-6f) * (u[12] < 0.5f ? 1.0f : -1.0f);
+            oobj = f3(q.x * (1.0f + off), q.y, q.z);
+            if (u[12] > 0.66f) oobj = f3(q.y, q.x * (1.0f + off), q.z); else if (u[12] > 0.33f) oobj = f3(q.z, q.y, q.x * (1.0f + off));
+        }
+        F3 org = mulMV(G.xf, oobj, 1.0f);
+        // the direction: at the point of the cube (hits through faces, edges, corners), nudged by a few ulps, or anywhere
+        const F3 target = mulMV(G.xf, onCube, 1.0f);
+        F3 dir = target - org;
+        const int dk = (int)(u[13] * 16.0f);
+        if (dk < 3) dir = f3(u[1] - 0.5f, u[2] - 0.5f, u[3] - 0.5f);
+        else if (dk < 6) dir = dir + f3(u[14] - 0.5f, u[15] - 0.5f, u[11] - 0.5f) * (1e-6f * (__builtin_fabsf(dir.x) + __builtin_fabsf(dir.y) + __builtin_fabsf(dir.z)));
+        else if (dk == 6) dir = mulMV(G.xf, f3(u[14] < 0.5f ? 1.0f : -1.0f, 0, 0), 0.0f);       // along an object axis
+        else if (dk == 7) dir = mulMV(G.xf, f3(0, u[14] - 0.5f, u[15] - 0.5f), 0.0f);            // in an object plane
+        else if (dk == 8) dir = f3(dir.x, 0.0f, dir.z);
+        else if (dk == 9) dir = f3(dir.x, dir.y * 1e-13f, dir.z * (u[14] < 0.5f ? 1e-20f : 1.0f));
+        dir = normalize(dir);
+        if (dk == 10) {                                  // raw bit patterns now and then: NaN, inf, denormals, huge
+            const uint32_t b = (uint32_t)x;
+            if (u[14] < 0.3f) dir.x = __uint_as_float(b); else if (u[14] < 0.6f) org.y = __uint_as_float(b); else dir = dir * __uint_as_float(b & 0x7fffffffu);
+        }
+        F3 P1 = f3(1, 2, 3), N1 = f3(4, 5, 6), P2 = P1, N2 = N1;
+        bool o1 = false, o2 = false;
+        const float t1 = boxIntersectionTest<false, false, false>(G, org, dir, P1, N1, o1);
+        const float t2 = boxIntersectionTest<false, false, true>(G, org, dir, P2, N2, o2);
+        auto same = [](float a, float b) { return __float_as_uint(a) == __float_as_uint(b) || (a != a && b != b); };
+        bool eq = same(t1, t2) && o1 == o2 && same(P1.x, P2.x) && same(P1.y, P2.y) && same(P1.z, P2.z) && same(N1.x, N2.x) && same(N1.y, N2.y) && same(N1.z, N2.z);
+        // (the early-miss variant as well: it returns before the slab phase or not at all)
+        F3 P3 = f3(1, 2, 3), N3 = f3(4, 5, 6);
+        bool o3 = false;
+        const float t3 = boxIntersectionTest<true, false, false>(G, org, dir, P3, N3, o3);
+        // (its argument -- both quotients of an axis the ray leaves are <= -0 -- takes finite products: a direction of 1e38 makes the
+        // transform overflow, inf - inf = NaN in the reference's loop and a plain miss here; the renderer's directions are unit vectors)
+        const bool tame = __builtin_fabsf(dir.x) + __builtin_fabsf(dir.y) + __builtin_fabsf(dir.z) < 1e30f;
+        if (tame) eq = eq && same(t3, t2) && o3 == o2 && same(P3.x, P2.x) && same(P3.y, P2.y) && same(P3.z, P2.z) && same(N3.x, N2.x);
+        bad += eq ? 0u : 1u;
+        if (!eq && dump) {                               // (the first few mismatching rays, for the host to print: PT_AMD_VERBOSE)
+            const unsigned long long slot = atomicAdd(&cnt[6], 1ull);
+            if (slot < 8) {
+                float *r = dump + 24 * slot;
+                r[0] = (float)(&G - geoms); r[1] = org.x; r[2] = org.y; r[3] = org.z; r[4] = dir.x; r[5] = dir.y; r[6] = dir.z;
+                r[7] = t1; r[8] = t2; r[9] = t3; r[10] = o1; r[11] = o2; r[12] = P1.x; r[13] = P1.y; r[14] = P1.z; r[15] = P2.x; r[16] = P2.y; r[17] = P2.z;
+                r[18] = N1.x; r[19] = N1.y; r[20] = N1.z; r[21] = N2.x; r[22] = N2.y; r[23] = N2.z;
+            }
+        }
+        ++nr;
+        {   // what the fast path says about this ray
+            const F3 qo = mulMV(G.inv, org, 1.0f), qdu = mulMV0(G.inv, G.invZ, dir);
+            F3 qd;
+            bool hit, outs;
+            int axis;
+            if (boxSlabsFastDecide(qo, qdu, qd, hit, outs, axis)) { ++nf; nh += hit ? 1u : 0u; }
+        }
+    }
+    atomicAdd(&cnt[0], (unsigned long long)nr);
+    if (nf) atomicAdd(&cnt[1], (unsigned long long)nf);
+    if (nh) atomicAdd(&cnt[2], (unsigned long long)nh);
+    if (bad) atomicAdd(&cnt[3], (unsigned long long)bad);
+}
+// divUnscaled(1, s) = 1.0f / s on EVERY float of [2^-40, 2^40] (the fast normalize's reciprocal), and divUnscaled(a, d) = a / d on
+// pseudo-random pairs of the box test's range (|a| <= 2^20 + 1, 2^-40 <= |d| <= 2): bad[0] / bad[1] count bit mismatches
+__global__ void k_sweep_div_unscaled(unsigned long long seed, int per_thread, unsigned long long *bad) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    unsigned int b0 = 0, b1 = 0;
+    for (unsigned long long bits = 0x2b800000ull + tid; bits <= 0x53800000ull; bits += stride) {
+        const float s = __uint_as_float((uint32_t)bits);
+        const float q = divUnscaled(1.0f, s, __builtin_amdgcn_rcpf(s)), r = 1.0f / s;
+        b0 += __float_as_uint(q) == __float_as_uint(r) ? 0u : 1u;
+    }
+    unsigned long long x = seed + tid * 0x9E3779B97F4A7C15ull;
+    for (int k = 0; k < per_thread; ++k) {
+        x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+        const uint32_t ab = (uint32_t)x, db = (uint32_t)(x >> 32);
+        // a: sign, exponent 2^-25 .. 2^20, any mantissa (or exactly 0); d: sign, exponent 2^-40 .. 2^0, any mantissa
+        float a = __uint_as_float((ab & 0x807fffffu) | ((uint32_t)(127 - 25 + (ab >> 23 & 63) % 46) << 23));
+        if ((k & 63) == 7) a = 0.0f;
+        const float d = __uint_as_float((db & 0x807fffffu) | ((uint32_t)(127 - 40 + (db >> 23 & 63) % 41) << 23));
+        const float q = divUnscaled(a, d, __builtin_amdgcn_rcpf(d)), r = a / d;
+        b1 += __float_as_uint(q) == __float_as_uint(r) ? 0u : 1u;
+    }
+    if (b0) atomicAdd(&bad[0], (unsigned long long)b0);
+    if (b1) atomicAdd(&bad[1], (unsigned long long)b1);
+}
 // slabQuotients vs the compiler's correctly rounded division; counts mismatching lanes
 __global__ void k_test_slab_quotients(const float *o, const float *d, int n, float *t1, float *t2, float *r1, float *r2) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -64,7 +64,7 @@ struct Ctrl {
     uint32_t pos[2][kMaxDepthSlots][kSeg][kCtrPad];
     uint32_t bump[2][kMaxDepthSlots][kCtrPad];
     // ticket[p][d][0] = tiles handed out beyond the two static ones per workgroup by the launch of bounce d (k_bounce: "tickets")
-    // (sharded: ticket t of shard s = blockIdx % kTicketShards stands for tile 2 grid + t kTicketShards + s -- one word for a whole
+    // (sharded: ticket t of shard s = blockIdx % n stands for tile 2 grid + t n + s, n = min(kTicketShards, grid) -- one word for a whole
     // launch's tiles serialised its 20 000 atomics at ~12 ns each, twice the launch's own length)
     uint32_t ticket[2][kMaxDepthSlots][kTicketShards][kCtrPad];
     // never zeroed by an iteration
@@ -737,6 +737,9 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
     // tile -- whose loads are requested before the compaction -- is always known: no new latency in the chain.  A shard's tickets are
     // drawn in increasing order, so a workgroup whose next tile lies beyond the queue's end holds no valid later one.
     uint32_t Tn1 = kTickets ? T + gridDim.x : 0u;   // the tile after T (carried only where tickets can be drawn; else always T + grid)
+    // (a grid smaller than kTicketShards -- a partitioned or small device, PT_AMD_BLOCKS_PER_CU, one workgroup per CU -- has one shard per
+    // workgroup: a shard nobody draws from would leave its tiles unvisited)
+    auto ticketShards = [&]() -> uint32_t { return gridDim.x < (uint32_t)kTicketShards ? gridDim.x : (uint32_t)kTicketShards; };
     while (T < numTiles) {
         // the lane id, opaque to the optimiser: the lane masks derived from it (tid < 16, wave > k, ...) are then
         // recomputed where a tile needs them -- one v_cmp each -- instead of being hoisted out of the loop into SGPR pairs
@@ -1503,7 +1506,7 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
             uint32_t tk = 0u;
             if (ticketed && tid == (uint32_t)CLS) {             // (the lane behind the reserving ones, wave 0: in flight together with the reservation's atomics)
                 const ArgsPtr A = launder(kargs);
-                tk = atomicAdd(&A->ctrl->ticket[A->parity][A->depth][blockIdx.x % kTicketShards][0], 1u);
+                tk = atomicAdd(&A->ctrl->ticket[A->parity][A->depth][blockIdx.x % ticketShards()][0], 1u);
             }
             if (tid < CLS) {
                 const ArgsPtr A = launder(kargs);
@@ -1522,7 +1525,7 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
                 s_base[CLS + tid] = sp;
                 s_base[2 * CLS + tid] = r1;
             }
-            if (ticketed && tid == (uint32_t)CLS) s_ticket[0] = 2u * gridDim.x + tk * (uint32_t)kTicketShards + blockIdx.x % kTicketShards;
+            if (ticketed && tid == (uint32_t)CLS) s_ticket[0] = 2u * gridDim.x + tk * ticketShards() + blockIdx.x % ticketShards();
             probe(23);                                          // (second barrier)
             __syncthreads();
             if (kTickets) Tn1 = ticketed ? s_ticket[0] : Tnext + gridDim.x;
