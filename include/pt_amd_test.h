@@ -94,6 +94,13 @@ int pt_test_mesh_cull_sweep(const PtGeom *geom, const float *tris, int ntris, ui
  * bit mismatches over `pairs` (o, d) pairs (must be 0). */
 int pt_test_slab_quotients(const float *o, const float *d, int n, float *t1, float *t2, float *ref1, float *ref2);
 int pt_test_slab_quotients_sweep(uint64_t seed, int64_t pairs, uint64_t *mismatches);
+/* The box test's fast slab phase (pt_device.h: boxSlabsFast -- comparisons on approximate quotients wherever their outcome is beyond
+ * doubt, ONE exact quotient, the reference's loop as the fallback) against the reference's loop alone: `rays` pseudo-random rays per
+ * call against the cubes of `geoms`, dense in edges, corners, grazes, surface origins, degenerate directions.  counts[0] = rays,
+ * [1] = rays the fast path decided, [2] = hits among those, [3] = bit mismatches of (t, P, normal source, outside) -- must be 0.
+ * div_mismatches[0]: the fast normalize's reciprocal against 1.0f / s on every float of [2^-40, 2^40]; [1]: the one exact quotient
+ * against a / d on 2^30 pairs of the box test's range -- both must be 0. */
+int pt_test_box_fast_sweep(const PtGeom *geoms, int ngeoms, uint64_t seed, int64_t rays, uint64_t counts[4], uint64_t div_mismatches[2]);
 /* sqrtUnscaled (the correctly rounded sqrt without its exponent-range handling, used by the hemisphere sampler)
  * next to the compiler's sqrt on every fp32 bit pattern of its range (+-0 and [2^-96, inf)), and inverseSqrtNearOne
  * (the re-normalisation of getPointOnRay) next to 1.0f / sqrtf on every bit pattern: mismatches[0] and [2] must be 0,

@@ -20,7 +20,7 @@ for scene_name, res, depth in SCENES:
     sc.set_resolution(*res)
     pt.pathtraceFree()
     pt.pathtraceInit(sc, traceDepth=depth, max_batch=8, pipeline_depth=3)
-    out = (C.c_uint64 * 32)()
+    out = (C.c_uint64 * 64)()
     L.pt_probe_read(out)
     for it in range(1, 33, 8):
         pt.pathtrace_batch(None, 0, it, 8)
@@ -31,4 +31,6 @@ for scene_name, res, depth in SCENES:
     print("%s %dx%d depth %d: %d wave-tiles after the first bounce (%.1f valid paths per wave); the FIRST bounce's phases are included in the counts below" % (scene_name, res[0], res[1], depth, v[14], v[15] / tiles))
     for k in list(range(7)) + list(range(8, 14)):
         print("  %-30s %10d wave executions, %5.1f active lanes each" % (names[k], v[2 * k], v[2 * k + 1] / max(v[2 * k], 1)))
+    for k, what in ((16, "box fast path: runs"), (17, "  guards fail (range, NaN)"), (18, "  hit / miss within the margin"), (19, "  a hit's axis within the margin"), (20, "  falls back on the exact loop")):
+        print("  %-30s %10d wave executions, %5.1f lanes each" % (what, v[2 * k], v[2 * k + 1] / max(v[2 * k], 1)))
 pt.pathtraceFree()

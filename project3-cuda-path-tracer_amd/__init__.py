@@ -57,7 +57,7 @@ ABI_SYMBOLS = [
 # every symbol include/pt_amd_test.h declares: libpt_amd_test.so only -- the product library must NOT export them
 TEST_ABI_SYMBOLS = [
     "pt_test_utilhash", "pt_test_rng", "pt_test_intersect", "pt_test_hemisphere", "pt_test_sincos", "pt_test_reflect_refract",
-    "pt_test_slab_quotients", "pt_test_slab_quotients_sweep", "pt_test_sphere_cull_sweep", "pt_test_unscaled_sqrt_sweep",
+    "pt_test_slab_quotients", "pt_test_slab_quotients_sweep", "pt_test_box_fast_sweep", "pt_test_sphere_cull_sweep", "pt_test_unscaled_sqrt_sweep",
     "pt_test_force_fault", "pt_test_pow", "pt_test_wall_box_sweep", "pt_test_mesh_intersect", "pt_test_mesh_bvh",
     "pt_test_mesh_cull_sweep", "pt_test_camera_cull_sweep", "pt_test_camera_cull_tables",
     "pt_test_wall_plane_sweep", "pt_test_sphere_halfline_sweep", "pt_test_sphere_cluster_sweep", "pt_test_sphere_clusters", "pt_test_camera_cull_margin",
@@ -120,6 +120,7 @@ def _bind(L, with_tests):
         L.pt_test_reflect_refract.argtypes = [vp, vp, vp, i32, vp, vp]
         L.pt_test_slab_quotients.argtypes = [vp, vp, i32, vp, vp, vp, vp]
         L.pt_test_slab_quotients_sweep.argtypes = [C.c_uint64, i64, u64p]
+        L.pt_test_box_fast_sweep.argtypes = [vp, i32, C.c_uint64, i64, u64p, u64p]
         L.pt_test_sphere_cull_sweep.argtypes = [vp, i32, C.c_uint64, i64, u64p, u64p]
         L.pt_test_sphere_halfline_sweep.argtypes = [vp, i32, C.c_uint64, i64, u64p, u64p, u64p]
         L.pt_test_sphere_cluster_sweep.argtypes = [vp, i32, C.c_uint64, i64, u64p, u64p, vp]
@@ -627,6 +628,16 @@ def test_camera_cull_margin(camera, geoms, samples=1):
     w, n = C.c_double(), C.c_uint64()
     _tcheck(test_lib().pt_test_camera_cull_margin(_p(cam), _p(geoms), len(geoms), samples, C.byref(w), C.byref(n)))
     return float(w.value), int(n.value)
+
+
+def test_box_fast_sweep(geoms, seed, rays):
+    """Device sweep of the box test's fast slab phase against the reference's loop.  Returns (rays, decided by the fast path, hits
+    among those, bit mismatches, mismatches of the fast reciprocal, mismatches of the fast quotient)."""
+    geoms = np.ascontiguousarray(geoms)
+    c = (C.c_uint64 * 4)()
+    d = (C.c_uint64 * 2)()
+    _tcheck(test_lib().pt_test_box_fast_sweep(_p(geoms), len(geoms), seed, rays, c, d))
+    return tuple(int(v) for v in c) + tuple(int(v) for v in d)
 
 
 def test_wall_plane_sweep(geoms, seed, rays):

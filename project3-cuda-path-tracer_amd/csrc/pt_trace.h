@@ -624,9 +624,11 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
         asm volatile("" : "+s"(h));
         return h;
     };
-    uint32_t nLight = 0, nMiss = 0;         // per-lane tallies (VGPRs are the less scarce kind here), reduced and flushed once at the end
+    // tallies of the WAVE, in scalar registers (a ballot's population per tile; rounds 1-4 kept them per lane: three vector registers across
+    // the whole tile loop, which round 5's box test needed back), flushed once at the end
+    uint32_t sLight = 0, sMiss = 0;
     uint32_t wvSel = 0;                     // which half of s_wave the current tile counts in (0 or kWaves * kCls)
-    uint32_t nEarly = 0;                    // survivors that certainly miss everything: ended at the scatter
+    uint32_t sEarly = 0;                    // survivors that certainly miss everything: ended at the scatter
     uint32_t sgIn = 0;                      // input segment of the tile being set up (tiles are visited in increasing order)
     // FIRST: the k-th tile of a workgroup is rotated k column bands to the right inside its row (see below).  The grid is a multiple
     // of the tiles per row (pt_init), so every tile of a workgroup has the same band c0 = blockIdx % tilesPerRow: ONE division, here.
@@ -788,7 +790,7 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
             // the next tile (no rays, no compaction, no barrier; the test is the same for the four waves of the workgroup).
             // (the four bounds loaded together and compared without short-circuit: one scalar load, no chain of dependent ones)
             if ((y0 < sr1) | (y0 > sr3) | (x0 + (kBlock - 1) < sr0) | (x0 > sr2)) {
-                nMiss += valid ? 1u : 0u;
+                sMiss += (uint32_t)__popcll(__ballot(valid));
                 T = Tnext;
                 continue;
             }
@@ -799,10 +801,10 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
 
         // (per-lane flags that are set deep inside the divergent code and read after it are ints: as bools they would live in
         // SGPR pairs and cost three mask operations at every join on the way out)
-        uint32_t aliveI = 0u;
+        // bit 0: the path goes on (a survivor), 1: it ended on an emitter, 2: it missed everything, 3: it ended at its scatter (certain to miss everything)
+        uint32_t fl = 0u;
         uint32_t smallCandI = 1u;                               // class bit 3 of a survivor
         uint32_t wallSel = 8u;                                  // class bits 0-2 of a survivor in a scene with walls (8: no walls: the octant)
-        uint32_t lightHitI = 0u, missedI = 0u;
         F3 org = f3(0, 0, 0), dir = f3(0, 0, 1), col = f3(0, 0, 0);
         int pix = 0;
         int packedCur = 0;                                      // later bounces: remainingBounces | batch index << 8, as loaded (ONE register
@@ -1166,7 +1168,7 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
             }
             probe(16);                                          // (shading)
             if (hit < 0) {
-                missedI = 1u;                                    // S4: background is black
+                fl = 4u;                                         // S4: background is black
             } else {
                 probe(9);
                 // per-lane primitive: LDS lookup of its hit record (sphere-heavy scenes: the compact record + the frame table)
@@ -1223,7 +1225,7 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
                 }
                 const MaterialDev &M = smats[ghMaterial];       // (the fields of the rarer branches)
                 if (mEmit > 0.0f) {                              // S5: emitter ends the path
-                    lightHitI = 1u;
+                    fl = 2u;
                     const ArgsPtr A = launder(kargs);
                     float *const contrib = A->contrib;
                     if (hotNow() & kHotContrib) {
@@ -1346,7 +1348,7 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
                     }
                     org = norg;
                     dir = ndir;
-                    aliveI = 1u;
+                    fl = 1u;
                     {                                            // class bit 3: can the new ray hit a small primitive at all?
                         const int nBinned = (int)hotBinned(hotNow());
                         if (nBinned > 0) {
@@ -1409,8 +1411,7 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
                                     // The path ends here and is tallied as what it is, a path that entered that bounce and missed.
                                     // (Not under pt_debug_trace_paths, which shows the queue as the oracle lists it.)
                                     if (cnt == 0 && smallCandI == 0u && (hotNow() & (kHotAllClassified | kHotContrib)) == (kHotAllClassified | kHotContrib)) {
-                                        aliveI = 0u;
-                                        ++nEarly;
+                                        fl = 8u;
                                     }
                                 }
                             } else if (CLUSTER) {
@@ -1455,18 +1456,19 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
                 sa += acc;
             }
 #endif
-            if (__float_as_uint(xa) + __float_as_uint(xb) + sa + sb == 0x12345677u && pix == -12345) nMiss += 7u;
+            if (__float_as_uint(xa) + __float_as_uint(xb) + sa + sb == 0x12345677u && pix == -12345) fl |= 4u;
         }
 #endif
         probe(17);                                              // (next tile's loads)
-        nLight += lightHitI;
-        nMiss += missedI;
+        sLight += (uint32_t)__popcll(__ballot((fl & 2u) != 0u));
+        sMiss += (uint32_t)__popcll(__ballot((fl & 4u) != 0u));
+        sEarly += (uint32_t)__popcll(__ballot((fl & 8u) != 0u));
         if (!FIRST) {       // the next tile of this workgroup that needs work: its loads fly during the compaction below
             while (Tnext < numTiles && !setupTile(Tnext, tid, nextMeta)) Tnext += gridDim.x;
             if (Tnext < numTiles) loadTile(nextMeta, nextRegs);
         }
         probe(18);                                              // (compaction)
-        const bool alive = aliveI != 0u;
+        const bool alive = (fl & 1u) != 0u;
 
         if (!(hotNow() & kHotLast)) {                                 // S8: compaction into `out`, binned by class
             // The compaction is the tile's latency chain (barrier, reservation round trip, barrier, stores): its waves issue
@@ -1571,7 +1573,7 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
     probe(29);                           // (timeline builds: the launch's sums go out)
     // tallies: lanes -> wave (shuffles) -> workgroup (LDS) -> ONE atomic per workgroup and tally on counters sharded kTallyShards ways
     // (every workgroup of a launch ends with these: unsharded, or one per wave, they serialise at the memory side)
-    const uint32_t waveLight = waveSum(nLight), waveEarly = waveSum(nEarly), waveMiss = waveSum(nMiss) + waveEarly;
+    const uint32_t waveLight = sLight, waveEarly = sEarly, waveMiss = sMiss + sEarly;
     __syncthreads();                                   // (every wave is done with the scratch of its last tile)
     if (threadIdx.x < 3) s_wave[threadIdx.x] = 0u;
     __syncthreads();

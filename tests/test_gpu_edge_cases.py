@@ -366,6 +366,19 @@ def test_undersized_pool_fails_loudly(gpu, oracle, monkeypatch):
     _compare(gpu, oracle, sc, [1, 2])                     # a fresh pt_init with real pools renders correctly again
 
 
+@pytest.mark.parametrize("grid", [8, 24, 56, 72])
+def test_grids_smaller_than_the_ticket_shards_visit_every_tile(gpu, oracle, monkeypatch, grid):
+    # tile tickets are drawn from min(kTicketShards, grid) shards -- with a grid below the 64 shards (a small or
+    # partitioned device, one workgroup per CU; PT_AMD_MAX_GRID: tests only) a shard nobody draws from would leave its tiles, their
+    # paths and their radiance out.  A frame of 1200 tiles per iteration on 8 .. 72 workgroups against the oracle, bit for bit,
+    # and every path accounted for.
+    sc = gpu.Scene(os.path.join(SCENES, "cornell.txt"))
+    sc.set_resolution(640, 480)
+    monkeypatch.setenv("PT_AMD_MAX_GRID", str(grid))
+    _compare(gpu, oracle, sc, [1, 2, 3], max_batch=2, pipeline_depth=2)
+    monkeypatch.delenv("PT_AMD_MAX_GRID")
+
+
 def test_forced_fault_words_are_reported(gpu):
     import torch
     # renderer: a fault word set by hand is reported by pt_sync and pt_counters and survives a counter reset

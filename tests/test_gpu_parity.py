@@ -105,6 +105,30 @@ def test_slab_quotients_equal_ieee_division(gpu):
     assert gpu.test_slab_quotients_sweep(12345, 1 << 30) == 0        # 2^30 more pairs on the device
 
 
+def test_box_fast_path_equals_the_exact_one(gpu, oracle):
+    # round 5: the box test decides its slab comparisons on approximate quotients where their outcome is beyond doubt and divides
+    # exactly ONCE (pt_device.h: boxSlabsFast); any doubt or operand outside its guards runs the reference's loop.  Both forms of the
+    # test, bit for bit, on rays dense in edges, corners, grazes, surface origins and degenerate directions -- thin walls, rotated and
+    # sheared boxes, tiny and huge ones, boxes far from the origin.
+    S = oracle.make_geom
+    sets = {
+        "cornell walls": [S(1, 0, (0, 0, 0), (0, 0, 0), (10, .01, 10)), S(1, 0, (0, 10, 0), (0, 0, 90), (.01, 10, 10)), S(1, 0, (0, 5, -5), (0, 90, 0), (.01, 10, 10)),
+                          S(1, 0, (-5, 5, 0), (0, 0, 0), (.01, 10, 10)), S(1, 0, (5, 5, 0), (0, 0, 0), (.01, 10, 10)), S(1, 0, (0, 10, 0), (0, 0, 0), (3, .3, 3))],
+        "rotated": [S(1, 0, (1, 2, 3), (30, 45, 60), (1, 2, 3)), S(1, 0, (-2, 1, 0), (10, 200, -75), (.5, .5, 4)), S(1, 0, (0, 0, 0), (45, 45, 45), (1, 1, 1))],
+        "extremes": [S(1, 0, (0, 0, 0), (0, 0, 0), (1e-3, 1e-3, 1e-3)), S(1, 0, (300, -200, 100), (5, 5, 5), (400, 1, 400)), S(1, 0, (1e4, 1e4, 1e4), (0, 30, 0), (2, 2, 2)),
+                     S(1, 0, (0, 0, 0), (0, 0, 0), (1e4, 1e-4, 1))],
+    }
+    total_fast = 0
+    for name, geoms in sets.items():
+        g = np.concatenate(geoms).view(gpu.GEOM_DTYPE)
+        rays, fast, hits, bad, bad_rcp, bad_div = gpu.test_box_fast_sweep(g, 31337 + _SW - 1, (1 << 26) * _SW)
+        print("%-14s rays %d, decided by the fast path %d (%.1f %%), hits among those %d, mismatches %d" % (name, rays, fast, 100.0 * fast / rays, hits, bad))
+        assert bad == 0 and bad_rcp == 0 and bad_div == 0, name
+        assert fast > rays // 2 and hits > rays // 16, name          # the fast path actually decides, hits and misses
+        total_fast += fast
+    assert total_fast > 1 << 26
+
+
 def test_unscaled_sqrt_exhaustive(gpu):
     # The hemisphere sampler issues the compiler's correctly rounded sqrt WITHOUT the instructions that only act near
     # the exponent limits (pt_device.h: sqrtUnscaled); its operands (u01 and 1 - up^2) are 0 or >= 2^-31 by
