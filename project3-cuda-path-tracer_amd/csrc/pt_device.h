@@ -584,12 +584,13 @@ __device__ __forceinline__ void boxSlabsFastFinish(F3 qo, F3 qd, bool outs, int 
 // rays (EARLY_MISS is set for the camera-ray bounce); results are identical either way.
 // CAM_ORIGIN: the ray starts at the camera, whose object-space position is precomputed (GeomDev::camObj).
 // `early` (wave-uniform, with EARLY_MISS): take the early miss at all -- callers that expect nearly every ray to hit skip its compares.
+// `onlyOne` (wave-uniform): the return value is only compared with 0 (see below): a hit returns the SQUARED distance.
 // EXACT_ONLY: the slab phase by the reference's loop alone (the parity sweep's other side; experiments)
 #ifndef PT_BOX_FAST
 #define PT_BOX_FAST 1
 #endif
 template <bool EARLY_MISS, bool CAM_ORIGIN = false, bool EXACT_ONLY = !PT_BOX_FAST, typename GD>
-__device__ __forceinline__ float boxIntersectionTest(const GD &g, F3 ro, F3 rd, F3 &P, F3 &nsrc, bool &outside, bool early = true) {
+__device__ __forceinline__ float boxIntersectionTest(const GD &g, F3 ro, F3 rd, F3 &P, F3 &nsrc, bool &outside, bool early = true, bool onlyOne = false) {
     probe(0);
     const F3 qo = CAM_ORIGIN ? f3(g.camObj[0], g.camObj[1], g.camObj[2]) : mulMV(g.inv, ro, 1.0f);
     const F3 qdu = mulMV0(g.inv, g.invZ, rd);
@@ -613,7 +614,11 @@ __device__ __forceinline__ float boxIntersectionTest(const GD &g, F3 ro, F3 rd, 
         P = mulMV(g.xf, getPointOnRay(qo, qd, tmin), 1.0f);
         // the slab normal's face index, as bits, in nsrc.x: normal = normalize(transform * (tmin_n, 0)) is looked up by it for the nearest hit only (cubeFace)
         nsrc = f3(__int_as_float(face), 0.0f, 0.0f);
-        return length(ro - P);
+        // `onlyOne` (wave-uniform): this primitive is the only one the caller looks at, so the distance is compared with nothing but 0 --
+        // and sqrt(x) > 0 exactly when x > 0: the squared distance stands in for it (a correctly rounded sqrt is 16 instructions)
+        const F3 dP = ro - P;
+        const float d2 = dot(dP, dP);
+        return onlyOne ? d2 : __builtin_sqrtf(d2);
     }
     return -1.0f;
 }

@@ -339,6 +339,13 @@ __global__ __launch_bounds__(kBlock) void k_debug_camera_rays(KParams prm, int i
 // times per wave with 1.8 active lanes).  After the loop, pass k tests every lane's k-th recorded sphere, each lane with
 // its own matrices from LDS -- 3-4 passes with tens of active lanes.  Same tests on the same operands; the nearest hit is
 // chosen by (distance, then file order), which is what the in-order loop with its strict `<` computes.
+// some value, for free (see the tile loop)
+__device__ __forceinline__ float anyFloat() {
+    float x;
+    asm volatile("" : "=v"(x));
+    return x;
+}
+__device__ __forceinline__ F3 anyF3() { return f3(anyFloat(), anyFloat(), anyFloat()); }
 __device__ __forceinline__ uint32_t waveSum(uint32_t v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -805,9 +812,12 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
         uint32_t fl = 0u;
         uint32_t smallCandI = 1u;                               // class bit 3 of a survivor
         uint32_t wallSel = 8u;                                  // class bits 0-2 of a survivor in a scene with walls (8: no walls: the octant)
-        F3 org = f3(0, 0, 0), dir = f3(0, 0, 1), col = f3(0, 0, 0);
-        int pix = 0;
-        int packedCur = 0;                                      // later bounces: remainingBounces | batch index << 8, as loaded (ONE register
+        // (a path's state is only ever read for the lanes that hold one -- and the record of the nearest hit only after a hit: whatever the
+        // registers happen to hold will do for the others.  Spelled as an empty asm's output, which costs no instruction and, unlike an
+        // uninitialised variable, is a definite value to the optimiser; the zeros they used to start from were ~25 v_mov per tile.)
+        F3 org = anyF3(), dir = anyF3(), col = anyF3();
+        int pix = __float_as_int(anyFloat());
+        int packedCur = __float_as_int(anyFloat());             // later bounces: remainingBounces | batch index << 8, as loaded (ONE register
                                                                 // across the tile; the iteration is shifted out where it is needed)
         auto iterOf = [&]() -> int { return FIRST ? itb : (packedCur >> 8); };
         uint32_t pixHash = 0u;                                  // FIRST: utilhash(pix), shared by the camera jitter's and the scatter's engines
@@ -867,12 +877,12 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
             if (FIRST) { if (inScene) probe(8); } else probe(7);                                   // tiles (waves with at least one valid path) and valid paths
             // nearest hit, geoms in file order, strict '<' so the first geom wins ties (S3)
             probe(15);                                          // (nearest-hit loop)
-            float tbest = 0.0f;
+            float tbest = anyFloat();
             int hit = -1;
-            F3 P = f3(0, 0, 0), nsrc = f3(0, 0, 0);
+            F3 P = anyF3(), nsrc = anyF3();
             // (an int, not a bool: a loop-carried per-lane flag would live in an SGPR pair and cost three mask operations at
             // every merge point of the loop over the primitives; as a VGPR it costs one select per update)
-            int outsideI = 0;
+            int outsideI = __float_as_int(anyFloat());
             const float dd = dot(dir, dir);
             int nCand = 0;                                       // MANY: spheres recorded by this lane
             float *s_sph = nullptr;                              // MANY: [ngeoms][kSphRowFloats], then [kListMax][kBlock] lists
@@ -910,6 +920,8 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
                 }
                 const GeomPtr geoms = (GeomPtr)(A->ggeoms);
                 const bool earlyMiss = FIRST || hotWalls(hotNow()) == 0u || (tileCls & 7u) >= 6u;    // (wave-uniform)
+                // a later tile whose class lists ONE primitive (its paths' one wall): a hit's distance is compared with nothing (PACKED: the spheres follow)
+                const bool onlyOne = !FIRST && !PACKED && gk1 - gk0 == 1;
                 for (int gk = gk0; gk < gk1; ++gk) {
                     int g, span = 0;
                     if (FIRST && listed) {
@@ -963,7 +975,7 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
                     } else {
                         // (the exact early miss pays where whole waves take it: not for camera rays inside a primitive's hull span -- 97 %
                         // of their box tests reach the hit phase -- nor in a tile whose class names the ONE wall its paths can still hit)
-                        t = boxIntersectionTest<!FIRST, FIRST && !DOF>(G, org, dir, p, n, o, earlyMiss);
+                        t = boxIntersectionTest<!FIRST, FIRST && !DOF>(G, org, dir, p, n, o, earlyMiss, onlyOne);
                     }
                     // (PACKED: a sphere tested in place above may hold the record with a higher index: file order decides a tie)
                     if (t > 0.0f && (hit < 0 || t < tbest || (PACKED && t == tbest && g < hit))) {
