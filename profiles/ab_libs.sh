@@ -4,7 +4,7 @@ args="$1"; shift
 mkdir -p gpurun_out/ab
 L=$PWD/project3-cuda-path-tracer_amd/csrc
 out=gpurun_out/ab/libs.txt; : > $out
-for rep in 1 2; do
+for rep in $(seq 1 ${REPS:-2}); do
 for v in "$@"; do
   PT_AMD_LIB=$L/libpt_amd$v.so python bench.py $args --cpu-spp 0 --dump-frame gpurun_out/ab/frame$v.npy 2>gpurun_out/ab/err$v.txt | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('lib$v', $rep, d['value'], d['roofline']['avg_launch_ms'])" >> $out || echo "lib$v FAILED" >> $out
 done

@@ -1215,6 +1215,15 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     // distribution over the classes (+ the trash chunk 0).  Chunk size: a power of two, at least 2048 (rounds 1-3: ~1/1024 of the
     // paths, so that the slack stayed around 10 % while a chunk outlasts the appends of one memory round trip).
     S.maxBatch = o.max_batch > 0 ? o.max_batch : 1;
+    {   // a path carries pixelIndex | batch index << pixBits in ONE word (ptk::PathC)
+        int pixBits = 1, batchBits = 0;
+        while (((long long)k.W * k.H - 1) >> pixBits) ++pixBits;
+        while ((S.maxBatch - 1) >> batchBits) ++batchBits;
+        if (pixBits + batchBits > 32)
+            return fail(PT_ERR_INVALID, "pt_init: %d x %d pixels and max_batch %d need %d + %d bits of a path's 32-bit index word: lower max_batch", k.W, k.H,
+                        S.maxBatch, pixBits, batchBits);
+        k.pixBits = pixBits;
+    }
     if (S.maxBatch == 1) S.flags &= ~PT_FLAG_TRACE_AHEAD;   // nothing to trace ahead with: every call traces its own iteration
     // slots are 32-bit element indices with 32-bit byte offsets: paths per pool must stay below 2^30
     const long long maxPaths = (long long)S.nLocal * S.maxBatch;
@@ -1896,7 +1905,8 @@ int pt_debug_trace_paths(int iter, int bounces, float *origin3, float *dir3, flo
                 off += m;
             }
     }
-    const int *pixcol = reinterpret_cast<const int *>(cols[9].data());
+    // (array C's third word: pixelIndex | batch index << pixBits; this private run traces ONE iteration: the batch index is 0)
+    const int *pixcol = reinterpret_cast<const int *>(cols[10].data());
     std::vector<size_t> order(n);
     for (size_t i = 0; i < n; ++i) order[i] = i;
     std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return pixcol[x] < pixcol[y]; });

@@ -11,7 +11,7 @@
 namespace ptk {
 using namespace ptd;
 
-constexpr int kNumArrays = 11;       // PathSegment: origin3, dir3, throughput3, pixelIndex, remainingBounces = 11 dwords = 44 bytes per path
+constexpr int kNumArrays = 11;       // PathSegment: origin3, dir3, throughput3, the pixel's hash, pixelIndex | batch index = 11 dwords = 44 bytes per path
 constexpr int kMaxDepthSlots = PT_MAX_DEPTH + 2;
 
 // ---- device control block ------------------------------------------------------------------------
@@ -88,6 +88,7 @@ struct KParams {
     int   nLocal;       // pixels rendered by this shard
     int   ngeoms, nmats;
     int   traceDepth;
+    int   pixBits;      // bits of a global pixel index (W * H - 1): PathC::pk = pixelIndex | batch index << pixBits
     int   poolChunks;   // chunks of a path pool (chunk 0 is the trash chunk: never handed out, written only after a fault)
     int   chunkShift;   // log2(paths per chunk), >= kMinChunkShift
     int   sceneRect[4]; // union of the primitives' pixel rectangles (GeomDev::rect): camera rays outside miss everything
@@ -149,8 +150,8 @@ struct KParams {
 };
 
 // SoA PathSegment pool: THREE arrays of `cap` = poolChunks << chunkShift elements -- A: float4 {origin, direction.x} at base,
-// B: float4 {direction.yz, throughput.xy} at base + 16 cap bytes, C: three dwords {throughput.z, pixelIndex, remainingBounces | batch
-// index << 8} at base + 32 cap bytes -- the same 44 bytes per path as eleven dword arrays (rounds 1-2), moved by 3 + 3 vector-memory
+// B: float4 {direction.yz, throughput.xy} at base + 16 cap bytes, C: three dwords {throughput.z, utilhash(pixelIndex), pixelIndex | batch
+// index << pixBits} at base + 32 cap bytes -- the same 44 bytes per path as eleven dword arrays (rounds 1-2), moved by 3 + 3 vector-memory
 // instructions per path and bounce instead of 11 + 11: round 3's in-kernel timeline showed a fifth of a later tile's time going into
 // ISSUING those instructions (64 lanes x 4 B each), not into waiting for their data.  A wave's access is 1 KiB (768 B) contiguous.
 // Chunk c owns [c << chunkShift, (c + 1) << chunkShift) of every array.
@@ -166,7 +167,11 @@ struct PathPool {
     __host__ __device__ __forceinline__ char *arrB(size_t slot) const { return reinterpret_cast<char *>(base) + 16 * (size_t)cap + 16 * slot; }
     __host__ __device__ __forceinline__ char *arrC(size_t slot) const { return reinterpret_cast<char *>(base) + 32 * (size_t)cap + 12 * slot; }
 };
-struct PathC { float cz; int pix, packed; };       // array C's element (12 bytes: one global_load / store_dwordx3)
+// array C's element (12 bytes: one global_load / store_dwordx3).  pixHash = utilhash(pixelIndex): the pixel's half of every bounce's RNG seed
+// (src/pathtrace.cu:41-45), computed ONCE, by the camera-ray bounce (rounds 1-4 stored remainingBounces here -- the same number for every path
+// of a launch, traceDepth - depth -- and hashed the pixel index again at every scatter: ~20 vector instructions per path and bounce);
+// pk = pixelIndex | batch index << KParams::pixBits (pt_init: the two fit 32 bits).
+struct PathC { float cz; uint32_t pixHash, pk; };
 
 // element `slot` of an array whose (wave-uniform) base pointer is `arr`: uniform 64-bit base + 32-bit byte offset, which
 // is the addressing form of global_load/store with an SGPR base (no 64-bit vector arithmetic per access)
@@ -671,7 +676,7 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
         const float *base;                  // the input pool's arrays (from setupTile's one scalar load to loadTile; dead afterwards)
         uint32_t cap;
     };
-    struct PathRegs { F3 org, dir, col; int pix, packed; };
+    struct PathRegs { F3 org, dir, col; uint32_t pixHash, pk; };
     // tile T of the queue -> its segment, class and the lane's slot; false: the tile needs no work at all
     auto setupTile = [&](uint32_t T, uint32_t tid, TileMeta &m) -> bool {
         // everything the set-up needs from the argument block: one scalar load, in flight while the segment is looked up in LDS
@@ -725,8 +730,8 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
             r.org = f3(a.x, a.y, a.z);
             r.dir = f3(a.w, b.x, b.y);
             r.col = f3(b.z, b.w, c.cz);
-            r.pix = c.pix;
-            r.packed = c.packed;                                // remainingBounces | batch index << 8
+            r.pixHash = c.pixHash;
+            r.pk = c.pk;                                        // pixelIndex | batch index << pixBits
         }
     };
     // the first tile of this workgroup that needs work, and its paths
@@ -816,11 +821,11 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
         // registers happen to hold will do for the others.  Spelled as an empty asm's output, which costs no instruction and, unlike an
         // uninitialised variable, is a definite value to the optimiser; the zeros they used to start from were ~25 v_mov per tile.)
         F3 org = anyF3(), dir = anyF3(), col = anyF3();
-        int pix = __float_as_int(anyFloat());
-        int packedCur = __float_as_int(anyFloat());             // later bounces: remainingBounces | batch index << 8, as loaded (ONE register
+        int pix = __float_as_int(anyFloat());                   // (FIRST; later bounces unpack it where it is needed: an emitter hit)
+        uint32_t pkCur = __float_as_uint(anyFloat());           // later bounces: pixelIndex | batch index << pixBits, as loaded (ONE register
                                                                 // across the tile; the iteration is shifted out where it is needed)
-        auto iterOf = [&]() -> int { return FIRST ? itb : (packedCur >> 8); };
-        uint32_t pixHash = 0u;                                  // FIRST: utilhash(pix), shared by the camera jitter's and the scatter's engines
+        auto iterOf = [&]() -> int { return FIRST ? itb : (int)(pkCur >> (uint32_t)launder(kargs)->prm.pixBits); };
+        uint32_t pixHash = __float_as_uint(anyFloat());         // utilhash(pix): FIRST computes it (the camera jitter's and the scatter's engines share it), later bounces load it
         if (valid) {
             // Camera rays (FIRST): a primitive is reachable only from the pixels inside the projection of its bounding
             // cube (GeomDev::rect, 2-pixel margin >> any rounding of the reference's tests), and nothing is reachable
@@ -868,10 +873,10 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
                 // arrived.  (Left to itself the register allocator copied the NEXT tile's pixel index right behind its load -- v_mov
                 // behind s_waitcnt vmcnt(2) -- and every wave sat out a memory round trip BEFORE the compaction's barriers instead of
                 // under them: the "3 loads issued: 7 %" of round 3's timeline.)
-                int cpix = cur.pix, cpacked = cur.packed;
-                if (!MANY) asm volatile("" : "+v"(cpix), "+v"(cpacked));   // (sphere-heavy variants: no register to spare for the copies)
-                pix = cpix;
-                packedCur = cpacked;
+                uint32_t chash = cur.pixHash, cpk = cur.pk;
+                if (!MANY) asm volatile("" : "+v"(chash), "+v"(cpk));      // (sphere-heavy variants: no register to spare for the copies)
+                pixHash = chash;
+                pkCur = cpk;
             }
 
             if (FIRST) { if (inScene) probe(8); } else probe(7);                                   // tiles (waves with at least one valid path) and valid paths
@@ -1247,11 +1252,12 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
                         const F3 c = (col * mcol) * mEmit;
                         // (index of the pixel in the radiance buffers: the frame's, or, for a row shard, the shard's own)
                         size_t frame = (size_t)A->prm.W * A->prm.H;
-                        uint32_t cpix = (uint32_t)pix;
+                        const uint32_t gpix = FIRST ? (uint32_t)pix : (pkCur & ((1u << (uint32_t)A->prm.pixBits) - 1u));
+                        uint32_t cpix = gpix;
                         if (hotNow() & kHotContribLocal) {
-                            const uint32_t y = fastDiv((uint32_t)pix, A->prm.magicW, A->prm.shiftW);
+                            const uint32_t y = fastDiv(gpix, A->prm.magicW, A->prm.shiftW);
                             const uint32_t lr = fastDiv(y, A->prm.magicS, A->prm.shiftS);
-                            cpix = (uint32_t)pix - (y - lr) * (uint32_t)A->prm.W;      // x + lr * W
+                            cpix = gpix - (y - lr) * (uint32_t)A->prm.W;               // x + lr * W
                             frame = (size_t)A->prm.nLocal;
                         }
                         const int itq = iterOf();
@@ -1265,7 +1271,7 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
                     }
                 } else if (!(hotNow() & kHotLast)) {                  // S6 scatter (S7: skipped on the last bounce)
                     probe(10);
-                    Rng rng = seedEngine(s_iterHash[iterOf()] ^ (FIRST ? pixHash : utilhash((uint32_t)pix)));   // = makeSeededRandomEngineHashed(., pix)
+                    Rng rng = seedEngine(s_iterHash[iterOf()] ^ pixHash);   // = makeSeededRandomEngineHashed(., pix)
                     const F3 scol = f3(M.specColor[0], M.specColor[1], M.specColor[2]);
                     F3 ndir = dir, norg;
                     bool diffuse = false;                        // the hemisphere is sampled at one place, after the branches
@@ -1439,7 +1445,7 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
         // store that never executes, so nothing is optimised away and no result changes)
         {
             float xa = org.x, xb = dir.y;
-            uint32_t sa = (uint32_t)__builtin_amdgcn_readfirstlane(pix), sb = sa ^ 0x55u;
+            uint32_t sa = (uint32_t)__builtin_amdgcn_readfirstlane((int)pixHash), sb = sa ^ 0x55u;
 #pragma unroll 1
             for (int q = 0; q < 25; ++q) {
 #if PT_EXP & 4        // vector, VGPR operands only
@@ -1468,7 +1474,7 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
                 sa += acc;
             }
 #endif
-            if (__float_as_uint(xa) + __float_as_uint(xb) + sa + sb == 0x12345677u && pix == -12345) fl |= 4u;
+            if (__float_as_uint(xa) + __float_as_uint(xb) + sa + sb == 0x12345677u && pixHash == 0x12345u && sa == 77u) fl |= 4u;
         }
 #endif
         probe(17);                                              // (next tile's loads)
@@ -1564,8 +1570,7 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
                 *reinterpret_cast<float4 *>(dst + 16 * (size_t)slot) = make_float4(org.x, org.y, org.z, dir.x);
                 *reinterpret_cast<float4 *>(dst + 16 * ocap + 16 * (size_t)slot) = make_float4(dir.y, dir.z, col.x, col.y);
                 PathC c;
-                // (remainingBounces - 1 | batch index << 8: the low byte is at least 1 here)
-                c.cz = col.z; c.pix = pix; c.packed = FIRST ? ((launder(kargs)->prm.traceDepth - 1) | (itb << 8)) : packedCur - 1;
+                c.cz = col.z; c.pixHash = pixHash; c.pk = FIRST ? ((uint32_t)pix | ((uint32_t)itb << (uint32_t)launder(kargs)->prm.pixBits)) : pkCur;
                 *reinterpret_cast<PathC *>(dst + 32 * ocap + 12 * (size_t)slot) = c;
             }
             // No third barrier: the counts are double-buffered.  The other half was last read in the previous tile, and every
