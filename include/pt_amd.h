@@ -13,9 +13,11 @@
  * src/sceneStructs.h:18-47, so `scene->geoms.data()`, `scene->materials.data()` and
  * `&scene->state.camera` pass straight through.
  *
- * All functions return PT_OK (0) or a negative PtStatus; pt_last_error() describes the last failure.
- * The library keeps ONE renderer instance per process, like the reference's file-static state
- * (src/pathtrace.cu:70-71).  Not thread-safe (the reference is single-threaded).
+ * All functions return PT_OK (0) or a negative PtStatus; pt_last_error() describes the calling thread's last failure.
+ * A renderer instance is a CONTEXT.  The functions below act on the calling thread's CURRENT context: the process-wide default one --
+ * one renderer per process, like the reference's file-static state (src/pathtrace.cu:70-71) -- unless pt_ctx_make_current named another
+ * (section "contexts and device groups" at the end: several renderers in one process, one per device of a node).  One context is driven by
+ * one host thread at a time (the reference is single-threaded); different threads may drive different contexts.
  */
 #ifndef PT_AMD_H
 #define PT_AMD_H
@@ -117,6 +119,10 @@ typedef struct PtOptions {
 
 #define PT_MAX_DEPTH 62
 #define PT_MAX_BATCH 256
+/* Bumped whenever a struct of this header changes size or meaning (5: round 5 -- contexts and groups; PtMesh has carried `normals` and
+ * `materials` since 4).  A host built against another header finds out with pt_abi_version() != PT_AMD_ABI_VERSION before it passes structs. */
+#define PT_AMD_ABI_VERSION 5
+int pt_abi_version(void);
 
 typedef struct PtCounters {
     int64_t live[PT_MAX_DEPTH + 2]; /* live[d] = paths entering bounce d (d = 1..depth), summed over   */
@@ -163,6 +169,8 @@ typedef struct PtMesh {
     const int32_t *materials;   /* or NULL: every face takes the object's material */
 } PtMesh;
 int pt_set_meshes(const PtMesh *meshes, int nmeshes);
+/* ... the same with the caller's sizeof(PtMesh): PT_ERR_INVALID instead of strided garbage when host and library disagree about the struct */
+int pt_set_meshes_sized(const PtMesh *meshes, int nmeshes, size_t mesh_struct_bytes);
 
 /* pathtraceInit: upload scene, allocate the accumulator and the SoA path-state buffers.
  * Replaces reference src/pathtrace.cu:75-85.  Calling it twice without pt_free re-initialises. */
@@ -211,13 +219,6 @@ const char *pt_last_error(void);
 /* Number of HIP devices visible (0 = none; the library then refuses to run). */
 int pt_device_count(void);
 
-/* ---- diagnostics for parity tests -------------------------------------------------------------
- * State of the paths still alive after `bounces` bounces of iteration `iter`, sorted by pixel index
- * (the device queue order is arrival order): arrays of capacity W*H (x3).  Does not touch the
- * accumulator. */
-int pt_debug_trace_paths(int iter, int bounces, float *origin3, float *dir3, float *color3,
-                         int32_t *pixelIndex, int32_t *count);
-
 /* ---- stream compaction library (the reference's empty stream_compaction/ stub, README.md:83-86):
  * work-efficient exclusive scan / compaction over DEVICE buffers, multi-block, any n >= 0 (compaction: n < 2^32).
  * Reduce-then-scan over at most 2048 chunks: three launches on `stream`, asynchronous, no workgroup waits for another;
@@ -226,6 +227,38 @@ int pt_scan_exclusive_i32(const int32_t *in_dev, int32_t *out_dev, int64_t n, vo
 /* keeps the non-zero elements in order; *count_dev (device) receives how many were kept */
 int pt_compact_nonzero_i32(const int32_t *in_dev, int32_t *out_dev, int64_t n, int64_t *count_dev,
                            void *stream);
+
+/* ---- contexts and device groups (round 5) -----------------------------------------------------------------------------------------
+ * The reference's renderer is one set of file-static globals bound to device 0 (src/pathtrace.cu:70-71, src/preview.cpp:107).  Here a
+ * renderer is a context: pt_ctx_create makes one, pt_ctx_make_current(ctx) makes every function above act on it for the calling thread
+ * (NULL: back to the default context), pt_ctx_destroy frees its renderer and the context.  A context initialised on a device makes that
+ * device current when it is made current.  pt_set_meshes registers meshes per context. */
+typedef struct PtContext PtContext;
+PtContext *pt_ctx_create(void);               /* NULL: out of memory */
+int        pt_ctx_make_current(PtContext *ctx /* NULL = the default context */);
+PtContext *pt_ctx_current(void);              /* NULL = the default context */
+int        pt_ctx_destroy(PtContext *ctx);
+
+/* A GROUP: n contexts that render the row shards y % n of ONE frame, member i on devices[i] (NULL: device i % pt_device_count()) -- the
+ * node's GPUs side by side in one host process, or several renderers on one device.  Pixels are seeded by their global index, so the
+ * shards together are the one-device frame bit for bit.  pt_group_init = pt_init on every member (opts' shard_rank / shard_count /
+ * device / stream / accum_dev are the group's to set; max_batch, pipeline_depth, flags and the lens apply to each member);
+ * pt_group_iterate_batch enqueues every member's batch (asynchronous: the devices run concurrently); pt_group_readback waits and
+ * assembles the frame's running sum on the host: by ONE ncclReduce(sum) of zero-padded full frames to member 0's device over xGMI
+ *  when the members sit on distinct devices and librccl.so can be loaded -- pt_group_collective() = "rccl reduce" -- else by
+ * copying every shard's rows to the host ("host gather").  PT_AMD_COLLECTIVE=host|rccl overrides (rccl: even for one member). */
+typedef struct PtGroup PtGroup;
+int  pt_group_create(PtGroup **out, int n, const int32_t *devices /* may be NULL */);
+void pt_group_destroy(PtGroup *g);
+int  pt_group_size(const PtGroup *g);
+const char *pt_group_collective(const PtGroup *g);
+int  pt_group_set_meshes(PtGroup *g, const PtMesh *meshes, int nmeshes);
+int  pt_group_init(PtGroup *g, const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMaterial *mats, int nmats, int traceDepth,
+                   const PtOptions *opts /* may be NULL */);
+int  pt_group_iterate_batch(PtGroup *g, int frame, int first_iter, int count);
+int  pt_group_sync(PtGroup *g);
+int  pt_group_readback(PtGroup *g, float *rgb_sum_host);
+int  pt_group_counters(PtGroup *g, PtCounters *out);      /* summed over the members; iterations: the least any member has committed */
 
 #ifdef __cplusplus
 }

@@ -16,6 +16,12 @@
 extern "C" {
 #endif
 
+/* ---- diagnostics of a renderer: the instance that lives in THIS library (initialise it with this library's pt_init) ----
+ * State of the paths still alive after `bounces` bounces of iteration `iter`, sorted by pixel index (the device queue order is
+ * arrival order): arrays of capacity W*H (x3).  Does not touch the accumulator.  (Rounds 1-4 exported it from the product.) */
+int pt_debug_trace_paths(int iter, int bounces, float *origin3, float *dir3, float *color3,
+                         int32_t *pixelIndex, int32_t *count);
+
 /* ---- device primitives evaluated on the GPU over HOST arrays (parity tests of rows a6-a12, a19):
  * the same __device__ functions the render kernels call. ------------------------------------------ */
 int pt_test_utilhash(const uint32_t *in, uint32_t *out, int n);

@@ -51,11 +51,16 @@ TEST_LIB_PATH = os.path.join(HERE, "csrc", "libpt_amd_test.so")
 # every symbol include/pt_amd.h declares: the product's whole exported surface
 ABI_SYMBOLS = [
     "pt_init", "pt_iterate", "pt_iterate_batch", "pt_sync", "pt_readback", "pt_readback_rgba8", "pt_counters",
-    "pt_counters_reset", "pt_free", "pt_last_error", "pt_device_count", "pt_debug_trace_paths",
-    "pt_scan_exclusive_i32", "pt_compact_nonzero_i32", "pt_pin_host", "pt_unpin_host", "pt_set_meshes",
+    "pt_counters_reset", "pt_free", "pt_last_error", "pt_device_count",
+    "pt_scan_exclusive_i32", "pt_compact_nonzero_i32", "pt_pin_host", "pt_unpin_host", "pt_set_meshes", "pt_set_meshes_sized", "pt_abi_version",
+    "pt_ctx_create", "pt_ctx_make_current", "pt_ctx_current", "pt_ctx_destroy",
+    "pt_group_create", "pt_group_destroy", "pt_group_size", "pt_group_collective", "pt_group_set_meshes", "pt_group_init", "pt_group_iterate_batch",
+    "pt_group_sync", "pt_group_readback", "pt_group_counters",
 ]
+PT_AMD_ABI_VERSION = 5
 # every symbol include/pt_amd_test.h declares: libpt_amd_test.so only -- the product library must NOT export them
 TEST_ABI_SYMBOLS = [
+    "pt_debug_trace_paths",
     "pt_test_utilhash", "pt_test_rng", "pt_test_intersect", "pt_test_hemisphere", "pt_test_sincos", "pt_test_reflect_refract",
     "pt_test_slab_quotients", "pt_test_slab_quotients_sweep", "pt_test_box_fast_sweep", "pt_test_sphere_cull_sweep", "pt_test_unscaled_sqrt_sweep",
     "pt_test_force_fault", "pt_test_pow", "pt_test_wall_box_sweep", "pt_test_mesh_intersect", "pt_test_mesh_bvh",
@@ -86,6 +91,7 @@ class PtError(RuntimeError):
 
 _lib = None
 _test = None
+_last_init = None           # the arguments of the last pathtraceInit (debug_trace_paths re-creates the scene in the test library)
 _host = None
 _atexit_registered = False
 
@@ -104,13 +110,33 @@ def _bind(L, with_tests):
     L.pt_free.restype = None
     L.pt_last_error.restype = C.c_char_p
     L.pt_device_count.argtypes = []
-    L.pt_debug_trace_paths.argtypes = [i32, i32, vp, vp, vp, vp, C.POINTER(C.c_int32)]
     L.pt_scan_exclusive_i32.argtypes = [vp, vp, i64, vp]
     L.pt_compact_nonzero_i32.argtypes = [vp, vp, i64, vp, vp]
     L.pt_pin_host.argtypes = [vp, C.c_size_t]
     L.pt_unpin_host.argtypes = []
     L.pt_set_meshes.argtypes = [C.POINTER(PtMesh), i32]
+    L.pt_set_meshes_sized.argtypes = [C.POINTER(PtMesh), i32, C.c_size_t]
+    L.pt_abi_version.argtypes = []
+    L.pt_ctx_create.argtypes = []
+    L.pt_ctx_create.restype = vp
+    L.pt_ctx_make_current.argtypes = [vp]
+    L.pt_ctx_current.argtypes = []
+    L.pt_ctx_current.restype = vp
+    L.pt_ctx_destroy.argtypes = [vp]
+    L.pt_group_create.argtypes = [C.POINTER(vp), i32, C.POINTER(C.c_int32)]
+    L.pt_group_destroy.argtypes = [vp]
+    L.pt_group_destroy.restype = None
+    L.pt_group_size.argtypes = [vp]
+    L.pt_group_collective.argtypes = [vp]
+    L.pt_group_collective.restype = C.c_char_p
+    L.pt_group_set_meshes.argtypes = [vp, C.POINTER(PtMesh), i32]
+    L.pt_group_init.argtypes = [vp, vp, vp, i32, vp, i32, i32, C.POINTER(PtOptions)]
+    L.pt_group_iterate_batch.argtypes = [vp, i32, i32, i32]
+    L.pt_group_sync.argtypes = [vp]
+    L.pt_group_readback.argtypes = [vp, vp]
+    L.pt_group_counters.argtypes = [vp, C.POINTER(PtCounters)]
     if with_tests:
+        L.pt_debug_trace_paths.argtypes = [i32, i32, vp, vp, vp, vp, C.POINTER(C.c_int32)]
         u64p = C.POINTER(C.c_uint64)
         L.pt_test_utilhash.argtypes = [vp, vp, i32]
         L.pt_test_rng.argtypes = [vp, i32, i32, vp]
@@ -321,11 +347,13 @@ def pathtraceInit(scene, shard_rank=0, shard_count=1, stream=0, accum_dev=0, dev
         _atexit_registered = True
     _check(lib().pt_init(_p(cam), _p(geoms), len(geoms), _p(mats), len(mats), depth, C.byref(opt)))
     _scene = scene
+    global _last_init
+    _last_init = (cam, geoms, mats, depth, (shard_rank, shard_count, device, flags, lens_radius, focal_distance),
+                  (getattr(scene, "meshes", None) or {}, getattr(scene, "mesh_normals", None), getattr(scene, "mesh_materials", None)))
 
 
-def set_meshes(meshes, normals=None, materials=None):
-    """pt_set_meshes: {geom index: (ntris, 9) triangles in object space} for the next pathtraceInit (an empty dict clears); optionally
-    {geom index: (ntris, 9) vertex normals} and {geom index: (ntris,) int32 face materials}."""
+def _mesh_array(meshes, normals=None, materials=None):
+    """(PtMesh array, count, the arrays it points into) for pt_set_meshes / pt_group_set_meshes"""
     keep = [(int(g), np.ascontiguousarray(t, np.float32).reshape(-1, 9)) for g, t in sorted(meshes.items())]
     extra = []                                       # (keeps the attribute arrays alive across the call)
     arr = (PtMesh * max(len(keep), 1))()
@@ -336,7 +364,16 @@ def set_meshes(meshes, normals=None, materials=None):
         mm = None if mm is None else np.ascontiguousarray(mm, np.int32).reshape(len(t))
         extra += [nn, mm]
         arr[i] = PtMesh(g, len(t), t.ctypes.data, None if nn is None else nn.ctypes.data, None if mm is None else mm.ctypes.data)
-    _check(lib().pt_set_meshes(arr, len(keep)))
+    return arr, len(keep), (keep, extra)
+
+
+def set_meshes(meshes, normals=None, materials=None, L=None):
+    """pt_set_meshes: {geom index: (ntris, 9) triangles in object space} for the next pathtraceInit (an empty dict clears); optionally
+    {geom index: (ntris, 9) vertex normals} and {geom index: (ntris,) int32 face materials}.  Through the sized entry point: a
+    library built against another PtMesh refuses instead of striding through garbage."""
+    arr, n, alive = _mesh_array(meshes, normals, materials)
+    L = L or lib()
+    _check(L.pt_set_meshes_sized(arr, n, C.sizeof(PtMesh)), L)
 
 
 def pathtrace(pbo, frame, iteration, readback=True):
@@ -400,12 +437,99 @@ def counters_reset():
 
 
 def debug_trace_paths(iteration, bounces, npixels):
-    o, d, c = (np.empty((npixels, 3), np.float32) for _ in range(3))
-    pix = np.empty(npixels, np.int32)
-    n = C.c_int32(0)
-    _check(lib().pt_debug_trace_paths(iteration, bounces, _p(o), _p(d), _p(c), _p(pix), C.byref(n)))
+    """State of the paths alive after `bounces` bounces of `iteration` (sorted by pixel).  A diagnostic of the TEST library (the product
+    exports none since round 5): the scene of the last pathtraceInit is initialised in libpt_amd_test.so's own renderer -- the same
+    kernels, its own instance -- traced there and freed again; the product's renderer is not touched."""
+    if _last_init is None:
+        raise PtError("debug_trace_paths before pathtraceInit")
+    T = test_lib()
+    cam, geoms, mats, depth, (rank, count, device, flags, lens_radius, focal_distance), meshes = _last_init
+    if _lib is T:                                    # (renderer_from_test_library: the renderer IS the test library's)
+        own = False
+    else:
+        own = True
+        set_meshes(*meshes, L=T)
+        opt = PtOptions(rank, count, device, flags & ~(PT_FLAG_TRACE_AHEAD | PT_FLAG_KERNEL_TIMING), 1, 1, None, None, lens_radius, focal_distance)
+        _tcheck(T.pt_init(_p(cam), _p(geoms), len(geoms), _p(mats), len(mats), depth, C.byref(opt)))
+    try:
+        o, d, c = (np.empty((npixels, 3), np.float32) for _ in range(3))
+        pix = np.empty(npixels, np.int32)
+        n = C.c_int32(0)
+        _tcheck(T.pt_debug_trace_paths(iteration, bounces, _p(o), _p(d), _p(c), _p(pix), C.byref(n)))
+    finally:
+        if own:
+            T.pt_free()
     k = n.value
     return o[:k], d[:k], c[:k], pix[:k]
+
+
+class Context:
+    """pt_ctx_*: a renderer instance of its own.  `with ctx:` makes it the calling thread's current context -- the renderer API of
+    this module then drives it -- and puts the previous one back."""
+
+    def __init__(self):
+        self.handle = lib().pt_ctx_create()
+        if not self.handle:
+            raise PtError("pt_ctx_create failed: %s" % lib().pt_last_error().decode())
+
+    def __enter__(self):
+        self._prev = lib().pt_ctx_current()
+        _check(lib().pt_ctx_make_current(self.handle))
+        return self
+
+    def __exit__(self, *exc):
+        _check(lib().pt_ctx_make_current(self._prev))
+        return False
+
+    def destroy(self):
+        if self.handle:
+            _check(lib().pt_ctx_destroy(self.handle))
+            self.handle = None
+
+
+class Group:
+    """pt_group_*: n contexts rendering the row shards y % n of one frame, member i on devices[i] (default: i % device count)."""
+
+    def __init__(self, n, devices=None):
+        h = C.c_void_p()
+        dv = None if devices is None else (C.c_int32 * n)(*devices)
+        _check(lib().pt_group_create(C.byref(h), n, dv))
+        self.handle, self.n, self._scene = h, n, None
+
+    @property
+    def collective(self):
+        return lib().pt_group_collective(self.handle).decode()
+
+    def init(self, scene, traceDepth=None, flags=0, pipeline_depth=0, max_batch=0, lens_radius=0.0, focal_distance=0.0):
+        geoms, mats, cam = (np.ascontiguousarray(x) for x in (scene.geoms, scene.materials, scene.camera))
+        arr, nm, alive = _mesh_array(getattr(scene, "meshes", None) or {}, getattr(scene, "mesh_normals", None), getattr(scene, "mesh_materials", None))
+        _check(lib().pt_group_set_meshes(self.handle, arr, nm))
+        opt = PtOptions(0, 1, -1, flags, pipeline_depth, max_batch, None, None, lens_radius, focal_distance)
+        _check(lib().pt_group_init(self.handle, _p(cam), _p(geoms), len(geoms), _p(mats), len(mats),
+                                   scene.traceDepth if traceDepth is None else traceDepth, C.byref(opt)))
+        self._scene = scene
+
+    def iterate_batch(self, first_iteration, count, frame=0):
+        _check(lib().pt_group_iterate_batch(self.handle, frame, first_iteration, count))
+
+    def sync(self):
+        _check(lib().pt_group_sync(self.handle))
+
+    def readback(self):
+        res = self._scene.camera["resolution"][0]
+        out = np.empty(int(res[0]) * int(res[1]) * 3, np.float32)
+        _check(lib().pt_group_readback(self.handle, _p(out)))
+        return out
+
+    def counters(self):
+        c = PtCounters()
+        _check(lib().pt_group_counters(self.handle, C.byref(c)))
+        return c
+
+    def destroy(self):
+        if self.handle:
+            lib().pt_group_destroy(self.handle)
+            self.handle = None
 
 
 def save_png(basename, image_sum, samples):

@@ -252,56 +252,6 @@ __device__ __forceinline__ uint32_t fastDiv(uint32_t n, uint32_t magic, uint32_t
     return (uint32_t)(((unsigned long long)n * magic) >> shift);
 }
 
-// ---- camera ray of the j-th pixel of this shard (spec S2) ------------------------------------------
-// pixel coordinates and global pixel index of the shard's j-th pixel
-__device__ __forceinline__ void shardPixel(const KParams &prm, int j, int &pix, int &x, int &y) {
-    const int lr = (int)fastDiv((uint32_t)j, prm.magicW, prm.shiftW);
-    x = j - lr * prm.W;
-    y = lr * prm.shardCount + prm.shardRank;
-    pix = x + y * prm.W;
-}
-// iterHash0 = iterationHash(iter, 0): camera jitter draws from the depth-0 stream of (iter, pixel)
-__device__ __forceinline__ void cameraRayAt(const KParams &prm, uint32_t iterHash0, int pix, int x, int y, F3 &org, F3 &dir) {
-    Rng rng = makeSeededRandomEngineHashed(iterHash0, pix);
-    const float jx = u01(rng);
-    const float jy = u01(rng);
-    const float sx = ((float)x + jx) - prm.halfW;
-    const float sy = ((float)y + jy) - prm.halfH;
-    const float a = prm.pixLenX * sx;
-    const float b = prm.pixLenY * sy;
-    const F3 view = f3(prm.view[0], prm.view[1], prm.view[2]);
-    const F3 up = f3(prm.up[0], prm.up[1], prm.up[2]);
-    const F3 right = f3(prm.right[0], prm.right[1], prm.right[2]);
-    org = f3(prm.pos[0], prm.pos[1], prm.pos[2]);
-    dir = normalize((view - right * a) - up * b);
-    if (prm.lensRadius > 0.0f) {     // thin lens, as in k_bounce<true, ., true>
-        const float lr = prm.lensRadius * __builtin_sqrtf(u01(rng));
-        const float phi = u01(rng) * kTwoPi;
-        float s, c;
-        sincosPoly(phi, s, c);
-        const float ft = prm.focalDistance / dot(dir, f3(prm.viewN[0], prm.viewN[1], prm.viewN[2]));
-        const F3 focus = org + dir * ft;
-        org = (org + right * (lr * c)) + up * (lr * s);
-        dir = normalize(focus - org);
-    }
-}
-__device__ __forceinline__ void cameraRay(const KParams &prm, int iter, int j, int &pix, int &x, int &y, F3 &org, F3 &dir) {
-    shardPixel(prm, j, pix, x, y);
-    cameraRayAt(prm, iterationHash(iter, 0), pix, x, y, org, dir);
-}
-
-// camera rays alone, for pt_debug_trace_paths(bounces = 0)
-__global__ __launch_bounds__(kBlock) void k_debug_camera_rays(KParams prm, int iter, float *o3, float *d3, int *pixOut) {
-    const int j = blockIdx.x * kBlock + threadIdx.x;
-    if (j >= prm.nLocal) return;
-    int pix, x, y;
-    F3 org, dir;
-    cameraRay(prm, iter, j, pix, x, y, org, dir);
-    o3[3 * j] = org.x; o3[3 * j + 1] = org.y; o3[3 * j + 2] = org.z;
-    d3[3 * j] = dir.x; d3[3 * j + 1] = dir.y; d3[3 * j + 2] = dir.z;
-    pixOut[j] = pix;
-}
-
 // ---- one bounce: intersect + shade + accumulate + compact (spec S3-S8) -----------------------------
 // Persistent workgroups walk the 256-path tiles of the bounce's queue (the kSeg input segments laid
 // end to end), blockIdx-strided.  Survivors are BINNED BY CLASS while they are compacted:

@@ -9,6 +9,11 @@
 #include "pt_amd.h"
 
 static Scene *hst_scene = NULL;
+// PT_AMD_DEVICES=<n> (n >= 2): the frame's rows are rendered by n renderers side by side -- one per HIP device of the node, member i
+// on device i % pt_device_count() -- behind the same three symbols (include/pt_amd.h: pt_group_*; the reference is hard-wired to
+// device 0, src/preview.cpp:107).  The image after every call is the one-device image bit for bit.  Headless hosts only: a device
+// `pbo` belongs to one device's GL context, which a group has none of.
+static PtGroup *group = NULL;
 static float extraLens = 0.0f, extraFocal = 0.0f;   // README extras (pathtraceExtras), off = the reference's renderer
 static bool extraDirect = false;
 
@@ -61,7 +66,18 @@ void pathtraceInit(Scene *scene) {
         meshes.push_back(m);
     }
 #endif
-    checkPtError(pt_set_meshes(meshes.empty() ? NULL : meshes.data(), (int)meshes.size()), "pathtraceInit");
+    int members = 1;
+    if (const char *e = getenv("PT_AMD_DEVICES")) members = atoi(e);
+    if (members >= 2) {
+        if (group && pt_group_size(group) != members) {
+            pt_group_destroy(group);
+            group = NULL;
+        }
+        if (!group) checkPtError(pt_group_create(&group, members, NULL), "pathtraceInit (PT_AMD_DEVICES)");
+        checkPtError(pt_group_set_meshes(group, meshes.empty() ? NULL : meshes.data(), (int)meshes.size()), "pathtraceInit");
+    } else {
+        checkPtError(pt_set_meshes_sized(meshes.empty() ? NULL : meshes.data(), (int)meshes.size(), sizeof(PtMesh)), "pathtraceInit");
+    }
     int status;
     for (;;) {
         opt.flags &= ~PT_FLAG_TRACE_AHEAD;
@@ -72,10 +88,11 @@ void pathtraceInit(Scene *scene) {
             opt.max_batch = ahead;
             opt.pipeline_depth = 2;     // one batch being consumed, one being traced (a third in flight only competes with the copy)
         }
-        status = pt_init(reinterpret_cast<const PtCamera *>(&scene->state.camera),
-                         reinterpret_cast<const PtGeom *>(scene->geoms.data()), (int)scene->geoms.size(),
-                         reinterpret_cast<const PtMaterial *>(scene->materials.data()), (int)scene->materials.size(),
-                         scene->state.traceDepth, &opt);
+        const PtCamera *cam = reinterpret_cast<const PtCamera *>(&scene->state.camera);
+        const PtGeom *geoms = reinterpret_cast<const PtGeom *>(scene->geoms.data());
+        const PtMaterial *mats = reinterpret_cast<const PtMaterial *>(scene->materials.data());
+        status = group ? pt_group_init(group, cam, geoms, (int)scene->geoms.size(), mats, (int)scene->materials.size(), scene->state.traceDepth, &opt)
+                       : pt_init(cam, geoms, (int)scene->geoms.size(), mats, (int)scene->materials.size(), scene->state.traceDepth, &opt);
         // (PT_ERR_INVALID / PT_ERR_HIP: a limit or an allocation that a smaller batch may satisfy; anything else is final)
         if (status == PT_OK || ahead <= 1 || (status != PT_ERR_INVALID && status != PT_ERR_HIP)) break;
         ahead /= 2;
@@ -83,7 +100,7 @@ void pathtraceInit(Scene *scene) {
     checkPtError(status, "pathtraceInit");
     // state.image is owned by the Scene and lives from Init to Free: page-lock it for the per-iteration copy below
     // (an optimisation only; failure to register is not an error of the renderer)
-    if (!scene->state.image.empty())
+    if (!group && !scene->state.image.empty())
         (void)pt_pin_host(scene->state.image.data(), scene->state.image.size() * sizeof(scene->state.image[0]));
 }
 
@@ -96,10 +113,23 @@ void pathtraceExtras(float lensRadius, float focalDistance, bool directLighting)
 }
 
 void pathtraceFree() {
+    if (group) {
+        pt_group_destroy(group);
+        group = NULL;
+    }
     pt_free();  // no-op when nothing was initialised (src/main.cpp:91-94 calls Free before the first Init)
 }
 
 void pathtrace(uchar4 *pbo, int frame, int iter) {
+    if (group) {
+        if (pbo) {
+            fprintf(stderr, "HIP error (pathtrace_shim.cpp): pathtrace: PT_AMD_DEVICES renders headless (pbo must be NULL)\n");
+            exit(EXIT_FAILURE);
+        }
+        checkPtError(pt_group_iterate_batch(group, frame, iter, 1), "pathtrace");
+        checkPtError(pt_group_readback(group, reinterpret_cast<float *>(hst_scene->state.image.data())), "pathtrace");
+        return;
+    }
     checkPtError(pt_iterate(frame, iter, pbo), "pathtrace");
     // Retrieve image from GPU: the un-normalised running sum (src/pathtrace.cu:170-171)
     checkPtError(pt_readback(reinterpret_cast<float *>(hst_scene->state.image.data())), "pathtrace");

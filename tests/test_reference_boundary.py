@@ -54,8 +54,8 @@ def _read_dump(path, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("move", [None, ("2", "0.5", "0.2", "-1", "0.05", "-0.1")])
-def test_reference_host_code_drives_the_hip_path(pt, oracle, tmp_path, move):
+@pytest.mark.parametrize("move,members", [(None, 1), (("2", "0.5", "0.2", "-1", "0.05", "-0.1"), 1), (None, 2), (("2", "0.5", "0.2", "-1", "0.05", "-0.1"), 3)])
+def test_reference_host_code_drives_the_hip_path(pt, oracle, tmp_path, move, members):
     """The reference's Scene loader + headers + runCuda order over the shim, on the GPU: the image it leaves in
     scene->state.image equals the oracle's bit for bit -- also after a camera move, which restarts the accumulation
     (iteration = 0 -> pathtraceFree(); pathtraceInit(scene), src/main.cpp:73-94) with the camera the reference's own glm
@@ -65,8 +65,14 @@ def test_reference_host_code_drives_the_hip_path(pt, oracle, tmp_path, move):
     if not os.path.exists(DRIVER):
         pytest.skip("oracle/_ref/ref_shim_driver is built only where /root/reference exists")
     out = str(tmp_path / "o.bin")
+    # members > 1: PT_AMD_DEVICES -- the unchanged reference host over a GROUP of renderers that share the frame's rows (pt_group_*:
+    # one per device of a node; on this one-GPU box they share the device): the same image, bit for bit
+    env = dict(os.environ)
+    env.pop("PT_AMD_DEVICES", None)
+    if members > 1:
+        env["PT_AMD_DEVICES"] = str(members)
     r = subprocess.run([DRIVER, os.path.join(SCENES, "cornell.txt"), "3", out] + (list(move) if move else []),
-                       capture_output=True, text=True, timeout=300)
+                       capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     assert ("%d pathtrace calls" % (5 if move else 3)) in r.stdout and "last iteration 3" in r.stdout
     cam, W, H, got = _read_dump(out, oracle)
