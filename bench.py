@@ -105,6 +105,15 @@ def parse(argv=None):
     ap.add_argument("--valu-rate-json", default=os.path.join(ROOT, "profiles", "valu_issue_rate.json"),
                     help="measured cycles per wave64 vector instruction per SIMD (profiles/valu_issue_rate.hip)")
     ap.add_argument("--dump-frame", default=None, help="rank 0 writes the final frame (float32 W*H*3 running sum) to this .npy file")
+    ap.add_argument("--configs", type=int, default=None,
+                    help="1: after the headline line's own measurement, measure the other BASELINE configurations that fit one GPU -- C4 (glass, 1920x1080, "
+                         "depth 16), C5 on one GPU (64 spheres, 4096x4096, 16 spp per step) and the mesh scene -- a few timed blocks each, every one "
+                         "in a child process of its own, and report them under `configs` with a roofline each.  Default: 1 for the plain "
+                         "`python bench.py [--steps K --warmup W]` on one GPU, 0 as soon as a scene / frame / depth / batch is given")
+    ap.add_argument("--roofline-bound", default="hbm", choices=["hbm", "valu_fp32"],
+                    help="what `roofline` prices the bounce kernel against: the 8 TB/s of HBM (the contract's bound; C2, C4, meshes) or the vector "
+                         "units' fp32 issue rate (SURVEY 8d: the 64-sphere configuration C5 is VALU-bound; needs that configuration's counters, --pmc-key)")
+    ap.add_argument("--pmc-key", default=None, help="take the PMC counters from profiles/pmc_configs.json[<key>] instead of --pmc-traffic-json")
     return ap.parse_args(argv)
 
 
@@ -290,6 +299,44 @@ def cpu_baseline(args, scene, pt):
             "c1": c1}
 
 
+# the other BASELINE configurations that fit one GPU (BASELINE.json configs[3], configs[4] on one of its eight GPUs) and the README's mesh
+# extra: (key, bench arguments, what the block says about itself)
+OTHER_CONFIGS = [
+    ("c4", ["--scene", "scenes/cornell_glass.txt", "--res", "1920", "1080", "--depth", "16", "--steps", "4", "--warmup", "1"],
+     "BASELINE config C4: Cornell + glass sphere, 1920x1080, 16 bounces, its 256 spp as 4 steps of 64"),
+    ("c5_one_gpu", ["--scene", "scenes/spheres64.txt", "--res", "4096", "4096", "--depth", "8", "--batch", "16", "--steps", "2", "--warmup", "1",
+                    "--roofline-bound", "valu_fp32"],
+     "BASELINE config C5 on ONE of its eight GPUs: 64-sphere scene, 4096x4096, 8 bounces, its 16 spp as one step"),
+    ("mesh", ["--scene", "scenes/cornell_mesh.txt", "--steps", "4", "--warmup", "1"],
+     "README extra (SURVEY 8f-4): Cornell box with two triangle meshes, 1280x720, 8 bounces, 64 spp per step"),
+]
+
+
+def other_configs(args):
+    """One child `bench.py` per configuration (its own process: its own renderer, pools and device memory, released when it ends), a few
+    timed blocks each; what comes back is that run's own line, cut down to the number, its spread, the workload and the roofline."""
+    out = {}
+    for key, extra, what in OTHER_CONFIGS:
+        cmd = [sys.executable, os.path.abspath(__file__)] + extra + ["--repeats", "3", "--cpu-spp", "0", "--per-iteration-sample", "0",
+                                                                      "--configs", "0", "--pmc-key", key, "--pipeline", str(args.pipeline)]
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not line:
+                out[key] = {"what": what, "error": "rc %d: %s" % (r.returncode, r.stderr.strip().splitlines()[-1] if r.stderr.strip() else "no output")}
+                continue
+            d = json.loads(line[-1])
+            out[key] = {"what": what, "value": d["value"], "unit": d["unit"], "value_min": d["value_min"], "value_max": d["value_max"],
+                        "steps": d["steps"], "warmup": d["warmup"], "repeats": d["repeats"], "ms_per_step": d["ms_per_step"],
+                        "workload": d["config"]["workload"], "live_segments_per_iteration": d["config"]["live_segments_per_iteration"],
+                        "roofline": d["roofline"], "command": "python bench.py " + " ".join(cmd[2:]),
+                        "wall_s_of_the_child_process": round(time.perf_counter() - t0, 1)}
+        except Exception as e:                               # (an extra block must never cost the line)
+            out[key] = {"what": what, "error": repr(e)}
+    return out
+
+
 def valu_issue_rate(path, waves_per_simd):
     """cycles per wave64 vector instruction per SIMD from the committed microbenchmark: the kernel-like instruction mix at
     the residency nearest to the kernel's, and the plain v_fma_f32 rate (wall-clock based columns)."""
@@ -318,6 +365,11 @@ def _on_sigterm(signum, frame):
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.configs is None:
+        # the driver's plain command (flags --gpus / --steps / --warmup only) reports every one-GPU configuration; any other run is about ONE
+        d = parse([])
+        args.configs = 1 if (args.gpus == 1 and world == 1 and all(getattr(args, k) == getattr(d, k) for k in
+                                                                     ("scene", "res", "depth", "batch", "pipeline", "scaling", "cpu_spp", "repeats"))) else 0
     if world == 1 and args.gpus > 1:
         self_launch(args)                                   # never returns
     import signal
@@ -650,6 +702,8 @@ def run(args, ctx):
     traffic, valu_insts, lds_conf, pmc_src, valu_util = None, None, None, None, None
     try:
         pmc = json.load(open(args.pmc_traffic_json))
+        if args.pmc_key:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_configs.json")))[args.pmc_key]
         here = ["%s %dx%d" % (os.path.relpath(args.scene, ROOT), W, H), "%d bounces" % D]
         if world == 1 and pmc.get("workload") == here and pmc.get("iterations_per_launch") == iters_per_launch:
             traffic = pmc["hbm_bytes_per_launch_iteration"] * iters_per_launch
@@ -692,6 +746,19 @@ def run(args, ctx):
                           "issue_bound_ms_per_launch": {"kernel_like_mix": round(t_mix, 5), "v_fma_f32": round(t_fma, 5)},
                           "frac_of_issue_bound": {"kernel_like_mix": round(t_mix / avg_ms, 4), "v_fma_f32": round(t_fma / avg_ms, 4)},
                           "lds_bank_conflict_cycles_per_launch": lds_conf}
+        if args.roofline_bound == "valu_fp32":
+            # a configuration whose kernel is bound by the vector units (C5: 70 primitives, ~7 kflop per segment) is priced
+            # against the vector-fp32 peak (MI355X_MICROARCH.md: 157.3 TFLOP/s = 1024 SIMDs x 64 FLOP per clock x 2.4 GHz, an FMA
+            # counting two).  `achieved` counts every wave64 vector instruction of the launch (PMC: SQ_INSTS_VALU of THIS configuration)
+            # as one such issue slot -- 64 lanes x 2 FLOP -- so `frac` is the share of the SIMDs' issue slots the kernel fills at the
+            # maximum clock: an upper bound of the arithmetic actually done (compares, selects and moves fill slots too).
+            hbm = {k: rf[k] for k in ("achieved", "peak", "unit", "frac", "frac_pipelined", "algorithmic_bytes_per_launch", "traffic_over_algorithmic")}
+            v_ach = valu_insts * 128.0 / (avg_ms * 1e-3) / 1e12 if (valu_insts and avg_ms > 0) else None
+            rf.update({"bound": "valu_fp32", "achieved": round(v_ach, 2) if v_ach else None, "peak": 157.3, "unit": "TFLOP/s",
+                       "frac": round(v_ach / 157.3, 5) if v_ach else None,
+                       "counted": "SQ_INSTS_VALU per launch x 64 lanes x 2 FLOP (one FMA issue slot each) / the launch's HIP-event duration",
+                       "hbm": hbm})
+            rf.pop("frac_pipelined", None)
         out = {
             "metric": "Mpaths/sec (paths = pixels x bounces x spp) at %dx%d, %d bounces" % (W, H, D),
             "value": round(nominal / dt / 1e6, 2), "unit": "Mpaths/s",
@@ -748,6 +815,8 @@ def run(args, ctx):
             pass
         if world == 1 and args.cpu_spp > 0:
             out["cpu_baseline"] = cpu_baseline(args, scene, pt)
+        if world == 1 and args.configs:
+            out["configs"] = other_configs(args)
         print(json.dumps(out), flush=True)
 
 

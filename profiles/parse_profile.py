@@ -65,6 +65,8 @@ def main():
     ap.add_argument("--pixels", type=int, default=1280 * 720)
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--set-default", action="store_true", help="also write profiles/pmc_traffic.json (what bench.py reads): the headline configuration only")
+    ap.add_argument("--config-key", default=None, help="also store the distilled counters under this key of profiles/pmc_configs.json (bench.py --pmc-key: "
+                                                       "the `configs` blocks of the default run -- c4, c5_one_gpu, mesh)")
     args = ap.parse_args()
     src = os.path.join(ROOT, "gpurun_out", "prof_" + args.tag)
     out = {}
@@ -190,6 +192,11 @@ def main():
                     pj["valu_utilisation_counter_derived"] = kb["SQ_INSTS_VALU"] * 2.0 / (1024.0 * kb["GRBM_GUI_ACTIVE"] / 8.0)
         if args.set_default:
             json.dump(pj, open(os.path.join(HERE, "pmc_traffic.json"), "w"), indent=1)
+        if args.config_key:
+            path = os.path.join(HERE, "pmc_configs.json")
+            allc = json.load(open(path)) if os.path.exists(path) else {}
+            allc[args.config_key] = pj
+            json.dump(allc, open(path, "w"), indent=1, sort_keys=True)
         out["k_bounce"]["traffic"] = pj
     if "SQ_LDS_BANK_CONFLICT" in kb:
         out["k_bounce"]["lds_bank_conflict_cycles_per_launch"] = kb["SQ_LDS_BANK_CONFLICT"]
