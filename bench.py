@@ -549,6 +549,8 @@ def run(args, ctx):
         barrier()
         t0 = time.perf_counter()
         nxt = run_steps(first_iter, steps, I, maxb, every, collective, reducer)
+        if reducer is not None:
+            reducer.finish()      # (gloo's asynchronous reduces are not the device's work: the closing barrier + synchronize would not wait for them)
         barrier()
         return max_over_ranks(time.perf_counter() - t0), nxt
 

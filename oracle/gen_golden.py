@@ -150,7 +150,7 @@ def run_isect(L, geom, rays):
 def main():
     if not os.path.isdir(REF):
         sys.exit("gen_golden.py needs /root/reference (authoring container only)")
-    subprocess.check_call(["make", "-s", "-C", HERE, "ref"])
+    subprocess.check_call(["make", "-s", "-C", HERE, "reflib"])    # (the libraries alone: no product build needed)
     os.makedirs(GOLD, exist_ok=True)
     L = load_ref()
     Ld = load_ref("libptref_dpow.so")

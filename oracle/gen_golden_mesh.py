@@ -22,7 +22,7 @@ GOLD = os.path.join(os.path.dirname(HERE), "tests", "golden")
 def main():
     if not os.path.isdir("/root/reference"):
         sys.exit("gen_golden_mesh.py needs /root/reference (authoring container only)")
-    subprocess.check_call(["make", "-s", "-C", HERE, "ref"])
+    subprocess.check_call(["make", "-s", "-C", HERE, "reflib"])
     L = C.CDLL(os.path.join(HERE, "_ref", "libptref.so"))
     L.ref_intersect_ray_triangle.argtypes = [C.c_void_p] * 6
     rng = np.random.default_rng(20151116)

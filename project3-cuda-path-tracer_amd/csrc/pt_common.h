@@ -4,9 +4,6 @@
 #include <stdint.h>
 
 namespace ptk {
-#ifndef PT_BLOCK
-#define PT_BLOCK 256
-#endif
-constexpr int kBlock = PT_BLOCK;     // threads per workgroup = paths per tile (4 wave64; PT_BLOCK: tile-size experiments only)
+constexpr int kBlock = 256;          // threads per workgroup = paths per tile (4 wave64)
 constexpr int kWaves = kBlock / 64;
 }  // namespace ptk

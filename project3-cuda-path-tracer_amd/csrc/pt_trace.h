@@ -17,13 +17,7 @@ constexpr int kMaxDepthSlots = PT_MAX_DEPTH + 2;
 // ---- device control block ------------------------------------------------------------------------
 constexpr int kOct = 8;              // direction octants: paths are binned by the signs of their new direction ...
 constexpr int kCls = 2 * kOct;       // ... and by "may hit a small primitive" (bit 3): 16 classes
-#ifndef PT_KSUB
-#define PT_KSUB 8
-#endif
-#ifndef PT_POOL
-#define PT_POOL 1                    // sphere-heavy scenes, later bounces: a wave's candidates tested in ONE pooled pass (k_bounce); 0: experiments only
-#endif
-constexpr int kSub = PT_KSUB;        // append-counter shards per class (workgroup blockIdx % kSub; PT_KSUB: shard-count experiments only)
+constexpr int kSub = 8;              // append-counter shards per class (workgroup blockIdx % kSub)
 constexpr int kSeg = kCls * kSub;    // path buffers are split into kSeg segments with one append counter each
 // Scenes with triangle meshes bin by TWO candidate bits instead of one (class bits 3 and 4: "may hit a binned primitive of group 0 /
 // of group 1" -- pt_init puts the costliest mesh alone into group 1): 32 classes of kSeg / 32 shards each in the same kSeg segments.
@@ -200,9 +194,7 @@ __device__ __forceinline__ void reserveRun(uint32_t *pos, uint32_t *bump, unsign
     base0 = base1 = 0u;
     split = total;
     uint32_t p = total ? atomicAdd(pos, total) : 0u;
-#if defined(PT_EXP) && (PT_EXP & 1)      // experiment: one more dependent memory round trip per reservation (how exposed is it?)
-    if (total) p += atomicAdd(pos + 1 + (p & 7u), 1u) >> 31;
-#endif
+    PT_EXP_RESERVE(p, pos, total)        // (experiment builds only: pt_experiments.h)
     const uint32_t k0 = p >> shift, k1 = (p + (total ? total - 1u : 0u)) >> shift;
     if (total && ((p & ((1u << shift) - 1u)) == 0u || k1 != k0)) { // this run holds the first slot of chunk k1: install the one after it
         const uint32_t kNew = k1 + 1u;
@@ -598,14 +590,8 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
     // long as T does: both are multiples of the tiles per row apart from c0 < tilesPerRow) and the rotated band.
     uint32_t rot = 0;                       // (c0 + k) % tilesPerRow of the tile about to be processed
     uint32_t rowShift = 0;                  // c0
-#ifndef PT_TICKETS
-#define PT_TICKETS 1
-#endif
-#ifndef PT_TICKETS_FIRST
-#define PT_TICKETS_FIRST 1
-#endif
     // (a camera-ray launch that draws tickets -- see TICKETS below -- takes its tiles in ticket order: no rotation to set up)
-    constexpr bool kTickets = PT_TICKETS && (!FIRST || PT_TICKETS_FIRST);
+    constexpr bool kTickets = true;
     const bool ticketed = kTickets && (hotWord & kHotLast) == 0u;
     if (FIRST && !ticketed) {
         const uint32_t tpr = (uint32_t)launder(kargs)->prm.tilesPerRow;
@@ -1007,18 +993,9 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
                         };
                         sweep32(base, mHi);
                         sweep32(base + 32, mLo);
-#if defined(PT_EXP) && (PT_EXP & 128)    // experiment: what does the sweep cost?  (run it twice; the masks are the same)
-                        {
-                            uint32_t xHi = 0u, xLo = 0u;
-                            asm volatile("" : "+v"(org.x));
-                            sweep32(base, xHi);
-                            sweep32(base + 32, xLo);
-                            mHi |= xHi; mLo |= xLo;
-                        }
-#endif
+                        PT_EXP_SWEEP_TWICE(base, mHi, mLo, org)         // (experiment builds only)
                     }
                     probe(25);                                      // (the candidates' passes)
-#if PT_POOL
                     // POOLED pass.  A pass of the loop below runs for the lanes that still hold a candidate -- a quarter of a wave in C5
                     // (profiles/probe_phases.py: 13.9 lanes per pass, 1.6 passes per tile) -- and a wave takes as many passes as its
                     // busiest lane has candidates.  When some lane has two or more and the wave's candidates are no more than its running lanes, ALL of
@@ -1103,7 +1080,6 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
                             }
                         }
                     }
-#endif
                     // pass k tests every lane's k-th candidate with that lane's own matrices from LDS
                     while (__ballot((mHi | mLo) != 0u) != 0ull) {     // wave-uniform trip count
                         if ((mHi | mLo) != 0u) {
@@ -1390,43 +1366,7 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
                 }
             }
         }
-#if defined(PT_EXP) && (PT_EXP & 0x7c)
-        // experiments: what is a tile's time sensitive to?  100 more instructions of one class per wave and tile (the result feeds a
-        // store that never executes, so nothing is optimised away and no result changes)
-        {
-            float xa = org.x, xb = dir.y;
-            uint32_t sa = (uint32_t)__builtin_amdgcn_readfirstlane((int)pixHash), sb = sa ^ 0x55u;
-#pragma unroll 1
-            for (int q = 0; q < 25; ++q) {
-#if PT_EXP & 4        // vector, VGPR operands only
-                asm volatile("v_fma_f32 %0, %0, %1, %1\n\tv_fma_f32 %1, %1, %0, %0\n\tv_fma_f32 %0, %0, %1, %1\n\tv_fma_f32 %1, %1, %0, %0" : "+v"(xa), "+v"(xb));
-#endif
-#if PT_EXP & 8        // vector with one SGPR operand
-                asm volatile("v_mul_f32 %0, %2, %0\n\tv_mul_f32 %1, %2, %1\n\tv_mul_f32 %0, %2, %0\n\tv_mul_f32 %1, %2, %1" : "+v"(xa), "+v"(xb) : "s"(sa));
-#endif
-#if PT_EXP & 16       // scalar ALU
-                asm volatile("s_add_u32 %0, %0, %1\n\ts_xor_b32 %1, %1, %0\n\ts_add_u32 %0, %0, %1\n\ts_xor_b32 %1, %1, %0" : "+s"(sa), "+s"(sb));
-#endif
-#if PT_EXP & 64       // compare into an SGPR pair + select on it
-                asm volatile("v_cmp_lt_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc\n\tv_cmp_gt_f32 vcc, %0, %1\n\tv_cndmask_b32 %1, %1, %0, vcc" : "+v"(xa), "+v"(xb) : : "vcc");
-#endif
-            }
-#if PT_EXP & 32       // 20 dependent scalar loads (a latency chain through the scalar cache)
-            {
-                const PT_CAS uint32_t *pp = (const PT_CAS uint32_t *)launder(kargs);
-                uint32_t acc = 0;
-#pragma unroll 1
-                for (int q = 0; q < 20; ++q) {
-                    uint32_t v;
-                    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(pp + ((acc & 3u))) : "memory");
-                    acc = (acc + v) & 0xffu;
-                }
-                sa += acc;
-            }
-#endif
-            if (__float_as_uint(xa) + __float_as_uint(xb) + sa + sb == 0x12345677u && pixHash == 0x12345u && sa == 77u) fl |= 4u;
-        }
-#endif
+        PT_EXP_TILE_LOAD(org, dir, pixHash, fl, kargs)          // (experiment builds only)
         probe(17);                                              // (next tile's loads)
         sLight += (uint32_t)__popcll(__ballot((fl & 2u) != 0u));
         sMiss += (uint32_t)__popcll(__ballot((fl & 4u) != 0u));
@@ -1499,10 +1439,7 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
             probe(23);                                          // (second barrier)
             __syncthreads();
             if (kTickets) Tn1 = ticketed ? s_ticket[0] : Tnext + gridDim.x;
-#if defined(PT_EXP) && (PT_EXP & 2)      // experiment: one more workgroup barrier per tile
-            asm volatile("" ::: "memory");
-            __syncthreads();
-#endif
+            PT_EXP_EXTRA_BARRIER()                                // (experiment builds only)
             probe(19);                                          // (stores)
             if (alive) {
                 const ArgsPtr A = launder(kargs);

@@ -42,16 +42,12 @@ def init_process_group(backend=None, timeout_s=600, single_rank=False):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world == 1 and not single_rank:
         return 0, 1
+    file_store = None
     if world == 1:
-        import socket
-        s = socket.socket()
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-        s.close()
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", str(port))
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
+        # a one-rank group needs no rendezvous over the network: a FileStore in a fresh temporary directory (probing a free TCP port,
+        # closing it and letting c10d bind it again left a window in which a parallel bench or test on the box could take it)
+        import tempfile
+        file_store = os.path.join(tempfile.mkdtemp(prefix="pt_amd_store_"), "store")
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     # HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC, the only kind this driver supports) is read when the HSA runtime
@@ -62,7 +58,11 @@ def init_process_group(backend=None, timeout_s=600, single_rank=False):
     kw = {}
     if backend == "nccl":
         kw["device_id"] = torch.device("cuda", torch.cuda.current_device())
-    dist.init_process_group(backend=backend, timeout=datetime.timedelta(seconds=timeout_s), **kw)
+    if file_store is not None:
+        dist.init_process_group(backend=backend, init_method="file://" + file_store, rank=0, world_size=1,
+                                timeout=datetime.timedelta(seconds=timeout_s), **kw)
+    else:
+        dist.init_process_group(backend=backend, timeout=datetime.timedelta(seconds=timeout_s), **kw)
     return dist.get_rank(), dist.get_world_size()
 
 
@@ -186,9 +186,13 @@ class PerIterationReducer:
                 self.work[k] = None
 
     def frame(self):
-        """rank `dst`: the frame of the latest collect() (summed over the ranks); other ranks: their own snapshot"""
+        """rank `dst`: the frame of the latest collect(), summed over the ranks.  Every other rank: None -- a reduce leaves the
+        contents of its buffer off the root unspecified (gloo and RCCL may park partial sums there)."""
+        import torch.distributed as dist
         self.finish()
-        return self.snap[self.last] if self.last is not None else None
+        if self.last is None or (self.collective and dist.get_rank() != self.dst):
+            return None
+        return self.snap[self.last]
 
     def bytes_per_call(self):
         return self.accum.numel() * self.accum.element_size()

@@ -130,6 +130,19 @@ Scene::Scene(std::string filename, bool verbose_) : verbose(verbose_) {
         else block = false;
         if (block && verbose) std::cout << " " << std::endl;
     }
+    // `usemtl <k>` names a MATERIAL of THIS file.  An OBJ from elsewhere may carry numeric material names of its own: an index the
+    // scene does not have falls back to the object's material, loudly (it used to surface only later, as pt_init's PT_ERR_INVALID).
+    for (size_t i = 0; i < meshes.size(); ++i) {
+        size_t bad = 0;
+        for (size_t f = 0; f < meshes[i].mats.size(); ++f)
+            if (meshes[i].mats[f] >= (int)materials.size()) {
+                meshes[i].mats[f] = -1;
+                ++bad;
+            }
+        if (bad)
+            std::cout << "WARNING: mesh of object " << meshes[i].geom << ": " << bad << " faces name a material (usemtl <k>) the scene has "
+                      << "not (" << materials.size() << " MATERIAL blocks): they take the object's material" << std::endl;
+    }
 }
 
 Scene::~Scene() {}

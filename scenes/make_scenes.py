@@ -87,6 +87,67 @@ def spheres64(seed=565):
     return s
 
 
+# ---- scenes OUTSIDE the Cornell shape (round 5: what do the kernels' scene-keyed heuristics cost elsewhere?) ------------------------------
+def lattice_scene(title, name, kind, n, seed, rotate):
+    """Cornell's room and light with n^3 primitives of `kind` on a jittered lattice inside it: sizes, (for cubes) orientations and the
+    material cycle from a minstd stream, like spheres64.txt"""
+    x = seed % 2147483647 or 1
+
+    def u01():
+        nonlocal x
+        x = (x * 48271) % 2147483647
+        return (x - 1) / 2147483648.0
+
+    mats = CORNELL_MATS + [GLASS]
+    s = f"// {title} (authored by this build; minstd seed {seed})\n\n"
+    for i, m in enumerate(mats):
+        s += material(i, *m)
+    s += camera("800 800", 45, 5000, 8, name)
+    for i, o in enumerate(CORNELL_OBJS[:6]):
+        s += obj(i, *o)
+    cyc = [1, 2, 3, 4, 5]
+    k = 6
+    step = 8.0 / n
+    for ix in range(n):
+        for iy in range(n):
+            for iz in range(n):
+                cx = -4 + (ix + 0.5) * step + (u01() - 0.5) * 0.3 * step
+                cy = 1 + (iy + 0.5) * step + (u01() - 0.5) * 0.3 * step
+                cz = -4 + (iz + 0.5) * step + (u01() - 0.5) * 0.3 * step
+                d = step * (0.3 + 0.3 * u01())
+                rot = "%.2f %.2f %.2f" % (360 * u01(), 360 * u01(), 360 * u01()) if rotate else "0 0 0"
+                sc = f"{d:.4f} {d * (0.5 + u01()):.4f} {d:.4f}" if rotate else f"{d:.4f} {d:.4f} {d:.4f}"
+                s += obj(k, f"{kind} {k - 6}", kind, cyc[(k - 6) % 5], f"{cx:.4f} {cy:.4f} {cz:.4f}", rot, sc)
+                k += 1
+    return s
+
+
+def room_tilted():
+    """A room none of whose walls is axis-aligned (every wall rotated about two axes, the whole room turned against the camera), a tilted
+    light, three spheres and two rotated cubes: nothing of Cornell's box shape for the wall certificates to lean on"""
+    mats = CORNELL_MATS + [GLASS]
+    s = "// tilted room: no axis-aligned wall, oblique camera (authored by this build)\n\n"
+    for i, m in enumerate(mats):
+        s += material(i, *m)
+    s += camera("800 800", 40, 5000, 8, "room_tilted", eye="1.5 5.5 11", view="-0.12 -0.05 -1", up="0.05 1 0")
+    objs = [
+        ("light, tilted", "cube", 0, "0.3 9.4 -0.5", "6 20 -4", "3.5 .3 3"),
+        ("floor", "cube", 1, "0 0 0", "3 17 -2", "12 .05 12"),
+        ("ceiling", "cube", 1, "0 10 0", "-4 10 2", "12 .05 12"),
+        ("back wall", "cube", 1, "0 5 -5.5", "85 3 12", "12 .05 11"),
+        ("left wall", "cube", 2, "-5.5 5 0", "0 15 88", "11 .05 12"),
+        ("right wall", "cube", 3, "5.5 5 0", "7 -12 93", "11 .05 12"),
+        ("mirror-mix sphere", "sphere", 4, "-1.5 3.5 -1", "0 0 0", "3 3 3"),
+        ("glass ellipsoid", "sphere", 5, "2 2.5 1", "30 45 60", "2 3 2"),
+        ("small white sphere", "sphere", 1, "0.5 6.5 -2", "0 0 0", "1.5 1.5 1.5"),
+        ("red block", "cube", 2, "-3 1.5 1.5", "10 35 5", "1.5 3 1.5"),
+        ("green block", "cube", 3, "3 1 -2.5", "0 60 20", "2 2 2"),
+    ]
+    for i, o in enumerate(objs):
+        s += obj(i, *o)
+    return s
+
+
 # ---- OBJ models (generated: no network, no third-party assets) ---------------------------------------------
 def icosphere(subdiv, radius=0.5):
     """Unit-diameter icosphere: 20 * 4^subdiv counter-clockwise (outward) triangles."""
@@ -221,6 +282,9 @@ def main():
     s += obj(0, "sphere", "sphere", 0, "0 0 0", "0 0 0", "3 3 3")
     w("sphere.txt", s)
     w("spheres64.txt", spheres64())
+    w("cubes64.txt", lattice_scene("64 rotated cubes in Cornell's room", "cubes64", "cube", 4, 7001, True))
+    w("spheres512.txt", lattice_scene("512 spheres in Cornell's room", "spheres512", "sphere", 8, 7002, False))
+    w("room_tilted.txt", room_tilted())
 
 
 if __name__ == "__main__":

@@ -175,3 +175,17 @@ def test_product_never_touches_the_oracle():
                 src = open(os.path.join(dp, f), errors="ignore").read()
                 code = "\n".join(l for l in src.split("\n") if "never touches oracle/" not in l)
                 assert "pt_oracle" not in code and "libptoracle" not in code and "import oracle" not in code, f
+
+
+def test_foreign_obj_material_names_fall_back_to_the_objects_material(pt, tmp_path, capfd):
+    # `usemtl <k>` is a MATERIAL index of the scene file; an OBJ from elsewhere with numeric material names of its own
+    # must not silently rebind faces (or fail much later, in pt_init): indices the scene does not have are dropped with a warning
+    (tmp_path / "m.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nv 0 0 1\nusemtl 1\nf 1 2 3\nusemtl 7\nf 1 2 4\nusemtl 250\nf 1 3 4\nusemtl rusty_metal\nf 2 3 4\n")
+    scene = ("MATERIAL 0\nRGB 1 1 1\nSPECEX 0\nSPECRGB 0 0 0\nREFL 0\nREFR 0\nREFRIOR 0\nEMITTANCE 5\n\n"
+             "MATERIAL 1\nRGB .5 .5 .5\nSPECEX 0\nSPECRGB 0 0 0\nREFL 0\nREFR 0\nREFRIOR 0\nEMITTANCE 0\n\n"
+             "CAMERA\nRES 8 8\nFOVY 45\nITERATIONS 1\nDEPTH 2\nFILE t\nEYE 0 0 5\nVIEW 0 0 -1\nUP 0 1 0\n\n"
+             "OBJECT 0\nmesh m.obj\nmaterial 0\nTRANS 0 0 0\nROTAT 0 0 0\nSCALE 1 1 1\n")
+    (tmp_path / "s.txt").write_text(scene)
+    sc = pt.Scene(str(tmp_path / "s.txt"))
+    assert sc.mesh_materials[0].tolist() == [1, -1, -1, -1]
+    assert "2 faces name a material" in capfd.readouterr().out
