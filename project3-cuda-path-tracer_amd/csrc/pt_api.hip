@@ -266,6 +266,8 @@ int launch_bounce(Slot &sl, int iter, int batch, int depth, bool lastBounce, flo
 // stream are ordered, so they share it)
 struct ScanWs {
     uint32_t *partial = nullptr;     // [kScanChunksMax + 1]
+    unsigned long long *chained = nullptr;   // k_scan_chained: {ticket, sums[kScanChunksMax]}
+    uint32_t gen = 0;                // calls of the chained scan on this stream (tags the sums; never 0)
 };
 std::map<hipStream_t, ScanWs> g_scan;
 std::mutex g_scanMutex;              // the scan library may be called from several host threads (one stream each)
@@ -276,6 +278,10 @@ std::mutex g_scanMutex;              // the scan library may be called from seve
 int scan_ws(hipStream_t st, ScanWs **out) {
     ScanWs &W = g_scan[st];          // (std::map: the reference stays valid while other streams are added)
     if (!W.partial) HIPCHECK(hipMalloc(&W.partial, (size_t)(kScanChunksMax + 1) * sizeof(uint32_t)));
+    if (!W.chained) {
+        HIPCHECK(hipMalloc(&W.chained, (size_t)(kScanChunksMax + 1) * sizeof(unsigned long long)));
+        HIPCHECK(hipMemset(W.chained, 0, (size_t)(kScanChunksMax + 1) * sizeof(unsigned long long)));
+    }
     *out = &W;
     return PT_OK;
 }
@@ -286,8 +292,10 @@ void scan_release() {
     std::lock_guard<std::mutex> lock(g_scanMutex);
     if (g_scan.empty()) return;
     (void)hipDeviceSynchronize();
-    for (auto &kv : g_scan)
+    for (auto &kv : g_scan) {
         if (kv.second.partial) (void)hipFree(kv.second.partial);
+        if (kv.second.chained) (void)hipFree(kv.second.chained);
+    }
     g_scan.clear();
 }
 bool scan_in_use() {
@@ -1282,9 +1290,20 @@ int pt_scan_exclusive_i32(const int32_t *in_dev, int32_t *out_dev, int64_t n, vo
     long long per;
     int chunks;
     scan_chunks(n, &per, &chunks);
-    hipLaunchKernelGGL((k_scan_reduce<false>), dim3(chunks), dim3(kBlock), 0, st, in_dev, (long long)n, per, wp->partial);
-    hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(kBlock), 0, st, wp->partial, chunks, (long long *)nullptr);
-    hipLaunchKernelGGL(k_scan_apply, dim3(chunks), dim3(kBlock), 0, st, in_dev, out_dev, (long long)n, per, wp->partial);
+    // Three launches (12 bytes of HBM traffic per element).  PT_AMD_SCAN=1: the ONE-launch form (k_scan_chained: ticketed chunks, chained
+    // prefix; 8 bytes per element when a chunk's second read comes out of the caches) -- measured SLOWER on MI355X, 0.214 against 0.172 ms at
+    // 2^26 (0.81 against 0.66 at 2^28): the 2048 resident workgroups' chunks (128 KB each) do not survive in the 4 MB L2 of an XCD between
+    // their two reads, so it moves the same 12 bytes and adds the ticket and the wait; kept selectable, not the default.
+    const char *mode = getenv("PT_AMD_SCAN");
+    if (!(mode && atoi(mode) == 1)) {
+        hipLaunchKernelGGL((k_scan_reduce<false>), dim3(chunks), dim3(kBlock), 0, st, in_dev, (long long)n, per, wp->partial);
+        hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(kBlock), 0, st, wp->partial, chunks, (long long *)nullptr);
+        hipLaunchKernelGGL(k_scan_apply, dim3(chunks), dim3(kBlock), 0, st, in_dev, out_dev, (long long)n, per, wp->partial);
+    } else {
+        if (++wp->gen == 0u) ++wp->gen;
+        HIPCHECK(hipMemsetAsync(wp->chained, 0, sizeof(uint32_t), st));          // the ticket (the sums are tagged with the call's generation)
+        hipLaunchKernelGGL(k_scan_chained, dim3(chunks), dim3(kBlock), 0, st, in_dev, out_dev, (long long)n, per, wp->chained, wp->gen);
+    }
     HIPCHECK(hipGetLastError());
     return PT_OK;
 }

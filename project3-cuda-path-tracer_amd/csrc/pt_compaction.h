@@ -6,7 +6,7 @@
 //   1. k_scan_reduce    one workgroup per chunk: its sum (scan) or its count of non-zero elements (compaction)
 //   2. k_scan_partials  one workgroup: exclusive scan of the chunk totals (they fit one tile)
 //   3. k_scan_apply / k_compact_apply   one workgroup per chunk: re-reads the chunk and writes its part of the result,
-//      starting from the chunk's prefix
+//      starting from the chunk's prefix (chunks newest first: the re-read comes out of the memory-side cache where it still holds them)
 // i.e. 12 bytes of traffic per element for the scan (8 is the minimum) and 8 + 4 per kept element for the compaction,
 // three launches on the caller's stream, and NO workgroup ever waits for another one: no tickets, no look-back, no spinning.
 // (Rounds 1-2 shipped a single-pass scan with decoupled look-back: one atomic ticket per tile on ONE address bounded it at
@@ -33,21 +33,22 @@ __device__ __forceinline__ void load_items(const int32_t *__restrict__ in, long 
         for (int k = 0; k < kScanItems; ++k) v[k] = base + k < n ? in[base + k] : 0;
     }
 }
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-// inclusive scan of one value per lane inside the wave
+// Inclusive scan of one value per lane inside the wave: six DPP steps, no LDS crossbar -- row_shr:1 / 2 / 4 / 8 inside each row of 16 lanes
+// (a source lane outside the row reads as 0), then row_bcast:15 (lane 15 of a row into the next row: rows 1 and 3) and row_bcast:31
+// (lane 31 into rows 2 and 3).  (Rounds 2-4 used __shfl_up: a ds_bpermute round trip, a compare and a select per step.)
 __device__ __forceinline__ uint32_t wave_inclusive(uint32_t x) {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t up = __shfl_up(x, o, 64);
-        if (lane >= o) x += up;
-    }
+#define PT_DPP_ADD(ctrl, rows) x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, ctrl, rows, 0xf, false)
+    PT_DPP_ADD(0x111, 0xf);     // row_shr:1
+    PT_DPP_ADD(0x112, 0xf);     // row_shr:2
+    PT_DPP_ADD(0x114, 0xf);     // row_shr:4
+    PT_DPP_ADD(0x118, 0xf);     // row_shr:8
+    PT_DPP_ADD(0x142, 0xa);     // row_bcast:15 -> rows 1, 3
+    PT_DPP_ADD(0x143, 0xc);     // row_bcast:31 -> rows 2, 3
+#undef PT_DPP_ADD
     return x;
 }
+// the wave's sum: lane 63 of its inclusive scan (a scalar)
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive(v), 63); }
 // the thread's exclusive offset inside the tile and the tile's total (one workgroup barrier; the caller puts another one
 // before s_wave is written again)
 __device__ __forceinline__ uint32_t tile_offsets(uint32_t mine, uint32_t *s_wave, uint32_t *tile_total) {
@@ -124,10 +125,14 @@ __global__ __launch_bounds__(kBlock) void k_scan_apply(const int32_t *__restrict
                                                        long long tilesPerChunk, const uint32_t *__restrict__ partial) {
     __shared__ uint32_t s_wave[kWaves];
     const long long numTiles = (n + kScanTile - 1) / kScanTile;
-    const long long t0 = (long long)blockIdx.x * tilesPerChunk;
+    // The chunks are taken NEWEST FIRST (workgroup 0 = the last chunk): k_scan_reduce has just streamed the whole array through the
+    // 256 MB memory-side cache front to back, so its END is what the cache still holds -- a second front-to-back pass would evict
+    // every line just before it needs it, the reverse pass reads most of the array from the cache instead of from HBM.
+    const long long chunk = (long long)gridDim.x - 1 - blockIdx.x;
+    const long long t0 = chunk * tilesPerChunk;
     const long long t1 = t0 + tilesPerChunk < numTiles ? t0 + tilesPerChunk : numTiles;
     const bool aligned = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
-    uint32_t carry = partial[blockIdx.x];
+    uint32_t carry = partial[chunk];
     for (long long tile = t0; tile < t1; ++tile) {
         const long long base = tile * kScanTile + (long long)threadIdx.x * kScanItems;
         const bool fast = aligned && (tile + 1) * kScanTile <= n;
@@ -158,33 +163,140 @@ __global__ __launch_bounds__(kBlock) void k_scan_apply(const int32_t *__restrict
     }
 }
 
-// 3b. stable compaction of a chunk's non-zero elements: a tile's kept elements are gathered in LDS (in order) and leave
-// with coalesced stores at the chunk's running position
-__global__ __launch_bounds__(kBlock) void k_compact_apply(const int32_t *__restrict__ in, int32_t *__restrict__ out, long long n,
-                                                          long long tilesPerChunk, const uint32_t *__restrict__ partial) {
+// ---- the scan in ONE launch (round 5): reduce, chained prefix, apply -- 8 bytes of HBM traffic per element ------------------------------------
+// A workgroup draws a chunk by ticket (so that every chunk with a lower index is already running), sums it (the first read: HBM), publishes
+// the sum tagged with the call's generation, adds up the sums of the chunks before it -- wave 0, 64 at a time, polling the few that are not
+// there yet: their owners hold earlier tickets, are running and wait for nobody before they publish, so every poll ends -- and then scans
+// the chunk from that prefix (the second read comes out of the caches: a chunk is 128 KB at 2^26 elements, and the 2048 of them together fit
+// the 256 MB memory-side cache).  `state` = {ticket, -, agg[kScanChunksMax] as (sum << 32 | generation)}: the ticket is zeroed by the host
+// before the launch (4 bytes), the sums need no clearing (a stale generation reads as "not there yet").
+// Measured (profiles/r05_scan_summary.txt): 0.214 ms at 2^26 against 0.172 of the three-launch form -- the chunks of 2048 resident
+// workgroups do not survive in the caches between their two reads; opt-in (PT_AMD_SCAN=1), not the default.
+__global__ __launch_bounds__(kBlock) void k_scan_chained(const int32_t *__restrict__ in, int32_t *__restrict__ out, long long n,
+                                                         long long tilesPerChunk, unsigned long long *state, uint32_t gen) {
     __shared__ uint32_t s_wave[kWaves];
-    __shared__ int32_t s_stage[kScanTile];
+    __shared__ uint32_t s_bcast[2];
+    if (threadIdx.x == 0) s_bcast[0] = atomicAdd(reinterpret_cast<uint32_t *>(state), 1u);
+    __syncthreads();
+    const long long chunk = (long long)s_bcast[0];
+    unsigned long long *const agg = state + 1;
     const long long numTiles = (n + kScanTile - 1) / kScanTile;
-    const long long t0 = (long long)blockIdx.x * tilesPerChunk;
+    const long long t0 = chunk * tilesPerChunk;
     const long long t1 = t0 + tilesPerChunk < numTiles ? t0 + tilesPerChunk : numTiles;
-    const bool aligned = (reinterpret_cast<uintptr_t>(in) & 15) == 0;
-    long long dst = (long long)partial[blockIdx.x];
+    const bool aligned = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    // 1. the chunk's sum
+    uint32_t acc = 0;
     for (long long tile = t0; tile < t1; ++tile) {
         const long long base = tile * kScanTile + (long long)threadIdx.x * kScanItems;
         int32_t v[kScanItems];
         load_items(in, base, n, aligned && (tile + 1) * kScanTile <= n, v);
-        uint32_t kept = 0;
 #pragma unroll
-        for (int k = 0; k < kScanItems; ++k) kept += v[k] != 0 ? 1u : 0u;
+        for (int k = 0; k < kScanItems; ++k) acc += (uint32_t)v[k];
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    // 2. publish it; the prefix = the sums of every chunk before this one
+    if (threadIdx.x < 64) {
+        uint32_t total = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) total += s_wave[w];
+        if (threadIdx.x == 0)
+            __hip_atomic_store(&agg[chunk], ((unsigned long long)total << 32) | gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // (relaxed: sum and tag travel in ONE word; a release would write the whole L2 back)
+        uint32_t pre = 0;
+        for (long long j0 = 0; j0 < chunk; j0 += 64) {
+            const long long j = j0 + (long long)threadIdx.x;
+            uint32_t val = 0;
+            if (j < chunk) {
+                unsigned long long e;
+                do {        // (bounded by the predecessors' own reduce: they run, and publish before they wait for anything)
+                    e = __hip_atomic_load(&agg[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } while ((uint32_t)e != gen);
+                val = (uint32_t)(e >> 32);
+            }
+            pre += wave_sum(val);
+        }
+        if (threadIdx.x == 0) s_bcast[1] = pre;
+    }
+    __syncthreads();
+    uint32_t carry = s_bcast[1];
+    // 3. the chunk once more (from the caches), scanned from its prefix
+    for (long long tile = t0; tile < t1; ++tile) {
+        const long long base = tile * kScanTile + (long long)threadIdx.x * kScanItems;
+        const bool fast = aligned && (tile + 1) * kScanTile <= n;
+        int32_t v[kScanItems];
+        load_items(in, base, n, fast, v);
+        uint32_t tsum = 0;
+#pragma unroll
+        for (int k = 0; k < kScanItems; ++k) tsum += (uint32_t)v[k];
         uint32_t total;
-        uint32_t off = tile_offsets(kept, s_wave, &total);
+        uint32_t run = carry + tile_offsets(tsum, s_wave, &total);
+        int32_t o[kScanItems];
 #pragma unroll
-        for (int k = 0; k < kScanItems; ++k)
-            if (v[k] != 0) s_stage[off++] = v[k];
+        for (int k = 0; k < kScanItems; ++k) {
+            o[k] = (int32_t)run;
+            run += (uint32_t)v[k];
+        }
+        if (fast) {
+#pragma unroll
+            for (int q = 0; q < kScanItems / 4; ++q)
+                *reinterpret_cast<int4 *>(out + base + 4 * q) = make_int4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < kScanItems; ++k)
+                if (base + k < n) out[base + k] = o[k];
+        }
+        carry += total;
+        __syncthreads();                       // s_wave is free again
+    }
+}
+
+// 3b. stable compaction of a chunk's non-zero elements by wave-level ballot / mbcnt (the north star's primitives; round 5).  A tile is read
+// STRIPED -- step k of a wave holds 64 CONSECUTIVE elements, k * 256 + its lanes -- so that a step's survivors are ranked by one ballot and
+// one mbcnt and leave for LDS as one run of consecutive words: no bank conflict by construction.  (Rounds 2-4: every thread scattered the
+// survivors of its own 16 consecutive elements to s_stage[off++] -- lanes of a wave wrote to unrelated banks: 31 % of the LDS-active cycles
+// were conflicts, profiles/r02_scan_summary.txt.)  The 64 (step, wave) counts of a tile are scanned by wave 0 (DPP) through LDS; the
+// staged run leaves with coalesced stores at the chunk's running position.
+__global__ __launch_bounds__(kBlock) void k_compact_apply(const int32_t *__restrict__ in, int32_t *__restrict__ out, long long n,
+                                                          long long tilesPerChunk, const uint32_t *__restrict__ partial) {
+    __shared__ uint32_t s_cnt[kScanItems * kWaves + 1];      // [step][wave] survivors, then their exclusive prefix; [64] = the tile's total
+    __shared__ int32_t s_stage[kScanTile];
+    static_assert(kScanItems * kWaves == 64, "wave 0 scans the (step, wave) counts with one value per lane");
+    const long long numTiles = (n + kScanTile - 1) / kScanTile;
+    const long long chunk = (long long)gridDim.x - 1 - blockIdx.x;           // (newest first: see k_scan_apply)
+    const long long t0 = chunk * tilesPerChunk;
+    const long long t1 = t0 + tilesPerChunk < numTiles ? t0 + tilesPerChunk : numTiles;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    long long dst = (long long)partial[chunk];
+    for (long long tile = t0; tile < t1; ++tile) {
+        const long long tb = tile * kScanTile + threadIdx.x;
+        const bool whole = (tile + 1) * kScanTile <= n;
+        int32_t v[kScanItems];
+#pragma unroll
+        for (int k = 0; k < kScanItems; ++k) v[k] = (whole || tb + (long long)k * kBlock < n) ? in[tb + (long long)k * kBlock] : 0;
+#pragma unroll
+        for (int k = 0; k < kScanItems; ++k) {
+            const unsigned long long b = __ballot(v[k] != 0);
+            if (lane == 0) s_cnt[k * kWaves + wave] = (uint32_t)__popcll(b);
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const uint32_t c = s_cnt[lane], inc = wave_inclusive(c);
+            s_cnt[lane] = inc - c;
+            if (lane == 63) s_cnt[64] = inc;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kScanItems; ++k) {
+            const unsigned long long b = __ballot(v[k] != 0);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+            if (v[k] != 0) s_stage[s_cnt[k * kWaves + wave] + rank] = v[k];
+        }
+        const uint32_t total = s_cnt[64];
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < total; i += kBlock) out[dst + i] = s_stage[i];
         dst += (long long)total;
-        __syncthreads();                       // s_stage and s_wave are free again
+        __syncthreads();                       // s_stage and s_cnt are free again
     }
 }
 

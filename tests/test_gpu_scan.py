@@ -66,3 +66,14 @@ def test_scan_is_idempotent_under_repetition_and_unaligned_views(pt, dev, oracle
             pt.scan_exclusive_dev(xv.data_ptr(), ov.data_ptr(), xv.numel(), torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         assert np.array_equal(ov.cpu().numpy(), oracle.scan_exclusive(a[off:]))
+
+
+@pytest.mark.parametrize("n", [1, 4097, 1000003, (1 << 24) + 1])
+def test_one_launch_chained_scan_equals_the_three_launch_form(pt, dev, oracle, n, monkeypatch):
+    # round 5: PT_AMD_SCAN=1 selects the one-launch form (ticketed chunks, chained prefix: k_scan_chained) -- measured slower on MI355X and
+    # therefore not the default (profiles/r05_scan_summary.txt), kept selectable: same result, also back to back on one workspace
+    monkeypatch.setenv("PT_AMD_SCAN", "1")
+    rng = np.random.default_rng(n + 11)
+    a = rng.integers(-1000, 1000, n).astype(np.int32)
+    for _ in range(3):
+        assert np.array_equal(_scan(pt, dev, a), oracle.scan_exclusive(a))
