@@ -112,7 +112,8 @@ struct State {
     int poolChunks = 0;     // chunks per path pool (incl. the trash chunk 0); a pool holds poolChunks * kChunk paths per array
     int grid = 0;           // persistent grid of k_bounce<false>
     int gridFirst = 0;      // ... and of k_bounce<true> (its own register budget, hence its own residency)
-    bool many = false;      // more than kBinMax spheres: the k_bounce<., true> variants (per-lane sphere lists)
+    bool many = false;      // more than kBinMax small primitives (spheres, cubes that are neither walls nor binned): the k_bounce<., true> variants
+    bool sweptCubes = false;  // ... some of them cubes (TileArgs::hot: kHotSweptCubes)
     bool dof = false;       // thin-lens camera: the k_bounce<true, ., true> variants for the camera-ray bounce
     bool plain = false;     // no refractive material, no specular exponent on a reflective one, no direct lighting: k_bounce<..., PLAIN>
     size_t ldsBytes = 0, ldsBytesNext = 0;   // dynamic LDS of the camera-ray launch / of the later ones
@@ -197,11 +198,15 @@ int resolve_events(std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, double &ms
 
 // The instantiation of k_bounce a launch takes: FIRST (camera rays), MANY (per-lane sphere lists: scenes with more than
 // kBinMax spheres), DOF (thin lens: the camera-ray launch only), MESH (scenes with triangle meshes).
-template <bool F, bool M, bool D, bool ME, bool PL = false>
-const void *kb() { return reinterpret_cast<const void *>(k_bounce<F, M, D, ME, PL>); }
+template <bool F, bool M, bool D, bool ME, bool PL = false, bool CU = false>
+const void *kb() { return reinterpret_cast<const void *>(k_bounce<F, M, D, ME, PL, CU>); }
 const void *bounce_kernel(bool first, bool dof) {
     // (plain scenes -- diffuse / emissive / perfect-mirror materials, no README extra: the instantiations without the rarer branches)
     if (R().plain && !R().mesh && !R().many && !dof) return first ? kb<true, false, false, false, true>() : kb<false, false, false, false, true>();
+    if (R().many && R().sweptCubes) {     // many small primitives, cubes among them: the per-lane tests take either type
+        if (R().mesh) return first ? (dof ? kb<true, true, true, true, false, true>() : kb<true, true, false, true, false, true>()) : kb<false, true, false, true, false, true>();
+        return first ? (dof ? kb<true, true, true, false, false, true>() : kb<true, true, false, false, false, true>()) : kb<false, true, false, false, false, true>();
+    }
     if (R().mesh && R().many) return first ? (dof ? kb<true, true, true, true>() : kb<true, true, false, true>()) : kb<false, true, false, true>();
     if (R().mesh) return first ? (dof ? kb<true, false, true, true>() : kb<true, false, false, true>()) : kb<false, false, false, true>();
     if (first && dof) return R().many ? kb<true, true, true, false>() : kb<true, false, true, false>();
@@ -917,14 +922,31 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
         HIPCHECK(hipMemcpy(R().dMeshRecs, meshRecs.data(), meshRecs.size() * sizeof(ptd::MeshUnit), hipMemcpyHostToDevice));
     }
 
-    int nspheres = 0;
-    for (int i = 0; i < ngeoms; ++i) nspheres += geoms[i].type == PT_SPHERE;
-    R().many = nspheres > kBinMax;
+    // The SWEPT primitives of a scene with many small ones (round 5: cubes too -- rounds 2-4 swept spheres only, and 64 small cubes cost
+    // 4.7 x what 64 spheres did, profiles/r05_generality.txt): every sphere, and every cube that is neither a wall nor binned.  Their
+    // bounding balls are swept per lane from a packed table (ptk::SphereCull) instead of being visited one by one by the whole wave.
+    std::vector<char> swept(ngeoms, 0);
+    int nswept = 0, nsweptCubes = 0;
+    for (int i = 0; i < ngeoms; ++i) {
+        const bool smallCube = geoms[i].type == PT_CUBE && !hg[i].binned && (hg[i].flags & 28) == 0 && std::isfinite(hg[i].cullR2);
+        swept[i] = geoms[i].type == PT_SPHERE || smallCube;
+        nswept += swept[i];
+    }
+    R().many = nswept > kBinMax;
     if (R().many && ngeoms > 65535) return fail(PT_ERR_INVALID, "pt_init: more than 65535 primitives");
-    if (R().many) {        // the later bounces take the spheres from a packed copy of their culling data (ptk::SphereCull)
+    if (!R().many) std::fill(swept.begin(), swept.end(), 0);
+    for (int i = 0; i < ngeoms; ++i)
+        if (swept[i] && geoms[i].type == PT_CUBE) {
+            ++nsweptCubes;
+            hg[i].flags |= 64;                        // (bit 6: a swept cube -- the camera-ray bounce lists it like a sphere)
+            hg[i].cullFlags |= 64;
+        }
+    R().sweptCubes = nsweptCubes > 0;
+    if (nsweptCubes) HIPCHECK(hipMemcpy(R().dgeoms, hg.data(), hg.size() * sizeof(GeomDev), hipMemcpyHostToDevice));
+    if (R().many) {        // the later bounces take the swept primitives from a packed copy of their culling data (ptk::SphereCull)
         std::vector<SphereCull> sc;
         for (int i = 0; i < ngeoms; ++i)
-            if (geoms[i].type == PT_SPHERE) {
+            if (swept[i]) {
                 SphereCull e;
                 memset(&e, 0, sizeof e);
                 for (int a = 0; a < 3; ++a) e.centre[a] = hg[i].centre[a];
@@ -954,7 +976,7 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
             // nothing left to hit (KParams::allClassified) -- when there is no primitive of another kind
             k.allClassified = 1;
             for (int i = 0; i < ngeoms; ++i)
-                if (!hg[i].binned && (hg[i].flags & 28) == 0 && geoms[i].type != PT_SPHERE) k.allClassified = 0;
+                if (!hg[i].binned && (hg[i].flags & 28) == 0 && !swept[i]) k.allClassified = 0;
         }
         if (sc.size() % 2) sc.push_back(sc.back());      // (two per scalar load; testing a sphere twice changes nothing)
         k.nSphCull = (int)sc.size();
@@ -997,7 +1019,7 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
             const int small = c >> 3;                                          // candidate bits: which groups of binned primitives
             const int wall = k.nWalls > 0 ? (c & 7) : 6;
             for (int i = 0; i < ngeoms; ++i) {
-                if (R().many && geoms[i].type == PT_SPHERE) continue;            // swept from their packed culling data
+                if (swept[i]) continue;                                          // swept from their packed culling data
                 if (hg[i].binned) {
                     int grp = 0;
                     for (int b = 0; b < k.nBinned; ++b)

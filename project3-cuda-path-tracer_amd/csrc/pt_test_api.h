@@ -303,7 +303,7 @@ int pt_test_sphere_halfline_sweep(const PtGeom *geoms, int ngeoms, uint64_t seed
     if (!geoms || ngeoms < 1 || !culled || !behind || !violations || rays < 0) return fail(PT_ERR_INVALID, "pt_test_sphere_halfline_sweep: bad argument");
     std::vector<GeomDev> hg(ngeoms);
     for (int i = 0; i < ngeoms; ++i) {
-        if (geoms[i].type != PT_SPHERE) return fail(PT_ERR_INVALID, "pt_test_sphere_halfline_sweep: spheres only");
+        if (geoms[i].type != PT_SPHERE && geoms[i].type != PT_CUBE) return fail(PT_ERR_INVALID, "pt_test_sphere_halfline_sweep: spheres and cubes only");
         pack_geom(geoms[i], hg[i]);
     }
     DevBuf<GeomDev> dg;

@@ -218,10 +218,12 @@ __global__ void k_sweep_sphere_halfline(const GeomDev *geoms, int ngeoms, unsign
             dir = normalize(c + f3(u[4] - 0.5f, u[5] - 0.5f, u[6] - 0.5f) * (2.6f * R) - org);
             if (u[7] < 0.1f) dir = -dir;
         } else if (family == 1) {
-            // a point of the sphere itself: the image of a unit-diameter object-space point, then 1e-3 along +-the world normal
-            const F3 pobj = od * 0.5f;
+            // a point of the primitive itself: the image of a unit-diameter object-space point (a cube: pushed out to its surface),
+            // then 1e-3 along +-the world normal (a cube: the direction away from its centre)
+            F3 pobj = od * 0.5f;
+            if (G.type == 1) pobj = pobj * (0.5f / __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(pobj.x), __builtin_fabsf(pobj.y)), __builtin_fabsf(pobj.z)));
             const F3 P = mulMV(G.xf, pobj, 1.0f);
-            const F3 N = normalize(mulMV(G.invT, pobj, 0.0f));
+            const F3 N = G.type == 1 ? normalize(P - c) : normalize(mulMV(G.invT, pobj, 0.0f));
             org = P + N * (u[0] < 0.5f ? 0.001f : -0.001f);
             dir = normalize(f3(u[4] - 0.5f, u[5] - 0.5f, u[6] - 0.5f));
         } else {
@@ -240,7 +242,7 @@ __global__ void k_sweep_sphere_halfline(const GeomDev *geoms, int ngeoms, unsign
             if (dot(org - c, dhat) > 0.0f) ++nb;
             F3 P, N;
             bool o;
-            const float t = sphereIntersectionTest(G, org, dir, P, N, o);
+            const float t = G.type == 1 ? boxIntersectionTest<false>(G, org, dir, P, N, o) : sphereIntersectionTest(G, org, dir, P, N, o);
             if (t != -1.0f) ++nv;
         }
     }

@@ -405,8 +405,12 @@ static_assert(sizeof(CullGroup) == 32 && offsetof(GeomDev, cullFlags) - offsetof
 // PLAIN: the scene's materials are diffuse, emissive or 50/50 perfect mirrors only and no README extra is on -- no refraction, no
 // specular lobe, no direct lighting: their code (a third of the scatter's static instructions: Schlick + refract, the lobe's pow, the
 // emitter pick) is not even compiled in.  Same results (the branches are never taken in such a scene); pt_init picks the instantiation.
-template <bool FIRST, bool MANY, bool DOF = false, bool MESH = false, bool PLAIN = false>
-__global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF ? 5 : (MANY ? (FIRST ? 7 : 6) : 8))) void k_bounce(BounceArgs argsByValue) {
+// CUBES (with MANY only): the swept small primitives include cubes -- the per-lane tests then look the primitive's type up and run the box
+// test for one; an instantiation of its own (four workgroups per CU: both tests inlined in every pass need the registers), so that a scene of
+// spheres runs exactly the code of rounds 2-4.
+template <bool FIRST, bool MANY, bool DOF = false, bool MESH = false, bool PLAIN = false, bool CUBES = false>
+__global__ __launch_bounds__(kBlock, (MANY && CUBES) ? 4 : (MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF ? 5 : (MANY ? (FIRST ? 7 : 6) : 8)))) void k_bounce(BounceArgs argsByValue) {
+    static_assert(MANY || !CUBES, "swept cubes only exist where primitives are swept");
     static_assert(FIRST || !DOF, "the lens only concerns the camera-ray bounce");
     (void)argsByValue;
     const ArgsPtr kargs = (ArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -903,13 +907,17 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
                             uint32_t *const stack = reinterpret_cast<uint32_t *>(smem + A2->prm.meshStackOff) + tid;
                             t = meshIntersectionTest<FIRST && !DOF, kBlock>(G, A2->meshRecs, G.meshRoot, G.meshStride, stack, org, dir, p, n, o, fm);
                         }
-                    } else if (!PACKED && (flags & 1) == 0) {          // (PACKED: no sphere comes this way)
+                    } else if (!PACKED && ((flags & 1) == 0 || (MANY && (flags & 64) != 0))) {    // (PACKED: no swept primitive comes this way)
                         probe(3);
+                        // a sphere -- or, in a scene with many small primitives, a small cube (flag bit 6): the bounding ball first;
+                        // MANY: recorded in the lane's list, tested after the loop with the lane's own matrices
                         if (!certainMiss(cg, org, dir, dd)) {
                             if (MANY && nCand < kListMax) {
                                 s_list[nCand * kBlock + tid] = (uint16_t)g;
                                 ++nCand;
-                            } else {                                 // (MANY: the lane's list is full -- test in place)
+                            } else if (MANY && (flags & 1) != 0) {   // (MANY: the lane's list is full -- test in place)
+                                t = boxIntersectionTest<false, FIRST && !DOF>(G, org, dir, p, n, o);
+                            } else {
                                 t = sphereIntersectionTest<FIRST && !DOF>(G, org, dir, p, n, o);
                             }
                         }
@@ -925,7 +933,19 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
                     }
                 }
             }
-            // the spheres a lane recorded: pass k tests every lane's k-th sphere with that lane's own matrices from LDS
+            // ONE swept primitive with the lane's own matrices (an LDS row: inverseTransform 12, transform 12, GeomDev::invZ 3): the sphere
+            // test -- or, where the scene's swept primitives include cubes (kHotSweptCubes) and this one is one, the box test
+            auto sweptTest = [&](int g, const float (&m)[28], F3 ro, F3 rdir, F3 &p, F3 &n, bool &o) -> float {
+                if (CUBES) {
+                    const ArgsPtr A = launder(kargs);
+                    if (S_GEOMHIT_SMALL(A->prm.nmats)[g].type == 1) {
+                        struct Rows { const float *inv, *invZ, *xf, *camObj; } rows = {m, m + 24, m + 12, m};
+                        return boxIntersectionTest<false, false>(rows, ro, rdir, p, n, o);
+                    }
+                }
+                return sphereIntersectionTestM<false>(m, m + 24, m + 12, m, ro, rdir, p, n, o);
+            };
+            // the primitives a lane recorded: pass k tests every lane's k-th one with that lane's own matrices from LDS
             auto candidatePass = [&]() {
                 for (int k = 0; __ballot(k < nCand) != 0ull; ++k) {          // wave-uniform trip count
                     if (k < nCand) {
@@ -940,7 +960,7 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
                         F3 p, n;
                         bool o = false;
                         probe(4);
-                        const float t = sphereIntersectionTestM<false>(m, m + 24, m + 12, m, org, dir, p, n, o);
+                        const float t = sweptTest(g, m, org, dir, p, n, o);
                         // a recorded sphere may precede, in file order, the primitive that holds the record so far
                         if (t > 0.0f && (hit < 0 || t < tbest || (t == tbest && g < hit))) {
                             tbest = t; hit = g; P = p; nsrc = n; outsideI = o ? 1 : 0;
@@ -1049,7 +1069,7 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
                                     }
                                     bool o = false;
                                     probe(4);
-                                    te = sphereIntersectionTestM<false>(m, m + 24, m + 12, m, oorg, odir, pe, ne, o);
+                                    te = sweptTest(ge, m, oorg, odir, pe, ne, o);
                                     oe = o ? 1 : 0;
                                 }
                                 // every owner collects its pairs: the same numbering, level by level
@@ -1100,7 +1120,7 @@ __global__ __launch_bounds__(kBlock, MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF 
                             F3 p, n;
                             bool o = false;
                             probe(4);
-                            const float t = sphereIntersectionTestM<false>(m, m + 24, m + 12, m, org, dir, p, n, o);
+                            const float t = sweptTest(g, m, org, dir, p, n, o);
                             // nearest by (distance, file order): a sphere may precede the primitive that holds the record so far
                             if (t > 0.0f && (hit < 0 || t < tbest || (t == tbest && g < hit))) {
                                 tbest = t; hit = g; P = p; nsrc = n; outsideI = o ? 1 : 0;

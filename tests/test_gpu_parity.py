@@ -177,6 +177,24 @@ def test_sphere_halfline_certificate_never_rejects_a_hit(gpu, oracle):
     assert culled > (1 << 28) // 5 and behind > (1 << 28) // 16      # both branches of the certificate fire, by the tens of millions
 
 
+def test_halfline_certificate_of_swept_cubes_never_rejects_a_hit(gpu, oracle):
+    # round 5: scenes with many small primitives sweep their small CUBES like their spheres -- the same certificate against the cube's
+    # bounding ball (rho = sqrt(3) / 2: its corners), i.e. a sufficient condition for the reference's `tmax >= tmin && tmax > 0` to fail
+    # (src/intersections.h:70).  2^28 rays of the same families against cubes: small, rotated, flat, far away.
+    geoms = np.concatenate([
+        oracle.make_geom(1, 0, (0, 10, 0), (0, 0, 0), (3, .3, 3)),            # Cornell's light
+        oracle.make_geom(1, 0, (1, 2, 3), (30, 45, 60), (1, 2, 3)),
+        oracle.make_geom(1, 0, (0, 0, 0), (0, 0, 0), (0.6, 0.6, 0.6)),
+        oracle.make_geom(1, 0, (2.5, 6, -2), (10, 20, 30), (0.05, 0.05, 0.05)),
+        oracle.make_geom(1, 0, (-3, 1, 2), (75, -20, 130), (8, 0.5, 3)),
+        oracle.make_geom(1, 0, (100, -50, 25), (0, 0, 0), (40, 40, 40)),
+        oracle.make_geom(1, 0, (4.1, 8.7, -3.3), (123, 231, 312), (1.1, 0.7, 1.9)),
+    ]).view(gpu.GEOM_DTYPE)
+    culled, behind, bad = gpu.test_sphere_halfline_sweep(geoms, 2027 + _SW - 1, (1 << 28) * _SW)
+    assert bad == 0
+    assert culled > (1 << 28) // 8 and behind > (1 << 28) // 32
+
+
 def test_sphere_cluster_boxes_never_reject_a_hit(gpu, oracle):
     # Sphere-heavy scenes without meshes bin the survivors by which of TWO spatial clusters of spheres their ray can hit (class bits 3 / 4,
     # a slab certificate against each cluster's inflated box: pt_api.hip build_sphere_clusters, k_bounce CLUSTER); a tile then sweeps only
