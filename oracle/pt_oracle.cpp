@@ -775,7 +775,11 @@ struct ORender {
                                           each material color", either branch divided by its probability (src/interactions.h:56-59) */
     int emitColorMode = 0;             /* 0 = an emitter hit contributes throughput x m.color x emittance (the build's choice: `color *= m.color`
                                           BEFORE the emitter test); 1 = throughput x emittance (m.color applied only to paths that go on) */
-    std::vector<int> emitters;         /* geoms with an emissive material, file order */
+    /* what the direct-lighting bounce samples (file order): every primitive with an emissive material -- a mesh: also one whose faces name
+     * an emissive material of their own -- with the object-space box it is sampled through: the unit cube [-.5, .5]^3 of a sphere or cube
+     * (centre 0, extent 1), the bounds of a mesh's vertices (round 5: README.md:107-108 x :112-116, emissive meshes) */
+    struct Emitter { int geom; V3 c, e; };
+    std::vector<Emitter> emitters;
     std::vector<OMesh> meshes;         /* triangle data of the geoms of type 2 */
     std::vector<int> meshOf;           /* geom -> index into meshes, -1 */
 };
@@ -1000,16 +1004,20 @@ static void scatter_to_light(const ORender &R, V3 n, V3 norg, V3 mcol, uint32_t 
     int ne = (int)R.emitters.size();
     int pick = (int)(rng_u01(rng) * (float)ne);
     if (pick > ne - 1) pick = ne - 1;
-    const OGeom &L = R.geoms[R.emitters[pick]];
+    const ORender::Emitter &E = R.emitters[pick];
+    const OGeom &L = R.geoms[E.geom];
     float ux = rng_u01(rng) - 0.5f;
     float uy = rng_u01(rng) - 0.5f;
     float uz = rng_u01(rng) - 0.5f;
-    V3 target = multiplyMV(m4_from(L.transform), v4(ux, uy, uz, 1.0f));
+    /* a point of the emitter's object-space box: centre + u x extent (the unit cube: 0 + u x 1 = u) */
+    V3 target = multiplyMV(m4_from(L.transform), v4(E.c.x + ux * E.e.x, E.c.y + uy * E.e.y, E.c.z + uz * E.e.z, 1.0f));
     V3 toward = sub(target, norg);
     ndir = normalize3(toward);
     float w = dot3(n, ndir);
     w = w > 0.0f ? w : 0.0f;
-    float rho2 = ((L.scale.x * L.scale.x + L.scale.y * L.scale.y) + L.scale.z * L.scale.z) * 0.25f;
+    /* rho^2 = |scale x extent|^2 / 4: the squared radius of the ball around the box */
+    const float sx = L.scale.x * E.e.x, sy = L.scale.y * E.e.y, sz = L.scale.z * E.e.z;
+    float rho2 = ((sx * sx + sy * sy) + sz * sz) * 0.25f;
     float cover = rho2 / dot3(toward, toward);
     cover = cover < 1.0f ? cover : 1.0f;
     color = muls(mul(color, mcol), w * cover);
@@ -1223,6 +1231,34 @@ void orc_camera_set_resolution(OCamera *cam, int w, int h) {
 }
 
 /* ---- renderer ------------------------------------------------------------ */
+/* the emitters of the direct-lighting bounce (ORender::emitters), from the primitives, their materials and the meshes set so far */
+static void rebuild_emitters(ORender *R) {
+    R->emitters.clear();
+    for (int i = 0; i < (int)R->geoms.size(); ++i) {
+        const OGeom &g = R->geoms[i];
+        bool emits = g.materialid >= 0 && g.materialid < (int)R->mats.size() && R->mats[g.materialid].emittance > 0.0f;
+        ORender::Emitter E;
+        E.geom = i;
+        E.c = v3(0, 0, 0);
+        E.e = v3(1, 1, 1);
+        if (g.type == 2) {
+            const int mi = i < (int)R->meshOf.size() ? R->meshOf[i] : -1;
+            if (mi < 0) continue;
+            const OMesh &m = R->meshes[(size_t)mi];
+            for (size_t f = 0; f < m.mats.size(); ++f)
+                emits = emits || (m.mats[f] >= 0 && m.mats[f] < (int)R->mats.size() && R->mats[m.mats[f]].emittance > 0.0f);
+            V3 lo = v3(m.tris[0], m.tris[1], m.tris[2]), hi = lo;
+            for (size_t q = 0; q + 2 < m.tris.size(); q += 3) {
+                lo = v3(min2(lo.x, m.tris[q]), min2(lo.y, m.tris[q + 1]), min2(lo.z, m.tris[q + 2]));
+                hi = v3(max2(hi.x, m.tris[q]), max2(hi.y, m.tris[q + 1]), max2(hi.z, m.tris[q + 2]));
+            }
+            E.c = muls(add(lo, hi), 0.5f);
+            E.e = sub(hi, lo);
+        }
+        if (emits) R->emitters.push_back(E);
+    }
+}
+
 ORender *orc_render_create(const OCamera *cam, const OGeom *geoms, int ngeoms, const OMaterial *mats,
                            int nmats, int traceDepth) {
     ORender *R = new ORender();
@@ -1244,10 +1280,8 @@ ORender *orc_render_create(const OCamera *cam, const OGeom *geoms, int ngeoms, c
     R->focalDistance = 0.0f;
     R->viewN = normalize3(R->view);
     R->directLighting = 0;
-    /* (direct lighting samples the unit cube of an emissive primitive: emissive meshes are not sampled) */
-    for (int i = 0; i < ngeoms; ++i)
-        if (geoms[i].type != 2 && mats[geoms[i].materialid].emittance > 0.0f) R->emitters.push_back(i);
     R->meshOf.assign(ngeoms, -1);
+    rebuild_emitters(R);
     return R;
 }
 void orc_render_set_mesh(ORender *R, int geom, const float *tris, int ntris) {
@@ -1258,6 +1292,7 @@ void orc_render_set_mesh(ORender *R, int geom, const float *tris, int ntris) {
     m.margin = mesh_margin(tris, ntris);
     R->meshOf[geom] = (int)R->meshes.size();
     R->meshes.push_back(m);
+    rebuild_emitters(R);
 }
 /* vertex normals (ntris x 9, or NULL: flat) and face materials (ntris, or NULL: the object's) of a mesh set before */
 void orc_render_set_mesh_attributes(ORender *R, int geom, const float *normals, const int *mats) {
@@ -1266,6 +1301,7 @@ void orc_render_set_mesh_attributes(ORender *R, int geom, const float *normals, 
     const size_t nt = m.tris.size() / 9;
     if (normals) m.normals.assign(normals, normals + 9 * nt); else m.normals.clear();
     if (mats) m.mats.assign(mats, mats + nt); else m.mats.clear();
+    rebuild_emitters(R);
 }
 float orc_mesh_margin(const float *tris, int ntris) { return mesh_margin(tris, ntris); }
 /* the two-sided triangle test alone: returns hit; tuv = (t, u, v) as far as they were evaluated (glm's baryPosition is (u, v, t)) */

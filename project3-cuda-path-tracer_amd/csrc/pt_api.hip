@@ -636,15 +636,32 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     // direct lighting: bounce `traceDepth` aims its diffuse scatter at a light and one more launch collects
     k.traceDepth = traceDepth + (direct ? 1 : 0);
     k.directDepth = direct ? traceDepth : 0;
+    // the emitters of the direct-lighting bounce, file order: primitives with an emissive material, sampled through their unit cube --
+    // and meshes (round 5) whose own or any of whose faces' materials emits, through the object-space bounds of their vertices
+    // (oracle/pt_oracle.cpp: rebuild_emitters, operation for operation)
     k.nEmit = 0;
-    for (int i = 0; i < ngeoms && k.nEmit < kEmitMax; ++i)
-        if (geoms[i].type != PT_MESH && mats[geoms[i].materialid].emittance > 0.0f) {   // (direct lighting samples unit cubes: not meshes)
-            const PtVec3 sc = geoms[i].scale;
-            const float xx = sc.x * sc.x, yy = sc.y * sc.y, zz = sc.z * sc.z;
-            const float xy = xx + yy;
-            k.emitRho2[k.nEmit] = (xy + zz) * 0.25f;
-            k.emitGeom[k.nEmit++] = i;
+    for (int i = 0; i < ngeoms && k.nEmit < kEmitMax; ++i) {
+        bool emits = mats[geoms[i].materialid].emittance > 0.0f;
+        float c[3] = {0.0f, 0.0f, 0.0f}, e[3] = {1.0f, 1.0f, 1.0f};
+        if (geoms[i].type == PT_MESH) {
+            const ptm::HostMesh *hm_ = mesh_of(i);
+            if (!hm_ || hm_->tris.size() < 9) continue;
+            for (int fm : hm_->mats) emits = emits || (fm >= 0 && fm < nmats && mats[fm].emittance > 0.0f);
+            float lo[3] = {hm_->tris[0], hm_->tris[1], hm_->tris[2]}, hi[3] = {lo[0], lo[1], lo[2]};
+            for (size_t q = 0; q + 2 < hm_->tris.size(); q += 3)
+                for (int a = 0; a < 3; ++a) {
+                    lo[a] = lo[a] < hm_->tris[q + a] ? lo[a] : hm_->tris[q + a];
+                    hi[a] = hi[a] < hm_->tris[q + a] ? hm_->tris[q + a] : hi[a];
+                }
+            for (int a = 0; a < 3; ++a) { c[a] = (lo[a] + hi[a]) * 0.5f; e[a] = hi[a] - lo[a]; }
         }
+        if (!emits) continue;
+        const PtVec3 sc = geoms[i].scale;
+        const float sx = sc.x * e[0], sy = sc.y * e[1], sz = sc.z * e[2];
+        k.emitRho2[k.nEmit] = ((sx * sx + sy * sy) + sz * sz) * 0.25f;
+        for (int a = 0; a < 3; ++a) { k.emitBox[k.nEmit][a] = c[a]; k.emitBox[k.nEmit][3 + a] = e[a]; }
+        k.emitGeom[k.nEmit++] = i;
+    }
     k.lensRadius = o.lens_radius;
     k.focalDistance = o.focal_distance;
     {

@@ -140,7 +140,8 @@ struct KParams {
                                        // classOff[c + 1]) (BounceArgs::classIdx): not the binned ones unless the class says so, of the walls only
                                        // the class's own, in sphere-heavy scenes no sphere (those come from sphCull)
     int   emitGeom[kEmitMax];
-    float emitRho2[kEmitMax];          // |scale|^2 / 4 of each: squared radius of its bounding ball
+    float emitRho2[kEmitMax];          // |scale x extent|^2 / 4 of each: squared radius of the ball around the box it is sampled through
+    float emitBox[kEmitMax][6];        // ... that object-space box as centre, extent: 0, 1 = the unit cube of a sphere or cube; a mesh: its vertices' bounds
 };
 
 // SoA PathSegment pool: THREE arrays of `cap` = poolChunks << chunkShift elements -- A: float4 {origin, direction.x} at base,
@@ -1284,7 +1285,10 @@ __global__ __launch_bounds__(kBlock, (MANY && CUBES) ? 4 : (MESH ? (MANY ? 4 : (
                             float m[12];
 #pragma unroll
                             for (int q = 0; q < 12; ++q) m[q] = xf[q];
-                            const F3 target = mulMV(m, f3(ux, uy, uz), 1.0f);
+                            // a point of the emitter's object-space box, centre + u x extent (the unit cube: 0 + u x 1 = u); per-lane emitter:
+                            // vector loads from the argument block
+                            const PT_CAS float *bx = &A->prm.emitBox[0][0] + 6 * pick;
+                            const F3 target = mulMV(m, f3(bx[0] + ux * bx[3], bx[1] + uy * bx[4], bx[2] + uz * bx[5]), 1.0f);
                             const F3 toward = target - norg;
                             ndir = normalize(toward);
                             float w = dot(N, ndir);

@@ -199,6 +199,25 @@ def test_mesh_attributes_render_against_the_oracle(gpu, oracle):
     _render_both(gpu, oracle, sc, 5, [3, 4], (96, 96), dump_bounces=(2,), lens_radius=0.3, focal_distance=9.0, direct_lighting=True)
 
 
+def test_direct_lighting_samples_emissive_meshes(gpu, oracle):
+    # round 5 (README.md:107-108 x :112-116; VERDICT round 4 "missing" #5): the direct-lighting bounce also aims at emissive MESHES --
+    # a uniformly chosen point of the object-space bounds of the mesh's vertices, as it does at the unit cube of a sphere or cube.  A
+    # scene whose ONLY emitter is a mesh (the icosphere takes the light's material, the ceiling light a diffuse one): path state after
+    # the aiming bounce and the frame are the oracle's bit for bit (and not the frame of the same scene without the flag).
+    import types
+    sc = gpu.Scene(os.path.join(SCENES, "mesh_small.txt"))
+    geoms = sc.geoms.copy()
+    geoms["materialid"][3] = 0                      # the icosphere emits
+    geoms["materialid"][0] = 1                      # the ceiling light does not
+    s2 = types.SimpleNamespace(geoms=geoms, materials=sc.materials, camera=sc.camera, traceDepth=3, meshes=sc.meshes, image=sc.image)
+    lit = _render_both(gpu, oracle, s2, 3, [1, 2, 3, 4], (96, 96), dump_bounces=(3,), direct_lighting=True)
+    plain = _render_both(gpu, oracle, s2, 3, [1, 2, 3, 4], (96, 96))
+    assert lit.max() > 0 and not np.array_equal(lit, plain)          # (the aiming bounce changes the picture: it reaches the mesh)
+    # ... next to an emissive face of a mesh with per-face materials and an emissive cube (file order decides who is picked)
+    sa = gpu.Scene(os.path.join(SCENES, "mesh_attributes.txt"))
+    _render_both(gpu, oracle, sa, 4, [1, 2], (96, 96), dump_bounces=(4,), direct_lighting=True)
+
+
 def test_face_material_beyond_the_scenes_materials_is_rejected(gpu):
     sc = gpu.Scene(os.path.join(SCENES, "mesh_attributes.txt"))
     bad = dict(sc.mesh_materials)
