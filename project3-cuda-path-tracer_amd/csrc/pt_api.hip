@@ -359,6 +359,10 @@ int persistent_grid(const void *kernel, size_t lds, int *grid) {
     // with batches in flight on neighbouring streams six per launch is better (131.2 G paths/s against 128.9 with eight):
     // the two free wave slots per SIMD go to the neighbouring batch's launches, which fill this launch's tail.
     int cap = R().nslots > 1 ? 6 : 8;
+    // PT_FLAG_TRACE_AHEAD (one call and one small commit per iteration while batches are traced ahead): four, so that the commit -- and the
+    // copies and collectives a caller puts behind it every iteration -- find free wave slots next to two batches' persistent workgroups
+    // instead of waiting for one of them to end (config C3 as written: 0.0538 -> 0.0492 ms per iteration, profiles/r05_c3_experiments.txt)
+    if ((R().flags & PT_FLAG_TRACE_AHEAD) && R().nslots > 1) cap = 4;
     if (const char *e = getenv("PT_AMD_BLOCKS_PER_CU")) cap = atoi(e);   // experiments only
     if (perCU > cap) perCU = cap;
     *grid = prop.multiProcessorCount * perCU;
