@@ -317,6 +317,7 @@ def other_configs(args):
     timed blocks each; what comes back is that run's own line, cut down to the number, its spread, the workload and the roofline."""
     out = {}
     for key, extra, what in OTHER_CONFIGS:
+        extra = [os.path.join(ROOT, a) if a.startswith("scenes/") else a for a in extra]     # (whatever directory the driver runs from)
         cmd = [sys.executable, os.path.abspath(__file__)] + extra + ["--repeats", "3", "--cpu-spp", "0", "--per-iteration-sample", "0",
                                                                       "--configs", "0", "--pmc-key", key, "--pipeline", str(args.pipeline)]
         t0 = time.perf_counter()

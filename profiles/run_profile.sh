@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 # one iteration in flight: a dispatch then owns the GPU, so its duration and counters are the kernel's own
 # (round 4: the step is 64 iterations -- BATCH=32 reproduces the sets of rounds 1-3; the per-iteration reading of config C3 is left out of the
 # profiled command: its thousands of small commit launches would drown the bounce kernels in the trace)
-BENCH="python3 $PWD/bench.py --steps $STEPS --warmup 4 --cpu-spp 0 --pipeline ${PIPELINE:-1} --batch ${BATCH:-64} --per-iteration-sample 0 ${BENCH_ARGS:-}"
+BENCH="python3 $PWD/bench.py --steps $STEPS --warmup 4 --cpu-spp 0 --pipeline ${PIPELINE:-1} --batch ${BATCH:-64} --per-iteration-sample 0 --configs 0 ${BENCH_ARGS:-}"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1 || { echo "trace failed"; tail -5 $OUT/trace.log; exit 1; }
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH > $OUT/pmc_fetch.log 2>&1 || { echo "pmc fetch failed"; tail -5 $OUT/pmc_fetch.log; exit 1; }
