@@ -642,7 +642,7 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     k.directDepth = direct ? traceDepth : 0;
     // the emitters of the direct-lighting bounce, file order: primitives with an emissive material, sampled through their unit cube --
     // and meshes (round 5) whose own or any of whose faces' materials emits, through the object-space bounds of their vertices
-    // (oracle/pt_oracle.cpp: rebuild_emitters, operation for operation)
+    // (the CPU oracle restates this loop operation for operation: its rebuild_emitters)
     k.nEmit = 0;
     for (int i = 0; i < ngeoms && k.nEmit < kEmitMax; ++i) {
         bool emits = mats[geoms[i].materialid].emittance > 0.0f;

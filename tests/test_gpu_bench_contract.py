@@ -84,3 +84,35 @@ def test_bench_json_contract(pt, tmp_path):
     assert cb["cpu_model"] and cb["host_cores"] >= 1 and cb["pinned_to_core"] is not None
     # BASELINE config C1 (sphere.txt 400x400, 1 spp, depth 4) on the CPU, in full
     assert cb["c1"]["value"] > 0 and cb["c1"]["runs"] == 15 and "400x400" in cb["c1"]["config"]
+
+
+def test_driver_command_reports_every_one_gpu_configuration(pt):
+    # round 5: the driver's own command -- `python bench.py` with nothing but --steps / --warmup -- carries, beside
+    # the headline C2 line, a `configs` block: C4, C5 on one of its eight GPUs and the mesh scene, each measured by a child bench.py of its
+    # own and each with a roofline priced against the bound SURVEY 8d names (C5: the vector units)
+    if pt.device_count() < 1:
+        pytest.fail("no HIP device: GPU tests must run on the MI355X box")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["steps"] == 4 and d["warmup"] == 2 and "cpu_baseline" in d and "roofline" in d
+    cf = d["configs"]
+    assert sorted(cf) == ["c4", "c5_one_gpu", "mesh"]
+    for k, v in cf.items():
+        assert "error" not in v, (k, v)
+        assert v["unit"] == "Mpaths/s" and v["value"] > 1000.0 and v["value_min"] <= v["value"] <= v["value_max"]
+        assert v["roofline"]["launches"] > 0 and v["roofline"]["avg_launch_ms"] > 0
+    assert "cornell_glass.txt 1920x1080, 16 bounces" in cf["c4"]["workload"] and cf["c4"]["roofline"]["bound"] == "hbm"
+    assert "spheres64.txt 4096x4096, 8 bounces, 16 spp per step" in cf["c5_one_gpu"]["workload"]
+    assert "cornell_mesh.txt 1280x720" in cf["mesh"]["workload"] and cf["mesh"]["roofline"]["bound"] == "hbm"
+    rf = cf["c5_one_gpu"]["roofline"]
+    assert rf["bound"] == "valu_fp32" and rf["unit"] == "TFLOP/s" and rf["peak"] == 157.3
+    # (the committed counters of that very configuration: profiles/pmc_configs.json)
+    assert rf["frac"] is not None and 0.3 < rf["frac"] < 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert rf["hbm"]["unit"] == "GB/s" and 0 < rf["hbm"]["frac"] < 1
+    for k in ("c4", "mesh"):
+        assert cf[k]["roofline"]["traffic"] is not None and 0.9 < cf[k]["roofline"]["traffic_over_algorithmic"] < 1.6
+    # a run that is about ONE configuration carries no block
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-spp", "0", "--per-iteration-sample", "0",
+                        "--repeats", "2"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "configs" not in json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
