@@ -87,6 +87,11 @@ enum {
                                     discard as well (the reference's camera-move restart, src/main.cpp:91-95).  Needs max_batch > 1
                                     to have any effect.  PtCounters: `iterations` counts committed iterations; live / light_hits /
                                     misses also cover the iterations traced ahead. */
+    PT_FLAG_MIXTURE_WEIGHTED = 16,/* A material with REFL > 0 scatters 50 / 50 between the mirror and the diffuse lobe.  The reference's comment asks
+                                    for "a 50/50 split ... divided by the probability" (src/interactions.h:54-58); the build's default
+                                    takes SURVEY S6's energy-conserving reading WITHOUT the 1 / p weight, because that is what the
+                                    staff render shows (the weighted form is 1.32 x on Cornell's back wall).  This flag renders the
+                                    documented reading: the branch taken carries its weight 2 (the oracle's mirror mode 1). */
     PT_FLAG_DIRECT_LIGHTING = 4  /* README.md:107-108: "a final ray directly to a random point on an emissive object": at the
                                     last of the traceDepth bounces a diffuse scatter aims at a uniformly chosen point of a
                                     uniformly chosen emissive primitive (cosine-weighted), and ONE more bounce collects what

@@ -44,6 +44,7 @@ PT_FLAG_KERNEL_TIMING = 1
 PT_FLAG_ACCUM_SHARD_ROWS = 2
 PT_FLAG_DIRECT_LIGHTING = 4
 PT_FLAG_TRACE_AHEAD = 8
+PT_FLAG_MIXTURE_WEIGHTED = 16
 
 # second link target of the same source: + the test-only entry points of include/pt_amd_test.h (tests/ and profiles/ only)
 TEST_LIB_PATH = os.path.join(HERE, "csrc", "libpt_amd_test.so")
@@ -320,7 +321,8 @@ _scene = None
 
 
 def pathtraceInit(scene, shard_rank=0, shard_count=1, stream=0, accum_dev=0, device=-1, flags=0, traceDepth=None,
-                  pipeline_depth=0, max_batch=0, lens_radius=0.0, focal_distance=0.0, direct_lighting=False, trace_ahead=False):
+                  pipeline_depth=0, max_batch=0, lens_radius=0.0, focal_distance=0.0, direct_lighting=False, trace_ahead=False,
+                  mixture_weighted=False):
     """reference src/pathtrace.cu:75-85.  `scene` is borrowed until pathtraceFree().
     lens_radius / focal_distance / direct_lighting: the README extras (depth of field, direct lighting), off by default.
     trace_ahead: PT_FLAG_TRACE_AHEAD -- pathtrace(pbo, frame, iter) called once per iteration draws on batches of max_batch
@@ -330,6 +332,8 @@ def pathtraceInit(scene, shard_rank=0, shard_count=1, stream=0, accum_dev=0, dev
         flags |= PT_FLAG_DIRECT_LIGHTING
     if trace_ahead:
         flags |= PT_FLAG_TRACE_AHEAD
+    if mixture_weighted:        # the REFL > 0 mixture with its 1 / p weights (src/interactions.h:54-58 to the letter; default: without)
+        flags |= PT_FLAG_MIXTURE_WEIGHTED
     opt = PtOptions(shard_rank, shard_count, device, flags, pipeline_depth, max_batch, stream or None, accum_dev or None,
                     lens_radius, focal_distance)
     geoms = np.ascontiguousarray(scene.geoms)

@@ -239,7 +239,7 @@ int launch_bounce(Slot &sl, int iter, int batch, int depth, bool lastBounce, flo
     ba.tile.skipNonCandidates = (lastBounce && R().prm.emittersBinned) ? 1u : 0u;
     ba.tile.hot = (lastBounce ? kHotLast : 0u) | (R().prm.allClassified ? kHotAllClassified : 0u) | (contrib ? kHotContrib : 0u) |
                   ((R().prm.directDepth != 0 && depth == R().prm.directDepth && R().prm.nEmit > 0) ? kHotToLight : 0u) |
-                  (R().prm.contribLocal ? kHotContribLocal : 0u) | ((uint32_t)R().prm.nWalls << 8) | ((uint32_t)R().prm.nSlotWalls << 11) |
+                  (R().prm.contribLocal ? kHotContribLocal : 0u) | ((R().flags & PT_FLAG_MIXTURE_WEIGHTED) ? kHotMixWeighted : 0u) | ((uint32_t)R().prm.nWalls << 8) | ((uint32_t)R().prm.nSlotWalls << 11) |
                   ((uint32_t)R().prm.nBinned << 14) | ((uint32_t)R().prm.nmats << 20);
     // sphere clusters: the queue that ENTERS the last bounce carries other candidate bits (k_bounce: kHotWritesLastBits) -- that launch only asks
     // whether a path ends on an emitter, and with every emitter binned it visits the tiles of the binned primitives' candidates alone
@@ -674,7 +674,7 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     }
     R().dof = o.lens_radius > 0.0f;
     // plain: nothing in the scene takes the scatter's rarer branches (PT_AMD_NO_PLAIN: experiments / tests only)
-    R().plain = !direct && !(getenv("PT_AMD_NO_PLAIN") && atoi(getenv("PT_AMD_NO_PLAIN")));
+    R().plain = !direct && !(o.flags & PT_FLAG_MIXTURE_WEIGHTED) && !(getenv("PT_AMD_NO_PLAIN") && atoi(getenv("PT_AMD_NO_PLAIN")));
     for (int i = 0; i < nmats; ++i)
         if (mats[i].hasRefractive > 0.0f || (mats[i].hasReflective > 0.0f && mats[i].specularExponent > 0.0f)) R().plain = false;
 

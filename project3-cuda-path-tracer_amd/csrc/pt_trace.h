@@ -344,6 +344,8 @@ constexpr uint32_t kHotLast = 1u, kHotAllClassified = 2u, kHotContrib = 4u, kHot
 // a binned primitive's candidate, bit 4 = a candidate of EITHER cluster (a tile with it sweeps all the spheres: they may stand in front of
 // the emitter).  kHotWritesLastBits: the launch that fills that queue; kHotReadsLastBits: the launch that reads it.
 constexpr uint32_t kHotWritesLastBits = 32u, kHotReadsLastBits = 64u;
+// PT_FLAG_MIXTURE_WEIGHTED: a REFL > 0 material's branch carries its 1 / p weight (src/interactions.h:54-58 read to the letter)
+constexpr uint32_t kHotMixWeighted = 128u;
 __host__ __device__ constexpr uint32_t hotWalls(uint32_t h) { return (h >> 8) & 7u; }
 __host__ __device__ constexpr uint32_t hotSlotWalls(uint32_t h) { return (h >> 11) & 7u; }
 __host__ __device__ constexpr uint32_t hotBinned(uint32_t h) { return (h >> 14) & 7u; }
@@ -1247,6 +1249,9 @@ __global__ __launch_bounds__(kBlock, (MANY && CUBES) ? 4 : (MESH ? (MANY ? 4 : (
                             col = col * mcol;
                         }
                     } else if (mRefl > 0.0f) {
+                        // (the documented variant: 50 / 50 "divided by the probability" -- x 2 whichever branch is taken; exact, so it
+                        // commutes with the colour products below.  Off by default: see PT_FLAG_MIXTURE_WEIGHTED)
+                        if (!PLAIN && (hotNow() & kHotMixWeighted)) col = col * 2.0f;
                         const float u = u01(rng);
                         if (u < 0.5f) {
                             ndir = reflect(dir, N);

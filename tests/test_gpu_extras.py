@@ -132,3 +132,27 @@ def test_headless_driver_with_extras(gpu, oracle, tmp_path):
                             "--out", base, "--lens", "0.3", "12", "--direct"] + extra, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
         assert np.array_equal(_decode_png(base + ".png"), want)
+
+
+def test_documented_mixture_variant_matches_the_oracle(gpu, oracle):
+    # `src/interactions.h:54-58` asks for the 50 / 50 mirror / diffuse split of a REFL > 0 material "divided by the
+    # probability"; the build's default is SURVEY S6's reading without the 1 / p weight (it matches the staff render).  The documented
+    # reading is now a product switch (PT_FLAG_MIXTURE_WEIGHTED): bit-identical to the oracle's mirror mode 1, and brighter than the default
+    sc = gpu.Scene(os.path.join(SCENES, "cornell.txt"))
+    sc.set_resolution(160, 120)
+    W, H = 160, 120
+    frames = {}
+    for weighted in (False, True):
+        ref = oracle.Renderer(sc.camera.view(oracle.CAMERA_DTYPE), sc.geoms.view(oracle.GEOM_DTYPE), sc.materials.view(oracle.MATERIAL_DTYPE), 8)
+        ref.set_variant(mirror_mode=1 if weighted else 0)
+        want = np.zeros(W * H * 3, np.float32)
+        for it in (1, 2, 3, 4):
+            ref.iterate(it, want)
+        gpu.pathtraceFree()
+        gpu.pathtraceInit(sc, max_batch=4, mixture_weighted=weighted)
+        gpu.pathtrace_batch(None, 0, 1, 4)
+        got = gpu.readback(W * H)
+        gpu.pathtraceFree()
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), weighted
+        frames[weighted] = got
+    assert frames[True].sum() > frames[False].sum()
