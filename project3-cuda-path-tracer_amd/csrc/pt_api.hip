@@ -31,6 +31,7 @@
 #include "../../include/pt_amd.h"
 #include "pt_compaction.h"
 #include "pt_trace.h"
+#include "pt_mesh_walk.h"
 #include "pt_mesh.h"
 // The entry points of include/pt_amd_test.h (device primitives one by one, soundness sweeps, the fault-word hook) exist only in
 // the second link target of this source, libpt_amd_test.so (-DPT_TEST_API): the product library exports none of them.
@@ -80,6 +81,7 @@ struct Slot {
     Ctrl *ctrl = nullptr;
     float *contrib = nullptr;      // maxBatch x W*H*3, zero between batches
     uint32_t *hitMask = nullptr;   // ceil(maxBatch / 32) x W*H: which iterations of the batch wrote a pixel's `contrib`, zero between batches
+    unsigned long long *meshHit = nullptr;   // scenes with meshes: the walks' result per path of the bounce being launched (BounceArgs::meshHit)
     hipEvent_t evDone = nullptr;       // all bounce launches of the slot's current iteration finished
     hipEvent_t evCommitted = nullptr;  // k_commit consumed (and re-zeroed) `contrib`
     int parity = 0;                // which half of Ctrl::cursor the slot's next batch uses
@@ -108,6 +110,11 @@ struct State {
     int *dClassIdx = nullptr;       // later bounces: per queue class, the primitives to look at (KParams::classOff)
     float4 *dMeshRecs = nullptr;    // ptd::MeshUnit[]: triangles and inner nodes of every mesh of the scene (k_bounce<., ., ., true>)
     bool mesh = false;      // the scene holds triangle meshes: the k_bounce<., false, ., true> variants
+    // ... whose walks run ahead of every bounce launch (k_mesh_walk): the meshes alone per queue class / in all / per image row
+    int *dWalkIdx = nullptr, *dWalkRowOff = nullptr;
+    int walkClassOff[kClsMax + 1] = {0}, walkAll0 = 0, walkAll1 = 0;
+    int gridWalk = 0, gridWalkFirst = 0;
+    size_t ldsWalk = 0;
     int numTilesMax = 0;    // upper bound of tiles in one bounce queue (incl. one partial tile per segment)
     int poolChunks = 0;     // chunks per path pool (incl. the trash chunk 0); a pool holds poolChunks * kChunk paths per array
     int grid = 0;           // persistent grid of k_bounce<false>
@@ -214,6 +221,11 @@ const void *bounce_kernel(bool first, bool dof) {
     return R().many ? kb<false, true, false, false>() : kb<false, false, false, false>();
 }
 
+const void *walk_kernel(bool first, bool dof) {
+    if (first) return dof ? reinterpret_cast<const void *>(k_mesh_walk<true, true>) : reinterpret_cast<const void *>(k_mesh_walk<true, false>);
+    return reinterpret_cast<const void *>(k_mesh_walk<false, false>);
+}
+
 int launch_bounce(Slot &sl, int iter, int batch, int depth, bool lastBounce, float *contrib, bool nextIsLast = false) {
     const PathPool in = pool(sl, (depth - 1) & 1);
     const PathPool out = pool(sl, depth & 1);
@@ -252,8 +264,14 @@ int launch_bounce(Slot &sl, int iter, int batch, int depth, bool lastBounce, flo
     ba.walls = R().dwalls;
     ba.meshRecs = R().dMeshRecs;
     ba.hostFault = R().hostFaultDev;
+    ba.meshHit = sl.meshHit; ba.walkIdx = R().dWalkIdx; ba.walkRowOff = R().dWalkRowOff;
+    memcpy(ba.walkClassOff, R().walkClassOff, sizeof ba.walkClassOff);
+    ba.walkAll0 = R().walkAll0; ba.walkAll1 = R().walkAll1;
     void *kargs[] = {&ba};
     const bool first = depth == 1;
+    // scenes with meshes: the walks of this bounce's rays, ahead of it (pt_mesh_walk.h)
+    if (R().mesh)
+        HIPCHECK(hipLaunchKernel(walk_kernel(first, first && R().dof), dim3(first ? R().gridWalkFirst : R().gridWalk), dim3(kBlock), kargs, R().ldsWalk, sl.stream));
     HIPCHECK(hipLaunchKernel(bounce_kernel(first, first && R().dof), dim3(first ? R().gridFirst : R().grid), dim3(kBlock), kargs, first ? R().ldsBytes : R().ldsBytesNext, sl.stream));
     if (e0) {
         HIPCHECK(hipEventRecord(e1, sl.stream));
@@ -510,6 +528,7 @@ void free_renderer() {
         if (sl.ctrl) (void)hipFree(sl.ctrl);
         if (sl.contrib) (void)hipFree(sl.contrib);
         if (sl.hitMask) (void)hipFree(sl.hitMask);
+        if (sl.meshHit) (void)hipFree(sl.meshHit);
         if (sl.evDone) (void)hipEventDestroy(sl.evDone);
         if (sl.evCommitted) (void)hipEventDestroy(sl.evCommitted);
         if (sl.stream) (void)hipStreamDestroy(sl.stream);
@@ -526,6 +545,8 @@ void free_renderer() {
     if (R().dRowOff) (void)hipFree(R().dRowOff);
     if (R().dRowIdx) (void)hipFree(R().dRowIdx);
     if (R().dMeshRecs) (void)hipFree(R().dMeshRecs);
+    if (R().dWalkIdx) (void)hipFree(R().dWalkIdx);
+    if (R().dWalkRowOff) (void)hipFree(R().dWalkRowOff);
     {   // (the registered meshes outlive the renderer: see State::meshes)
         std::vector<ptm::HostMesh> keep = std::move(R().meshes);
         R() = State();
@@ -726,13 +747,18 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     }
     k.poolChunks = R().poolChunks;
     const size_t cap = (size_t)R().poolChunks << k.chunkShift;
+    // scenes with meshes: a record per path of a bounce's input queue (camera rays: per pixel of the tiles' padded index space) -- BounceArgs::meshHit
+    bool anyMesh = false;
+    for (int i = 0; i < ngeoms; ++i) anyMesh = anyMesh || geoms[i].type == PT_MESH;
+    const size_t meshHitWords = anyMesh ? std::max(cap, (size_t)k.nLocalPad * (size_t)R().maxBatch) : 0;
     // Iterations are independent (RNG keyed on pixel/iteration/depth), so up to `nslots` of them are in flight
     // on their own streams; the small late-bounce launches of one overlap the big early launches of the next.
     R().nslots = o.pipeline_depth > 0 ? o.pipeline_depth : 3;
     {   // the memory budget BEFORE the first large allocation: a batch that does not fit fails here, with nothing to undo
         const size_t cpx = k.contribLocal ? (size_t)(R().nLocal > 0 ? R().nLocal : 1) : (size_t)R().P;
         const size_t perSlot = 2 * (cap * kNumArrays * sizeof(float) + (size_t)kSeg * R().poolChunks * sizeof(unsigned long long)) + sizeof(Ctrl) +
-                               (size_t)R().maxBatch * cpx * 3 * sizeof(float) + (size_t)((R().maxBatch + 31) / 32) * cpx * sizeof(uint32_t);
+                               (size_t)R().maxBatch * cpx * 3 * sizeof(float) + (size_t)((R().maxBatch + 31) / 32) * cpx * sizeof(uint32_t) +
+                               meshHitWords * sizeof(unsigned long long);
         const size_t need = perSlot * (size_t)R().nslots;
         size_t freeB = 0, totalB = 0;
         HIPCHECK(hipMemGetInfo(&freeB, &totalB));
@@ -757,6 +783,7 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
         HIPCHECK(hipMemset(sl.contrib, 0, (size_t)R().maxBatch * cpx * 3 * sizeof(float)));
         HIPCHECK(hipMalloc(&sl.hitMask, (size_t)((R().maxBatch + 31) / 32) * cpx * sizeof(uint32_t)));
         HIPCHECK(hipMemset(sl.hitMask, 0, (size_t)((R().maxBatch + 31) / 32) * cpx * sizeof(uint32_t)));
+        if (meshHitWords) HIPCHECK(hipMalloc(&sl.meshHit, meshHitWords * sizeof(unsigned long long)));
         HIPCHECK(hipEventCreateWithFlags(&sl.evDone, hipEventDisableTiming));
         HIPCHECK(hipEventCreateWithFlags(&sl.evCommitted, hipEventDisableTiming));
     }
@@ -774,6 +801,7 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
         const bool isMesh = geoms[i].type == PT_MESH;
         if (isMesh) boxes[i] = box;
         uint32_t root = ptd::kMeshEnd, stride = 0;
+        const uint32_t unit0 = (uint32_t)meshRecs.size();        // (the mesh's units: its triangles -- and normals -- lie in [unit0, root))
         if (isMesh) {
             const ptm::HostMesh *hm_ = mesh_of(i);
             for (int fm : hm_->mats)
@@ -787,7 +815,7 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
         }
         pack_geom(geoms[i], hg[i], k.pos, isMesh ? box : nullptr);
         hg[i].meshRoot = root;
-        if (isMesh) hg[i].meshStride = stride;
+        if (isMesh) { hg[i].meshStride = stride; hg[i].meshUnit0 = unit0; hg[i].meshUnit1 = root; }
         if (geoms[i].type == PT_CUBE) {
             if (k.nCubes >= 32767) return fail(PT_ERR_INVALID, "pt_init: more than 32767 cubes");
             hg[i].frameSlot = (short)k.nCubes++;
@@ -1060,6 +1088,34 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
             HIPCHECK(hipMalloc(&R().dRowIdx, cc.rowIdx.size() * sizeof(int)));
             HIPCHECK(hipMemcpy(R().dRowIdx, cc.rowIdx.data(), cc.rowIdx.size() * sizeof(int), hipMemcpyHostToDevice));
         }
+        if (!meshRecs.empty()) {
+            // the mesh walks (k_mesh_walk) look at the meshes alone: the classes' lists, one list of all, the rows' lists (pairs as rowIdx's)
+            std::vector<int> w;
+            for (int c = 0; c < kClsMax; ++c) {
+                R().walkClassOff[c] = (int)w.size();
+                for (int e = k.classOff[c]; e < (c + 1 < kClsMax ? k.classOff[c + 1] : (int)idx.size()); ++e)
+                    if (hg[idx[e]].flags & 32) w.push_back(idx[e]);
+            }
+            R().walkClassOff[kClsMax] = (int)w.size();
+            R().walkAll0 = (int)w.size();
+            for (int i = 0; i < ngeoms; ++i)
+                if (hg[i].flags & 32) w.push_back(i);
+            R().walkAll1 = (int)w.size();
+            if (!cc.rowOff.empty()) {
+                if (w.size() % 2) w.push_back(0);                  // (the rows' entries are pairs: offsets count pairs from the array's start)
+                std::vector<int> ro(cc.rowOff.size());
+                for (size_t y = 0; y + 1 < cc.rowOff.size(); ++y) {
+                    ro[y] = (int)(w.size() / 2);
+                    for (int e = cc.rowOff[y]; e < cc.rowOff[y + 1]; ++e)
+                        if (hg[cc.rowIdx[2 * e]].flags & 32) { w.push_back(cc.rowIdx[2 * e]); w.push_back(cc.rowIdx[2 * e + 1]); }
+                }
+                ro[cc.rowOff.size() - 1] = (int)(w.size() / 2);
+                HIPCHECK(hipMalloc(&R().dWalkRowOff, ro.size() * sizeof(int)));
+                HIPCHECK(hipMemcpy(R().dWalkRowOff, ro.data(), ro.size() * sizeof(int), hipMemcpyHostToDevice));
+            }
+            HIPCHECK(hipMalloc(&R().dWalkIdx, w.size() * sizeof(int)));
+            HIPCHECK(hipMemcpy(R().dWalkIdx, w.data(), w.size() * sizeof(int), hipMemcpyHostToDevice));
+        }
         if (idx.empty()) idx.push_back(0);
         HIPCHECK(hipMalloc(&R().dClassIdx, idx.size() * sizeof(int)));
         HIPCHECK(hipMemcpy(R().dClassIdx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -1075,10 +1131,10 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     k.pairOff = (int)(ldsFixed + sphMapBytes);
     R().ldsBytes = ldsFixed + (R().many ? std::max((size_t)kListMax * kBlock * sizeof(uint16_t), sphMapBytes + pairBytes) : 0);
     R().ldsBytesNext = (R().many && !R().mesh) ? ldsFixed + sphMapBytes + pairBytes : 0;
-    if (R().mesh) {        // the lanes' stacks of far children (ptd::meshIntersectionTest): kBlock words per level, behind everything else
-        R().ldsBytes = (R().ldsBytes + 15) / 16 * 16;
-        k.meshStackOff = (int)R().ldsBytes;
-        R().ldsBytes += (size_t)std::max(meshStackNeed, 1) * kBlock * sizeof(uint32_t);
+    k.meshStackOff = 0;
+    if (R().mesh) {        // (the lanes' stacks of far children belong to the walk's own launches: k_mesh_walk)
+        R().ldsWalk = walkLdsBytes(meshStackNeed);
+        if (R().ldsWalk > 160 * 1024) return fail(PT_ERR_INVALID, "pt_init: a mesh's hierarchy needs %d stack levels (%zu B of LDS)", meshStackNeed, R().ldsWalk);
     }
     if (R().ldsBytesNext == 0) R().ldsBytesNext = R().ldsBytes;
     if (R().ldsBytes > 160 * 1024) return fail(PT_ERR_INVALID, "pt_init: scene does not fit the 160 KiB LDS (%zu B)", R().ldsBytes);
@@ -1089,6 +1145,21 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
         HIPCHECK(hipFuncSetAttribute(kFirst, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R().ldsBytes));
         HIPCHECK(hipFuncSetAttribute(kNext, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R().ldsBytes));
     }
+    if (R().mesh)
+        for (int first = 0; first < 2; ++first) {
+            const void *kw = walk_kernel(first != 0, first && R().dof);
+            if (R().ldsWalk > 64 * 1024) HIPCHECK(hipFuncSetAttribute(kw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R().ldsWalk));
+            int dev = 0, perCU = 0;
+            HIPCHECK(hipGetDevice(&dev));
+            hipDeviceProp_t prop;
+            HIPCHECK(hipGetDeviceProperties(&prop, dev));
+            HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kw, kBlock, R().ldsWalk));
+            if (perCU < 1) perCU = 1;
+            if (const char *e = getenv("PT_AMD_WALK_BLOCKS_PER_CU")) perCU = std::max(1, atoi(e));   // experiments only
+            int &grid = first ? R().gridWalkFirst : R().gridWalk;
+            grid = prop.multiProcessorCount * perCU;
+            if (const char *e = getenv("PT_AMD_MAX_GRID")) grid = std::max(1, std::min(grid, atoi(e)));
+        }
     for (int first = 0; first < 2; ++first) {
         int &grid = first ? R().gridFirst : R().grid;
         int rc = persistent_grid(first ? kFirst : kNext, first ? R().ldsBytes : R().ldsBytesNext, &grid);

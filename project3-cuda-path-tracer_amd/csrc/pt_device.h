@@ -137,7 +137,10 @@ struct GeomDev {
     // with the operations the kernels would issue per hit
     union {
         float cubeFrame[54];
-        uint32_t meshStride;   // a mesh: nodes per copy of its hierarchy; the copy for direction octant k starts at meshRoot + k * meshStride
+        struct {
+            uint32_t meshStride;   // a mesh: nodes per copy of its hierarchy; the copy for direction octant k starts at meshRoot + k * meshStride
+            uint32_t meshUnit0, meshUnit1;   // ... and the units of the scene's record array that hold its triangles: [meshUnit0, meshUnit1)
+        };
     };
     // 1: a small primitive the queue is binned by (KParams::binGeom): tiles of paths that certainly miss all of them
     // skip it (mirrored in flags)
@@ -919,6 +922,42 @@ __device__ __forceinline__ float meshIntersectionTest(const GD &g, const float4 
     P = mulMV(g.xf, obj, 1.0f);
     nsrc = nobj;         // normal = +-normalize(invTranspose * (nobj, 0)): hitNormal(), evaluated for the nearest hit only
     outside = bestFront != 0u;
+    return length(ro_w - P);
+}
+
+// What a walk's WINNER -- triangle record `best` -- means for the ray: the outputs of meshIntersectionTest, from the triangle alone.  The
+// render kernels' walks run ahead of the bounce, in a kernel of their own (pt_mesh_walk.h), and leave the winner's unit per path; the bounce
+// evaluates it here: t, and (u, v) for the vertex normals, are the triangle test's, evaluated once more (same operands, same bits).
+template <bool CAM_ORIGIN = false, typename GD>
+__device__ __forceinline__ float meshWinner(const GD &g, const float4 *recs, uint32_t best, bool front, F3 ro_w, F3 rd_w, F3 &P, F3 &nsrc,
+                                            bool &outside, int &faceMat) {
+    const F3 ro = CAM_ORIGIN ? f3(g.camObj[0], g.camObj[1], g.camObj[2]) : mulMV(g.inv, ro_w, 1.0f);
+    const F3 rd = normalize(mulMV0(g.inv, g.invZ, rd_w));
+    const float4 a = recs[(size_t)best], b = recs[(size_t)best + 1], c = recs[(size_t)best + 2];
+    const F3 w0 = f3(a.x, a.y, a.z);
+    const F3 e1 = f3(a.w, b.x, b.y) - w0, e2 = f3(b.z, b.w, c.x) - w0;
+    const F3 nface = cross(e1, e2);
+    F3 nobj = normalize(nface);
+    faceMat = (int)__float_as_uint(c.z);
+    const uint32_t nref = __float_as_uint(c.w);
+    const F3 p = cross(rd, e2);
+    const float f = 1.0f / dot(e1, p);
+    const F3 sv = ro - w0;
+    const F3 q = cross(sv, e1);
+    const float tbest = f * dot(e2, q);
+    if (nref != 0u) {
+        const float u = f * dot(sv, p);
+        const float v = f * dot(rd, q);
+        const float4 n0 = recs[(size_t)nref], n1 = recs[(size_t)nref + 1], n2 = recs[(size_t)nref + 2];
+        const float w = (1.0f - u) - v;
+        F3 ns = (f3(n0.x, n0.y, n0.z) * w + f3(n0.w, n1.x, n1.y) * u) + f3(n1.z, n1.w, n2.x) * v;
+        if (dot(ns, nface) < 0.0f) ns = -ns;
+        if (dot(ns, ns) > 0.0f) nobj = normalize(ns);
+    }
+    const F3 obj = getPointOnRay(ro, rd, tbest);
+    P = mulMV(g.xf, obj, 1.0f);
+    nsrc = nobj;
+    outside = front;
     return length(ro_w - P);
 }
 

@@ -1,0 +1,344 @@
+// pt_mesh_walk.h -- the walks of the triangle meshes' hierarchies, AHEAD of the bounce that uses their results (round 5).
+// Header-only part of the single translation unit pt_api.hip (namespace ptk).
+//
+// Rounds 2-4 walked a mesh inside k_bounce's loop over a tile's primitives, every lane its own ray.  The walks of a wave are of very
+// unequal length -- on scenes/cornell_mesh.txt a ray takes 13 inner steps on average, the longest of a wave's 53 rays 69 -- and a wave
+// steps until its last lane is through: ten lanes of 64 were at work in an average step (profiles/r05_mesh_probe.txt), and a tile cannot
+// take new rays in, because everything behind the walk (shading, scatter, compaction) needs the whole tile's hits.  Handing parts of a
+// long walk to the wave's idle lanes was built and measured (bit-identical, 2 % slower: the rounds of a walk are as long as before).
+//
+// So the walks left the tile.  k_mesh_walk runs BEFORE the bounce launch over the same queue: persistent WAVES, each on its own, draw
+// tiles (tickets), test the tile's rays against the bounding balls of the meshes its class lists (the camera-ray bounce: its row's),
+// and queue a JOB (path, mesh) in LDS for every ray that may hit; a lane that is through with a walk takes the next job, whatever
+// tile it came from.  A job's result is folded into the path's record with one 64-bit atomic minimum,
+//     meshHit[path] = bits of the world distance << 32 | winning triangle's unit << 1 | front side        (all ones: no mesh is hit),
+// which IS the rule of the bounce's loop over the meshes -- nearest first, of two equally near the one earlier in the list: the lists
+// are in file order, and so are the meshes' units in the record array.  The bounce then evaluates the winner alone (ptd::meshWinner).
+// Same rays, same tests (ptd::meshPlanesPass / meshBoxPass / meshTriangle), same winner: the frame is the one of rounds 2-4, bit for bit.
+#pragma once
+#include "pt_trace.h"
+
+namespace ptk {
+
+constexpr int kWalkQueue = 128;          // jobs a wave holds at most (8 bytes each)
+#ifndef PT_WALK_IDLE_MIN
+#define PT_WALK_IDLE_MIN 24
+#endif
+#ifndef PT_WALK_LEAF_MIN
+#define PT_WALK_LEAF_MIN 24
+#endif
+constexpr int kWalkIdleMin = PT_WALK_IDLE_MIN;   // idle lanes a wave counts before it hands out jobs (and queues more)
+constexpr int kWalkLeafMin = PT_WALK_LEAF_MIN;   // lanes that hold a triangle before the wave tests triangles
+constexpr int kWalkLdsFixedWords = kSeg + (kSeg + 2) + 2 * kWalkQueue * kWaves;     // segment counts and prefix, the waves' queues
+static_assert((kSeg + kSeg + 2) % 2 == 0, "the queues hold 64-bit jobs");
+// dynamic LDS of a launch: the fixed part, then the lanes' stacks of waiting far children, [levels][kBlock] words
+inline size_t walkLdsBytes(int levels) { return ((size_t)kWalkLdsFixedWords + (size_t)(levels < 1 ? 1 : levels) * kBlock) * sizeof(uint32_t); }
+
+template <bool FIRST, bool DOF>
+__global__ __launch_bounds__(kBlock, 8) void k_mesh_walk(BounceArgs A) {
+    static_assert(FIRST || !DOF, "the lens only concerns the camera rays");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int CLS = kClsMax, SUB = kSeg / CLS;             // (scenes with meshes bin by two candidate bits: 32 classes)
+    uint32_t *const s_segcnt = reinterpret_cast<uint32_t *>(smem);      // [kSeg]   paths per input segment (0: a class that lists no mesh)
+    uint32_t *const s_segpre = s_segcnt + kSeg;                          // [kSeg+2] tile prefix per input segment
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    unsigned long long *const s_queue = reinterpret_cast<unsigned long long *>(s_segpre + kSeg + 2) + wave * kWalkQueue;
+    uint32_t *const stack = reinterpret_cast<uint32_t *>(smem) + kWalkLdsFixedWords + threadIdx.x;
+    const KParams &prm = A.prm;
+    Ctrl *const ctrl = A.ctrl;
+    const int depth = A.depth, parity = A.parity;
+
+    // the tiles of this launch (as k_bounce's prologue counts them), without those of the classes that list no mesh
+    uint32_t numTiles;
+    if (FIRST) {
+        numTiles = (uint32_t)prm.nLocalPad / kBlock * (uint32_t)A.batch;
+    } else {
+        const bool skipNonCand = A.tile.skipNonCandidates != 0u;
+        if (threadIdx.x < 64) {
+            constexpr int kPerLane = (kSeg + 63) / 64;
+            uint32_t cs[kPerLane], ts[kPerLane];
+            uint32_t inc = 0u;
+#pragma unroll
+            for (int q = 0; q < kPerLane; ++q) {
+                const int sgi = (int)threadIdx.x * kPerLane + q;
+                const int cls = sgi / SUB;
+                cs[q] = sgi < kSeg ? ctrl->pos[parity][depth][sgi][0] : 0u;
+                if (sgi >= kSeg || A.walkClassOff[cls + 1] == A.walkClassOff[cls]) cs[q] = 0u;
+                if (skipNonCand && ((uint32_t)cls & 24u) == 0u) cs[q] = 0u;      // (the bounce skips these tiles: k_bounce, kEmitBits)
+                ts[q] = (cs[q] + kBlock - 1) / kBlock;
+                inc += ts[q];
+            }
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t up = __shfl_up(inc, o, 64);
+                if ((int)threadIdx.x >= o) inc += up;
+            }
+            uint32_t run = inc;
+#pragma unroll
+            for (int q = kPerLane - 1; q >= 0; --q) {
+                const int sgi = (int)threadIdx.x * kPerLane + q;
+                if (sgi < kSeg) { s_segcnt[sgi] = cs[q]; s_segpre[sgi + 1] = run; }
+                run -= ts[q];
+            }
+            if (threadIdx.x == 0) s_segpre[0] = 0;
+        }
+        __syncthreads();
+        numTiles = s_segpre[kSeg];
+    }
+    // (re-arm the tickets of the slot's next batch; nobody draws from the other parity's now)
+    if (blockIdx.x == 0 && threadIdx.x < kTicketShards) ctrl->walkTicket[parity ^ 1][depth][threadIdx.x][0] = 0u;
+
+    // ---- tickets: wave w of the launch draws the tiles t n + s of shard s = w % n, n = min(kTicketShards, waves), in increasing order
+    const uint32_t nWaves = gridDim.x * kWaves;
+    const uint32_t nShards = nWaves < (uint32_t)kTicketShards ? nWaves : (uint32_t)kTicketShards;
+    const uint32_t shard = (blockIdx.x * kWaves + wave) % nShards;
+    uint32_t *const ticket = &ctrl->walkTicket[parity][depth][shard][0];
+    bool exhausted = false;
+    auto nextTile = [&]() -> uint32_t {
+        uint32_t t = 0u;
+        if (lane == 0) t = atomicAdd(ticket, 1u);
+        const uint32_t T = (uint32_t)__builtin_amdgcn_readfirstlane((int)t) * nShards + shard;
+        return T < numTiles ? T : 0xffffffffu;
+    };
+
+    // ---- the ray of record index i (a path's slot in the input pool; camera rays: i = 256 tile + lane in the padded pixel space)
+    auto fetchRay = [&](uint32_t i, F3 &org, F3 &dir) {
+        if (FIRST) {
+            const uint32_t itb = fastDiv(i, prm.magicN, prm.shiftN);
+            const uint32_t j = i - itb * (uint32_t)prm.nLocalPad;
+            const int lr = (int)fastDiv(j, prm.magicWp, prm.shiftWp);
+            const int sr0 = prm.sceneRect[0];
+            const int x = ((int)j - lr * prm.Wp) + ((sr0 > 0 ? sr0 : 0) & ~(kBlock - 1));
+            const int y = lr * prm.shardCount + prm.firstY0;
+            cameraRayAt(prm, iterationHash(A.iter + (int)itb, 0), x + y * prm.W, x, y, org, dir);
+        } else {
+            const float4 a = *reinterpret_cast<const float4 *>(A.in.arrA(i));
+            const float4 b = *reinterpret_cast<const float4 *>(A.in.arrB(i));
+            org = f3(a.x, a.y, a.z);
+            dir = f3(a.w, b.x, b.y);
+        }
+    };
+
+    // ---- queueing: the tile being turned into jobs -- a QUARTER (this wave's 64 lanes) and a mesh of its list at a time, so that the
+    // queue never has to take more than 64 jobs in one go
+    uint32_t curT = 0xffffffffu, curQ = 0u, curK = 0u;
+    uint32_t qn = 0u;                                           // jobs in the queue
+    auto refill = [&]() {
+        while (qn + 64u <= (uint32_t)kWalkQueue) {
+            probeCount(27, true);
+            if (curT == 0xffffffffu) {
+                if (exhausted) break;
+                curT = nextTile();
+                if (curT == 0xffffffffu) { exhausted = true; break; }
+                curQ = 0u; curK = 0u;
+            }
+            // the quarter's rays and its list of meshes
+            bool valid;
+            uint32_t idx;
+            int px = 0, py = 0;
+            int l0, l1;
+            bool rows = false;
+            if (FIRST) {
+                const uint32_t idx0 = curT * kBlock;
+                const uint32_t itb0 = fastDiv(idx0, prm.magicN, prm.shiftN);
+                const uint32_t j0 = idx0 - itb0 * (uint32_t)prm.nLocalPad;
+                const int lr0 = (int)fastDiv(j0, prm.magicWp, prm.shiftWp);
+                const int sr0 = prm.sceneRect[0], sr1 = prm.sceneRect[1], sr2 = prm.sceneRect[2], sr3 = prm.sceneRect[3];
+                const int x0 = ((int)j0 - lr0 * prm.Wp) + ((sr0 > 0 ? sr0 : 0) & ~(kBlock - 1));
+                const int y0 = lr0 * prm.shardCount + prm.firstY0;
+                if ((y0 < sr1) | (y0 > sr3) | (x0 + (kBlock - 1) < sr0) | (x0 > sr2)) {      // (the bounce skips the tile as a whole)
+                    curT = 0xffffffffu;
+                    continue;
+                }
+                px = x0 + (int)(curQ * 64u + lane);
+                py = y0;
+                idx = idx0 + curQ * 64u + lane;
+                valid = px < prm.W && px >= sr0 && px <= sr2;        // (inScene: the rows were tested above)
+                if (!DOF && A.walkRowOff != nullptr) {
+                    rows = true;
+                    l0 = A.walkRowOff[y0]; l1 = A.walkRowOff[y0 + 1];
+                } else {
+                    l0 = A.walkAll0; l1 = A.walkAll1;
+                }
+            } else {
+                uint32_t cnt = 0u;
+#pragma unroll
+                for (int q = 0; q < kSeg / 64; ++q) cnt += (uint32_t)__popcll(__ballot(s_segpre[1 + 64 * q + lane] <= curT));
+                const uint32_t sg = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt);
+                const uint32_t segFirst = s_segpre[sg];
+                const uint32_t local = (curT - segFirst) * kBlock + curQ * 64u + lane;
+                valid = local < s_segcnt[sg];
+                const uint32_t shift = (uint32_t)prm.chunkShift, poolChunks = (uint32_t)prm.poolChunks;
+                const uint32_t j = ((curT - segFirst) * kBlock) >> shift;
+                uint32_t chunk = 1u + sg;
+                if (j != 0u) {
+                    const unsigned long long e = j < poolChunks ? A.in.list[(size_t)sg * poolChunks + j] : 0ull;
+                    chunk = (uint32_t)(e >> 32) == A.genIn ? (uint32_t)e : 0u;
+                    chunk = chunk < poolChunks ? chunk : 0u;
+                }
+                idx = (chunk << shift) + (local - (j << shift));
+                const uint32_t cls = sg / SUB;
+                l0 = A.walkClassOff[cls]; l1 = A.walkClassOff[cls + 1];
+            }
+            if (l1 - l0 == 0) {                                  // (camera rays: a row no mesh reaches -- the bounce asks for no record)
+                curT = 0xffffffffu;
+                continue;
+            }
+            F3 org = f3(0, 0, 0), dir = f3(0, 0, 1);
+            if (valid) fetchRay(idx, org, dir);
+            if (curK == 0u) {
+                // no mesh is hit, unless a walk says otherwise; the store is COMPLETE before this wave issues an atomic on the word
+                if (FIRST || valid) A.meshHit[idx] = ~0ull;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            const float dd = dot(dir, dir);
+            bool full = false;
+            for (int k = (int)curK; k < l1 - l0; ++k) {
+                if (qn + 64u > (uint32_t)kWalkQueue) {           // (no room for a mesh's worth of jobs: go on from here next time)
+                    curK = (uint32_t)k;
+                    full = true;
+                    break;
+                }
+                int g, span = 0;
+                if (rows) { g = A.walkIdx[2 * (l0 + k)]; span = A.walkIdx[2 * (l0 + k) + 1]; }
+                else g = A.walkIdx[l0 + k];
+                const GeomDev &G = A.ggeoms[g];
+                bool want = valid;
+                if (FIRST && !DOF) {
+                    if (rows) want = want & (px >= (span & 0xffff)) & (px <= (span >> 16));
+                    else want = want & (px >= G.rect[0]) & (px <= G.rect[2]) & (py >= G.rect[1]) & (py <= G.rect[3]);
+                }
+                want = want && !certainMiss(G, org, dir, dd);
+                probeCount(28, want);
+                const unsigned long long b = __ballot(want);
+                if (b != 0ull) {
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+                    if (want) s_queue[qn + rank] = ((unsigned long long)(uint32_t)g << 32) | idx;
+                    qn += (uint32_t)__popcll(b);
+                }
+            }
+            if (full) break;
+            curK = 0u;
+            if (++curQ == 4u) curT = 0xffffffffu;
+        }
+    };
+
+    // ---- the walks: a lane's state
+    constexpr uint32_t kDone = 0xffffffffu;                     // (reads as a triangle's ref: the loop over inner nodes stops on it)
+    bool busy = false, pending = false;                         // pending: through with a job whose result is not folded in yet
+    uint32_t jobIdx = 0u, jobGeom = 0u;
+    F3 ro = f3(0, 0, 0), rd = f3(0, 0, 1), inv = f3(1, 1, 1), rc = f3(0, 0, 0);
+    uint32_t keyT = 0xffffffffu, keyI = 0xffffffffu;            // the best hit so far: bits of t + 0.0f, unit << 1 | front (all ones: none; t then reads as a NaN)
+    uint32_t ref = kDone;
+    uint32_t *sp = stack;
+    auto pop = [&]() -> uint32_t {
+        if (sp == stack) return kDone;
+        sp -= kBlock;
+        return *sp;
+    };
+    const float4 *const recs = A.meshRecs;
+    // ONE loop, three kinds of step; the wave votes on the next one:
+    //   hand-out   when kWalkIdleMin lanes stand idle and there is work to give them (or nobody is at work at all): what the lanes that
+    //              are through have found goes into their paths' records, the queue is topped up, the idle lanes take jobs;
+    //   triangles  when kWalkLeafMin lanes hold one (or no lane holds an inner node): the triangle's own box, then the triangle;
+    //   inner node otherwise: the lanes that hold one test its two children.
+    // (Rounds 3-4 -- and this kernel's first version -- ran "inner nodes until EVERY lane holds a triangle, then the triangles": a round was
+    // as long as the longest descent of its lanes, 13 steps where a lane's own took 4.7 -- profiles/r05_mesh_probe.txt.)
+    for (;;) {
+        const bool atInner = busy && !(ref & kMeshLeaf), atLeaf = busy && (ref & kMeshLeaf) != 0u;
+        const uint32_t nInner = (uint32_t)__popcll(__ballot(atInner)), nLeaf = (uint32_t)__popcll(__ballot(atLeaf));
+        const unsigned long long idleMask = __ballot(!busy);
+        const uint32_t nIdle = (uint32_t)__popcll(idleMask);
+        const bool more = qn != 0u || !exhausted;
+        if ((more && nIdle >= (uint32_t)kWalkIdleMin) || nInner + nLeaf == 0u) {
+            // what the lanes that are through have found: the winner's distance in the world, and into the path's record with it.
+            // (t: the bits of t + 0.0f serve -- a winner at -0 differs from +0 in the signs of zeros of P alone, which the length squares away)
+            probeCount(21, pending);                            // (instrumented build: the walk's wave steps and their lanes)
+            if (pending) {
+                pending = false;
+                if (keyT != 0xffffffffu) {
+                    F3 org, dir;
+                    fetchRay(jobIdx, org, dir);
+                    const GeomDev &G = A.ggeoms[jobGeom];
+                    const F3 P = mulMV(G.xf, getPointOnRay(ro, rd, __uint_as_float(keyT)), 1.0f);
+                    const float t = length(org - P);
+                    if (t > 0.0f)
+                        __hip_atomic_fetch_min(A.meshHit + jobIdx, ((unsigned long long)__float_as_uint(t) << 32) | keyI, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (qn < nIdle) refill();
+            // the idle lanes take the youngest jobs
+            const uint32_t take = nIdle < qn ? nIdle : qn;
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idleMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idleMask, 0u));
+            probeCount(26, !busy && rank < take);
+            if (!busy && rank < take) {
+                const unsigned long long job = s_queue[qn - 1u - rank];
+                jobIdx = (uint32_t)job;
+                jobGeom = (uint32_t)(job >> 32);
+                F3 org, dir;
+                fetchRay(jobIdx, org, dir);
+                const GeomDev &G = A.ggeoms[jobGeom];
+                ro = (FIRST && !DOF) ? f3(G.camObj[0], G.camObj[1], G.camObj[2]) : mulMV(G.inv, org, 1.0f);
+                rd = normalize(mulMV0(G.inv, G.invZ, dir));
+                inv = f3(guardedReciprocal(rd.x), guardedReciprocal(rd.y), guardedReciprocal(rd.z));
+                rc = f3(-(ro.x * inv.x), -(ro.y * inv.y), -(ro.z * inv.z));
+                const uint32_t octant = (__float_as_uint(inv.x) >> 31) | ((__float_as_uint(inv.y) >> 31) << 1) | ((__float_as_uint(inv.z) >> 31) << 2);
+                ref = G.meshRoot + octant * G.meshStride;
+                sp = stack;
+                keyT = keyI = 0xffffffffu;
+                busy = true;
+            }
+            qn -= take;
+            if (take == 0u && nInner + nLeaf == 0u) break;      // (no job left anywhere: the queue is empty and the tiles are drawn)
+        } else if (nLeaf >= (uint32_t)kWalkLeafMin || nInner == 0u) {
+            probeCount(24, atLeaf);
+            if (atLeaf) {
+                const float4 *r = recs + (size_t)(ref & ~kMeshLeaf);
+                const float4 q0 = r[0], q1 = r[1];
+                const float2 q2 = *reinterpret_cast<const float2 *>(r + 2);
+                const F3 v0 = f3(q0.x, q0.y, q0.z), v1 = f3(q0.w, q1.x, q1.y), v2 = f3(q1.z, q1.w, q2.x);
+                const float m = q2.y;
+                // the triangle's box as pt_mesh.h states it: min / max of the vertices, moved outwards by the mesh's margin
+                const F3 lo = f3(__builtin_fminf(__builtin_fminf(v0.x, v1.x), v2.x) - m, __builtin_fminf(__builtin_fminf(v0.y, v1.y), v2.y) - m,
+                                 __builtin_fminf(__builtin_fminf(v0.z, v1.z), v2.z) - m);
+                const F3 hi = f3(__builtin_fmaxf(__builtin_fmaxf(v0.x, v1.x), v2.x) + m, __builtin_fmaxf(__builtin_fmaxf(v0.y, v1.y), v2.y) + m,
+                                 __builtin_fmaxf(__builtin_fmaxf(v0.z, v1.z), v2.z) + m);
+                float tmin;
+                if (meshBoxPass(lo, hi, inv, rc, true, __uint_as_float(keyT), tmin)) {
+                    float t;
+                    bool front;
+                    if (meshTriangle(ro, rd, v0, v1 - v0, v2 - v0, t, front)) {
+                        // (accepted t are >= 0: the order of the bits of t + 0.0f is the order of the values, -0 = +0 included)
+                        const uint32_t kt = __float_as_uint(t + 0.0f), ki = ((ref & ~kMeshLeaf) << 1) | (front ? 1u : 0u);
+                        if ((t >= tmin) & ((kt < keyT) | ((kt == keyT) & (ki < keyI)))) {
+                            keyT = kt;
+                            keyI = ki;
+                        }
+                    }
+                }
+                ref = pop();
+            }
+        } else {
+            probeCount(22, atInner);
+            if (atInner) {
+                const float4 *r = recs + (size_t)ref;
+                const float4 q0 = r[0], q1 = r[1];
+                const float tb = __uint_as_float(keyT);
+                const bool passN = meshPlanesPass(__float_as_uint(q0.x), __float_as_uint(q0.y), __float_as_uint(q0.z), inv, rc, true, tb);
+                const bool passF = meshPlanesPass(__float_as_uint(q1.x), __float_as_uint(q1.y), __float_as_uint(q1.z), inv, rc, true, tb);
+                const uint32_t refN = __float_as_uint(q0.w), refF = __float_as_uint(q1.w);
+                if (passN & passF) {
+                    *sp = refF;
+                    sp += kBlock;
+                }
+                ref = passN ? refN : (passF ? refF : pop());
+            }
+        }
+        if (busy && ref == kDone) {                             // (through with its job: nothing waits on its stack)
+            busy = false;
+            pending = true;
+        }
+    }
+}
+
+}  // namespace ptk

@@ -15,31 +15,6 @@ __device__ __forceinline__ void shardPixel(const KParams &prm, int j, int &pix, 
     y = lr * prm.shardCount + prm.shardRank;
     pix = x + y * prm.W;
 }
-// iterHash0 = iterationHash(iter, 0): camera jitter draws from the depth-0 stream of (iter, pixel)
-__device__ __forceinline__ void cameraRayAt(const KParams &prm, uint32_t iterHash0, int pix, int x, int y, F3 &org, F3 &dir) {
-    Rng rng = makeSeededRandomEngineHashed(iterHash0, pix);
-    const float jx = u01(rng);
-    const float jy = u01(rng);
-    const float sx = ((float)x + jx) - prm.halfW;
-    const float sy = ((float)y + jy) - prm.halfH;
-    const float a = prm.pixLenX * sx;
-    const float b = prm.pixLenY * sy;
-    const F3 view = f3(prm.view[0], prm.view[1], prm.view[2]);
-    const F3 up = f3(prm.up[0], prm.up[1], prm.up[2]);
-    const F3 right = f3(prm.right[0], prm.right[1], prm.right[2]);
-    org = f3(prm.pos[0], prm.pos[1], prm.pos[2]);
-    dir = normalize((view - right * a) - up * b);
-    if (prm.lensRadius > 0.0f) {     // thin lens, as in k_bounce<true, ., true>
-        const float lr = prm.lensRadius * __builtin_sqrtf(u01(rng));
-        const float phi = u01(rng) * kTwoPi;
-        float s, c;
-        sincosPoly(phi, s, c);
-        const float ft = prm.focalDistance / dot(dir, f3(prm.viewN[0], prm.viewN[1], prm.viewN[2]));
-        const F3 focus = org + dir * ft;
-        org = (org + right * (lr * c)) + up * (lr * s);
-        dir = normalize(focus - org);
-    }
-}
 __device__ __forceinline__ void cameraRay(const KParams &prm, int iter, int j, int &pix, int &x, int &y, F3 &org, F3 &dir) {
     shardPixel(prm, j, pix, x, y);
     cameraRayAt(prm, iterationHash(iter, 0), pix, x, y, org, dir);

@@ -61,6 +61,9 @@ struct Ctrl {
     // (sharded: ticket t of shard s = blockIdx % n stands for tile 2 grid + t n + s, n = min(kTicketShards, grid) -- one word for a whole
     // launch's tiles serialised its 20 000 atomics at ~12 ns each, twice the launch's own length)
     uint32_t ticket[2][kMaxDepthSlots][kTicketShards][kCtrPad];
+    // ... and the tiles handed out by the mesh walk that runs ahead of bounce d (k_mesh_walk, pt_mesh_walk.h: all of its tiles are drawn;
+    // the walk of (p, d) zeroes the words of (p ^ 1, d), its slot's next batch)
+    uint32_t walkTicket[2][kMaxDepthSlots][kTicketShards][kCtrPad];
     // never zeroed by an iteration
     uint32_t error;                    // sticky device fault: kFault* bits (pool exhausted, chunk-list poll timeout)
     uint32_t pad[kCtrPad - 1];
@@ -245,6 +248,34 @@ __device__ __forceinline__ uint32_t fastDiv(uint32_t n, uint32_t magic, uint32_t
     return (uint32_t)(((unsigned long long)n * magic) >> shift);
 }
 
+// The camera ray of pixel (x, y) = index pix (spec S2) as k_bounce<true, ...> builds it in place: jitter from the depth-0 stream of
+// (iteration, pixel) -- iterHash0 = iterationHash(iter, 0) --, then the thin lens if the camera has one.  (The mesh walk and the test
+// library's kernels call this; the camera-ray bounce keeps its own inlined copy, whose register allocation is measured.)
+__device__ __forceinline__ void cameraRayAt(const KParams &prm, uint32_t iterHash0, int pix, int x, int y, F3 &org, F3 &dir) {
+    Rng rng = makeSeededRandomEngineHashed(iterHash0, pix);
+    const float jx = u01(rng);
+    const float jy = u01(rng);
+    const float sx = ((float)x + jx) - prm.halfW;
+    const float sy = ((float)y + jy) - prm.halfH;
+    const float a = prm.pixLenX * sx;
+    const float b = prm.pixLenY * sy;
+    const F3 view = f3(prm.view[0], prm.view[1], prm.view[2]);
+    const F3 up = f3(prm.up[0], prm.up[1], prm.up[2]);
+    const F3 right = f3(prm.right[0], prm.right[1], prm.right[2]);
+    org = f3(prm.pos[0], prm.pos[1], prm.pos[2]);
+    dir = normalize((view - right * a) - up * b);
+    if (prm.lensRadius > 0.0f) {     // thin lens, as in k_bounce<true, ., true>
+        const float lr = prm.lensRadius * __builtin_sqrtf(u01(rng));
+        const float phi = u01(rng) * kTwoPi;
+        float s, c;
+        sincosPoly(phi, s, c);
+        const float ft = prm.focalDistance / dot(dir, f3(prm.viewN[0], prm.viewN[1], prm.viewN[2]));
+        const F3 focus = org + dir * ft;
+        org = (org + right * (lr * c)) + up * (lr * s);
+        dir = normalize(focus - org);
+    }
+}
+
 // ---- one bounce: intersect + shade + accumulate + compact (spec S3-S8) -----------------------------
 // Persistent workgroups walk the 256-path tiles of the bounce's queue (the kSeg input segments laid
 // end to end), blockIdx-strided.  Survivors are BINNED BY CLASS while they are compacted:
@@ -371,6 +402,14 @@ struct BounceArgs {
     const int *rowIdx;                  //   rowOff[y] .. rowOff[y + 1] of rowIdx, file order: pairs {primitive, x0 | x1 << 16} = the row's pixels
                                         //   inside the hull of the primitive's projected corners (pt_init); rowOff == nullptr: every primitive
     uint32_t *hostFault;                // the sticky fault word's copy in page-locked host memory (written by a batch's last launch), or nullptr
+    // ---- scenes with meshes: the walks run AHEAD of the bounce (k_mesh_walk) and leave, per path of a tile that lists a mesh, the nearest
+    // mesh hit: meshHit[i] = bits of its distance << 32 | the winning triangle's unit << 1 | front side (all ones: none), i = the path's slot
+    // in the input pool (camera rays: its index in the tiles' padded pixel space)
+    unsigned long long *meshHit;
+    const int *walkIdx;                 // the meshes alone: per queue class (walkClassOff), all of them ([walkAll0, walkAll1)), per image row pairs as rowIdx (walkRowOff)
+    const int *walkRowOff;              // ... nullptr where rowOff is
+    int walkClassOff[kClsMax + 1];
+    int walkAll0, walkAll1;
 };
 typedef const PT_CAS BounceArgs *ArgsPtr;
 typedef const PT_CAS GeomDev *GeomPtr;
@@ -714,6 +753,7 @@ __global__ __launch_bounds__(kBlock, (MANY && CUBES) ? 4 : (MESH ? (MANY ? 4 : (
         PathRegs cur = nextRegs;
         int itb = 0;                                            // which iteration of the batch this path belongs to
         int px = 0, py = 0;                                     // pixel coordinates (FIRST only)
+        uint32_t recIdx0 = 0u;                                  // FIRST, MESH: the tile's first index in the padded pixel space (BounceArgs::meshHit)
         if (FIRST) {
             const ArgsPtr A = launder(kargs);
             const PT_CAS KParams &prm = A->prm;
@@ -729,6 +769,7 @@ __global__ __launch_bounds__(kBlock, (MANY && CUBES) ? 4 : (MESH ? (MANY ? 4 : (
             }
             // the tile's (wave-uniform) position: iteration of the batch, row of the shard, first column -- no per-lane divisions
             const uint32_t idx0 = pixTile * kBlock;
+            if (MESH) recIdx0 = idx0;
             const uint32_t itb0 = fastDiv(idx0, prm.magicN, prm.shiftN);
             const uint32_t j0 = idx0 - itb0 * (uint32_t)prm.nLocalPad;
             const int lr0 = (int)fastDiv(j0, prm.magicWp, prm.shiftWp);
@@ -904,12 +945,13 @@ __global__ __launch_bounds__(kBlock, (MANY && CUBES) ? 4 : (MESH ? (MANY ? 4 : (
                     if (!inRect) {
                         // (not reachable from this pixel: t stays -1)
                     } else if (MESH && (flags & 32) != 0) {
-                        // a triangle mesh: its bounding ball first, then every lane walks the mesh's hierarchy on its own
-                        if (!certainMiss(cg, org, dir, dd)) {
-                            const ArgsPtr A2 = launder(kargs);
-                            uint32_t *const stack = reinterpret_cast<uint32_t *>(smem + A2->prm.meshStackOff) + tid;
-                            t = meshIntersectionTest<FIRST && !DOF, kBlock>(G, A2->meshRecs, G.meshRoot, G.meshStride, stack, org, dir, p, n, o, fm);
-                        }
+                        // a triangle mesh: the walks ran AHEAD of this launch (k_mesh_walk: rays from many tiles side by side, a lane that is
+                        // through with one takes the next), and the path's record names the winning triangle among the meshes its tile lists
+                        const ArgsPtr A2 = launder(kargs);
+                        const unsigned long long rec = A2->meshHit[FIRST ? recIdx0 + tid : nextMeta.idx];
+                        const uint32_t unit = (uint32_t)rec >> 1;
+                        if (rec != ~0ull && unit >= G.meshUnit0 && unit < G.meshUnit1)
+                            t = meshWinner<FIRST && !DOF>(G, A2->meshRecs, unit, ((uint32_t)rec & 1u) != 0u, org, dir, p, n, o, fm);
                     } else if (!PACKED && ((flags & 1) == 0 || (MANY && (flags & 64) != 0))) {    // (PACKED: no swept primitive comes this way)
                         probe(3);
                         // a sphere -- or, in a scene with many small primitives, a small cube (flag bit 6): the bounding ball first;
