@@ -24,7 +24,8 @@ L.pt_probe_read(out)
 v = [int(x) for x in out]
 paths = 32 * 1280 * 720
 print("%s 1280x720 depth 8, 32 iterations = %.1f M camera rays" % (scene, paths / 1e6))
-for k, what in ((21, "results folded in (lanes = finished walks)"), (26, "hand-outs (lanes = jobs taken)"), (22, "inner-node steps"), (24, "triangle steps"), (27, "queueing: quarter-tile visits"),
+for k, what in ((21, "results folded in (lanes = finished walks)"), (26, "hand-outs (lanes = jobs taken)"), (22, "inner-node steps"), (24, "triangle steps"), (29, "loop turns with lanes at an inner node"), (30, "loop turns with lanes at a triangle"),
+                (31, "loop turns with idle lanes"), (23, "loop turns with nothing left to hand out"), (27, "queueing: quarter-tile visits"),
                 (28, "queueing: (quarter, mesh) with jobs (lanes = jobs)"), (7, "tiles of the later bounces (waves)"), (8, "tiles of the camera bounce (waves)")):
     w, l = v[2 * k], v[2 * k + 1]
     print("  %-58s %11d wave executions, %5.1f lanes each (%.2f per camera ray)" % (what, w, l / max(w, 1), l / paths))

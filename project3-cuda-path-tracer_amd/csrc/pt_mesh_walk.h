@@ -27,6 +27,10 @@ constexpr int kWalkQueue = 128;          // jobs a wave holds at most (8 bytes e
 #ifndef PT_WALK_LEAF_MIN
 #define PT_WALK_LEAF_MIN 24
 #endif
+#ifndef PT_WALK_QUARTERS_MIN
+#define PT_WALK_QUARTERS_MIN 8
+#endif
+constexpr int kWalkQuartersMin = PT_WALK_QUARTERS_MIN;   // quarter tiles (64 paths each) per wave of a launch, at least (see the tickets)
 constexpr int kWalkIdleMin = PT_WALK_IDLE_MIN;   // idle lanes a wave counts before it hands out jobs (and queues more)
 constexpr int kWalkLeafMin = PT_WALK_LEAF_MIN;   // lanes that hold a triangle before the wave tests triangles
 constexpr int kWalkLdsFixedWords = kSeg + (kSeg + 2) + 2 * kWalkQueue * kWaves;     // segment counts and prefix, the waves' queues
@@ -88,8 +92,18 @@ __global__ __launch_bounds__(kBlock, 8) void k_mesh_walk(BounceArgs A) {
     // (re-arm the tickets of the slot's next batch; nobody draws from the other parity's now)
     if (blockIdx.x == 0 && threadIdx.x < kTicketShards) ctrl->walkTicket[parity ^ 1][depth][threadIdx.x][0] = 0u;
 
-    // ---- tickets: wave w of the launch draws the tiles t n + s of shard s = w % n, n = min(kTicketShards, waves), in increasing order
-    const uint32_t nWaves = gridDim.x * kWaves;
+    // ---- tickets: wave w of the launch draws the QUARTER tiles t n + s (quarter q of tile T: 4 T + q) of shard s = w % n,
+    // n = min(kTicketShards, waves), in increasing order -- a quarter, ~50 jobs, is a tenth of a wave's share of a late bounce
+    // (a wave wants kWalkQuartersMin quarters or more to its name -- with fewer, most of its time is the tail of its last jobs: the late bounces of
+    // a batch hold a few jobs per LANE of a full grid -- so the waves beyond that many end here; at least one per CU-sized group stays)
+    uint32_t nWaves = gridDim.x * kWaves;
+    {
+        const uint32_t want = 4u * numTiles / (uint32_t)kWalkQuartersMin;
+        const uint32_t floor = nWaves < 256u ? nWaves : 256u;
+        const uint32_t cap = want > floor ? want : floor;
+        if (cap < nWaves) nWaves = cap;
+        if (blockIdx.x * kWaves + wave >= nWaves) return;
+    }
     const uint32_t nShards = nWaves < (uint32_t)kTicketShards ? nWaves : (uint32_t)kTicketShards;
     const uint32_t shard = (blockIdx.x * kWaves + wave) % nShards;
     uint32_t *const ticket = &ctrl->walkTicket[parity][depth][shard][0];
@@ -98,7 +112,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_mesh_walk(BounceArgs A) {
         uint32_t t = 0u;
         if (lane == 0) t = atomicAdd(ticket, 1u);
         const uint32_t T = (uint32_t)__builtin_amdgcn_readfirstlane((int)t) * nShards + shard;
-        return T < numTiles ? T : 0xffffffffu;
+        return T < 4u * numTiles ? T : 0xffffffffu;
     };
 
     // ---- the ray of record index i (a path's slot in the input pool; camera rays: i = 256 tile + lane in the padded pixel space)
@@ -119,8 +133,8 @@ __global__ __launch_bounds__(kBlock, 8) void k_mesh_walk(BounceArgs A) {
         }
     };
 
-    // ---- queueing: the tile being turned into jobs -- a QUARTER (this wave's 64 lanes) and a mesh of its list at a time, so that the
-    // queue never has to take more than 64 jobs in one go
+    // ---- queueing: the quarter tile being turned into jobs, a mesh of its list at a time, so that the queue never has to take more
+    // than 64 jobs in one go
     uint32_t curT = 0xffffffffu, curQ = 0u, curK = 0u;
     uint32_t qn = 0u;                                           // jobs in the queue
     auto refill = [&]() {
@@ -128,9 +142,9 @@ __global__ __launch_bounds__(kBlock, 8) void k_mesh_walk(BounceArgs A) {
             probeCount(27, true);
             if (curT == 0xffffffffu) {
                 if (exhausted) break;
-                curT = nextTile();
-                if (curT == 0xffffffffu) { exhausted = true; break; }
-                curQ = 0u; curK = 0u;
+                const uint32_t t4 = nextTile();
+                if (t4 == 0xffffffffu) { exhausted = true; break; }
+                curT = t4 >> 2; curQ = t4 & 3u; curK = 0u;
             }
             // the quarter's rays and its list of meshes
             bool valid;
@@ -219,7 +233,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_mesh_walk(BounceArgs A) {
             }
             if (full) break;
             curK = 0u;
-            if (++curQ == 4u) curT = 0xffffffffu;
+            curT = 0xffffffffu;
         }
     };
 
@@ -250,6 +264,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_mesh_walk(BounceArgs A) {
         const unsigned long long idleMask = __ballot(!busy);
         const uint32_t nIdle = (uint32_t)__popcll(idleMask);
         const bool more = qn != 0u || !exhausted;
+        probeCount(29, atInner); probeCount(30, atLeaf); probeCount(31, !busy); probeCount(23, !more);
         if ((more && nIdle >= (uint32_t)kWalkIdleMin) || nInner + nLeaf == 0u) {
             // what the lanes that are through have found: the winner's distance in the world, and into the path's record with it.
             // (t: the bits of t + 0.0f serve -- a winner at -0 differs from +0 in the signs of zeros of P alone, which the length squares away)
