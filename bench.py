@@ -721,7 +721,9 @@ def run(args, ctx):
     if rank == 0:
         nominal = P * D * iters_block
         walls = sorted(A["walls"])
-        rf = {"bound": "hbm", "kernel": "k_bounce (fused [camera rays+]intersect+shade+compact, one launch per bounce and batch)",
+        rf = {"bound": "hbm", "kernel": ("k_mesh_walk + k_bounce (the walks of the bounce's rays through the meshes' hierarchies, then the fused bounce: one pair "
+                                         "of launches per bounce and batch, timed together)") if getattr(scene, "meshes", None) else
+                                        "k_bounce (fused [camera rays+]intersect+shade+compact, one launch per bounce and batch)",
               "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
               "frac": round(achieved / HBM_PEAK_GBS, 5),
               "traffic": traffic,

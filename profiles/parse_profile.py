@@ -45,6 +45,8 @@ def inst(name):
 def kind(name):
     if "k_bounce" in name:
         return "k_bounce"
+    if "k_mesh_walk" in name:      # scenes with meshes: the walks of a bounce's rays, launched right before it (round 5)
+        return "k_mesh_walk"
     if "k_generate_rays" in name:
         return "k_generate_rays"
     if "k_commit" in name:
@@ -155,7 +157,12 @@ def main():
         cal["write_factor_16B_per_lane_stores"] = n_scan / (sum(wr16) / len(wr16))
     out["calibration"] = cal
 
-    kb = out.get("k_bounce", {}).get("pmc_per_dispatch", {})
+    kb = dict(out.get("k_bounce", {}).get("pmc_per_dispatch", {}))
+    kw = out.get("k_mesh_walk", {}).get("pmc_per_dispatch", {})
+    if kw:
+        # a "launch" of a mesh scene is the pair bench.py times together (pt_api.hip: launch_bounce): the walk, then the bounce
+        for c, v in kw.items():
+            kb[c] = kb.get(c, 0.0) + v
     if "FETCH_SIZE" in kb and "WRITE_SIZE" in kb:
         rf = cal.get("read_factor_16B_per_lane_loads", cal.get("read_factor", 2.0))
         # snap to the two documented regimes (exact, or the 2x under-count of coalesced streams)
@@ -166,6 +173,8 @@ def main():
         pj = {"hbm_bytes_per_launch": round(traffic, 1), "read_factor_used": rf_used,
               "read_factor_calibrated": rf, "write_factor_calibrated": cal.get("write_factor"),
               "source": "profiles/%s_pmc_summary.json" % args.tag}
+        if kw:
+            pj["launch"] = "k_mesh_walk + k_bounce (counters of the two dispatches added)"
         # which bench configuration the counters belong to: bench.py reports them only for the same one, scaled by the
         # iterations a launch carries (the figures are stored per iteration of a launch's batch)
         ipl = None

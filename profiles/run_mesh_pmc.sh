@@ -26,7 +26,7 @@ f, grp = sys.argv[1], sys.argv[2]
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(set)
 for r in csv.DictReader(open(f)):
     k = r["Kernel_Name"]
-    if "k_bounce" not in k: continue
+    if "k_bounce" not in k and "k_mesh_walk" not in k: continue
     k = k.split("(")[0].replace("void ptk::", "")
     acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[k].add(r["Dispatch_Id"])
 for k in acc:

@@ -12,7 +12,9 @@ def short(name):
     return m.group(1) if m else name[:40]
 
 
-idx = [i for i, r in enumerate(rows) if 'k_bounce<true' in r['Kernel_Name']]
+# (a batch starts with the camera-ray bounce -- in a scene with meshes, with the walks that run ahead of it)
+first = 'k_mesh_walk<true' if any('k_mesh_walk<true' in r['Kernel_Name'] for r in rows) else 'k_bounce<true'
+idx = [i for i, r in enumerate(rows) if first in r['Kernel_Name']]
 i0 = idx[len(idx) // 2]
 n = (idx[len(idx) // 2 + 1] - i0) if len(idx) > len(idx) // 2 + 1 else 10
 prev_end = None

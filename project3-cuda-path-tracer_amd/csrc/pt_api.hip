@@ -1099,8 +1099,13 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
             R().walkClassOff[kClsMax] = (int)w.size();
             R().walkAll0 = (int)w.size();
             for (int i = 0; i < ngeoms; ++i)
-                if (hg[i].flags & 32) w.push_back(i);
+                if (hg[i].flags & 32) {
+                    if (w.size() - (size_t)R().walkAll0 >= 32767) return fail(PT_ERR_INVALID, "pt_init: more than 32767 meshes");
+                    hg[i].frameSlot = (short)(w.size() - (size_t)R().walkAll0);     // (a mesh's ordinal: its row of the walk's LDS table)
+                    w.push_back(i);
+                }
             R().walkAll1 = (int)w.size();
+            HIPCHECK(hipMemcpy(R().dgeoms, hg.data(), hg.size() * sizeof(GeomDev), hipMemcpyHostToDevice));
             if (!cc.rowOff.empty()) {
                 if (w.size() % 2) w.push_back(0);                  // (the rows' entries are pairs: offsets count pairs from the array's start)
                 std::vector<int> ro(cc.rowOff.size());
@@ -1133,7 +1138,7 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     R().ldsBytesNext = (R().many && !R().mesh) ? ldsFixed + sphMapBytes + pairBytes : 0;
     k.meshStackOff = 0;
     if (R().mesh) {        // (the lanes' stacks of far children belong to the walk's own launches: k_mesh_walk)
-        R().ldsWalk = walkLdsBytes(meshStackNeed);
+        R().ldsWalk = walkLdsBytes(meshStackNeed, R().walkAll1 - R().walkAll0);
         if (R().ldsWalk > 160 * 1024) return fail(PT_ERR_INVALID, "pt_init: a mesh's hierarchy needs %d stack levels (%zu B of LDS)", meshStackNeed, R().ldsWalk);
     }
     if (R().ldsBytesNext == 0) R().ldsBytesNext = R().ldsBytes;

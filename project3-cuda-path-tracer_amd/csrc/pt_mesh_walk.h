@@ -36,7 +36,20 @@ constexpr int kWalkLeafMin = PT_WALK_LEAF_MIN;   // lanes that hold a triangle b
 constexpr int kWalkLdsFixedWords = kSeg + (kSeg + 2) + 2 * kWalkQueue * kWaves;     // segment counts and prefix, the waves' queues
 static_assert((kSeg + kSeg + 2) % 2 == 0, "the queues hold 64-bit jobs");
 // dynamic LDS of a launch: the fixed part, then the lanes' stacks of waiting far children, [levels][kBlock] words
-inline size_t walkLdsBytes(int levels) { return ((size_t)kWalkLdsFixedWords + (size_t)(levels < 1 ? 1 : levels) * kBlock) * sizeof(uint32_t); }
+// what a lane needs of the mesh whose hierarchy it walks, staged in LDS by every workgroup (a gather of it from the primitives' 448-byte
+// records, per lane and job, was a fifth of the kernel's vector-memory instructions: profiles/r05_walk_pmc_summary.txt)
+struct WalkMesh {
+    float inv[12], invZ[3];
+    uint32_t root;
+    float xf[12], camObj[3];
+    uint32_t stride;
+};
+static_assert(sizeof(WalkMesh) == 128, "eight 16-byte words");
+constexpr int kWalkMeshWords = (int)(sizeof(WalkMesh) / sizeof(uint32_t));
+// dynamic LDS of a launch: the fixed part, the table of the scene's meshes, then the lanes' stacks of waiting far children, [levels][kBlock] words
+inline size_t walkLdsBytes(int levels, int nmeshes) {
+    return ((size_t)kWalkLdsFixedWords + (size_t)nmeshes * kWalkMeshWords + (size_t)(levels < 1 ? 1 : levels) * kBlock) * sizeof(uint32_t);
+}
 
 template <bool FIRST, bool DOF>
 __global__ __launch_bounds__(kBlock, 8) void k_mesh_walk(BounceArgs A) {
@@ -47,7 +60,23 @@ __global__ __launch_bounds__(kBlock, 8) void k_mesh_walk(BounceArgs A) {
     uint32_t *const s_segpre = s_segcnt + kSeg;                          // [kSeg+2] tile prefix per input segment
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     unsigned long long *const s_queue = reinterpret_cast<unsigned long long *>(s_segpre + kSeg + 2) + wave * kWalkQueue;
-    uint32_t *const stack = reinterpret_cast<uint32_t *>(smem) + kWalkLdsFixedWords + threadIdx.x;
+    // (a job names its mesh by its ordinal among the scene's meshes, GeomDev::frameSlot = its row here)
+    const int nMeshes = A.walkAll1 - A.walkAll0;
+    WalkMesh *const s_mesh = reinterpret_cast<WalkMesh *>(reinterpret_cast<uint32_t *>(smem) + kWalkLdsFixedWords);
+    uint32_t *const stack = reinterpret_cast<uint32_t *>(smem) + kWalkLdsFixedWords + nMeshes * kWalkMeshWords + threadIdx.x;
+    for (int i = threadIdx.x; i < nMeshes * kWalkMeshWords; i += kBlock) {
+        const int m = i / kWalkMeshWords, w = i - m * kWalkMeshWords;
+        const GeomDev &G = A.ggeoms[A.walkIdx[A.walkAll0 + m]];
+        uint32_t v;
+        if (w < 12) v = __float_as_uint(G.inv[w]);
+        else if (w < 15) v = __float_as_uint(G.invZ[w - 12]);
+        else if (w == 15) v = G.meshRoot;
+        else if (w < 28) v = __float_as_uint(G.xf[w - 16]);
+        else if (w < 31) v = __float_as_uint(G.camObj[w - 28]);
+        else v = G.meshStride;
+        reinterpret_cast<uint32_t *>(s_mesh)[i] = v;
+    }
+    __syncthreads();
     const KParams &prm = A.prm;
     Ctrl *const ctrl = A.ctrl;
     const int depth = A.depth, parity = A.parity;
@@ -227,7 +256,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_mesh_walk(BounceArgs A) {
                 const unsigned long long b = __ballot(want);
                 if (b != 0ull) {
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
-                    if (want) s_queue[qn + rank] = ((unsigned long long)(uint32_t)g << 32) | idx;
+                    if (want) s_queue[qn + rank] = ((unsigned long long)(uint32_t)G.frameSlot << 32) | idx;
                     qn += (uint32_t)__popcll(b);
                 }
             }
@@ -274,7 +303,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_mesh_walk(BounceArgs A) {
                 if (keyT != 0xffffffffu) {
                     F3 org, dir;
                     fetchRay(jobIdx, org, dir);
-                    const GeomDev &G = A.ggeoms[jobGeom];
+                    const WalkMesh &G = s_mesh[jobGeom];
                     const F3 P = mulMV(G.xf, getPointOnRay(ro, rd, __uint_as_float(keyT)), 1.0f);
                     const float t = length(org - P);
                     if (t > 0.0f)
@@ -292,13 +321,13 @@ __global__ __launch_bounds__(kBlock, 8) void k_mesh_walk(BounceArgs A) {
                 jobGeom = (uint32_t)(job >> 32);
                 F3 org, dir;
                 fetchRay(jobIdx, org, dir);
-                const GeomDev &G = A.ggeoms[jobGeom];
+                const WalkMesh &G = s_mesh[jobGeom];
                 ro = (FIRST && !DOF) ? f3(G.camObj[0], G.camObj[1], G.camObj[2]) : mulMV(G.inv, org, 1.0f);
                 rd = normalize(mulMV0(G.inv, G.invZ, dir));
                 inv = f3(guardedReciprocal(rd.x), guardedReciprocal(rd.y), guardedReciprocal(rd.z));
                 rc = f3(-(ro.x * inv.x), -(ro.y * inv.y), -(ro.z * inv.z));
                 const uint32_t octant = (__float_as_uint(inv.x) >> 31) | ((__float_as_uint(inv.y) >> 31) << 1) | ((__float_as_uint(inv.z) >> 31) << 2);
-                ref = G.meshRoot + octant * G.meshStride;
+                ref = G.root + octant * G.stride;
                 sp = stack;
                 keyT = keyI = 0xffffffffu;
                 busy = true;
