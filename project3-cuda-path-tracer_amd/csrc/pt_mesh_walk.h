@@ -25,7 +25,7 @@ constexpr int kWalkQueue = 128;          // jobs a wave holds at most (8 bytes e
 #define PT_WALK_IDLE_MIN 24
 #endif
 #ifndef PT_WALK_LEAF_MIN
-#define PT_WALK_LEAF_MIN 24
+#define PT_WALK_LEAF_MIN 16
 #endif
 #ifndef PT_WALK_QUARTERS_MIN
 #define PT_WALK_QUARTERS_MIN 8

@@ -451,7 +451,11 @@ static_assert(sizeof(CullGroup) == 32 && offsetof(GeomDev, cullFlags) - offsetof
 // test for one; an instantiation of its own (four workgroups per CU: both tests inlined in every pass need the registers), so that a scene of
 // spheres runs exactly the code of rounds 2-4.
 template <bool FIRST, bool MANY, bool DOF = false, bool MESH = false, bool PLAIN = false, bool CUBES = false>
-__global__ __launch_bounds__(kBlock, (MANY && CUBES) ? 4 : (MESH ? (MANY ? 4 : (FIRST ? 5 : 6)) : (DOF ? 5 : (MANY ? (FIRST ? 7 : 6) : 8)))) void k_bounce(BounceArgs argsByValue) {
+#ifndef PT_MESH_WG_FIRST
+#define PT_MESH_WG_FIRST 6
+#define PT_MESH_WG_NEXT 7
+#endif
+__global__ __launch_bounds__(kBlock, (MANY && CUBES) ? 4 : (MESH ? (MANY ? 4 : (FIRST ? PT_MESH_WG_FIRST : PT_MESH_WG_NEXT)) : (DOF ? 5 : (MANY ? (FIRST ? 7 : 6) : 8)))) void k_bounce(BounceArgs argsByValue) {
     static_assert(MANY || !CUBES, "swept cubes only exist where primitives are swept");
     static_assert(FIRST || !DOF, "the lens only concerns the camera-ray bounce");
     (void)argsByValue;

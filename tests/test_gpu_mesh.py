@@ -403,3 +403,20 @@ def test_sphere_heavy_scene_with_a_mesh(gpu, oracle):
     sc.set_resolution = None
     _render_both(gpu, oracle, sc, 6, [1, 2, 3], (96, 72), dump_bounces=(1, 3))
     _render_both(gpu, oracle, sc, 4, [5, 6], (96, 72), rank=1, count=2, lens_radius=0.2, focal_distance=8.0)
+
+
+@pytest.mark.gpu
+def test_walks_ahead_of_the_bounce_on_small_grids_and_ragged_rows(gpu, oracle, monkeypatch):
+    # round 5: the mesh walks run in a kernel of their own ahead of every bounce launch (pt_mesh_walk.h): persistent waves that draw
+    # quarter tiles from sharded tickets.  Rows of 300 pixels (two tiles per row, the second one ragged: a quarter of 44 pixels and two
+    # empty ones), a camera-ray-only render (trace depth 1: the bounce takes its tiles in rotated order, the walk in ticket order), and
+    # grids smaller than the ticket shards (one shard per wave) -- the oracle's frame and per-bounce path state, bit for bit
+    sc = gpu.Scene(os.path.join(SCENES, "mesh_small.txt"))
+    sc.set_resolution(300, 70)
+    _render_both(gpu, oracle, sc, 1, [1, 2, 3], (300, 70))
+    _render_both(gpu, oracle, sc, 4, [1, 2, 3], (300, 70), dump_bounces=(1, 3))
+    for grid in ("8", "24"):
+        monkeypatch.setenv("PT_AMD_MAX_GRID", grid)
+        _render_both(gpu, oracle, sc, 4, [5, 6, 7], (300, 70), dump_bounces=(2,))
+        _render_both(gpu, oracle, sc, 3, [1, 2], (300, 70), lens_radius=0.3, focal_distance=9.0)
+    monkeypatch.delenv("PT_AMD_MAX_GRID")
