@@ -8,7 +8,7 @@ cull, 5/6/4 sphere transform / roots / hit, 16 shading, 9 a hit, 10 scatter, 11 
 import collections, re, sys
 lines = open(sys.argv[1]).read().split("\n")
 want = sys.argv[2] if len(sys.argv) > 2 else "k_bounceILb0ELb0ELb0ELb0E"
-start = [i for i, l in enumerate(lines) if l.startswith("_ZN3ptk8") and want in l and ": ; @" in l][0]
+start = [i for i, l in enumerate(lines) if l.startswith("_ZN3ptk") and want in l and ": ; @" in l][0]
 seg, cur = collections.OrderedDict(), "entry"
 for l in lines[start + 1:]:
     if l.startswith(".Lfunc_end"):

@@ -44,7 +44,7 @@ __device__ __forceinline__ void phaseStamp(int k) {
     }
 }
 __device__ __forceinline__ void probe(int k) {
-    if (k >= 9) phaseStamp(k);        // (the tile-level marks only: the marks inside the intersection tests would dominate what they measure)
+    if (k >= 9 && k < 32) phaseStamp(k);        // (the tile-level marks only; 40 and up: the mesh walk's listing marks: the marks inside the intersection tests would dominate what they measure)
 }
 __device__ __forceinline__ void probeCount(int, bool) {}
 __device__ __forceinline__ void censusEnter() {}

@@ -288,6 +288,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_mesh_walk(BounceArgs A) {
     // (Rounds 3-4 -- and this kernel's first version -- ran "inner nodes until EVERY lane holds a triangle, then the triangles": a round was
     // as long as the longest descent of its lanes, 13 steps where a lane's own took 4.7 -- profiles/r05_mesh_probe.txt.)
     for (;;) {
+        probe(40);                                              // (marks of the ISA listing: the vote)
         const bool atInner = busy && !(ref & kMeshLeaf), atLeaf = busy && (ref & kMeshLeaf) != 0u;
         const uint32_t nInner = (uint32_t)__popcll(__ballot(atInner)), nLeaf = (uint32_t)__popcll(__ballot(atLeaf));
         const unsigned long long idleMask = __ballot(!busy);
@@ -295,6 +296,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_mesh_walk(BounceArgs A) {
         const bool more = qn != 0u || !exhausted;
         probeCount(29, atInner); probeCount(30, atLeaf); probeCount(31, !busy); probeCount(23, !more);
         if ((more && nIdle >= (uint32_t)kWalkIdleMin) || nInner + nLeaf == 0u) {
+            probe(41);                                          // (hand-out: fold)
             // what the lanes that are through have found: the winner's distance in the world, and into the path's record with it.
             // (t: the bits of t + 0.0f serve -- a winner at -0 differs from +0 in the signs of zeros of P alone, which the length squares away)
             probeCount(21, pending);                            // (instrumented build: the walk's wave steps and their lanes)
@@ -310,7 +312,9 @@ __global__ __launch_bounds__(kBlock, 8) void k_mesh_walk(BounceArgs A) {
                         __hip_atomic_fetch_min(A.meshHit + jobIdx, ((unsigned long long)__float_as_uint(t) << 32) | keyI, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
+            probe(42);                                          // (queueing)
             if (qn < nIdle) refill();
+            probe(43);                                          // (jobs to lanes)
             // the idle lanes take the youngest jobs
             const uint32_t take = nIdle < qn ? nIdle : qn;
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idleMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idleMask, 0u));
@@ -335,6 +339,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_mesh_walk(BounceArgs A) {
             qn -= take;
             if (take == 0u && nInner + nLeaf == 0u) break;      // (no job left anywhere: the queue is empty and the tiles are drawn)
         } else if (nLeaf >= (uint32_t)kWalkLeafMin || nInner == 0u) {
+            probe(44);                                          // (triangles)
             probeCount(24, atLeaf);
             if (atLeaf) {
                 const float4 *r = recs + (size_t)(ref & ~kMeshLeaf);
@@ -363,6 +368,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_mesh_walk(BounceArgs A) {
                 ref = pop();
             }
         } else {
+            probe(45);                                          // (inner node)
             probeCount(22, atInner);
             if (atInner) {
                 const float4 *r = recs + (size_t)ref;
@@ -378,6 +384,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_mesh_walk(BounceArgs A) {
                 ref = passN ? refN : (passF ? refF : pop());
             }
         }
+        probe(46);                                              // (the turn's end)
         if (busy && ref == kDone) {                             // (through with its job: nothing waits on its stack)
             busy = false;
             pending = true;
