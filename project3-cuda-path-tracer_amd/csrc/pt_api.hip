@@ -967,7 +967,7 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     HIPCHECK(hipMemcpy(R().dwalls, hw.data(), hw.size() * sizeof(WallBox), hipMemcpyHostToDevice));
     R().mesh = !meshRecs.empty();
     if (R().mesh) {
-        HIPCHECK(hipMalloc(&R().dMeshRecs, meshRecs.size() * sizeof(ptd::MeshUnit)));
+        HIPCHECK(hipMalloc(&R().dMeshRecs, (meshRecs.size() + 4) * sizeof(ptd::MeshUnit)));     // (+ 4: a walk may read the record behind the last one)
         HIPCHECK(hipMemcpy(R().dMeshRecs, meshRecs.data(), meshRecs.size() * sizeof(ptd::MeshUnit), hipMemcpyHostToDevice));
     }
 
