@@ -103,6 +103,7 @@ struct State {
     Slot slot[kMaxSlots];
     GeomDev *dgeoms = nullptr;
     float4 *dGeomHit = nullptr;     // GeomHitDev[ngeoms], as the kernels stage it in LDS (scenes that are not sphere-heavy)
+    float *dRows = nullptr;         // sphere-heavy scenes of hundreds of primitives: the matrix rows that do not go to LDS (BounceArgs::rows)
     MaterialDev *dmats = nullptr;
     WallBox *dwalls = nullptr;
     SphereCull *dSphCull = nullptr; // sphere-heavy scenes: packed culling data of the spheres, and ...
@@ -264,6 +265,7 @@ int launch_bounce(Slot &sl, int iter, int batch, int depth, bool lastBounce, flo
     ba.walls = R().dwalls;
     ba.meshRecs = R().dMeshRecs;
     ba.hostFault = R().hostFaultDev;
+    ba.rows = reinterpret_cast<const float4 *>(R().dRows);
     ba.meshHit = sl.meshHit; ba.walkIdx = R().dWalkIdx; ba.walkRowOff = R().dWalkRowOff;
     memcpy(ba.walkClassOff, R().walkClassOff, sizeof ba.walkClassOff);
     ba.walkAll0 = R().walkAll0; ba.walkAll1 = R().walkAll1;
@@ -538,6 +540,7 @@ void free_renderer() {
     if (R().ownImage && R().image) (void)hipFree(R().image);
     if (R().dgeoms) (void)hipFree(R().dgeoms);
     if (R().dGeomHit) (void)hipFree(R().dGeomHit);
+    if (R().dRows) (void)hipFree(R().dRows);
     if (R().dmats) (void)hipFree(R().dmats);
     if (R().dwalls) (void)hipFree(R().dwalls);
     if (R().dSphCull) (void)hipFree(R().dSphCull);
@@ -1037,11 +1040,18 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
         // round trips, 28 us at the head of every launch of C5 (profiles/timeline_phases.py: 62 k cycles against Cornell's 10 k).
         {
             const size_t hitB = manyHitBytes(ngeoms), frameB = (size_t)k.nCubes * 54 * sizeof(float) + manyFramePad(k.nCubes);
-            const size_t rowB = (size_t)ngeoms * kSphRowFloats * sizeof(float), mapB = ((size_t)k.nSphCull + 7) / 8 * 8 * sizeof(uint16_t);
+            // (scenes of hundreds of primitives: the matrix rows -- 112 B per primitive -- stay in global memory, KParams::ldsRowFloats = 0; with
+            // them a workgroup of the 518-primitive scene took 103 KB of LDS, one per CU.  The limit: what four workgroups per CU leave each.)
+            const size_t rowsAll = (size_t)ngeoms * kSphRowFloats * sizeof(float);
+            const size_t ldsWithRows = sizeof(MaterialDev) * nmats + (size_t)miscWords(kClsMax) * sizeof(uint32_t) + hitB + frameB + rowsAll + (size_t)kListMax * kBlock * sizeof(uint16_t);
+            const bool rowsInLds = ldsWithRows <= 40 * 1024 && !(getenv("PT_AMD_ROWS_GLOBAL") && atoi(getenv("PT_AMD_ROWS_GLOBAL")));   // (the variable: tests only)
+            k.ldsRowFloats = rowsInLds ? ngeoms * kSphRowFloats : 0;
+            const size_t rowB = rowsInLds ? rowsAll : 0, mapB = ((size_t)k.nSphCull + 7) / 8 * 8 * sizeof(uint16_t);
             std::vector<unsigned char> blob(hitB + frameB + rowB + mapB, 0);
+            std::vector<float> rowsGlobal(rowsInLds ? 0 : (size_t)ngeoms * kSphRowFloats, 0.0f);
             GeomHitSmall *hs = reinterpret_cast<GeomHitSmall *>(blob.data());
             float *fr = reinterpret_cast<float *>(blob.data() + hitB);
-            float *rows = reinterpret_cast<float *>(blob.data() + hitB + frameB);
+            float *rows = rowsInLds ? reinterpret_cast<float *>(blob.data() + hitB + frameB) : rowsGlobal.data();
             uint16_t *map = reinterpret_cast<uint16_t *>(blob.data() + hitB + frameB + rowB);
             for (int g = 0; g < ngeoms; ++g) {
                 const GeomDev &G = hg[g];
@@ -1056,6 +1066,10 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
             R().dGeomHit = nullptr;
             HIPCHECK(hipMalloc(&R().dGeomHit, blob.size()));
             HIPCHECK(hipMemcpy(R().dGeomHit, blob.data(), blob.size(), hipMemcpyHostToDevice));
+            if (!rowsInLds) {
+                HIPCHECK(hipMalloc(&R().dRows, rowsGlobal.size() * sizeof(float)));
+                HIPCHECK(hipMemcpy(R().dRows, rowsGlobal.data(), rowsGlobal.size() * sizeof(float), hipMemcpyHostToDevice));
+            }
         }
     }
     {   // Later bounces: which primitives a tile of queue class c looks at.  Class bit 3 = its paths may hit a binned primitive;
@@ -1127,7 +1141,7 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     }
     const size_t ldsFixed = sizeof(MaterialDev) * nmats + (size_t)miscWords((R().mesh || R().many) ? kClsMax : kCls) * sizeof(uint32_t) +
                             (R().many ? manyHitBytes(ngeoms) + (size_t)k.nCubes * 54 * sizeof(float) + manyFramePad(k.nCubes) +
-                                          (size_t)ngeoms * kSphRowFloats * sizeof(float)
+                                          (size_t)k.ldsRowFloats * sizeof(float)
                                     : sizeof(GeomHitDev) * ngeoms);
     // (sphere-heavy scenes: the camera-ray launch keeps the lanes' candidate lists behind the tables, the later ones only the sweep's
     // entry -> primitive map -- 4 KB less, which is what their seventh workgroup per CU needs)

@@ -137,6 +137,8 @@ struct KParams {
                                        // bits 3 / 4 say which clusters its ray can hit at all, and a tile sweeps only those (k_bounce: CLUSTER)
     float sphOMax;                     // ... largest |x| + |y| + |z| of a ray origin the clusters' box certificates are issued for
     float sphBox[2][8];                // ... the clusters' inflated world boxes {lo, hi, -, -} (ptd::wallCertainMiss); neither cluster is empty (pt_init)
+    int   ldsRowFloats;                // sphere-heavy scenes: floats of the primitives' matrix rows in LDS, ngeoms x kSphRowFloats -- or 0: the rows stay in global
+                                       // memory (BounceArgs::rows; scenes of hundreds of primitives, whose rows would leave one workgroup per CU)
     int   pairOff;                     // sphere-heavy scenes, later bounces: byte offset of the pooled pass's pair descriptors in the dynamic LDS ([kWaves][64] words)
     int   meshStackOff;                // scenes with meshes: byte offset of the lanes' traversal stacks in the dynamic LDS ([levels][kBlock] words)
     int   classOff[kClsMax + 1];          // later bounces: the primitives a tile of class c has to look at are classIdx[classOff[c] ..
@@ -405,6 +407,7 @@ struct BounceArgs {
     // ---- scenes with meshes: the walks run AHEAD of the bounce (k_mesh_walk) and leave, per path of a tile that lists a mesh, the nearest
     // mesh hit: meshHit[i] = bits of its distance << 32 | the winning triangle's unit << 1 | front side (all ones: none), i = the path's slot
     // in the input pool (camera rays: its index in the tiles' padded pixel space)
+    const float4 *rows;                 // sphere-heavy scenes: [ngeoms][7] the primitives' matrix rows (inverseTransform, transform, GeomDev::invZ), as the LDS copy holds them
     unsigned long long *meshHit;
     const int *walkIdx;                 // the meshes alone: per queue class (walkClassOff), all of them ([walkAll0, walkAll1)), per image row pairs as rowIdx (walkRowOff)
     const int *walkRowOff;              // ... nullptr where rowOff is
@@ -592,7 +595,7 @@ __global__ __launch_bounds__(kBlock, (MANY && CUBES) ? 4 : (MESH ? (MANY ? 4 : (
             // the tables of a sphere-heavy scene -- hit records, face frames, matrix rows, (later bounces) the sweep's entry -> primitive
             // map -- arrive as ONE host-built image in this very layout (pt_init): a straight copy, four 16-byte loads per lane in flight
             const int n16 = (int)((manyHitBytes(ngeoms) + (size_t)A->prm.nCubes * 54 * sizeof(float) + manyFramePad(A->prm.nCubes) +
-                                   (size_t)ngeoms * kSphRowFloats * sizeof(float) +
+                                   (size_t)A->prm.ldsRowFloats * sizeof(float) +
                                    (FIRST ? 0 : ((size_t)A->prm.nSphCull + 7) / 8 * 8 * sizeof(uint16_t))) / 16);
             float4 *const dst = reinterpret_cast<float4 *>(S_GEOMHIT_SMALL(A->prm.nmats));
             for (int i0 = 0; i0 < n16; i0 += 4 * kBlock) {
@@ -883,8 +886,28 @@ __global__ __launch_bounds__(kBlock, (MANY && CUBES) ? 4 : (MESH ? (MANY ? 4 : (
             if (MANY) {
                 const ArgsPtr A = launder(kargs);
                 s_sph = S_SPH(A->prm.nmats, A->prm.ngeoms, A->prm.nCubes);
-                s_list = reinterpret_cast<uint16_t *>(s_sph + (size_t)A->prm.ngeoms * kSphRowFloats);
+                s_list = reinterpret_cast<uint16_t *>(s_sph + (size_t)A->prm.ldsRowFloats);
             }
+            // the matrix row of primitive g for a per-lane test: from the LDS table -- or, in a scene of hundreds of primitives whose rows
+            // would leave one workgroup per CU, from their copy in global memory (KParams::ldsRowFloats; wave-uniform)
+            auto loadRow = [&](int g, float (&m)[28]) {
+                const ArgsPtr A = launder(kargs);
+                if (A->prm.ldsRowFloats != 0) {
+                    const float4 *row = reinterpret_cast<const float4 *>(s_sph + g * kSphRowFloats);
+#pragma unroll
+                    for (int q = 0; q < 7; ++q) {
+                        const float4 v = row[q];
+                        m[4 * q] = v.x; m[4 * q + 1] = v.y; m[4 * q + 2] = v.z; m[4 * q + 3] = v.w;
+                    }
+                } else {
+                    const float4 *row = A->rows + (size_t)g * 7;
+#pragma unroll
+                    for (int q = 0; q < 7; ++q) {
+                        const float4 v = row[q];
+                        m[4 * q] = v.x; m[4 * q + 1] = v.y; m[4 * q + 2] = v.z; m[4 * q + 3] = v.w;
+                    }
+                }
+            };
             // Sphere-heavy scenes, later bounces: the spheres come from their packed culling data (order does not matter: the
             // nearest hit is taken by (distance, file order)), AFTER the loop over the primitives that are not spheres.
             constexpr bool PACKED = MANY && !FIRST;
@@ -999,13 +1022,8 @@ __global__ __launch_bounds__(kBlock, (MANY && CUBES) ? 4 : (MESH ? (MANY ? 4 : (
                 for (int k = 0; __ballot(k < nCand) != 0ull; ++k) {          // wave-uniform trip count
                     if (k < nCand) {
                         const int g = s_list[k * kBlock + tid];
-                        const float4 *row = reinterpret_cast<const float4 *>(s_sph + g * kSphRowFloats);
                         float m[28];
-#pragma unroll
-                        for (int q = 0; q < 7; ++q) {
-                            const float4 v = row[q];
-                            m[4 * q] = v.x; m[4 * q + 1] = v.y; m[4 * q + 2] = v.z; m[4 * q + 3] = v.w;
-                        }
+                        loadRow(g, m);
                         F3 p, n;
                         bool o = false;
                         probe(4);
@@ -1109,13 +1127,8 @@ __global__ __launch_bounds__(kBlock, (MANY && CUBES) ? 4 : (MESH ? (MANY ? 4 : (
                                 F3 pe = f3(0, 0, 0), ne = f3(0, 0, 0);
                                 if (ln < total) {
                                     ge = sphGeom[base + (int)(desc >> 8)];
-                                    const float4 *row = reinterpret_cast<const float4 *>(s_sph + ge * kSphRowFloats);
                                     float m[28];
-#pragma unroll
-                                    for (int q = 0; q < 7; ++q) {
-                                        const float4 v = row[q];
-                                        m[4 * q] = v.x; m[4 * q + 1] = v.y; m[4 * q + 2] = v.z; m[4 * q + 3] = v.w;
-                                    }
+                                    loadRow(ge, m);
                                     bool o = false;
                                     probe(4);
                                     te = sweptTest(ge, m, oorg, odir, pe, ne, o);
@@ -1159,13 +1172,8 @@ __global__ __launch_bounds__(kBlock, (MANY && CUBES) ? 4 : (MESH ? (MANY ? 4 : (
                             mHi = hi ? rest : mHi;
                             mLo = hi ? mLo : rest;
                             const int g = sphGeom[base + (hi ? 0 : 32) + j];
-                            const float4 *row = reinterpret_cast<const float4 *>(s_sph + g * kSphRowFloats);
                             float m[28];
-#pragma unroll
-                            for (int q = 0; q < 7; ++q) {
-                                const float4 v = row[q];
-                                m[4 * q] = v.x; m[4 * q + 1] = v.y; m[4 * q + 2] = v.z; m[4 * q + 3] = v.w;
-                            }
+                            loadRow(g, m);
                             F3 p, n;
                             bool o = false;
                             probe(4);

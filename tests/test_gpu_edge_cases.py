@@ -510,3 +510,21 @@ def test_closed_cornell_box_matches_the_oracle_and_lets_nothing_escape(gpu, orac
     assert int(cnt.misses) == 0 and int(cnt.light_hits) == hits
     assert all(int(cnt.ended_early[d]) == 0 for d in range(10))          # nothing to end early in a closed box
     assert live[8] > 0.5 * live[1]                                       # the closed box keeps most paths alive to the last bounce
+
+
+@pytest.mark.gpu
+def test_matrix_rows_from_global_memory_in_scenes_of_hundreds_of_primitives(gpu, oracle, monkeypatch):
+    # round 5: a sphere-heavy workgroup stages every primitive's matrix row (112 B) in LDS -- at 518 primitives 58 KB of a 103 KB
+    # workgroup, one per CU.  Beyond 40 KB of LDS the rows stay in global memory (KParams::ldsRowFloats = 0) and a per-lane test reads its
+    # row from there.  The 518-sphere scene takes that path by itself; PT_AMD_ROWS_GLOBAL=1 forces it on the 64-sphere and the
+    # 64-cube scene (the per-lane sphere AND box tests, camera rays and later bounces): the oracle's frames, bit for bit.
+    sc = gpu.Scene(os.path.join(SCENES, "spheres512.txt"))
+    sc.set_resolution(96, 64)
+    _compare(gpu, oracle, sc, [1, 2])
+    monkeypatch.setenv("PT_AMD_ROWS_GLOBAL", "1")
+    for name in ("spheres64.txt", "cubes64.txt"):
+        sc = gpu.Scene(os.path.join(SCENES, name))
+        sc.set_resolution(96, 64)
+        _compare(gpu, oracle, sc, [1, 2, 3])
+        _compare(gpu, oracle, sc, [4, 5, 6, 7], max_batch=4, pipeline_depth=2)
+    monkeypatch.delenv("PT_AMD_ROWS_GLOBAL")
