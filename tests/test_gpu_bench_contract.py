@@ -110,8 +110,10 @@ def test_driver_command_reports_every_one_gpu_configuration(pt):
     # (the committed counters of that very configuration: profiles/pmc_configs.json)
     assert rf["frac"] is not None and 0.3 < rf["frac"] < 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert rf["hbm"]["unit"] == "GB/s" and 0 < rf["hbm"]["frac"] < 1
-    for k in ("c4", "mesh"):
-        assert cf[k]["roofline"]["traffic"] is not None and 0.9 < cf[k]["roofline"]["traffic_over_algorithmic"] < 1.6
+    # (the mesh scene's launch is the pair k_mesh_walk + k_bounce: the walk reads the rays of the tiles that list a mesh once more and leaves an
+    # 8-byte record per path, which the algorithmic figure -- the path state in and out, as for every configuration -- does not count)
+    for k, hi in (("c4", 1.6), ("mesh", 2.0)):
+        assert cf[k]["roofline"]["traffic"] is not None and 0.9 < cf[k]["roofline"]["traffic_over_algorithmic"] < hi
     # a run that is about ONE configuration carries no block
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-spp", "0", "--per-iteration-sample", "0",
                         "--repeats", "2"], capture_output=True, text=True, timeout=600)
