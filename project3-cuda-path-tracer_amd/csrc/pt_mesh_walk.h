@@ -3,12 +3,12 @@
 //
 // Rounds 2-4 walked a mesh inside k_bounce's loop over a tile's primitives, every lane its own ray.  The walks of a wave are of very
 // unequal length -- on scenes/cornell_mesh.txt a ray takes 13 inner steps on average, the longest of a wave's 53 rays 69 -- and a wave
-// steps until its last lane is through: ten lanes of 64 were at work in an average step (profiles/r05_mesh_probe.txt), and a tile cannot
+// steps until its last lane is through: ten lanes of 64 were at work in an average step (profiles/r05_mesh_walk_experiments.txt), and a tile cannot
 // take new rays in, because everything behind the walk (shading, scatter, compaction) needs the whole tile's hits.  Handing parts of a
 // long walk to the wave's idle lanes was built and measured (bit-identical, 2 % slower: the rounds of a walk are as long as before).
 //
 // So the walks left the tile.  k_mesh_walk runs BEFORE the bounce launch over the same queue: persistent WAVES, each on its own, draw
-// tiles (tickets), test the tile's rays against the bounding balls of the meshes its class lists (the camera-ray bounce: its row's),
+// quarter tiles (tickets), test their rays against the bounding balls of the meshes its class lists (the camera-ray bounce: its row's),
 // and queue a JOB (path, mesh) in LDS for every ray that may hit; a lane that is through with a walk takes the next job, whatever
 // tile it came from.  A job's result is folded into the path's record with one 64-bit atomic minimum,
 //     meshHit[path] = bits of the world distance << 32 | winning triangle's unit << 1 | front side        (all ones: no mesh is hit),
@@ -38,9 +38,8 @@ constexpr int kWalkIdleMin = PT_WALK_IDLE_MIN;   // idle lanes a wave counts bef
 constexpr int kWalkLeafMin = PT_WALK_LEAF_MIN;   // lanes that hold a triangle before the wave tests triangles
 constexpr int kWalkLdsFixedWords = kSeg + (kSeg + 2) + 2 * kWalkQueue * kWaves;     // segment counts and prefix, the waves' queues
 static_assert((kSeg + kSeg + 2) % 2 == 0, "the queues hold 64-bit jobs");
-// dynamic LDS of a launch: the fixed part, then the lanes' stacks of waiting far children, [levels][kBlock] words
 // what a lane needs of the mesh whose hierarchy it walks, staged in LDS by every workgroup (a gather of it from the primitives' 448-byte
-// records, per lane and job, was a fifth of the kernel's vector-memory instructions: profiles/r05_walk_pmc_summary.txt)
+// records, per lane and job, was a fifth of the kernel's vector-memory instructions: profiles/r05_mesh_walk_experiments.txt, 2h)
 struct WalkMesh {
     float inv[12], invZ[3];
     uint32_t root;
@@ -289,7 +288,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_mesh_walk(BounceArgs A) {
     //   triangles  when kWalkLeafMin lanes hold one (or no lane holds an inner node): the triangle's own box, then the triangle;
     //   inner node otherwise: the lanes that hold one test its two children.
     // (Rounds 3-4 -- and this kernel's first version -- ran "inner nodes until EVERY lane holds a triangle, then the triangles": a round was
-    // as long as the longest descent of its lanes, 13 steps where a lane's own took 4.7 -- profiles/r05_mesh_probe.txt.)
+    // as long as the longest descent of its lanes, 13 steps where a lane's own took 4.7 -- profiles/r05_mesh_walk_experiments.txt.)
     for (;;) {
         probe(40);                                              // (marks of the ISA listing: the vote)
         const bool atInner = busy && !(ref & kMeshLeaf), atLeaf = busy && (ref & kMeshLeaf) != 0u;
