@@ -252,7 +252,7 @@ int launch_bounce(Slot &sl, int iter, int batch, int depth, bool lastBounce, flo
     ba.tile.skipNonCandidates = (lastBounce && R().prm.emittersBinned) ? 1u : 0u;
     ba.tile.hot = (lastBounce ? kHotLast : 0u) | (R().prm.allClassified ? kHotAllClassified : 0u) | (contrib ? kHotContrib : 0u) |
                   ((R().prm.directDepth != 0 && depth == R().prm.directDepth && R().prm.nEmit > 0) ? kHotToLight : 0u) |
-                  (R().prm.contribLocal ? kHotContribLocal : 0u) | ((R().flags & PT_FLAG_MIXTURE_WEIGHTED) ? kHotMixWeighted : 0u) | ((uint32_t)R().prm.nWalls << 8) | ((uint32_t)R().prm.nSlotWalls << 11) |
+                  (R().prm.contribLocal ? kHotContribLocal : 0u) | ((R().flags & PT_FLAG_MIXTURE_WEIGHTED) ? kHotMixWeighted : 0u) | ((uint32_t)R().prm.nWalls << 8) | ((uint32_t)R().prm.nSlotWalls << 11) | ((uint32_t)R().prm.nPlaneWalls << 17) |
                   ((uint32_t)R().prm.nBinned << 14) | ((uint32_t)R().prm.nmats << 20);
     // sphere clusters: the queue that ENTERS the last bounce carries other candidate bits (k_bounce: kHotWritesLastBits) -- that launch only asks
     // whether a path ends on an emitter, and with every emitter binned it visits the tiles of the binned primitives' candidates alone
@@ -930,7 +930,8 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
             hg[wallGeom[w]].flags |= (w + 1) << 2;
             hg[wallGeom[w]].cullFlags |= (w + 1) << 2;
         }
-        if (const char *e = getenv("PT_AMD_NO_WALLS")) { if (atoi(e)) { for (int i = 0; i < ngeoms; ++i) { hg[i].flags &= 3; hg[i].cullFlags &= 3; } k.nWalls = 0; k.wallOMax = 0.0f; k.nSlotWalls = 0; } }   // experiments only
+        if (const char *e = getenv("PT_AMD_NO_WALLS")) { if (atoi(e)) { for (int i = 0; i < ngeoms; ++i) { hg[i].flags &= 3; hg[i].cullFlags &= 3; } k.nWalls = 0; k.wallOMax = 0.0f; k.nSlotWalls = 0; k.nPlaneWalls = 0; } }   // experiments only
+        if (k.nPlaneWalls > 0) R().plain = false;      // (the rotated walls' certificate lives in the general instantiations only: k_bounce, wallPlanesOriented)
         k.allClassified = k.nWalls > 0 ? 1 : 0;
         for (int i = 0; i < ngeoms; ++i)
             if (!hg[i].binned && (hg[i].flags & 28) == 0) k.allClassified = 0;
@@ -1208,8 +1209,8 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
         }
     }
     if (getenv("PT_AMD_VERBOSE") && atoi(getenv("PT_AMD_VERBOSE")))       // experiments: what pt_init decided
-        fprintf(stderr, "pt_init: lds %zu / %zu B, grid %d / %d, mesh %d many %d plain %d, binned %d walls %d allClassified %d, sphCull %d (cluster 0: %d) omax %g\n",
-                R().ldsBytes, R().ldsBytesNext, R().gridFirst, R().grid, (int)R().mesh, (int)R().many, (int)R().plain, k.nBinned, k.nWalls, k.allClassified, k.nSphCull,
+        fprintf(stderr, "pt_init: lds %zu / %zu B, grid %d / %d, mesh %d many %d plain %d, binned %d walls %d (slots %d, planes %d) allClassified %d, sphCull %d (cluster 0: %d) omax %g\n",
+                R().ldsBytes, R().ldsBytesNext, R().gridFirst, R().grid, (int)R().mesh, (int)R().many, (int)R().plain, k.nBinned, k.nWalls, k.nSlotWalls, k.nPlaneWalls, k.allClassified, k.nSphCull,
                 k.sphN0, (double)k.sphOMax);
     HIPCHECK(hipDeviceSynchronize());
     R().init = true;

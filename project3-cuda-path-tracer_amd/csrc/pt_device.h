@@ -686,6 +686,38 @@ __device__ __forceinline__ uint32_t wallPlanesPossible(const KP &prm, F3 o, F3 d
     return possible;
 }
 
+// The same certificate for ROTATED walls (round 5: a room none of whose walls is axis-aligned ran at a third of Cornell's rate -- the world
+// boxes of tilted slabs fill the room, and no certificate was ever issued).  A cube lies on ONE side of the plane of each of its faces,
+// whichever way that face looks: with n the unit normal of the face that looks at the scene's interior, pointing there, and th the largest
+// n . corner of the inflated cube moved further that way by the slack, a segment whose end points both have n . x > th misses the cube.
+// The segment is the one of wallPlanesPossible -- the ray from its origin to where it leaves `outer` --, the margins are its margins
+// plus the rounding of the two dot products (host: choose_walls).  planeN[w] = {n, th} of wall first + w.
+// (tests/test_gpu_parity.py::test_wall_planes_never_reject_a_hit sweeps rotated rooms too.)
+template <typename KP>
+__device__ __forceinline__ uint32_t wallPlanesOriented(const KP &prm, F3 o, F3 d, F3 inv, int first, int count) {
+    const float bx = inv.x > 0.0f ? prm.outerHi[0] : prm.outerLo[0];
+    const float by = inv.y > 0.0f ? prm.outerHi[1] : prm.outerLo[1];
+    const float bz = inv.z > 0.0f ? prm.outerHi[2] : prm.outerLo[2];
+    float tOut = __builtin_fminf(__builtin_fminf((bx - o.x) * inv.x, (by - o.y) * inv.y), (bz - o.z) * inv.z);
+    // ... and where it leaves the half-spaces n . x >= far of the rotated walls (each holds every wall's cube: the convex set the segment
+    // lives in is `outer` cut by them -- the world box of a room of tilted slabs reaches far behind its walls, where their planes cross)
+    for (int w = 0; w < count; ++w) {
+        const float nx = prm.planeN[w][0], ny = prm.planeN[w][1], nz = prm.planeN[w][2], far = prm.planeN[w][4];
+        const float so = __builtin_fmaf(nz, o.z, __builtin_fmaf(ny, o.y, nx * o.x)), sd = __builtin_fmaf(nz, d.z, __builtin_fmaf(ny, d.y, nx * d.x));
+        const float t = (far - so) * __builtin_amdgcn_rcpf(sd);
+        tOut = ((sd < 0.0f) & (t > 0.0f)) ? __builtin_fminf(tOut, t) : tOut;     // (an origin beyond `far`, a NaN: this half-space cuts nothing)
+    }
+    const F3 e = f3(__builtin_fmaf(d.x, tOut, o.x), __builtin_fmaf(d.y, tOut, o.y), __builtin_fmaf(d.z, tOut, o.z));
+    const bool leaves = (tOut > 0.0f) & (tOut < 3.0e38f);          // (NaN fails both)
+    uint32_t possible = 0u;
+    for (int w = 0; w < count; ++w) {
+        const float nx = prm.planeN[w][0], ny = prm.planeN[w][1], nz = prm.planeN[w][2], th = prm.planeN[w][3];
+        const float so = __builtin_fmaf(nz, o.z, __builtin_fmaf(ny, o.y, nx * o.x)), se = __builtin_fmaf(nz, e.z, __builtin_fmaf(ny, e.y, nx * e.x));
+        possible |= ((so > th) & (se > th) & leaves) ? 0u : (1u << (first + w));
+    }
+    return possible;
+}
+
 // src/intersections.h:101-143 (pow(radius, 2) == 0.25f in the float overload nvcc selects).
 // `inv`, `invZ`, `xf`: rows 0-2 of inverseTransform (and its w = 0 products, GeomDev::invZ) / transform as mulMV expects them -- SGPR operands when the sphere is
 // wave-uniform (GeomDev through the scalar path), registers when every lane tests its own sphere (k_bounce<., MANY>).

@@ -287,6 +287,8 @@ void choose_walls(const PtGeom *geoms, int ngeoms, const std::vector<GeomDev> &h
     k.nWalls = n;
     k.wallOMax = n > 0 ? (float)omaxAll : 0.0f;      // the margin must hold for every wall
     k.nSlotWalls = 0;
+    k.nPlaneWalls = 0;
+    memset(k.planeN, 0, sizeof k.planeN);
     for (int sl = 0; sl < 6; ++sl) { k.slotTh[sl] = 0.0f; k.slotBit[sl] = 0u; }
     for (int a = 0; a < 3; ++a) k.outerLo[a] = k.outerHi[a] = 0.0f;
     wallGeom.clear();
@@ -302,7 +304,73 @@ void choose_walls(const PtGeom *geoms, int ngeoms, const std::vector<GeomDev> &h
     std::vector<int> slot(n, -1);
     std::vector<double> th(n, 0.0);
     bool taken[6] = {false, false, false, false, false, false};
+    // ROTATED walls (an edge of the cube that is not parallel to a world axis): their world boxes are far larger than they are, so they
+    // take no slot; the plane of the face that looks at C, the middle of `outer`, certifies them instead (ptd::wallPlanesOriented):
+    // n = that face's unit normal towards C, th = the largest n . corner + the box's inflation (wall_box: 4e-5 S) + the slack (the
+    // exit point's rounding as above, the two dot products', and n's own rounding to float: 3e-6 (wallOMax + |diagonal of outer|)).
+    std::vector<int> rotated(n, 0);
+    std::vector<std::array<double, 4>> plane(n);
+    std::vector<double> planeS(n, 0.0);
+    double Smax = 0;            // the largest inflation scale among the walls (wall_box)
+    std::vector<std::array<double, 3>> allCorners;   // every wall's cube, corner by corner
+    for (int w = 0; w < n; ++w) {
+        const PtGeom &g = geoms[which[w]];
+        WallBox tmp;
+        Smax = std::max(Smax, wall_box(g, tmp));
+        for (int q = 0; q < 8; ++q) {
+            const double o[3] = {(q & 1) ? 0.5 : -0.5, (q & 2) ? 0.5 : -0.5, (q & 4) ? 0.5 : -0.5};
+            std::array<double, 3> c;
+            for (int r = 0; r < 3; ++r)
+                c[r] = (double)g.transform[0 + r] * o[0] + (double)g.transform[4 + r] * o[1] + (double)g.transform[8 + r] * o[2] + (double)g.transform[12 + r];
+            allCorners.push_back(c);
+        }
+    }
+    const bool noOriented = getenv("PT_AMD_NO_ORIENTED_WALLS") && atoi(getenv("PT_AMD_NO_ORIENTED_WALLS"));     // (experiments: round 4's behaviour)
+    for (int w = 0; w < n && std::isfinite(slack) && !noOriented; ++w) {
+        const PtGeom &g = geoms[which[w]];
+        bool aligned = true;
+        for (int c = 0; c < 3; ++c) {           // column c of the transform: the world direction of the cube's edge c
+            double m = 0;
+            int big = 0;
+            for (int r = 0; r < 3; ++r) m = std::max(m, std::fabs((double)g.transform[4 * c + r]));
+            for (int r = 0; r < 3; ++r) big += std::fabs((double)g.transform[4 * c + r]) > 1e-7 * m ? 1 : 0;
+            aligned = aligned && big <= 1;
+        }
+        if (aligned) continue;
+        // (a SMALL rotated cube -- a tilted light under the ceiling -- keeps the slab test against its world box: the plane of one face says
+        // little about a box that spans a fraction of the room, the box around it a lot)
+        if ((double)hg[which[w]].boundR < 0.2 * diag) { rotated[w] = -1; continue; }
+        double corner[8][3];
+        for (int q = 0; q < 8; ++q) {
+            const double o[3] = {(q & 1) ? 0.5 : -0.5, (q & 2) ? 0.5 : -0.5, (q & 4) ? 0.5 : -0.5};
+            for (int r = 0; r < 3; ++r)
+                corner[q][r] = (double)g.transform[0 + r] * o[0] + (double)g.transform[4 + r] * o[1] + (double)g.transform[8 + r] * o[2] + (double)g.transform[12 + r];
+        }
+        WallBox tmp;
+        const double Sw = wall_box(g, tmp);
+        const double C[3] = {0.5 * (lo[0] + hi[0]), 0.5 * (lo[1] + hi[1]), 0.5 * (lo[2] + hi[2])};
+        double bestGap = 1e-3 * diag;           // (C clearly on the far side of the face, or no plane)
+        for (int a = 0; a < 3; ++a)
+            for (int sgn = -1; sgn <= 1; sgn += 2) {
+                // outward normal of the face (sgn e_a in the cube's space): sgn x row a of the inverse transform; towards C: its negative
+                double nn[3] = {-sgn * (double)g.inverseTransform[0 + a], -sgn * (double)g.inverseTransform[4 + a], -sgn * (double)g.inverseTransform[8 + a]};
+                const double len = std::sqrt(nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2]);
+                if (!(len > 0) || !std::isfinite(len)) continue;
+                for (double &v : nn) v /= len;
+                double th = -INFINITY;
+                for (int q = 0; q < 8; ++q) th = std::max(th, nn[0] * corner[q][0] + nn[1] * corner[q][1] + nn[2] * corner[q][2]);
+                const double gap = (nn[0] * C[0] + nn[1] * C[1] + nn[2] * C[2]) - th;
+                if (gap > bestGap && std::isfinite(th)) {
+                    bestGap = gap;
+                    rotated[w] = 1;
+                    plane[w] = {nn[0], nn[1], nn[2], th + 4e-5 * Sw + 3e-6 * (omaxAll + diag)};
+                    planeS[w] = Sw;
+                }
+            }
+        if (!rotated[w]) rotated[w] = -1;       // (rotated, no usable face: the slab test)
+    }
     for (int w = 0; w < n && std::isfinite(slack); ++w) {            // (largest walls first)
+        if (rotated[w] != 0) continue;
         double best = 0;
         for (int a = 0; a < 3; ++a) {
             const double C = 0.5 * (lo[a] + hi[a]), ext = std::max(hi[a] - lo[a], 1e-30);
@@ -312,11 +380,23 @@ void choose_walls(const PtGeom *geoms, int ngeoms, const std::vector<GeomDev> &h
         }
         if (slot[w] >= 0) taken[slot[w]] = true;
     }
-    for (int pass = 0; pass < 2; ++pass)                              // walls with a slot first
+    for (int pass = 0; pass < 3; ++pass)                              // walls with a slot first, then those with a plane of their own, then the rest
         for (int w = 0; w < n; ++w)
-            if ((slot[w] >= 0) == (pass == 0)) {
+            if ((slot[w] >= 0 ? 0 : (rotated[w] == 1 ? 1 : 2)) == pass) {
                 const int idx = (int)wallGeom.size();
                 hw[idx] = boxes[w];
+                if (pass == 1) {
+                    float *pn = k.planeN[k.nPlaneWalls++];
+                    for (int q = 0; q < 3; ++q) pn[q] = (float)plane[w][q];
+                    const float t = (float)plane[w][3];
+                    pn[3] = (double)t < plane[w][3] ? std::nextafter(t, INFINITY) : t;          // (towards the interior: the certificate may only get rarer)
+                    // `far`: the half-space n . x >= far holds every wall's inflated cube (the segment's end may only move OUTWARDS)
+                    double farD = INFINITY;
+                    for (const auto &c : allCorners) farD = std::min(farD, (double)pn[0] * c[0] + (double)pn[1] * c[1] + (double)pn[2] * c[2]);
+                    farD -= 4e-5 * Smax + 3e-6 * (omaxAll + diag);
+                    const float ff = (float)farD;
+                    pn[4] = (double)ff > farD ? std::nextafter(ff, -INFINITY) : ff;
+                }
                 if (slot[w] >= 0) {
                     // rounded towards the interior: a threshold may only make the certificate rarer
                     const float t = (float)th[w];

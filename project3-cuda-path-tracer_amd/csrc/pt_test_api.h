@@ -585,9 +585,9 @@ int pt_test_wall_plane_sweep(const PtGeom *geoms, int ngeoms, uint64_t seed, int
     std::vector<WallBox> hw(kWallMax);
     std::vector<int> wallGeom;
     choose_walls(geoms, ngeoms, hg, k, hw, wallGeom);
-    *nplane = k.nSlotWalls;
+    *nplane = k.nSlotWalls + k.nPlaneWalls;
     *certified = *violations = *single = 0;
-    if (k.nWalls < 1 || k.nSlotWalls < 1) return PT_OK;
+    if (k.nWalls < 1 || k.nSlotWalls + k.nPlaneWalls < 1) return PT_OK;
     std::vector<GeomDev> wg(k.nWalls);
     for (int w = 0; w < k.nWalls; ++w) wg[w] = hg[wallGeom[w]];
     DevBuf<GeomDev> dg;

@@ -465,7 +465,7 @@ __global__ void k_sweep_wall_planes(KParams prm, const GeomDev *wallGeoms, const
                                     unsigned long long *certified, unsigned long long *violations, unsigned long long *single) {
     unsigned long long x = seed + (blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ull;
     unsigned int nc = 0, nv = 0, ns = 0;
-    const int nPlane = prm.nSlotWalls;
+    const int nPlane = prm.nSlotWalls + prm.nPlaneWalls;      // (walls certified by an axis slot's plane, then by the plane of a rotated cube's inner face)
     const F3 olo = f3(prm.outerLo[0], prm.outerLo[1], prm.outerLo[2]), ohi = f3(prm.outerHi[0], prm.outerHi[1], prm.outerHi[2]);
     const F3 oc = (olo + ohi) * 0.5f, oh = (ohi - olo) * 0.5f;
     for (int k = 0; k < per_thread; ++k) {
@@ -495,6 +495,21 @@ __global__ void k_sweep_wall_planes(KParams prm, const GeomDev *wallGeoms, const
                 else if (a != 1) org.y = oc.y + m * oh.y * (1.0f - 2e-3f * u[8]);
                 else org.z = oc.z + m * oh.z * (1.0f - 2e-3f * u[8]);
             }
+            if (wi >= prm.nSlotWalls && wi < nPlane && u[7] < 0.6f) {
+                // a ROTATED wall: on the cube's own face that looks at the room's middle, 0 .. 4e-3 off it (1e-3 in half of the cases)
+                const GeomDev &G = wallGeoms[wi];
+                const F3 c0 = f3(G.xf[0], G.xf[1], G.xf[2]), c1 = f3(G.xf[3], G.xf[4], G.xf[5]), c2 = f3(G.xf[6], G.xf[7], G.xf[8]);
+                const float l0 = dot(c0, c0), l1 = dot(c1, c1), l2 = dot(c2, c2);
+                const int ta = l0 <= l1 && l0 <= l2 ? 0 : (l1 <= l2 ? 1 : 2);
+                const F3 ca = ta == 0 ? c0 : (ta == 1 ? c1 : c2);
+                const float len = __builtin_sqrtf(ta == 0 ? l0 : (ta == 1 ? l1 : l2));
+                const F3 centre = f3(G.xf[9], G.xf[10], G.xf[11]);
+                const float sgn = dot(ca, oc - centre) >= 0.0f ? 1.0f : -1.0f;
+                F3 po = f3((u[2] - 0.5f) * 0.999f, (u[3] - 0.5f) * 0.999f, (u[4] - 0.5f) * 0.999f);
+                const float h = sgn * (0.5f + off / len);
+                if (ta == 0) po.x = h; else if (ta == 1) po.y = h; else po.z = h;
+                org = mulMV(G.xf, po, 1.0f);
+            }
         } else if (u[1] < 0.85f) {
             org = oc + f3((2 * u[2] - 1) * oh.x, (2 * u[3] - 1) * oh.y, (2 * u[4] - 1) * oh.z);
         } else {
@@ -515,7 +530,8 @@ __global__ void k_sweep_wall_planes(KParams prm, const GeomDev *wallGeoms, const
         const float l1 = (__builtin_fabsf(org.x) + __builtin_fabsf(org.y)) + __builtin_fabsf(org.z);
         if (!(l1 <= prm.wallOMax)) continue;
         const F3 inv = f3(__builtin_amdgcn_rcpf(dir.x), __builtin_amdgcn_rcpf(dir.y), __builtin_amdgcn_rcpf(dir.z));
-        const uint32_t possible = wallPlanesPossible(prm, org, dir, inv);
+        uint32_t possible = wallPlanesPossible(prm, org, dir, inv);
+        if (prm.nPlaneWalls > 0) possible |= wallPlanesOriented(prm, org, dir, inv, prm.nSlotWalls, prm.nPlaneWalls);
         for (int w = 0; w < nPlane; ++w)
             if (!((possible >> w) & 1u)) {
                 ++nc;

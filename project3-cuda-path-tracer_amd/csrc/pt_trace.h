@@ -124,6 +124,11 @@ struct KParams {
     float slotTh[6];          // the slot's plane, moved towards the interior by the slack that covers the exit point's rounding
     uint32_t slotBit[6];      // 1 << (the slot's wall), or 0: no wall in this slot
     float outerLo[3], outerHi[3];   // box around all the walls' inflated boxes
+    // Walls nSlotWalls .. nSlotWalls + nPlaneWalls - 1 are ROTATED cubes: certified by the plane of the face that looks at the scene's
+    // interior, whatever its direction (ptd::wallPlanesOriented; round 5): {unit normal n towards the interior, threshold moved that way,
+    // `far`: n . x of the half-space n . x >= far that holds EVERY wall's inflated cube -- the ray's segment ends where it leaves it}
+    int   nPlaneWalls;
+    float planeN[kWallMax][8];
     // ---- README extras, all off by default
     float lensRadius, focalDistance;   // thin lens (depth of field, README.md:100-101); radius 0 = pinhole
     float viewN[3];                    // normalize(view)
@@ -367,7 +372,7 @@ struct TileArgs {
     // be its own scalar load in the phase that asks for it, and round 3's experiments price a dependent scalar-cache round trip at
     // half a percent of a tile's time (profiles/r03_sensitivity_experiments.txt).
     //   bit 0 lastBounce, 1 allClassified, 2 radiance is parked (contrib != null), 3 this bounce aims at a light (direct lighting),
-    //   4 contribLocal, 5 / 6 the output / input queue carries the last bounce's candidate bits; bits 8-10 nWalls, 11-13 nSlotWalls, 14-16 nBinned, 20-31 nmats
+    //   4 contribLocal, 5 / 6 the output / input queue carries the last bounce's candidate bits; bits 8-10 nWalls, 11-13 nSlotWalls, 14-16 nBinned, 17-19 nPlaneWalls, 20-31 nmats
     uint32_t hot;
 };
 constexpr uint32_t kHotLast = 1u, kHotAllClassified = 2u, kHotContrib = 4u, kHotToLight = 8u, kHotContribLocal = 16u;
@@ -381,6 +386,7 @@ constexpr uint32_t kHotWritesLastBits = 32u, kHotReadsLastBits = 64u;
 constexpr uint32_t kHotMixWeighted = 128u;
 __host__ __device__ constexpr uint32_t hotWalls(uint32_t h) { return (h >> 8) & 7u; }
 __host__ __device__ constexpr uint32_t hotSlotWalls(uint32_t h) { return (h >> 11) & 7u; }
+__host__ __device__ constexpr uint32_t hotPlaneWalls(uint32_t h) { return (h >> 17) & 7u; }
 __host__ __device__ constexpr uint32_t hotBinned(uint32_t h) { return (h >> 14) & 7u; }
 __host__ __device__ constexpr uint32_t hotMats(uint32_t h) { return h >> 20; }
 static_assert(sizeof(TileArgs) == 40, "ten dwords");
@@ -1430,7 +1436,11 @@ __global__ __launch_bounds__(kBlock, (MANY && CUBES) ? 4 : (MESH ? (MANY ? 4 : (
                                     const WallPtr walls = (WallPtr)(A->walls);
                                     probe(13);
                                     uint32_t possible = wallPlanesPossible(A->prm, norg, ndir, inv);     // walls 0 .. nSlotWalls - 1
-                                    for (int w = (int)hotSlotWalls(hotNow()); w < nWalls; ++w) { probe(13);
+                                    // (rotated walls: the plane of their inner face, whatever its direction -- never in the PLAIN instantiations,
+                                    // which pt_init does not pick for a scene that has one)
+                                    const int nPl = PLAIN ? 0 : (int)hotPlaneWalls(hotNow());
+                                    if (!PLAIN && nPl > 0) possible |= wallPlanesOriented(A->prm, norg, ndir, inv, (int)hotSlotWalls(hotNow()), nPl);
+                                    for (int w = (int)hotSlotWalls(hotNow()) + nPl; w < nWalls; ++w) { probe(13);
                                         possible |= wallCertainMiss(*(launder(walls) + w), norg, inv) ? 0u : (1u << w); }
                                     const int cnt = __popc(possible);
                                     wallSel = cnt == 1 ? (uint32_t)(__ffs((int)possible) - 1) : (cnt == 0 ? 7u : 6u);
