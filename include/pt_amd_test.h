@@ -57,12 +57,16 @@ int pt_test_sphere_clusters(const PtGeom *geoms, int ngeoms, float *info18, int3
  * the wall a path can still hit) soundness: as above, for the cubes of `geoms`. */
 int pt_test_wall_box_sweep(const PtGeom *geoms, int ngeoms, uint64_t seed, int64_t rays, uint64_t *culled,
                            uint64_t *violations);
-/* wallPlanesPossible (the one-plane-per-wall certificates of the survivors' queue classes; pt_init's choose_walls numbers the cubes of
+/* wallPlanesPossible / wallPlanesOriented (the one-plane-per-wall certificates of the survivors' queue classes; pt_init's choose_walls numbers the cubes of
  * `geoms` as walls exactly as a render would) soundness: `rays` pseudo-random rays from the walls' inner faces, the corners, the
  * interior and beyond; *violations = (ray, wall) pairs certified as missed although the full test hits (must be 0), *certified =
  * certificates issued, *single = rays left with exactly one possible wall, *nplane = walls that have a plane. */
 int pt_test_wall_plane_sweep(const PtGeom *geoms, int ngeoms, uint64_t seed, int64_t rays, int32_t *nplane, uint64_t *certified,
                              uint64_t *violations, uint64_t *single);
+/* (host only, no GPU needed) the planes pt_init's choose_walls keeps for ROTATED walls (ptd::wallPlanesOriented, round 5): planes[w] =
+ * {unit normal towards the scene's interior (3), threshold, far} of plane wall w, wall_geom[i] = the primitive that is wall i (walls with
+ * an axis slot first, then the plane walls, then the rest), *nslot / *nplane / *nwalls their counts.  planes: 6 x 5 floats, wall_geom: 6 ints. */
+int pt_test_wall_planes(const PtGeom *geoms, int ngeoms, float *planes, int32_t *wall_geom, int32_t *nslot, int32_t *nplane, int32_t *nwalls);
 /* Screen-space culling of camera rays (per-primitive pixel rectangles, their union, the per-row primitive lists with their hull
  * spans -- everything pt_init derives from the camera, built here by the very same host functions) soundness: every pixel of
  * `cam`'s frame sends `samples` camera rays through the full tests of every primitive; *violations = hits from a pixel the culling

@@ -66,7 +66,7 @@ TEST_ABI_SYMBOLS = [
     "pt_test_slab_quotients", "pt_test_slab_quotients_sweep", "pt_test_box_fast_sweep", "pt_test_sphere_cull_sweep", "pt_test_unscaled_sqrt_sweep",
     "pt_test_force_fault", "pt_test_pow", "pt_test_wall_box_sweep", "pt_test_mesh_intersect", "pt_test_mesh_bvh",
     "pt_test_mesh_cull_sweep", "pt_test_camera_cull_sweep", "pt_test_camera_cull_tables",
-    "pt_test_wall_plane_sweep", "pt_test_sphere_halfline_sweep", "pt_test_sphere_cluster_sweep", "pt_test_sphere_clusters", "pt_test_camera_cull_margin",
+    "pt_test_wall_plane_sweep", "pt_test_wall_planes", "pt_test_sphere_halfline_sweep", "pt_test_sphere_cluster_sweep", "pt_test_sphere_clusters", "pt_test_camera_cull_margin",
 ]
 
 
@@ -163,6 +163,7 @@ def _bind(L, with_tests):
         L.pt_test_camera_cull_tables.argtypes = [vp, vp, i32, vp, vp, vp]
         L.pt_test_camera_cull_margin.argtypes = [vp, vp, i32, i32, C.POINTER(C.c_double), u64p]
         L.pt_test_wall_plane_sweep.argtypes = [vp, i32, C.c_uint64, i64, C.POINTER(C.c_int32)] + [u64p] * 3
+        L.pt_test_wall_planes.argtypes = [vp, i32, vp, vp] + [C.POINTER(C.c_int32)] * 3
     return L
 
 
@@ -775,6 +776,16 @@ def test_wall_plane_sweep(geoms, seed, rays):
     c, v, s1 = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
     _tcheck(test_lib().pt_test_wall_plane_sweep(_p(geoms), len(geoms), seed, rays, C.byref(n), C.byref(c), C.byref(v), C.byref(s1)))
     return int(n.value), int(c.value), int(v.value), int(s1.value)
+
+
+def test_wall_planes(geoms):
+    """Host only (no GPU): the planes pt_init keeps for rotated walls.  Returns (planes [nplane][5] = normal, threshold, far; wall_geom, nslot, nwalls)."""
+    geoms = np.ascontiguousarray(geoms)
+    planes = np.zeros((6, 5), np.float32)
+    wg = np.zeros(6, np.int32)
+    ns, npl, nw = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    _tcheck(test_lib().pt_test_wall_planes(_p(geoms), len(geoms), _p(planes), _p(wg), C.byref(ns), C.byref(npl), C.byref(nw)))
+    return planes[:npl.value].copy(), wg[:nw.value].copy(), int(ns.value), int(nw.value)
 
 
 def scan_exclusive_dev(in_ptr, out_ptr, n, stream=0):

@@ -271,6 +271,27 @@ int pt_test_mesh_bvh(const float *tris, int ntris, int octant, uint32_t *units4,
     return PT_OK;
 }
 
+// host only: no GPU is touched
+int pt_test_wall_planes(const PtGeom *geoms, int ngeoms, float *planes, int32_t *wall_geom, int32_t *nslot, int32_t *nplane, int32_t *nwalls) {
+    if (!geoms || ngeoms < 1 || !planes || !wall_geom || !nslot || !nplane || !nwalls) return fail(PT_ERR_INVALID, "pt_test_wall_planes: bad argument");
+    std::vector<GeomDev> hg(ngeoms);
+    for (int i = 0; i < ngeoms; ++i) {
+        if (geoms[i].type != PT_CUBE) return fail(PT_ERR_INVALID, "pt_test_wall_planes: cubes only");
+        pack_geom(geoms[i], hg[i]);
+    }
+    KParams k;
+    memset(&k, 0, sizeof k);
+    std::vector<WallBox> hw(kWallMax);
+    std::vector<int> wallGeom;
+    choose_walls(geoms, ngeoms, hg, k, hw, wallGeom);
+    *nslot = k.nSlotWalls; *nplane = k.nPlaneWalls; *nwalls = k.nWalls;
+    for (int w = 0; w < kWallMax; ++w) {
+        for (int q = 0; q < 5; ++q) planes[5 * w + q] = w < k.nPlaneWalls ? k.planeN[w][q] : 0.0f;
+        wall_geom[w] = w < (int)wallGeom.size() ? wallGeom[w] : -1;
+    }
+    return PT_OK;
+}
+
 int pt_test_sphere_cull_sweep(const PtGeom *geoms, int ngeoms, uint64_t seed, int64_t rays, uint64_t *culled,
                               uint64_t *violations) {
     NEED_GPU();
