@@ -129,7 +129,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_mesh_walk(BounceArgs A) {
     // a batch hold a few jobs per LANE of a full grid -- so the waves beyond that many end here; at least one per CU-sized group stays)
     uint32_t nWaves = gridDim.x * kWaves;
     {
-        const uint32_t want = 4u * numTiles / (uint32_t)kWalkQuartersMin;
+        const uint32_t want = 4u * numTiles / (uint32_t)kWalkQuartersMin;      // (camera rays: far more tiles than waves)
         const uint32_t floor = nWaves < 256u ? nWaves : 256u;
         const uint32_t cap = want > floor ? want : floor;
         if (cap < nWaves) nWaves = cap;
@@ -138,12 +138,15 @@ __global__ __launch_bounds__(kBlock, 8) void k_mesh_walk(BounceArgs A) {
     const uint32_t nShards = nWaves < (uint32_t)kTicketShards ? nWaves : (uint32_t)kTicketShards;
     const uint32_t shard = (blockIdx.x * kWaves + wave) % nShards;
     uint32_t *const ticket = &ctrl->walkTicket[parity][depth][shard][0];
+    // (later bounces: a ticket is a QUARTER tile, 4 T + q -- a wave's share of a late bounce is a handful of tiles; camera rays: a whole tile --
+    // a batch holds hundreds of thousands of them, most outside the meshes' rows and spans, and a ticket per quarter was 14 000 atomics per word)
+    constexpr uint32_t kPerTile = FIRST ? 1u : 4u;
     bool exhausted = false;
     auto nextTile = [&]() -> uint32_t {
         uint32_t t = 0u;
         if (lane == 0) t = atomicAdd(ticket, 1u);
         const uint32_t T = (uint32_t)__builtin_amdgcn_readfirstlane((int)t) * nShards + shard;
-        return T < 4u * numTiles ? T : 0xffffffffu;
+        return T < kPerTile * numTiles ? T : 0xffffffffu;
     };
 
     // ---- the ray of record index i (a path's slot in the input pool; camera rays: i = 256 tile + lane in the padded pixel space)
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_mesh_walk(BounceArgs A) {
                 if (exhausted) break;
                 const uint32_t t4 = nextTile();
                 if (t4 == 0xffffffffu) { exhausted = true; break; }
-                curT = t4 >> 2; curQ = t4 & 3u; curK = 0u;
+                curT = FIRST ? t4 : t4 >> 2; curQ = FIRST ? 0u : t4 & 3u; curK = 0u;
             }
             // the quarter's rays and its list of meshes
             bool valid;
@@ -264,7 +267,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_mesh_walk(BounceArgs A) {
             }
             if (full) break;
             curK = 0u;
-            curT = 0xffffffffu;
+            if (!FIRST || ++curQ == 4u) curT = 0xffffffffu;      // (camera rays: the tile's next quarter)
         }
     };
 
