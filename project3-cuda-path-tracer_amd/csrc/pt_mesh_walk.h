@@ -232,8 +232,29 @@ __global__ __launch_bounds__(kBlock, 8) void k_mesh_walk(BounceArgs A) {
                 curT = 0xffffffffu;
                 continue;
             }
+            // camera rays: only the pixels inside a mesh's span (its rectangle) can reach it -- the bounce asks for the records of those alone --, and a
+            // quarter that holds none of them is done (a mesh covers a fraction of its rows: most of their rays were built for nothing)
+            bool reach = valid;
+            if (FIRST && !DOF) {
+                reach = false;
+                for (int k = 0; k < l1 - l0; ++k) {
+                    if (rows) {
+                        const int span = A.walkIdx[2 * (l0 + k) + 1];
+                        reach = reach | ((px >= (span & 0xffff)) & (px <= (span >> 16)));
+                    } else {
+                        const GeomDev &G = A.ggeoms[A.walkIdx[l0 + k]];
+                        reach = reach | ((px >= G.rect[0]) & (px <= G.rect[2]) & (py >= G.rect[1]) & (py <= G.rect[3]));
+                    }
+                }
+                reach = reach & valid;
+                if (__ballot(reach) == 0ull) {
+                    curK = 0u;
+                    if (++curQ == 4u) curT = 0xffffffffu;
+                    continue;
+                }
+            }
             F3 org = f3(0, 0, 0), dir = f3(0, 0, 1);
-            if (valid) fetchRay(idx, org, dir);
+            if (reach) fetchRay(idx, org, dir);
             if (curK == 0u) {
                 // no mesh is hit, unless a walk says otherwise; the store is COMPLETE before this wave issues an atomic on the word
                 if (FIRST || valid) A.meshHit[idx] = ~0ull;
@@ -251,7 +272,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_mesh_walk(BounceArgs A) {
                 if (rows) { g = A.walkIdx[2 * (l0 + k)]; span = A.walkIdx[2 * (l0 + k) + 1]; }
                 else g = A.walkIdx[l0 + k];
                 const GeomDev &G = A.ggeoms[g];
-                bool want = valid;
+                bool want = reach;
                 if (FIRST && !DOF) {
                     if (rows) want = want & (px >= (span & 0xffff)) & (px <= (span >> 16));
                     else want = want & (px >= G.rect[0]) & (px <= G.rect[2]) & (py >= G.rect[1]) & (py <= G.rect[3]);
