@@ -329,8 +329,14 @@ __global__ __launch_bounds__(kBlock, 8) void k_mesh_walk(BounceArgs A) {
             if (pending) {
                 pending = false;
                 if (keyT != 0xffffffffu) {
+                    // (the ray's origin in the world: the eye for pinhole camera rays, else the first of the path's two 16-byte words)
                     F3 org, dir;
-                    fetchRay(jobIdx, org, dir);
+                    if (FIRST && !DOF) org = f3(prm.pos[0], prm.pos[1], prm.pos[2]);
+                    else if (FIRST) fetchRay(jobIdx, org, dir);
+                    else {
+                        const float4 a = *reinterpret_cast<const float4 *>(A.in.arrA(jobIdx));
+                        org = f3(a.x, a.y, a.z);
+                    }
                     const WalkMesh &G = s_mesh[jobGeom];
                     const F3 P = mulMV(G.xf, getPointOnRay(ro, rd, __uint_as_float(keyT)), 1.0f);
                     const float t = length(org - P);
