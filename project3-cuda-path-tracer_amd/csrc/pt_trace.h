@@ -461,7 +461,7 @@ static_assert(sizeof(CullGroup) == 32 && offsetof(GeomDev, cullFlags) - offsetof
 // spheres runs exactly the code of rounds 2-4.
 template <bool FIRST, bool MANY, bool DOF = false, bool MESH = false, bool PLAIN = false, bool CUBES = false>
 #ifndef PT_MESH_WG_FIRST
-#define PT_MESH_WG_FIRST 6
+#define PT_MESH_WG_FIRST 7
 #define PT_MESH_WG_NEXT 7
 #endif
 __global__ __launch_bounds__(kBlock, (MANY && CUBES) ? 4 : (MESH ? (MANY ? 4 : (FIRST ? PT_MESH_WG_FIRST : PT_MESH_WG_NEXT)) : (DOF ? 5 : (MANY ? (FIRST ? 7 : 6) : 8)))) void k_bounce(BounceArgs argsByValue) {
