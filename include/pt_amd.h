@@ -124,9 +124,10 @@ typedef struct PtOptions {
 
 #define PT_MAX_DEPTH 62
 #define PT_MAX_BATCH 256
-/* Bumped whenever a struct of this header changes size or meaning (5: round 5 -- contexts and groups; PtMesh has carried `normals` and
- * `materials` since 4).  A host built against another header finds out with pt_abi_version() != PT_AMD_ABI_VERSION before it passes structs. */
-#define PT_AMD_ABI_VERSION 5
+/* Bumped whenever a struct of this header changes size or meaning (6: round 6 -- pt_group_iterate / pt_group_reduce, the group's asynchronous
+ * assembly; 5: contexts and groups; PtMesh has carried `normals` and `materials` since 4).  A host built against another header finds out with
+ * pt_abi_version() != PT_AMD_ABI_VERSION before it passes structs. */
+#define PT_AMD_ABI_VERSION 6
 int pt_abi_version(void);
 
 typedef struct PtCounters {
@@ -242,16 +243,36 @@ typedef struct PtContext PtContext;
 PtContext *pt_ctx_create(void);               /* NULL: out of memory */
 int        pt_ctx_make_current(PtContext *ctx /* NULL = the default context */);
 PtContext *pt_ctx_current(void);              /* NULL = the default context */
-int        pt_ctx_destroy(PtContext *ctx);
+int        pt_ctx_destroy(PtContext *ctx);    /* PT_ERR_INVALID while the context is current on ANOTHER thread (that thread's next call
+                                                 would act on freed memory); the caller's own current context may be destroyed: the
+                                                 thread falls back to the default one.  The current HIP device is left as it was. */
 
 /* A GROUP: n contexts that render the row shards y % n of ONE frame, member i on devices[i] (NULL: device i % pt_device_count()) -- the
- * node's GPUs side by side in one host process, or several renderers on one device.  Pixels are seeded by their global index, so the
- * shards together are the one-device frame bit for bit.  pt_group_init = pt_init on every member (opts' shard_rank / shard_count /
- * device / stream / accum_dev are the group's to set; max_batch, pipeline_depth, flags and the lens apply to each member);
- * pt_group_iterate_batch enqueues every member's batch (asynchronous: the devices run concurrently); pt_group_readback waits and
- * assembles the frame's running sum on the host: by ONE ncclReduce(sum) of zero-padded full frames to member 0's device over xGMI
- *  when the members sit on distinct devices and librccl.so can be loaded -- pt_group_collective() = "rccl reduce" -- else by
- * copying every shard's rows to the host ("host gather").  PT_AMD_COLLECTIVE=host|rccl overrides (rccl: even for one member). */
+ * node's GPUs side by side in one host process ("single process, ncclCommInitAll, one stream per device"; the reference is
+ * hard-wired to device 0, src/preview.cpp:107), or several renderers on one device.  Pixels are seeded by their global index, so the shards
+ * together are the one-device frame bit for bit.  Every member's launches are enqueued by a host thread of its own.
+ *   pt_group_init            = pt_init on every member (opts' shard_rank / shard_count / device / stream / accum_dev are the group's to set;
+ *                              max_batch, pipeline_depth, flags and the lens apply to each member).  The members on one device commit their rows
+ *                              into ONE zero-padded full-frame accumulator of that device.
+ *   pt_group_iterate_batch   enqueues every member's wavefront batch (asynchronous: the devices run concurrently).
+ *   pt_group_reduce          assembles the frame from what has been committed so far, asynchronously: members on DISTINCT devices (and
+ *                              librccl.so loadable: dlopen, never linked) by ONE ncclReduce(sum, float32, 3 W H, root = member 0's device) over
+ *                              xGMI of double-buffered snapshots of the devices' accumulators on a collective stream per device -- the next
+ *                              iteration's commits wait on the device for the snapshot only, never for the reduce, and nothing waits on the host;
+ *                              members that all share ONE device need no collective (their accumulator is the frame).
+ *   pt_group_iterate         = pt_group_iterate_batch(frame, iter, 1) + pt_group_reduce: BASELINE config C3 as written -- the reference's
+ *                              per-iteration full-frame transfer (src/pathtrace.cu:170-171, src/main.cpp:97-106) with the reduce in its place.
+ *                              With PT_FLAG_TRACE_AHEAD in opts->flags the iteration comes out of batches traced ahead (one small commit per call).
+ *   pt_group_readback        the latest assembled frame's running sum on the host (assembling first if commits were enqueued since): one D2H copy
+ *                              on the root's collective stream and a wait for THAT stream -- not for the batches traced ahead.
+ *   pt_group_sync            waits for every member's streams and the collective streams; reports a member's device fault.
+ * pt_group_collective() says how the frame is assembled: "rccl reduce ..." (with "unmeasured across devices": NO multi-GPU node was
+ * available to any build round -- the leg has run in a one-rank communicator only), "shared accumulator" (one device) or "host gather"
+ * (several devices without RCCL: every device's frame copied to the host, rows taken from their owners; synchronous).
+ * PT_AMD_COLLECTIVE=host|rccl overrides (rccl: a one-rank communicator even when every member shares one device);
+ * PT_AMD_GROUP_THREADS=0 issues every member's work from the calling thread (experiments).
+ * A failed ncclReduce leaves RCCL's call group closed (ncclGroupEnd runs on every path) and the group usable: a later call tries again.
+ * A group the host forgets to destroy is destroyed by the library's exit handler. */
 typedef struct PtGroup PtGroup;
 int  pt_group_create(PtGroup **out, int n, const int32_t *devices /* may be NULL */);
 void pt_group_destroy(PtGroup *g);
@@ -261,6 +282,8 @@ int  pt_group_set_meshes(PtGroup *g, const PtMesh *meshes, int nmeshes);
 int  pt_group_init(PtGroup *g, const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMaterial *mats, int nmats, int traceDepth,
                    const PtOptions *opts /* may be NULL */);
 int  pt_group_iterate_batch(PtGroup *g, int frame, int first_iter, int count);
+int  pt_group_iterate(PtGroup *g, int frame, int iter);
+int  pt_group_reduce(PtGroup *g);
 int  pt_group_sync(PtGroup *g);
 int  pt_group_readback(PtGroup *g, float *rgb_sum_host);
 int  pt_group_counters(PtGroup *g, PtCounters *out);      /* summed over the members; iterations: the least any member has committed */

@@ -118,6 +118,9 @@ int pt_test_box_fast_sweep(const PtGeom *geoms, int ngeoms, uint64_t seed, int64
 int pt_test_unscaled_sqrt_sweep(uint64_t mismatches[4]);
 /* sets the renderer's device fault word by hand (2; 0 clears it in every slot), so that the reporting path can be tested */
 int pt_test_force_fault(int which);
+/* the next `count` assemblies of the group issue their ncclReduce with a NULL communicator (ncclInvalidArgument): the error path of
+ * pt_group_reduce / pt_group_iterate / pt_group_readback -- ncclGroupEnd must still run and a later call must succeed */
+int pt_test_group_fail_next_reduce(PtGroup *g, int count);
 int pt_test_hemisphere(const float *normals3, const int32_t *iter_index_depth3, int n, float *out3);
 int pt_test_sincos(const float *x, int n, float *s, float *c);
 int pt_test_pow(const float *x, const float *e, int n, float *out);   /* build-defined x^e of the imperfect-specular sampler */

@@ -56,9 +56,9 @@ ABI_SYMBOLS = [
     "pt_scan_exclusive_i32", "pt_compact_nonzero_i32", "pt_pin_host", "pt_unpin_host", "pt_set_meshes", "pt_set_meshes_sized", "pt_abi_version",
     "pt_ctx_create", "pt_ctx_make_current", "pt_ctx_current", "pt_ctx_destroy",
     "pt_group_create", "pt_group_destroy", "pt_group_size", "pt_group_collective", "pt_group_set_meshes", "pt_group_init", "pt_group_iterate_batch",
-    "pt_group_sync", "pt_group_readback", "pt_group_counters",
+    "pt_group_iterate", "pt_group_reduce", "pt_group_sync", "pt_group_readback", "pt_group_counters",
 ]
-PT_AMD_ABI_VERSION = 5
+PT_AMD_ABI_VERSION = 6
 # every symbol include/pt_amd_test.h declares: libpt_amd_test.so only -- the product library must NOT export them
 TEST_ABI_SYMBOLS = [
     "pt_debug_trace_paths",
@@ -67,6 +67,7 @@ TEST_ABI_SYMBOLS = [
     "pt_test_force_fault", "pt_test_pow", "pt_test_wall_box_sweep", "pt_test_mesh_intersect", "pt_test_mesh_bvh",
     "pt_test_mesh_cull_sweep", "pt_test_camera_cull_sweep", "pt_test_camera_cull_tables",
     "pt_test_wall_plane_sweep", "pt_test_wall_planes", "pt_test_sphere_halfline_sweep", "pt_test_sphere_cluster_sweep", "pt_test_sphere_clusters", "pt_test_camera_cull_margin",
+    "pt_test_group_fail_next_reduce",
 ]
 
 
@@ -133,6 +134,8 @@ def _bind(L, with_tests):
     L.pt_group_set_meshes.argtypes = [vp, C.POINTER(PtMesh), i32]
     L.pt_group_init.argtypes = [vp, vp, vp, i32, vp, i32, i32, C.POINTER(PtOptions)]
     L.pt_group_iterate_batch.argtypes = [vp, i32, i32, i32]
+    L.pt_group_iterate.argtypes = [vp, i32, i32]
+    L.pt_group_reduce.argtypes = [vp]
     L.pt_group_sync.argtypes = [vp]
     L.pt_group_readback.argtypes = [vp, vp]
     L.pt_group_counters.argtypes = [vp, C.POINTER(PtCounters)]
@@ -164,6 +167,7 @@ def _bind(L, with_tests):
         L.pt_test_camera_cull_margin.argtypes = [vp, vp, i32, i32, C.POINTER(C.c_double), u64p]
         L.pt_test_wall_plane_sweep.argtypes = [vp, i32, C.c_uint64, i64, C.POINTER(C.c_int32)] + [u64p] * 3
         L.pt_test_wall_planes.argtypes = [vp, i32, vp, vp] + [C.POINTER(C.c_int32)] * 3
+        L.pt_test_group_fail_next_reduce.argtypes = [vp, i32]
     return L
 
 
@@ -516,6 +520,14 @@ class Group:
 
     def iterate_batch(self, first_iteration, count, frame=0):
         _check(lib().pt_group_iterate_batch(self.handle, frame, first_iteration, count))
+
+    def iterate(self, iteration, frame=0):
+        """config C3 as written: one iteration on every member, then the frame's (asynchronous) assembly"""
+        _check(lib().pt_group_iterate(self.handle, frame, iteration))
+
+    def reduce(self):
+        """assemble the frame from what has been committed so far (asynchronous)"""
+        _check(lib().pt_group_reduce(self.handle))
 
     def sync(self):
         _check(lib().pt_group_sync(self.handle))

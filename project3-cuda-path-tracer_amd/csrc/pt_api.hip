@@ -16,6 +16,10 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <thread>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -23,6 +27,7 @@
 #include <cstring>
 #include <deque>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -161,6 +166,9 @@ thread_local State *t_ctx = &g_default;
 inline State &R() { return *t_ctx; }
 std::mutex g_ctxMutex;                    // guards g_contexts
 std::vector<State *> g_contexts;          // every context pt_ctx_create made and pt_ctx_destroy has not released (the exit handler frees their renderers)
+std::mutex g_groupMutex;                  // guards g_groups
+std::vector<PtGroup *> g_groups;          // every group pt_group_create made and pt_group_destroy has not released (the exit handler destroys them:
+                                          // their issuing threads, communicators, streams and frame buffers -- pt_group.h)
 
 const ptm::HostMesh *mesh_of(int geom) {
     for (const ptm::HostMesh &m : R().meshes)
@@ -290,18 +298,22 @@ int launch_bounce(Slot &sl, int iter, int batch, int depth, bool lastBounce, flo
 // scan library workspace: the chunk totals, one buffer per stream (calls on different streams may overlap; calls on one
 // stream are ordered, so they share it)
 struct ScanWs {
+    int device = -1;                 // the device the buffers live on
     uint32_t *partial = nullptr;     // [kScanChunksMax + 1]
     unsigned long long *chained = nullptr;   // k_scan_chained: {ticket, sums[kScanChunksMax]}
     uint32_t gen = 0;                // calls of the chained scan on this stream (tags the sums; never 0)
 };
-std::map<hipStream_t, ScanWs> g_scan;
+std::map<std::pair<int, hipStream_t>, ScanWs> g_scan;   // per (device, stream): the NULL stream -- or an equal handle -- of another device is another workspace
 std::mutex g_scanMutex;              // the scan library may be called from several host threads (one stream each)
 
 // The caller HOLDS g_scanMutex from here until its launches that use the workspace are enqueued: pt_free, which releases the
 // workspaces, takes the same lock first and then waits for the device -- so a workspace is never freed between its look-up and the
 // kernels that use it (round 3 handed the pointer out of the lock: a second host thread could enqueue on freed memory).
 int scan_ws(hipStream_t st, ScanWs **out) {
-    ScanWs &W = g_scan[st];          // (std::map: the reference stays valid while other streams are added)
+    int dev = 0;
+    HIPCHECK(hipGetDevice(&dev));    // the device current at the call: where the caller's buffers live and the kernels will run
+    ScanWs &W = g_scan[std::make_pair(dev, st)];          // (std::map: the reference stays valid while other streams are added)
+    W.device = dev;
     if (!W.partial) HIPCHECK(hipMalloc(&W.partial, (size_t)(kScanChunksMax + 1) * sizeof(uint32_t)));
     if (!W.chained) {
         HIPCHECK(hipMalloc(&W.chained, (size_t)(kScanChunksMax + 1) * sizeof(unsigned long long)));
@@ -316,12 +328,19 @@ int scan_ws(hipStream_t st, ScanWs **out) {
 void scan_release() {
     std::lock_guard<std::mutex> lock(g_scanMutex);
     if (g_scan.empty()) return;
-    (void)hipDeviceSynchronize();
-    for (auto &kv : g_scan) {
+    int cur = -1, synced = -1;
+    (void)hipGetDevice(&cur);
+    for (auto &kv : g_scan) {        // (ordered by device: every device that owns a workspace is waited for once, then its buffers go)
+        if (kv.second.device != synced) {
+            (void)hipSetDevice(kv.second.device);
+            (void)hipDeviceSynchronize();
+            synced = kv.second.device;
+        }
         if (kv.second.partial) (void)hipFree(kv.second.partial);
         if (kv.second.chained) (void)hipFree(kv.second.chained);
     }
     g_scan.clear();
+    if (cur >= 0) (void)hipSetDevice(cur);
 }
 bool scan_in_use() {
     std::lock_guard<std::mutex> lock(g_scanMutex);
@@ -452,8 +471,18 @@ int discard_ahead() {
 // this handler is registered after the library's first HIP call, and exit handlers run in reverse order of registration --
 // so that no launch of this process is still executing when its queues, its code object and its memory go away.
 extern "C" void pt_free(void);
+extern "C" void pt_group_destroy(PtGroup *g);
 void free_renderer();
 void exit_handler() {
+    for (;;) {                                    // groups the host forgot: their members' renderers, threads, RCCL communicators, buffers
+        PtGroup *g = nullptr;
+        {
+            std::lock_guard<std::mutex> lock(g_groupMutex);
+            if (!g_groups.empty()) g = g_groups.back();
+        }
+        if (!g) break;
+        pt_group_destroy(g);
+    }
     pt_free();                                    // the calling thread's current context (normally the default one) + the scan library
     std::vector<State *> all;
     {
@@ -468,11 +497,8 @@ void exit_handler() {
     t_ctx = &g_default;
 }
 void register_exit_handler() {
-    static bool done = false;
-    if (!done) {
-        done = true;
-        atexit(exit_handler);
-    }
+    static std::once_flag once;                   // (several host threads may drive contexts of their own)
+    std::call_once(once, [] { atexit(exit_handler); });
 }
 
 template <typename T>
@@ -509,7 +535,7 @@ namespace {
 // everything pt_init allocated (pt_free, and pt_init's own restart)
 void free_renderer() {
     // pathtraceFree before the first Init (src/main.cpp:91-94) must be a no-op
-    if (!R().init && !R().image && !R().dgeoms && R().nslots == 0 && !R().hostFault) return;
+    if (!R().init && !R().image && !R().dgeoms && R().nslots == 0 && !R().hostFault && !R().pinnedHost) return;
     if (R().device >= 0 && R().nslots > 0) (void)hipSetDevice(R().device);     // (a host that switched devices in between)
     for (int i = 0; i < kMaxSlots; ++i)
         if (R().slot[i].stream) (void)hipStreamSynchronize(R().slot[i].stream);
@@ -1287,7 +1313,7 @@ int pt_iterate(int frame, int iter, void *rgba8_dev) { return pt_iterate_batch(f
 int pt_sync(void) {
     if (!R().init) {
         if (!scan_in_use()) return fail(PT_ERR_NOT_INIT, "pt_sync before pt_init");
-        HIPCHECK(hipDeviceSynchronize());          // the scan library alone
+        HIPCHECK(hipDeviceSynchronize());          // the scan library alone (the current device's calls)
         return PT_OK;
     }
     return check_device_fault();
@@ -1362,7 +1388,8 @@ int pt_counters(PtCounters *out) {
     rc = resolve_events(R().evBounce, R().msBounce, R().nBounce);
     if (rc) return rc;
     memset(out, 0, sizeof *out);
-    static Ctrl h;   // 0.5 MB: keep it off the stack
+    std::unique_ptr<Ctrl> hp(new Ctrl);   // 2 MB: off the stack, and not shared by the host threads that drive other contexts
+    Ctrl &h = *hp;
     uint32_t faultBits = 0;
     for (int i = 0; i < R().nslots; ++i) {
         HIPCHECK(hipMemcpy(&h, R().slot[i].ctrl, sizeof h, hipMemcpyDeviceToHost));

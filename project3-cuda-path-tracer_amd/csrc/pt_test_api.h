@@ -120,6 +120,12 @@ int pt_test_force_fault(int which) {
 #define DOWN(host, buf, count) HIPCHECK(hipMemcpy(host, buf.p, (size_t)(count) * sizeof(*buf.p), hipMemcpyDeviceToHost))
 #define GRID(n) dim3(((n) + 255) / 256), dim3(256), 0, 0
 
+int pt_test_group_fail_next_reduce(PtGroup *g, int count) {
+    if (!g || count < 0) return fail(PT_ERR_INVALID, "pt_test_group_fail_next_reduce: bad argument");
+    g->failReduces = count;
+    return PT_OK;
+}
+
 int pt_test_utilhash(const uint32_t *in, uint32_t *out, int n) {
     NEED_GPU();
     if (n <= 0) return PT_OK;

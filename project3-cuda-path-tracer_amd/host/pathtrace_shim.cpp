@@ -100,7 +100,8 @@ void pathtraceInit(Scene *scene) {
     checkPtError(status, "pathtraceInit");
     // state.image is owned by the Scene and lives from Init to Free: page-lock it for the per-iteration copy below
     // (an optimisation only; failure to register is not an error of the renderer)
-    if (!group && !scene->state.image.empty())
+    // (a group's read-back copies into the same buffer: the registration is process-wide, made through the default context)
+    if (!scene->state.image.empty())
         (void)pt_pin_host(scene->state.image.data(), scene->state.image.size() * sizeof(scene->state.image[0]));
 }
 
@@ -126,7 +127,9 @@ void pathtrace(uchar4 *pbo, int frame, int iter) {
             fprintf(stderr, "HIP error (pathtrace_shim.cpp): pathtrace: PT_AMD_DEVICES renders headless (pbo must be NULL)\n");
             exit(EXIT_FAILURE);
         }
-        checkPtError(pt_group_iterate_batch(group, frame, iter, 1), "pathtrace");
+        // one iteration on every member and the frame's reduce (asynchronous: the members go on tracing ahead), then the copy of the
+        // reduced frame, which waits for the collective stream alone
+        checkPtError(pt_group_iterate(group, frame, iter), "pathtrace");
         checkPtError(pt_group_readback(group, reinterpret_cast<float *>(hst_scene->state.image.data())), "pathtrace");
         return;
     }

@@ -61,6 +61,19 @@ assert L.pt_iterate_batch(0, 33, 32, None) == 0
 assert not pt._atexit_registered
 """
 
+# a GROUP the host forgets (round 6): three members with an issuing thread each, the frame's assembly through a one-rank RCCL
+# communicator, batches traced ahead -- the library's exit handler stops the threads, frees the members and the communicator
+CHILD_FORGETS_GROUP = PRELUDE + r"""
+os.environ["PT_AMD_COLLECTIVE"] = "rccl"
+g = pt.Group(3)
+g.init(sc, traceDepth=8, flags=pt.PT_FLAG_TRACE_AHEAD, pipeline_depth=2, max_batch=32)
+for it in range(1, 4):
+    g.iterate(it)
+img = g.readback()
+assert img.max() > 0
+# the main module ends here: no sync, no pt_group_destroy
+"""
+
 CHILD_FOLLOWING = PRELUDE + r"""
 pt.pathtraceInit(sc, traceDepth=8, pipeline_depth=2, max_batch=32)
 pt.pathtrace_batch(None, 0, 1, 32)
@@ -107,6 +120,11 @@ def test_processes_that_leave_with_batches_in_flight(pt, tmp_path):
     _no_dump(r)
     # 3. the raw C ABI without the package's hook: the library's exit handler alone
     r = _run(CHILD_RAW_ABI)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert _clean(r.stderr) == [], r.stderr[-2000:]
+    _no_dump(r)
+    # 4. a group nobody destroyed: member threads, RCCL communicator, batches traced ahead
+    r = _run(CHILD_FORGETS_GROUP)
     assert r.returncode == 0, r.stderr[-2000:]
     assert _clean(r.stderr) == [], r.stderr[-2000:]
     _no_dump(r)
