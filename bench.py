@@ -114,6 +114,19 @@ def parse(argv=None):
                     help="what `roofline` prices the bounce kernel against: the 8 TB/s of HBM (the contract's bound; C2, C4, meshes) or the vector "
                          "units' fp32 issue rate (SURVEY 8d: the 64-sphere configuration C5 is VALU-bound; needs that configuration's counters, --pmc-key)")
     ap.add_argument("--pmc-key", default=None, help="take the PMC counters from profiles/pmc_configs.json[<key>] instead of --pmc-traffic-json")
+    ap.add_argument("--group-blocks", type=int, default=None,
+                    help="1: also measure the C ABI's device groups in child processes (`--group`): at N = 1 eight members on the one device and config C3 as "
+                         "written through the library's own collective, at N > 1 a group over the N devices beside the ranks' reading.  Default: as --configs "
+                         "at N = 1, as --extra-passes at N > 1")
+    ap.add_argument("--group", type=int, default=0,
+                    help="M > 0: measure the C ABI's own multi-device host path instead of the ranks -- ONE process, a pt_group of M members (include/pt_amd.h: "
+                         "pt_group_*; SURVEY 8e: single process, ncclCommInitAll, one stream per device), member i on device i %% --group-devices, a host thread "
+                         "per member, the frame assembled by the library's own collective after every wavefront batch -- and print that block's JSON line "
+                         "(bench.py runs itself this way as a child process for the `group` blocks of the driver's line)")
+    ap.add_argument("--group-devices", type=int, default=0, help="--group: distinct HIP devices the members are dealt over (0: min(M, devices visible))")
+    ap.add_argument("--group-c3", type=int, default=0,
+                    help="--group: 1 = config C3 as written instead of the batch mode: one pt_group_iterate (one iteration out of batches traced ahead on every "
+                         "member + the frame's reduce) per ITERATION")
     return ap.parse_args(argv)
 
 
@@ -357,6 +370,144 @@ def valu_issue_rate(path, waves_per_simd):
     return {"mix": mix[0], "fma": fma[0], "waves_per_simd": mix[1]}
 
 
+def run_group(args):
+    """`bench.py --group M`: the hot path through the C ABI's device groups, one process.  A step is `--batch` x D iterations of the whole frame
+    (D = distinct devices: the weak reading of bench.py; on ONE device a step is the single GPU's step, its rows divided over the members);
+    the members trace it in wavefront batches of min(PT_MAX_BATCH, --batch x M) iterations (a member's launch then carries as many paths as
+    the single GPU's, capped by PT_MAX_BATCH -- the ranks of `--gpus N` fuse steps the same way), pt_group_reduce after every batch.
+    Timed like the headline: `--warmup` steps, then `--repeats` blocks of EXACTLY `--steps` steps between pt_group_sync on both sides."""
+    import numpy as np
+    import __graft_entry__ as ge
+    pt = ge.load_package()
+    ndev_visible = pt.device_count()
+    if ndev_visible < 1:
+        print("bench.py --group needs a GPU (the hot path has no CPU fallback)", file=sys.stderr)
+        return 1
+    M = args.group
+    nd = args.group_devices if args.group_devices > 0 else min(M, ndev_visible)
+    if nd > ndev_visible:
+        print("bench.py --group: %d devices asked for, %d visible" % (nd, ndev_visible), file=sys.stderr)
+        return 2
+    W, H = args.res
+    D, B = args.depth, args.batch
+    steps = args.steps if args.steps is not None else 32
+    warmup = args.warmup if args.warmup is not None else 4
+    scene = pt.Scene(args.scene)
+    scene.set_resolution(W, H)
+    P = W * H
+    I = B * nd                                            # iterations of the whole frame per step
+    g = pt.Group(M, devices=[i % nd for i in range(M)])
+    out = {"members": M, "devices": nd, "members_per_device": (M + nd - 1) // nd, "collective": g.collective,
+           "issue_threads": 0 if (M == 1 or os.environ.get("PT_AMD_GROUP_THREADS") == "0") else M}
+    try:
+        if args.group_c3:
+            g.init(scene, traceDepth=D, flags=pt.PT_FLAG_TRACE_AHEAD, pipeline_depth=min(args.pipeline, 2) if args.pipeline > 0 else 2, max_batch=B)
+            it = 1
+            for _ in range(max(warmup, 1) * B):
+                g.iterate(it)
+                it += 1
+            g.sync()
+            walls, enq = [], []
+            for _ in range(args.repeats):
+                t0 = time.perf_counter()
+                for _ in range(steps * I):
+                    g.iterate(it)
+                    it += 1
+                t1 = time.perf_counter()
+                g.sync()
+                t2 = time.perf_counter()
+                walls.append(t2 - t0)
+                enq.append(t1 - t0)
+            walls.sort()
+            dt = walls[len(walls) // 2]
+            out.update({"value": round(P * D * I * steps / dt / 1e6, 2), "unit": "Mpaths/s", "steps": steps, "iterations_per_step": I,
+                        "iterations_per_wavefront_batch": B, "ms_per_step": round(dt / steps * 1e3, 4),
+                        "ms_per_iteration": round(dt / (steps * I) * 1e3, 5), "ms_per_iteration_min": round(walls[0] / (steps * I) * 1e3, 5),
+                        "ms_per_iteration_max": round(walls[-1] / (steps * I) * 1e3, 5), "repeats": len(walls),
+                        "host_enqueue_us_per_iteration": round(sorted(enq)[len(enq) // 2] / (steps * I) * 1e6, 2),
+                        "mode": "strong scaling, one pt_group_iterate per iteration: every member commits one iteration of a wavefront batch traced ahead "
+                                "(PT_FLAG_TRACE_AHEAD) into the accumulator AND into one of two snapshot frames (k_commit), the library's collective "
+                                "reads the snapshot on its own stream"})
+            frame = g.readback()
+        else:
+            maxb = min(pt.PT_MAX_BATCH, B * M)
+            g.init(scene, traceDepth=D, pipeline_depth=min(args.pipeline, 2) if (M > nd and args.pipeline > 0) else args.pipeline, max_batch=maxb)
+
+            def run(first, nsteps):
+                it, end, nb = first, first + nsteps * I, 0
+                while it < end:
+                    n = min(maxb, end - it)
+                    g.iterate_batch(it, n)
+                    g.reduce()
+                    it += n
+                    nb += 1
+                return it, nb
+
+            it, _ = run(1, warmup)
+            g.sync()
+            walls, enq, nb = [], [], 1
+            for _ in range(args.repeats):
+                t0 = time.perf_counter()
+                it, nb = run(it, steps)
+                t1 = time.perf_counter()
+                g.sync()
+                t2 = time.perf_counter()
+                walls.append(t2 - t0)
+                enq.append(t1 - t0)
+            blocks = list(walls)
+            walls.sort()
+            dt = walls[len(walls) // 2]
+            nominal = P * D * I * steps
+            out.update({"value": round(nominal / dt / 1e6, 2), "unit": "Mpaths/s", "value_min": round(nominal / walls[-1] / 1e6, 2),
+                        "value_max": round(nominal / walls[0] / 1e6, 2), "steps": steps, "warmup": warmup, "repeats": len(walls),
+                        "iterations_per_step": I, "iterations_per_wavefront_batch": maxb, "ms_per_step": round(dt / steps * 1e3, 4),
+                        "ms_per_step_blocks": [round(w / steps * 1e3, 4) for w in blocks],
+                        "host_enqueue_us_per_wavefront_batch": round(sorted(enq)[len(enq) // 2] / max(nb, 1) * 1e6, 1),
+                        "gpu_ms_per_wavefront_batch": round(dt / max(nb, 1) * 1e3, 4),
+                        "mode": "%s, pt_group_iterate_batch + pt_group_reduce per wavefront batch" % ("weak scaling over %d devices" % nd if nd > 1 else
+                                                                                                    "one device, its rows divided over the members")})
+            frame = g.readback()
+        c = g.counters()
+        out["iterations_committed"] = int(c.iterations)
+        out["workload"] = "%s %dx%d, %d bounces" % (os.path.relpath(args.scene, ROOT), W, H, D)
+        if args.dump_frame:
+            np.save(args.dump_frame, frame)
+    finally:
+        g.destroy()
+    print(json.dumps(out), flush=True)
+    return 0
+
+
+def group_block(args, members, devices, c3=False, extra_env=None, timeout=300):
+    """one `bench.py --group` child process (its own HIP runtime, queues and device memory); returns its line, or {"error": ...}"""
+    cmd = [sys.executable, os.path.abspath(__file__), "--group", str(members), "--group-devices", str(devices), "--group-c3", "1" if c3 else "0",
+           "--scene", args.scene, "--res", str(args.res[0]), str(args.res[1]), "--depth", str(args.depth), "--batch", str(args.batch),
+           "--steps", str(args.steps), "--warmup", str(args.warmup), "--repeats", str(5 if not c3 else 3), "--pipeline", str(args.pipeline)]
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    env.update(extra_env or {})
+    t0 = time.perf_counter()
+    p = None
+    try:
+        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+        so, se = p.communicate(timeout=timeout)
+        line = [l for l in so.splitlines() if l.startswith("{")]
+        if p.returncode != 0 or not line:
+            return {"error": "rc %d: %s" % (p.returncode, se.strip().splitlines()[-1] if se.strip() else "no output")}
+        d = json.loads(line[-1])
+        d["command"] = "python bench.py " + " ".join(cmd[2:]) + ("" if not extra_env else "   (env: %s)" % " ".join("%s=%s" % kv for kv in sorted(extra_env.items())))
+        d["wall_s_of_the_child_process"] = round(time.perf_counter() - t0, 1)
+        return d
+    except subprocess.TimeoutExpired:
+        if p is not None:
+            p.kill()                                         # (the exact child this call started)
+            p.communicate()
+        return {"error": "no line within %d s: killed" % timeout}
+    except Exception as e:                                   # (an extra block must never cost the line)
+        return {"error": repr(e)}
+
+
 def _on_sigterm(signum, frame):
     # torchrun ends the surviving ranks of a failed job with SIGTERM, which Python does not turn into an exception by itself: raise
     # one, so that main()'s `finally: cleanup()` drains the streams and frees the renderer before the process goes away
@@ -371,6 +522,8 @@ def main():
         d = parse([])
         args.configs = 1 if (args.gpus == 1 and world == 1 and all(getattr(args, k) == getattr(d, k) for k in
                                                                      ("scene", "res", "depth", "batch", "pipeline", "scaling", "cpu_spp", "repeats"))) else 0
+    if args.group > 0:
+        sys.exit(run_group(args))
     if world == 1 and args.gpus > 1:
         self_launch(args)                                   # never returns
     import signal
@@ -681,6 +834,26 @@ def run(args, ctx):
     cnt = Bp["counters"]
     pt.pathtraceFree()
 
+    # ---- the C ABI's own multi-device host path (pt_group_*: ONE process, a host thread and a renderer per member, the library's collective;
+    #      SURVEY 8e), each reading in a child process of its own (`bench.py --group`), while this process's renderers are freed and its ranks wait:
+    #      N = 1: eight members on the one device against the headline, and config C3 as written through the library's own per-iteration reduce
+    #             (a one-rank RCCL communicator: the call path a one-GPU box can run);
+    #      N > 1: rank 0 starts a group over the N devices -- what the reference's single-process host (src/main.cpp:72-113) would drive.
+    groups = None
+    want_groups = args.group_blocks if args.group_blocks is not None else (args.configs if world == 1 else args.extra_passes)
+    if want_groups:
+        barrier()
+        if rank == 0:
+            groups = {}
+            if world == 1:
+                groups["group_8_members_one_device"] = group_block(args, 8, 1)
+                groups["c3_as_written"] = group_block(args, 1, 1, c3=True, extra_env={"PT_AMD_COLLECTIVE": "rccl"})
+            else:
+                nd = min(world, ngpu)
+                groups["group"] = group_block(args, world, nd)
+                groups["group_c3_as_written"] = group_block(args, world, nd, c3=True)
+        barrier()
+
     iters_block = args.steps * I                             # iterations of one timed block
     liveA = [int(cntA.live[d]) for d in range(D + 2)]
     live = [int(cnt.live[d]) for d in range(D + 2)]
@@ -805,6 +978,19 @@ def run(args, ctx):
             out["multi_gpu"] = multi
         if c3 is not None:
             out["value_c3_as_written"] = c3
+        if groups:
+            one = groups.get("group_8_members_one_device")
+            if one and "value" in one:
+                one["of_the_one_context_rate"] = round(one["value"] / out["value"], 4)
+            gc3 = groups.pop("c3_as_written", None)
+            if gc3 is not None and world == 1:
+                # N = 1: the protocol through the LIBRARY's own collective is the reading; the torch.distributed one stands beside it
+                if c3 is not None:
+                    out["value_c3_as_written_torch_distributed"] = c3
+                out["value_c3_as_written"] = gc3
+            out.update(groups)
+            out["multi_device_note"] = ("pt_group's RCCL reduce has only ever run in a ONE-rank communicator: no multi-GPU node was available to any build round; "
+                                        "N > 1 figures of either path are unmeasured unless this line's n_gpus says otherwise")
         out["box_calibration"] = box_calibration(pt, torch)
         tm = telemetry.report() if telemetry else None
         out["box_calibration"]["telemetry_during_timed_blocks"] = tm

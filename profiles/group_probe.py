@@ -19,7 +19,7 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--steps", type=int, default=12)
+ap.add_argument("--steps", type=int, default=16)
 ap.add_argument("--iters", type=int, default=2048)
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--only", default="")
@@ -60,7 +60,18 @@ def one_context(pipeline):
     return rate(best[1], args.steps * B)
 
 
-def group(members, pipeline, threads, collective=None, reduce_every_step=False):
+def group(members, pipeline, threads, collective=None, reduce_every_step=False, fuse=1):
+    """`fuse`: the members trace `fuse` steps as ONE wavefront batch (a member of 8 carries 1/8 of a step's paths per launch: bench.py's ranks
+    fuse steps the same way), the frame reduced per fused batch"""
+    global B
+    B0, B = B, B * fuse
+    try:
+        return _group(members, pipeline, threads, collective, reduce_every_step, fuse)
+    finally:
+        B = B0
+
+
+def _group(members, pipeline, threads, collective, reduce_every_step, fuse):
     os.environ["PT_AMD_GROUP_THREADS"] = "1" if threads else "0"
     if collective:
         os.environ["PT_AMD_COLLECTIVE"] = collective
@@ -77,7 +88,7 @@ def group(members, pipeline, threads, collective=None, reduce_every_step=False):
         best = None
         for _ in range(5):
             t0 = time.perf_counter()
-            for _ in range(args.steps):
+            for _ in range(max(1, args.steps // fuse)):
                 g.iterate_batch(it, B)
                 if reduce_every_step:
                     g.reduce()
@@ -90,9 +101,10 @@ def group(members, pipeline, threads, collective=None, reduce_every_step=False):
         how = g.collective
     finally:
         g.destroy()
-    print("group of %d on one device, pipeline %d, threads %d%s [%s]: %.1f G paths/s, host enqueue %.1f us per step of %d"
-          % (members, pipeline, threads, ", reduce per step" if reduce_every_step else "", how, rate(best[1], args.steps * B), best[0] / args.steps * 1e6, B), flush=True)
-    return rate(best[1], args.steps * B)
+    nb = max(1, args.steps // fuse)
+    print("group of %d on one device, pipeline %d, threads %d%s [%s]: %.1f G paths/s, host enqueue %.1f us per batch of %d"
+          % (members, pipeline, threads, ", reduce per batch" if reduce_every_step else "", how, rate(best[1], nb * B), best[0] / nb * 1e6, B), flush=True)
+    return rate(best[1], nb * B)
 
 
 def c3(members, collective, threads=1, pipeline=2):
@@ -151,6 +163,21 @@ def c3_plain(pipeline=2):
           % (pipeline, best[1] / args.iters * 1e3, rate(best[1], args.iters), best[0] / args.iters * 1e6), flush=True)
 
 
+if args.only == "g8":
+    base = one_context(3)
+    for pl, fuse in ((1, 1), (2, 1), (2, 2), (2, 4), (3, 4), (1, 4)):
+        v = group(8, pl, 1, fuse=fuse)
+        print("    = %.3f of the one-context rate" % (v / base), flush=True)
+    v = group(8, 2, 0, fuse=4)
+    print("    = %.3f of the one-context rate" % (v / base), flush=True)
+    v = group(8, 2, 1, collective="rccl", reduce_every_step=True, fuse=4)
+    print("    = %.3f of the one-context rate" % (v / base), flush=True)
+    sys.exit(0)
+if args.only == "c3":
+    c3_plain()
+    c3(1, "rccl")
+    c3(1, None)
+    sys.exit(0)
 if "a" in (args.only or "ab"):
     base = one_context(3)
     one_context(2)

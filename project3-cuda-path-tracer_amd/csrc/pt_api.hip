@@ -152,6 +152,10 @@ struct State {
     // and pt_readback_rgba8, which synchronise anyway, then report a faulted render without a device-to-host copy of their own.
     uint32_t *hostFault = nullptr;       // host address
     uint32_t *hostFaultDev = nullptr;    // the same word as the kernels address it
+    // device groups (pt_group.h): the full frame the NEXT commit also copies this shard's pixels into (k_commit's `snap`: the snapshot a
+    // frame reduce reads), and the event -- the reduce that last read that buffer -- the commit has to wait for first.  Set per call.
+    float *snapTarget = nullptr;
+    hipEvent_t snapWait = nullptr;
     // triangle soups registered by pt_set_meshes, consumed by the next pt_init (kept across pt_free: the reference's
     // Free -> Init restart protocol re-initialises the same scene)
     std::vector<ptm::HostMesh> meshes;
@@ -434,8 +438,13 @@ int trace_batch(Slot &sl, int first_iter, int count) {
 // iterations [b0, b1) of the slot's batch of `count` into the accumulator (or nowhere: `discard`), on the caller's stream
 int commit_range(Slot &sl, int count, int b0, int b1, bool discard) {
     if (R().nLocal > 0) {
+        float *snap = discard ? nullptr : R().snapTarget;
+        if (snap && R().snapWait) {
+            HIPCHECK(hipStreamWaitEvent(R().stream, R().snapWait, 0));
+            R().snapWait = nullptr;
+        }
         hipLaunchKernelGGL(k_commit, dim3((R().nLocal + kBlock - 1) / kBlock), dim3(kBlock), 0, R().stream, R().prm, R().image, sl.contrib, sl.hitMask,
-                           count, (R().flags & PT_FLAG_ACCUM_SHARD_ROWS) ? 1 : 0, b0, b1, discard ? 1 : 0);
+                           count, (R().flags & PT_FLAG_ACCUM_SHARD_ROWS) ? 1 : 0, b0, b1, discard ? 1 : 0, snap);
         HIPCHECK(hipGetLastError());
     }
     return PT_OK;

@@ -13,14 +13,14 @@
 //     side instead of one after the other (a C2 shard of 1/8 is ~0.24 ms of GPU time per batch of 64 -- less than one thread needs to
 //     enqueue eight members' launches).  PT_AMD_GROUP_THREADS=0: the calling thread issues everything (experiments).
 //   * The frame is ASSEMBLED asynchronously (assemble(); pt_group_iterate / pt_group_reduce / the first pt_group_readback after a batch):
-//       "rccl reduce"         distinct devices, librccl.so loaded (dlopen; single process, ncclCommInitAll): per device, a SNAPSHOT of
-//                             the accumulator into one of two buffers on the device's leader stream (behind its members' commits, by events),
-//                             then ncclReduce(sum, float32, 3 W H, root = member 0's device) of the snapshots on the device's collective stream
-//                             into one of two result buffers -- x + 0 is exact: disjoint rows.  Nothing waits on the host: the next
-//                             iteration's commits wait (on the device) for the snapshot only, the reduce of iteration i runs while
-//                             iteration i + 1 is committed and the batches traced ahead keep tracing; a buffer is reused two calls later
-//                             behind its reduce's event.  pt_group_readback = one D2H copy of the latest result on the root's collective
-//                             stream + a wait for THAT stream only.
+//       "rccl reduce"         distinct devices, librccl.so loaded (dlopen; single process, ncclCommInitAll): every member's commit
+//                             ALSO writes its rows' new values into one of two SNAPSHOT frames of its device (k_commit's `snap`: the
+//                             accumulator is read once, for the addition and the copy), then ONE ncclReduce(sum, float32, 3 W H, root =
+//                             member 0's device) of the snapshots, in place at the root, on the device's collective stream behind the
+//                             members' commit events -- x + 0 is exact: disjoint rows.  Nothing waits on the host: the reduce of
+//                             iteration i runs while iteration i + 1 is committed into the OTHER snapshot and the batches traced ahead keep
+//                             tracing; a snapshot is written again two calls later, behind its reduce's event.  pt_group_readback = one
+//                             D2H copy of the latest reduced snapshot on the root's collective stream + a wait for THAT stream only.
 //       "shared accumulator"  every member on ONE device: the accumulator is the frame; readback copies it behind the members' commit events.
 //       "host gather"         several devices without RCCL (PT_AMD_COLLECTIVE=host, no librccl.so): every device's frame is copied to the host
 //                             and the rows are taken from their owners' (synchronous; a fallback).
@@ -196,11 +196,10 @@ struct Worker {
 // what a group holds per DISTINCT device
 struct GroupDevice {
     int device = 0;
-    std::vector<int> members;              // indices into PtGroup::ctx; members[0] is the LEADER: the snapshot is taken on its stream
+    std::vector<int> members;              // indices into PtGroup::ctx
     float *full = nullptr;                 // the zero-padded full-frame accumulator the members on this device commit into
-    float *snap[2] = {nullptr, nullptr};   // rccl: the reduce reads a snapshot, so that the next iteration's commits need not wait for it
+    float *snap[2] = {nullptr, nullptr};   // rccl: the members' commits copy their rows here (k_commit's `snap`); the reduce reads -- at the root: in place
     hipStream_t coll = nullptr;            // the collective's stream (and the read-back's)
-    hipEvent_t evSnap[2] = {nullptr, nullptr};    // snapshot k taken (leader stream)
     hipEvent_t evRed[2] = {nullptr, nullptr};     // the reduce that read snapshot k is through (collective stream)
     void *comm = nullptr;                  // ncclComm_t
 };
@@ -215,7 +214,7 @@ struct PtGroup {
     std::vector<std::unique_ptr<Worker>> worker;   // [n] or empty (PT_AMD_GROUP_THREADS=0, one member)
     std::vector<GroupDevice> dev;          // distinct devices, dev[0] = member 0's = the reduce's root
     bool rccl = false;                     // the frame is assembled by ncclReduce (else: shared accumulator / on the host)
-    float *reduced[2] = {nullptr, nullptr};   // rccl: the reduce's result on dev[0], double-buffered (read-back of frame i beside the reduce of i + 1)
+    std::vector<char> waitRed;             // [n] rccl: the member's next commit writes a snapshot a reduce may still be reading: wait for evRed first
     int W = 0, H = 0;
     bool inited = false;
     bool dirty = false;                    // commits were enqueued since the frame was last assembled
@@ -258,9 +257,6 @@ void group_release_buffers(PtGroup *g) {
         for (int q = 0; q < 2; ++q)
             if (d.snap[q]) { (void)hipFree(d.snap[q]); d.snap[q] = nullptr; }
     }
-    if (!g->dev.empty()) (void)hipSetDevice(g->dev[0].device);
-    for (int q = 0; q < 2; ++q)
-        if (g->reduced[q]) { (void)hipFree(g->reduced[q]); g->reduced[q] = nullptr; }
     g->inited = false;
     g->dirty = false;
     g->last = -1;
@@ -268,7 +264,6 @@ void group_release_buffers(PtGroup *g) {
 
 // Assemble the frame from what the members have committed so far -- asynchronously: nothing here waits on the host.
 int assemble(PtGroup *g) {
-    const size_t frameBytes = (size_t)g->W * g->H * 3 * sizeof(float);
     const int k = g->k;
     if (!g->rccl) {
         // shared accumulator / host gather: the accumulators ARE the frame's parts; the read-back orders itself behind the commits
@@ -279,17 +274,11 @@ int assemble(PtGroup *g) {
         g->dirty = false;
         return PT_OK;
     }
-    // 1. per device: the snapshot, on the leader's stream, behind every co-member's commits and behind the reduce that last read the buffer
+    if (!g->dirty && g->last >= 0) return PT_OK;                 // nothing was committed since the last assembly: its frame stands
+    // 1. per device: the collective stream behind the commits that wrote snapshot k (every member's last call wrote its rows there)
     for (GroupDevice &d : g->dev) {
         HIPCHECK(hipSetDevice(d.device));
-        const hipStream_t lead = g->stream[d.members[0]];
-        for (size_t q = 1; q < d.members.size(); ++q) HIPCHECK(hipStreamWaitEvent(lead, g->evCommit[d.members[q]], 0));
-        HIPCHECK(hipStreamWaitEvent(lead, d.evRed[k], 0));
-        HIPCHECK(hipMemcpyAsync(d.snap[k], d.full, frameBytes, hipMemcpyDeviceToDevice, lead));
-        HIPCHECK(hipEventRecord(d.evSnap[k], lead));
-        // (the co-members' NEXT commits must not run under the copy: their streams wait for it; the leader's own follow in stream order)
-        for (size_t q = 1; q < d.members.size(); ++q) HIPCHECK(hipStreamWaitEvent(g->stream[d.members[q]], d.evSnap[k], 0));
-        HIPCHECK(hipStreamWaitEvent(d.coll, d.evSnap[k], 0));
+        for (int m : d.members) HIPCHECK(hipStreamWaitEvent(d.coll, g->evCommit[m], 0));
     }
     // 2. ONE ncclReduce(sum) of the snapshots to dev[0].  No early return between GroupStart and GroupEnd: the first error is
     //    kept, the group is always closed, then the call fails -- an open RCCL group would swallow every later collective of the process.
@@ -300,14 +289,14 @@ int assemble(PtGroup *g) {
             GroupDevice &d = g->dev[di];
             if (hipSetDevice(d.device) != hipSuccess) { rHip = 1; continue; }
             void *comm = g->failReduces > 0 ? nullptr : d.comm;
-            const int ri = rc_.Reduce(d.snap[k], di == 0 ? g->reduced[k] : nullptr, (size_t)g->W * g->H * 3, kNcclFloat, kNcclSum, 0, comm, d.coll);
+            const int ri = rc_.Reduce(d.snap[k], di == 0 ? d.snap[k] : nullptr, (size_t)g->W * g->H * 3, kNcclFloat, kNcclSum, 0, comm, d.coll);
             if (ri != 0 && r == 0) r = ri;
         }
         const int r2 = rc_.GroupEnd();
         if (r == 0) r = r2;
     }
     if (g->failReduces > 0) --g->failReduces;
-    // (an error leaves the snapshot's events recorded and nothing enqueued on the collective streams: the next call starts clean)
+    // (an error leaves the snapshot as the commits wrote it and nothing but waits on the collective streams: the next call tries again)
     if (r != 0 || rHip) return fail(PT_ERR_HIP, "pt_group: ncclReduce failed: %s", rHip ? "hipSetDevice" : rc_.GetErrorString(r));
     for (GroupDevice &d : g->dev) {
         HIPCHECK(hipSetDevice(d.device));
@@ -316,6 +305,35 @@ int assemble(PtGroup *g) {
     g->last = k;
     g->k = k ^ 1;
     g->dirty = false;
+    std::fill(g->waitRed.begin(), g->waitRed.end(), 1);      // snapshot k ^ 1 was last read by the reduce before this one
+    return PT_OK;
+}
+}  // namespace
+
+namespace {
+// the collective's streams, events and RCCL's communicator: once per group, behind the members' first pt_init (see pt_group_create)
+int ensure_collective(PtGroup *g) {
+    for (GroupDevice &d : g->dev) {
+        if (d.coll) continue;
+        HIPCHECK(hipSetDevice(d.device));
+        HIPCHECK(hipStreamCreateWithFlags(&d.coll, hipStreamNonBlocking));
+        for (int q = 0; q < 2; ++q) HIPCHECK(hipEventCreateWithFlags(&d.evRed[q], hipEventDisableTiming));
+    }
+    if (g->rccl && !g->dev[0].comm) {
+        const int nd = (int)g->dev.size();
+        std::vector<void *> comms(nd, nullptr);
+        std::vector<int> devs;
+        for (const GroupDevice &d : g->dev) devs.push_back(d.device);
+        std::lock_guard<std::mutex> lock(g_rcclMutex);
+        const int r = rccl().CommInitAll(comms.data(), nd, devs.data());
+        if (r != 0) {
+            fprintf(stderr, "pt_group_init: ncclCommInitAll failed (%s): the frame is assembled %s\n", rccl().GetErrorString(r), nd > 1 ? "on the host" : "in place");
+            g->rccl = false;
+            g->how = nd > 1 ? "host gather" : "shared accumulator";
+        } else {
+            for (int q = 0; q < nd; ++q) g->dev[q].comm = comms[q];
+        }
+    }
     return PT_OK;
 }
 }  // namespace
@@ -349,19 +367,22 @@ int pt_group_create(PtGroup **out, int n, const int32_t *devices) {
         if (!c) { pt_group_destroy(g); return PT_ERR_INVALID; }
         g->ctx.push_back(c);
     }
-    // streams and events: a stream per member for its commits (NOT the null stream: eight members' commits would queue up on it), a
-    // collective stream per device
+    // Streams.  A process gets FOUR hardware queues per device by default (GPU_MAX_HW_QUEUES), handed to streams as they are created; a
+    // fifth stream shares a queue with an earlier one, and work that shares a queue runs in queue order whatever the streams say: commits
+    // that land behind a tracing stream's bounce launches wait for whole launches (config C3 as written, one member: 0.046 against 0.040 ms
+    // per iteration; 0.053 against 0.0445 with the collective -- profiles/r06_group_experiments.txt).  So: a member that has its device to
+    // itself commits on that device's NULL stream (the renderer's other streams are non-blocking: nothing synchronises with it implicitly),
+    // and everything the collective needs -- its stream, RCCL's communicator with the streams IT creates -- is made AFTER the members'
+    // first pt_init has created their tracing streams (ensure_collective, from pt_group_init): null, two tracing streams, collective.
+    // Members that share a device (the one-GPU rehearsal) get a commit stream each.
     g->stream.assign(n, nullptr);
     g->evCommit.assign(n, nullptr);
     bool ok = true;
-    for (int i = 0; i < n && ok; ++i)
-        ok = hipSetDevice(g->device[i]) == hipSuccess && hipStreamCreateWithFlags(&g->stream[i], hipStreamNonBlocking) == hipSuccess &&
-             hipEventCreateWithFlags(&g->evCommit[i], hipEventDisableTiming) == hipSuccess && hipEventRecord(g->evCommit[i], g->stream[i]) == hipSuccess;
-    for (GroupDevice &d : g->dev) {
-        ok = ok && hipSetDevice(d.device) == hipSuccess && hipStreamCreateWithFlags(&d.coll, hipStreamNonBlocking) == hipSuccess;
-        for (int q = 0; q < 2 && ok; ++q)
-            ok = hipEventCreateWithFlags(&d.evSnap[q], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&d.evRed[q], hipEventDisableTiming) == hipSuccess &&
-                 hipEventRecord(d.evSnap[q], d.coll) == hipSuccess && hipEventRecord(d.evRed[q], d.coll) == hipSuccess;
+    const char *ownStreams = getenv("PT_AMD_GROUP_OWN_STREAMS");      // experiments only
+    for (int i = 0; i < n && ok; ++i) {
+        const bool alone = g->dev[g->devIndex[i]].members.size() == 1 && !(ownStreams && atoi(ownStreams));
+        ok = hipSetDevice(g->device[i]) == hipSuccess && (alone || hipStreamCreateWithFlags(&g->stream[i], hipStreamNonBlocking) == hipSuccess) &&
+             hipEventCreateWithFlags(&g->evCommit[i], hipEventDisableTiming) == hipSuccess;
     }
     if (!ok) {
         pt_group_destroy(g);
@@ -369,6 +390,7 @@ int pt_group_create(PtGroup **out, int n, const int32_t *devices) {
     }
     // RCCL: one rank per DISTINCT device, one process (ncclCommInitAll).  Members that all share one device need no collective
     // (PT_AMD_COLLECTIVE=rccl sends their frame through a one-rank communicator all the same: the call path on a one-GPU box).
+    // The library is loaded here -- pt_group_collective() answers from now on --, the communicator is made by the first pt_group_init.
     const char *want = getenv("PT_AMD_COLLECTIVE");
     const bool forbid = want && !strcmp(want, "host");
     const bool force = want && !strcmp(want, "rccl");
@@ -377,17 +399,8 @@ int pt_group_create(PtGroup **out, int n, const int32_t *devices) {
     if (!forbid && (nd > 1 || force)) {
         std::lock_guard<std::mutex> lock(g_rcclMutex);
         if (rccl().load()) {
-            std::vector<void *> comms(nd, nullptr);
-            std::vector<int> devs;
-            for (const GroupDevice &d : g->dev) devs.push_back(d.device);
-            const int r = rccl().CommInitAll(comms.data(), nd, devs.data());
-            if (r != 0) {
-                fprintf(stderr, "pt_group_create: ncclCommInitAll failed (%s): the frame is assembled on the host\n", rccl().GetErrorString(r));
-            } else {
-                for (int q = 0; q < nd; ++q) g->dev[q].comm = comms[q];
-                g->rccl = true;
-                g->how = nd > 1 ? "rccl reduce (unmeasured across devices: no multi-GPU node was available to the build)" : "rccl reduce (one-rank communicator)";
-            }
+            g->rccl = true;
+            g->how = nd > 1 ? "rccl reduce (unmeasured across devices: no multi-GPU node was available to the build)" : "rccl reduce (one-rank communicator)";
         }
     }
     // the members' issuing threads
@@ -428,14 +441,13 @@ void pt_group_destroy(PtGroup *g) {
     for (size_t i = 0; i < g->stream.size(); ++i) {
         (void)hipSetDevice(g->device[i]);
         if (g->evCommit[i]) (void)hipEventDestroy(g->evCommit[i]);
-        if (g->stream[i]) { (void)hipStreamSynchronize(g->stream[i]); (void)hipStreamDestroy(g->stream[i]); }
+        (void)hipStreamSynchronize(g->stream[i]);
+        if (g->stream[i]) (void)hipStreamDestroy(g->stream[i]);
     }
     for (GroupDevice &d : g->dev) {
         (void)hipSetDevice(d.device);
-        for (int q = 0; q < 2; ++q) {
-            if (d.evSnap[q]) (void)hipEventDestroy(d.evSnap[q]);
+        for (int q = 0; q < 2; ++q)
             if (d.evRed[q]) (void)hipEventDestroy(d.evRed[q]);
-        }
         if (d.coll) (void)hipStreamDestroy(d.coll);
         if (d.comm) (void)rccl().CommDestroy(d.comm);
     }
@@ -479,13 +491,13 @@ int pt_group_init(PtGroup *g, const PtCamera *cam, const PtGeom *geoms, int ngeo
         HIPCHECK(hipMalloc(&d.full, frameBytes));
         HIPCHECK(hipMemset(d.full, 0, frameBytes));
         if (g->rccl)
-            for (int q = 0; q < 2; ++q) HIPCHECK(hipMalloc(&d.snap[q], frameBytes));
+            for (int q = 0; q < 2; ++q) {       // (zeroed: the rows of the OTHER devices' members stay zero, which is what the sum needs)
+                HIPCHECK(hipMalloc(&d.snap[q], frameBytes));
+                HIPCHECK(hipMemset(d.snap[q], 0, frameBytes));
+            }
+        HIPCHECK(hipDeviceSynchronize());
     }
-    if (g->rccl) {
-        HIPCHECK(hipSetDevice(g->dev[0].device));
-        for (int q = 0; q < 2; ++q) HIPCHECK(hipMalloc(&g->reduced[q], frameBytes));
-    }
-    HIPCHECK(hipDeviceSynchronize());
+    g->waitRed.assign(n, 0);
     PtOptions base;
     memset(&base, 0, sizeof base);
     if (opts) base = *opts;
@@ -500,6 +512,7 @@ int pt_group_init(PtGroup *g, const PtCamera *cam, const PtGeom *geoms, int ngeo
         return pt_init(cam, geoms, ngeoms, mats, nmats, traceDepth, &o);
     });
     if (rc) return rc;
+    if ((rc = ensure_collective(g))) return rc;      // (behind the members' tracing streams: see pt_group_create)
     g->inited = true;
     g->dirty = false;
     g->k = 0;
@@ -513,6 +526,12 @@ int pt_group_iterate_batch(PtGroup *g, int frame, int first_iter, int count) {
     if (!g->inited) return fail(PT_ERR_NOT_INIT, "pt_group_iterate_batch before pt_group_init");
     CurrentGuard guard;
     int rc = for_members(g, [&](int i) -> int {
+        if (g->rccl) {      // this call's commit copies the member's rows into snapshot k as well
+            GroupDevice &d = g->dev[g->devIndex[i]];
+            R().snapTarget = d.snap[g->k];
+            R().snapWait = g->waitRed[i] ? d.evRed[g->k] : nullptr;
+            g->waitRed[i] = 0;
+        }
         int r = pt_iterate_batch(frame, first_iter, count, nullptr);
         if (r) return r;
         HIPCHECK(hipEventRecord(g->evCommit[i], g->stream[i]));
@@ -564,7 +583,7 @@ int pt_group_readback(PtGroup *g, float *rgb_sum_host) {
     }
     if (g->rccl) {
         HIPCHECK(hipSetDevice(g->dev[0].device));
-        HIPCHECK(hipMemcpyAsync(rgb_sum_host, g->reduced[g->last], frameFloats * sizeof(float), hipMemcpyDeviceToHost, g->dev[0].coll));
+        HIPCHECK(hipMemcpyAsync(rgb_sum_host, g->dev[0].snap[g->last], frameFloats * sizeof(float), hipMemcpyDeviceToHost, g->dev[0].coll));
         HIPCHECK(hipStreamSynchronize(g->dev[0].coll));
     } else if (g->dev.size() == 1) {
         HIPCHECK(hipSetDevice(g->dev[0].device));

@@ -1607,8 +1607,11 @@ __global__ __launch_bounds__(kBlock, (MANY && CUBES) ? 4 : (MESH ? (MANY ? 4 : (
 // [b0, b1) = the iterations of the batch this launch consumes (the whole batch: 0, batch); the others stay parked -- their
 // radiance entries and mask bits untouched -- for a later launch (PT_FLAG_TRACE_AHEAD: pt_iterate commits ONE iteration of a
 // batch that was traced ahead).  `discard`: consume without adding (a traced-ahead batch the caller did not come back for).
+// `snap` (round 6; device groups, pt_group.h): a full frame that receives the value of EVERY pixel of this shard after the commit --
+// the snapshot a frame reduce reads while the next iteration is committed -- in the same pass: the accumulator is read once, for the
+// addition and for the copy (a separate 11 MB device-to-device copy per iteration cost config C3 as written ~7 us each).
 __global__ __launch_bounds__(kBlock) void k_commit(KParams prm, float *image, float *contrib, uint32_t *hitMask, int batch, int compactRows,
-                                                   int b0, int b1, int discard) {
+                                                   int b0, int b1, int discard, float *snap) {
     const int j = blockIdx.x * kBlock + threadIdx.x;
     if (j >= prm.nLocal) return;
     const int lr = j / prm.W;
@@ -1623,6 +1626,8 @@ __global__ __launch_bounds__(kBlock) void k_commit(KParams prm, float *image, fl
     constexpr int kWordsMax = (PT_MAX_BATCH + 31) / 32;
     uint32_t mw[kWordsMax], keep[kWordsMax];
     uint32_t any = 0u;
+    float ax = 0.0f, ay = 0.0f, az = 0.0f;
+    if (snap) { ax = px[0]; ay = px[1]; az = px[2]; }            // (with a snapshot every pixel is read: issued beside the mask words)
 #pragma unroll
     for (int w = 0; w < kWordsMax; ++w) {
         // bits of word w inside [b0, b1)
@@ -1635,8 +1640,12 @@ __global__ __launch_bounds__(kBlock) void k_commit(KParams prm, float *image, fl
         keep[w] = word & ~range;
         any |= mw[w];
     }
-    if (any == 0u) return;
-    float ax = px[0], ay = px[1], az = px[2];
+    float *const sp = snap ? snap + 3 * gpix : nullptr;
+    if (any == 0u) {
+        if (sp) { sp[0] = ax; sp[1] = ay; sp[2] = az; }
+        return;
+    }
+    if (!snap) { ax = px[0]; ay = px[1]; az = px[2]; }
 #pragma unroll
     for (int w = 0; w < kWordsMax; ++w) {
         uint32_t m = mw[w];
@@ -1666,6 +1675,7 @@ __global__ __launch_bounds__(kBlock) void k_commit(KParams prm, float *image, fl
         }
     }
     if (!discard) { px[0] = ax; px[1] = ay; px[2] = az; }
+    if (sp) { sp[0] = ax; sp[1] = ay; sp[2] = az; }
 }
 
 // ---- sendImageToPBO (reference src/pathtrace.cu:48-68) ---------------------------------------------

@@ -114,7 +114,65 @@ def test_driver_command_reports_every_one_gpu_configuration(pt):
     # 8-byte record per path, which the algorithmic figure -- the path state in and out, as for every configuration -- does not count)
     for k, hi in (("c4", 1.6), ("mesh", 2.0)):
         assert cf[k]["roofline"]["traffic"] is not None and 0.9 < cf[k]["roofline"]["traffic_over_algorithmic"] < hi
+    # round 6: the C ABI's own multi-device host path is IN the driver's line.  Eight members on the one device
+    # (a host thread each, one shared accumulator) against the headline; config C3 as written through the LIBRARY's per-iteration reduce
+    # (one member, a one-rank RCCL communicator: snapshot fused into the commit, ncclReduce on the collective stream), the
+    # torch.distributed reading of rounds 4-5 beside it
+    g8 = d["group_8_members_one_device"]
+    assert "error" not in g8, g8
+    assert g8["members"] == 8 and g8["devices"] == 1 and g8["issue_threads"] == 8 and g8["collective"] == "shared accumulator"
+    assert g8["iterations_per_step"] == 64 and g8["iterations_per_wavefront_batch"] == 256 and g8["value"] > 1000.0
+    assert abs(g8["of_the_one_context_rate"] - g8["value"] / d["value"]) < 1e-3 and g8["of_the_one_context_rate"] > 0.8
+    assert g8["host_enqueue_us_per_wavefront_batch"] < 1e3 * g8["gpu_ms_per_wavefront_batch"]     # the host is not what bounds it
+    c3 = d["value_c3_as_written"]
+    assert "error" not in c3, c3
+    assert c3["members"] == 1 and c3["collective"].startswith("rccl reduce") and "one-rank" in c3["collective"]
+    assert c3["iterations_per_step"] == 64 and c3["steps"] == 4 and 0 < c3["ms_per_iteration"] < 0.2
+    assert "pt_group_iterate per iteration" in c3["mode"]
+    assert "error" not in d["value_c3_as_written_torch_distributed"] and "unmeasured" in d["multi_device_note"]
     # a run that is about ONE configuration carries no block
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-spp", "0", "--per-iteration-sample", "0",
                         "--repeats", "2"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "configs" not in json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def _batched_frame(pt, iterations):
+    import numpy as np
+    sc = pt.Scene(os.path.join(ROOT, "scenes", "cornell.txt"))
+    sc.set_resolution(1280, 720)
+    pt.pathtraceFree()
+    pt.pathtraceInit(sc, traceDepth=8, pipeline_depth=2, max_batch=64)
+    for it in range(1, iterations + 1, 64):
+        pt.pathtrace_batch(None, 0, it, 64)
+    want = pt.readback(1280 * 720)
+    pt.pathtraceFree()
+    assert want.max() > 0
+    return want
+
+
+def test_group_mode_renders_the_one_device_frame(pt, tmp_path):
+    # `bench.py --group M`: what the `group` blocks of the driver's line run.  The frame each mode leaves is the batched one-renderer
+    # frame of the same iterations, bit for bit: 8 members on the one device in wavefront batches of 256, and config C3 as written --
+    # one pt_group_iterate per iteration -- through a one-rank RCCL communicator.
+    import numpy as np
+    if pt.device_count() < 1:
+        pytest.fail("no HIP device: GPU tests must run on the MI355X box")
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "PT_AMD_COLLECTIVE", "PT_AMD_GROUP_THREADS"):
+        env.pop(k, None)
+    dump = str(tmp_path / "g8.npy")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--group", "8", "--group-devices", "1", "--steps", "4", "--warmup", "1",
+                        "--repeats", "2", "--dump-frame", dump], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["members"] == 8 and d["devices"] == 1 and d["collective"] == "shared accumulator" and d["iterations_committed"] == (1 + 2 * 4) * 64
+    assert d["iterations_per_wavefront_batch"] == 256 and d["value"] > 1000.0 and len(d["ms_per_step_blocks"]) == 2
+    assert np.array_equal(np.load(dump).view(np.uint32), _batched_frame(pt, 9 * 64).view(np.uint32))
+    dump = str(tmp_path / "c3.npy")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--group", "1", "--group-c3", "1", "--steps", "2", "--warmup", "1",
+                        "--repeats", "2", "--dump-frame", dump], capture_output=True, text=True, timeout=600, env=dict(env, PT_AMD_COLLECTIVE="rccl"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["members"] == 1 and d["collective"].startswith("rccl reduce") and d["iterations_committed"] == (1 + 2 * 2) * 64
+    assert 0 < d["ms_per_iteration"] < 0.2 and d["host_enqueue_us_per_iteration"] > 0
+    assert np.array_equal(np.load(dump).view(np.uint32), _batched_frame(pt, 5 * 64).view(np.uint32))
