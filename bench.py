@@ -23,9 +23,10 @@ The timed block -- EXACTLY `--steps` steps between barrier + device synchronisat
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (what the driver does)
 
 N > 1: image rows are sharded round-robin over the ranks (row y -> rank y % N), every rank accumulates only its
-own rows (packed), and ONE collective -- a gather of the row blocks to rank 0, RCCL over xGMI -- assembles the frame
-(disjoint rows: bit-identical to 1 GPU; it moves 1/N of the bytes the reduce of zero-padded full frames would;
-`--collective reduce` runs that reduce instead).  `--collective-every batch` (default) issues it after every
+own rows (packed), and ONE collective -- RCCL over xGMI -- assembles the frame at rank 0: the reduce(sum, float32, 3 W H,
+root 0) of zero-padded full frames that north_star and SURVEY 8e name (the default since round 6), or `--collective gather`:
+the gather of the row blocks (disjoint rows: both are bit-identical to 1 GPU; the gather moves 1/N of the bytes).  The
+N > 1 line carries both readings (`multi_gpu.value_collective_gather`).  `--collective-every batch` (default) issues it after every
 committed wavefront batch, `--collective-every 1` after every single iteration (BASELINE config C3 as written:
 one pt_iterate + one collective per iteration).  The default run also times a bounded sample of the per-iteration
 mode and reports it in config.per_iteration_collective.
@@ -93,8 +94,9 @@ def parse(argv=None):
                          "config C3 as written: a fixed number of samples, divided)")
     ap.add_argument("--collective-every", default="batch", choices=["batch", "1"],
                     help="N > 1: assemble the frame at rank 0 after every wavefront batch, or after every iteration")
-    ap.add_argument("--collective", default="gather", choices=["gather", "reduce"],
-                    help="N > 1: gather of the packed row blocks (default) or reduce(sum) of zero-padded full frames")
+    ap.add_argument("--collective", default="reduce", choices=["gather", "reduce"],
+                    help="N > 1: reduce(sum, float32, 3 W H, root 0) of zero-padded full frames -- the collective north_star and SURVEY 8e name (default "
+                         "since round 6) -- or the gather of the packed row blocks (1/N of the bytes: rows are disjoint); the N > 1 line carries BOTH readings")
     ap.add_argument("--per-iteration-sample", type=int, default=None,
                     help="whole steps timed in the per-iteration mode of BASELINE config C3 (strong scaling, one pt_iterate + one "
                          "reduce per iteration, N = 1 included); default = --steps; 0 = skip")
@@ -802,6 +804,9 @@ def run(args, ctx):
         if args.extra_passes:
             other = "strong" if args.scaling == "weak" else "weak"
             multi["value_" + other] = reading(other, every, args.collective, args.steps, min(args.warmup, 2))
+            # ... and the headline's own pass once more with the OTHER collective (reduce: the contract's; gather: 1/N of the bytes)
+            other_coll = "gather" if args.collective == "reduce" else "reduce"
+            multi["value_collective_" + other_coll] = reading(args.scaling, every, other_coll, args.steps, min(args.warmup, 2))
 
     # ---- BASELINE config C3 to the letter, N >= 1: a fixed number of samples divided over the ranks, one pt_iterate and one
     #      reduce(sum) of zero-padded full frames per ITERATION (the reference's per-iteration full-frame transfer,
@@ -1008,6 +1013,12 @@ def run(args, ctx):
             out["cpu_baseline"] = cpu_baseline(args, scene, pt)
         if world == 1 and args.configs:
             out["configs"] = other_configs(args)
+        # a block measured by a child process that failed stands in the line with an `error` key -- and is NAMED here, so that a line that
+        # lacks a configuration cannot pass for a complete one
+        failed = [k for k, v in out.get("configs", {}).items() if "error" in v]
+        failed += [k for k in ("group_8_members_one_device", "group", "group_c3_as_written", "value_c3_as_written") if isinstance(out.get(k), dict) and "error" in out[k]]
+        if "configs" in out or groups:
+            out["configs_failed"] = failed
         print(json.dumps(out), flush=True)
 
 

@@ -443,8 +443,13 @@ int commit_range(Slot &sl, int count, int b0, int b1, bool discard) {
             HIPCHECK(hipStreamWaitEvent(R().stream, R().snapWait, 0));
             R().snapWait = nullptr;
         }
-        hipLaunchKernelGGL(k_commit, dim3((R().nLocal + kBlock - 1) / kBlock), dim3(kBlock), 0, R().stream, R().prm, R().image, sl.contrib, sl.hitMask,
-                           count, (R().flags & PT_FLAG_ACCUM_SHARD_ROWS) ? 1 : 0, b0, b1, discard ? 1 : 0, snap);
+        const int compact = (R().flags & PT_FLAG_ACCUM_SHARD_ROWS) ? 1 : 0;
+        if (b1 == b0 + 1)      // one iteration of the batch (the reference's protocol over a batch traced ahead): the light kernel
+            hipLaunchKernelGGL(k_commit_one, dim3((R().nLocal + kBlock - 1) / kBlock), dim3(kBlock), 0, R().stream, R().prm, R().image, sl.contrib, sl.hitMask,
+                               compact, b0, discard ? 1 : 0, snap);
+        else
+            hipLaunchKernelGGL(k_commit, dim3((R().nLocal + kBlock - 1) / kBlock), dim3(kBlock), 0, R().stream, R().prm, R().image, sl.contrib, sl.hitMask,
+                               count, compact, b0, b1, discard ? 1 : 0, snap);
         HIPCHECK(hipGetLastError());
     }
     return PT_OK;

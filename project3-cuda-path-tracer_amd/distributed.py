@@ -2,16 +2,19 @@
 
 Image rows are dealt to the ranks like cards (row y -> rank y % world), which balances the black
 border rows and the bright light rows.  Every rank accumulates ONLY its own rows, packed
-(PT_FLAG_ACCUM_SHARD_ROWS), and the frame is assembled at rank 0 by a single collective -- a gather of the
-row blocks (RCCL over xGMI on the GPUs, gloo in the CPU tests) -- issued by the caller after every iteration
-(BASELINE config C3 as written; bench.py --collective-every 1) or after every wavefront batch of iterations
-(--collective-every batch: accumulation is additive, so the frame at rank 0 is the same whenever it is assembled).
+(PT_FLAG_ACCUM_SHARD_ROWS), and the frame is assembled at rank 0 by a single collective (RCCL over xGMI on
+the GPUs, gloo in the CPU tests) issued by the caller after every iteration (BASELINE config C3 as written;
+bench.py --collective-every 1) or after every wavefront batch of iterations (--collective-every batch:
+accumulation is additive, so the frame at rank 0 is the same whenever it is assembled).
 
-Why a gather and not the reduce(sum) of zero-padded full frames that BASELINE.json sketches: the rows
-are disjoint, so the reduce would add x + 0 + ... + 0 -- the same result (both are bit-identical to a
-single-GPU render) for world x the bytes.  xGMI is point-to-point: in the gather every rank
-sends its 1/world of the frame straight to rank 0 over its own link (1.4 MB per rank for 1280x720 at
-world = 8) instead of pushing 11 MB around a ring.
+Two collectives, chosen by the caller (bench.py --collective; since round 6 its default is the contract's):
+  "reduce"  reduce(sum, float32, 3 W H, root 0) of zero-padded full frames -- what north_star and SURVEY 8e name;
+  "gather"  gather of the packed row blocks: the rows are disjoint, so the reduce adds x + 0 + ... + 0 -- the same
+            bits (both are a single-GPU render's) for world x the bytes.  xGMI is point-to-point: in the
+            gather every rank sends its 1/world of the frame straight to rank 0 over its own link (1.4 MB per rank
+            for 1280x720 at world = 8) instead of pushing 11 MB around a ring.
+One N > 1 bench line carries both readings.  (The C ABI's own multi-device path -- csrc/pt_group.h, ONE process --
+uses the reduce.)
 """
 import os
 
@@ -93,7 +96,7 @@ def _interleave_rows(bufs, frame, width, height, world):
             rows_view[r::world].copy_(bufs[r][:n * width * 3].view(n, width * 3))
 
 
-def gather_frame(block, bufs, frame, width, height, dst=0, collective="gather", always_collective=False):
+def gather_frame(block, bufs, frame, width, height, dst=0, collective="reduce", always_collective=False):
     """The data path's single collective: rank `dst` receives every rank's packed rows and interleaves
     them into `frame` (H*W*3 floats).  `block` is this rank's packed accumulator, padded to
     padded_block_floats(); it keeps accumulating, the collective only reads it.
@@ -101,9 +104,8 @@ def gather_frame(block, bufs, frame, width, height, dst=0, collective="gather", 
     `collective` is chosen by the caller, once, identically on every rank (a command-line option in bench.py);
     nothing here switches it at run time, and an error of the backend propagates -- a failed RCCL collective
     leaves the communicator unusable, so there is nothing to fall back to:
-      "gather"  every rank sends its 1/world of the frame straight to `dst` (default);
-      "reduce"  the reduce(sum) of zero-padded full frames that BASELINE.json sketches: same bits (x + 0 is
-                exact), world x the bytes.
+      "reduce"  the reduce(sum) of zero-padded full frames that BASELINE.json names (default): x + 0 is exact;
+      "gather"  every rank sends its 1/world of the frame straight to `dst`: same bits, 1/world of the bytes.
     `always_collective`: issue the collective even in a one-rank group (tests: the RCCL call path on a single GPU)."""
     import torch
     import torch.distributed as dist

@@ -42,7 +42,7 @@ def _worker(rank, world, port, res, iters, out_path):
         npix = c.live[1]
         packed = sparse.reshape(H, W * 3)[mine].reshape(-1)      # what PT_FLAG_ACCUM_SHARD_ROWS holds
         block[:packed.size] = torch.from_numpy(packed)
-        ptdist.gather_frame(block, bufs, frame, W, H, dst=0)
+        ptdist.gather_frame(block, bufs, frame, W, H, dst=0, collective="gather")
         if rank == 0:
             ren.iterate(it, full)
             ok = ok and np.array_equal(frame.numpy().view(np.uint32), full.view(np.uint32))

@@ -91,10 +91,12 @@ def _single_rank_frame(pt, iterations, batch):
     return got
 
 
-@pytest.mark.parametrize("every,extra,ranks,scaling", [("batch", [], 2, "weak"), ("1", ["--batch", "4"], 2, "weak"),
-                                                       ("batch", ["--collective", "reduce", "--batch", "8"], 2, "strong"),
-                                                       ("1", ["--collective", "reduce", "--batch", "4"], 2, "strong"),   # config C3 as written
-                                                       ("batch", ["--batch", "16"], 4, "strong"), ("batch", ["--batch", "96"], 3, "weak")])
+@pytest.mark.parametrize("every,extra,ranks,scaling", [("batch", ["--group-blocks", "1"], 2, "weak"),       # the default collective: the reduce
+                                                       ("1", ["--collective", "gather", "--batch", "4"], 2, "weak"),
+                                                       ("batch", ["--batch", "8"], 2, "strong"),
+                                                       ("1", ["--batch", "4"], 2, "strong"),   # config C3 as written
+                                                       ("batch", ["--collective", "gather", "--batch", "16"], 4, "strong"),
+                                                       ("batch", ["--collective", "gather", "--batch", "96"], 3, "weak")])
 def test_bench_two_ranks_contract(pt, tmp_path, every, extra, ranks, scaling):
     # bench.py --gpus 2 (and 4) WITHOUT a torchrun environment: it starts its ranks itself (torch.distributed.run as a
     # child, one process per rank -- exactly what the driver launches); gloo stands in for RCCL because both ranks
@@ -109,7 +111,7 @@ def test_bench_two_ranks_contract(pt, tmp_path, every, extra, ranks, scaling):
     steps, warmup, repeats = 3, 1, 2
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", str(steps), "--warmup", str(warmup),
                         "--repeats", str(repeats), "--collective-every", every, "--per-iteration-sample", "1", "--dump-frame", dump,
-                        "--dump-c3-frame", dump_c3] + extra
+                        "--dump-c3-frame", dump_c3] + extra + ([] if "--group-blocks" in extra else ["--group-blocks", "0"])
                        + ([] if scaling == "weak" else ["--scaling", "strong"]),                # (weak is the default)
                        capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -151,7 +153,20 @@ def test_bench_two_ranks_contract(pt, tmp_path, every, extra, ranks, scaling):
     assert c3_want.max() > 0 and np.array_equal(c3_got.view(np.uint32), c3_want.view(np.uint32))
     mg = d["multi_gpu"]
     block = -(-720 // ranks) * 1280 * 12                            # a rank's packed rows, padded to the largest shard
-    assert mg["collective_bytes_per_call"]["sent_by_each_rank"] == (1280 * 720 * 12 if "reduce" in extra else block)
+    assert mg["collective"] == ("gather" if "gather" in extra else "reduce")                      # (the contract's reduce is the default since round 6)
+    assert mg["collective_bytes_per_call"]["sent_by_each_rank"] == (block if "gather" in extra else 1280 * 720 * 12)
+    # ... and the line carries the OTHER collective's reading of the same pass beside it
+    oc = d["multi_gpu"]["value_collective_" + ("reduce" if "gather" in extra else "gather")]
+    assert oc["value"] > 0 and ("one reduce per" in oc["mode"]) == ("gather" in extra)
+    if "--group-blocks" in extra:
+        # round 6: beside the ranks, rank 0 measures the C ABI's own multi-device path in child processes -- a pt_group of as many members as there
+        # are ranks (here on the one device: a rehearsal, and the line says so), in batch mode and as config C3 as written
+        gb, gc = d["group"], d["group_c3_as_written"]
+        assert "error" not in gb and "error" not in gc, (gb, gc)
+        assert gb["members"] == ranks and gb["devices"] == 1 and gb["collective"] == "shared accumulator" and gb["value"] > 0
+        assert gc["members"] == ranks and gc["ms_per_iteration"] > 0 and "unmeasured" in d["multi_device_note"]
+    else:
+        assert "group" not in d
     # (the collective is timed on its own, outside the steps: with gloo ranks sharing one GPU and the host's cores its share of a step
     # is whatever the box's load makes it -- 0.3 .. 1.6 seen; the field must be there and sane, its size is not the test's business)
     assert mg["collective_ms_per_call"] > 0 and 0 < mg["collective_share_of_step"] < 100
