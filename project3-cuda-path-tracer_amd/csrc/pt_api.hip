@@ -118,6 +118,8 @@ struct State {
     bool mesh = false;      // the scene holds triangle meshes: the k_bounce<., false, ., true> variants
     // ... whose walks run ahead of every bounce launch (k_mesh_walk): the meshes alone per queue class / in all / per image row
     int *dWalkIdx = nullptr, *dWalkRowOff = nullptr;
+    float4 *dWalkMeshRows = nullptr;   // ptk::WalkMesh per mesh (BounceArgs::walkMeshRows); walkMeshLds: how many of them a workgroup stages in LDS (all, or none)
+    int walkMeshLds = 0;
     int walkClassOff[kClsMax + 1] = {0}, walkAll0 = 0, walkAll1 = 0;
     int gridWalk = 0, gridWalkFirst = 0;
     size_t ldsWalk = 0;
@@ -235,8 +237,12 @@ const void *bounce_kernel(bool first, bool dof) {
 }
 
 const void *walk_kernel(bool first, bool dof) {
-    if (first) return dof ? reinterpret_cast<const void *>(k_mesh_walk<true, true>) : reinterpret_cast<const void *>(k_mesh_walk<true, false>);
-    return reinterpret_cast<const void *>(k_mesh_walk<false, false>);
+    if (R().walkMeshLds != 0) {      // the meshes' rows in LDS (scenes of at most kWalkMeshLdsMax meshes)
+        if (first) return dof ? reinterpret_cast<const void *>(k_mesh_walk<true, true, true>) : reinterpret_cast<const void *>(k_mesh_walk<true, false, true>);
+        return reinterpret_cast<const void *>(k_mesh_walk<false, false, true>);
+    }
+    if (first) return dof ? reinterpret_cast<const void *>(k_mesh_walk<true, true, false>) : reinterpret_cast<const void *>(k_mesh_walk<true, false, false>);
+    return reinterpret_cast<const void *>(k_mesh_walk<false, false, false>);
 }
 
 int launch_bounce(Slot &sl, int iter, int batch, int depth, bool lastBounce, float *contrib, bool nextIsLast = false) {
@@ -281,6 +287,7 @@ int launch_bounce(Slot &sl, int iter, int batch, int depth, bool lastBounce, flo
     ba.meshHit = sl.meshHit; ba.walkIdx = R().dWalkIdx; ba.walkRowOff = R().dWalkRowOff;
     memcpy(ba.walkClassOff, R().walkClassOff, sizeof ba.walkClassOff);
     ba.walkAll0 = R().walkAll0; ba.walkAll1 = R().walkAll1;
+    ba.walkMeshRows = R().dWalkMeshRows; ba.walkMeshLds = R().walkMeshLds;
     void *kargs[] = {&ba};
     const bool first = depth == 1;
     // scenes with meshes: the walks of this bounce's rays, ahead of it (pt_mesh_walk.h)
@@ -590,6 +597,7 @@ void free_renderer() {
     if (R().dMeshRecs) (void)hipFree(R().dMeshRecs);
     if (R().dWalkIdx) (void)hipFree(R().dWalkIdx);
     if (R().dWalkRowOff) (void)hipFree(R().dWalkRowOff);
+    if (R().dWalkMeshRows) (void)hipFree(R().dWalkMeshRows);
     {   // (the registered meshes outlive the renderer: see State::meshes)
         std::vector<ptm::HostMesh> keep = std::move(R().meshes);
         R() = State();
@@ -1161,6 +1169,22 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
                 }
             R().walkAll1 = (int)w.size();
             HIPCHECK(hipMemcpy(R().dgeoms, hg.data(), hg.size() * sizeof(GeomDev), hipMemcpyHostToDevice));
+            {   // the walk's rows, one per mesh in the order of their ordinals (ptk::WalkMesh)
+                const int nm = R().walkAll1 - R().walkAll0;
+                std::vector<WalkMesh> rowsW((size_t)nm);
+                for (int q = 0; q < nm; ++q) {
+                    const GeomDev &G = hg[(size_t)w[(size_t)R().walkAll0 + q]];
+                    WalkMesh &r = rowsW[(size_t)q];
+                    memcpy(r.inv, G.inv, sizeof r.inv); memcpy(r.invZ, G.invZ, sizeof r.invZ);
+                    r.root = G.meshRoot;
+                    memcpy(r.xf, G.xf, sizeof r.xf); memcpy(r.camObj, G.camObj, sizeof r.camObj);
+                    r.stride = G.meshStride;
+                }
+                HIPCHECK(hipMalloc(&R().dWalkMeshRows, std::max<size_t>(rowsW.size(), 1) * sizeof(WalkMesh)));
+                HIPCHECK(hipMemcpy(R().dWalkMeshRows, rowsW.data(), rowsW.size() * sizeof(WalkMesh), hipMemcpyHostToDevice));
+                const bool forceGlobal = getenv("PT_AMD_WALK_ROWS_GLOBAL") && atoi(getenv("PT_AMD_WALK_ROWS_GLOBAL"));      // tests only
+                R().walkMeshLds = (nm <= kWalkMeshLdsMax && !forceGlobal) ? nm : 0;
+            }
             if (!cc.rowOff.empty()) {
                 if (w.size() % 2) w.push_back(0);                  // (the rows' entries are pairs: offsets count pairs from the array's start)
                 std::vector<int> ro(cc.rowOff.size());
@@ -1193,8 +1217,8 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     R().ldsBytesNext = (R().many && !R().mesh) ? ldsFixed + sphMapBytes + pairBytes : 0;
     k.meshStackOff = 0;
     if (R().mesh) {        // (the lanes' stacks of far children belong to the walk's own launches: k_mesh_walk)
-        R().ldsWalk = walkLdsBytes(meshStackNeed, R().walkAll1 - R().walkAll0);
-        if (R().ldsWalk > 160 * 1024) return fail(PT_ERR_INVALID, "pt_init: a mesh's hierarchy needs %d stack levels (%zu B of LDS)", meshStackNeed, R().ldsWalk);
+        R().ldsWalk = walkLdsBytes(meshStackNeed, R().walkMeshLds);
+        if (R().ldsWalk > 160 * 1024) return fail(PT_ERR_INVALID, "pt_init: a mesh's hierarchy needs %d stack levels (%zu B of LDS for the lanes' stacks)", meshStackNeed, R().ldsWalk);
     }
     if (R().ldsBytesNext == 0) R().ldsBytesNext = R().ldsBytes;
     if (R().ldsBytes > 160 * 1024) return fail(PT_ERR_INVALID, "pt_init: scene does not fit the 160 KiB LDS (%zu B)", R().ldsBytes);

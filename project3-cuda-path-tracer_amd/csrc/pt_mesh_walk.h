@@ -48,13 +48,19 @@ struct WalkMesh {
 };
 static_assert(sizeof(WalkMesh) == 128, "eight 16-byte words");
 constexpr int kWalkMeshWords = (int)(sizeof(WalkMesh) / sizeof(uint32_t));
+constexpr int kWalkMeshLdsMax = 32;      // meshes whose rows go to LDS (4 KB); a scene with more reads them from global memory, per job
 // dynamic LDS of a launch: the fixed part, the table of the scene's meshes, then the lanes' stacks of waiting far children, [levels][kBlock] words
 inline size_t walkLdsBytes(int levels, int nmeshes) {
-    return ((size_t)kWalkLdsFixedWords + (size_t)nmeshes * kWalkMeshWords + (size_t)(levels < 1 ? 1 : levels) * kBlock) * sizeof(uint32_t);
+    // (+ 2 levels: the sentinel below a lane's first entry, and the slot above a full stack, which an inner step writes whether it keeps it or not)
+    return ((size_t)kWalkLdsFixedWords + (size_t)nmeshes * kWalkMeshWords + (size_t)((levels < 1 ? 1 : levels) + 2) * kBlock) * sizeof(uint32_t);
 }
 
-template <bool FIRST, bool DOF>
-__global__ __launch_bounds__(kBlock, 8) void k_mesh_walk(BounceArgs A) {
+// ROWS_LDS: the per-mesh rows (WalkMesh) are staged in LDS -- scenes of at most kWalkMeshLdsMax meshes; else every job reads its mesh's row from
+// global memory (an instantiation of its own: both forms in one kernel cost the common one its registers)
+// (the pinhole camera-ray walk carries the pixel's coordinates through its queueing and needs a 65th register: seven workgroups per CU for it --
+// with eight it parked the triangle test's `front` flag in scratch inside the leaf step; it is a twentieth of a mesh scene's GPU time)
+template <bool FIRST, bool DOF, bool ROWS_LDS>
+__global__ __launch_bounds__(kBlock, (FIRST && !DOF) ? 7 : 8) void k_mesh_walk(BounceArgs A) {
     static_assert(FIRST || !DOF, "the lens only concerns the camera rays");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int CLS = kClsMax, SUB = kSeg / CLS;             // (scenes with meshes bin by two candidate bits: 32 classes)
@@ -62,22 +68,19 @@ __global__ __launch_bounds__(kBlock, 8) void k_mesh_walk(BounceArgs A) {
     uint32_t *const s_segpre = s_segcnt + kSeg;                          // [kSeg+2] tile prefix per input segment
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     unsigned long long *const s_queue = reinterpret_cast<unsigned long long *>(s_segpre + kSeg + 2) + wave * kWalkQueue;
-    // (a job names its mesh by its ordinal among the scene's meshes, GeomDev::frameSlot = its row here)
-    const int nMeshes = A.walkAll1 - A.walkAll0;
+    // (a job names its mesh by its ordinal among the scene's meshes, GeomDev::frameSlot = its row of the table: the host's copy
+    // A.walkMeshRows, staged here when it is small)
+    const int nMeshes = ROWS_LDS ? A.walkMeshLds : 0;
     WalkMesh *const s_mesh = reinterpret_cast<WalkMesh *>(reinterpret_cast<uint32_t *>(smem) + kWalkLdsFixedWords);
-    uint32_t *const stack = reinterpret_cast<uint32_t *>(smem) + kWalkLdsFixedWords + nMeshes * kWalkMeshWords + threadIdx.x;
-    for (int i = threadIdx.x; i < nMeshes * kWalkMeshWords; i += kBlock) {
-        const int m = i / kWalkMeshWords, w = i - m * kWalkMeshWords;
-        const GeomDev &G = A.ggeoms[A.walkIdx[A.walkAll0 + m]];
-        uint32_t v;
-        if (w < 12) v = __float_as_uint(G.inv[w]);
-        else if (w < 15) v = __float_as_uint(G.invZ[w - 12]);
-        else if (w == 15) v = G.meshRoot;
-        else if (w < 28) v = __float_as_uint(G.xf[w - 16]);
-        else if (w < 31) v = __float_as_uint(G.camObj[w - 28]);
-        else v = G.meshStride;
-        reinterpret_cast<uint32_t *>(s_mesh)[i] = v;
-    }
+    const WalkMesh *const g_mesh = reinterpret_cast<const WalkMesh *>(A.walkMeshRows);
+    auto withMesh = [&](uint32_t g, auto &&f) {                 // f(the row of mesh g)
+        if (ROWS_LDS) f(s_mesh[g]);
+        else f(g_mesh[g]);
+    };
+    // (a lane's stack: slot 0 holds kDone for good -- popping an empty stack yields "through" without a test --, its entries start at slot 1)
+    uint32_t *const stack = reinterpret_cast<uint32_t *>(smem) + kWalkLdsFixedWords + nMeshes * kWalkMeshWords + threadIdx.x + kBlock;
+    stack[-kBlock] = 0xffffffffu;
+    for (int i = threadIdx.x; i < nMeshes * kWalkMeshWords; i += kBlock) reinterpret_cast<uint32_t *>(s_mesh)[i] = reinterpret_cast<const uint32_t *>(g_mesh)[i];
     __syncthreads();
     const KParams &prm = A.prm;
     Ctrl *const ctrl = A.ctrl;
@@ -294,14 +297,15 @@ __global__ __launch_bounds__(kBlock, 8) void k_mesh_walk(BounceArgs A) {
 
     // ---- the walks: a lane's state
     constexpr uint32_t kDone = 0xffffffffu;                     // (reads as a triangle's ref: the loop over inner nodes stops on it)
-    bool busy = false, pending = false;                         // pending: through with a job whose result is not folded in yet
-    uint32_t jobIdx = 0u, jobGeom = 0u;
+    // (a lane is idle exactly when ref == kDone; one that is idle WITH a job -- jobIdx != kNoJob -- is through with it and its result not
+    // folded in yet: no flags beside the two words, and nothing to update at a turn's end)
+    constexpr uint32_t kNoJob = 0xffffffffu;
+    uint32_t jobIdx = kNoJob, jobGeom = 0u;
     F3 ro = f3(0, 0, 0), rd = f3(0, 0, 1), inv = f3(1, 1, 1), rc = f3(0, 0, 0);
     uint32_t keyT = 0xffffffffu, keyI = 0xffffffffu;            // the best hit so far: bits of t + 0.0f, unit << 1 | front (all ones: none; t then reads as a NaN)
     uint32_t ref = kDone;
     uint32_t *sp = stack;
-    auto pop = [&]() -> uint32_t {
-        if (sp == stack) return kDone;
+    auto pop = [&]() -> uint32_t {                              // (the sentinel below the first entry: an empty stack pops kDone, and the walk ends there)
         sp -= kBlock;
         return *sp;
     };
@@ -315,19 +319,22 @@ __global__ __launch_bounds__(kBlock, 8) void k_mesh_walk(BounceArgs A) {
     // as long as the longest descent of its lanes, 13 steps where a lane's own took 4.7 -- profiles/r05_mesh_walk_experiments.txt.)
     for (;;) {
         probe(40);                                              // (marks of the ISA listing: the vote)
-        const bool atInner = busy && !(ref & kMeshLeaf), atLeaf = busy && (ref & kMeshLeaf) != 0u;
-        const uint32_t nInner = (uint32_t)__popcll(__ballot(atInner)), nLeaf = (uint32_t)__popcll(__ballot(atLeaf));
+        // (two ballots: kDone reads as a triangle's ref, so "at an inner node" is the leaf bit alone, and the lanes at a triangle are the rest --
+        // every lane of the wave is in this loop)
+        const bool busy = ref != kDone;
+        const bool atInner = !(ref & kMeshLeaf), atLeaf = busy && !atInner;
         const unsigned long long idleMask = __ballot(!busy);
-        const uint32_t nIdle = (uint32_t)__popcll(idleMask);
+        const uint32_t nInner = (uint32_t)__popcll(__ballot(atInner)), nIdle = (uint32_t)__popcll(idleMask);
+        const uint32_t nLeaf = 64u - nInner - nIdle;
         const bool more = qn != 0u || !exhausted;
         probeCount(29, atInner); probeCount(30, atLeaf); probeCount(31, !busy); probeCount(23, !more);
         if ((more && nIdle >= (uint32_t)kWalkIdleMin) || nInner + nLeaf == 0u) {
             probe(41);                                          // (hand-out: fold)
             // what the lanes that are through have found: the winner's distance in the world, and into the path's record with it.
             // (t: the bits of t + 0.0f serve -- a winner at -0 differs from +0 in the signs of zeros of P alone, which the length squares away)
+            const bool pending = !busy && jobIdx != kNoJob;
             probeCount(21, pending);                            // (instrumented build: the walk's wave steps and their lanes)
             if (pending) {
-                pending = false;
                 if (keyT != 0xffffffffu) {
                     // (the ray's origin in the world: the eye for pinhole camera rays, else the first of the path's two 16-byte words)
                     F3 org, dir;
@@ -337,12 +344,14 @@ __global__ __launch_bounds__(kBlock, 8) void k_mesh_walk(BounceArgs A) {
                         const float4 a = *reinterpret_cast<const float4 *>(A.in.arrA(jobIdx));
                         org = f3(a.x, a.y, a.z);
                     }
-                    const WalkMesh &G = s_mesh[jobGeom];
-                    const F3 P = mulMV(G.xf, getPointOnRay(ro, rd, __uint_as_float(keyT)), 1.0f);
-                    const float t = length(org - P);
-                    if (t > 0.0f)
-                        __hip_atomic_fetch_min(A.meshHit + jobIdx, ((unsigned long long)__float_as_uint(t) << 32) | keyI, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    withMesh(jobGeom, [&](const WalkMesh &G) {
+                        const F3 P = mulMV(G.xf, getPointOnRay(ro, rd, __uint_as_float(keyT)), 1.0f);
+                        const float t = length(org - P);
+                        if (t > 0.0f)
+                            __hip_atomic_fetch_min(A.meshHit + jobIdx, ((unsigned long long)__float_as_uint(t) << 32) | keyI, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    });
                 }
+                jobIdx = kNoJob;
             }
             probe(42);                                          // (queueing)
             if (qn < nIdle) refill();
@@ -357,16 +366,16 @@ __global__ __launch_bounds__(kBlock, 8) void k_mesh_walk(BounceArgs A) {
                 jobGeom = (uint32_t)(job >> 32);
                 F3 org, dir;
                 fetchRay(jobIdx, org, dir);
-                const WalkMesh &G = s_mesh[jobGeom];
-                ro = (FIRST && !DOF) ? f3(G.camObj[0], G.camObj[1], G.camObj[2]) : mulMV(G.inv, org, 1.0f);
-                rd = normalize(mulMV0(G.inv, G.invZ, dir));
-                inv = f3(guardedReciprocal(rd.x), guardedReciprocal(rd.y), guardedReciprocal(rd.z));
-                rc = f3(-(ro.x * inv.x), -(ro.y * inv.y), -(ro.z * inv.z));
-                const uint32_t octant = (__float_as_uint(inv.x) >> 31) | ((__float_as_uint(inv.y) >> 31) << 1) | ((__float_as_uint(inv.z) >> 31) << 2);
-                ref = G.root + octant * G.stride;
+                withMesh(jobGeom, [&](const WalkMesh &G) {
+                    ro = (FIRST && !DOF) ? f3(G.camObj[0], G.camObj[1], G.camObj[2]) : mulMV(G.inv, org, 1.0f);
+                    rd = normalize(mulMV0(G.inv, G.invZ, dir));
+                    inv = f3(guardedReciprocal(rd.x), guardedReciprocal(rd.y), guardedReciprocal(rd.z));
+                    rc = f3(-(ro.x * inv.x), -(ro.y * inv.y), -(ro.z * inv.z));
+                    const uint32_t octant = (__float_as_uint(inv.x) >> 31) | ((__float_as_uint(inv.y) >> 31) << 1) | ((__float_as_uint(inv.z) >> 31) << 2);
+                    ref = G.root + octant * G.stride;
+                });
                 sp = stack;
                 keyT = keyI = 0xffffffffu;
-                busy = true;
             }
             qn -= take;
             if (take == 0u && nInner + nLeaf == 0u) break;      // (no job left anywhere: the queue is empty and the tiles are drawn)
@@ -417,10 +426,10 @@ __global__ __launch_bounds__(kBlock, 8) void k_mesh_walk(BounceArgs A) {
                     const bool passN = meshPlanesPass(__float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(a.z), inv, rc, true, tb);
                     const bool passF = meshPlanesPass(__float_as_uint(b.x), __float_as_uint(b.y), __float_as_uint(b.z), inv, rc, true, tb);
                     const uint32_t refN = __float_as_uint(a.w), refF = __float_as_uint(b.w);
-                    if (passN & passF) {
-                        *sp = refF;
-                        sp += kBlock;
-                    }
+                    // (the far child goes to the slot above the top whether it waits there or not -- the slot is free --, and the top moves when
+                    // both pass: no branch around the store)
+                    *sp = refF;
+                    sp += (passN & passF) ? kBlock : 0;
                     ref = passN ? refN : (passF ? refF : pop());
                 };
                 step(q0, q1);
@@ -430,10 +439,6 @@ __global__ __launch_bounds__(kBlock, 8) void k_mesh_walk(BounceArgs A) {
             }
         }
         probe(46);                                              // (the turn's end)
-        if (busy && ref == kDone) {                             // (through with its job: nothing waits on its stack)
-            busy = false;
-            pending = true;
-        }
     }
 }
 

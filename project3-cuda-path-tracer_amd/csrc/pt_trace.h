@@ -419,6 +419,11 @@ struct BounceArgs {
     const int *walkRowOff;              // ... nullptr where rowOff is
     int walkClassOff[kClsMax + 1];
     int walkAll0, walkAll1;
+    // the walk's per-mesh rows (ptk::WalkMesh, 128 B each, made by pt_init): staged in LDS by every workgroup when the scene holds at most
+    // kWalkMeshLdsMax meshes (walkMeshLds = their number), else read from here per job (walkMeshLds = 0: a table of a thousand meshes would
+    // not fit the LDS, and one of a hundred would cost the kernel its residency)
+    const float4 *walkMeshRows;
+    int walkMeshLds;
 };
 typedef const PT_CAS BounceArgs *ArgsPtr;
 typedef const PT_CAS GeomDev *GeomPtr;

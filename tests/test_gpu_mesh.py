@@ -420,3 +420,27 @@ def test_walks_ahead_of_the_bounce_on_small_grids_and_ragged_rows(gpu, oracle, m
         _render_both(gpu, oracle, sc, 4, [5, 6, 7], (300, 70), dump_bounces=(2,))
         _render_both(gpu, oracle, sc, 3, [1, 2], (300, 70), lens_radius=0.3, focal_distance=9.0)
     monkeypatch.delenv("PT_AMD_MAX_GRID")
+
+
+def test_scene_of_forty_meshes_reads_the_walks_rows_from_global_memory(gpu, oracle, monkeypatch):
+    """the walk kernel staged a 128-byte row per mesh in every workgroup's LDS -- a hundred meshes cost it its residency, a
+    thousand failed pt_init.  Beyond 32 meshes the rows now stay in global memory (k_mesh_walk<., ., false>): forty small icospheres over a
+    floor, one of them the light, against the oracle's loop over every triangle; and the small scene through BOTH forms, bit for bit."""
+    sc = gpu.Scene(os.path.join(SCENES, "mesh_small.txt"))
+    tris = _icosphere(0)
+    rng = np.random.default_rng(5)
+    geoms = [oracle.make_geom(1, 1, (0, -0.1, 0), (0, 0, 0), (14, 0.2, 14)),                    # a floor (cube, diffuse)
+             oracle.make_geom(2, 0, (0, 7, 0), (0, 0, 0), (5, 0.6, 5))]                          # the light: a flattened icosphere
+    for k in range(39):
+        x, z = (k % 7 - 3) * 1.6 + rng.uniform(-0.3, 0.3), (k // 7 - 2.5) * 1.6 + rng.uniform(-0.3, 0.3)
+        geoms.append(oracle.make_geom(2, [1, 4, 5][k % 3], (x, rng.uniform(0.6, 2.5), z), tuple(rng.uniform(0, 90, 3)), tuple(rng.uniform(0.7, 1.4, 3))))
+    sc.geoms = np.concatenate(geoms).view(sc.geoms.dtype)
+    sc.meshes = {i: tris for i in range(1, 41)}
+    sc.set_resolution = None
+    got = _render_both(gpu, oracle, sc, 4, [1, 2], (96, 96), dump_bounces=(1, 2))
+    assert (got > 0).mean() > 0.01
+    small = gpu.Scene(os.path.join(SCENES, "mesh_small.txt"))
+    lds = _render_both(gpu, oracle, small, 5, [1, 2, 3], (96, 96))
+    monkeypatch.setenv("PT_AMD_WALK_ROWS_GLOBAL", "1")
+    glob = _render_both(gpu, oracle, small, 5, [1, 2, 3], (96, 96))
+    assert np.array_equal(lds.view(np.uint32), glob.view(np.uint32))
