@@ -49,6 +49,9 @@ int pt_test_sphere_halfline_sweep(const PtGeom *geoms, int ngeoms, uint64_t seed
  * the origins, the size of cluster 0 in the table, the two boxes {lo, hi, -, -}. */
 int pt_test_sphere_cluster_sweep(const PtGeom *geoms, int ngeoms, uint64_t seed, int64_t rays, uint64_t *certified2, uint64_t *violations,
                                  float *info18);
+/* ... and of the sphere GROUPS' bounding balls (k_bounce<..., GROUPS>: scenes of hundreds of swept primitives, pt_init: build_sphere_groups): a group
+ * certified as missed sends the ray through the full test of each of its 16 members; a hit is a violation (must be 0) */
+int pt_test_sphere_group_sweep(const PtGeom *geoms, int ngeoms, uint64_t seed, int64_t rays, uint64_t *certified, uint64_t *violations, int32_t *ngroups);
 /* ... and the clusters themselves for inspection (host only, no GPU needed): info18 as above; table[k] = the primitive behind entry k of the
  * sweep's table (cluster 0 = entries 0 .. info18[1] - 1, padded to an even count with a copy of its last sphere; then cluster 1 -- whose end pt_init
  * pads likewise), *ntable entries (<= table_cap). */

@@ -67,7 +67,7 @@ TEST_ABI_SYMBOLS = [
     "pt_test_force_fault", "pt_test_pow", "pt_test_wall_box_sweep", "pt_test_mesh_intersect", "pt_test_mesh_bvh",
     "pt_test_mesh_cull_sweep", "pt_test_camera_cull_sweep", "pt_test_camera_cull_tables",
     "pt_test_wall_plane_sweep", "pt_test_wall_planes", "pt_test_sphere_halfline_sweep", "pt_test_sphere_cluster_sweep", "pt_test_sphere_clusters", "pt_test_camera_cull_margin",
-    "pt_test_group_fail_next_reduce",
+    "pt_test_group_fail_next_reduce", "pt_test_sphere_group_sweep",
 ]
 
 
@@ -168,6 +168,7 @@ def _bind(L, with_tests):
         L.pt_test_wall_plane_sweep.argtypes = [vp, i32, C.c_uint64, i64, C.POINTER(C.c_int32)] + [u64p] * 3
         L.pt_test_wall_planes.argtypes = [vp, i32, vp, vp] + [C.POINTER(C.c_int32)] * 3
         L.pt_test_group_fail_next_reduce.argtypes = [vp, i32]
+        L.pt_test_sphere_group_sweep.argtypes = [vp, i32, C.c_uint64, i64, u64p, u64p, C.POINTER(C.c_int32)]
     return L
 
 
@@ -720,6 +721,14 @@ def test_sphere_cluster_sweep(geoms, seed, rays):
     _tcheck(test_lib().pt_test_sphere_cluster_sweep(_p(geoms), len(geoms), seed, rays, cert, C.byref(bad), info.ctypes.data))
     boxes = info[2:].reshape(2, 8)[:, :6].copy()
     return [int(cert[0]), int(cert[1])], int(bad.value), {"omax": float(info[0]), "n0": int(info[1]), "boxes": boxes}
+
+
+def test_sphere_group_sweep(geoms, seed, rays):
+    """(group certificates issued, violations, groups): pt_test_sphere_group_sweep"""
+    g = np.ascontiguousarray(geoms)
+    cert, viol, ng = C.c_uint64(), C.c_uint64(), C.c_int32()
+    _tcheck(test_lib().pt_test_sphere_group_sweep(_p(g), len(g), seed, rays, C.byref(cert), C.byref(viol), C.byref(ng)))
+    return int(cert.value), int(viol.value), int(ng.value)
 
 
 def sphere_clusters(geoms):

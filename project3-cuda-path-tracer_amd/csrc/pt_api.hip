@@ -112,6 +112,8 @@ struct State {
     MaterialDev *dmats = nullptr;
     WallBox *dwalls = nullptr;
     SphereCull *dSphCull = nullptr; // sphere-heavy scenes: packed culling data of the spheres, and ...
+    SphereCull *dSphGroups = nullptr;   // ... scenes of hundreds of them: the bounding balls of the table's groups (BounceArgs::sphGroups)
+    bool grouped = false;           // ... whose later bounces take the k_bounce<..., GROUPS> instantiations
     int *dRowOff = nullptr, *dRowIdx = nullptr;   // camera-ray bounce: per image row, the primitives whose pixel rectangle covers it
     int *dClassIdx = nullptr;       // later bounces: per queue class, the primitives to look at (KParams::classOff)
     float4 *dMeshRecs = nullptr;    // ptd::MeshUnit[]: triangles and inner nodes of every mesh of the scene (k_bounce<., ., ., true>)
@@ -220,11 +222,15 @@ int resolve_events(std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, double &ms
 
 // The instantiation of k_bounce a launch takes: FIRST (camera rays), MANY (per-lane sphere lists: scenes with more than
 // kBinMax spheres), DOF (thin lens: the camera-ray launch only), MESH (scenes with triangle meshes).
-template <bool F, bool M, bool D, bool ME, bool PL = false, bool CU = false>
-const void *kb() { return reinterpret_cast<const void *>(k_bounce<F, M, D, ME, PL, CU>); }
+template <bool F, bool M, bool D, bool ME, bool PL = false, bool CU = false, bool GR = false>
+const void *kb() { return reinterpret_cast<const void *>(k_bounce<F, M, D, ME, PL, CU, GR>); }
 const void *bounce_kernel(bool first, bool dof) {
     // (plain scenes -- diffuse / emissive / perfect-mirror materials, no README extra: the instantiations without the rarer branches)
     if (R().plain && !R().mesh && !R().many && !dof) return first ? kb<true, false, false, false, true>() : kb<false, false, false, false, true>();
+    if (R().grouped && !first)            // hundreds of swept primitives: the two-level sweep, nothing of the scene's tables in LDS
+        return R().sweptCubes ? kb<false, true, false, false, false, true, true>() : kb<false, true, false, false, false, false, true>();
+    if (R().grouped && !dof)              // ... and their (pinhole) camera-ray bounce: hit records, frames and rows from global memory too
+        return R().sweptCubes ? kb<true, true, false, false, false, true, true>() : kb<true, true, false, false, false, false, true>();
     if (R().many && R().sweptCubes) {     // many small primitives, cubes among them: the per-lane tests take either type
         if (R().mesh) return first ? (dof ? kb<true, true, true, true, false, true>() : kb<true, true, false, true, false, true>()) : kb<false, true, false, true, false, true>();
         return first ? (dof ? kb<true, true, true, false, false, true>() : kb<true, true, false, false, false, true>()) : kb<false, true, false, false, false, true>();
@@ -288,6 +294,7 @@ int launch_bounce(Slot &sl, int iter, int batch, int depth, bool lastBounce, flo
     memcpy(ba.walkClassOff, R().walkClassOff, sizeof ba.walkClassOff);
     ba.walkAll0 = R().walkAll0; ba.walkAll1 = R().walkAll1;
     ba.walkMeshRows = R().dWalkMeshRows; ba.walkMeshLds = R().walkMeshLds;
+    ba.sphGroups = R().dSphGroups;
     void *kargs[] = {&ba};
     const bool first = depth == 1;
     // scenes with meshes: the walks of this bounce's rays, ahead of it (pt_mesh_walk.h)
@@ -591,6 +598,7 @@ void free_renderer() {
     if (R().dmats) (void)hipFree(R().dmats);
     if (R().dwalls) (void)hipFree(R().dwalls);
     if (R().dSphCull) (void)hipFree(R().dSphCull);
+    if (R().dSphGroups) (void)hipFree(R().dSphGroups);
     if (R().dClassIdx) (void)hipFree(R().dClassIdx);
     if (R().dRowOff) (void)hipFree(R().dRowOff);
     if (R().dRowIdx) (void)hipFree(R().dRowIdx);
@@ -1080,6 +1088,26 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
                 if (!hg[i].binned && (hg[i].flags & 28) == 0 && !swept[i]) k.allClassified = 0;
         }
         if (sc.size() % 2) sc.push_back(sc.back());      // (two per scalar load; testing a sphere twice changes nothing)
+        // Hundreds of swept primitives (round 6): the flat sweep of the later bounces is linear in their number (512 spheres: 3.5 x the time of 64).
+        // The table then comes in spatial groups of kSphGroupSize with a bounding ball each, and the later bounces take instantiations of their
+        // own (k_bounce<..., GROUPS>: two-level sweep, no scene table in LDS).  PT_AMD_GROUPS=0 / 1: never / whenever possible (experiments, tests).
+        k.nSphGroups = 0; k.grpN0 = 0; k.grpOMax = 0.0f; k.grpLds = 0;
+        std::vector<SphereCull> groups;
+        {
+            const char *ge = getenv("PT_AMD_GROUPS");
+            R().grouped = meshRecs.empty() && (ge ? atoi(ge) != 0 : nswept >= kGroupedMin);
+            if (R().grouped) {
+                int n0 = k.sphN0;
+                const double ob = scene_origin_bound(geoms, ngeoms, hg);
+                build_sphere_groups(sc, n0, ob, sdir, groups, k.grpN0);
+                k.sphN0 = n0;
+                k.nSphGroups = (int)(sc.size() / (size_t)kSphGroupSize);
+                k.grpOMax = std::nextafter((float)ob, 0.0f);
+                k.grpLds = (int)sc.size() <= kGroupLdsMax ? 1 : 0;
+                HIPCHECK(hipMalloc(&R().dSphGroups, groups.size() * sizeof(SphereCull)));
+                HIPCHECK(hipMemcpy(R().dSphGroups, groups.data(), groups.size() * sizeof(SphereCull), hipMemcpyHostToDevice));
+            }
+        }
         k.nSphCull = (int)sc.size();
         HIPCHECK(hipMalloc(&R().dSphCull, sc.size() * sizeof(SphereCull)));
         HIPCHECK(hipMemcpy(R().dSphCull, sc.data(), sc.size() * sizeof(SphereCull), hipMemcpyHostToDevice));
@@ -1093,10 +1121,12 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
             // them a workgroup of the 518-primitive scene took 103 KB of LDS, one per CU.  The limit: what four workgroups per CU leave each.)
             const size_t rowsAll = (size_t)ngeoms * kSphRowFloats * sizeof(float);
             const size_t ldsWithRows = sizeof(MaterialDev) * nmats + (size_t)miscWords(kClsMax) * sizeof(uint32_t) + hitB + frameB + rowsAll + (size_t)kListMax * kBlock * sizeof(uint16_t);
-            const bool rowsInLds = ldsWithRows <= 40 * 1024 && !(getenv("PT_AMD_ROWS_GLOBAL") && atoi(getenv("PT_AMD_ROWS_GLOBAL")));   // (the variable: tests only)
+            const bool rowsInLds = ldsWithRows <= 40 * 1024 && !R().grouped && !(getenv("PT_AMD_ROWS_GLOBAL") && atoi(getenv("PT_AMD_ROWS_GLOBAL")));   // (the variable: tests only)
             k.ldsRowFloats = rowsInLds ? ngeoms * kSphRowFloats : 0;
             const size_t rowB = rowsInLds ? rowsAll : 0, mapB = ((size_t)k.nSphCull + 7) / 8 * 8 * sizeof(uint16_t);
-            std::vector<unsigned char> blob(hitB + frameB + rowB + mapB, 0);
+            // (+ 64 bytes: behind the last cube's frames a row of NaNs -- what k_bounce<..., GROUPS>, which reads the frames from this image in
+            // global memory, selects for a cube hit without an exit slab, as the other kernels select their NaN row in LDS)
+            std::vector<unsigned char> blob(hitB + frameB + rowB + mapB + 64, 0);
             std::vector<float> rowsGlobal(rowsInLds ? 0 : (size_t)ngeoms * kSphRowFloats, 0.0f);
             GeomHitSmall *hs = reinterpret_cast<GeomHitSmall *>(blob.data());
             float *fr = reinterpret_cast<float *>(blob.data() + hitB);
@@ -1111,6 +1141,10 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
                 memcpy(r, G.inv, 12 * sizeof(float)); memcpy(r + 12, G.xf, 12 * sizeof(float)); memcpy(r + 24, G.invZ, 3 * sizeof(float));
             }
             for (int i = 0; i < k.nSphCull; ++i) map[i] = (uint16_t)sc[i].geom;
+            if (R().grouped) {
+                const float qnan = std::nanf("");
+                for (int q = 0; q < 9; ++q) memcpy(blob.data() + hitB + (size_t)k.nCubes * 54 * sizeof(float) + q * sizeof(float), &qnan, sizeof qnan);
+            }
             if (R().dGeomHit) (void)hipFree(R().dGeomHit);
             R().dGeomHit = nullptr;
             HIPCHECK(hipMalloc(&R().dGeomHit, blob.size()));
@@ -1215,6 +1249,15 @@ int pt_init(const PtCamera *cam, const PtGeom *geoms, int ngeoms, const PtMateri
     k.pairOff = (int)(ldsFixed + sphMapBytes);
     R().ldsBytes = ldsFixed + (R().many ? std::max((size_t)kListMax * kBlock * sizeof(uint16_t), sphMapBytes + pairBytes) : 0);
     R().ldsBytesNext = (R().many && !R().mesh) ? ldsFixed + sphMapBytes + pairBytes : 0;
+    if (R().grouped && !R().dof)      // (the camera-ray bounce of a grouped scene: the materials and the lanes' candidate lists)
+        R().ldsBytes = sizeof(MaterialDev) * nmats + (size_t)miscWords(kClsMax) * sizeof(uint32_t) + (size_t)kListMax * kBlock * sizeof(uint16_t) + 16;
+    if (R().grouped)       // (the later bounces stage the materials and nothing else of the scene)
+    {
+        // (... and, behind them, the lanes' parked candidates: KParams::pairOff, [kCandPairs][kBlock] words)
+        const size_t members = sizeof(MaterialDev) * nmats + (size_t)miscWords(kClsMax) * sizeof(uint32_t) + (k.grpLds ? ((size_t)k.nSphCull * 18 + 15) / 16 * 16 : 0);
+        k.pairOff = (int)members;
+        R().ldsBytesNext = members + (size_t)kCandPairs * kBlock * sizeof(uint32_t) + 16;
+    }
     k.meshStackOff = 0;
     if (R().mesh) {        // (the lanes' stacks of far children belong to the walk's own launches: k_mesh_walk)
         R().ldsWalk = walkLdsBytes(meshStackNeed, R().walkMeshLds);

@@ -257,6 +257,97 @@ bool build_sphere_clusters(const PtGeom *geoms, int ngeoms, const std::vector<Ge
     return true;
 }
 
+// Scenes of HUNDREDS of swept primitives (k_bounce<..., GROUPS>): the packed table in spatial GROUPS of kSphGroupSize consecutive entries, each
+// with a bounding ball.  `sc` comes in as build_sphere_clusters left it (cluster 0 = [0, n0), cluster 1 = the rest; n0 = 0: no clusters) and
+// leaves with every cluster's entries ordered by recursive median splits of their centres (the widest axis; the left side a multiple of the
+// group size, so only a cluster's last group is short: padded with copies of its last entry -- testing a primitive twice changes nothing),
+// cluster 0 padded to an EVEN number of groups; `groups` receives one entry per group in the table's own format (geom = -1).
+// What a group's certificate rests on: its ball holds, for every member i, the ball of radius r_i = sqrt(cullR2_i + K_i ocMax_i^2) (1 + 1e-6)
+// around the member's centre -- exactly the balls build_sphere_clusters' boxes hold --, ocMax_i = omax + |centre_i| for the origins with
+// |x| + |y| + |z| <= omax.  The device tests the group like a member (ptd::sphereHalfLineExcessScaled, the scene's one scaled direction):
+// x = |oc|^2 - s^2 p^2 > T = R^2 s^2 (1 + 1e-6) implies d^2 - K_max |oc|^2 >= x / s^2 > R^2 up to fp32 rounding of x (4 ulp of |oc|^2 = 2.4e-7
+// |oc|^2, against K_max >= 1e-4), i.e. the exact half-line passes the group's ball at a distance -- and so every member's ball: each member's
+// own certificate would hold, with the room its ball was given.  Origins beyond omax take every group (k_bounce).
+// (tests/test_gpu_parity.py::test_sphere_group_balls_never_reject_a_hit: pt_test_sphere_group_sweep.)
+void build_sphere_groups(std::vector<SphereCull> &sc, int &n0, double omax, float sdir, std::vector<SphereCull> &groups, int &grpN0) {
+    const int S = kSphGroupSize;
+    auto order = [&](std::vector<SphereCull> &v) {
+        struct Rec {
+            std::vector<SphereCull> &v;
+            int S;
+            void run(int lo, int hi) {
+                if (hi - lo <= S) return;
+                double cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
+                for (int i = lo; i < hi; ++i)
+                    for (int a = 0; a < 3; ++a) { cmin[a] = std::min(cmin[a], (double)v[(size_t)i].centre[a]); cmax[a] = std::max(cmax[a], (double)v[(size_t)i].centre[a]); }
+                int axis = 0;
+                for (int a = 1; a < 3; ++a)
+                    if (cmax[a] - cmin[a] > cmax[axis] - cmin[axis]) axis = a;
+                int mid = lo + ((hi - lo) / 2 + S - 1) / S * S;
+                if (mid >= hi) mid = lo + (hi - lo) / 2 / S * S;
+                if (mid <= lo) return;
+                std::nth_element(v.begin() + lo, v.begin() + mid, v.begin() + hi, [axis](const SphereCull &x, const SphereCull &y) {
+                    return x.centre[axis] < y.centre[axis] || (x.centre[axis] == y.centre[axis] && x.geom < y.geom);
+                });
+                run(lo, mid);
+                run(mid, hi);
+            }
+        } r{v, S};
+        r.run(0, (int)v.size());
+        while (v.size() % (size_t)S) v.push_back(v.back());
+    };
+    std::vector<SphereCull> c0(sc.begin(), sc.begin() + n0), c1(sc.begin() + n0, sc.end());
+    if (!c0.empty()) {
+        order(c0);
+        if ((c0.size() / (size_t)S) % 2) c0.insert(c0.end(), c0.end() - S, c0.end());      // an even number of groups: the last one once more
+    }
+    if (!c1.empty()) order(c1);
+    sc = c0;
+    sc.insert(sc.end(), c1.begin(), c1.end());
+    n0 = (int)c0.size();
+    grpN0 = n0 / S;
+    groups.clear();
+    for (size_t g = 0; g * (size_t)S < sc.size(); ++g) {
+        double c[3] = {0, 0, 0};
+        for (int i = 0; i < S; ++i)
+            for (int a = 0; a < 3; ++a) c[a] += (double)sc[g * S + i].centre[a] / S;
+        SphereCull e;
+        memset(&e, 0, sizeof e);
+        for (int a = 0; a < 3; ++a) e.centre[a] = (float)c[a];
+        double R = 0;
+        for (int i = 0; i < S; ++i) {
+            const SphereCull &m = sc[g * S + i];
+            const double cn = std::sqrt((double)m.centre[0] * m.centre[0] + (double)m.centre[1] * m.centre[1] + (double)m.centre[2] * m.centre[2]);
+            const double ocMax = omax + cn;
+            const double r = std::sqrt((double)m.cullR2 + (double)m.cullK * ocMax * ocMax) * (1.0 + 1e-6);
+            const double dx = (double)m.centre[0] - e.centre[0], dy = (double)m.centre[1] - e.centre[1], dz = (double)m.centre[2] - e.centre[2];
+            R = std::max(R, std::sqrt(dx * dx + dy * dy + dz * dz) + r);
+        }
+        R *= 1.0 + 1e-6;
+        e.cullR2 = std::nextafter((float)(R * R * (double)sdir * (double)sdir * (1.0 + 1e-6)), INFINITY);
+        e.cullK = 0.0f;
+        e.geom = -1;
+        groups.push_back(e);
+    }
+    if (groups.size() % 2) groups.push_back(groups.back());      // (the table is read two entries per scalar load; the pad is never evaluated)
+}
+
+// the bound on the ray origins worth a certificate: a scattered ray starts on a primitive -- the scene's own extent, |x| + |y| + |z| over its
+// bounding box, with a quarter to spare (as build_sphere_clusters takes it)
+double scene_origin_bound(const PtGeom *geoms, int ngeoms, const std::vector<GeomDev> &hg) {
+    double omax = 0.0, slo[3] = {INFINITY, INFINITY, INFINITY}, shi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = 0; i < ngeoms; ++i) {
+        WallBox wb;
+        if (geoms[i].type == PT_CUBE && wall_box(geoms[i], wb) >= 0)
+            for (int a = 0; a < 3; ++a) { slo[a] = std::min(slo[a], (double)wb.lo[a]); shi[a] = std::max(shi[a], (double)wb.hi[a]); }
+        else if (std::isfinite(hg[i].boundR))
+            for (int a = 0; a < 3; ++a) { slo[a] = std::min(slo[a], (double)hg[i].centre[a] - hg[i].boundR); shi[a] = std::max(shi[a], (double)hg[i].centre[a] + hg[i].boundR); }
+    }
+    for (int a = 0; a < 3; ++a) omax += std::max(std::fabs(slo[a]), std::fabs(shi[a]));
+    omax *= 1.25;
+    return std::isfinite(omax) ? omax : 0.0;
+}
+
 // The walls of a scene -- its large cubes: not binned, finite, at most kWallMax of them, the largest first -- with what the survivors'
 // certificates need (k_bounce: which wall can a scattered ray still hit?): the inflated world boxes (wall_box), the bound on the ray
 // origins the margins hold for, and for the walls that have one the PLANE of their box that faces the scene's interior

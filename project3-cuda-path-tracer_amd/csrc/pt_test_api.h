@@ -448,6 +448,56 @@ int pt_test_sphere_cluster_sweep(const PtGeom *geoms, int ngeoms, uint64_t seed,
     return PT_OK;
 }
 
+int pt_test_sphere_group_sweep(const PtGeom *geoms, int ngeoms, uint64_t seed, int64_t rays, uint64_t *certified, uint64_t *violations, int32_t *ngroups) {
+    NEED_GPU();
+    if (!geoms || ngeoms < 2 || !certified || !violations || rays < 0) return fail(PT_ERR_INVALID, "pt_test_sphere_group_sweep: bad argument");
+    for (int i = 0; i < ngeoms; ++i)
+        if (geoms[i].type == PT_MESH) return fail(PT_ERR_INVALID, "pt_test_sphere_group_sweep: spheres and cubes only");
+    // the groups exactly as pt_init builds them for this scene's spheres (one cluster: clusters only split the table in two before the grouping)
+    std::vector<GeomDev> hg;
+    std::vector<SphereCull> sc;
+    pack_sphere_cull(geoms, ngeoms, hg, sc);
+    if (sc.size() < 2) return fail(PT_ERR_INVALID, "pt_test_sphere_group_sweep: fewer than two spheres");
+    double kmax = 0.0;
+    for (const SphereCull &e : sc) kmax = std::max(kmax, (double)e.cullK);
+    const float sdir = std::nextafter((float)std::sqrt(1.0 / (1.0 - kmax)), INFINITY);
+    const double ob = scene_origin_bound(geoms, ngeoms, hg);
+    std::vector<SphereCull> groups;
+    int n0 = 0, grpN0 = 0;
+    build_sphere_groups(sc, n0, ob, sdir, groups, grpN0);
+    const int ng = (int)(sc.size() / (size_t)kSphGroupSize);
+    if (ngroups) *ngroups = ng;
+    std::vector<GeomDev> hs;
+    for (const SphereCull &e : sc) hs.push_back(hg[e.geom]);
+    F3 slo = F3{INFINITY, INFINITY, INFINITY}, shi = F3{-INFINITY, -INFINITY, -INFINITY};
+    for (int i = 0; i < ngeoms; ++i) {
+        const float r = hg[i].boundR;
+        if (!std::isfinite(r)) continue;
+        slo = F3{std::min(slo.x, hg[i].centre[0] - r), std::min(slo.y, hg[i].centre[1] - r), std::min(slo.z, hg[i].centre[2] - r)};
+        shi = F3{std::max(shi.x, hg[i].centre[0] + r), std::max(shi.y, hg[i].centre[1] + r), std::max(shi.z, hg[i].centre[2] + r)};
+    }
+    DevBuf<GeomDev> ds;
+    DevBuf<SphereCull> dg;
+    DevBuf<unsigned long long> cnt;
+    UP(ds, hs.data(), (int)hs.size());
+    UP(dg, groups.data(), (int)groups.size());
+    int rc = cnt.alloc(2);
+    if (rc) return rc;
+    HIPCHECK(hipMemset(cnt.p, 0, 16));
+    const int per_thread = 64, threads = 256;
+    long long blocks = (rays + (long long)per_thread * threads - 1) / ((long long)per_thread * threads);
+    if (blocks < 1) blocks = 1;
+    if (blocks > (1 << 22)) blocks = 1 << 22;
+    hipLaunchKernelGGL(k_sweep_sphere_groups, dim3((unsigned)blocks), dim3(threads), 0, 0, ds.p, (int)hs.size(), dg.p, ng, sdir, std::nextafter((float)ob, 0.0f), slo, shi,
+                       (unsigned long long)seed, per_thread, cnt.p, cnt.p + 1);
+    HIPCHECK(hipDeviceSynchronize());
+    unsigned long long hc[2] = {0, 0};
+    HIPCHECK(hipMemcpy(hc, cnt.p, 16, hipMemcpyDeviceToHost));
+    *certified = hc[0];
+    *violations = hc[1];
+    return PT_OK;
+}
+
 int pt_test_wall_box_sweep(const PtGeom *geoms, int ngeoms, uint64_t seed, int64_t rays, uint64_t *culled, uint64_t *violations) {
     NEED_GPU();
     if (!geoms || ngeoms < 1 || !culled || !violations || rays < 0) return fail(PT_ERR_INVALID, "pt_test_wall_box_sweep: bad argument");

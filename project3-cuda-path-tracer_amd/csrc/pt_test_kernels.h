@@ -343,6 +343,73 @@ __global__ void k_sweep_sphere_clusters(const GeomDev *spheres, int nspheres, in
     if (nv) atomicAdd(violations, (unsigned long long)nv);
 }
 
+// Soundness sweep of the sphere GROUPS' bounding balls (k_bounce<..., GROUPS>; pt_host_scene.h: build_sphere_groups): `spheres` in table order,
+// group g = entries [16 g, 16 g + 16), groups[g] = its ball {centre, threshold of the scaled certificate}; certificates are issued for origins
+// with |x| + |y| + |z| <= omax.  Rays: scatters off a sphere's own surface; from the scene's extent towards a group's ball and its shell (0.9 ..
+// 1.2 of the radius, where the margins decide); from close by, towards it or away; axis- and plane-parallel directions with exact zeros; unit
+// and non-unit lengths.  A group certified as missed sends the ray through the FULL test of each of its members: a hit is a VIOLATION (0).
+__global__ void k_sweep_sphere_groups(const GeomDev *spheres, int nspheres, const SphereCull *groups, int ngroups, float sdir, float omax, F3 sceneLo,
+                                      F3 sceneHi, unsigned long long seed, int per_thread, unsigned long long *certified, unsigned long long *violations) {
+    unsigned long long x = seed + (blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ull;
+    unsigned int nc = 0, nv = 0;
+    for (int k = 0; k < per_thread; ++k) {
+        float u[12];
+        for (int j = 0; j < 12; ++j) {
+            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+            u[j] = (float)(x >> 40) * (1.0f / 16777216.0f);
+        }
+        const SphereCull Gs = groups[(int)(u[10] * (float)ngroups) % ngroups];
+        const F3 c = f3(Gs.centre[0], Gs.centre[1], Gs.centre[2]);
+        const float R = __builtin_sqrtf(Gs.cullR2) / sdir;
+        const float shell = u[9] < 0.5f ? 0.9f + 0.3f * u[8] : u[8];
+        const F3 tgt = c + normalize(f3(u[0] - 0.5f, u[1] - 0.5f, u[2] - 0.5f)) * (R * shell);
+        const int family = k & 3;
+        F3 org, dir;
+        if (family == 0) {              // a scatter off a sphere (any of them), any direction or at the group's shell
+            const GeomDev &G = spheres[(int)(u[3] * (float)nspheres) % nspheres];
+            const F3 pobj = normalize(f3(u[4] - 0.5f, u[5] - 0.5f, u[6] - 0.5f)) * 0.5f;
+            const F3 P = mulMV(G.xf, pobj, 1.0f);
+            const F3 N = normalize(mulMV(G.invT, pobj, 0.0f));
+            org = P + N * (u[7] < 0.5f ? 0.001f : -0.001f);
+            dir = u[11] < 0.5f ? normalize(f3(u[0] - 0.5f, u[1] - 0.5f, u[2] - 0.5f)) : normalize(tgt - org);
+        } else if (family == 1) {       // from the scene's extent towards the ball and its shell
+            org = f3(sceneLo.x + u[4] * (sceneHi.x - sceneLo.x), sceneLo.y + u[5] * (sceneHi.y - sceneLo.y), sceneLo.z + u[6] * (sceneHi.z - sceneLo.z));
+            dir = normalize(tgt - org);
+        } else if (family == 2) {       // from close to the ball (2^-8 .. 2^2 of its radius away from the target), towards it or away
+            const float dist = __builtin_exp2f(u[3] * 10.0f - 8.0f) * R;
+            const F3 od = normalize(f3(u[4] - 0.5f, u[5] - 0.5f, u[6] - 0.5f));
+            org = tgt + od * dist;
+            dir = normalize(tgt - org);
+            if (u[7] > 0.8f) dir = -dir;
+        } else {                        // axis-parallel and plane-parallel directions (exact zeros)
+            const float dist = __builtin_exp2f(u[3] * 10.0f - 8.0f) * R;
+            const int ax = (int)(u[7] * 3.0f) % 3;
+            F3 od = f3(ax == 0 ? 1.0f : 0.0f, ax == 1 ? 1.0f : 0.0f, ax == 2 ? 1.0f : 0.0f);
+            if (u[11] < 0.5f) od = normalize(f3(ax == 0 ? 0.0f : u[4] - 0.5f, ax == 1 ? 0.0f : u[5] - 0.5f, ax == 2 ? 0.0f : u[6] - 0.5f));
+            org = tgt + od * dist;
+            dir = -od;
+            if (u[8] > 0.8f) dir = od;
+        }
+        dir = dir * (u[9] < 0.7f ? 1.0f : __builtin_exp2f(4.0f * u[8] - 2.0f));
+        const float l1 = (__builtin_fabsf(org.x) + __builtin_fabsf(org.y)) + __builtin_fabsf(org.z);
+        if (!(l1 <= omax)) continue;
+        const F3 dhat = unitDirectionScaled(dir, dot(dir, dir), sdir);
+        for (int g = 0; g < ngroups; ++g) {
+            const SphereCull E = groups[g];
+            const float xe = sphereHalfLineExcessScaled(f3(E.centre[0], E.centre[1], E.centre[2]), org, dhat);
+            if (!(E.cullR2 < xe)) continue;                     // (the kernel's own comparison: candidate = !(cullR2 < x))
+            ++nc;
+            for (int si = g * kSphGroupSize; si < (g + 1) * kSphGroupSize && si < nspheres; ++si) {
+                F3 P, N;
+                bool o;
+                if (sphereIntersectionTest(spheres[si], org, dir, P, N, o) != -1.0f) ++nv;
+            }
+        }
+    }
+    if (nc) atomicAdd(certified, (unsigned long long)nc);
+    if (nv) atomicAdd(violations, (unsigned long long)nv);
+}
+
 // Soundness sweep of the camera-ray culling (GeomDev::rect, KParams::sceneRect, the per-row lists with their hull spans): every
 // pixel of the frame sends `samples` camera rays (the render kernel's own cameraRayAt: iterations 1 .. samples of the pixel's
 // depth-0 stream) through the FULL test of EVERY primitive, exactly the instantiations the camera-ray bounce runs.  A hit from a

@@ -145,6 +145,13 @@ struct KParams {
     int   ldsRowFloats;                // sphere-heavy scenes: floats of the primitives' matrix rows in LDS, ngeoms x kSphRowFloats -- or 0: the rows stay in global
                                        // memory (BounceArgs::rows; scenes of hundreds of primitives, whose rows would leave one workgroup per CU)
     int   pairOff;                     // sphere-heavy scenes, later bounces: byte offset of the pooled pass's pair descriptors in the dynamic LDS ([kWaves][64] words)
+    // scenes of HUNDREDS of swept primitives (round 6; k_bounce<..., GROUPS>): the table's entries come in spatial GROUPS of kSphGroupSize
+    // consecutive ones, each with a bounding ball of its members' certificate balls (BounceArgs::sphGroups, entries like the table's own); a
+    // later tile tests the groups' balls first and sweeps, lane by lane, only the groups its ray may reach
+    int   nSphGroups;                  // ... groups in all (0: none -- the flat sweep)
+    int   grpN0;                       // ... the first grpN0 of them hold cluster 0's entries [0, sphN0)
+    float grpOMax;                     // ... largest |x| + |y| + |z| of a ray origin the groups' certificates are issued for
+    int   grpLds;                      // ... 1: the entries' {centre, threshold} and primitive indices are staged in LDS behind the materials (nSphCull <= kGroupLdsMax)
     int   meshStackOff;                // scenes with meshes: byte offset of the lanes' traversal stacks in the dynamic LDS ([levels][kBlock] words)
     int   classOff[kClsMax + 1];          // later bounces: the primitives a tile of class c has to look at are classIdx[classOff[c] ..
                                        // classOff[c + 1]) (BounceArgs::classIdx): not the binned ones unless the class says so, of the walls only
@@ -352,6 +359,11 @@ struct SphereCull {
     int   pad[2];
 };
 static_assert(sizeof(SphereCull) == 32, "two per s_load_dwordx16");
+constexpr int kSphGroupSize = 8;         // entries per group (k_bounce<..., GROUPS>): an 8-bit outcome mask per lane and group
+constexpr int kCandPairs = 12;           // words a lane parks its candidates in between two rounds of passes (k_bounce<..., GROUPS>: [kCandPairs][kBlock] in LDS)
+constexpr int kGroupLdsMax = 1280;       // entries whose level-2 data -- {centre, threshold} 16 B + the primitive's index 2 B -- a grouped workgroup stages in LDS
+                                         // (23 KB: six workgroups per CU); a longer table is read from global memory, lane by lane
+constexpr int kGroupedMin = 128;         // swept primitives from which a scene's later bounces take the grouped instantiations (pt_init)
 typedef int int16v __attribute__((ext_vector_type(16)));
 
 // LDS layout of the sphere-heavy variants: the 68-byte hit records are padded to a multiple of 16 B, and so is the frame table
@@ -424,6 +436,7 @@ struct BounceArgs {
     // not fit the LDS, and one of a hundred would cost the kernel its residency)
     const float4 *walkMeshRows;
     int walkMeshLds;
+    const SphereCull *sphGroups;        // scenes of hundreds of swept primitives: the groups' bounding balls (KParams::nSphGroups), or nullptr
 };
 typedef const PT_CAS BounceArgs *ArgsPtr;
 typedef const PT_CAS GeomDev *GeomPtr;
@@ -464,13 +477,18 @@ static_assert(sizeof(CullGroup) == 32 && offsetof(GeomDev, cullFlags) - offsetof
 // CUBES (with MANY only): the swept small primitives include cubes -- the per-lane tests then look the primitive's type up and run the box
 // test for one; an instantiation of its own (four workgroups per CU: both tests inlined in every pass need the registers), so that a scene of
 // spheres runs exactly the code of rounds 2-4.
-template <bool FIRST, bool MANY, bool DOF = false, bool MESH = false, bool PLAIN = false, bool CUBES = false>
+// GROUPS (with MANY, no meshes): scenes of hundreds of swept primitives -- the later bounces' sweep is two-level (the groups' bounding balls,
+// then per LANE the members of the groups its ray may reach), and neither hit records nor matrix rows nor face frames are staged in LDS,
+// in the camera-ray bounce either (518 primitives' records left it three workgroups per CU): instantiations of their own, so that the
+// 64-sphere configuration runs the code it ran before.
+template <bool FIRST, bool MANY, bool DOF = false, bool MESH = false, bool PLAIN = false, bool CUBES = false, bool GROUPS = false>
 #ifndef PT_MESH_WG_FIRST
 #define PT_MESH_WG_FIRST 7
 #define PT_MESH_WG_NEXT 7
 #endif
-__global__ __launch_bounds__(kBlock, (MANY && CUBES) ? 4 : (MESH ? (MANY ? 4 : (FIRST ? PT_MESH_WG_FIRST : PT_MESH_WG_NEXT)) : (DOF ? 5 : (MANY ? (FIRST ? 7 : 6) : 8)))) void k_bounce(BounceArgs argsByValue) {
+__global__ __launch_bounds__(kBlock, (MANY && CUBES) ? 4 : (MESH ? (MANY ? 4 : (FIRST ? PT_MESH_WG_FIRST : PT_MESH_WG_NEXT)) : (DOF ? 5 : (MANY ? (FIRST ? 7 : (GROUPS ? 5 : 6)) : 8)))) void k_bounce(BounceArgs argsByValue) {
     static_assert(MANY || !CUBES, "swept cubes only exist where primitives are swept");
+    static_assert(!GROUPS || (MANY && !MESH && !DOF), "groups: sphere-heavy scenes without meshes (the camera-ray bounce: its pinhole form)");
     static_assert(FIRST || !DOF, "the lens only concerns the camera-ray bounce");
     (void)argsByValue;
     const ArgsPtr kargs = (ArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -602,7 +620,7 @@ __global__ __launch_bounds__(kBlock, (MANY && CUBES) ? 4 : (MESH ? (MANY ? 4 : (
         float4 *mdst = reinterpret_cast<float4 *>(smats);
         if ((int)threadIdx.x < m16) mdst[threadIdx.x] = stageM;
         for (int i = threadIdx.x + kBlock; i < m16; i += kBlock) mdst[i] = msrc[i];
-        if (MANY) {
+        if (MANY && !GROUPS) {
             // the tables of a sphere-heavy scene -- hit records, face frames, matrix rows, (later bounces) the sweep's entry -> primitive
             // map -- arrive as ONE host-built image in this very layout (pt_init): a straight copy, four 16-byte loads per lane in flight
             const int n16 = (int)((manyHitBytes(ngeoms) + (size_t)A->prm.nCubes * 54 * sizeof(float) + manyFramePad(A->prm.nCubes) +
@@ -621,6 +639,19 @@ __global__ __launch_bounds__(kBlock, (MANY && CUBES) ? 4 : (MESH ? (MANY ? 4 : (
                     const int i = i0 + q * kBlock + (int)threadIdx.x;
                     if (i < n16) dst[i] = v[q];
                 }
+            }
+        }
+        if (GROUPS && !FIRST && A->prm.grpLds) {
+            // the sweep's level-2 data: per entry {centre, threshold} (the first 16 bytes of its SphereCull) and the primitive's index -- what a
+            // lane reads for the members of ITS candidate groups (from global memory a group's sixteen-byte loads were a chain of round trips)
+            const int nS = A->prm.nSphCull;
+            float4 *const e16 = reinterpret_cast<float4 *>(smem + kMiscWords * sizeof(uint32_t) + sizeof(MaterialDev) * A->prm.nmats);
+            uint16_t *const emap = reinterpret_cast<uint16_t *>(e16 + nS);
+            const float4 *const src = reinterpret_cast<const float4 *>(A->sphCull);
+            for (int i = threadIdx.x; i < nS; i += kBlock) {
+                const float4 a = src[2 * i], b = src[2 * i + 1];
+                e16[i] = a;
+                emap[i] = (uint16_t)__float_as_int(b.y);
             }
         }
         if (!MANY) {
@@ -894,16 +925,18 @@ __global__ __launch_bounds__(kBlock, (MANY && CUBES) ? 4 : (MESH ? (MANY ? 4 : (
             int nCand = 0;                                       // MANY: spheres recorded by this lane
             float *s_sph = nullptr;                              // MANY: [ngeoms][kSphRowFloats], then [kListMax][kBlock] lists
             uint16_t *s_list = nullptr;
-            if (MANY) {
+            if (MANY && !GROUPS) {
                 const ArgsPtr A = launder(kargs);
                 s_sph = S_SPH(A->prm.nmats, A->prm.ngeoms, A->prm.nCubes);
                 s_list = reinterpret_cast<uint16_t *>(s_sph + (size_t)A->prm.ldsRowFloats);
+            } else if (GROUPS && FIRST) {                        // (no scene table in LDS: the lanes' candidate lists follow the materials)
+                s_list = reinterpret_cast<uint16_t *>(smem + kMiscWords * sizeof(uint32_t) + sizeof(MaterialDev) * launder(kargs)->prm.nmats);
             }
             // the matrix row of primitive g for a per-lane test: from the LDS table -- or, in a scene of hundreds of primitives whose rows
             // would leave one workgroup per CU, from their copy in global memory (KParams::ldsRowFloats; wave-uniform)
             auto loadRow = [&](int g, float (&m)[28]) {
                 const ArgsPtr A = launder(kargs);
-                if (A->prm.ldsRowFloats != 0) {
+                if (!GROUPS && A->prm.ldsRowFloats != 0) {
                     const float4 *row = reinterpret_cast<const float4 *>(s_sph + g * kSphRowFloats);
 #pragma unroll
                     for (int q = 0; q < 7; ++q) {
@@ -1021,7 +1054,9 @@ __global__ __launch_bounds__(kBlock, (MANY && CUBES) ? 4 : (MESH ? (MANY ? 4 : (
             auto sweptTest = [&](int g, const float (&m)[28], F3 ro, F3 rdir, F3 &p, F3 &n, bool &o) -> float {
                 if (CUBES) {
                     const ArgsPtr A = launder(kargs);
-                    if (S_GEOMHIT_SMALL(A->prm.nmats)[g].type == 1) {
+                    // (GROUPS: the hit records are not staged -- the image pt_init made of them in global memory, BounceArgs::ghit)
+                    const int type = GROUPS ? reinterpret_cast<const GeomHitSmall *>(A->ghit)[g].type : S_GEOMHIT_SMALL(A->prm.nmats)[g].type;
+                    if (type == 1) {
                         struct Rows { const float *inv, *invZ, *xf, *camObj; } rows = {m, m + 24, m + 12, m};
                         return boxIntersectionTest<false, false>(rows, ro, rdir, p, n, o);
                     }
@@ -1047,7 +1082,122 @@ __global__ __launch_bounds__(kBlock, (MANY && CUBES) ? 4 : (MESH ? (MANY ? 4 : (
                 }
             };
             if (MANY && !PACKED) candidatePass();
-            if (PACKED) {
+            if (PACKED && GROUPS) {
+                // TWO-LEVEL sweep (scenes of hundreds of swept primitives: the flat sweep below is linear in their number -- 512 spheres cost
+                // 3.5 x what 64 did).  Level 1: the groups' bounding balls, wave-uniform through the scalar path like the flat sweep's entries,
+                // the outcomes shifted into per-lane masks.  Level 2: every lane takes ITS next candidate group and runs the members' own
+                // certificates -- the flat sweep's, on the same operands: entries read per lane from the table in global memory -- then the
+                // reference's test on the members that remain.  A group's ball holds every member's certificate ball for origins within
+                // grpOMax (pt_init: build_sphere_groups), so a half-line that misses it passes every member's certificate: the members
+                // skipped are certified misses, the candidates the flat sweep's own -- same hits, same (distance, file order) winner.
+                probe(24);
+                const ArgsPtr A = launder(kargs);
+                int gN = A->prm.nSphGroups, gG0 = 0;
+                if (CLUSTER) {                                       // (the classes' cluster bits, as for the flat sweep)
+                    if (hotNow() & kHotReadsLastBits) {
+                        gN = (tileCls & 16u) ? gN : 0;
+                    } else {
+                        gN = (tileCls & 16u) ? gN : A->prm.grpN0;
+                        gG0 = (tileCls & 8u) ? 0 : A->prm.grpN0;
+                    }
+                }
+                const PT_CAS SphereCull *gt = (const PT_CAS SphereCull *)(A->sphGroups);
+                const float4 *const ent = reinterpret_cast<const float4 *>(A->sphCull);    // entry e: ent[2 e] = {centre, cullR2}, ent[2 e + 1] = {cullK, geom, -, -}
+                const F3 dhat = unitDirectionScaled(dir, dd, A->prm.sphDirScale);
+                // (an origin beyond the bound the groups' balls were built for -- none of a scattered ray's -- takes every group)
+                const bool nearO = (__builtin_fabsf(org.x) + __builtin_fabsf(org.y)) + __builtin_fabsf(org.z) <= A->prm.grpOMax;
+                for (int base = gG0; base < gN; base += 64) {         // (wave-uniform: rounds of 64 groups)
+                    uint32_t gHi = 0u, gLo = 0u;                      // group base + j: bit 31 - j of gHi (j < 32) / of gLo
+                    if (inScene) {
+                        auto sweepG = [&](int k0, uint32_t &m) {
+                            const int n = min(32, gN - k0);
+                            if (n <= 0) return;
+                            for (int k = 0; k < n; k += 2) {           // (two per 64-byte scalar load; the table is padded to an even count)
+                                int16v v;
+                                asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(gt + k0 + k) : "memory");
+#pragma unroll
+                                for (int h = 0; h < 2; ++h) {
+                                    if (h == 1 && k + 1 >= n) break;
+                                    const float x = sphereHalfLineExcessScaled(f3(__int_as_float(v[8 * h]), __int_as_float(v[8 * h + 1]), __int_as_float(v[8 * h + 2])), org, dhat);
+                                    asm("v_cmp_nlt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "s"(__int_as_float(v[8 * h + 3])), "v"(x) : "vcc");
+                                }
+                            }
+                            m <<= (32 - n);
+                            if (!nearO) m = 0xffffffffu << (32 - n);
+                        };
+                        sweepG(base, gHi);
+                        sweepG(base + 32, gLo);
+                    }
+                    probe(25);
+                    // level 2, lane by lane; `E16(e)` = entry e's {centre, threshold}, `GEOM(e)` = its primitive: from LDS (the common case) or global memory.
+                    // A lane's candidates are PARKED -- one word per group that has any: group << 8 | its members' outcome bits, in the lane's
+                    // column of an LDS list -- and tested when every lane is through with its groups: the passes then number the busiest lane's
+                    // candidates in all (3-4), where testing group by group cost a pass per group turn with a handful of lanes at work.
+                    auto level2 = [&](auto E16, auto GEOM) {
+                        uint32_t *const s_cand = reinterpret_cast<uint32_t *>(smem + A->prm.pairOff) + tid;      // [kCandPairs][kBlock]
+                        uint32_t nP = 0u;                             // words parked by this lane
+                        auto passes = [&]() {
+                            uint32_t rd = 0u, cur = 0u;               // the word being consumed: group << 8 | bits left
+                            for (;;) {
+                                if ((cur & 0xffu) == 0u && rd < nP) { cur = s_cand[rd * kBlock]; ++rd; }
+                                const bool has = (cur & 0xffu) != 0u;
+                                if (__ballot(has) == 0ull) break;     // (wave-uniform: the busiest lane's candidates)
+                                if (has) {
+                                    const int j = __builtin_clz(cur << 24);           // member 0 at bit 7
+                                    cur &= ~(0x80u >> j);
+                                    const int g = GEOM((int)(cur >> 8) * kSphGroupSize + j);
+                                    float mr[28];
+                                    loadRow(g, mr);
+                                    F3 p, n;
+                                    bool o = false;
+                                    probe(4);
+                                    const float t = sweptTest(g, mr, org, dir, p, n, o);
+                                    if (t > 0.0f && (hit < 0 || t < tbest || (t == tbest && g < hit))) {
+                                        tbest = t; hit = g; P = p; nsrc = n; outsideI = o ? 1 : 0;
+                                    }
+                                }
+                            }
+                            nP = 0u;
+                        };
+                        while (__ballot((gHi | gLo) != 0u) != 0ull) { // wave-uniform trip count: the busiest lane's candidate groups
+                            if (__ballot(nP >= (uint32_t)kCandPairs) != 0ull) passes();      // (a lane's column is full: everybody tests what is parked)
+                            if ((gHi | gLo) != 0u) {
+                                const bool hi = gHi != 0u;
+                                const uint32_t mm = hi ? gHi : gLo;
+                                const int j = __builtin_clz(mm);
+                                const uint32_t rest = mm & ~(0x80000000u >> j);
+                                gHi = hi ? rest : gHi;
+                                gLo = hi ? gLo : rest;
+                                const int grp = base + (hi ? 0 : 32) + j;
+                                const int e0 = grp * kSphGroupSize;
+                                uint32_t m = 0u;                      // member i: bit 7 - i
+#pragma unroll
+                                for (int q = 0; q < kSphGroupSize; q += 4) {       // (four loads in flight: sixteen registers, not thirty-two)
+                                    float4 c[4];
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i) c[i] = E16(e0 + q + i);
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i) {
+                                        probe(3);
+                                        const float x = sphereHalfLineExcessScaled(f3(c[i].x, c[i].y, c[i].z), org, dhat);
+                                        m = (m << 1) | (!(c[i].w < x) ? 1u : 0u);  // candidate = !(cullR2 < x) (NaN: candidate)
+                                    }
+                                }
+                                if (m != 0u) { s_cand[nP * kBlock] = ((uint32_t)grp << 8) | m; ++nP; }
+                            }
+                        }
+                        passes();
+                    };
+                    if (A->prm.grpLds) {
+                        const float4 *const e16 = reinterpret_cast<const float4 *>(smem + kMiscWords * sizeof(uint32_t) + sizeof(MaterialDev) * A->prm.nmats);
+                        const uint16_t *const emap = reinterpret_cast<const uint16_t *>(e16 + A->prm.nSphCull);
+                        level2([&](int e) { return e16[e]; }, [&](int e) { return (int)emap[e]; });
+                    } else {
+                        level2([&](int e) { return ent[2 * e]; }, [&](int e) { return __float_as_int(ent[2 * e + 1].y); });
+                    }
+                }
+            }
+            if (PACKED && !GROUPS) {
                 // The sweep keeps no list: the outcome of a sphere's bounding-ball test (sphereHalfLineExcess, pt_device.h) is SHIFTED into a per-lane bit mask (compare,
                 // then add-with-carry m = m + m + vcc: two instructions, no branch, no exec-mask change, no LDS), 64 spheres per
                 // round; the candidate passes then take each lane's set bits from the top.  (Rounds 1-3 recorded up to eight
@@ -1211,9 +1361,10 @@ __global__ __launch_bounds__(kBlock, (MANY && CUBES) ? 4 : (MESH ? (MANY ? 4 : (
                 const float4 *hrec1 = nullptr;                   // small scenes: the record's second 16 bytes {material colour, material index}
                 if (MANY) {
                     const ArgsPtr A = launder(kargs);
-                    const GeomHitSmall &h = S_GEOMHIT_SMALL(A->prm.nmats)[hit];
+                    const GeomHitSmall &h = GROUPS ? reinterpret_cast<const GeomHitSmall *>(A->ghit)[hit] : S_GEOMHIT_SMALL(A->prm.nmats)[hit];
                     ghType = h.type; ghMaterial = h.material; ghNm = h.nm;
-                    ghFrame = S_FRAMES(A->prm.nmats, A->prm.ngeoms) + h.frame * 54;
+                    ghFrame = (GROUPS ? reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(A->ghit) + manyHitBytes(A->prm.ngeoms))
+                                      : S_FRAMES(A->prm.nmats, A->prm.ngeoms)) + h.frame * 54;
                     if (MESH && faceMat != 0) ghMaterial = faceMat - 1;
                     const MaterialDev &Mm = smats[ghMaterial];
                     mEmit = Mm.emittance; mRefl = Mm.hasReflective; mRefr = Mm.hasRefractive;
@@ -1239,7 +1390,11 @@ __global__ __launch_bounds__(kBlock, (MANY && CUBES) ? 4 : (MESH ? (MANY ? 4 : (
                 const bool outside = (outsideI & 1) != 0;
                 // a cube face's frame (normal + the sampler's two tangents, nine floats): ONE select on the address -- the face's
                 // row of the table, or the row of NaNs for a hit without an exit slab -- instead of nine on the values
-                const float *const fv = faceOk ? ghFrame + 9 * face : s_nan;
+                // (GROUPS: the frames live in global memory, and so does their row of NaNs -- behind the last cube's frames, pt_init)
+                const float *const nanRow = GROUPS ? reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(launder(kargs)->ghit) +
+                                                                                     manyHitBytes(launder(kargs)->prm.ngeoms)) + launder(kargs)->prm.nCubes * 54
+                                                   : s_nan;
+                const float *const fv = faceOk ? ghFrame + 9 * face : nanRow;
                 const F3 N = isSphere ? hitNormalSphere(ghNm, nsrc, outside) : f3(fv[0], fv[1], fv[2]);
                 F3 mcol = mcolMany;
                 if (!MANY) {

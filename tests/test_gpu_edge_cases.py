@@ -528,3 +528,36 @@ def test_matrix_rows_from_global_memory_in_scenes_of_hundreds_of_primitives(gpu,
         _compare(gpu, oracle, sc, [1, 2, 3])
         _compare(gpu, oracle, sc, [4, 5, 6, 7], max_batch=4, pipeline_depth=2)
     monkeypatch.delenv("PT_AMD_ROWS_GLOBAL")
+
+
+@pytest.mark.gpu
+def test_grouped_sweep_of_scenes_of_hundreds_of_primitives(gpu, oracle, monkeypatch):
+    # round 6: beyond 128 swept primitives the later bounces take k_bounce<..., GROUPS> -- the table in spatial groups
+    # of 16 with a bounding ball each, a two-level sweep (the groups' balls wave-uniform, then per LANE the members of the groups its ray may
+    # reach), hit records / frames / matrix rows read from global memory.  The 518-sphere scene and the 200 random ellipsoids take it by
+    # themselves; PT_AMD_GROUPS=1 forces it on the 64-sphere scene (two clusters, a light behind the first candidate bit, last-bounce bits)
+    # and on the 64-cube scene (swept cubes: the per-lane box test, the frames' NaN row in global memory); PT_AMD_GROUPS=0 renders the
+    # 518-sphere scene with the flat sweep.  All against the oracle, bit for bit -- frames and live counts.
+    sc = gpu.Scene(os.path.join(SCENES, "spheres512.txt"))
+    sc.set_resolution(96, 64)
+    _compare(gpu, oracle, sc, [1, 2])
+    _compare(gpu, oracle, sc, [3, 4, 5, 6], max_batch=4, pipeline_depth=2)
+    monkeypatch.setenv("PT_AMD_GROUPS", "0")
+    _compare(gpu, oracle, sc, [1, 2])
+    monkeypatch.setenv("PT_AMD_GROUPS", "1")
+    for name in ("spheres64.txt", "cubes64.txt"):
+        sc = gpu.Scene(os.path.join(SCENES, name))
+        sc.set_resolution(96, 64)
+        _compare(gpu, oracle, sc, [1, 2, 3])
+        _compare(gpu, oracle, sc, [4, 5, 6, 7], max_batch=4, pipeline_depth=2)
+    # coincident and nested spheres (every one a candidate of the same groups: file order decides the ties), as a grouped scene
+    geoms = [oracle.make_geom(1, 1, (0, -1, 0), (0, 0, 0), (30, 1, 30)), oracle.make_geom(0, 0, (0, 12, 0), (0, 0, 0), (6, 1, 6))]
+    for k in range(12):
+        geoms.append(oracle.make_geom(0, 1 + k % 3, (0, 4, 0), (0, 0, 0), (3, 3, 3)))
+    for k in range(10):
+        geoms.append(oracle.make_geom(0, 3, (0, 4, 0), (10 * k, 5 * k, 0), (3.2 + 0.4 * k, 3.2 + 0.3 * k, 3.2 + 0.5 * k)))
+    mats = np.concatenate([_mat(oracle, emit=4.0), _mat(oracle, (.8, .8, .8)), _mat(oracle, (.9, .3, .3), refl=1.0, spec=(.9, .9, .9)),
+                           _mat(oracle, (.95, .95, .95), refr=1.0, ior=1.5, spec=(.95, .95, .95))])
+    sc = _scene(gpu, oracle, np.concatenate(geoms), mats, (96, 64), 10, eye=(0, 5, 14))
+    _compare(gpu, oracle, sc, [1, 2, 3], max_batch=4, pipeline_depth=2)
+    monkeypatch.delenv("PT_AMD_GROUPS")

@@ -225,6 +225,28 @@ def test_sphere_cluster_boxes_never_reject_a_hit(gpu, oracle):
     assert total > 0
 
 
+def test_sphere_group_balls_never_reject_a_hit(gpu, oracle):
+    # round 6: scenes of hundreds of swept primitives keep their packed table in spatial groups of 16 with a bounding ball each; a later
+    # tile sweeps a group's members only for the lanes whose half-line may reach the ball (k_bounce<..., GROUPS>; pt_host_scene.h:
+    # build_sphere_groups).  A ball certified as missed must imply the reference's miss (src/intersections.h:101-143) for EVERY member.
+    # 2^28 rays per scene: the 512-sphere lattice; 300 random ellipsoids (anisotropic: K |oc|^2 is large for them), tiny and large,
+    # rotated; a cloud far off the origin.
+    sc = oracle.Scene(os.path.join(SCENES, "spheres512.txt"))
+    rng = np.random.default_rng(43)
+    odd = [oracle.make_geom(1, 1, (0, 0, 0), (0, 0, 0), (30, 0.02, 30)), oracle.make_geom(1, 1, (0, 12, 0), (0, 0, 30), (30, 0.02, 30))]
+    for i in range(300):
+        c = rng.uniform(-6, 6, 3) + np.array([3.0, 6.0, -2.0])
+        scale = np.exp(rng.uniform(np.log(0.05), np.log(2.0), 3)) if i % 3 else np.full(3, np.exp(rng.uniform(np.log(0.05), np.log(3.0))))
+        odd.append(oracle.make_geom(0, 1, tuple(c), tuple(rng.uniform(-180, 180, 3)), tuple(scale)))
+    far = [oracle.make_geom(1, 1, (100, -50, 25), (0, 0, 0), (60, 0.1, 60))]
+    for i in range(150):
+        far.append(oracle.make_geom(0, 1, tuple(np.array([100.0, -40.0, 25.0]) + rng.uniform(-20, 20, 3)), (0, 0, 0), (0.5 + 0.02 * i,) * 3))
+    for name, geoms in (("spheres512", sc.geoms), ("odd", np.concatenate(odd)), ("far", np.concatenate(far))):
+        cert, bad, ng = gpu.test_sphere_group_sweep(geoms.view(gpu.GEOM_DTYPE), 4343 + _SW - 1, (1 << 28) * _SW)
+        assert bad == 0, (name, bad, cert, ng)
+        assert ng >= 9 and cert > (1 << 28), (name, cert, ng)        # (every ray is tried against every group: most groups are certified)
+
+
 def test_cube_culling_never_rejects_a_hit(gpu, oracle):
     # the same bounding-ball test decides which queue tiles skip the scene's small cubes (k_bounce bins survivors by
     # it): it must imply the reference's own miss for cubes of every shape -- the Cornell light and walls, thin plates
