@@ -112,7 +112,7 @@ def test_driver_command_reports_every_one_gpu_configuration(pt):
     assert rf["hbm"]["unit"] == "GB/s" and 0 < rf["hbm"]["frac"] < 1
     # (the mesh scene's launch is the pair k_mesh_walk + k_bounce: the walk reads the rays of the tiles that list a mesh once more and leaves an
     # 8-byte record per path, which the algorithmic figure -- the path state in and out, as for every configuration -- does not count)
-    for k, hi in (("c4", 1.6), ("mesh", 2.0)):
+    for k, hi in (("c4", 1.6), ("mesh", 1.7)):      # (mesh: 1.59-1.60 measured in rounds 5 and 6; round 5 had loosened the bound to 2.0)
         assert cf[k]["roofline"]["traffic"] is not None and 0.9 < cf[k]["roofline"]["traffic_over_algorithmic"] < hi
     # round 6: the C ABI's own multi-device host path is IN the driver's line.  Eight members on the one device
     # (a host thread each, one shared accumulator) against the headline; config C3 as written through the LIBRARY's per-iteration reduce
