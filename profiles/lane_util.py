@@ -6,7 +6,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = {}
 for tag in sys.argv[1:]:
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
-    for f in glob.glob(os.path.join(ROOT, "gpurun_out", "lane_" + tag, "pass*", "*", "*counter_collection.csv")):
+    files = []
+    for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "lane_" + tag, "pass*"))):      # (gpurun MERGES runs: the newest file of every pass)
+        fs = sorted(glob.glob(os.path.join(d, "*", "*counter_collection.csv")), key=os.path.getmtime)
+        files += fs[-1:]
+    for f in files:
         for r in csv.DictReader(open(f)):
             m = re.search(r"(k_bounce|k_mesh_walk|k_commit\w*)(<[^>]*>)?", r["Kernel_Name"])
             if m:
