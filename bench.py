@@ -846,6 +846,22 @@ def run(args, ctx):
     #      N > 1: rank 0 starts a group over the N devices -- what the reference's single-process host (src/main.cpp:72-113) would drive.
     groups = None
     want_groups = args.group_blocks if args.group_blocks is not None else (args.configs if world == 1 else args.extra_passes)
+    def wait_for_rank0(key):
+        """the other ranks wait ON THE HOST for rank 0's child process (a key of the rendezvous store): a collective barrier would spin on
+        their GPUs for as long as the group measurement -- which uses those very GPUs -- takes"""
+        if world == 1:
+            return
+        try:
+            import datetime
+            from torch.distributed.distributed_c10d import _get_default_store
+            store = _get_default_store()
+            if rank == 0:
+                store.set(key, "1")
+            else:
+                store.wait([key], datetime.timedelta(seconds=900))
+        except Exception:
+            pass                                            # (the barrier below still brings the ranks together)
+
     if want_groups:
         barrier()
         if rank == 0:
@@ -857,6 +873,7 @@ def run(args, ctx):
                 nd = min(world, ngpu)
                 groups["group"] = group_block(args, world, nd)
                 groups["group_c3_as_written"] = group_block(args, world, nd, c3=True)
+        wait_for_rank0("pt_amd_group_blocks_done")
         barrier()
 
     iters_block = args.steps * I                             # iterations of one timed block
