@@ -191,3 +191,13 @@ def test_foreign_obj_material_names_fall_back_to_the_objects_material(pt, tmp_pa
     sc = pt.Scene(str(tmp_path / "s.txt"))
     assert sc.mesh_materials[0].tolist() == [1, -1, -1, -1]
     assert "2 faces name a material" in capfd.readouterr().out
+
+
+def test_bench_group_mode_without_a_gpu_fails_loudly(pt):
+    # `bench.py --group M` (the C ABI's device groups, what the `group` blocks of the driver's line run) has no CPU fallback either:
+    # without a HIP device it says so and exits non-zero -- no line, no oracle standing in
+    if pt.device_count() > 0:
+        pytest.skip("GPU present")
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--group", "2", "--steps", "1", "--warmup", "1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1 and "needs a GPU" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
