@@ -84,11 +84,11 @@ struct Slot {
     unsigned long long *chunkList[2] = {nullptr, nullptr}; // per pool: [kSeg][poolChunks] chunk lists of the queue it holds
     uint32_t gen[2] = {0, 0};      // per pool: serial number of the launch that filled it (tags the chunk-list entries)
     Ctrl *ctrl = nullptr;
-    float *contrib = nullptr;      // maxBatch x W*H*3, zero between batches
+    float *contrib = nullptr;      // maxBatch x W*H*3: an entry is valid while its bit of `hitMask` is set
     uint32_t *hitMask = nullptr;   // ceil(maxBatch / 32) x W*H: which iterations of the batch wrote a pixel's `contrib`, zero between batches
     unsigned long long *meshHit = nullptr;   // scenes with meshes: the walks' result per path of the bounce being launched (BounceArgs::meshHit)
     hipEvent_t evDone = nullptr;       // all bounce launches of the slot's current iteration finished
-    hipEvent_t evCommitted = nullptr;  // k_commit consumed (and re-zeroed) `contrib`
+    hipEvent_t evCommitted = nullptr;  // k_commit consumed `contrib` (cleared the masks' bits)
     int parity = 0;                // which half of Ctrl::cursor the slot's next batch uses
 };
 
