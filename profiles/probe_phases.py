@@ -13,7 +13,8 @@ L.pt_probe_read.argtypes = [C.POINTER(C.c_uint64)]
 names = ["box: transform + early miss", "box: normalize + slabs", "box: hit phase", "sphere: cull test",
          "sphere: transform + radicand", "sphere: roots", "sphere: hit phase", "tile (later bounces)",
          "tile (camera bounce, in scene)", "shading (a hit)", "scatter", "hemisphere sample", "bounding-ball certificate", "wall certificate"]
-SCENES = (("cornell.txt", (1280, 720), 1), ("cornell.txt", (1280, 720), 8), ("cornell_glass.txt", (1920, 1080), 16), ("spheres64.txt", (1024, 1024), 8), ("cornell_mesh.txt", (1280, 720), 8))
+SCENES = (("cornell.txt", (1280, 720), 1), ("cornell.txt", (1280, 720), 8), ("cornell_glass.txt", (1920, 1080), 16), ("spheres64.txt", (1024, 1024), 8), ("cornell_mesh.txt", (1280, 720), 8),
+          ("cubes64.txt", (1024, 1024), 8), ("spheres512.txt", (1024, 1024), 8))
 if len(sys.argv) > 1: SCENES = tuple(x for x in SCENES if x[0] in sys.argv[1:])
 for scene_name, res, depth in SCENES:
     sc = pt.Scene(os.path.join(ROOT, "scenes", scene_name))
