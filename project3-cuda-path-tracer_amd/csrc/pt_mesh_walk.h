@@ -285,7 +285,8 @@ __global__ __launch_bounds__(kBlock, (FIRST && !DOF) ? 7 : 8) void k_mesh_walk(B
                 const unsigned long long b = __ballot(want);
                 if (b != 0ull) {
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
-                    if (want) s_queue[qn + rank] = ((unsigned long long)(uint32_t)G.frameSlot << 32) | idx;
+                    // (bit 63: the tile lists this ONE mesh -- its record has no rival to be compared with: see the fold)
+                    if (want) s_queue[qn + rank] = ((unsigned long long)(((uint32_t)G.frameSlot & 0x7fffu) | (l1 - l0 == 1 ? 0x80000000u : 0u)) << 32) | idx;
                     qn += (uint32_t)__popcll(b);
                 }
             }
@@ -335,7 +336,12 @@ __global__ __launch_bounds__(kBlock, (FIRST && !DOF) ? 7 : 8) void k_mesh_walk(B
             const bool pending = !busy && jobIdx != kNoJob;
             probeCount(21, pending);                            // (instrumented build: the walk's wave steps and their lanes)
             if (pending) {
-                if (keyT != 0xffffffffu) {
+                if (keyT != 0xffffffffu && (jobGeom & 0x80000000u) != 0u) {
+                    // the tile lists one mesh: nothing to take a minimum with -- the bounce evaluates the winner's distance itself (meshWinner: the
+                    // same operations on the same operands) and drops a hit at distance <= 0 exactly as the comparison below would have.  A plain
+                    // store of the winner in place of the ray's re-read, the point, its transform, the length and the atomic.
+                    A.meshHit[jobIdx] = (unsigned long long)keyI;
+                } else if (keyT != 0xffffffffu) {
                     // (the ray's origin in the world: the eye for pinhole camera rays, else the first of the path's two 16-byte words)
                     F3 org, dir;
                     if (FIRST && !DOF) org = f3(prm.pos[0], prm.pos[1], prm.pos[2]);
@@ -344,7 +350,7 @@ __global__ __launch_bounds__(kBlock, (FIRST && !DOF) ? 7 : 8) void k_mesh_walk(B
                         const float4 a = *reinterpret_cast<const float4 *>(A.in.arrA(jobIdx));
                         org = f3(a.x, a.y, a.z);
                     }
-                    withMesh(jobGeom, [&](const WalkMesh &G) {
+                    withMesh(jobGeom & 0x7fffu, [&](const WalkMesh &G) {
                         const F3 P = mulMV(G.xf, getPointOnRay(ro, rd, __uint_as_float(keyT)), 1.0f);
                         const float t = length(org - P);
                         if (t > 0.0f)
@@ -366,7 +372,7 @@ __global__ __launch_bounds__(kBlock, (FIRST && !DOF) ? 7 : 8) void k_mesh_walk(B
                 jobGeom = (uint32_t)(job >> 32);
                 F3 org, dir;
                 fetchRay(jobIdx, org, dir);
-                withMesh(jobGeom, [&](const WalkMesh &G) {
+                withMesh(jobGeom & 0x7fffu, [&](const WalkMesh &G) {
                     ro = (FIRST && !DOF) ? f3(G.camObj[0], G.camObj[1], G.camObj[2]) : mulMV(G.inv, org, 1.0f);
                     rd = normalize(mulMV0(G.inv, G.invZ, dir));
                     inv = f3(guardedReciprocal(rd.x), guardedReciprocal(rd.y), guardedReciprocal(rd.z));

@@ -424,6 +424,7 @@ struct BounceArgs {
     uint32_t *hostFault;                // the sticky fault word's copy in page-locked host memory (written by a batch's last launch), or nullptr
     // ---- scenes with meshes: the walks run AHEAD of the bounce (k_mesh_walk) and leave, per path of a tile that lists a mesh, the nearest
     // mesh hit: meshHit[i] = bits of its distance << 32 | the winning triangle's unit << 1 | front side (all ones: none), i = the path's slot
+    // (the distance only orders the hits of SEVERAL meshes -- the walk's atomic minimum; a tile that lists one mesh leaves it zero)
     // in the input pool (camera rays: its index in the tiles' padded pixel space)
     const float4 *rows;                 // sphere-heavy scenes: [ngeoms][7] the primitives' matrix rows (inverseTransform, transform, GeomDev::invZ), as the LDS copy holds them
     unsigned long long *meshHit;
