@@ -1538,9 +1538,12 @@ int pt_scan_exclusive_i32(const int32_t *in_dev, int32_t *out_dev, int64_t n, vo
     // their two reads, so it moves the same 12 bytes and adds the ticket and the wait; kept selectable, not the default.
     const char *mode = getenv("PT_AMD_SCAN");
     if (!(mode && atoi(mode) == 1)) {
-        hipLaunchKernelGGL((k_scan_reduce<false>), dim3(chunks), dim3(kBlock), 0, st, in_dev, (long long)n, per, wp->partial);
+        // (chunks of four tiles or more take the kernels that load a tile ahead)
+        if (per >= 4) hipLaunchKernelGGL((k_scan_reduce<false, true>), dim3(chunks), dim3(kBlock), 0, st, in_dev, (long long)n, per, wp->partial);
+        else hipLaunchKernelGGL((k_scan_reduce<false, false>), dim3(chunks), dim3(kBlock), 0, st, in_dev, (long long)n, per, wp->partial);
         hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(kBlock), 0, st, wp->partial, chunks, (long long *)nullptr);
-        hipLaunchKernelGGL(k_scan_apply, dim3(chunks), dim3(kBlock), 0, st, in_dev, out_dev, (long long)n, per, wp->partial);
+        if (per >= 4) hipLaunchKernelGGL((k_scan_apply<true>), dim3(chunks), dim3(kBlock), 0, st, in_dev, out_dev, (long long)n, per, wp->partial);
+        else hipLaunchKernelGGL((k_scan_apply<false>), dim3(chunks), dim3(kBlock), 0, st, in_dev, out_dev, (long long)n, per, wp->partial);
     } else {
         if (++wp->gen == 0u) ++wp->gen;
         HIPCHECK(hipMemsetAsync(wp->chained, 0, sizeof(uint32_t), st));          // the ticket (the sums are tagged with the call's generation)
@@ -1567,7 +1570,8 @@ int pt_compact_nonzero_i32(const int32_t *in_dev, int32_t *out_dev, int64_t n, i
     long long per;
     int chunks;
     scan_chunks(n, &per, &chunks);
-    hipLaunchKernelGGL((k_scan_reduce<true>), dim3(chunks), dim3(kBlock), 0, st, in_dev, (long long)n, per, wp->partial);
+    if (per >= 4) hipLaunchKernelGGL((k_scan_reduce<true, true>), dim3(chunks), dim3(kBlock), 0, st, in_dev, (long long)n, per, wp->partial);
+    else hipLaunchKernelGGL((k_scan_reduce<true, false>), dim3(chunks), dim3(kBlock), 0, st, in_dev, (long long)n, per, wp->partial);
     hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(kBlock), 0, st, wp->partial, chunks, reinterpret_cast<long long *>(count_dev));
     hipLaunchKernelGGL(k_compact_apply, dim3(chunks), dim3(kBlock), 0, st, in_dev, out_dev, (long long)n, per, wp->partial);
     HIPCHECK(hipGetLastError());

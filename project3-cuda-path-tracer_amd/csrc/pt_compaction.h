@@ -68,7 +68,9 @@ __device__ __forceinline__ uint32_t tile_offsets(uint32_t mine, uint32_t *s_wave
 }
 
 // 1. chunk totals: COUNT = false: sum of the elements (mod 2^32); true: number of non-zero elements
-template <bool COUNT>
+// PIPE (chunks of four tiles or more): the next tile's loads are issued before the current tile is worked on -- +4 .. 5 % at 2^26 and 2^28
+// elements, -4 % at 2^24, where a chunk is two tiles: the host picks (profiles/r06_scan_summary.txt)
+template <bool COUNT, bool PIPE>
 __global__ __launch_bounds__(kBlock) void k_scan_reduce(const int32_t *__restrict__ in, long long n, long long tilesPerChunk,
                                                         uint32_t *__restrict__ partial) {
     __shared__ uint32_t s_wave[kWaves];
@@ -77,12 +79,18 @@ __global__ __launch_bounds__(kBlock) void k_scan_reduce(const int32_t *__restric
     const long long t1 = t0 + tilesPerChunk < numTiles ? t0 + tilesPerChunk : numTiles;
     const bool aligned = (reinterpret_cast<uintptr_t>(in) & 15) == 0;
     uint32_t acc = 0;
+    // (the NEXT tile's loads are issued before this tile is summed: two tiles' worth of loads in flight per workgroup -- round 6)
+    int32_t v[kScanItems], nx[kScanItems];
+    if (PIPE && t0 < t1) load_items(in, t0 * kScanTile + (long long)threadIdx.x * kScanItems, n, aligned && (t0 + 1) * kScanTile <= n, v);
     for (long long tile = t0; tile < t1; ++tile) {
-        const long long base = tile * kScanTile + (long long)threadIdx.x * kScanItems;
-        int32_t v[kScanItems];
-        load_items(in, base, n, aligned && (tile + 1) * kScanTile <= n, v);
+        if (!PIPE) load_items(in, tile * kScanTile + (long long)threadIdx.x * kScanItems, n, aligned && (tile + 1) * kScanTile <= n, v);
+        if (PIPE && tile + 1 < t1) load_items(in, (tile + 1) * kScanTile + (long long)threadIdx.x * kScanItems, n, aligned && (tile + 2) * kScanTile <= n, nx);
 #pragma unroll
         for (int k = 0; k < kScanItems; ++k) acc += COUNT ? (v[k] != 0 ? 1u : 0u) : (uint32_t)v[k];
+        if (PIPE) {
+#pragma unroll
+            for (int k = 0; k < kScanItems; ++k) v[k] = nx[k];
+        }
     }
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = acc;
@@ -121,9 +129,10 @@ __global__ __launch_bounds__(kBlock) void k_scan_partials(uint32_t *partial, int
 }
 
 // 3a. the scan of a chunk, starting from its prefix
+template <bool PIPE>
 __global__ __launch_bounds__(kBlock) void k_scan_apply(const int32_t *__restrict__ in, int32_t *__restrict__ out, long long n,
                                                        long long tilesPerChunk, const uint32_t *__restrict__ partial) {
-    __shared__ uint32_t s_wave[kWaves];
+    __shared__ uint32_t s_wave[2 * kWaves];      // (the waves' totals of two consecutive tiles: ONE barrier per tile instead of two -- round 6)
     const long long numTiles = (n + kScanTile - 1) / kScanTile;
     // The chunks are taken NEWEST FIRST (workgroup 0 = the last chunk): k_scan_reduce has just streamed the whole array through the
     // 256 MB memory-side cache front to back, so its END is what the cache still holds -- a second front-to-back pass would evict
@@ -133,16 +142,21 @@ __global__ __launch_bounds__(kBlock) void k_scan_apply(const int32_t *__restrict
     const long long t1 = t0 + tilesPerChunk < numTiles ? t0 + tilesPerChunk : numTiles;
     const bool aligned = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
     uint32_t carry = partial[chunk];
+    // (the NEXT tile's loads are issued before this tile's scan -- its barriers and its stores -- so that a workgroup's memory round trips
+    // overlap its own work, not only its neighbours': round 6)
+    int32_t v[kScanItems], nx[kScanItems];
+    if (PIPE && t0 < t1) load_items(in, t0 * kScanTile + (long long)threadIdx.x * kScanItems, n, aligned && (t0 + 1) * kScanTile <= n, v);
     for (long long tile = t0; tile < t1; ++tile) {
         const long long base = tile * kScanTile + (long long)threadIdx.x * kScanItems;
         const bool fast = aligned && (tile + 1) * kScanTile <= n;
-        int32_t v[kScanItems];
-        load_items(in, base, n, fast, v);
+        if (!PIPE) load_items(in, base, n, fast, v);
+        if (PIPE && tile + 1 < t1) load_items(in, (tile + 1) * kScanTile + (long long)threadIdx.x * kScanItems, n, aligned && (tile + 2) * kScanTile <= n, nx);
         uint32_t tsum = 0;
 #pragma unroll
         for (int k = 0; k < kScanItems; ++k) tsum += (uint32_t)v[k];
         uint32_t total;
-        uint32_t run = carry + tile_offsets(tsum, s_wave, &total);
+        // (this tile's half of s_wave was last read before the previous tile's barrier: nobody is still in it)
+        uint32_t run = carry + tile_offsets(tsum, s_wave + ((tile - t0) & 1) * kWaves, &total);
         int32_t o[kScanItems];
 #pragma unroll
         for (int k = 0; k < kScanItems; ++k) {
@@ -159,7 +173,10 @@ __global__ __launch_bounds__(kBlock) void k_scan_apply(const int32_t *__restrict
                 if (base + k < n) out[base + k] = o[k];
         }
         carry += total;
-        __syncthreads();                       // s_wave is free again
+        if (PIPE) {
+#pragma unroll
+            for (int k = 0; k < kScanItems; ++k) v[k] = nx[k];
+        }
     }
 }
 
