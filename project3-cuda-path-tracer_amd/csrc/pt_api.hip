@@ -1532,16 +1532,15 @@ int pt_scan_exclusive_i32(const int32_t *in_dev, int32_t *out_dev, int64_t n, vo
     long long per;
     int chunks;
     scan_chunks(n, &per, &chunks);
-    // Three launches (12 bytes of HBM traffic per element).  PT_AMD_SCAN=1: the ONE-launch form (k_scan_chained: ticketed chunks, chained
+    // Two launches (12 bytes of HBM traffic per element).  PT_AMD_SCAN=1: the ONE-launch form (k_scan_chained: ticketed chunks, chained
     // prefix; 8 bytes per element when a chunk's second read comes out of the caches) -- measured SLOWER on MI355X, 0.214 against 0.172 ms at
     // 2^26 (0.81 against 0.66 at 2^28): the 2048 resident workgroups' chunks (128 KB each) do not survive in the 4 MB L2 of an XCD between
     // their two reads, so it moves the same 12 bytes and adds the ticket and the wait; kept selectable, not the default.
     const char *mode = getenv("PT_AMD_SCAN");
     if (!(mode && atoi(mode) == 1)) {
-        // (chunks of four tiles or more take the kernels that load a tile ahead)
+        // (chunks of four tiles or more take the kernels that load a tile ahead; the apply adds up the totals before its chunk itself)
         if (per >= 4) hipLaunchKernelGGL((k_scan_reduce<false, true>), dim3(chunks), dim3(kBlock), 0, st, in_dev, (long long)n, per, wp->partial);
         else hipLaunchKernelGGL((k_scan_reduce<false, false>), dim3(chunks), dim3(kBlock), 0, st, in_dev, (long long)n, per, wp->partial);
-        hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(kBlock), 0, st, wp->partial, chunks, (long long *)nullptr);
         if (per >= 4) hipLaunchKernelGGL((k_scan_apply<true>), dim3(chunks), dim3(kBlock), 0, st, in_dev, out_dev, (long long)n, per, wp->partial);
         else hipLaunchKernelGGL((k_scan_apply<false>), dim3(chunks), dim3(kBlock), 0, st, in_dev, out_dev, (long long)n, per, wp->partial);
     } else {

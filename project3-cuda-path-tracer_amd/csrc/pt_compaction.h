@@ -4,11 +4,12 @@
 //
 // Reduce-then-scan over CHUNKS: the array is cut into at most 2048 chunks of whole 4096-element tiles;
 //   1. k_scan_reduce    one workgroup per chunk: its sum (scan) or its count of non-zero elements (compaction)
-//   2. k_scan_partials  one workgroup: exclusive scan of the chunk totals (they fit one tile)
+//   2. k_scan_partials  one workgroup: exclusive scan of the chunk totals (they fit one tile) -- the compaction only (it also delivers the count);
+//      the scan's step 3 adds up the totals before its chunk itself (round 6)
 //   3. k_scan_apply / k_compact_apply   one workgroup per chunk: re-reads the chunk and writes its part of the result,
 //      starting from the chunk's prefix (chunks newest first: the re-read comes out of the memory-side cache where it still holds them)
 // i.e. 12 bytes of traffic per element for the scan (8 is the minimum) and 8 + 4 per kept element for the compaction,
-// three launches on the caller's stream, and NO workgroup ever waits for another one: no tickets, no look-back, no spinning.
+// two / three launches on the caller's stream, and NO workgroup ever waits for another one: no tickets, no look-back, no spinning.
 // (Rounds 1-2 shipped a single-pass scan with decoupled look-back: one atomic ticket per tile on ONE address bounded it at
 // 25 / 180 GB/s with 256- / 1024-element tiles and at 500 GB/s with 4096-element ones.)
 #pragma once
@@ -31,6 +32,19 @@ __device__ __forceinline__ void load_items(const int32_t *__restrict__ in, long 
     } else {
 #pragma unroll
         for (int k = 0; k < kScanItems; ++k) v[k] = base + k < n ? in[base + k] : 0;
+    }
+}
+// the same tile for a SUM (any order will do): thread t takes the 16-byte words t, t + 256, t + 512, t + 768 of the tile -- a wave's load is one
+// run of 1 KB instead of 64 pieces of 16 bytes 64 bytes apart (round 6)
+__device__ __forceinline__ void load_items_striped(const int32_t *__restrict__ in, long long tileBase, long long n, bool fast, int32_t (&v)[kScanItems]) {
+    if (fast) {
+#pragma unroll
+        for (int q = 0; q < kScanItems / 4; ++q) {
+            const int4 x = *reinterpret_cast<const int4 *>(in + tileBase + 4 * (q * kBlock + (long long)threadIdx.x));
+            v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
+        }
+    } else {
+        load_items(in, tileBase + (long long)threadIdx.x * kScanItems, n, false, v);
     }
 }
 // Inclusive scan of one value per lane inside the wave: six DPP steps, no LDS crossbar -- row_shr:1 / 2 / 4 / 8 inside each row of 16 lanes
@@ -81,10 +95,11 @@ __global__ __launch_bounds__(kBlock) void k_scan_reduce(const int32_t *__restric
     uint32_t acc = 0;
     // (the NEXT tile's loads are issued before this tile is summed: two tiles' worth of loads in flight per workgroup -- round 6)
     int32_t v[kScanItems], nx[kScanItems];
-    if (PIPE && t0 < t1) load_items(in, t0 * kScanTile + (long long)threadIdx.x * kScanItems, n, aligned && (t0 + 1) * kScanTile <= n, v);
+    auto load = [&](long long tile, int32_t (&w)[kScanItems]) { load_items_striped(in, tile * kScanTile, n, aligned && (tile + 1) * kScanTile <= n, w); };
+    if (PIPE && t0 < t1) load(t0, v);
     for (long long tile = t0; tile < t1; ++tile) {
-        if (!PIPE) load_items(in, tile * kScanTile + (long long)threadIdx.x * kScanItems, n, aligned && (tile + 1) * kScanTile <= n, v);
-        if (PIPE && tile + 1 < t1) load_items(in, (tile + 1) * kScanTile + (long long)threadIdx.x * kScanItems, n, aligned && (tile + 2) * kScanTile <= n, nx);
+        if (!PIPE) load(tile, v);
+        if (PIPE && tile + 1 < t1) load(tile + 1, nx);
 #pragma unroll
         for (int k = 0; k < kScanItems; ++k) acc += COUNT ? (v[k] != 0 ? 1u : 0u) : (uint32_t)v[k];
         if (PIPE) {
@@ -129,6 +144,8 @@ __global__ __launch_bounds__(kBlock) void k_scan_partials(uint32_t *partial, int
 }
 
 // 3a. the scan of a chunk, starting from its prefix
+// `partial` holds the chunks' TOTALS as k_scan_reduce left them: the workgroup adds up the ones before its chunk itself (at most 2047 words, eight
+// per thread) -- the scan is TWO launches, k_scan_partials (one workgroup, ~5 us of launch and round trips) serves the compaction only (round 6)
 template <bool PIPE>
 __global__ __launch_bounds__(kBlock) void k_scan_apply(const int32_t *__restrict__ in, int32_t *__restrict__ out, long long n,
                                                        long long tilesPerChunk, const uint32_t *__restrict__ partial) {
@@ -141,11 +158,25 @@ __global__ __launch_bounds__(kBlock) void k_scan_apply(const int32_t *__restrict
     const long long t0 = chunk * tilesPerChunk;
     const long long t1 = t0 + tilesPerChunk < numTiles ? t0 + tilesPerChunk : numTiles;
     const bool aligned = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
-    uint32_t carry = partial[chunk];
-    // (the NEXT tile's loads are issued before this tile's scan -- its barriers and its stores -- so that a workgroup's memory round trips
-    // overlap its own work, not only its neighbours': round 6)
     int32_t v[kScanItems], nx[kScanItems];
     if (PIPE && t0 < t1) load_items(in, t0 * kScanTile + (long long)threadIdx.x * kScanItems, n, aligned && (t0 + 1) * kScanTile <= n, v);
+    // (the totals before the chunk are loaded behind the first tile's elements and added up inside the first tile's own barrier: every
+    // workgroup of the launch is resident at once, so a prologue of its own is paid in full -- measured: +4 us at 2^26 elements.  Eight
+    // INDEPENDENT loads: a loop of `chunk / 256` trips waits for each load before it issues the next one, +7 us)
+    __shared__ uint32_t s_pre[kWaves];
+    uint32_t carry = 0, pacc = 0;
+    {
+        uint32_t pv[kScanChunksMax / kBlock];
+#pragma unroll
+        for (int k = 0; k < kScanChunksMax / kBlock; ++k) {
+            const long long i = (long long)k * kBlock + threadIdx.x;
+            pv[k] = i < chunk ? partial[i] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < kScanChunksMax / kBlock; ++k) pacc += pv[k];
+    }
+    // (the NEXT tile's loads are issued before this tile's scan -- its barriers and its stores -- so that a workgroup's memory round trips
+    // overlap its own work, not only its neighbours': round 6)
     for (long long tile = t0; tile < t1; ++tile) {
         const long long base = tile * kScanTile + (long long)threadIdx.x * kScanItems;
         const bool fast = aligned && (tile + 1) * kScanTile <= n;
@@ -155,8 +186,17 @@ __global__ __launch_bounds__(kBlock) void k_scan_apply(const int32_t *__restrict
 #pragma unroll
         for (int k = 0; k < kScanItems; ++k) tsum += (uint32_t)v[k];
         uint32_t total;
+        if (tile == t0) {
+            pacc = wave_sum(pacc);
+            if ((threadIdx.x & 63) == 0) s_pre[threadIdx.x >> 6] = pacc;
+        }
         // (this tile's half of s_wave was last read before the previous tile's barrier: nobody is still in it)
-        uint32_t run = carry + tile_offsets(tsum, s_wave + ((tile - t0) & 1) * kWaves, &total);
+        const uint32_t offs = tile_offsets(tsum, s_wave + ((tile - t0) & 1) * kWaves, &total);
+        if (tile == t0) {
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) carry += s_pre[w];
+        }
+        uint32_t run = carry + offs;
         int32_t o[kScanItems];
 #pragma unroll
         for (int k = 0; k < kScanItems; ++k) {
