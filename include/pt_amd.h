@@ -227,7 +227,7 @@ int pt_device_count(void);
 
 /* ---- stream compaction library (the reference's empty stream_compaction/ stub, README.md:83-86):
  * work-efficient exclusive scan / compaction over DEVICE buffers, multi-block, any n >= 0 (compaction: n < 2^32).
- * Reduce-then-scan over at most 2048 chunks: two (scan) / three (compaction) launches on `stream`, asynchronous, no workgroup waits for another;
+ * Reduce-then-scan over at most 2048 chunks: two launches on `stream`, asynchronous, no workgroup waits for another;
  * calls on different streams use separate workspaces and may overlap.  Sums wrap modulo 2^32 like int32 arithmetic. ---------- */
 int pt_scan_exclusive_i32(const int32_t *in_dev, int32_t *out_dev, int64_t n, void *stream);
 /* keeps the non-zero elements in order; *count_dev (device) receives how many were kept */

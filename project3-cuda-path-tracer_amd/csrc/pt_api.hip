@@ -1571,8 +1571,10 @@ int pt_compact_nonzero_i32(const int32_t *in_dev, int32_t *out_dev, int64_t n, i
     scan_chunks(n, &per, &chunks);
     if (per >= 4) hipLaunchKernelGGL((k_scan_reduce<true, true>), dim3(chunks), dim3(kBlock), 0, st, in_dev, (long long)n, per, wp->partial);
     else hipLaunchKernelGGL((k_scan_reduce<true, false>), dim3(chunks), dim3(kBlock), 0, st, in_dev, (long long)n, per, wp->partial);
-    hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(kBlock), 0, st, wp->partial, chunks, reinterpret_cast<long long *>(count_dev));
-    hipLaunchKernelGGL(k_compact_apply, dim3(chunks), dim3(kBlock), 0, st, in_dev, out_dev, (long long)n, per, wp->partial);
+    if (per >= 4)
+        hipLaunchKernelGGL((k_compact_apply<true>), dim3(chunks), dim3(kBlock), 0, st, in_dev, out_dev, (long long)n, per, wp->partial, reinterpret_cast<long long *>(count_dev));
+    else
+        hipLaunchKernelGGL((k_compact_apply<false>), dim3(chunks), dim3(kBlock), 0, st, in_dev, out_dev, (long long)n, per, wp->partial, reinterpret_cast<long long *>(count_dev));
     HIPCHECK(hipGetLastError());
     return PT_OK;
 }

@@ -4,12 +4,12 @@
 //
 // Reduce-then-scan over CHUNKS: the array is cut into at most 2048 chunks of whole 4096-element tiles;
 //   1. k_scan_reduce    one workgroup per chunk: its sum (scan) or its count of non-zero elements (compaction)
-//   2. k_scan_partials  one workgroup: exclusive scan of the chunk totals (they fit one tile) -- the compaction only (it also delivers the count);
-//      the scan's step 3 adds up the totals before its chunk itself (round 6)
-//   3. k_scan_apply / k_compact_apply   one workgroup per chunk: re-reads the chunk and writes its part of the result,
-//      starting from the chunk's prefix (chunks newest first: the re-read comes out of the memory-side cache where it still holds them)
+//   2. k_scan_apply / k_compact_apply   one workgroup per chunk: adds up the totals of the chunks before its own (at most 2047 words), re-reads
+//      the chunk and writes its part of the result from that prefix (chunks newest first: the re-read comes out of the memory-side cache where
+//      it still holds them); the workgroup of the last chunk delivers the compaction's count
 // i.e. 12 bytes of traffic per element for the scan (8 is the minimum) and 8 + 4 per kept element for the compaction,
-// two / three launches on the caller's stream, and NO workgroup ever waits for another one: no tickets, no look-back, no spinning.
+// TWO launches on the caller's stream, and NO workgroup ever waits for another one: no tickets, no look-back, no spinning.
+// (Rounds 3-5 ran a third launch between the two -- one workgroup scanning the chunk totals: ~5 us, a quarter of a call at 2^22 elements.)
 // (Rounds 1-2 shipped a single-pass scan with decoupled look-back: one atomic ticket per tile on ONE address bounded it at
 // 25 / 180 GB/s with 256- / 1024-element tiles and at 500 GB/s with 4096-element ones.)
 #pragma once
@@ -118,34 +118,9 @@ __global__ __launch_bounds__(kBlock) void k_scan_reduce(const int32_t *__restric
     }
 }
 
-// 2. exclusive scan of the chunk totals in place (chunks <= kScanTile); the grand total goes to partial[chunks] and, for the
-// compaction, to *count_out
-__global__ __launch_bounds__(kBlock) void k_scan_partials(uint32_t *partial, int chunks, long long *count_out) {
-    __shared__ uint32_t s_wave[kWaves];
-    uint32_t v[kScanItems], mine = 0;
-#pragma unroll
-    for (int k = 0; k < kScanItems; ++k) {
-        const int i = threadIdx.x * kScanItems + k;
-        v[k] = i < chunks ? partial[i] : 0u;
-        mine += v[k];
-    }
-    uint32_t total;
-    uint32_t run = tile_offsets(mine, s_wave, &total);
-#pragma unroll
-    for (int k = 0; k < kScanItems; ++k) {
-        const int i = threadIdx.x * kScanItems + k;
-        if (i < chunks) partial[i] = run;
-        run += v[k];
-    }
-    if (threadIdx.x == 0) {
-        partial[chunks] = total;
-        if (count_out) *count_out = (long long)total;
-    }
-}
-
-// 3a. the scan of a chunk, starting from its prefix
+// 2a. the scan of a chunk, starting from its prefix
 // `partial` holds the chunks' TOTALS as k_scan_reduce left them: the workgroup adds up the ones before its chunk itself (at most 2047 words, eight
-// per thread) -- the scan is TWO launches, k_scan_partials (one workgroup, ~5 us of launch and round trips) serves the compaction only (round 6)
+// per thread) -- no launch in between that scans the totals (one workgroup, ~5 us of launch and round trips: round 6)
 template <bool PIPE>
 __global__ __launch_bounds__(kBlock) void k_scan_apply(const int32_t *__restrict__ in, int32_t *__restrict__ out, long long n,
                                                        long long tilesPerChunk, const uint32_t *__restrict__ partial) {
@@ -308,35 +283,67 @@ __global__ __launch_bounds__(kBlock) void k_scan_chained(const int32_t *__restri
     }
 }
 
-// 3b. stable compaction of a chunk's non-zero elements by wave-level ballot / mbcnt (the north star's primitives; round 5).  A tile is read
+// 2b. stable compaction of a chunk's non-zero elements by wave-level ballot / mbcnt (the north star's primitives; round 5).  A tile is read
 // STRIPED -- step k of a wave holds 64 CONSECUTIVE elements, k * 256 + its lanes -- so that a step's survivors are ranked by one ballot and
 // one mbcnt and leave for LDS as one run of consecutive words: no bank conflict by construction.  (Rounds 2-4: every thread scattered the
 // survivors of its own 16 consecutive elements to s_stage[off++] -- lanes of a wave wrote to unrelated banks: 31 % of the LDS-active cycles
 // were conflicts, profiles/r02_scan_summary.txt.)  The 64 (step, wave) counts of a tile are scanned by wave 0 (DPP) through LDS; the
 // staged run leaves with coalesced stores at the chunk's running position.
+// `partial` holds the chunks' COUNTS as k_scan_reduce<true> left them; the workgroup adds up the ones before its chunk itself, inside its first
+// tile's barrier (see k_scan_apply), and the one that takes the last chunk delivers the grand total: two launches (round 6)
+template <bool PIPE>
 __global__ __launch_bounds__(kBlock) void k_compact_apply(const int32_t *__restrict__ in, int32_t *__restrict__ out, long long n,
-                                                          long long tilesPerChunk, const uint32_t *__restrict__ partial) {
+                                                          long long tilesPerChunk, const uint32_t *__restrict__ partial, long long *count_out) {
     __shared__ uint32_t s_cnt[kScanItems * kWaves + 1];      // [step][wave] survivors, then their exclusive prefix; [64] = the tile's total
     __shared__ int32_t s_stage[kScanTile];
+    __shared__ uint32_t s_pre[kWaves];
     static_assert(kScanItems * kWaves == 64, "wave 0 scans the (step, wave) counts with one value per lane");
     const long long numTiles = (n + kScanTile - 1) / kScanTile;
     const long long chunk = (long long)gridDim.x - 1 - blockIdx.x;           // (newest first: see k_scan_apply)
     const long long t0 = chunk * tilesPerChunk;
     const long long t1 = t0 + tilesPerChunk < numTiles ? t0 + tilesPerChunk : numTiles;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    long long dst = (long long)partial[chunk];
-    for (long long tile = t0; tile < t1; ++tile) {
+    auto load = [&](long long tile, int32_t (&w)[kScanItems]) {
         const long long tb = tile * kScanTile + threadIdx.x;
         const bool whole = (tile + 1) * kScanTile <= n;
-        int32_t v[kScanItems];
 #pragma unroll
-        for (int k = 0; k < kScanItems; ++k) v[k] = (whole || tb + (long long)k * kBlock < n) ? in[tb + (long long)k * kBlock] : 0;
+        for (int k = 0; k < kScanItems; ++k) w[k] = (whole || tb + (long long)k * kBlock < n) ? in[tb + (long long)k * kBlock] : 0;
+    };
+    int32_t v[kScanItems], nx[kScanItems];
+    if (PIPE && t0 < t1) load(t0, v);
+    uint32_t pacc = 0;
+    {
+        uint32_t pv[kScanChunksMax / kBlock];
+#pragma unroll
+        for (int k = 0; k < kScanChunksMax / kBlock; ++k) {
+            const long long i = (long long)k * kBlock + threadIdx.x;
+            pv[k] = i < chunk ? partial[i] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < kScanChunksMax / kBlock; ++k) pacc += pv[k];
+    }
+    const uint32_t own = partial[chunk];
+    long long dst = 0;
+    for (long long tile = t0; tile < t1; ++tile) {
+        if (!PIPE) load(tile, v);
+        if (PIPE && tile + 1 < t1) load(tile + 1, nx);
 #pragma unroll
         for (int k = 0; k < kScanItems; ++k) {
             const unsigned long long b = __ballot(v[k] != 0);
             if (lane == 0) s_cnt[k * kWaves + wave] = (uint32_t)__popcll(b);
         }
+        if (tile == t0) {
+            pacc = wave_sum(pacc);
+            if (lane == 0) s_pre[wave] = pacc;
+        }
         __syncthreads();
+        if (tile == t0) {
+            uint32_t pre = 0;
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) pre += s_pre[w];
+            dst = (long long)pre;
+            if (blockIdx.x == 0 && threadIdx.x == 0) *count_out = (long long)pre + (long long)own;      // (workgroup 0 takes the LAST chunk)
+        }
         if (wave == 0) {
             const uint32_t c = s_cnt[lane], inc = wave_inclusive(c);
             s_cnt[lane] = inc - c;
@@ -354,6 +361,10 @@ __global__ __launch_bounds__(kBlock) void k_compact_apply(const int32_t *__restr
         for (uint32_t i = threadIdx.x; i < total; i += kBlock) out[dst + i] = s_stage[i];
         dst += (long long)total;
         __syncthreads();                       // s_stage and s_cnt are free again
+        if (PIPE) {
+#pragma unroll
+            for (int k = 0; k < kScanItems; ++k) v[k] = nx[k];
+        }
     }
 }
 
