@@ -77,3 +77,30 @@ def test_one_launch_chained_scan_equals_the_three_launch_form(pt, dev, oracle, n
     a = rng.integers(-1000, 1000, n).astype(np.int32)
     for _ in range(3):
         assert np.array_equal(_scan(pt, dev, a), oracle.scan_exclusive(a))
+
+
+@pytest.mark.parametrize("n", [(1 << 25) + 3, 5 * 2048 * 4096 - 1, (1 << 26)])
+def test_long_chunks_take_the_tile_ahead_kernels(pt, dev, n):
+    # round 6: chunks of four tiles or more (n > 3 * 2048 * 4096 = 25.2 M elements) run k_scan_reduce / k_scan_apply / k_compact_apply with the
+    # next tile's loads in flight; every size above is smaller.  Checked on the device against torch (the CPU oracle takes seconds per case here):
+    # values wrap modulo 2^32 like int32 arithmetic; 16-byte-aligned and not; ragged last tile and an exact multiple of the tile.
+    torch = dev
+    g = torch.Generator(device="cuda").manual_seed(n & 0xffff)
+    keep = (torch.rand(n + 3, device="cuda", generator=g) < 0.3)
+    vals = torch.randint(-(1 << 30), 1 << 30, (n + 3,), device="cuda", dtype=torch.int32, generator=g) * keep.to(torch.int32)
+    out = torch.empty_like(vals)
+    cnt = torch.full((1,), -1, dtype=torch.int64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    for off in (0, 3):
+        x, o = vals[off:off + n], out[off:off + n]
+        pt.scan_exclusive_dev(x.data_ptr(), o.data_ptr(), n, st)
+        want = torch.cumsum(x.to(torch.int64), 0) - x.to(torch.int64)
+        assert torch.equal(o.to(torch.int64) & 0xffffffff, want & 0xffffffff)
+        del want
+        o.fill_(-1)
+        pt.compact_nonzero_dev(x.data_ptr(), o.data_ptr(), n, cnt.data_ptr(), st)
+        torch.cuda.synchronize()
+        k = int(cnt.item())
+        nz = x[x != 0]
+        assert k == nz.numel() and torch.equal(o[:k], nz)
+        del nz
