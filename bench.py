@@ -84,7 +84,7 @@ def parse(argv=None):
     ap.add_argument("--cpu-spp", type=int, default=40, help="spp of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--pipeline", type=int, default=3,
                     help="batches in flight (PtOptions.pipeline_depth; 0 = library default 3).  Round 4: 3 -- with steps of 64 iterations a third "
-                         "batch in flight is worth +1.5 .. 4 % (profiles/exp_r4i.sh, exp_r4k.sh); the per-iteration reading of config C3 keeps 2")
+                         "batch in flight is worth +1.5 .. 4 %% (profiles/exp_r4i.sh, exp_r4k.sh); the per-iteration reading of config C3 keeps 2")
     ap.add_argument("--batch", type=int, default=64,
                     help="iterations per step = iterations traced as one wavefront batch (64 = the spp of BASELINE config C2)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],

@@ -723,8 +723,8 @@ __device__ __forceinline__ uint32_t wallPlanesOriented(const KP &prm, F3 o, F3 d
 // wave-uniform (GeomDev through the scalar path), registers when every lane tests its own sphere (k_bounce<., MANY>).
 // `camObj`: the precomputed object-space origin of a camera ray, or nullptr.
 template <bool CAM_ORIGIN, typename P1, typename P2, typename P3, typename P4>
-__device__ __forceinline__ float sphereIntersectionTestM(P1 inv, P2 invZ, P3 xf, P4 camObj,
-                                                         F3 ro_w, F3 rd_w, F3 &P, F3 &nsrc, bool &outside) {
+__device__ __forceinline__ float sphereIntersectionTestLazy(P1 inv, P2 invZ, P3 loadXf, P4 camObj,
+                                                            F3 ro_w, F3 rd_w, F3 &P, F3 &nsrc, bool &outside) {
     F3 ro = CAM_ORIGIN ? f3(camObj[0], camObj[1], camObj[2]) : mulMV(inv, ro_w, 1.0f);
     F3 rd = normalize(mulMV0(inv, invZ, rd_w));
     float vDotDirection = dot(ro, rd);
@@ -747,9 +747,19 @@ __device__ __forceinline__ float sphereIntersectionTestM(P1 inv, P2 invZ, P3 xf,
     }
     probe(6);
     F3 obj = getPointOnRay(ro, rd, t);
+    float xf[12];
+    loadXf(xf);      // (the transform's rows are fetched HERE, by the lanes that hit: sphere-heavy scenes read them per lane from LDS / global memory)
     P = mulMV(xf, obj, 1.0f);
     nsrc = obj;      // normal = +-normalize(invTranspose * (obj, 0)): hitNormal(), evaluated for the nearest hit only
     return length(ro_w - P);
+}
+template <bool CAM_ORIGIN = false, typename P1, typename P2, typename P3, typename P4>
+__device__ __forceinline__ float sphereIntersectionTestM(P1 inv, P2 invZ, P3 xf, P4 camObj,
+                                                         F3 ro_w, F3 rd_w, F3 &P, F3 &nsrc, bool &outside) {
+    return sphereIntersectionTestLazy<CAM_ORIGIN>(inv, invZ, [&](float (&x)[12]) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) x[i] = xf[i];
+    }, camObj, ro_w, rd_w, P, nsrc, outside);
 }
 template <bool CAM_ORIGIN = false, typename GD>
 __device__ __forceinline__ float sphereIntersectionTest(const GD &g, F3 ro_w, F3 rd_w, F3 &P, F3 &nsrc,

@@ -487,7 +487,10 @@ template <bool FIRST, bool MANY, bool DOF = false, bool MESH = false, bool PLAIN
 #define PT_MESH_WG_FIRST 7
 #define PT_MESH_WG_NEXT 7
 #endif
-__global__ __launch_bounds__(kBlock, (MANY && CUBES) ? 4 : (MESH ? (MANY ? 4 : (FIRST ? PT_MESH_WG_FIRST : PT_MESH_WG_NEXT)) : (DOF ? 5 : (MANY ? (FIRST ? 7 : (GROUPS ? 5 : 6)) : 8)))) void k_bounce(BounceArgs argsByValue) {
+#ifndef PT_GROUPS_WG
+#define PT_GROUPS_WG 5
+#endif
+__global__ __launch_bounds__(kBlock, (MANY && CUBES) ? 4 : (MESH ? (MANY ? 4 : (FIRST ? PT_MESH_WG_FIRST : PT_MESH_WG_NEXT)) : (DOF ? 5 : (MANY ? (FIRST ? 7 : (GROUPS ? PT_GROUPS_WG : 6)) : 8)))) void k_bounce(BounceArgs argsByValue) {
     static_assert(MANY || !CUBES, "swept cubes only exist where primitives are swept");
     static_assert(!GROUPS || (MANY && !MESH && !DOF), "groups: sphere-heavy scenes without meshes (the camera-ray bounce: its pinhole form)");
     static_assert(FIRST || !DOF, "the lens only concerns the camera-ray bounce");
@@ -935,12 +938,15 @@ __global__ __launch_bounds__(kBlock, (MANY && CUBES) ? 4 : (MESH ? (MANY ? 4 : (
             }
             // the matrix row of primitive g for a per-lane test: from the LDS table -- or, in a scene of hundreds of primitives whose rows
             // would leave one workgroup per CU, from their copy in global memory (KParams::ldsRowFloats; wave-uniform)
+            // (spheres only -- !CUBES: the 16-byte words 0-2, inverseTransform, and 6, GeomDev::invZ, are what a test needs before it knows that it
+            // hits; words 3-5, the transform, are read by the lanes that do: loadRowXf.  Four per-lane 16-byte reads per candidate instead of seven)
             auto loadRow = [&](int g, float (&m)[28]) {
                 const ArgsPtr A = launder(kargs);
                 if (!GROUPS && A->prm.ldsRowFloats != 0) {
                     const float4 *row = reinterpret_cast<const float4 *>(s_sph + g * kSphRowFloats);
 #pragma unroll
                     for (int q = 0; q < 7; ++q) {
+                        if (!CUBES && q >= 3 && q < 6) continue;
                         const float4 v = row[q];
                         m[4 * q] = v.x; m[4 * q + 1] = v.y; m[4 * q + 2] = v.z; m[4 * q + 3] = v.w;
                     }
@@ -948,8 +954,27 @@ __global__ __launch_bounds__(kBlock, (MANY && CUBES) ? 4 : (MESH ? (MANY ? 4 : (
                     const float4 *row = A->rows + (size_t)g * 7;
 #pragma unroll
                     for (int q = 0; q < 7; ++q) {
+                        if (!CUBES && q >= 3 && q < 6) continue;
                         const float4 v = row[q];
                         m[4 * q] = v.x; m[4 * q + 1] = v.y; m[4 * q + 2] = v.z; m[4 * q + 3] = v.w;
+                    }
+                }
+            };
+            auto loadRowXf = [&](int g, float (&x)[12]) {
+                const ArgsPtr A = launder(kargs);
+                if (!GROUPS && A->prm.ldsRowFloats != 0) {
+                    const float4 *row = reinterpret_cast<const float4 *>(s_sph + g * kSphRowFloats) + 3;
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const float4 v = row[q];
+                        x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+                    }
+                } else {
+                    const float4 *row = A->rows + (size_t)g * 7 + 3;
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const float4 v = row[q];
+                        x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
                     }
                 }
             };
@@ -1062,7 +1087,8 @@ __global__ __launch_bounds__(kBlock, (MANY && CUBES) ? 4 : (MESH ? (MANY ? 4 : (
                         return boxIntersectionTest<false, false>(rows, ro, rdir, p, n, o);
                     }
                 }
-                return sphereIntersectionTestM<false>(m, m + 24, m + 12, m, ro, rdir, p, n, o);
+                if (CUBES) return sphereIntersectionTestM<false>(m, m + 24, m + 12, m, ro, rdir, p, n, o);
+                return sphereIntersectionTestLazy<false>(m, m + 24, [&](float (&x)[12]) { loadRowXf(g, x); }, m, ro, rdir, p, n, o);
             };
             // the primitives a lane recorded: pass k tests every lane's k-th one with that lane's own matrices from LDS
             auto candidatePass = [&]() {
