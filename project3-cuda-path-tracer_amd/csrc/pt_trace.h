@@ -490,7 +490,10 @@ template <bool FIRST, bool MANY, bool DOF = false, bool MESH = false, bool PLAIN
 #ifndef PT_GROUPS_WG
 #define PT_GROUPS_WG 5
 #endif
-__global__ __launch_bounds__(kBlock, (MANY && CUBES) ? 4 : (MESH ? (MANY ? 4 : (FIRST ? PT_MESH_WG_FIRST : PT_MESH_WG_NEXT)) : (DOF ? 5 : (MANY ? (FIRST ? 7 : (GROUPS ? PT_GROUPS_WG : 6)) : 8)))) void k_bounce(BounceArgs argsByValue) {
+#ifndef PT_CUBES_WG
+#define PT_CUBES_WG 4
+#endif
+__global__ __launch_bounds__(kBlock, (MANY && CUBES) ? (GROUPS ? 4 : PT_CUBES_WG) : (MESH ? (MANY ? 4 : (FIRST ? PT_MESH_WG_FIRST : PT_MESH_WG_NEXT)) : (DOF ? 5 : (MANY ? (FIRST ? 7 : (GROUPS ? PT_GROUPS_WG : 6)) : 8)))) void k_bounce(BounceArgs argsByValue) {
     static_assert(MANY || !CUBES, "swept cubes only exist where primitives are swept");
     static_assert(!GROUPS || (MANY && !MESH && !DOF), "groups: sphere-heavy scenes without meshes (the camera-ray bounce: its pinhole form)");
     static_assert(FIRST || !DOF, "the lens only concerns the camera-ray bounce");
